@@ -1,0 +1,155 @@
+"""Generate / verify the golden fixtures under tests/golden/.  TEST INFRASTRUCTURE ONLY.
+
+Runs ONLY where /root/reference exists (the build container).  It executes the reference's own
+model source files (ppvector/models/{ecapa_tdnn,tdnn,pooling,utils,fc}.py, ppvector/loss/aamloss.py)
+unmodified through ``oracle/paddle_shim`` with weights from ``oracle.models.*_params(seed)`` and
+
+  1. asserts that the oracle restatement (oracle/models.py) reproduces the reference graph's
+     outputs (eval AND train-mode BN) to float32 round-off, and
+  2. freezes inputs + reference outputs as small .npz fixtures that travel to the GPU box.
+
+Usage:  python oracle/gen_golden.py            # check + (re)write fixtures
+        python oracle/gen_golden.py --check    # check only (used by tests/test_oracle_pin.py)
+"""
+import argparse
+import importlib
+import os
+import sys
+import wave
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+REF = '/root/reference'
+
+
+def read_wav_16k_mono(path, n=48000):
+    w = wave.open(path)
+    assert w.getframerate() == 16000 and w.getnchannels() == 1 and w.getsampwidth() == 2
+    x = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
+    out = np.zeros(n, dtype=np.int16)
+    m = min(n, x.shape[0])
+    out[:m] = x[:m]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--check', action='store_true')
+    args = ap.parse_args()
+    if not os.path.isdir(REF):
+        print('reference not present; nothing to do')
+        return 0
+
+    from oracle import paddle_shim
+    from oracle import models as om
+    from oracle import fbank as ofb
+    paddle_shim.install()
+    ref_ecapa = importlib.import_module('ppvector.models.ecapa_tdnn')
+    ref_tdnn = importlib.import_module('ppvector.models.tdnn')
+    ref_fc = importlib.import_module('ppvector.models.fc')
+    ref_aam = importlib.import_module('ppvector.loss.aamloss')
+    torch.manual_seed(0)
+    out = {}
+    worst = 0.0
+
+    def cmp(name, a, b, tol):
+        nonlocal worst
+        a = a.detach().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)
+        b = b.detach().double().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, np.float64)
+        err = float(np.max(np.abs(a - b)) / max(1.0, float(np.max(np.abs(b)))))
+        worst = max(worst, err)
+        print(f'  {name:34s} rel-max-err {err:.3e}  (tol {tol:.0e})')
+        assert err <= tol, f'{name}: oracle deviates from the reference graph ({err})'
+
+    rng = np.random.RandomState(7)
+    # ---------------- ECAPA-TDNN (configs/ecapa_tdnn.yml model_args), F=80
+    F_, C_ = 80, 2796
+    p = om.ecapa_params(input_size=F_, seed=1000)
+    model = ref_ecapa.EcapaTdnn(input_size=F_, embd_dim=192, pooling_type='ASP',
+                                channels=[512, 512, 512, 512, 1536])
+    sd = model.state_dict()
+    assert set(sd.keys()) == set(p.keys()), (set(sd.keys()) ^ set(p.keys()))
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(p[k].shape), k
+    model.load_state_dict(p)
+    n_train, n_buf = om.count_params(p)
+    print(f'ECAPA F=80 params: trainable {n_train}, buffers {n_buf}')
+    p64 = om.ecapa_params(input_size=64, seed=1)
+    t64, b64 = om.count_params(p64)
+    # README.md:341-345: total 8,039,808 incl. classifier 192*9726; non-trainable 19,328
+    assert t64 + b64 + 192 * 9726 == 8039808 and b64 == 19328, (t64, b64)
+    x = rng.standard_normal((2, 64, F_)).astype(np.float32) * 3.0
+    xt = paddle_shim.to_tensor(x)
+    model.eval()
+    with torch.no_grad():
+        emb_ref = model(xt)
+        emb_or = om.ecapa_forward(p, torch.from_numpy(x))
+    cmp('ecapa eval emb', emb_or, emb_ref, 2e-5)
+    model.train()
+    with torch.no_grad():
+        emb_ref_tr = model(xt)
+        emb_or_tr = om.ecapa_forward(p, torch.from_numpy(x), training=True)
+    cmp('ecapa train-BN emb', emb_or_tr, emb_ref_tr, 2e-4)
+    # head + AAM loss
+    W = om.head_params(192, C_, seed=1001)
+    head = ref_fc.SpeakerIdentification(input_dim=192, num_speakers=C_, classifier_type='Cosine')
+    head.load_state_dict({'weight': W})
+    labels = rng.randint(0, C_, size=(2,)).astype(np.int64)
+    with torch.no_grad():
+        o = head(emb_ref)
+        logits_or = om.cosine_head(emb_ref.as_subclass(torch.Tensor), W)
+    cmp('cosine head logits', logits_or, o['logits'], 1e-6)
+    losses_ref = []
+    for margin, ls, easy in ((0.2, 0.0, False), (0.0, 0.0, False), (0.3, 0.1, False), (0.2, 0.0, True)):
+        crit = ref_aam.AAMLoss(margin=0.2, scale=32, easy_margin=easy, label_smoothing=ls)
+        crit.update(margin=margin)
+        with torch.no_grad():
+            l_ref = crit(o, paddle_shim.to_tensor(labels))
+            l_or = om.aam_loss(logits_or, torch.from_numpy(labels), margin, 32.0, easy, ls)
+        cmp(f'aam loss m={margin} ls={ls} easy={easy}', l_or, l_ref, 1e-5)
+        losses_ref.append(float(l_ref))
+    out['ecapa_ref_small.npz'] = dict(
+        x=x, labels=labels, emb_eval=emb_ref.numpy(), emb_train=emb_ref_tr.numpy(),
+        logits=o['logits'].numpy(), losses=np.asarray(losses_ref, np.float64),
+        loss_cfg=np.asarray([[0.2, 0.0, 0], [0.0, 0.0, 0], [0.3, 0.1, 0], [0.2, 0.0, 1]], np.float64),
+        param_seed=np.int64(1000), head_seed=np.int64(1001), n_train=np.int64(n_train), n_buf=np.int64(n_buf))
+
+    # ---------------- TDNN (configs/tdnn.yml), F=80
+    pt = om.tdnn_params(input_size=F_, seed=1000)
+    tm = ref_tdnn.TDNN(input_size=F_, channels=512, embd_dim=192, pooling_type='ASP')
+    sdt = tm.state_dict()
+    assert set(sdt.keys()) == set(pt.keys()), (set(sdt.keys()) ^ set(pt.keys()))
+    tm.load_state_dict(pt)
+    tm.eval()
+    with torch.no_grad():
+        e_ref = tm(xt)
+        e_or = om.tdnn_forward(pt, torch.from_numpy(x))
+    cmp('tdnn eval emb', e_or, e_ref, 2e-5)
+    out['tdnn_ref_small.npz'] = dict(x=x, emb_eval=e_ref.numpy(), param_seed=np.int64(1000))
+
+    # ---------------- real speech: 4 reference WAVs (3 s crops) -> oracle Fbank -> reference ECAPA graph
+    names = ['a_1', 'a_2', 'b_1', 'b_2']
+    pcm = np.stack([read_wav_16k_mono(f'{REF}/dataset/{n}.wav') for n in names])
+    wav = (pcm.astype(np.float32) / 32768.0)
+    feats = ofb.featurize(wav, feature_method='Fbank', method_args=dict(sr=16000, n_mels=80))
+    model.eval()
+    with torch.no_grad():
+        emb_w = model(paddle_shim.to_tensor(feats)).numpy()
+    en = emb_w / np.linalg.norm(emb_w, axis=1, keepdims=True)
+    out['wavs_3s.npz'] = dict(pcm=pcm, names=np.asarray(names), feats=feats, emb_eval=emb_w, cos=en @ en.T)
+    print(f'worst rel-max-err {worst:.3e}')
+
+    if not args.check:
+        os.makedirs(GOLD, exist_ok=True)
+        for fn, d in out.items():
+            np.savez_compressed(os.path.join(GOLD, fn), **d)
+            print('wrote', fn, os.path.getsize(os.path.join(GOLD, fn)), 'bytes')
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

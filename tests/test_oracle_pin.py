@@ -1,0 +1,105 @@
+"""CPU tests: the oracle against the committed golden fixtures (tests/golden/*.npz).
+
+The fixtures hold outputs of the REFERENCE's own model files (ppvector/models/ecapa_tdnn.py,
+tdnn.py, fc.py, loss/aamloss.py) executed through oracle/paddle_shim by oracle/gen_golden.py.
+Where /root/reference is present (build container) the generator's --check mode is re-run too.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fbank as ofb
+from oracle import models as om
+from oracle import scoring as osc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def test_ecapa_oracle_matches_reference_golden(golden_dir):
+    g = _load(golden_dir, 'ecapa_ref_small.npz')
+    p = om.ecapa_params(input_size=80, seed=int(g['param_seed']))
+    n_train, n_buf = om.count_params(p)
+    assert (n_train, n_buf) == (int(g['n_train']), int(g['n_buf'])) == (6194048, 19328)
+    x = torch.from_numpy(g['x'])
+    with torch.no_grad():
+        emb = om.ecapa_forward(p, x).numpy()
+        emb_tr = om.ecapa_forward(p, x, training=True).numpy()
+    assert np.max(np.abs(emb - g['emb_eval'])) < 1e-4 * np.max(np.abs(g['emb_eval']))
+    assert np.max(np.abs(emb_tr - g['emb_train'])) < 1e-3 * np.max(np.abs(g['emb_train']))
+    W = om.head_params(192, 2796, seed=int(g['head_seed']))
+    logits = om.cosine_head(torch.from_numpy(g['emb_eval']), W)
+    assert np.max(np.abs(logits.numpy() - g['logits'])) < 1e-6
+    for (margin, ls, easy), ref in zip(g['loss_cfg'], g['losses']):
+        l = om.aam_loss(logits, torch.from_numpy(g['labels']), float(margin), 32.0, bool(easy), float(ls))
+        assert abs(float(l) - ref) < 1e-4
+
+
+def test_readme_parameter_inventory():
+    # README.md:341-345 (paddle.summary at F=64, 9726 classes): total 8,039,808; non-trainable 19,328
+    p = om.ecapa_params(input_size=64, seed=0)
+    t, b = om.count_params(p)
+    assert t + b + 192 * 9726 == 8039808
+    assert b == 19328
+
+
+def test_tdnn_oracle_matches_reference_golden(golden_dir):
+    g = _load(golden_dir, 'tdnn_ref_small.npz')
+    p = om.tdnn_params(input_size=80, seed=int(g['param_seed']))
+    with torch.no_grad():
+        emb = om.tdnn_forward(p, torch.from_numpy(g['x'])).numpy()
+    assert np.max(np.abs(emb - g['emb_eval'])) < 1e-4 * np.max(np.abs(g['emb_eval']))
+
+
+def test_real_speech_fixture(golden_dir):
+    g = _load(golden_dir, 'wavs_3s.npz')
+    wav = g['pcm'].astype(np.float32) / 32768.0
+    feats = ofb.featurize(wav, method_args=dict(sr=16000, n_mels=80))
+    assert feats.shape == (4, 298, 80)
+    assert np.max(np.abs(feats - g['feats'])) < 1e-4
+    p = om.ecapa_params(input_size=80, seed=1000)
+    with torch.no_grad():
+        emb = om.ecapa_forward(p, torch.from_numpy(g['feats'])).numpy()
+    cos = osc.cosine_matrix(emb.astype(np.float64), emb.astype(np.float64))
+    assert np.max(np.abs(cos - g['cos'])) < 1e-5
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference'), reason='reference sources not on this box')
+def test_regenerate_against_reference_sources():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'gen_golden.py'), '--check'],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_margin_schedule_endpoints():
+    spe, me = 10, 60
+    assert om.margin_schedule(0, spe, me) == 0.0
+    assert om.margin_schedule(int(me * 0.3) * spe - 1, spe, me) == 0.0
+    assert om.margin_schedule(int(me * 0.7) * spe, spe, me) == 0.3
+    mid = om.margin_schedule(int(me * 0.5) * spe, spe, me)
+    assert 0.0 < mid < 0.3
+    m = om.aam_margins(0.2)
+    assert abs(m['th'] - np.cos(np.pi - 0.2)) < 1e-12 and abs(m['mmm'] - (1 + np.cos(np.pi - 0.2))) < 1e-12
+
+
+def test_eer_known_answer():
+    # perfectly separable scores -> EER 0; fully overlapping symmetric -> 0.5
+    s = np.asarray([0.9, 0.8, 0.7, 0.2, 0.1, 0.0])
+    y = np.asarray([1, 1, 1, 0, 0, 0])
+    fnr, fpr, _ = osc.fnr_fpr(s, y)
+    assert osc.eer(fnr, fpr) == pytest.approx(0.0, abs=1e-12)
+    assert osc.min_dcf(fnr, fpr) == pytest.approx(0.0, abs=1e-12)
+    s2 = np.asarray([0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8])
+    y2 = np.asarray([1, 0, 1, 0, 1, 0, 1, 0])
+    fnr, fpr, _ = osc.fnr_fpr(s2, y2)
+    e, thr = osc.eer(fnr, fpr, s2)
+    assert 0.3 < e < 0.7
+    sc, lab = osc.trial_scores(np.eye(3), [0, 1, 2], np.eye(3), [0, 1, 2])
+    assert sc.shape == (9,) and lab.sum() == 3
