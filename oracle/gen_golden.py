@@ -94,6 +94,7 @@ def main():
         emb_ref_tr = model(xt)
         emb_or_tr = om.ecapa_forward(p, torch.from_numpy(x), training=True)
     cmp('ecapa train-BN emb', emb_or_tr, emb_ref_tr, 2e-4)
+    model.load_state_dict(p)            # the train-mode forward moved the running stats: restore
     # head + AAM loss
     W = om.head_params(192, C_, seed=1001)
     head = ref_fc.SpeakerIdentification(input_dim=192, num_speakers=C_, classifier_type='Cosine')
