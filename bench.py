@@ -1,0 +1,227 @@
+#!/usr/bin/env python
+"""Headline benchmark: utterances/s (3 s @ 16 kHz) through the hot path on N MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic input already resident in HBM:
+    waveforms (B, 48000) f32 -> HIP Fbank+CMN -> HIP ECAPA-TDNN forward (bf16 MFMA, f32 accumulate,
+    eval-mode BN) -> cosine head (2796 classes) + AAM-softmax loss.
+Workload = BASELINE.json configs[1] (ECAPA-TDNN + Fbank, 2796 classes, batch 256, bf16).  Utterances
+are independent, so N GPUs run N shards of the data with no data-path collective (weak scaling:
+batch 256 per GPU); the only cross-rank traffic is the timing barrier / max-reduce.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  "roofline"     : the dominant kernel family (conv GEMM, bf16 in / bf16 out, 128x128 tile: the nine
+                   launches per step that carry 90 % of the forward's flops) timed launch-by-launch
+                   with HIP events on the launching stream, against the dense bf16 MFMA peak;
+  "cpu_baseline" : the CPU oracle (reference algorithm restated on NumPy + PyTorch-CPU fp32 -- NOT
+                   the PaddlePaddle binary) timed on this host's cores on a bounded sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, 'voiceprintrecognition-paddlepaddle_amd')
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+BATCH, N_SAMPLES, N_MELS, N_CLASSES, EMBD = 256, 48000, 80, 2796, 192
+PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA, MI355X_MICROARCH.md
+ALG_GFLOP_PER_UTT = 2.857          # ECAPA forward, algorithmic
+
+
+def conv_family_shapes(T):
+    """(Cin, Cout, KW, dil) of the launches of conv_gemm_kernel<bf16, bf16, 128> in one ECAPA step."""
+    s = [(80, 512, 5, 1)]
+    for d in (2, 3, 4):
+        s += [(512, 512, 1, 1), (512, 512, 1, 1)]          # tdnn1, tdnn2 of each SE-Res2 block
+    s += [(1536, 1536, 1, 1), (1536, 128, 1, 1)]           # MFA, ASP attention TDNN (x part)
+    return s
+
+
+def roofline_pass(reps):
+    """Replays the dominant kernel family launch by launch (same shapes, dtypes and buffer sizes as
+    inside the step), each launch bracketed by HIP events on the launching stream."""
+    from ppvector import _native as N
+    lib, ctx = N.lib(), N.ctx()
+    T = 298
+    M = BATCH * T
+    dev = torch.device('cuda')
+    g = torch.Generator(device='cuda').manual_seed(1)
+    total_ms, total_flop, per_shape = 0.0, 0.0, []
+    for (cin, cout, kw, dil) in conv_family_shapes(T):
+        x = torch.randn((M, cin), device=dev, generator=g).to(torch.bfloat16)
+        w = (torch.randn((cout, kw * cin), device=dev, generator=g) / (kw * cin) ** 0.5).to(torch.bfloat16)
+        bias = torch.randn((cout,), device=dev, generator=g)
+        sc = torch.rand((cout,), device=dev, generator=g) + 0.5
+        sh = torch.randn((cout,), device=dev, generator=g)
+        y = torch.empty((M, cout), device=dev, dtype=torch.bfloat16)
+        d = N.Conv1dDesc()
+        d.dtype_in = d.dtype_out = N.VP_BF16
+        d.B, d.T_in, d.T_out, d.Cin, d.Cout, d.KW, d.dilation, d.stride = BATCH, T, T, cin, cout, kw, dil, 1
+        d.pad_mode, d.pad_left = N.VP_PAD_REFLECT, dil * (kw - 1) // 2
+        d.x, d.ldx, d.w, d.bias = x.data_ptr(), cin, w.data_ptr(), bias.data_ptr()
+        d.act, d.bn_scale, d.bn_shift = N.VP_ACT_RELU, sc.data_ptr(), sh.data_ptr()
+        d.y, d.ldy = y.data_ptr(), cout
+        for _ in range(2):
+            N.check(lib.vp_conv1d_fwd(ctx, C.byref(d), N.stream_ptr()), ctx)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in evs:
+            a.record()
+            N.check(lib.vp_conv1d_fwd(ctx, C.byref(d), N.stream_ptr()), ctx)
+            b.record()
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in evs) / reps
+        flop = 2.0 * M * cout * kw * cin
+        total_ms += ms
+        total_flop += flop
+        per_shape.append({'cin': cin, 'cout': cout, 'kw': kw, 'ms': round(ms, 4), 'tflops': round(flop / ms / 1e9, 1)})
+        del x, w, y
+    n = len(per_shape)
+    achieved = total_flop / (total_ms * 1e-3) / 1e12
+    traffic = None
+    tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get('conv_gemm_bf16_128_bytes_per_launch')
+        except Exception:
+            traffic = None
+    return {'bound': 'mfma', 'kernel': 'conv_gemm_kernel<bf16,bf16,128> (9 launches/step, 90% of forward flops)',
+            'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
+            'flop_per_launch': total_flop / n, 'avg_launch_ms': round(total_ms / n, 4), 'launches': per_shape}
+
+
+def cpu_baseline(target_s=15.0):
+    """CPU oracle on the host cores: Fbank+CMN (NumPy f32) -> ECAPA-TDNN (PyTorch-CPU f32, eval) ->
+    cosine head + AAMLoss, same synthetic inputs, bounded sample."""
+    from oracle import fbank as ofb
+    from oracle import models as om
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    p = om.ecapa_params(N_MELS, seed=1000)
+    W = om.head_params(EMBD, N_CLASSES, seed=1001)
+
+    def run(n):
+        w = ofb.synth_waves(n, N_SAMPLES, seed=1000)
+        labels = torch.arange(n) % N_CLASSES
+        t0 = time.perf_counter()
+        feats = ofb.featurize(w, method_args=dict(sr=16000, n_mels=N_MELS))
+        with torch.no_grad():
+            emb = om.ecapa_forward(p, torch.from_numpy(feats))
+            loss = om.aam_loss(om.cosine_head(emb, W), labels, 0.2, 32.0)
+        float(loss)
+        return time.perf_counter() - t0
+
+    run(2)                                   # warm-up (thread pools, oneDNN primitives)
+    t8 = run(8)
+    n = int(max(8, min(256, round(8 * target_s / max(t8, 1e-3) / 8) * 8)))
+    t = run(n)
+    return {'value': round(n / t, 2), 'unit': 'utterances/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} synthetic 3 s utterances, one batch, eval forward + AAM loss, {t:.1f} s wall; '
+                      'reference algorithm restated on NumPy + PyTorch-CPU fp32 (not the PaddlePaddle binary)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs: the engine has no CPU fallback'
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl')          # RCCL
+    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE {world}'
+
+    from oracle import fbank as ofb
+    from oracle import models as om
+    from ppvector.data_utils.featurizer import AudioFeaturizer
+    from ppvector.loss.aamloss import AAMLoss
+    from ppvector.models.ecapa_tdnn import EcapaTdnn
+    from ppvector.models.fc import SpeakerIdentification
+
+    dev = torch.device('cuda', local_rank)
+    # synthetic inputs, resident in HBM before the timed region (seed per rank: distinct shards)
+    wav = torch.from_numpy(ofb.synth_waves(BATCH, N_SAMPLES, seed=1000 + rank)).to(dev)
+    labels = (torch.arange(BATCH, device=dev) * 7 + rank) % N_CLASSES
+    fz = AudioFeaturizer('Fbank', dict(sr=16000, n_mels=N_MELS))
+    model = EcapaTdnn(N_MELS, embd_dim=EMBD, pooling_type='ASP', channels=[512, 512, 512, 512, 1536])
+    model.load_state_dict(om.ecapa_params(N_MELS, seed=1000))      # random init, BN stats randomised
+    model = model.to(dev).eval()
+    head = SpeakerIdentification(EMBD, N_CLASSES)
+    head.load_state_dict({'weight': om.head_params(EMBD, N_CLASSES, seed=1001)})
+    head = head.to(dev)
+    crit = AAMLoss(margin=0.2, scale=32, easy_margin=False, label_smoothing=0.0)
+    eng = model.engine(args.dtype)
+    want16 = args.dtype == 'bfloat16'
+
+    def step():
+        feats = fz(wav, want_bf16=want16)
+        emb = eng.forward(feats)
+        return crit(head(emb), labels)
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    loss_v = float(loss)
+    assert np.isfinite(loss_v)
+
+    out = None
+    if rank == 0:
+        value = world * BATCH * args.steps / dt
+        out = {
+            'metric': 'utterances/sec (3 s, 16 kHz) ECAPA-TDNN fwd+AAM', 'value': round(value, 1),
+            'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'bf16' if want16 else 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: ECAPA-TDNN (C=512, MFA 1536, ASP, embd 192) + Kaldi Fbank 80, '
+                                   '3 s @ 16 kHz (T=298), 2796-class cosine head + AAMLoss, eval-mode forward, '
+                                   f'batch {BATCH} per GPU, inputs resident in HBM, random-init weights',
+                       'batch_per_gpu': BATCH, 'global_batch': BATCH * world, 'parallelism': f'dp{world} (no collective)'},
+            'loss': round(loss_v, 5),
+            'stage_roofline_frac': round(value / world * ALG_GFLOP_PER_UTT / 1e3 / PEAK_BF16_TFLOPS, 4),
+        }
+        if world == 1 and not args.no_roofline and want16:
+            out['roofline'] = roofline_pass(reps=10)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

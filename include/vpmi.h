@@ -1,0 +1,225 @@
+/*
+ * vpmi.h -- C ABI of libvpmi.so, the MI355X (gfx950) engine for the ppvector hot path.
+ *
+ * The reference (yeyupiaoling/VoiceprintRecognition-PaddlePaddle, ppvector 1.1.1) is pure Python and
+ * has NO FFI / operator-plugin interface: its seams are Python call signatures into PaddlePaddle
+ * (SURVEY.md section 8(b)).  Each entry point below therefore names the reference Python call site whose
+ * arithmetic it replaces; INTEGRATION.md shows the ctypes binding a ppvector maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _h; the caller (PyTorch) owns all
+ *     buffers and the stream; calls are asynchronous on `stream` and hold no mutable global state
+ *     beyond the opaque vp_ctx (which owns small read-only device tables: twiddles, window, mel bank);
+ *   - activations are "frame-major" (B, T, C): one frame = one contiguous channel vector -- the
+ *     reference's (B, T, F) feature layout (featurizer.py:46) kept end to end, so its
+ *     transpose([0,2,1]) (ecapa_tdnn.py:256) never materialises;
+ *   - return 0 on success, <0 = VP_E*; never throws; vp_last_error(ctx) gives the text;
+ *   - no torch types anywhere in this header.
+ */
+#ifndef VPMI_H
+#define VPMI_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VPMI_VERSION 100
+
+typedef struct vp_ctx vp_ctx;
+typedef void* vp_stream; /* hipStream_t */
+
+enum { VP_OK = 0, VP_EINVAL = -1, VP_ENOMEM = -2, VP_EHIP = -3, VP_EUNSUP = -4, VP_EWORKSPACE = -5 };
+enum { VP_F32 = 0, VP_BF16 = 1 };                  /* element type of activations / GEMM weights     */
+enum { VP_PAD_NONE = 0, VP_PAD_REFLECT = 1, VP_PAD_ZERO = 2 };
+enum { VP_ACT_NONE = 0, VP_ACT_RELU = 1, VP_ACT_SIGMOID = 2, VP_ACT_TANH = 3 };
+
+int vp_version(void);
+vp_ctx* vp_create(int device);                      /* NULL on failure                                */
+void vp_destroy(vp_ctx* ctx);
+const char* vp_last_error(vp_ctx* ctx);             /* host string, valid until the next failing call */
+
+/* ------------------------------------------------------------------------------------------------
+ * Fbank + CMN  -- replaces AudioFeaturizer.forward (ppvector/data_utils/featurizer.py:33-60) with
+ * feature_method 'Fbank' -> KaldiFbank.forward (featurizer.py:88-101) ->
+ * paddleaudio.compliance.kaldi.fbank(waveform, sr=, n_mels=) (call site featurizer.py:97).
+ * wav (B, L) f32 in [-1,1]  ->  out (B, T, n_mels) f32, time-mean subtracted over the padded T,
+ * rows t >= int32(lens_ratio[b] * T) zeroed when lens_ratio != NULL (featurizer.py:51-59).
+ * out_bf16 (optional) receives the same tensor rounded to bf16 for the bf16 network path.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int sample_rate;        /* 16000 */
+    int n_mels;             /* paddleaudio default 23; configs use 80 */
+    float frame_length_ms;  /* 25 */
+    float frame_shift_ms;   /* 10 */
+    float preemph;          /* 0.97 */
+    int remove_dc;          /* 1 */
+    float low_freq;         /* 20 */
+    float high_freq;        /* 0 -> Nyquist */
+    float log_floor;        /* 1e-7 */
+} vp_fbank_opts;
+
+void vp_fbank_default_opts(vp_fbank_opts* o);
+int vp_fbank_num_frames(const vp_fbank_opts* o, int n_samples);       /* snip_edges frame count   */
+size_t vp_fbank_workspace_bytes(const vp_fbank_opts* o, int B, int L);
+int vp_fbank_cmn_f32(vp_ctx* ctx, const float* wav, const float* lens_ratio, int B, int L,
+                     const vp_fbank_opts* o, float* out, void* out_bf16, void* ws, size_t ws_bytes,
+                     vp_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * conv1d as implicit GEMM with fused epilogue -- replaces, per launch, the reference chain
+ *   Conv1d.forward (models/utils.py:65-93: reflect "same" pad + nn.Conv1D)  /  nn.Conv1D (tdnn.py:13-21)
+ *   -> activation -> BatchNorm1d (models/utils.py:96-119, eval mode)   i.e. TDNNBlock (utils.py:147-148),
+ * plus the Res2Net "x_i + y_{i-1}" hand-off (ecapa_tdnn.py:36-47) and the time-sums that SEBlock
+ * (ecapa_tdnn.py:69-78) and AttentiveStatisticsPooling's global context (pooling.py:97-104) need.
+ *
+ *   y[b,t,n] = act2( bn( act( bias[n] + rowbias[b,n] + sum_{j<KW} sum_{c<Cin}
+ *                    w[n][j*Cin+c] * x[b, src(t,j), c] ) ) )
+ *   src(t,j) = t*stride - pad_left + j*dilation, reflected / zero-filled per pad_mode.
+ * x, y, add_in, aux are (B*T, ld) row-major with a channel offset (so slices of a concat buffer
+ * are addressed in place); channels [0, xsplit) of x may come from a second tensor x2 (KW == 1).
+ * aux = y + add_in (same dtype as y).  psum/psumsq: per (M-tile, utterance-segment) partial sums
+ * of (y - bn_shift) and its square over the tile's rows, layout [tiles_m][nseg][Cout] f32.
+ * Alignment: Cin, ldx, xoff, xsplit multiples of 16 B / sizeof(elem); Cout, ldy, yoff multiples of 4.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int dtype_in, dtype_out;
+    int B, T_in, T_out;
+    int Cin, Cout, KW, dilation, stride, pad_left, pad_mode;
+    const void* x;   int ldx, xoff;
+    const void* x2;  int ldx2, x2off, xsplit;
+    const void* w;                       /* [Cout][KW*Cin], dtype_in */
+    const float* bias;                   /* [Cout] or NULL */
+    const float* rowbias;                /* [B][Cout] or NULL */
+    int act;                             /* VP_ACT_NONE | VP_ACT_RELU, applied before BN */
+    const float* bn_scale;               /* [Cout] or NULL: gamma / sqrt(var + eps) */
+    const float* bn_shift;               /* [Cout] or NULL: beta - mean * scale */
+    int act2;                            /* VP_ACT_NONE | VP_ACT_TANH, applied after BN */
+    void* y;         int ldy, yoff;
+    const void* add_in; int ld_add, add_off;
+    void* aux;       int ld_aux, aux_off;
+    float* psum;
+    float* psumsq;
+} vp_conv1d_desc;
+
+int vp_conv1d_tiles_m(int B, int T_out);            /* rows of the psum arrays                     */
+int vp_conv1d_nseg(int T_out);                      /* utterance segments per M-tile               */
+int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream);
+
+/* mean / std over time from the conv1d partial sums: stats[b][0:C] = mean, stats[b][C:2C] = std,
+ * std = sqrt(max(E[(x-mean)^2], eps)) -- pooling.py:90-93 with the all-ones mask of pooling.py:94-101
+ * (lengths=None, the only branch the shipped entry points reach, trainer.py:210). */
+int vp_moments_finalize(vp_ctx* ctx, const float* psum, const float* psumsq, const float* shift,
+                        int B, int T, int C, float eps, int want_std, float* stats, vp_stream stream);
+
+/* small dense layer in exact f32 (f32 MFMA): out[M][N] = act(a[M][K] @ W + bias).
+ * w_is_kn = 0: W given as [N][K];  1: W given as [K][N] (Paddle Linear / fc.py weight layout). */
+int vp_dense_f32(vp_ctx* ctx, const float* a, int lda, const float* w, int w_is_kn, const float* bias,
+                 int M, int N, int K, int act, float* out, int ldo, vp_stream stream);
+
+/* f32 -> bf16 (round to nearest even) of a contiguous tensor; x 16-B aligned, y 8-B aligned. */
+int vp_cast_f32_bf16(vp_ctx* ctx, const float* x, void* y, long long n, vp_stream stream);
+
+/* SE gate applied + residual: out = x * s[b, c] + res  (ecapa_tdnn.py:82 and :142). */
+int vp_se_scale_residual(vp_ctx* ctx, int dtype, const void* x, int ldx, int xoff, const float* s,
+                         const void* res, int ldr, int roff, void* out, int ldo, int ooff,
+                         int B, int T, int C, vp_stream stream);
+
+/* attention softmax over time + weighted mean/std (pooling.py:114-123):
+ * logits (B*T, C) f32, x (B*T, ldx) -> pooled (B, 2C) f32 = [mean | std]. */
+int vp_asp_softmax_stats(vp_ctx* ctx, int dtype, const float* logits, const void* x, int ldx, int xoff,
+                         int B, int T, int C, float eps, float* pooled, vp_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole-backbone forward, eval mode -- replaces EcapaTdnn.forward (models/ecapa_tdnn.py:245-276)
+ * and TDNN.forward (models/tdnn.py:46-68).  Weights are packed by the host (BN folded to
+ * scale/shift, conv weights as [Cout][KW*Cin] in `dtype`).
+ * ---------------------------------------------------------------------------------------------- */
+#define VP_MAX_SE_BLOCKS 8
+#define VP_MAX_RES2 15
+
+typedef struct {
+    const void* w;            /* [cout][kw*cin] in the network dtype */
+    const float* bias;        /* [cout] */
+    const float* bn_scale;    /* [cout] or NULL */
+    const float* bn_shift;    /* [cout] or NULL */
+    int cin, cout, kw, dil;
+} vp_tdnn_layer;
+
+typedef struct {
+    vp_tdnn_layer tdnn1;
+    vp_tdnn_layer res2[VP_MAX_RES2];
+    vp_tdnn_layer tdnn2;
+    const float* se_w1;       /* [se_ch][C]  f32 */
+    const float* se_b1;       /* [se_ch] */
+    const float* se_w2;       /* [C][se_ch]  f32 */
+    const float* se_b2;       /* [C] */
+} vp_se_res2_block;
+
+typedef struct {
+    vp_tdnn_layer tdnn;       /* x-part of the attention TDNN: w [att][C]; bias, BN as usual */
+    const float* w_ctx;       /* [att][2C] f32: columns acting on the tiled mean | std, or NULL */
+    const void* conv_w;       /* [C][att] network dtype */
+    const float* conv_b;      /* [C] */
+    int C, att;
+} vp_asp_weights;
+
+typedef struct {
+    int dtype;                /* VP_F32 | VP_BF16 */
+    int feat_dim, embd_dim, n_blocks, res2_scale, se_ch;
+    vp_tdnn_layer block0;
+    vp_se_res2_block blk[VP_MAX_SE_BLOCKS];
+    vp_tdnn_layer mfa;
+    vp_asp_weights asp;
+    const float* fc_w;        /* [embd][2*C_mfa] f32, asp_bn folded in */
+    const float* fc_b;        /* [embd] */
+} vp_ecapa_weights;
+
+size_t vp_ecapa_workspace_bytes(const vp_ecapa_weights* w, int B, int T);
+/* feats: (B, T, feat_dim) in w->dtype; emb: (B, embd_dim) f32. */
+int vp_ecapa_fwd(vp_ctx* ctx, const vp_ecapa_weights* w, const void* feats, int B, int T, float* emb,
+                 void* ws, size_t ws_bytes, vp_stream stream);
+
+typedef struct {
+    int dtype;
+    int feat_dim, embd_dim, channels;
+    vp_tdnn_layer td[5];      /* un-padded convs, ReLU then BN (td[4]: no BN) */
+    vp_asp_weights asp;
+    const float* lin_w;       /* [embd][2*channels] f32 with bn5 and bn6 folded in */
+    const float* lin_b;       /* [embd] */
+} vp_tdnn_weights;
+
+size_t vp_tdnn_workspace_bytes(const vp_tdnn_weights* w, int B, int T);
+int vp_tdnn_fwd(vp_ctx* ctx, const vp_tdnn_weights* w, const void* feats, int B, int T, float* emb,
+                void* ws, size_t ws_bytes, vp_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Cosine classifier + AAM-softmax loss -- replaces SpeakerIdentification.forward 'Cosine' branch
+ * (models/fc.py:41-53) and AAMLoss.forward (loss/aamloss.py:28-47) incl. CrossEntropyLoss
+ * (label_smoothing, mean reduction).  emb (B, D) f32; W (D, C) f32 (fc.py:31 layout); labels int64.
+ * logits (B, C) f32 = cosines (optional output); row_loss (B) f32; loss (1) f32 = mean.
+ * ---------------------------------------------------------------------------------------------- */
+size_t vp_cosine_logits_workspace_bytes(int B, int D, int C);
+int vp_cosine_logits_f32(vp_ctx* ctx, const float* emb, const float* W, int B, int D, int C, float* logits,
+                         void* ws, size_t ws_bytes, vp_stream stream);                 /* fc.py:49 alone   */
+int vp_aam_ce_fwd(vp_ctx* ctx, const float* logits, const int64_t* labels, int B, int C, float margin, float scale,
+                  float label_smoothing, int easy_margin, float* loss, float* row_loss,
+                  vp_stream stream);                                                    /* aamloss.py:28-47 */
+size_t vp_cosine_aam_workspace_bytes(int B, int D, int C);
+int vp_cosine_aam_ce_fwd(vp_ctx* ctx, const float* emb, const float* W, const int64_t* labels, int B, int D,
+                         int C, float margin, float scale, float label_smoothing, int easy_margin,
+                         float* loss, float* logits, float* row_loss, void* ws, size_t ws_bytes,
+                         vp_stream stream);
+
+/* Trial scoring -- replaces the per-trial sklearn cosine_similarity loop of
+ * PPVectorTrainer.evaluate (trainer.py:416-423) and PPVectorPredictor.contrast (predict.py:282):
+ * scores[i][j] = <a_i, b_j> / (|a_i| |b_j|). */
+size_t vp_cosine_scores_workspace_bytes(int Na, int Nb, int D);
+int vp_cosine_scores_f32(vp_ctx* ctx, const float* a, const float* b, int Na, int Nb, int D, float* scores,
+                         void* ws, size_t ws_bytes, vp_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VPMI_H */

@@ -1,0 +1,150 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/vpmi.h declares (no compute calls: there is no GPU here), host-side logic of the Python
+mirror (registries, config loading, schedules, metrics, parameter naming)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from ppvector import _native as N
+    hdr = open(os.path.join(ROOT, 'include', 'vpmi.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(vp_[a-z0-9_]+)\s*\(', hdr))
+    assert len(declared) >= 25
+    lib = N.load_library()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f'{name} declared in vpmi.h but not exported'
+    assert declared == set(N.EXPORTED_SYMBOLS), declared ^ set(N.EXPORTED_SYMBOLS)
+    assert lib.vp_version() == 100
+    import ctypes as C
+    o = N.FbankOpts()
+    lib.vp_fbank_default_opts(C.byref(o))
+    assert (o.sample_rate, o.n_mels, o.remove_dc) == (16000, 23, 1)
+    assert lib.vp_fbank_num_frames(C.byref(o), 48000) == 298
+    assert lib.vp_fbank_num_frames(C.byref(o), 399) == 0
+    assert lib.vp_conv1d_tiles_m(256, 298) == 596 and lib.vp_conv1d_nseg(298) == 2 and lib.vp_conv1d_nseg(64) == 3
+
+
+def test_struct_sizes_match_header_layout():
+    import ctypes as C
+    from ppvector import _native as N
+    assert C.sizeof(N.TdnnLayer) == 4 * 8 + 4 * 4
+    assert C.sizeof(N.FbankOpts) == 9 * 4
+    assert C.sizeof(N.SeRes2Block) == 17 * C.sizeof(N.TdnnLayer) + 4 * 8
+    assert C.sizeof(N.AspWeights) == C.sizeof(N.TdnnLayer) + 3 * 8 + 8
+
+
+def test_no_cpu_fallback():
+    from ppvector import _native as N
+    from ppvector.data_utils.featurizer import AudioFeaturizer
+    from ppvector.models.ecapa_tdnn import EcapaTdnn
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    fz = AudioFeaturizer('Fbank', {'sr': 16000, 'n_mels': 80})
+    with pytest.raises(N.VpmiError):
+        fz(torch.zeros(2, 16000))
+    m = EcapaTdnn(80).eval()
+    with pytest.raises(N.VpmiError):
+        m(torch.zeros(1, 50, 80))
+
+
+@pytest.mark.parametrize('cfg', ['ecapa_tdnn.yml', 'tdnn.yml'])
+def test_reference_configs_build(cfg):
+    from ppvector.loss import build_loss
+    from ppvector.models import build_model
+    from ppvector.data_utils.featurizer import AudioFeaturizer
+    from ppvector.utils.utils import dict_to_object
+    path = os.path.join('/root/reference/configs', cfg)
+    if os.path.exists(path):        # the reference's own YAML, unmodified, where it is present
+        raw = yaml.safe_load(open(path, encoding='utf-8'))
+    else:                           # same keys, restated (the reference tree does not travel)
+        model = {'ecapa_tdnn.yml': dict(model='EcapaTdnn', model_args=dict(embd_dim=192, pooling_type='ASP',
+                                                                           channels=[512, 512, 512, 512, 1536])),
+                 'tdnn.yml': dict(model='TDNN', model_args=dict(embd_dim=192, pooling_type='ASP'))}[cfg]
+        model['classifier'] = dict(classifier_type='Cosine', num_speakers=2796, num_blocks=0)
+        raw = dict(preprocess_conf=dict(feature_method='Fbank', method_args=dict(sr=16000, n_mels=80)),
+                   model_conf=model,
+                   loss_conf=dict(loss='AAMLoss', loss_args=dict(margin=0.2, scale=32, easy_margin=False,
+                                                                 label_smoothing=0.0)))
+    configs = dict_to_object(raw)
+    fz = AudioFeaturizer(feature_method=configs.preprocess_conf.feature_method,
+                         method_args=configs.preprocess_conf.get('method_args', {}))
+    assert fz.feature_dim == 80
+    model = build_model(input_size=fz.feature_dim, configs=configs)
+    assert model.embd_dim == 192
+    loss = build_loss(configs)
+    assert hasattr(loss, 'update')
+    loss.update(margin=0.1)
+    assert abs(loss.cos_m - np.cos(0.1)) < 1e-12
+
+
+def test_state_dict_names_match_reference_scheme():
+    from oracle import models as om
+    from ppvector.models.ecapa_tdnn import EcapaTdnn
+    from ppvector.models.tdnn import TDNN
+    m = EcapaTdnn(80)
+    p = om.ecapa_params(80)
+    assert set(m.state_dict().keys()) == set(p.keys())
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(p[k].shape), k
+    m.load_state_dict(p)
+    t = TDNN(80)
+    pt = om.tdnn_params(80)
+    assert set(t.state_dict().keys()) == set(pt.keys())
+    t.load_state_dict(pt)
+    # nn.Sequential(backbone, classifier) key scheme of the reference checkpoints: "0.<...>", "1.weight"
+    from ppvector.models.fc import SpeakerIdentification
+    seq = torch.nn.Sequential(m, SpeakerIdentification(192, 10))
+    assert '0.blocks.0.conv.conv.weight' in seq.state_dict() and '1.weight' in seq.state_dict()
+    assert tuple(seq.state_dict()['1.weight'].shape) == (192, 10)
+
+
+def test_unknown_names_raise_like_reference():
+    from ppvector.data_utils.featurizer import AudioFeaturizer
+    from ppvector.models.ecapa_tdnn import EcapaTdnn
+    from ppvector.models.fc import SpeakerIdentification
+    with pytest.raises(Exception):
+        AudioFeaturizer('Nope')
+    with pytest.raises(Exception):
+        EcapaTdnn(80, pooling_type='XYZ')
+    with pytest.raises(ValueError):
+        SpeakerIdentification(192, 4, classifier_type='Nope')
+    assert AudioFeaturizer('MelSpectrogram', {}).feature_dim == 64
+    assert AudioFeaturizer('Spectrogram', {}).feature_dim == 257
+
+
+def test_margin_scheduler_matches_oracle():
+    from oracle import models as om
+    from ppvector.loss.aamloss import AAMLoss
+    from ppvector.optimizer.scheduler import MarginScheduler, cosine_decay_with_warmup
+    crit = AAMLoss()
+    spe, me = 7, 20
+    ms = MarginScheduler(crit, increase_start_epoch=int(me * 0.3), fix_epoch=int(me * 0.7), step_per_epoch=spe)
+    for step in range(spe * me):
+        ms.step()
+        assert abs(ms.get_margin() - om.margin_schedule(step, spe, me)) < 1e-12
+        assert abs(crit.margin - ms.get_margin()) < 1e-15
+    lr = cosine_decay_with_warmup(0.001, spe, fix_epoch=me, warmup_epoch=5, min_lr=1e-5)
+    assert lr[0] == 0.0 and abs(lr[5 * spe] - 0.001) < 1e-12 and lr[-1] > 1e-5 and len(lr) == spe * me + 1
+
+
+def test_metrics_match_oracle():
+    from oracle import scoring as osc
+    from ppvector.metric.metrics import compute_dcf, compute_eer, compute_fnr_fpr
+    rng = np.random.RandomState(0)
+    scores = np.concatenate([rng.normal(0.6, 0.2, 300), rng.normal(0.1, 0.2, 3000)])
+    labels = np.concatenate([np.ones(300, int), np.zeros(3000, int)])
+    fnr, fpr, thr = compute_fnr_fpr(scores, labels)
+    f2, p2, t2 = osc.fnr_fpr(scores, labels)
+    assert np.array_equal(fnr, f2) and np.array_equal(fpr, p2) and np.array_equal(thr, t2)
+    e, th = compute_eer(fnr, fpr, scores)
+    e2, th2 = osc.eer(f2, p2, scores)
+    assert e == e2 and th == th2 and 0.05 < e < 0.2
+    assert compute_dcf(fnr, fpr) == osc.min_dcf(f2, p2)

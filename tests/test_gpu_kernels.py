@@ -1,0 +1,366 @@
+"""GPU parity tests, kernel level: each C-ABI entry point of libvpmi against the CPU oracle /
+a float64 restatement of the same reference op, on seeded inputs.  Run with -m gpu on an MI355X.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import fbank as ofb
+from oracle import models as om
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def N():
+    from ppvector import _native as N
+    if not torch.cuda.is_available():
+        pytest.fail('no GPU visible: these tests must run on an MI355X (no CPU fallback exists)')
+    N.ctx(0)
+    return N
+
+
+def dev(x, dtype=None):
+    t = torch.as_tensor(np.asarray(x)) if not isinstance(x, torch.Tensor) else x
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda().contiguous()
+
+
+# --------------------------------------------------------------------------------------- Fbank
+@pytest.mark.parametrize('B,L', [(1, 400), (3, 16000), (2, 48000), (5, 7919)])
+def test_fbank_matches_oracle(N, B, L):
+    from ppvector.data_utils.featurizer import AudioFeaturizer
+    w = ofb.synth_waves(B, L, seed=11 + L, lowpass=0.8 if L % 2 else 0.0)
+    ref = ofb.featurize(w, method_args=dict(sr=16000, n_mels=80))
+    fz = AudioFeaturizer('Fbank', dict(sr=16000, n_mels=80))
+    out = fz(dev(w), want_bf16=True)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert got.shape == ref.shape
+    # tolerance: f32 FFT/log round-off on log-mel energies (values span ~[-12, 8])
+    assert np.max(np.abs(got - ref)) < 2e-3, np.max(np.abs(got - ref))
+    assert np.mean(np.abs(got - ref)) < 2e-5
+    twin = out._vp_bf16.float().cpu().numpy()
+    assert np.max(np.abs(twin - got)) <= np.max(np.abs(got)) * 2 ** -8 + 1e-6
+
+
+def test_fbank_mask_and_1d(N):
+    from ppvector.data_utils.featurizer import AudioFeaturizer
+    w = ofb.synth_waves(4, 12000, seed=5)
+    ratio = np.asarray([1.0, 0.75, 0.5, 0.13], np.float32)
+    ref = ofb.featurize(w, ratio, method_args=dict(sr=16000, n_mels=80))
+    fz = AudioFeaturizer('Fbank', dict(sr=16000, n_mels=80))
+    got = fz(dev(w), dev(ratio)).cpu().numpy()
+    assert np.max(np.abs(got - ref)) < 2e-3
+    T = ref.shape[1]
+    lens = (ratio * np.float32(T)).astype(np.int32)
+    for b in range(4):
+        assert np.all(got[b, lens[b]:] == 0)
+    one = fz(dev(w[0])).cpu().numpy()
+    assert one.shape == (1, T, 80)
+    with pytest.raises(ValueError):
+        fz(dev(w[:, :300]))
+    f23 = AudioFeaturizer('Fbank', dict(sr=16000))
+    assert f23.feature_dim == 23
+    r23 = ofb.featurize(w[:1], method_args=dict(sr=16000))
+    assert np.max(np.abs(f23(dev(w[:1])).cpu().numpy() - r23)) < 2e-3
+
+
+def test_fbank_real_speech_golden(N, golden_dir):
+    from ppvector.data_utils.featurizer import AudioFeaturizer
+    g = np.load(f'{golden_dir}/wavs_3s.npz')
+    wav = g['pcm'].astype(np.float32) / 32768.0
+    fz = AudioFeaturizer('Fbank', dict(sr=16000, n_mels=80))
+    got = fz(dev(wav)).cpu().numpy()
+    assert got.shape == (4, 298, 80)
+    d = np.abs(got - g['feats'])
+    assert d.max() < 5e-3 and d.mean() < 5e-5, (d.max(), d.mean())
+
+
+# --------------------------------------------------------------------------------------- conv1d
+def conv_ref(x, w, bias, kw, dil, pad_mode, stride=1):
+    """x (B,T,Cin) f64, w (Cout, Cin, kw) -> (B,T_out,Cout) f64, the reference's conv semantics."""
+    xt = x.transpose(1, 2)
+    pad = dil * (kw - 1) // 2
+    if pad_mode == 'reflect' and pad > 0:
+        xt = F.pad(xt, (pad, pad), mode='reflect')
+    elif pad_mode == 'zero' and pad > 0:
+        xt = F.pad(xt, (pad, pad))
+    y = F.conv1d(xt, w, bias, stride=stride, dilation=dil)
+    return y.transpose(1, 2)
+
+
+def run_conv(N, x, w, bias, kw, dil, pad_mode, dtype, out_dtype=None, relu=False, bn=None, act2=0, rowbias=None,
+             add_in=None, want_sums=False, x2=None, xsplit=0, T_out=None):
+    lib, ctx = N.lib(), N.ctx(0)
+    B, T, Cin = x.shape
+    Cout = w.shape[0]
+    tdt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    odt = tdt if out_dtype is None else (torch.bfloat16 if out_dtype == 'bf16' else torch.float32)
+    pm = {'none': N.VP_PAD_NONE, 'reflect': N.VP_PAD_REFLECT, 'zero': N.VP_PAD_ZERO}[pad_mode]
+    if T_out is None:
+        T_out = T if pad_mode != 'none' else T - dil * (kw - 1)
+    xd = dev(x, tdt)
+    wd = dev(w.permute(0, 2, 1).reshape(Cout, kw * Cin), tdt)
+    y = torch.zeros((B, T_out, Cout), dtype=odt, device='cuda')
+    d = N.Conv1dDesc()
+    d.dtype_in, d.dtype_out = N.dtype_id(tdt), N.dtype_id(odt)
+    d.B, d.T_in, d.T_out, d.Cin, d.Cout, d.KW, d.dilation, d.stride = B, T, T_out, Cin, Cout, kw, dil, 1
+    d.pad_mode, d.pad_left = pm, (0 if pad_mode == 'none' else dil * (kw - 1) // 2)
+    d.x, d.ldx, d.xoff = xd.data_ptr(), Cin, 0
+    keep = [xd, wd, y]
+    if x2 is not None:
+        x2d = dev(x2, tdt)
+        keep.append(x2d)
+        d.x2, d.ldx2, d.x2off, d.xsplit = x2d.data_ptr(), x2.shape[2], 0, xsplit
+    d.w = wd.data_ptr()
+    if bias is not None:
+        bd = dev(bias, torch.float32); keep.append(bd); d.bias = bd.data_ptr()
+    if rowbias is not None:
+        rd = dev(rowbias, torch.float32); keep.append(rd); d.rowbias = rd.data_ptr()
+    d.act = N.VP_ACT_RELU if relu else N.VP_ACT_NONE
+    if bn is not None:
+        sc, sh = dev(bn[0], torch.float32), dev(bn[1], torch.float32)
+        keep += [sc, sh]
+        d.bn_scale, d.bn_shift = sc.data_ptr(), sh.data_ptr()
+    d.act2 = act2
+    d.y, d.ldy, d.yoff = y.data_ptr(), Cout, 0
+    aux = None
+    if add_in is not None:
+        ad = dev(add_in, odt)
+        aux = torch.zeros_like(y)
+        keep += [ad, aux]
+        d.add_in, d.ld_add, d.add_off = ad.data_ptr(), Cout, 0
+        d.aux, d.ld_aux, d.aux_off = aux.data_ptr(), Cout, 0
+    ps = pq = None
+    if want_sums:
+        tiles, nseg = lib.vp_conv1d_tiles_m(B, T_out), lib.vp_conv1d_nseg(T_out)
+        ps = torch.full((tiles, nseg, Cout), float('nan'), dtype=torch.float32, device='cuda')
+        pq = torch.full((tiles, nseg, Cout), float('nan'), dtype=torch.float32, device='cuda')
+        d.psum, d.psumsq = ps.data_ptr(), pq.data_ptr()
+    N.check(lib.vp_conv1d_fwd(ctx, C.byref(d), N.stream_ptr()), ctx)
+    torch.cuda.synchronize()
+    return y, aux, ps, pq
+
+
+def q(t, dtype):
+    """Quantise a float64 tensor the way the kernel's inputs are quantised."""
+    return t.to(torch.bfloat16).double() if dtype == 'bf16' else t.float().double()
+
+
+CONV_CASES = [
+    # B, T, Cin, Cout, kw, dil, pad
+    (2, 64, 80, 512, 5, 1, 'reflect'),      # ECAPA block0 geometry (K = 400: ragged last K stage)
+    (3, 50, 64, 64, 3, 2, 'reflect'),       # Res2 conv, BN=64 tile, crosses utterances inside a tile
+    (2, 77, 64, 64, 3, 4, 'reflect'),
+    (1, 298, 512, 512, 1, 1, 'reflect'),    # 1x1
+    (2, 40, 128, 192, 1, 1, 'reflect'),     # Cout not a multiple of the tile
+    (2, 64, 80, 128, 5, 1, 'none'),         # TDNN un-padded
+    (2, 60, 128, 64, 3, 3, 'none'),
+    (2, 33, 64, 128, 3, 2, 'zero'),
+]
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv1d_plain(N, case, dtype):
+    B, T, Cin, Cout, kw, dil, pad = case
+    g = torch.Generator().manual_seed(1000 + CONV_CASES.index(case))
+    x = torch.randn(B, T, Cin, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, kw, generator=g, dtype=torch.float64) / (Cin * kw) ** 0.5
+    bias = torch.randn(Cout, generator=g, dtype=torch.float64)
+    ref = conv_ref(q(x, dtype), q(w, dtype), bias, kw, dil, pad)
+    y, _, _, _ = run_conv(N, x, w, bias, kw, dil, pad, dtype, out_dtype='f32' if dtype == 'f32' else 'f32')
+    err = (y.double().cpu() - ref).abs().max().item()
+    # same quantised inputs on both sides: only accumulation order / f32 accumulate differs
+    assert err < 2e-4, err
+    assert y.shape == ref.shape
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_conv1d_full_epilogue(N, dtype):
+    B, T, Cin, Cout, kw, dil = 3, 70, 64, 192, 3, 2
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, T, Cin, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, kw, generator=g, dtype=torch.float64) / (Cin * kw) ** 0.5
+    bias = torch.randn(Cout, generator=g, dtype=torch.float64)
+    rowbias = torch.randn(B, Cout, generator=g, dtype=torch.float64)
+    sc = torch.rand(Cout, generator=g, dtype=torch.float64) + 0.5
+    sh = torch.randn(Cout, generator=g, dtype=torch.float64)
+    add = torch.randn(B, T, Cout, generator=g, dtype=torch.float64)
+    z = conv_ref(q(x, dtype), q(w, dtype), bias, kw, dil, 'reflect') + rowbias[:, None, :]
+    ref = torch.relu(z) * sc + sh
+    y, aux, ps, pq = run_conv(N, x, w, bias, kw, dil, 'reflect', dtype, relu=True, bn=(sc, sh), rowbias=rowbias,
+                              add_in=add, want_sums=True)
+    tol = 3e-2 if dtype == 'bf16' else 2e-4         # bf16: output rounding of O(1..4) values
+    assert (y.double().cpu() - ref).abs().max().item() < tol
+    addq = q(add, dtype)
+    assert (aux.double().cpu() - (ref + addq)).abs().max().item() < 2 * tol
+    # time sums of (y - shift): rebuild per utterance from the per-tile partials
+    lib = N.lib()
+    nseg = lib.vp_conv1d_nseg(T)
+    ps, pq = ps.double().cpu(), pq.double().cpu()
+    assert not torch.isnan(ps).any() and not torch.isnan(pq).any()
+    for b in range(B):
+        s1 = torch.zeros(Cout, dtype=torch.float64)
+        s2 = torch.zeros(Cout, dtype=torch.float64)
+        for tm in range((b * T) // 128, ((b + 1) * T - 1) // 128 + 1):
+            sg = b - (tm * 128) // T
+            s1 += ps[tm, sg]
+            s2 += pq[tm, sg]
+        dref = ref[b] - sh
+        # the sums are taken from the f32 accumulators (before any bf16 rounding of y)
+        assert (s1 - dref.sum(0)).abs().max().item() < 1e-4 * max(1.0, dref.sum(0).abs().max().item())
+        assert (s2 - (dref ** 2).sum(0)).abs().max().item() < 1e-4 * (dref ** 2).sum(0).abs().max().item()
+    # tanh second activation
+    y2, _, _, _ = run_conv(N, x, w, bias, kw, dil, 'reflect', dtype, relu=True, bn=(sc, sh), act2=N.VP_ACT_TANH)
+    assert (y2.double().cpu() - torch.tanh(torch.relu(z - rowbias[:, None, :]) * sc + sh)).abs().max().item() < tol
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_conv1d_split_source(N, dtype):
+    """tdnn2's input: channels [0, 64) from one tensor, the rest from another (y_0 = x_0)."""
+    B, T, Cin, Cout = 2, 45, 256, 128
+    g = torch.Generator().manual_seed(8)
+    xa = torch.randn(B, T, Cin, generator=g, dtype=torch.float64)
+    xb = torch.randn(B, T, Cin, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, 1, generator=g, dtype=torch.float64) / Cin ** 0.5
+    xcat = torch.cat([xb[:, :, :64], xa[:, :, 64:]], dim=2)
+    ref = conv_ref(q(xcat, dtype), q(w, dtype), None, 1, 1, 'reflect')
+    y, _, _, _ = run_conv(N, xa, w, None, 1, 1, 'reflect', dtype, out_dtype='f32', x2=xb, xsplit=64)
+    assert (y.double().cpu() - ref).abs().max().item() < 2e-4
+
+
+def test_conv1d_rejects_bad_shapes(N):
+    x = torch.randn(1, 8, 20, dtype=torch.float64)
+    w = torch.randn(16, 20, 3, dtype=torch.float64)
+    with pytest.raises(N.VpmiError):
+        run_conv(N, x, w, None, 3, 1, 'reflect', 'bf16')            # Cin % 8 != 0
+    x = torch.randn(1, 2, 16, dtype=torch.float64)
+    w = torch.randn(16, 16, 3, dtype=torch.float64)
+    with pytest.raises(N.VpmiError):
+        run_conv(N, x, w, None, 3, 4, 'reflect', 'f32')             # reflect pad >= T
+
+
+# --------------------------------------------------------------------------------------- small ops
+@pytest.mark.parametrize('M,Nn,K,kn', [(256, 192, 3072, 0), (7, 128, 512, 0), (33, 50, 37, 0), (256, 2796, 192, 1),
+                                      (5, 17, 19, 1)])
+def test_dense_f32(N, M, Nn, K, kn):
+    g = torch.Generator().manual_seed(M + Nn + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(K, Nn, generator=g) if kn else torch.randn(Nn, K, generator=g)
+    bias = torch.randn(Nn, generator=g)
+    ref = a.double() @ (w.double() if kn else w.double().t()) + bias.double()
+    out = torch.empty(M, Nn, device='cuda')
+    lib, ctx = N.lib(), N.ctx(0)
+    ad, wd, bd = dev(a), dev(w), dev(bias)
+    for act, fn in ((N.VP_ACT_NONE, lambda t: t), (N.VP_ACT_RELU, torch.relu), (N.VP_ACT_SIGMOID, torch.sigmoid)):
+        N.check(lib.vp_dense_f32(ctx, ad.data_ptr(), K, wd.data_ptr(), kn, bd.data_ptr(), M, Nn, K, act,
+                                 out.data_ptr(), Nn, N.stream_ptr()), ctx)
+        torch.cuda.synchronize()
+        err = (out.double().cpu() - fn(ref)).abs().max().item()
+        assert err < 1e-5 * max(1.0, K ** 0.5), (act, err)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_se_scale_residual_and_cast(N, dtype):
+    tdt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    B, T, Cc = 3, 37, 128
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, T, Cc, generator=g).to(tdt)
+    r = torch.randn(B, T, 2 * Cc, generator=g).to(tdt)
+    s = torch.rand(B, Cc, generator=g)
+    out = torch.zeros(B, T, 3 * Cc, dtype=tdt, device='cuda')
+    lib, ctx = N.lib(), N.ctx(0)
+    xd, rd, sd = dev(x), dev(r), dev(s)
+    N.check(lib.vp_se_scale_residual(ctx, N.dtype_id(tdt), xd.data_ptr(), Cc, 0, sd.data_ptr(), rd.data_ptr(), 2 * Cc,
+                                     Cc, out.data_ptr(), 3 * Cc, 2 * Cc, B, T, Cc, N.stream_ptr()), ctx)
+    torch.cuda.synchronize()
+    ref = (x.float() * s[:, None, :] + r[:, :, Cc:].float()).to(tdt)
+    got = out.cpu()
+    assert torch.equal(got[:, :, 2 * Cc:].float(), ref.float()) or \
+        (got[:, :, 2 * Cc:].float() - ref.float()).abs().max().item() <= 2 ** -7 * ref.float().abs().max().item()
+    assert torch.all(got[:, :, :2 * Cc] == 0)
+    v = torch.randn(1001, generator=g)
+    y = torch.empty(1001, dtype=torch.bfloat16, device='cuda')
+    vd = dev(v)
+    N.check(lib.vp_cast_f32_bf16(ctx, vd.data_ptr(), y.data_ptr(), 1001, N.stream_ptr()), ctx)
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu(), v.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_asp_softmax_stats(N, dtype):
+    tdt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    B, T, Cc = 3, 61, 192
+    g = torch.Generator().manual_seed(4)
+    e = torch.randn(B, T, Cc, generator=g) * 3
+    x = (torch.randn(B, T, Cc, generator=g) + 2.0).to(tdt)
+    lib, ctx = N.lib(), N.ctx(0)
+    pooled = torch.empty(B, 2 * Cc, device='cuda')
+    ed, xd = dev(e), dev(x)
+    N.check(lib.vp_asp_softmax_stats(ctx, N.dtype_id(tdt), ed.data_ptr(), xd.data_ptr(), Cc, 0, B, T, Cc, 1e-12,
+                                     pooled.data_ptr(), N.stream_ptr()), ctx)
+    torch.cuda.synchronize()
+    a = torch.softmax(e.double(), dim=1)
+    xd64 = x.double()
+    mean = (a * xd64).sum(1)
+    std = torch.sqrt(((a * (xd64 - mean[:, None, :]) ** 2).sum(1)).clamp(min=1e-12))
+    got = pooled.double().cpu()
+    assert (got[:, :Cc] - mean).abs().max().item() < 1e-5
+    assert (got[:, Cc:] - std).abs().max().item() < 1e-4
+
+
+# --------------------------------------------------------------------------------------- head
+def test_cosine_head_and_aam_golden(N, golden_dir):
+    from ppvector.models.fc import SpeakerIdentification
+    from ppvector.loss.aamloss import AAMLoss
+    g = np.load(f'{golden_dir}/ecapa_ref_small.npz')
+    W = om.head_params(192, 2796, seed=int(g['head_seed']))
+    head = SpeakerIdentification(input_dim=192, num_speakers=2796, classifier_type='Cosine')
+    head.load_state_dict({'weight': W})
+    head.cuda()
+    out = head(dev(g['emb_eval']))
+    assert out['features'].shape == (2, 192)
+    assert np.max(np.abs(out['logits'].cpu().numpy() - g['logits'])) < 1e-6
+    labels = dev(g['labels'])
+    for (margin, ls, easy), ref in zip(g['loss_cfg'], g['losses']):
+        crit = AAMLoss(margin=0.2, scale=32, easy_margin=bool(easy), label_smoothing=float(ls))
+        crit.update(margin=float(margin))
+        loss = crit(out, labels)
+        assert abs(float(loss) - ref) < 2e-5 * max(1.0, abs(ref)), (margin, ls, easy, float(loss), ref)
+
+
+def test_aam_loss_random_batch_vs_oracle(N):
+    from ppvector.loss.aamloss import AAMLoss
+    g = torch.Generator().manual_seed(9)
+    B, D, Cn = 64, 192, 2796
+    emb = torch.randn(B, D, generator=g)
+    W = om.head_params(D, Cn, seed=3)
+    labels = torch.randint(0, Cn, (B,), generator=g)
+    logits = om.cosine_head(emb, W)
+    lib, ctx = N.lib(), N.ctx(0)
+    ws = torch.empty(lib.vp_cosine_aam_workspace_bytes(B, D, Cn), dtype=torch.uint8, device='cuda')
+    loss = torch.empty(1, device='cuda'); row = torch.empty(B, device='cuda'); lg = torch.empty(B, Cn, device='cuda')
+    ed, Wd, ld = dev(emb), dev(W), dev(labels)
+    for margin, ls in ((0.0, 0.0), (0.2, 0.0), (0.3, 0.1)):
+        N.check(lib.vp_cosine_aam_ce_fwd(ctx, ed.data_ptr(), Wd.data_ptr(), ld.data_ptr(), B, D, Cn, margin, 32.0, ls, 0,
+                                         loss.data_ptr(), lg.data_ptr(), row.data_ptr(), ws.data_ptr(), ws.numel(),
+                                         N.stream_ptr()), ctx)
+        torch.cuda.synchronize()
+        ref = om.aam_loss(logits.double(), labels, margin, 32.0, False, ls)
+        assert abs(float(loss) - float(ref)) < 2e-5 * float(ref)
+        assert (lg.cpu() - logits).abs().max().item() < 1e-6
+
+
+def test_cosine_scores(N):
+    from ppvector.metric.metrics import cosine_score_matrix
+    from oracle import scoring as osc
+    g = np.random.RandomState(0)
+    a, b = g.standard_normal((37, 192)).astype(np.float32), g.standard_normal((9, 192)).astype(np.float32)
+    got = cosine_score_matrix(dev(a), dev(b)).cpu().numpy()
+    assert np.max(np.abs(got - osc.cosine_matrix(a.astype(np.float64), b.astype(np.float64)))) < 1e-6

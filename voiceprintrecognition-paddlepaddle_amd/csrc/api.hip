@@ -1,0 +1,28 @@
+// Context management for libvpmi.
+#include "common.h"
+
+#include <stdlib.h>
+
+extern "C" {
+
+int vp_version(void) { return VPMI_VERSION; }
+
+vp_ctx* vp_create(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return nullptr;
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    vp_ctx* c = (vp_ctx*)calloc(1, sizeof(vp_ctx));
+    if (!c) return nullptr;
+    c->device = device;
+    return c;
+}
+
+void vp_destroy(vp_ctx* ctx) {
+    if (!ctx) return;
+    vp_fbank_release_tables(ctx);
+    free(ctx);
+}
+
+const char* vp_last_error(vp_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+}  // extern "C"

@@ -1,0 +1,84 @@
+// Shared host/device helpers for libvpmi (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/vpmi.h"
+
+struct vp_ctx {
+    int device;
+    char err[512];
+    // Fbank tables (built lazily per option set; tiny, read-only)
+    vp_fbank_opts fb_opts;
+    int fb_valid;
+    int fb_win, fb_shift, fb_nfft, fb_nmel, fb_nnz;
+    float* fb_window;     // [win]
+    float2* fb_twiddle;   // [nfft/2] e^{-2 pi i k / nfft}
+    int* fb_mel_start;    // [nmel + 1] CSR offsets into fb_mel_w
+    int* fb_mel_bin0;     // [nmel] first FFT bin of each filter
+    float* fb_mel_w;      // [nnz]
+};
+
+#define VP_FAIL(ctx, code, ...)                                      \
+    do {                                                             \
+        if (ctx) snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__); \
+        return (code);                                               \
+    } while (0)
+
+#define VP_HIP(ctx, call)                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) VP_FAIL(ctx, VP_EHIP, "%s: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define VP_LAUNCH_CHECK(ctx, name)                                                            \
+    do {                                                                                      \
+        hipError_t e_ = hipGetLastError();                                                    \
+        if (e_ != hipSuccess) VP_FAIL(ctx, VP_EHIP, "launch %s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline size_t vp_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <typename T> struct vp_elem;
+template <> struct vp_elem<float> { static constexpr int id = VP_F32; };
+template <> struct vp_elem<bf16_t> { static constexpr int id = VP_BF16; };
+
+__device__ __forceinline__ float vp_to_f32(float v) { return v; }
+__device__ __forceinline__ float vp_to_f32(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T vp_from_f32(float v);
+template <> __device__ __forceinline__ float vp_from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t vp_from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+__device__ __forceinline__ float vp_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float vp_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+static inline size_t vp_dtype_size(int dt) { return dt == VP_BF16 ? 2 : 4; }
+
+// M-tile of the conv GEMM: the partial time-sum arrays are indexed by it
+#define VP_CONV_BM 128
+
+// internal launchers shared between translation units
+int vp_dense_f32_ex(vp_ctx* ctx, const float* a, int lda, const float* w, int w_is_kn, const float* bias,
+                    const float* rowscale, const float* colscale, int M, int N, int K, int act, float* out,
+                    int ldo, hipStream_t st);
+int vp_asp_softmax_stats_ex(vp_ctx* ctx, int dtype, const float* logits, const void* x, int ldx, int xoff,
+                            const float* center, int ldc, int B, int T, int C, float eps, float* pooled, hipStream_t st);
+int vp_row_inv_norm(vp_ctx* ctx, const float* x, int rows, int D, int ld, float eps, float* inv, hipStream_t st);
+
+// kernels' host launchers (defined in the .hip files)
+int vp_fbank_release_tables(vp_ctx* ctx);

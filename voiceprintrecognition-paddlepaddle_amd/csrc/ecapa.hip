@@ -1,0 +1,263 @@
+// Whole-backbone forward (eval mode) for ECAPA-TDNN and TDNN: the launch graph over the kernels in
+// conv_gemm.hip / small_ops.hip.  Host-only code; everything it enqueues is asynchronous on the
+// caller's stream and touches only the caller's workspace, so the sequence is hipGraph-capturable.
+//
+// Reference graphs: EcapaTdnn.forward (ppvector/models/ecapa_tdnn.py:245-276) with SERes2NetBlock
+// (:129-142), Res2NetBlock (:36-47), SEBlock (:69-82), AttentiveStatisticsPooling (pooling.py:86-125),
+// asp_bn + fc (:271-274); TDNN.forward (ppvector/models/tdnn.py:46-68).
+// What never materialises compared with the reference: the (B,F,T) transpose, reflect-padded
+// copies, torch.chunk / concat copies (slices of one (B*T, n*C) buffer are addressed in place),
+// the x_i + y_{i-1} temporaries' extra pass (written by the producing conv), the (B, 3C, T)
+// global-context concat of ASP (its mean/std columns collapse to a per-utterance bias).
+#include "common.h"
+
+namespace {
+
+struct Carver {
+    char* base; size_t off; size_t cap;
+    Carver(void* p, size_t c) : base((char*)p), off(0), cap(c) {}
+    void* take(size_t bytes) {
+        size_t o = off;
+        off += vp_align_up(bytes ? bytes : 1, 256);
+        return base ? (void*)(base + o) : nullptr;
+    }
+};
+
+void tdnn_desc(vp_conv1d_desc& d, const vp_tdnn_layer& L, int dtype, int B, int T_in, int T_out, int pad_mode) {
+    memset(&d, 0, sizeof(d));
+    d.dtype_in = dtype; d.dtype_out = dtype; d.B = B; d.T_in = T_in; d.T_out = T_out;
+    d.Cin = L.cin; d.Cout = L.cout; d.KW = L.kw; d.dilation = L.dil; d.stride = 1;
+    d.pad_mode = pad_mode;
+    d.pad_left = pad_mode == VP_PAD_NONE ? 0 : L.dil * (L.kw - 1) / 2;
+    d.w = L.w; d.bias = L.bias; d.act = VP_ACT_RELU; d.bn_scale = L.bn_scale; d.bn_shift = L.bn_shift;
+}
+
+struct AspBufs { void* h; float* e; float* psum; float* psumsq; float* stats; float* rowbias; float* pooled; };
+
+// x: (B*T, C) activations already written with psum/psumsq partials (shift = the producing layer's
+// bn_shift or NULL).  Leaves pooled (B, 2C) = [mean | std].
+int run_asp(vp_ctx* ctx, const vp_asp_weights& A, int dtype, const void* x, int ldx, const float* shift,
+            int B, int T, const AspBufs& w, hipStream_t st) {
+    const int C = A.C;
+    int rc = vp_moments_finalize(ctx, w.psum, w.psumsq, shift, B, T, C, 1e-12f, 1, w.stats, st);
+    if (rc) return rc;
+    if (A.w_ctx) {
+        rc = vp_dense_f32_ex(ctx, w.stats, 2 * C, A.w_ctx, 0, nullptr, nullptr, nullptr, B, A.att, 2 * C, VP_ACT_NONE,
+                             w.rowbias, A.att, st);
+        if (rc) return rc;
+    }
+    vp_conv1d_desc d;
+    tdnn_desc(d, A.tdnn, dtype, B, T, T, VP_PAD_REFLECT);
+    d.x = x; d.ldx = ldx; d.xoff = 0; d.rowbias = A.w_ctx ? w.rowbias : nullptr; d.act2 = VP_ACT_TANH;
+    d.y = w.h; d.ldy = A.att; d.yoff = 0;
+    rc = vp_conv1d_fwd(ctx, &d, st);
+    if (rc) return rc;
+    memset(&d, 0, sizeof(d));
+    d.dtype_in = dtype; d.dtype_out = VP_F32; d.B = B; d.T_in = T; d.T_out = T; d.Cin = A.att; d.Cout = C;
+    d.KW = 1; d.dilation = 1; d.stride = 1; d.pad_mode = VP_PAD_REFLECT; d.pad_left = 0;
+    d.x = w.h; d.ldx = A.att; d.w = A.conv_w; d.bias = A.conv_b; d.y = w.e; d.ldy = C;
+    rc = vp_conv1d_fwd(ctx, &d, st);
+    if (rc) return rc;
+    return vp_asp_softmax_stats_ex(ctx, dtype, w.e, x, ldx, 0, w.stats, 2 * C, B, T, C, 1e-12f, w.pooled, st);
+}
+
+struct EcapaPlan {
+    void *cat0, *cat, *t1, *r2, *t2, *tmpA, *tmpB, *mfa, *h;
+    float *e, *psum, *psumsq, *stats, *se_h, *se_s, *rowbias, *pooled;
+    size_t total;
+};
+
+int plan_ecapa(const vp_ecapa_weights* w, int B, int T, void* ws, size_t cap, EcapaPlan& p) {
+    const size_t es = vp_dtype_size(w->dtype);
+    const size_t M = (size_t)B * T;
+    const int C = w->block0.cout, Cm = w->mfa.cout, nb = w->n_blocks;
+    const int width = C / w->res2_scale;
+    const int cmax = C > Cm ? C : Cm;
+    const size_t nps = (size_t)vp_conv1d_tiles_m(B, T) * vp_conv1d_nseg(T) * cmax * sizeof(float);
+    Carver c(ws, cap);
+    p.cat0 = c.take(M * C * es);
+    p.cat = c.take(M * (size_t)nb * C * es);
+    p.t1 = c.take(M * C * es);
+    p.r2 = c.take(M * C * es);
+    p.t2 = c.take(M * C * es);
+    p.tmpA = c.take(M * width * es);
+    p.tmpB = c.take(M * width * es);
+    p.mfa = c.take(M * Cm * es);
+    p.h = c.take(M * w->asp.att * es);
+    p.e = (float*)c.take(M * Cm * sizeof(float));
+    p.psum = (float*)c.take(nps);
+    p.psumsq = (float*)c.take(nps);
+    p.stats = (float*)c.take((size_t)B * 2 * cmax * sizeof(float));
+    p.se_h = (float*)c.take((size_t)B * w->se_ch * sizeof(float));
+    p.se_s = (float*)c.take((size_t)B * C * sizeof(float));
+    p.rowbias = (float*)c.take((size_t)B * w->asp.att * sizeof(float));
+    p.pooled = (float*)c.take((size_t)B * 2 * Cm * sizeof(float));
+    p.total = c.off;
+    return VP_OK;
+}
+
+int check_ecapa(vp_ctx* ctx, const vp_ecapa_weights* w) {
+    if (w->dtype != VP_F32 && w->dtype != VP_BF16) VP_FAIL(ctx, VP_EINVAL, "ecapa: bad dtype");
+    if (w->n_blocks < 1 || w->n_blocks > VP_MAX_SE_BLOCKS) VP_FAIL(ctx, VP_EINVAL, "ecapa: n_blocks %d", w->n_blocks);
+    if (w->res2_scale < 2 || w->res2_scale - 1 > VP_MAX_RES2) VP_FAIL(ctx, VP_EINVAL, "ecapa: res2_scale %d", w->res2_scale);
+    const int C = w->block0.cout;
+    const int epc = w->dtype == VP_BF16 ? 8 : 4;
+    if (C % w->res2_scale || (C / w->res2_scale) % epc) VP_FAIL(ctx, VP_EINVAL, "ecapa: channels %d not divisible", C);
+    for (int i = 0; i < w->n_blocks; ++i) {
+        const vp_se_res2_block& b = w->blk[i];
+        if (b.tdnn1.cin != C || b.tdnn1.cout != C || b.tdnn2.cin != C || b.tdnn2.cout != C)
+            VP_FAIL(ctx, VP_EUNSUP, "ecapa: SE-Res2 blocks must keep %d channels (shortcut conv not built)", C);
+    }
+    if (w->mfa.cin != w->n_blocks * C) VP_FAIL(ctx, VP_EINVAL, "ecapa: mfa.cin %d != %d", w->mfa.cin, w->n_blocks * C);
+    if (w->asp.C != w->mfa.cout) VP_FAIL(ctx, VP_EINVAL, "ecapa: asp.C mismatch");
+    return VP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t vp_ecapa_workspace_bytes(const vp_ecapa_weights* w, int B, int T) {
+    if (!w || B <= 0 || T <= 0) return 0;
+    EcapaPlan p;
+    plan_ecapa(w, B, T, nullptr, 0, p);
+    return p.total;
+}
+
+int vp_ecapa_fwd(vp_ctx* ctx, const vp_ecapa_weights* w, const void* feats, int B, int T, float* emb,
+                 void* ws, size_t ws_bytes, vp_stream stream) {
+    if (!ctx || !w || !feats || !emb || B <= 0 || T <= 0) VP_FAIL(ctx, VP_EINVAL, "ecapa: bad arguments");
+    int rc = check_ecapa(ctx, w);
+    if (rc) return rc;
+    EcapaPlan p;
+    plan_ecapa(w, B, T, ws, ws_bytes, p);
+    if (!ws || ws_bytes < p.total) VP_FAIL(ctx, VP_EWORKSPACE, "ecapa: workspace %zu < %zu", ws_bytes, p.total);
+    hipStream_t st = (hipStream_t)stream;
+    const int dt = w->dtype;
+    const int C = w->block0.cout, Cm = w->mfa.cout, nb = w->n_blocks, sc = w->res2_scale;
+    const int width = C / sc, ldcat = nb * C;
+    vp_conv1d_desc d;
+
+    // blocks[0]: TDNNBlock(F -> C, k5) on the (B, T, F) features
+    tdnn_desc(d, w->block0, dt, B, T, T, VP_PAD_REFLECT);
+    d.x = feats; d.ldx = w->feat_dim; d.y = p.cat0; d.ldy = C;
+    if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+
+    const void* xin = p.cat0;
+    int ld_in = C, off_in = 0;
+    for (int i = 0; i < nb; ++i) {
+        const vp_se_res2_block& blk = w->blk[i];
+        // tdnn1 (1x1)
+        tdnn_desc(d, blk.tdnn1, dt, B, T, T, VP_PAD_REFLECT);
+        d.x = xin; d.ldx = ld_in; d.xoff = off_in; d.y = p.t1; d.ldy = C;
+        if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+        // Res2Net chain: y_j = f_j(x_j + y_{j-1}); conv j writes y_j into r2 slice j and
+        // (y_j + x_{j+1}) into the ping-pong input of conv j+1
+        void* tin = nullptr;
+        void* tout = p.tmpA;
+        for (int j = 1; j < sc; ++j) {
+            tdnn_desc(d, blk.res2[j - 1], dt, B, T, T, VP_PAD_REFLECT);
+            if (j == 1) { d.x = p.t1; d.ldx = C; d.xoff = width; }
+            else { d.x = tin; d.ldx = width; d.xoff = 0; }
+            d.y = p.r2; d.ldy = C; d.yoff = j * width;
+            if (j + 1 < sc) {
+                d.add_in = p.t1; d.ld_add = C; d.add_off = (j + 1) * width;
+                d.aux = tout; d.ld_aux = width; d.aux_off = 0;
+            }
+            if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+            tin = tout;
+            tout = (tout == p.tmpA) ? p.tmpB : p.tmpA;
+        }
+        // tdnn2 (1x1) over concat(y_0 = x_0 from t1, y_1.. from r2), with the SE time sums fused
+        tdnn_desc(d, blk.tdnn2, dt, B, T, T, VP_PAD_REFLECT);
+        d.x = p.r2; d.ldx = C; d.xoff = 0; d.x2 = p.t1; d.ldx2 = C; d.x2off = 0; d.xsplit = width;
+        d.y = p.t2; d.ldy = C; d.psum = p.psum;
+        if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+        // SE: mean over time -> 1x1 -> ReLU -> 1x1 -> sigmoid
+        if ((rc = vp_moments_finalize(ctx, p.psum, nullptr, blk.tdnn2.bn_shift, B, T, C, 0.f, 0, p.stats, st))) return rc;
+        if ((rc = vp_dense_f32_ex(ctx, p.stats, C, blk.se_w1, 0, blk.se_b1, nullptr, nullptr, B, w->se_ch, C, VP_ACT_RELU,
+                                  p.se_h, w->se_ch, st))) return rc;
+        if ((rc = vp_dense_f32_ex(ctx, p.se_h, w->se_ch, blk.se_w2, 0, blk.se_b2, nullptr, nullptr, B, C, w->se_ch,
+                                  VP_ACT_SIGMOID, p.se_s, C, st))) return rc;
+        // gate + residual, written straight into slice i of the MFA input
+        if ((rc = vp_se_scale_residual(ctx, dt, p.t2, C, 0, p.se_s, xin, ld_in, off_in, p.cat, ldcat, i * C, B, T, C, st)))
+            return rc;
+        xin = p.cat; ld_in = ldcat; off_in = i * C;
+    }
+    // MFA (1x1 over the concat), with the global-context time moments fused
+    tdnn_desc(d, w->mfa, dt, B, T, T, VP_PAD_REFLECT);
+    d.x = p.cat; d.ldx = ldcat; d.y = p.mfa; d.ldy = Cm; d.psum = p.psum; d.psumsq = p.psumsq;
+    if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+    AspBufs ab{p.h, p.e, p.psum, p.psumsq, p.stats, p.rowbias, p.pooled};
+    if ((rc = run_asp(ctx, w->asp, dt, p.mfa, Cm, w->mfa.bn_shift, B, T, ab, st))) return rc;
+    // asp_bn (folded) + fc
+    return vp_dense_f32_ex(ctx, p.pooled, 2 * Cm, w->fc_w, 0, w->fc_b, nullptr, nullptr, B, w->embd_dim, 2 * Cm,
+                           VP_ACT_NONE, emb, w->embd_dim, st);
+}
+
+// ------------------------------------------------------------------------------------- TDNN
+static void tdnn_T(const vp_tdnn_weights* w, int T, int Ts[6]) {
+    Ts[0] = T;
+    for (int i = 0; i < 5; ++i) Ts[i + 1] = Ts[i] - w->td[i].dil * (w->td[i].kw - 1);
+}
+
+struct TdnnPlan { void* a; void* b; void* h; float *e, *psum, *psumsq, *stats, *rowbias, *pooled; size_t total; };
+
+static void plan_tdnn(const vp_tdnn_weights* w, int B, int T, void* ws, size_t cap, TdnnPlan& p) {
+    const size_t es = vp_dtype_size(w->dtype);
+    const int C = w->channels;
+    int Ts[6];
+    tdnn_T(w, T, Ts);
+    const int T1 = Ts[1] > 0 ? Ts[1] : 1, T5 = Ts[5] > 0 ? Ts[5] : 1;
+    Carver c(ws, cap);
+    p.a = c.take((size_t)B * T1 * C * es);
+    p.b = c.take((size_t)B * T1 * C * es);
+    p.h = c.take((size_t)B * T5 * w->asp.att * es);
+    p.e = (float*)c.take((size_t)B * T5 * C * sizeof(float));
+    const size_t nps = (size_t)vp_conv1d_tiles_m(B, T5) * vp_conv1d_nseg(T5) * C * sizeof(float);
+    p.psum = (float*)c.take(nps);
+    p.psumsq = (float*)c.take(nps);
+    p.stats = (float*)c.take((size_t)B * 2 * C * sizeof(float));
+    p.rowbias = (float*)c.take((size_t)B * w->asp.att * sizeof(float));
+    p.pooled = (float*)c.take((size_t)B * 2 * C * sizeof(float));
+    p.total = c.off;
+}
+
+size_t vp_tdnn_workspace_bytes(const vp_tdnn_weights* w, int B, int T) {
+    if (!w || B <= 0 || T <= 0) return 0;
+    TdnnPlan p;
+    plan_tdnn(w, B, T, nullptr, 0, p);
+    return p.total;
+}
+
+int vp_tdnn_fwd(vp_ctx* ctx, const vp_tdnn_weights* w, const void* feats, int B, int T, float* emb,
+                void* ws, size_t ws_bytes, vp_stream stream) {
+    if (!ctx || !w || !feats || !emb || B <= 0 || T <= 0) VP_FAIL(ctx, VP_EINVAL, "tdnn: bad arguments");
+    if (w->dtype != VP_F32 && w->dtype != VP_BF16) VP_FAIL(ctx, VP_EINVAL, "tdnn: bad dtype");
+    int Ts[6];
+    tdnn_T(w, T, Ts);
+    if (Ts[5] < 1) VP_FAIL(ctx, VP_EINVAL, "tdnn: %d frames are fewer than the receptive field", T);
+    TdnnPlan p;
+    plan_tdnn(w, B, T, ws, ws_bytes, p);
+    if (!ws || ws_bytes < p.total) VP_FAIL(ctx, VP_EWORKSPACE, "tdnn: workspace %zu < %zu", ws_bytes, p.total);
+    hipStream_t st = (hipStream_t)stream;
+    const int C = w->channels;
+    int rc;
+    vp_conv1d_desc d;
+    const void* x = feats;
+    int ldx = w->feat_dim;
+    void* outs[5] = {p.a, p.b, p.a, p.b, p.a};
+    for (int i = 0; i < 5; ++i) {
+        tdnn_desc(d, w->td[i], w->dtype, B, Ts[i], Ts[i + 1], VP_PAD_NONE);
+        d.x = x; d.ldx = ldx; d.y = outs[i]; d.ldy = C;
+        if (i == 4) { d.psum = p.psum; d.psumsq = p.psumsq; }
+        if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+        x = outs[i]; ldx = C;
+    }
+    AspBufs ab{p.h, p.e, p.psum, p.psumsq, p.stats, p.rowbias, p.pooled};
+    if ((rc = run_asp(ctx, w->asp, w->dtype, x, C, w->td[4].bn_shift, B, Ts[5], ab, st))) return rc;
+    return vp_dense_f32_ex(ctx, p.pooled, 2 * C, w->lin_w, 0, w->lin_b, nullptr, nullptr, B, w->embd_dim, 2 * C,
+                           VP_ACT_NONE, emb, w->embd_dim, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,345 @@
+// Kaldi Fbank + CMN on gfx950.
+//
+// Replaces AudioFeaturizer.forward (ppvector/data_utils/featurizer.py:33-60) for feature_method
+// 'Fbank' (KaldiFbank.forward, featurizer.py:88-101 -> paddleaudio.compliance.kaldi.fbank).
+//
+// Bound: HBM: algorithmic bytes per utterance = 4*L (waveform in) + 4*T*n_mels
+// (features out) = 287,360 B for 3 s @ 16 kHz, 80 mels.
+//
+// Kernel 1 (fbank_frames): one workgroup = 4 waves = a tile of FRAMES_PER_WG consecutive frames of
+//   one utterance; each wave owns one frame at a time: coalesced load of the 400-sample window
+//   (overlapping windows are L1/L2 hits, HBM sees each sample once), DC removal by a wave
+//   reduction, pre-emphasis + Povey window on the fly, a 256-point complex Stockham radix-4 FFT of
+//   the even/odd-packed frame in LDS (4 stages, one radix-4 butterfly per lane per stage), real-FFT
+//   unpack to the 256 power bins, sparse triangular mel bank (CSR, <= ~18 taps per filter), log.
+//   Writes raw log-mel (B,T,F) and per-tile column sums for the CMN.
+// Kernel 2 (fbank_cmn): subtracts the per-utterance time mean, applies the length mask, optionally
+//   emits the bf16 copy the bf16 network consumes.  The feature tensor (24 MB at B=256) is
+//   L2/Infinity-Cache resident between the two kernels.
+#include "common.h"
+
+#include <math.h>
+#include <vector>
+
+namespace {
+
+constexpr int FB_WAVES = 4;
+constexpr int FRAMES_PER_WG = 16;
+constexpr int FB_MAX_WIN = 512;
+constexpr int FB_NFFT = 512;          // only the 512-point (25 ms @ 16 kHz) geometry is built
+constexpr int FB_NC = FB_NFFT / 2;    // complex FFT length
+constexpr int FB_MAX_MEL = 128;
+constexpr int FB_MAX_NNZ = 1024;
+
+struct FbankArgs {
+    const float* wav;
+    float* out;
+    float* psum;       // [B][tiles][n_mels]
+    const float* window;
+    const float2* tw;  // [512] e^{-2 pi i k/512}
+    const int* mel_start;
+    const int* mel_bin0;
+    const float* mel_w;
+    int B, L, T, tiles, win, shift, n_mels, nnz;
+    float preemph, log_floor;
+    int remove_dc;
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+__global__ __launch_bounds__(FB_WAVES * 64) void fbank_frames_kernel(FbankArgs a) {
+    __shared__ float2 s_tw[FB_NFFT];
+    __shared__ float s_win[FB_MAX_WIN];
+    __shared__ float s_melw[FB_MAX_NNZ];
+    __shared__ int s_mstart[FB_MAX_MEL + 1];
+    __shared__ int s_mbin0[FB_MAX_MEL];
+    __shared__ float s_frame[FB_WAVES][FB_MAX_WIN];
+    __shared__ float2 s_buf[FB_WAVES][2][FB_NC];
+    __shared__ float s_pow[FB_WAVES][FB_NC];
+    __shared__ float s_red[FB_WAVES][FB_MAX_MEL];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int tile = blockIdx.x;
+    const int b = blockIdx.y;
+
+    for (int i = tid; i < FB_NFFT; i += FB_WAVES * 64) s_tw[i] = a.tw[i];
+    for (int i = tid; i < a.win; i += FB_WAVES * 64) s_win[i] = a.window[i];
+    for (int i = tid; i < a.nnz; i += FB_WAVES * 64) s_melw[i] = a.mel_w[i];
+    for (int i = tid; i <= a.n_mels; i += FB_WAVES * 64) s_mstart[i] = a.mel_start[i];
+    for (int i = tid; i < a.n_mels; i += FB_WAVES * 64) s_mbin0[i] = a.mel_bin0[i];
+    __syncthreads();
+
+    const float* wav = a.wav + (size_t)b * a.L;
+    float acc0 = 0.f, acc1 = 0.f;   // column sums for mel bins lane and lane+64
+    float* fr = s_frame[wv];
+
+    for (int fi = wv; fi < FRAMES_PER_WG; fi += FB_WAVES) {
+        const int t = tile * FRAMES_PER_WG + fi;
+        if (t >= a.T) break;                         // wave-uniform
+        const float* src = wav + (size_t)t * a.shift;
+        float part = 0.f;
+        for (int i = lane; i < a.win; i += 64) {
+            float v = src[i];
+            fr[i] = v;
+            part += v;
+        }
+        float mean = a.remove_dc ? vp_wave_sum(part) / (float)a.win : 0.f;
+        __builtin_amdgcn_wave_barrier();
+        // even/odd pack: z[n] = x[2n] + i x[2n+1], zero beyond the window
+        float2* d0 = s_buf[wv][0];
+        float2* d1 = s_buf[wv][1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = lane + 64 * r;
+            float re = 0.f, im = 0.f;
+            const int i0 = 2 * n, i1 = 2 * n + 1;
+            if (i0 < a.win) {
+                float c = fr[i0] - mean;
+                float p = fr[i0 > 0 ? i0 - 1 : 0] - mean;
+                re = (c - a.preemph * p) * s_win[i0];
+            }
+            if (i1 < a.win) {
+                float c = fr[i1] - mean;
+                float p = fr[i1 - 1] - mean;
+                im = (c - a.preemph * p) * s_win[i1];
+            }
+            d0[n] = make_float2(re, im);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // 256-point complex FFT: Stockham radix-4, Ns = 1, 4, 16, 64; thread j = lane
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int Ns = 1 << (2 * s);
+            const int jm = lane & (Ns - 1);
+            const int twstep = (FB_NFFT / 4) >> (2 * s);     // 512 / (4 * Ns)
+            float2 v0 = d0[lane];
+            float2 v1 = d0[lane + 64];
+            float2 v2 = d0[lane + 128];
+            float2 v3 = d0[lane + 192];
+            v1 = cmul(v1, s_tw[(jm * twstep) & (FB_NFFT - 1)]);
+            v2 = cmul(v2, s_tw[(2 * jm * twstep) & (FB_NFFT - 1)]);
+            v3 = cmul(v3, s_tw[(3 * jm * twstep) & (FB_NFFT - 1)]);
+            // radix-4 butterfly, forward (W4 = -i)
+            float2 s02 = make_float2(v0.x + v2.x, v0.y + v2.y);
+            float2 d02 = make_float2(v0.x - v2.x, v0.y - v2.y);
+            float2 s13 = make_float2(v1.x + v3.x, v1.y + v3.y);
+            float2 d13 = make_float2(v1.x - v3.x, v1.y - v3.y);
+            float2 o0 = make_float2(s02.x + s13.x, s02.y + s13.y);
+            float2 o2 = make_float2(s02.x - s13.x, s02.y - s13.y);
+            float2 o1 = make_float2(d02.x + d13.y, d02.y - d13.x);   // d02 - i*d13
+            float2 o3 = make_float2(d02.x - d13.y, d02.y + d13.x);   // d02 + i*d13
+            const int idx = ((lane >> (2 * s)) << (2 * s + 2)) + jm;  // (j/Ns)*Ns*4 + j%Ns
+            d1[idx] = o0;
+            d1[idx + Ns] = o1;
+            d1[idx + 2 * Ns] = o2;
+            d1[idx + 3 * Ns] = o3;
+            __builtin_amdgcn_wave_barrier();
+            float2* tmp = d0; d0 = d1; d1 = tmp;
+        }
+        // real-FFT unpack -> power bins 0..255 (Nyquist bin has zero mel weight in Kaldi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = lane + 64 * r;
+            float2 zk = d0[k];
+            float2 zn = d0[(FB_NC - k) & (FB_NC - 1)];
+            float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+            float2 o = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));  // (zk - conj(zn)) / (2i)
+            float2 wo = cmul(o, s_tw[k]);
+            float xr = e.x + wo.x, xi = e.y + wo.y;
+            s_pow[wv][k] = xr * xr + xi * xi;
+        }
+        __builtin_amdgcn_wave_barrier();
+        float* orow = a.out + ((size_t)b * a.T + t) * a.n_mels;
+        for (int m = lane, it = 0; m < a.n_mels; m += 64, ++it) {
+            const int s0 = s_mstart[m], s1 = s_mstart[m + 1], k0 = s_mbin0[m];
+            float e = 0.f;
+            for (int q = s0; q < s1; ++q) e += s_melw[q] * s_pow[wv][k0 + (q - s0)];
+            float v = logf(fmaxf(e, a.log_floor));
+            orow[m] = v;
+            if (it == 0) acc0 += v; else acc1 += v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // per-tile column sums (deterministic: fixed wave order)
+    s_red[wv][lane] = acc0;
+    s_red[wv][lane + 64] = acc1;
+    __syncthreads();
+    if (tid < a.n_mels) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < FB_WAVES; ++w) s += s_red[w][tid];
+        a.psum[((size_t)b * a.tiles + tile) * a.n_mels + tid] = s;
+    }
+}
+
+struct CmnArgs {
+    float* out;
+    bf16_t* out_bf16;
+    const float* psum;
+    const float* lens_ratio;
+    int B, T, tiles, n_mels;
+};
+
+__global__ __launch_bounds__(256) void fbank_cmn_kernel(CmnArgs a) {
+    __shared__ float s_mean[FB_MAX_MEL];
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    if (tid < a.n_mels) {
+        float s = 0.f;
+        for (int i = 0; i < a.tiles; ++i) s += a.psum[((size_t)b * a.tiles + i) * a.n_mels + tid];
+        s_mean[tid] = s / (float)a.T;
+    }
+    __syncthreads();
+    int valid = a.T;
+    if (a.lens_ratio) valid = (int)(a.lens_ratio[b] * (float)a.T);      // astype(int32): truncation
+    const int per_blk = (a.T * a.n_mels + gridDim.x - 1) / gridDim.x;
+    const int e0 = blockIdx.x * per_blk;
+    const int e1 = min(e0 + per_blk, a.T * a.n_mels);
+    float* o = a.out + (size_t)b * a.T * a.n_mels;
+    bf16_t* ob = a.out_bf16 ? a.out_bf16 + (size_t)b * a.T * a.n_mels : nullptr;
+    for (int e = e0 + tid; e < e1; e += 256) {
+        const int t = e / a.n_mels;
+        const int m = e - t * a.n_mels;
+        float v = (t < valid) ? (o[e] - s_mean[m]) : 0.f;
+        o[e] = v;
+        if (ob) ob[e] = (bf16_t)v;
+    }
+}
+
+double mel_of(double f) { return 1127.0 * log(1.0 + f / 700.0); }
+
+bool same_opts(const vp_fbank_opts& x, const vp_fbank_opts& y) { return memcmp(&x, &y, sizeof(x)) == 0; }
+
+int build_tables(vp_ctx* ctx, const vp_fbank_opts* o) {
+    if (ctx->fb_valid && same_opts(ctx->fb_opts, *o)) return VP_OK;
+    vp_fbank_release_tables(ctx);
+    const int win = (int)(o->sample_rate * o->frame_length_ms * 0.001f);
+    const int shift = (int)(o->sample_rate * o->frame_shift_ms * 0.001f);
+    int nfft = 1;
+    while (nfft < win) nfft <<= 1;
+    if (nfft != FB_NFFT || win > FB_MAX_WIN || win < 2)
+        VP_FAIL(ctx, VP_EUNSUP, "fbank: only a 512-point FFT geometry is built (window %d -> nfft %d)", win, nfft);
+    if (o->n_mels < 1 || o->n_mels > FB_MAX_MEL) VP_FAIL(ctx, VP_EUNSUP, "fbank: n_mels %d out of range", o->n_mels);
+    std::vector<float> window(win);
+    for (int i = 0; i < win; ++i)
+        window[i] = (float)pow(0.5 - 0.5 * cos(2.0 * M_PI * i / (win - 1)), 0.85);   // povey
+    std::vector<float2> tw(nfft);
+    for (int k = 0; k < nfft; ++k) {
+        double ang = -2.0 * M_PI * k / nfft;
+        tw[k] = make_float2((float)cos(ang), (float)sin(ang));
+    }
+    // Kaldi mel banks over bins [0, nfft/2); Nyquist column is zero
+    const int nbins = nfft / 2;
+    const double nyq = 0.5 * o->sample_rate;
+    double hi = o->high_freq;
+    if (hi <= 0.0) hi += nyq;
+    const double bin_w = (double)o->sample_rate / nfft;
+    const double mlo = mel_of(o->low_freq), mhi = mel_of(hi);
+    const double delta = (mhi - mlo) / (o->n_mels + 1);
+    std::vector<int> start(o->n_mels + 1), bin0(o->n_mels);
+    std::vector<float> wts;
+    for (int m = 0; m < o->n_mels; ++m) {
+        const double l = mlo + m * delta, c = l + delta, r = l + 2.0 * delta;
+        start[m] = (int)wts.size();
+        int first = -1, last = -2;
+        std::vector<float> row(nbins, 0.f);
+        for (int k = 0; k < nbins; ++k) {
+            const double x = mel_of(bin_w * k);
+            const double up = (x - l) / (c - l), down = (r - x) / (r - c);
+            const double w = fmax(0.0, fmin(up, down));
+            row[k] = (float)w;
+            if (w > 0.0) { if (first < 0) first = k; last = k; }
+        }
+        if (first < 0) { first = 0; last = -1; }
+        bin0[m] = first;
+        for (int k = first; k <= last; ++k) wts.push_back(row[k]);
+    }
+    start[o->n_mels] = (int)wts.size();
+    if (wts.size() > FB_MAX_NNZ) VP_FAIL(ctx, VP_EUNSUP, "fbank: mel bank too dense (%zu taps)", wts.size());
+    if (wts.empty()) wts.push_back(0.f);
+    VP_HIP(ctx, hipMalloc(&ctx->fb_window, win * sizeof(float)));
+    VP_HIP(ctx, hipMalloc(&ctx->fb_twiddle, nfft * sizeof(float2)));
+    VP_HIP(ctx, hipMalloc(&ctx->fb_mel_start, (o->n_mels + 1) * sizeof(int)));
+    VP_HIP(ctx, hipMalloc(&ctx->fb_mel_bin0, o->n_mels * sizeof(int)));
+    VP_HIP(ctx, hipMalloc(&ctx->fb_mel_w, wts.size() * sizeof(float)));
+    VP_HIP(ctx, hipMemcpy(ctx->fb_window, window.data(), win * sizeof(float), hipMemcpyHostToDevice));
+    VP_HIP(ctx, hipMemcpy(ctx->fb_twiddle, tw.data(), nfft * sizeof(float2), hipMemcpyHostToDevice));
+    VP_HIP(ctx, hipMemcpy(ctx->fb_mel_start, start.data(), (o->n_mels + 1) * sizeof(int), hipMemcpyHostToDevice));
+    VP_HIP(ctx, hipMemcpy(ctx->fb_mel_bin0, bin0.data(), o->n_mels * sizeof(int), hipMemcpyHostToDevice));
+    VP_HIP(ctx, hipMemcpy(ctx->fb_mel_w, wts.data(), wts.size() * sizeof(float), hipMemcpyHostToDevice));
+    ctx->fb_opts = *o;
+    ctx->fb_win = win; ctx->fb_shift = shift; ctx->fb_nfft = nfft; ctx->fb_nmel = o->n_mels;
+    ctx->fb_nnz = (int)wts.size();
+    ctx->fb_valid = 1;
+    return VP_OK;
+}
+
+}  // namespace
+
+int vp_fbank_release_tables(vp_ctx* ctx) {
+    if (!ctx) return VP_OK;
+    if (ctx->fb_window) (void)hipFree(ctx->fb_window);
+    if (ctx->fb_twiddle) (void)hipFree(ctx->fb_twiddle);
+    if (ctx->fb_mel_start) (void)hipFree(ctx->fb_mel_start);
+    if (ctx->fb_mel_bin0) (void)hipFree(ctx->fb_mel_bin0);
+    if (ctx->fb_mel_w) (void)hipFree(ctx->fb_mel_w);
+    ctx->fb_window = nullptr; ctx->fb_twiddle = nullptr; ctx->fb_mel_start = nullptr;
+    ctx->fb_mel_bin0 = nullptr; ctx->fb_mel_w = nullptr; ctx->fb_valid = 0;
+    return VP_OK;
+}
+
+extern "C" {
+
+void vp_fbank_default_opts(vp_fbank_opts* o) {
+    o->sample_rate = 16000; o->n_mels = 23; o->frame_length_ms = 25.f; o->frame_shift_ms = 10.f;
+    o->preemph = 0.97f; o->remove_dc = 1; o->low_freq = 20.f; o->high_freq = 0.f; o->log_floor = 1e-7f;
+}
+
+int vp_fbank_num_frames(const vp_fbank_opts* o, int n_samples) {
+    const int win = (int)(o->sample_rate * o->frame_length_ms * 0.001f);
+    const int shift = (int)(o->sample_rate * o->frame_shift_ms * 0.001f);
+    if (n_samples < win || shift <= 0) return 0;
+    return 1 + (n_samples - win) / shift;
+}
+
+size_t vp_fbank_workspace_bytes(const vp_fbank_opts* o, int B, int L) {
+    const int T = vp_fbank_num_frames(o, L);
+    const int tiles = (T + FRAMES_PER_WG - 1) / FRAMES_PER_WG;
+    return vp_align_up((size_t)B * (tiles > 0 ? tiles : 1) * o->n_mels * sizeof(float), 256);
+}
+
+int vp_fbank_cmn_f32(vp_ctx* ctx, const float* wav, const float* lens_ratio, int B, int L,
+                     const vp_fbank_opts* o, float* out, void* out_bf16, void* ws, size_t ws_bytes,
+                     vp_stream stream) {
+    if (!ctx || !wav || !o || !out || B <= 0) VP_FAIL(ctx, VP_EINVAL, "fbank: bad arguments");
+    const int T = vp_fbank_num_frames(o, L);
+    if (T <= 0) VP_FAIL(ctx, VP_EINVAL, "fbank: %d samples give no frame", L);
+    if (B > 65535) VP_FAIL(ctx, VP_EINVAL, "fbank: batch %d > 65535", B);
+    int rc = build_tables(ctx, o);
+    if (rc != VP_OK) return rc;
+    if (!ws || ws_bytes < vp_fbank_workspace_bytes(o, B, L)) VP_FAIL(ctx, VP_EWORKSPACE, "fbank: workspace too small");
+    const int tiles = (T + FRAMES_PER_WG - 1) / FRAMES_PER_WG;
+    hipStream_t st = (hipStream_t)stream;
+    FbankArgs a;
+    a.wav = wav; a.out = out; a.psum = (float*)ws; a.window = ctx->fb_window; a.tw = ctx->fb_twiddle;
+    a.mel_start = ctx->fb_mel_start; a.mel_bin0 = ctx->fb_mel_bin0; a.mel_w = ctx->fb_mel_w;
+    a.B = B; a.L = L; a.T = T; a.tiles = tiles; a.win = ctx->fb_win; a.shift = ctx->fb_shift;
+    a.n_mels = o->n_mels; a.nnz = ctx->fb_nnz; a.preemph = o->preemph; a.log_floor = o->log_floor;
+    a.remove_dc = o->remove_dc;
+    hipLaunchKernelGGL(fbank_frames_kernel, dim3(tiles, B), dim3(FB_WAVES * 64), 0, st, a);
+    VP_LAUNCH_CHECK(ctx, "fbank_frames");
+    CmnArgs c;
+    c.out = out; c.out_bf16 = (bf16_t*)out_bf16; c.psum = (const float*)ws; c.lens_ratio = lens_ratio;
+    c.B = B; c.T = T; c.tiles = tiles; c.n_mels = o->n_mels;
+    int gx = (T * o->n_mels + 4095) / 4096;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(fbank_cmn_kernel, dim3(gx, B), dim3(256), 0, st, c);
+    VP_LAUNCH_CHECK(ctx, "fbank_cmn");
+    return VP_OK;
+}
+
+}  // extern "C"

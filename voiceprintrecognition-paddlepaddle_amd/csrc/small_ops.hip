@@ -1,0 +1,320 @@
+// Per-utterance (M = batch) pieces of the path: time-moment finalisation, exact-f32 dense layers on
+// the f32 matrix cores, SE gating + residual, attention softmax + weighted statistics.
+// All HBM/L2-bound or tiny; kept in f32 so that they add no error on top of the f32 reference.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- moments from conv partial sums
+// SEBlock mean (ecapa_tdnn.py:78) and ASP global-context mean/std (pooling.py:90-104, mask of ones)
+struct MomArgs {
+    const float* psum; const float* psumsq; const float* shift; float* stats;
+    int B, T, C, nseg, want_std; float eps;
+};
+
+__global__ __launch_bounds__(256) void moments_kernel(MomArgs a) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= a.C) return;
+    const int t0 = (int)(((long long)b * a.T) / VP_CONV_BM);
+    const int t1 = (int)(((long long)(b + 1) * a.T - 1) / VP_CONV_BM);
+    float s1 = 0.f, s2 = 0.f;
+    for (int tm = t0; tm <= t1; ++tm) {
+        const int sg = b - (int)(((long long)tm * VP_CONV_BM) / a.T);
+        const size_t idx = ((size_t)tm * a.nseg + sg) * a.C + c;
+        s1 += a.psum[idx];
+        if (a.want_std) s2 += a.psumsq[idx];
+    }
+    const float invT = 1.f / (float)a.T;
+    const float md = s1 * invT;
+    const float sh = a.shift ? a.shift[c] : 0.f;
+    const int ld = a.want_std ? 2 * a.C : a.C;
+    a.stats[(size_t)b * ld + c] = sh + md;
+    if (a.want_std) {
+        const float var = s2 * invT - md * md;
+        a.stats[(size_t)b * ld + a.C + c] = sqrtf(fmaxf(var, a.eps));
+    }
+}
+
+// ---------------------------------------------------------------- dense f32 on v_mfma_f32_16x16x4_f32
+// One 16x16 output tile per workgroup; the 4 waves split K and reduce through LDS (fixed order).
+struct DenseArgs {
+    const float* a; const float* w; const float* bias; const float* rowscale; const float* colscale; float* out;
+    int lda, ldo, M, N, K, w_is_kn, act, kper, vec_ok, wvec_ok;
+};
+
+__global__ __launch_bounds__(256) void dense_f32_kernel(DenseArgs p) {
+    __shared__ float red[4][16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    const int kbeg = wv * p.kper;
+    const int kend = min(p.K, kbeg + p.kper);
+    const int am = m0 + li, bn = n0 + li;
+    const bool aok = am < p.M, bok = bn < p.N;
+    const float* arow = p.a + (size_t)(aok ? am : 0) * p.lda;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int kk = kbeg; kk < kend; kk += 16) {
+        const int k = kk + 4 * g;
+        float av[4] = {0.f, 0.f, 0.f, 0.f}, bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (aok) {
+            if (p.vec_ok && k + 3 < kend) {
+                float4 t = *reinterpret_cast<const float4*>(arow + k);
+                av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (k + e < kend) av[e] = arow[k + e];
+            }
+        }
+        if (bok) {
+            if (p.w_is_kn) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (k + e < kend) bv[e] = p.w[(size_t)(k + e) * p.N + bn];
+            } else {
+                const float* wrow = p.w + (size_t)bn * p.K;
+                if (p.wvec_ok && k + 3 < kend) {
+                    float4 t = *reinterpret_cast<const float4*>(wrow + k);
+                    bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (k + e < kend) bv[e] = wrow[k + e];
+                }
+            }
+        }
+        // lane group g feeds k = kk + 4g + e to instruction e for BOTH operands
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], acc, 0, 0, 0);
+    }
+    // acc[r] = C[row = 4g + r (m)][col = li (n)]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wv][4 * g + r][li] = acc[r];
+    __syncthreads();
+    const int mm = tid >> 4, nn = tid & 15;
+    const int m = m0 + mm, n = n0 + nn;
+    if (m < p.M && n < p.N) {
+        float v = red[0][mm][nn] + red[1][mm][nn] + red[2][mm][nn] + red[3][mm][nn];
+        if (p.rowscale) v *= p.rowscale[m];
+        if (p.colscale) v *= p.colscale[n];
+        if (p.bias) v += p.bias[n];
+        if (p.act == VP_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (p.act == VP_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+        else if (p.act == VP_ACT_TANH) v = tanhf(v);
+        p.out[(size_t)m * p.ldo + n] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void row_inv_norm_kernel(const float* x, int rows, int D, int ld, float eps, float* inv) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) { float v = x[(size_t)row * ld + d]; s += v * v; }
+    s = vp_wave_sum(s);
+    if (lane == 0) inv[row] = 1.f / fmaxf(sqrtf(s), eps);
+}
+
+// ---------------------------------------------------------------- SE gate + residual (ecapa_tdnn.py:82,142)
+template <typename T>
+struct SeArgs {
+    const T* x; const float* s; const T* res; T* out;
+    int ldx, xoff, ldr, roff, ldo, ooff, T_, C; long long total;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void se_scale_residual_kernel(SeArgs<T> a) {
+    constexpr int V = 16 / (int)sizeof(T);
+    const int cv = a.C / V;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < a.total; idx += (long long)gridDim.x * 256) {
+        const long long m = idx / cv;
+        const int c = (int)(idx - m * cv) * V;
+        const int b = (int)(m / a.T_);
+        uint4 xr = *reinterpret_cast<const uint4*>(a.x + m * a.ldx + a.xoff + c);
+        uint4 rr = *reinterpret_cast<const uint4*>(a.res + m * a.ldr + a.roff + c);
+        const T* xe = reinterpret_cast<const T*>(&xr);
+        const T* re = reinterpret_cast<const T*>(&rr);
+        const float* sp = a.s + (size_t)b * a.C + c;
+        uint4 o;
+        T* oe = reinterpret_cast<T*>(&o);
+#pragma unroll
+        for (int e = 0; e < V; ++e) oe[e] = vp_from_f32<T>(vp_to_f32(xe[e]) * sp[e] + vp_to_f32(re[e]));
+        *reinterpret_cast<uint4*>(a.out + m * a.ldo + a.ooff + c) = o;
+    }
+}
+
+// ---------------------------------------------------------------- ASP softmax over time + weighted stats
+// pooling.py:114-123: attn = softmax_t(logits); mean = sum attn x; std = sqrt(clip(sum attn (x-mean)^2, eps)).
+// One workgroup = 64 channels of one utterance; the 4 waves split the frames, online softmax per
+// lane, merged through LDS.  x is centred on `center` (the plain time mean) to keep the variance
+// well conditioned in f32.
+template <typename T>
+struct AspArgs {
+    const float* logits; const T* x; const float* center; float* pooled;
+    int ldx, xoff, ldc, B, T_, C; float eps;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void asp_softmax_stats_kernel(AspArgs<T> a) {
+    __shared__ float sm[4][4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 64 + lane;
+    const bool ok = c < a.C;
+    const int cc = ok ? c : 0;
+    const float mu0 = a.center ? a.center[(size_t)b * a.ldc + cc] : 0.f;
+    float mx = -INFINITY, s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    const size_t row0 = (size_t)b * a.T_;
+    for (int t = wv; t < a.T_; t += 4) {
+        const float e = a.logits[(row0 + t) * a.C + cc];
+        const float xv = vp_to_f32(a.x[(row0 + t) * a.ldx + a.xoff + cc]) - mu0;
+        if (e > mx) {
+            const float f = expf(mx - e);       // exp(-inf) = 0 on the first frame
+            s0 = s0 * f + 1.f; s1 = s1 * f + xv; s2 = s2 * f + xv * xv; mx = e;
+        } else {
+            const float p = expf(e - mx);
+            s0 += p; s1 += p * xv; s2 += p * xv * xv;
+        }
+    }
+    sm[wv][0][lane] = mx; sm[wv][1][lane] = s0; sm[wv][2][lane] = s1; sm[wv][3][lane] = s2;
+    __syncthreads();
+    if (wv == 0 && ok) {
+        float M = fmaxf(fmaxf(sm[0][0][lane], sm[1][0][lane]), fmaxf(sm[2][0][lane], sm[3][0][lane]));
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float mw = sm[w][0][lane];
+            const float f = (mw == -INFINITY) ? 0.f : expf(mw - M);
+            t0 += sm[w][1][lane] * f; t1 += sm[w][2][lane] * f; t2 += sm[w][3][lane] * f;
+        }
+        const float md = t1 / t0;
+        const float var = t2 / t0 - md * md;
+        a.pooled[(size_t)b * 2 * a.C + c] = mu0 + md;
+        a.pooled[(size_t)b * 2 * a.C + a.C + c] = sqrtf(fmaxf(var, a.eps));
+    }
+}
+
+}  // namespace
+
+int vp_dense_f32_ex(vp_ctx* ctx, const float* a, int lda, const float* w, int w_is_kn, const float* bias,
+                    const float* rowscale, const float* colscale, int M, int N, int K, int act, float* out,
+                    int ldo, hipStream_t st) {
+    if (!a || !w || !out || M <= 0 || N <= 0 || K <= 0) VP_FAIL(ctx, VP_EINVAL, "dense: bad arguments");
+    DenseArgs p;
+    p.a = a; p.w = w; p.bias = bias; p.rowscale = rowscale; p.colscale = colscale; p.out = out;
+    p.lda = lda; p.ldo = ldo; p.M = M; p.N = N; p.K = K; p.w_is_kn = w_is_kn; p.act = act;
+    p.kper = ((K + 3) / 4 + 15) / 16 * 16;
+    p.vec_ok = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
+    p.wvec_ok = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
+    dim3 grid((N + 15) / 16, (M + 15) / 16);
+    if (grid.y > 65535) VP_FAIL(ctx, VP_EINVAL, "dense: M too large");
+    hipLaunchKernelGGL(dense_f32_kernel, grid, dim3(256), 0, st, p);
+    VP_LAUNCH_CHECK(ctx, "dense_f32");
+    return VP_OK;
+}
+
+int vp_row_inv_norm(vp_ctx* ctx, const float* x, int rows, int D, int ld, float eps, float* inv, hipStream_t st) {
+    hipLaunchKernelGGL(row_inv_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, rows, D, ld, eps, inv);
+    VP_LAUNCH_CHECK(ctx, "row_inv_norm");
+    return VP_OK;
+}
+
+extern "C" {
+
+int vp_moments_finalize(vp_ctx* ctx, const float* psum, const float* psumsq, const float* shift,
+                        int B, int T, int C, float eps, int want_std, float* stats, vp_stream stream) {
+    if (!ctx || !psum || !stats || (want_std && !psumsq) || B <= 0 || T <= 0 || C <= 0)
+        VP_FAIL(ctx, VP_EINVAL, "moments: bad arguments");
+    if (B > 65535) VP_FAIL(ctx, VP_EINVAL, "moments: batch too large");
+    MomArgs a;
+    a.psum = psum; a.psumsq = psumsq; a.shift = shift; a.stats = stats; a.B = B; a.T = T; a.C = C;
+    a.nseg = vp_conv1d_nseg(T); a.want_std = want_std; a.eps = eps;
+    hipLaunchKernelGGL(moments_kernel, dim3((C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, a);
+    VP_LAUNCH_CHECK(ctx, "moments");
+    return VP_OK;
+}
+
+int vp_dense_f32(vp_ctx* ctx, const float* a, int lda, const float* w, int w_is_kn, const float* bias,
+                 int M, int N, int K, int act, float* out, int ldo, vp_stream stream) {
+    if (!ctx) return VP_EINVAL;
+    return vp_dense_f32_ex(ctx, a, lda, w, w_is_kn, bias, nullptr, nullptr, M, N, K, act, out, ldo, (hipStream_t)stream);
+}
+
+int vp_se_scale_residual(vp_ctx* ctx, int dtype, const void* x, int ldx, int xoff, const float* s,
+                         const void* res, int ldr, int roff, void* out, int ldo, int ooff,
+                         int B, int T, int C, vp_stream stream) {
+    if (!ctx || !x || !s || !res || !out || B <= 0 || T <= 0 || C <= 0) VP_FAIL(ctx, VP_EINVAL, "se: bad arguments");
+    const int V = dtype == VP_BF16 ? 8 : 4;
+    if (C % V || ldx % V || xoff % V || ldr % V || roff % V || ldo % V || ooff % V)
+        VP_FAIL(ctx, VP_EINVAL, "se: C/ld/off must be multiples of %d", V);
+    const long long total = (long long)B * T * (C / V);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == VP_BF16) {
+        SeArgs<bf16_t> a{(const bf16_t*)x, s, (const bf16_t*)res, (bf16_t*)out, ldx, xoff, ldr, roff, ldo, ooff, T, C, total};
+        hipLaunchKernelGGL(se_scale_residual_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    } else if (dtype == VP_F32) {
+        SeArgs<float> a{(const float*)x, s, (const float*)res, (float*)out, ldx, xoff, ldr, roff, ldo, ooff, T, C, total};
+        hipLaunchKernelGGL(se_scale_residual_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    } else {
+        VP_FAIL(ctx, VP_EINVAL, "se: bad dtype");
+    }
+    VP_LAUNCH_CHECK(ctx, "se_scale_residual");
+    return VP_OK;
+}
+
+}  // extern "C"
+
+int vp_asp_softmax_stats_ex(vp_ctx* ctx, int dtype, const float* logits, const void* x, int ldx, int xoff,
+                            const float* center, int ldc, int B, int T, int C, float eps, float* pooled, hipStream_t st) {
+    if (!ctx || !logits || !x || !pooled || B <= 0 || T <= 0 || C <= 0) VP_FAIL(ctx, VP_EINVAL, "asp: bad arguments");
+    if (B > 65535) VP_FAIL(ctx, VP_EINVAL, "asp: batch too large");
+    dim3 grid((C + 63) / 64, B);
+    if (dtype == VP_BF16) {
+        AspArgs<bf16_t> a{logits, (const bf16_t*)x, center, pooled, ldx, xoff, ldc, B, T, C, eps};
+        hipLaunchKernelGGL(asp_softmax_stats_kernel<bf16_t>, grid, dim3(256), 0, st, a);
+    } else if (dtype == VP_F32) {
+        AspArgs<float> a{logits, (const float*)x, center, pooled, ldx, xoff, ldc, B, T, C, eps};
+        hipLaunchKernelGGL(asp_softmax_stats_kernel<float>, grid, dim3(256), 0, st, a);
+    } else {
+        VP_FAIL(ctx, VP_EINVAL, "asp: bad dtype");
+    }
+    VP_LAUNCH_CHECK(ctx, "asp_softmax_stats");
+    return VP_OK;
+}
+
+extern "C" {
+
+int vp_asp_softmax_stats(vp_ctx* ctx, int dtype, const float* logits, const void* x, int ldx, int xoff,
+                         int B, int T, int C, float eps, float* pooled, vp_stream stream) {
+    return vp_asp_softmax_stats_ex(ctx, dtype, logits, x, ldx, xoff, nullptr, 0, B, T, C, eps, pooled, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- f32 -> bf16 cast (model entry when the
+// caller hands over f32 features without the fused bf16 twin the Fbank kernel can emit)
+namespace {
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* x, bf16_t* y, long long n) {
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * 1024) {
+        if (i + 3 < n) {
+            float4 v = *reinterpret_cast<const float4*>(x + i);
+            bf16x4 o;
+            o[0] = (bf16_t)v.x; o[1] = (bf16_t)v.y; o[2] = (bf16_t)v.z; o[3] = (bf16_t)v.w;
+            *reinterpret_cast<bf16x4*>(y + i) = o;
+        } else {
+            for (long long j = i; j < n; ++j) y[j] = (bf16_t)x[j];
+        }
+    }
+}
+}  // namespace
+
+extern "C" int vp_cast_f32_bf16(vp_ctx* ctx, const float* x, void* y, long long n, vp_stream stream) {
+    if (!ctx || !x || !y || n <= 0) VP_FAIL(ctx, VP_EINVAL, "cast: bad arguments");
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 7)) VP_FAIL(ctx, VP_EINVAL, "cast: misaligned");
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, n);
+    VP_LAUNCH_CHECK(ctx, "cast_bf16");
+    return VP_OK;
+}

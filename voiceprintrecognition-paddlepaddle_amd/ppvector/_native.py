@@ -1,0 +1,195 @@
+"""ctypes binding of libvpmi.so (include/vpmi.h) -- the only compute backend of this package.
+
+There is deliberately NO CPU / PyTorch fallback: if the HIP library is missing or no GPU is
+visible, every compute entry point raises.  PyTorch is used for device memory, the current HIP
+stream and (later) torch.distributed only.
+"""
+import ctypes as C
+import os
+import threading
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(HERE)
+LIB_PATH = os.path.join(PKG_ROOT, 'lib', 'libvpmi.so')
+
+VP_F32, VP_BF16 = 0, 1
+VP_PAD_NONE, VP_PAD_REFLECT, VP_PAD_ZERO = 0, 1, 2
+VP_ACT_NONE, VP_ACT_RELU, VP_ACT_SIGMOID, VP_ACT_TANH = 0, 1, 2, 3
+VP_MAX_SE_BLOCKS, VP_MAX_RES2 = 8, 15
+
+c_void_p, c_int, c_float, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+
+class FbankOpts(C.Structure):
+    _fields_ = [('sample_rate', c_int), ('n_mels', c_int), ('frame_length_ms', c_float),
+                ('frame_shift_ms', c_float), ('preemph', c_float), ('remove_dc', c_int),
+                ('low_freq', c_float), ('high_freq', c_float), ('log_floor', c_float)]
+
+
+class Conv1dDesc(C.Structure):
+    _fields_ = [('dtype_in', c_int), ('dtype_out', c_int), ('B', c_int), ('T_in', c_int), ('T_out', c_int),
+                ('Cin', c_int), ('Cout', c_int), ('KW', c_int), ('dilation', c_int), ('stride', c_int),
+                ('pad_left', c_int), ('pad_mode', c_int),
+                ('x', c_void_p), ('ldx', c_int), ('xoff', c_int),
+                ('x2', c_void_p), ('ldx2', c_int), ('x2off', c_int), ('xsplit', c_int),
+                ('w', c_void_p), ('bias', c_void_p), ('rowbias', c_void_p), ('act', c_int),
+                ('bn_scale', c_void_p), ('bn_shift', c_void_p), ('act2', c_int),
+                ('y', c_void_p), ('ldy', c_int), ('yoff', c_int),
+                ('add_in', c_void_p), ('ld_add', c_int), ('add_off', c_int),
+                ('aux', c_void_p), ('ld_aux', c_int), ('aux_off', c_int),
+                ('psum', c_void_p), ('psumsq', c_void_p)]
+
+
+class TdnnLayer(C.Structure):
+    _fields_ = [('w', c_void_p), ('bias', c_void_p), ('bn_scale', c_void_p), ('bn_shift', c_void_p),
+                ('cin', c_int), ('cout', c_int), ('kw', c_int), ('dil', c_int)]
+
+
+class SeRes2Block(C.Structure):
+    _fields_ = [('tdnn1', TdnnLayer), ('res2', TdnnLayer * VP_MAX_RES2), ('tdnn2', TdnnLayer),
+                ('se_w1', c_void_p), ('se_b1', c_void_p), ('se_w2', c_void_p), ('se_b2', c_void_p)]
+
+
+class AspWeights(C.Structure):
+    _fields_ = [('tdnn', TdnnLayer), ('w_ctx', c_void_p), ('conv_w', c_void_p), ('conv_b', c_void_p),
+                ('C', c_int), ('att', c_int)]
+
+
+class EcapaWeights(C.Structure):
+    _fields_ = [('dtype', c_int), ('feat_dim', c_int), ('embd_dim', c_int), ('n_blocks', c_int),
+                ('res2_scale', c_int), ('se_ch', c_int), ('block0', TdnnLayer),
+                ('blk', SeRes2Block * VP_MAX_SE_BLOCKS), ('mfa', TdnnLayer), ('asp', AspWeights),
+                ('fc_w', c_void_p), ('fc_b', c_void_p)]
+
+
+class TdnnWeights(C.Structure):
+    _fields_ = [('dtype', c_int), ('feat_dim', c_int), ('embd_dim', c_int), ('channels', c_int),
+                ('td', TdnnLayer * 5), ('asp', AspWeights), ('lin_w', c_void_p), ('lin_b', c_void_p)]
+
+
+_PROTOS = {
+    'vp_version': (c_int, []),
+    'vp_create': (c_void_p, [c_int]),
+    'vp_destroy': (None, [c_void_p]),
+    'vp_last_error': (C.c_char_p, [c_void_p]),
+    'vp_fbank_default_opts': (None, [C.POINTER(FbankOpts)]),
+    'vp_fbank_num_frames': (c_int, [C.POINTER(FbankOpts), c_int]),
+    'vp_fbank_workspace_bytes': (c_size_t, [C.POINTER(FbankOpts), c_int, c_int]),
+    'vp_fbank_cmn_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, C.POINTER(FbankOpts), c_void_p,
+                                 c_void_p, c_void_p, c_size_t, c_void_p]),
+    'vp_conv1d_tiles_m': (c_int, [c_int, c_int]),
+    'vp_conv1d_nseg': (c_int, [c_int]),
+    'vp_conv1d_fwd': (c_int, [c_void_p, C.POINTER(Conv1dDesc), c_void_p]),
+    'vp_moments_finalize': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int,
+                                    c_void_p, c_void_p]),
+    'vp_dense_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                             c_void_p, c_int, c_void_p]),
+    'vp_cast_f32_bf16': (c_int, [c_void_p, c_void_p, c_void_p, C.c_longlong, c_void_p]),
+    'vp_se_scale_residual': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                                     c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'vp_asp_softmax_stats': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                     c_float, c_void_p, c_void_p]),
+    'vp_ecapa_workspace_bytes': (c_size_t, [C.POINTER(EcapaWeights), c_int, c_int]),
+    'vp_ecapa_fwd': (c_int, [c_void_p, C.POINTER(EcapaWeights), c_void_p, c_int, c_int, c_void_p, c_void_p,
+                             c_size_t, c_void_p]),
+    'vp_tdnn_workspace_bytes': (c_size_t, [C.POINTER(TdnnWeights), c_int, c_int]),
+    'vp_tdnn_fwd': (c_int, [c_void_p, C.POINTER(TdnnWeights), c_void_p, c_int, c_int, c_void_p, c_void_p,
+                            c_size_t, c_void_p]),
+    'vp_cosine_logits_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'vp_cosine_logits_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                     c_size_t, c_void_p]),
+    'vp_aam_ce_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int,
+                              c_void_p, c_void_p, c_void_p]),
+    'vp_cosine_aam_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'vp_cosine_aam_ce_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float,
+                                     c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'vp_cosine_scores_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'vp_cosine_scores_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                     c_size_t, c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_PROTOS.keys())
+
+_lib = None
+_lock = threading.Lock()
+_ctx = {}
+
+
+class VpmiError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen libvpmi.so and set the prototypes.  Works without a GPU (symbol checks only)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise VpmiError(f'{LIB_PATH} is missing: build it with `python {PKG_ROOT}/build.py` '
+                                '(there is no CPU fallback)')
+            lib = C.CDLL(LIB_PATH)
+            for name, (res, args) in _PROTOS.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def lib():
+    return load_library()
+
+
+def ctx(device=None):
+    """Per-device vp_ctx; requires a visible GPU."""
+    if not torch.cuda.is_available():
+        raise VpmiError('no HIP device visible: the ppvector MI355X engine has no CPU fallback')
+    if device is None:
+        device = torch.cuda.current_device()
+    device = torch.device(device).index if not isinstance(device, int) else device
+    if device is None:
+        device = torch.cuda.current_device()
+    with _lock:
+        if device not in _ctx:
+            h = lib().vp_create(device)
+            if not h:
+                raise VpmiError(f'vp_create({device}) failed')
+            _ctx[device] = h
+    return _ctx[device]
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc, c=None):
+    if rc != 0:
+        msg = lib().vp_last_error(c).decode('utf-8', 'replace') if c else ''
+        raise VpmiError(f'libvpmi error {rc}: {msg}')
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def dtype_id(torch_dtype):
+    if torch_dtype == torch.float32:
+        return VP_F32
+    if torch_dtype == torch.bfloat16:
+        return VP_BF16
+    raise VpmiError(f'unsupported dtype {torch_dtype}')
+
+
+class Workspace:
+    """Grow-only device scratch, one per consumer; reused across calls so the steady state
+    allocates nothing (hipGraph-friendly)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        return self.buf

@@ -1,0 +1,108 @@
+"""AudioFeaturizer on the MI355X engine.
+
+Mirrors ppvector/data_utils/featurizer.py:7-80 (constructor arguments, call signature,
+``feature_dim``, the exceptions for unknown methods).  'Fbank' (KaldiFbank, featurizer.py:83-101)
+runs in one fused HIP pipeline (csrc/fbank.hip): framing, DC removal, pre-emphasis, Povey window,
+512-point FFT, Kaldi mel bank, log, time-mean subtraction and the length mask.
+"""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from ppvector import _native as N
+
+_KALDI_KW = {'sr': 'sample_rate', 'n_mels': 'n_mels', 'frame_length': 'frame_length_ms',
+             'frame_shift': 'frame_shift_ms', 'preemphasis_coefficient': 'preemph',
+             'remove_dc_offset': 'remove_dc', 'low_freq': 'low_freq', 'high_freq': 'high_freq'}
+_KALDI_FIXED = {'dither': 0.0, 'window_type': 'povey', 'snip_edges': True, 'use_energy': False,
+                'use_log_fbank': True, 'use_power': True, 'round_to_power_of_two': True,
+                'subtract_mean': False, 'htk_compat': False, 'raw_energy': True, 'channel': -1,
+                'vtln_warp': 1.0, 'energy_floor': 1.0, 'blackman_coeff': 0.42, 'vtln_low': 100.0,
+                'vtln_high': -500.0}
+
+
+class AudioFeaturizer(nn.Module):
+    """音频特征器 (feature_method: 'Fbank' on the HIP engine).
+
+    :param feature_method: 所使用的预处理方法
+    :param method_args: 预处理方法的参数
+    """
+
+    def __init__(self, feature_method='MelSpectrogram', method_args={}):
+        super().__init__()
+        self._method_args = method_args
+        self._feature_method = feature_method
+        if feature_method == 'Fbank':
+            self._opts = self._fbank_opts(method_args)
+        elif feature_method in ('LogMelSpectrogram', 'MelSpectrogram', 'Spectrogram', 'MFCC'):
+            self._opts = None       # known to the reference; not built on the HIP engine yet
+        else:
+            raise Exception(f'预处理方法 {self._feature_method} 不存在!')
+        self._ws = N.Workspace()
+
+    @staticmethod
+    def _fbank_opts(method_args):
+        o = N.FbankOpts()
+        N.lib().vp_fbank_default_opts(C.byref(o))
+        for k, v in dict(method_args).items():
+            if k in _KALDI_KW:
+                setattr(o, _KALDI_KW[k], type(getattr(o, _KALDI_KW[k]))(v))
+            elif k in _KALDI_FIXED:
+                if v != _KALDI_FIXED[k]:
+                    raise NotImplementedError(f'Fbank option {k}={v} is not built on the HIP engine')
+            else:
+                raise TypeError(f"fbank() got an unexpected keyword argument '{k}'")
+        return o
+
+    def num_frames(self, n_samples):
+        return N.lib().vp_fbank_num_frames(C.byref(self._opts), int(n_samples))
+
+    def forward(self, waveforms, input_lens_ratio=None, want_bf16=False):
+        """waveforms (L,) or (B, L) float32 on the GPU -> (B, T, F) float32.
+
+        With want_bf16 the bf16 copy the bf16 network consumes is produced by the same kernel and
+        attached to the result as ``._vp_bf16``.
+        """
+        if self._opts is None:
+            raise NotImplementedError(f'feature_method {self._feature_method} is not built on the HIP engine yet '
+                                      '(Fbank is); there is no CPU fallback')
+        if waveforms.dim() == 1:
+            waveforms = waveforms.unsqueeze(0)
+        if not waveforms.is_cuda:
+            raise N.VpmiError('AudioFeaturizer needs GPU tensors: the engine has no CPU fallback')
+        wav = waveforms.contiguous().float()
+        B, L = wav.shape
+        lib, ctx = N.lib(), N.ctx(wav.device)
+        T = lib.vp_fbank_num_frames(C.byref(self._opts), L)
+        if T <= 0:
+            raise ValueError(f'{L} samples are shorter than one analysis window')
+        F = self._opts.n_mels
+        out = torch.empty((B, T, F), dtype=torch.float32, device=wav.device)
+        out16 = torch.empty((B, T, F), dtype=torch.bfloat16, device=wav.device) if want_bf16 else None
+        ratio = None
+        if input_lens_ratio is not None:
+            ratio = input_lens_ratio.to(device=wav.device, dtype=torch.float32).contiguous()
+        nws = lib.vp_fbank_workspace_bytes(C.byref(self._opts), B, L)
+        ws = self._ws.get(nws, wav.device)
+        N.check(lib.vp_fbank_cmn_f32(ctx, N.ptr(wav), N.ptr(ratio), B, L, C.byref(self._opts), N.ptr(out),
+                                     N.ptr(out16), N.ptr(ws), ws.numel(), N.stream_ptr()), ctx)
+        if out16 is not None:
+            out._vp_bf16 = out16
+        return out
+
+    @property
+    def feature_dim(self):
+        """返回特征大小"""
+        if self._feature_method == 'LogMelSpectrogram':
+            return self._method_args.get('n_mels', 128)
+        elif self._feature_method == 'MelSpectrogram':
+            return self._method_args.get('n_mels', 64)
+        elif self._feature_method == 'Spectrogram':
+            return self._method_args.get('n_fft', 512) // 2 + 1
+        elif self._feature_method == 'MFCC':
+            return self._method_args.get('n_mfcc', 40)
+        elif self._feature_method == 'Fbank':
+            return self._method_args.get('n_mels', 23)
+        else:
+            raise Exception('没有{}预处理方法'.format(self._feature_method))

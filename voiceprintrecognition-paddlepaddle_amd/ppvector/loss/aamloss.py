@@ -1,0 +1,45 @@
+"""AAMLoss on the MI355X engine (ppvector/loss/aamloss.py:8-53).
+
+forward(inputs, labels) takes the classifier's dict and returns the scalar mean loss;
+update(margin) is what MarginScheduler calls every step (optimizer/scheduler.py:69,76).  The
+margin / one-hot mix / scale / softmax-CE(label_smoothing) chain is one kernel over the logits
+(csrc/head.hip aam_ce_rows_kernel) -- no one-hot tensor, no (B, C) temporaries.
+"""
+import math
+
+import torch
+from torch import nn
+
+from ppvector import _native as N
+
+
+class AAMLoss(nn.Module):
+    def __init__(self, margin=0.2, scale=32, easy_margin=False, label_smoothing=0.0):
+        super().__init__()
+        self.scale = scale
+        self.easy_margin = easy_margin
+        self.label_smoothing = label_smoothing
+        self.update(margin)
+
+    def forward(self, inputs, labels):
+        features, logits = inputs['features'], inputs['logits']
+        if not logits.is_cuda:
+            raise N.VpmiError('AAMLoss needs GPU tensors: the engine has no CPU fallback')
+        logits = logits.contiguous().float()
+        labels = labels.to(device=logits.device, dtype=torch.int64).reshape(-1).contiguous()
+        B, Cn = logits.shape
+        lib, ctx = N.lib(), N.ctx(logits.device)
+        loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
+        row = torch.empty((B,), dtype=torch.float32, device=logits.device)
+        N.check(lib.vp_aam_ce_fwd(ctx, logits.data_ptr(), labels.data_ptr(), B, Cn, float(self.margin),
+                                  float(self.scale), float(self.label_smoothing), int(bool(self.easy_margin)),
+                                  loss.data_ptr(), row.data_ptr(), N.stream_ptr()), ctx)
+        self.row_loss = row
+        return loss[0]
+
+    def update(self, margin=0.2):
+        self.margin = margin
+        self.cos_m = math.cos(margin)
+        self.sin_m = math.sin(margin)
+        self.th = math.cos(math.pi - margin)
+        self.mmm = 1.0 + math.cos(math.pi - margin)

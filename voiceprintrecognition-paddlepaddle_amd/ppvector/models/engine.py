@@ -1,0 +1,174 @@
+"""Host-side packing of model parameters into the C structs of include/vpmi.h, and the launch.
+
+A packed engine owns contiguous device copies of the weights in the layout the kernels want
+(conv weights [Cout][k*Cin] in the network dtype, BN folded to f32 scale/shift, the ASP context
+columns split off, asp_bn / bn5 / bn6 folded into the last dense layer).  Packing is redone only
+when a parameter's version counter moves.
+"""
+import ctypes as C
+
+import torch
+
+import ppvector
+from ppvector import _native as N
+from ppvector.models.utils import f32, pack_conv_weight
+
+_TORCH_DT = {'float32': torch.float32, 'bfloat16': torch.bfloat16}
+
+
+def _versions(module):
+    return tuple(t._version for t in list(module.parameters()) + list(module.buffers()))
+
+
+class _Engine:
+    def __init__(self, module, dtype_name):
+        self.dtype_name = dtype_name
+        self.tdtype = _TORCH_DT[dtype_name]
+        self.dt = N.dtype_id(self.tdtype)
+        self.keep = []            # device tensors referenced by the C struct
+        self.versions = _versions(module)
+        self.device = next(module.parameters()).device
+        self.ws = N.Workspace()
+
+    def _p(self, t):
+        if t is None:
+            return None
+        t = t.contiguous()
+        self.keep.append(t)
+        return t.data_ptr()
+
+    def tdnn_layer(self, L, conv, bn, dil, w_override=None):
+        """conv: _ConvParams; bn: _BNParams or None."""
+        cout, cin, kw = conv.weight.shape
+        w = w_override if w_override is not None else pack_conv_weight(conv.weight, self.tdtype)
+        L.w = self._p(w)
+        L.bias = self._p(f32(conv.bias))
+        if bn is not None:
+            sc, sh = bn.folded()
+            L.bn_scale, L.bn_shift = self._p(sc), self._p(sh)
+        L.cin, L.cout, L.kw, L.dil = (w.shape[1] // kw), cout, kw, dil
+
+    def asp(self, A, asp):
+        Cc = asp.channels
+        w = asp.tdnn.conv.conv.weight.detach()[:, :, 0]                 # (att, 3C | C)
+        wx = w[:, :Cc].to(self.tdtype).contiguous()
+        self.tdnn_layer(A.tdnn, asp.tdnn.conv.conv, asp.tdnn.norm.norm, 1, w_override=wx)
+        A.tdnn.cin, A.tdnn.kw = Cc, 1
+        A.w_ctx = self._p(w[:, Cc:].float().contiguous()) if asp.global_context else None
+        A.conv_w = self._p(pack_conv_weight(asp.conv.conv.weight, self.tdtype))
+        A.conv_b = self._p(f32(asp.conv.conv.bias))
+        A.C, A.att = Cc, asp.attention_channels
+
+    def feats_in(self, x):
+        """(B,T,F) f32 (API contract) -> tensor in the network dtype (no copy on the f32 path)."""
+        if not x.is_cuda:
+            raise N.VpmiError('model input must be a GPU tensor: the engine has no CPU fallback')
+        if self.tdtype == torch.float32:
+            return x.contiguous().float()
+        twin = getattr(x, '_vp_bf16', None)
+        if twin is not None and twin.shape == x.shape:
+            return twin
+        if x.dtype == torch.bfloat16:
+            return x.contiguous()
+        x = x.contiguous().float()
+        y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        ctx = N.ctx(x.device)
+        N.check(N.lib().vp_cast_f32_bf16(ctx, x.data_ptr(), y.data_ptr(), x.numel(), N.stream_ptr()), ctx)
+        return y
+
+
+class EcapaEngine(_Engine):
+    def __init__(self, m, dtype_name):
+        super().__init__(m, dtype_name)
+        W = N.EcapaWeights()
+        W.dtype, W.feat_dim, W.embd_dim = self.dt, m.input_size, m.embd_dim
+        W.n_blocks, W.res2_scale, W.se_ch = len(m.blocks) - 1, m.res2net_scale, m.se_channels
+        b0 = m.blocks[0]
+        self.tdnn_layer(W.block0, b0.conv.conv, b0.norm.norm, b0.conv.dilation)
+        for i, blk in enumerate(list(m.blocks)[1:]):
+            if blk.shortcut is not None:
+                raise NotImplementedError('SERes2NetBlock with in_channels != out_channels (shortcut conv) is not built')
+            S = W.blk[i]
+            self.tdnn_layer(S.tdnn1, blk.tdnn1.conv.conv, blk.tdnn1.norm.norm, 1)
+            for j, rb in enumerate(blk.res2net_block.blocks):
+                self.tdnn_layer(S.res2[j], rb.conv.conv, rb.norm.norm, rb.conv.dilation)
+            self.tdnn_layer(S.tdnn2, blk.tdnn2.conv.conv, blk.tdnn2.norm.norm, 1)
+            S.se_w1 = self._p(blk.se_block.conv1.conv.weight.detach()[:, :, 0].float())
+            S.se_b1 = self._p(f32(blk.se_block.conv1.conv.bias))
+            S.se_w2 = self._p(blk.se_block.conv2.conv.weight.detach()[:, :, 0].float())
+            S.se_b2 = self._p(f32(blk.se_block.conv2.conv.bias))
+        self.tdnn_layer(W.mfa, m.mfa.conv.conv, m.mfa.norm.norm, m.mfa.conv.dilation)
+        self.asp(W.asp, m.asp)
+        # asp_bn folded into fc: fc(bn(p)) = (W*scale) p + (b + W shift)
+        sc, sh = m.asp_bn.norm.folded()
+        fw = m.fc.conv.weight.detach()[:, :, 0].float()
+        W.fc_w = self._p(fw * sc[None, :])
+        W.fc_b = self._p(m.fc.conv.bias.detach().float() + fw @ sh)
+        self.W = W
+
+    def forward(self, x):
+        xin = self.feats_in(x)
+        B, T, F = xin.shape
+        lib, ctx = N.lib(), N.ctx(xin.device)
+        emb = torch.empty((B, self.W.embd_dim), dtype=torch.float32, device=xin.device)
+        nws = lib.vp_ecapa_workspace_bytes(C.byref(self.W), B, T)
+        ws = self.ws.get(nws, xin.device)
+        N.check(lib.vp_ecapa_fwd(ctx, C.byref(self.W), xin.data_ptr(), B, T, emb.data_ptr(), ws.data_ptr(),
+                                 ws.numel(), N.stream_ptr()), ctx)
+        return emb
+
+
+class TdnnEngine(_Engine):
+    def __init__(self, m, dtype_name):
+        super().__init__(m, dtype_name)
+        W = N.TdnnWeights()
+        W.dtype, W.feat_dim, W.embd_dim, W.channels = self.dt, m.input_size, m.embd_dim, m.channels
+        convs = [m.td_layer1, m.td_layer2, m.td_layer3, m.td_layer4, m.td_layer5]
+        bns = [m.bn1, m.bn2, m.bn3, m.bn4, None]
+        for i, (cv, bn, d) in enumerate(zip(convs, bns, (1, 2, 3, 1, 1))):
+            self.tdnn_layer(W.td[i], cv, bn, d)
+        self.asp(W.asp, m.pooling)
+        # bn5 and bn6 folded around the Linear (Paddle weight [in, out])
+        s5, h5 = m.bn5.norm.folded()
+        s6, h6 = m.bn6.norm.folded()
+        lw = m.linear.weight.detach().float().t()                     # [out, in]
+        lb = m.linear.bias.detach().float()
+        W.lin_w = self._p(lw * s5[None, :] * s6[:, None])
+        W.lin_b = self._p((lb + lw @ h5) * s6 + h6)
+        self.W = W
+
+    def forward(self, x):
+        xin = self.feats_in(x)
+        B, T, F = xin.shape
+        lib, ctx = N.lib(), N.ctx(xin.device)
+        emb = torch.empty((B, self.W.embd_dim), dtype=torch.float32, device=xin.device)
+        nws = lib.vp_tdnn_workspace_bytes(C.byref(self.W), B, T)
+        ws = self.ws.get(nws, xin.device)
+        N.check(lib.vp_tdnn_fwd(ctx, C.byref(self.W), xin.data_ptr(), B, T, emb.data_ptr(), ws.data_ptr(),
+                                ws.numel(), N.stream_ptr()), ctx)
+        return emb
+
+
+class EngineMixin:
+    """forward() of a backbone: eval-mode fused forward on the HIP engine."""
+    _engine_cls = None
+
+    def engine(self, dtype_name=None):
+        dtype_name = dtype_name or ppvector.get_compute_dtype()
+        cache = self.__dict__.setdefault('_engines', {})
+        e = cache.get(dtype_name)
+        if e is None or e.versions != _versions(self) or e.device != next(self.parameters()).device:
+            with torch.no_grad():
+                e = self._engine_cls(self, dtype_name)
+            cache[dtype_name] = e
+        return e
+
+    def forward(self, x, lengths=None):
+        if lengths is not None:
+            raise NotImplementedError('lengths= is never passed by the reference entry points (trainer.py:210); '
+                                      'the masked branches are not built')
+        if self.training:
+            raise NotImplementedError('training-mode (batch-statistics) forward/backward on the HIP engine is the '
+                                      'next scope row (DESIGN.md); call .eval() for embedding extraction')
+        with torch.no_grad():
+            return self.engine().forward(x)
