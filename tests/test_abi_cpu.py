@@ -148,3 +148,26 @@ def test_metrics_match_oracle():
     e2, th2 = osc.eer(f2, p2, scores)
     assert e == e2 and th == th2 and 0.05 < e < 0.2
     assert compute_dcf(fnr, fpr) == osc.min_dcf(f2, p2)
+
+
+def test_ctx_path_does_not_deadlock(monkeypatch):
+    """ctx() nests lib()/load_library() under one lock: must fail fast without a device, not hang."""
+    import threading
+    from ppvector import _native as N
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
+    monkeypatch.setattr(torch.cuda, 'current_device', lambda: 0)
+    res = []
+
+    def run():
+        try:
+            N.ctx(0)
+            res.append('ok')
+        except N.VpmiError as e:
+            res.append(str(e))
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(30)
+    assert res and 'vp_create' in res[0]

@@ -113,7 +113,7 @@ _PROTOS = {
 EXPORTED_SYMBOLS = tuple(_PROTOS.keys())
 
 _lib = None
-_lock = threading.Lock()
+_lock = threading.RLock()      # re-entrant: ctx() -> lib() -> load_library() nest
 _ctx = {}
 
 
@@ -151,9 +151,10 @@ def ctx(device=None):
     device = torch.device(device).index if not isinstance(device, int) else device
     if device is None:
         device = torch.cuda.current_device()
+    library = lib()
     with _lock:
         if device not in _ctx:
-            h = lib().vp_create(device)
+            h = library.vp_create(device)
             if not h:
                 raise VpmiError(f'vp_create({device}) failed')
             _ctx[device] = h
