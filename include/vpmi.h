@@ -78,17 +78,18 @@ int vp_fbank_cmn_f32(vp_ctx* ctx, const float* wav, const float* lens_ratio, int
  *                    w[n][j*Cin+c] * x[b, src(t,j), c] ) ) )
  *   src(t,j) = t*stride - pad_left + j*dilation, reflected / zero-filled per pad_mode.
  * x, y, add_in, aux are (B*T, ld) row-major with a channel offset (so slices of a concat buffer
- * are addressed in place); channels [0, xsplit) of x may come from a second tensor x2 (KW == 1).
+ * are addressed in place); output columns [0, ysplit) can additionally be stored to a second
+ * tensor y2 (Res2Net's pass-through chunk y_0 = x_0 lands in the concat buffer for free).
  * aux = y + add_in (same dtype as y).  psum/psumsq: per (M-tile, utterance-segment) partial sums
  * of (y - bn_shift) and its square over the tile's rows, layout [tiles_m][nseg][Cout] f32.
- * Alignment: Cin, ldx, xoff, xsplit multiples of 16 B / sizeof(elem); Cout, ldy, yoff multiples of 4.
+ * Alignment: Cin, ldx, xoff multiples of 16 B / sizeof(elem); Cout, ldy, yoff, ysplit multiples of 4.
+ * Each operand tensor must be smaller than 4 GiB (32-bit buffer offsets).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
     int dtype_in, dtype_out;
     int B, T_in, T_out;
     int Cin, Cout, KW, dilation, stride, pad_left, pad_mode;
     const void* x;   int ldx, xoff;
-    const void* x2;  int ldx2, x2off, xsplit;
     const void* w;                       /* [Cout][KW*Cin], dtype_in */
     const float* bias;                   /* [Cout] or NULL */
     const float* rowbias;                /* [B][Cout] or NULL */
@@ -97,6 +98,7 @@ typedef struct {
     const float* bn_shift;               /* [Cout] or NULL: beta - mean * scale */
     int act2;                            /* VP_ACT_NONE | VP_ACT_TANH, applied after BN */
     void* y;         int ldy, yoff;
+    void* y2;        int ldy2, y2off, ysplit;   /* columns [0, ysplit) are ALSO stored to y2 */
     const void* add_in; int ld_add, add_off;
     void* aux;       int ld_aux, aux_off;
     float* psum;

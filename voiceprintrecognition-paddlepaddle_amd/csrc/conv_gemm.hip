@@ -23,14 +23,17 @@ constexpr int ROWB = 128;        // bytes of K per tile row per stage
 constexpr int NSEG_MAX = 8;
 
 struct ConvArgs {
-    const void* x; const void* x2; const void* w;
+    const void* x; const void* w;
     const float* bias; const float* rowbias; const float* bn_scale; const float* bn_shift;
-    void* y; const void* add_in; void* aux; float* psum; float* psumsq;
-    int ldx, xoff, ldx2, x2off, xsplit, ldy, yoff, ld_add, add_off, ld_aux, aux_off;
+    void* y; void* y2; const void* add_in; void* aux; float* psum; float* psumsq;
+    unsigned x_bytes, w_bytes;
+    int ldx, xoff, ldy, yoff, ldy2, y2off, ysplit, ld_add, add_off, ld_aux, aux_off;
     int M, N, K, KC, cpt, KT;
     int T_in, T_out, dilation, stride, pad_left, pad_mode, act, act2;
     int tiles_m, tiles_n, nseg;
 };
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { bf16x8 v; };
@@ -110,62 +113,69 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
     const int tm = swz / a.tiles_n, tn = swz - tm * a.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    const TI* __restrict__ X = static_cast<const TI*>(a.x);
-    const TI* __restrict__ X2 = static_cast<const TI*>(a.x2);
-    const TI* __restrict__ W = static_cast<const TI*>(a.w);
+    // Operands are fetched with buffer loads through wave-uniform resource descriptors: a 32-bit
+    // byte offset per lane, and anything that must read as zero (rows past M, channels past K, zero
+    // padding, weight rows past N) gets an out-of-range offset -- the hardware returns 0, no branch,
+    // no select on the loaded value, so the loads stay in flight across the MFMA block.
+    constexpr unsigned ES = sizeof(TI);
+    constexpr unsigned OOB = 0xfffffff0u;      // every dword of the 16-B access is >= num_records, no wrap
+    const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.w_bytes, 0x00020000);
 
     // global -> LDS staging assignment: 16-B chunk cc of rows r0 + 32 i
     const int cc = tid & 7, r0 = tid >> 3;
     const int pw = (cc ^ (r0 & 7)) << 4;
-    int rowbase[4], tpos[4];
-    bool rvalid[4];
+    unsigned rowoff[4], woff[BROWS];
+    int tpos[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + r0 + 32 * i;
-        rvalid[i] = m < a.M;
-        const int mm = rvalid[i] ? m : 0;
+        const bool ok = m < a.M;
+        const int mm = ok ? m : 0;
         const int b = mm / a.T_out;
         const int t = mm - b * a.T_out;
-        rowbase[i] = b * a.T_in;
+        rowoff[i] = ok ? ((unsigned)(b * a.T_in) * (unsigned)a.ldx + (unsigned)a.xoff) * ES : OOB;
         tpos[i] = t * a.stride - a.pad_left;
     }
-    uint4 ra[4], rb[BROWS];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) {
+        const int n = n0 + r0 + 32 * i;
+        woff[i] = n < a.N ? (unsigned)n * (unsigned)a.K * ES : OOB;
+    }
+    const bool zero_pad = a.pad_mode == VP_PAD_ZERO;
+    const unsigned ldxb = (unsigned)a.ldx * ES;
+    u32x4 ra[4], rb[BROWS];
 
     auto gload = [&](int kt) {
         const int q = kt * 8 + cc;
         const bool kv = q < a.KC;
         const int j = q / a.cpt;
-        const int c0 = (q - j * a.cpt) * EPC;
-        const TI* xb = X;
-        int ld = a.ldx, off = a.xoff;
-        if (c0 < a.xsplit) { xb = X2; ld = a.ldx2; off = a.x2off; }
+        const unsigned cb = (unsigned)(q - j * a.cpt) * 16u;          // byte offset of the chunk in its tap
+        const int tj = j * a.dilation;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int ts = tpos[i] + j * a.dilation;
-            bool ok = kv && rvalid[i];
-            if (a.pad_mode == VP_PAD_REFLECT) {
-                ts = ts < 0 ? -ts : ts;
-                ts = ts >= a.T_in ? 2 * (a.T_in - 1) - ts : ts;
-            } else if (a.pad_mode == VP_PAD_ZERO) {
-                ok = ok && ts >= 0 && ts < a.T_in;
-            }
-            ra[i] = ok ? *reinterpret_cast<const uint4*>(xb + (size_t)(rowbase[i] + ts) * ld + off + c0) : zero4;
+            const int traw = tpos[i] + tj;
+            int ts = traw < 0 ? -traw : traw;                          // reflect (identity when in range)
+            ts = ts >= a.T_in ? 2 * (a.T_in - 1) - ts : ts;
+            const bool inr = traw >= 0 && traw < a.T_in;
+            const bool ok = kv && rowoff[i] != OOB && (inr || !zero_pad);
+            const unsigned off = rowoff[i] + (unsigned)ts * ldxb + cb;
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrd, ok ? off : OOB, 0, 0);
         }
+        const unsigned kb = (unsigned)q * 16u;
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) {
-            const int n = n0 + r0 + 32 * i;
-            const bool ok = kv && n < a.N;
-            rb[i] = ok ? *reinterpret_cast<const uint4*>(W + (size_t)n * a.K + (size_t)q * EPC) : zero4;
+            const bool ok = kv && woff[i] != OOB;
+            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wsrd, ok ? woff[i] + kb : OOB, 0, 0);
         }
     };
     auto swrite = [&](int s) {
         char* As = smem + s * STAGE;
         char* Bs = As + BM * ROWB;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(As + (r0 + 32 * i) * ROWB + pw) = ra[i];
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(As + (r0 + 32 * i) * ROWB + pw) = ra[i];
 #pragma unroll
-        for (int i = 0; i < BROWS; ++i) *reinterpret_cast<uint4*>(Bs + (r0 + 32 * i) * ROWB + pw) = rb[i];
+        for (int i = 0; i < BROWS; ++i) *reinterpret_cast<u32x4*>(Bs + (r0 + 32 * i) * ROWB + pw) = rb[i];
     };
 
     f32x4 acc[MI][NI];
@@ -201,6 +211,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
 
     // ------------------------------------------------------------------ epilogue
     TO* __restrict__ Y = static_cast<TO*>(a.y);
+    TO* __restrict__ Y2 = static_cast<TO*>(a.y2);
     const TO* __restrict__ ADD = static_cast<const TO*>(a.add_in);
     TO* __restrict__ AUX = static_cast<TO*>(a.aux);
     const int bfirst = m0 / a.T_out;
@@ -237,6 +248,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
             }
             if (ok) {
                 store4(Y + (size_t)m * a.ldy + a.yoff + nb, v);
+                if (nb < a.ysplit) store4(Y2 + (size_t)m * a.ldy2 + a.y2off + nb, v);
                 if (AUX) {
                     float ad[4];
                     load4(ADD + (size_t)m * a.ld_add + a.add_off + nb, ad);
@@ -326,10 +338,15 @@ int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream) {
         VP_FAIL(ctx, VP_EINVAL, "conv1d: bad shape");
     if (d->Cin % epc || d->ldx % epc || d->xoff % epc) VP_FAIL(ctx, VP_EINVAL, "conv1d: Cin/ldx/xoff must be multiples of %d", epc);
     if (d->Cout % 4 || d->ldy % 4 || d->yoff % 4) VP_FAIL(ctx, VP_EINVAL, "conv1d: Cout/ldy/yoff must be multiples of 4");
-    if (d->xsplit) {
-        if (!d->x2 || d->KW != 1 || d->xsplit % epc || d->ldx2 % epc || d->x2off % epc || d->xsplit > d->Cin)
-            VP_FAIL(ctx, VP_EINVAL, "conv1d: bad x2 split");
+    if (d->ysplit) {
+        if (!d->y2 || d->ysplit % 4 || d->ldy2 % 4 || d->y2off % 4 || d->ysplit > d->Cout)
+            VP_FAIL(ctx, VP_EINVAL, "conv1d: bad y2 split");
     }
+    const size_t es = d->dtype_in == VP_BF16 ? 2 : 4;
+    const unsigned long long xbytes = ((unsigned long long)d->B * d->T_in - 1) * d->ldx * es + (d->xoff + d->Cin) * es;
+    const unsigned long long wbytes = (unsigned long long)d->Cout * d->KW * d->Cin * es;
+    if (xbytes >= 0xffffff00ull || wbytes >= 0xffffff00ull)
+        VP_FAIL(ctx, VP_EUNSUP, "conv1d: operand larger than 4 GiB (32-bit buffer offsets)");
     if (d->aux && (!d->add_in || d->ld_add % 4 || d->add_off % 4 || d->ld_aux % 4 || d->aux_off % 4))
         VP_FAIL(ctx, VP_EINVAL, "conv1d: bad aux/add_in");
     const int span = d->dilation * (d->KW - 1);
@@ -346,10 +363,11 @@ int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream) {
     if ((long long)d->B * d->T_out > 0x7fffffffLL / 2) VP_FAIL(ctx, VP_EINVAL, "conv1d: B*T too large");
     ConvArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = d->x; a.x2 = d->xsplit ? d->x2 : d->x; a.w = d->w; a.bias = d->bias; a.rowbias = d->rowbias;
+    a.x = d->x; a.w = d->w; a.bias = d->bias; a.rowbias = d->rowbias;
+    a.x_bytes = (unsigned)xbytes; a.w_bytes = (unsigned)wbytes; a.y2 = d->y2;
     a.bn_scale = d->bn_scale; a.bn_shift = d->bn_shift; a.y = d->y; a.add_in = d->add_in; a.aux = d->aux;
     a.psum = d->psum; a.psumsq = d->psumsq;
-    a.ldx = d->ldx; a.xoff = d->xoff; a.ldx2 = d->ldx2; a.x2off = d->x2off; a.xsplit = d->xsplit;
+    a.ldx = d->ldx; a.xoff = d->xoff; a.ldy2 = d->ldy2; a.y2off = d->y2off; a.ysplit = d->ysplit;
     a.ldy = d->ldy; a.yoff = d->yoff; a.ld_add = d->ld_add; a.add_off = d->add_off; a.ld_aux = d->ld_aux;
     a.aux_off = d->aux_off;
     a.M = d->B * d->T_out; a.N = d->Cout; a.K = d->KW * d->Cin; a.cpt = d->Cin / epc; a.KC = a.K / epc;

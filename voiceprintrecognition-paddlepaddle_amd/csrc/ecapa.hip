@@ -150,6 +150,7 @@ int vp_ecapa_fwd(vp_ctx* ctx, const vp_ecapa_weights* w, const void* feats, int 
         // tdnn1 (1x1)
         tdnn_desc(d, blk.tdnn1, dt, B, T, T, VP_PAD_REFLECT);
         d.x = xin; d.ldx = ld_in; d.xoff = off_in; d.y = p.t1; d.ldy = C;
+        d.y2 = p.r2; d.ldy2 = C; d.y2off = 0; d.ysplit = width;       // y_0 = x_0 goes straight into the concat
         if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
         // Res2Net chain: y_j = f_j(x_j + y_{j-1}); conv j writes y_j into r2 slice j and
         // (y_j + x_{j+1}) into the ping-pong input of conv j+1
@@ -168,9 +169,9 @@ int vp_ecapa_fwd(vp_ctx* ctx, const vp_ecapa_weights* w, const void* feats, int 
             tin = tout;
             tout = (tout == p.tmpA) ? p.tmpB : p.tmpA;
         }
-        // tdnn2 (1x1) over concat(y_0 = x_0 from t1, y_1.. from r2), with the SE time sums fused
+        // tdnn2 (1x1) over concat(y_0 .. y_{s-1}) = r2, with the SE time sums fused
         tdnn_desc(d, blk.tdnn2, dt, B, T, T, VP_PAD_REFLECT);
-        d.x = p.r2; d.ldx = C; d.xoff = 0; d.x2 = p.t1; d.ldx2 = C; d.x2off = 0; d.xsplit = width;
+        d.x = p.r2; d.ldx = C; d.xoff = 0;
         d.y = p.t2; d.ldy = C; d.psum = p.psum;
         if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
         // SE: mean over time -> 1x1 -> ReLU -> 1x1 -> sigmoid

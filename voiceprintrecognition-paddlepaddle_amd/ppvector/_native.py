@@ -33,10 +33,10 @@ class Conv1dDesc(C.Structure):
                 ('Cin', c_int), ('Cout', c_int), ('KW', c_int), ('dilation', c_int), ('stride', c_int),
                 ('pad_left', c_int), ('pad_mode', c_int),
                 ('x', c_void_p), ('ldx', c_int), ('xoff', c_int),
-                ('x2', c_void_p), ('ldx2', c_int), ('x2off', c_int), ('xsplit', c_int),
                 ('w', c_void_p), ('bias', c_void_p), ('rowbias', c_void_p), ('act', c_int),
                 ('bn_scale', c_void_p), ('bn_shift', c_void_p), ('act2', c_int),
                 ('y', c_void_p), ('ldy', c_int), ('yoff', c_int),
+                ('y2', c_void_p), ('ldy2', c_int), ('y2off', c_int), ('ysplit', c_int),
                 ('add_in', c_void_p), ('ld_add', c_int), ('add_off', c_int),
                 ('aux', c_void_p), ('ld_aux', c_int), ('aux_off', c_int),
                 ('psum', c_void_p), ('psumsq', c_void_p)]
