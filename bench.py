@@ -134,6 +134,37 @@ def cpu_baseline(target_s=15.0):
                       'reference algorithm restated on NumPy + PyTorch-CPU fp32 (not the PaddlePaddle binary)'}
 
 
+def shard_seed(base, rank):
+    """Each rank draws its own shard of the synthetic data (independent utterances, no overlap)."""
+    return base + rank
+
+
+def run_timed(step, steps, warmup, dist, device):
+    """W untimed steps, then exactly K steps between barrier + synchronize pairs; returns
+    (max-over-ranks seconds, last step result).  Works on CPU (gloo) for the world_size-2 test."""
+    sync = torch.cuda.synchronize if (device is not None and torch.device(device).type == 'cuda') else (lambda: None)
+    out = None
+    for _ in range(warmup):
+        out = step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    return dt, out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -165,7 +196,7 @@ def main():
 
     dev = torch.device('cuda', local_rank)
     # synthetic inputs, resident in HBM before the timed region (seed per rank: distinct shards)
-    wav = torch.from_numpy(ofb.synth_waves(BATCH, N_SAMPLES, seed=1000 + rank)).to(dev)
+    wav = torch.from_numpy(ofb.synth_waves(BATCH, N_SAMPLES, seed=shard_seed(1000, rank))).to(dev)
     labels = (torch.arange(BATCH, device=dev) * 7 + rank) % N_CLASSES
     fz = AudioFeaturizer('Fbank', dict(sr=16000, n_mels=N_MELS))
     model = EcapaTdnn(N_MELS, embd_dim=EMBD, pooling_type='ASP', channels=[512, 512, 512, 512, 1536])
@@ -183,24 +214,7 @@ def main():
         emb = eng.forward(feats)
         return crit(head(emb), labels)
 
-    for _ in range(args.warmup):
-        loss = step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
+    dt, loss = run_timed(step, args.steps, args.warmup, dist, dev)
     loss_v = float(loss)
     assert np.isfinite(loss_v)
 

@@ -1,0 +1,48 @@
+"""world_size-2 gloo test (CPU) of the N>1 bench path: the forward path shards by utterance with no
+data-path collective, so what N>1 adds is the barrier-bracketed timing and the max-over-ranks
+reduction.  (RCCL gradient all-reduce belongs to the training row, not built yet.)"""
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import bench
+    calls = []
+
+    def step():
+        time.sleep(0.01 * (rank + 1))          # rank 1 is the slow one
+        calls.append(1)
+        return len(calls)
+
+    dt, out = bench.run_timed(step, steps=5, warmup=2, dist=dist, device=torch.device('cpu'))
+    q.put((rank, dt, out, len(calls), bench.shard_seed(1000, rank)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_timing_is_max_over_ranks():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, dt0, out0, n0, s0), (r1, dt1, out1, n1, s1) = res
+    assert n0 == n1 == 7 and out0 == out1 == 7            # W + K steps each, exactly
+    assert abs(dt0 - dt1) < 1e-9                           # both report the reduced (max) time
+    assert dt0 >= 5 * 0.02 * 0.9                           # ... which is the slow rank's
+    assert s0 != s1                                        # distinct data shards

@@ -16,7 +16,7 @@ timeout 400 python bench.py --steps 10 --warmup 3 > gpurun_out/bench_$TAG.log 2>
 echo "bench rc=$?"
 tail -n 3 gpurun_out/bench_$TAG.log | cut -c 1-3000
 if [ "${PROF:-1}" = "1" ]; then
-  timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$TAG -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > gpurun_out/prof_$TAG.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > gpurun_out/prof_$TAG.log 2>&1
   echo "rocprof rc=$?"
   find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -n 1 | xargs -I{} cp {} gpurun_out/kernel_stats_$TAG.csv
   find gpurun_out/prof_$TAG -name "*kernel_trace.csv" -delete
