@@ -137,3 +137,19 @@ def test_training_mode_is_refused_not_faked(ecapa):
             ecapa(torch.zeros(2, 64, 80, device='cuda'))
     finally:
         ecapa.eval()
+
+
+def test_long_utterance_falls_back_to_per_conv_path(ecapa):
+    """T = 600 frames (6 s): the fused Res2 chain does not fit LDS (T > 512) and the engine must take
+    the per-conv launches; T = 28 (0.3 s, the reference's min_duration) exercises short tiles."""
+    p = om.ecapa_params(80, seed=1000)
+    for T, B in ((600, 2), (28, 3)):
+        g = torch.Generator().manual_seed(T)
+        x = torch.randn(B, T, 80, generator=g) * 3.0
+        with torch.no_grad():
+            ref = om.ecapa_forward(p, x).numpy()
+        for dtype, tol in (('float32', 2e-4), ('bfloat16', 6e-2)):
+            emb = ecapa.engine(dtype).forward(x.cuda()).cpu().numpy()
+            rel = np.linalg.norm(emb - ref) / np.linalg.norm(ref)
+            print(f'[T={T} {dtype}] rel-L2 {rel:.3e}')
+            assert rel < tol, (T, dtype, rel)

@@ -78,6 +78,11 @@ int vp_dense_f32_ex(vp_ctx* ctx, const float* a, int lda, const float* w, int w_
                     int ldo, hipStream_t st);
 int vp_asp_softmax_stats_ex(vp_ctx* ctx, int dtype, const float* logits, const void* x, int ldx, int xoff,
                             const float* center, int ldc, int B, int T, int C, float eps, float* pooled, hipStream_t st);
+int vp_res2_chain_bf16(vp_ctx* ctx, const vp_tdnn_layer* layers, int nconv, const void* t1, void* r2, int B, int T,
+                       int C, int width, hipStream_t st);
+int vp_asp_fused_bf16(vp_ctx* ctx, const void* h, const void* w, const float* bias, const void* x, int ldx,
+                      const float* center, int ldc, int B, int T, int C, int att, float eps, float* pooled,
+                      hipStream_t st);
 int vp_row_inv_norm(vp_ctx* ctx, const float* x, int rows, int D, int ld, float eps, float* inv, hipStream_t st);
 
 // kernels' host launchers (defined in the .hip files)

@@ -52,6 +52,10 @@ int run_asp(vp_ctx* ctx, const vp_asp_weights& A, int dtype, const void* x, int 
     d.y = w.h; d.ldy = A.att; d.yoff = 0;
     rc = vp_conv1d_fwd(ctx, &d, st);
     if (rc) return rc;
+    if (dtype == VP_BF16) {       // logits GEMM + softmax + weighted stats in one kernel; no (B*T, C) f32 logits
+        rc = vp_asp_fused_bf16(ctx, w.h, A.conv_w, A.conv_b, x, ldx, w.stats, 2 * C, B, T, C, A.att, 1e-12f, w.pooled, st);
+        if (rc != VP_EUNSUP) return rc;
+    }
     memset(&d, 0, sizeof(d));
     d.dtype_in = dtype; d.dtype_out = VP_F32; d.B = B; d.T_in = T; d.T_out = T; d.Cin = A.att; d.Cout = C;
     d.KW = 1; d.dilation = 1; d.stride = 1; d.pad_mode = VP_PAD_REFLECT; d.pad_left = 0;
@@ -152,11 +156,13 @@ int vp_ecapa_fwd(vp_ctx* ctx, const vp_ecapa_weights* w, const void* feats, int 
         d.x = xin; d.ldx = ld_in; d.xoff = off_in; d.y = p.t1; d.ldy = C;
         d.y2 = p.r2; d.ldy2 = C; d.y2off = 0; d.ysplit = width;       // y_0 = x_0 goes straight into the concat
         if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
-        // Res2Net chain: y_j = f_j(x_j + y_{j-1}); conv j writes y_j into r2 slice j and
-        // (y_j + x_{j+1}) into the ping-pong input of conv j+1
+        // Res2Net chain: fused per-utterance kernel when it fits LDS, else one launch per conv
+        int fused = VP_EUNSUP;
+        if (dt == VP_BF16) fused = vp_res2_chain_bf16(ctx, blk.res2, sc - 1, p.t1, p.r2, B, T, C, width, st);
+        if (fused != VP_OK && fused != VP_EUNSUP) return fused;
         void* tin = nullptr;
         void* tout = p.tmpA;
-        for (int j = 1; j < sc; ++j) {
+        for (int j = 1; j < sc && fused != VP_OK; ++j) {
             tdnn_desc(d, blk.res2[j - 1], dt, B, T, T, VP_PAD_REFLECT);
             if (j == 1) { d.x = p.t1; d.ldx = C; d.xoff = width; }
             else { d.x = tin; d.ldx = width; d.xoff = 0; }

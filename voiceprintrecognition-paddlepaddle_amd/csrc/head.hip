@@ -13,12 +13,17 @@
 
 namespace {
 
+// 64 columns x 4 row-groups per workgroup: coalesced 256-B row reads, fixed-order 4-way reduction
 __global__ __launch_bounds__(256) void col_inv_norm_kernel(const float* w, int D, int C, float eps, float* inv) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float sm[4][64];
+    const int lc = threadIdx.x & 63, dg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lc;
     float s = 0.f;
-    for (int d = 0; d < D; ++d) { float v = w[(size_t)d * C + c]; s += v * v; }
-    inv[c] = 1.f / fmaxf(sqrtf(s), eps);
+    if (c < C)
+        for (int d = dg; d < D; d += 4) { const float v = w[(size_t)d * C + c]; s += v * v; }
+    sm[dg][lc] = s;
+    __syncthreads();
+    if (dg == 0 && c < C) inv[c] = 1.f / fmaxf(sqrtf(sm[0][lc] + sm[1][lc] + sm[2][lc] + sm[3][lc]), eps);
 }
 
 struct AamArgs {
@@ -100,7 +105,7 @@ int vp_cosine_logits_f32(vp_ctx* ctx, const float* emb, const float* W, int B, i
     float* cinv = (float*)((char*)ws + vp_align_up((size_t)B * 4, 256));
     int rc = vp_row_inv_norm(ctx, emb, B, D, D, 1e-12f, rinv, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(col_inv_norm_kernel, dim3((C + 255) / 256), dim3(256), 0, st, W, D, C, 1e-12f, cinv);
+    hipLaunchKernelGGL(col_inv_norm_kernel, dim3((C + 63) / 64), dim3(256), 0, st, W, D, C, 1e-12f, cinv);
     VP_LAUNCH_CHECK(ctx, "col_inv_norm");
     return vp_dense_f32_ex(ctx, emb, D, W, /*w_is_kn=*/1, nullptr, rinv, cinv, B, C, D, VP_ACT_NONE, logits, C, st);
 }
