@@ -56,22 +56,22 @@ __global__ __launch_bounds__(256) void asp_fused_kernel(AspFusedArgs a) {
     float mx[2] = {-INFINITY, -INFINITY}, s0[2] = {0.f, 0.f}, s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
 
     const int ntile = (a.T + 15) / 16;
-    for (int mt = 0; mt < ntile; ++mt) {
-        // A operand: frames mt*16 + li of h
-        const int ta = min(mt * 16 + li, a.T - 1);
+    // loads of frame tile mt+1 are issued before the MFMAs / exps of tile mt (register double buffer)
+    auto load_tile = [&](int mt, bf16x8 (&hf)[4], bf16_t (&xr)[2][4]) {
+        const int ta = min(mt * 16 + li, a.T - 1);                    // A operand: frames mt*16 + li of h
         const bf16_t* hr = a.h + (row0 + ta) * AF_ATT;
-        bf16x8 hf[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) hf[ks] = *reinterpret_cast<const bf16x8*>(hr + (ks * 4 + g) * 8);
-        // this lane's result rows: frames mt*16 + g*4 + r
-        float xv[2][4];
-        const int t0 = mt * 16 + g * 4;
+        const int t0 = mt * 16 + g * 4;                                // result rows: frames t0 + r
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const size_t xr = (row0 + min(t0 + r, a.T - 1)) * a.ldx;
+            const size_t xo = (row0 + min(t0 + r, a.T - 1)) * a.ldx;
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) xv[ni][r] = (float)a.x[xr + ch[ni]] - mu0[ni];
+            for (int ni = 0; ni < 2; ++ni) xr[ni][r] = a.x[xo + ch[ni]];
         }
+    };
+    auto compute_tile = [&](int mt, const bf16x8 (&hf)[4], const bf16_t (&xr)[2][4]) {
+        const int t0 = mt * 16 + g * 4;
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
@@ -96,9 +96,22 @@ __global__ __launch_bounds__(256) void asp_fused_kernel(AspFusedArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float p = expf(e[r] - mx[ni]);              // exp(-inf) = 0 for frames past T
-                    s0[ni] += p; s1[ni] += p * xv[ni][r]; s2[ni] += p * xv[ni][r] * xv[ni][r];
+                    const float xv = (float)xr[ni][r] - mu0[ni];
+                    s0[ni] += p; s1[ni] += p * xv; s2[ni] += p * xv * xv;
                 }
             }
+        }
+    };
+    bf16x8 h0[4], h1[4];
+    bf16_t x0[2][4], x1[2][4];
+    load_tile(0, h0, x0);
+    for (int mt = 0; mt < ntile; mt += 2) {
+        const bool odd = mt + 1 < ntile;
+        if (odd) load_tile(mt + 1, h1, x1);
+        compute_tile(mt, h0, x0);
+        if (odd) {
+            if (mt + 2 < ntile) load_tile(mt + 2, h0, x0);
+            compute_tile(mt + 1, h1, x1);
         }
     }
 #pragma unroll

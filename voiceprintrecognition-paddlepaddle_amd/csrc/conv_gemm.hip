@@ -87,7 +87,7 @@ __device__ __forceinline__ void load4(const bf16_t* p, float v[4]) {
     v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
 }
 
-template <typename TI, typename TO, int BN>
+template <typename TI, typename TO, int BN, bool KW1>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
     constexpr int EPC = 16 / (int)sizeof(TI);        // elements per 16-B chunk
     constexpr int KSTEPS = (8 * EPC) / 32;           // MFMA k-steps per stage: bf16 2, f32 1
@@ -144,32 +144,55 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
     }
     const bool zero_pad = a.pad_mode == VP_PAD_ZERO;
     const unsigned ldxb = (unsigned)a.ldx * ES;
-    u32x4 ra[4], rb[BROWS];
+    // 1x1 convolutions (most of the flops): the source row of every staged row is fixed, only the
+    // K offset moves -- hoist the whole row address out of the K loop.
+    unsigned rowfix[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int traw = tpos[i];
+        int ts = traw < 0 ? -traw : traw;
+        ts = ts >= a.T_in ? 2 * (a.T_in - 1) - ts : ts;
+        const bool inr = traw >= 0 && traw < a.T_in;
+        rowfix[i] = (rowoff[i] != OOB && (inr || !zero_pad)) ? rowoff[i] + (unsigned)ts * ldxb : OOB;
+    }
 
-    auto gload = [&](int kt) {
+    // TWO register stages: the loads of K-stage k+2 are issued while stage k is computed and are
+    // written to LDS at the end of stage k+1, so a fetch has two stages of MFMA work to land
+    // (one stage was not enough to cover HBM/L2 latency with only two workgroups per CU).
+    u32x4 ra0[4], rb0[BROWS], ra1[4], rb1[BROWS];
+
+    auto gload = [&](int kt, u32x4 (&ra)[4], u32x4 (&rb)[BROWS]) {
         const int q = kt * 8 + cc;
         const bool kv = q < a.KC;
-        const int j = q / a.cpt;
-        const unsigned cb = (unsigned)(q - j * a.cpt) * 16u;          // byte offset of the chunk in its tap
-        const int tj = j * a.dilation;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int traw = tpos[i] + tj;
-            int ts = traw < 0 ? -traw : traw;                          // reflect (identity when in range)
-            ts = ts >= a.T_in ? 2 * (a.T_in - 1) - ts : ts;
-            const bool inr = traw >= 0 && traw < a.T_in;
-            const bool ok = kv && rowoff[i] != OOB && (inr || !zero_pad);
-            const unsigned off = rowoff[i] + (unsigned)ts * ldxb + cb;
-            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrd, ok ? off : OOB, 0, 0);
-        }
         const unsigned kb = (unsigned)q * 16u;
+        if constexpr (KW1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = kv && rowfix[i] != OOB;
+                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrd, ok ? rowfix[i] + kb : OOB, 0, 0);
+            }
+        } else {
+            const int j = q / a.cpt;
+            const unsigned cb = (unsigned)(q - j * a.cpt) * 16u;      // byte offset of the chunk in its tap
+            const int tj = j * a.dilation;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int traw = tpos[i] + tj;
+                int ts = traw < 0 ? -traw : traw;                      // reflect (identity when in range)
+                ts = ts >= a.T_in ? 2 * (a.T_in - 1) - ts : ts;
+                const bool inr = traw >= 0 && traw < a.T_in;
+                const bool ok = kv && rowoff[i] != OOB && (inr || !zero_pad);
+                const unsigned off = rowoff[i] + (unsigned)ts * ldxb + cb;
+                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrd, ok ? off : OOB, 0, 0);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) {
             const bool ok = kv && woff[i] != OOB;
             rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wsrd, ok ? woff[i] + kb : OOB, 0, 0);
         }
     };
-    auto swrite = [&](int s) {
+    auto swrite = [&](int s, const u32x4 (&ra)[4], const u32x4 (&rb)[BROWS]) {
         char* As = smem + s * STAGE;
         char* Bs = As + BM * ROWB;
 #pragma unroll
@@ -184,14 +207,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    gload(0);
-    swrite(0);
-    __syncthreads();
-    for (int kt = 0; kt < a.KT; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < a.KT;
-        if (more) gload(kt + 1);
-        const char* As = smem + cur * STAGE;
+    auto compute = [&](int s) {
+        const char* As = smem + s * STAGE;
         const char* Bs = As + BM * ROWB;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -205,7 +222,24 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) mma(wf[ni], xf[mi], acc[mi][ni]);
         }
-        if (more) swrite(cur ^ 1);
+    };
+
+    const int KT = a.KT;
+    gload(0, ra0, rb0);
+    if (KT > 1) gload(1, ra1, rb1);
+    swrite(0, ra0, rb0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; kt += 2) {
+        // even stage kt on LDS[0]; set0 <- stage kt+2; set1 (stage kt+1) -> LDS[1]
+        if (kt + 2 < KT) gload(kt + 2, ra0, rb0);
+        compute(0);
+        if (kt + 1 < KT) swrite(1, ra1, rb1);
+        __syncthreads();
+        if (kt + 1 >= KT) break;
+        // odd stage kt+1 on LDS[1]; set1 <- stage kt+3; set0 (stage kt+2) -> LDS[0]
+        if (kt + 3 < KT) gload(kt + 3, ra1, rb1);
+        compute(1);
+        if (kt + 2 < KT) swrite(0, ra0, rb0);
         __syncthreads();
     }
 
@@ -306,18 +340,23 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
     }
 }
 
-template <typename TI, typename TO, int BN>
-int launch(vp_ctx* ctx, const ConvArgs& a, hipStream_t st) {
+template <typename TI, typename TO, int BN, bool KW1>
+int launch1(vp_ctx* ctx, const ConvArgs& a, hipStream_t st) {
     constexpr int smem = 2 * (BM + BN) * ROWB;
     static bool attr_set = false;
     if (!attr_set) {
-        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_kernel<TI, TO, BN>),
+        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_kernel<TI, TO, BN, KW1>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_gemm_kernel<TI, TO, BN>), dim3(a.tiles_m * a.tiles_n), dim3(256), smem, st, a);
+    hipLaunchKernelGGL((conv_gemm_kernel<TI, TO, BN, KW1>), dim3(a.tiles_m * a.tiles_n), dim3(256), smem, st, a);
     VP_LAUNCH_CHECK(ctx, "conv_gemm");
     return VP_OK;
+}
+
+template <typename TI, typename TO, int BN>
+int launch(vp_ctx* ctx, const ConvArgs& a, hipStream_t st) {
+    return a.KC == a.cpt ? launch1<TI, TO, BN, true>(ctx, a, st) : launch1<TI, TO, BN, false>(ctx, a, st);
 }
 
 }  // namespace

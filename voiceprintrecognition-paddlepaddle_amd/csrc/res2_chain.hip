@@ -11,7 +11,8 @@
 //   - y_j goes to global memory once (slice j of the concat buffer), x_{j+1} is read once.
 // MFMA-bound in principle (2*T*64*192 flop per conv) but short: what it removes is 7 launches,
 // 7 HBM/L2 round trips of the activations and the aux buffers.  Used when T*w*2 bytes * 2 + weights
-// fit in LDS (T <= 512 at w = 64); longer utterances fall back to the per-conv path.
+// fit in LDS and each wave owns <= 3 frame tiles (T <= 384 at w = 64); longer utterances fall back
+// to the per-conv path.
 #include "common.h"
 
 namespace {
@@ -20,6 +21,7 @@ constexpr int R2_W = 64;            // chunk width (channels per Res2 scale slic
 constexpr int R2_K = 3 * R2_W;      // K of one conv
 constexpr int R2_THREADS = 512;
 constexpr int R2_WAVES = R2_THREADS / 64;
+constexpr int R2_ROUNDS = 3;        // frame tiles (16 frames) per wave: T <= 16 * 8 * 3 = 384
 
 struct Res2Args {
     const bf16_t* t1;        // (B*T, C): tdnn1 output, x_j = columns [j*w, (j+1)*w)
@@ -78,14 +80,36 @@ __global__ __launch_bounds__(R2_THREADS, 1) void res2_chain_kernel(Res2Args a) {
         *reinterpret_cast<uint4*>(act0 + t * 128 + ((c ^ (t & 7)) << 4)) = v;
     }
     store_weights(0);
-    __syncthreads();
 
     const int ntile = a.TP / 16;
+    // per-conv epilogue parameters live in LDS (read as float4 per N-tile) to keep VGPRs for prefetch
+    float* prm = reinterpret_cast<float*>(wt0 + 2 * WT_BYTES);          // [nconv][3][64]
+    for (int i = tid; i < a.nconv * 192; i += R2_THREADS) {
+        const int j = i / 192, k = i - j * 192, which = k >> 6, n = k & 63;
+        prm[i] = which == 0 ? a.bias[j][n] : (which == 1 ? a.scale[j][n] : a.shift[j][n]);
+    }
+    // x_{j+2} rows of this wave's frames, prefetched ONE CONV AHEAD (global latency ~ a whole conv)
+    bf16x4 xcur[R2_ROUNDS][4], xnxt[R2_ROUNDS][4];
+    auto fetch_x = [&](int j, bf16x4 (&dst)[R2_ROUNDS][4]) {           // x chunk used by conv j's epilogue
+        const int col = (j + 2) * R2_W;
+#pragma unroll
+        for (int r = 0; r < R2_ROUNDS; ++r) {
+            const int t = min((wv + r * R2_WAVES) * 16 + li, a.T - 1);
+            const bf16_t* xp = a.t1 + (row0 + t) * a.C + col;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) dst[r][ni] = *reinterpret_cast<const bf16x4*>(xp + ni * 16 + g * 4);
+        }
+    };
+    if (a.nconv > 1) fetch_x(0, xcur);
+    __syncthreads();
+
     for (int j = 0; j < a.nconv; ++j) {
         const char* ain = act0 + (j & 1) * act_bytes;
         char* aout = act0 + ((j + 1) & 1) * act_bytes;
         const char* wl = wt0 + (j & 1) * WT_BYTES;
-        if (j + 1 < a.nconv) fetch_weights(j + 1);                  // in flight under this conv's MFMAs
+        const bool has_next = j + 1 < a.nconv;
+        if (has_next) fetch_weights(j + 1);                           // in flight under this conv's MFMAs
+        if (j + 2 < a.nconv) fetch_x(j + 1, xnxt);
         // weight fragments for the 4 N-tiles x 3 taps x 2 k-steps: registers, reused for every frame
         bf16x8 wf[4][6];
 #pragma unroll
@@ -97,28 +121,13 @@ __global__ __launch_bounds__(R2_THREADS, 1) void res2_chain_kernel(Res2Args a) {
                 wf[ni][s] = *reinterpret_cast<const bf16x8*>(wl + n * 384 + (((c & ~7) | ((c ^ n) & 7)) << 4));
             }
         }
-        float bias4[4][4], sc4[4][4], sh4[4][4];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int nb = ni * 16 + g * 4;
-            const float4 bb = *reinterpret_cast<const float4*>(a.bias[j] + nb);
-            const float4 ss = *reinterpret_cast<const float4*>(a.scale[j] + nb);
-            const float4 hh = *reinterpret_cast<const float4*>(a.shift[j] + nb);
-            bias4[ni][0] = bb.x; bias4[ni][1] = bb.y; bias4[ni][2] = bb.z; bias4[ni][3] = bb.w;
-            sc4[ni][0] = ss.x; sc4[ni][1] = ss.y; sc4[ni][2] = ss.z; sc4[ni][3] = ss.w;
-            sh4[ni][0] = hh.x; sh4[ni][1] = hh.y; sh4[ni][2] = hh.z; sh4[ni][3] = hh.w;
-        }
+        const float* pj = prm + j * 192;
         const int slice = (j + 1) * R2_W;                             // y_{j+1} in the reference's numbering
-        const bool has_next = j + 1 < a.nconv;
-        for (int mt = wv; mt < ntile; mt += R2_WAVES) {
-            const int t = mt * 16 + li;                                // this lane's frame (B operand column)
-            const int tc = min(t, a.T - 1);
-            const bf16_t* xnext = a.t1 + (row0 + tc) * a.C + slice + R2_W;
-            bf16x4 xn[4];
-            if (has_next) {                                            // x_{j+2}: fetched under the MFMAs
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) xn[ni] = *reinterpret_cast<const bf16x4*>(xnext + ni * 16 + g * 4);
-            }
+        for (int r = 0; r < R2_ROUNDS; ++r) {
+            const int mt = wv + r * R2_WAVES;
+            if (mt >= ntile) break;                                    // wave-uniform
+            const int t = mt * 16 + li;                                // this lane's frame (B operand column)
             f32x4 acc[4];
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) acc[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -141,24 +150,33 @@ __global__ __launch_bounds__(R2_THREADS, 1) void res2_chain_kernel(Res2Args a) {
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
                     const int nb = ni * 16 + g * 4;
+                    const float4 bb = *reinterpret_cast<const float4*>(pj + nb);
+                    const float4 ss = *reinterpret_cast<const float4*>(pj + 64 + nb);
+                    const float4 hh = *reinterpret_cast<const float4*>(pj + 128 + nb);
                     float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        v[r] = fmaxf(acc[ni][r] + bias4[ni][r], 0.f) * sc4[ni][r] + sh4[ni][r];
+                    v[0] = fmaxf(acc[ni][0] + bb.x, 0.f) * ss.x + hh.x;
+                    v[1] = fmaxf(acc[ni][1] + bb.y, 0.f) * ss.y + hh.y;
+                    v[2] = fmaxf(acc[ni][2] + bb.z, 0.f) * ss.z + hh.z;
+                    v[3] = fmaxf(acc[ni][3] + bb.w, 0.f) * ss.w + hh.w;
                     bf16x4 o;
                     o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
                     *reinterpret_cast<bf16x4*>(yrow + nb) = o;
                     if (has_next) {
+                        const bf16x4 xn = xcur[r][ni];
                         bf16x4 s;
-                        s[0] = (bf16_t)(v[0] + (float)xn[ni][0]); s[1] = (bf16_t)(v[1] + (float)xn[ni][1]);
-                        s[2] = (bf16_t)(v[2] + (float)xn[ni][2]); s[3] = (bf16_t)(v[3] + (float)xn[ni][3]);
+                        s[0] = (bf16_t)(v[0] + (float)xn[0]); s[1] = (bf16_t)(v[1] + (float)xn[1]);
+                        s[2] = (bf16_t)(v[2] + (float)xn[2]); s[3] = (bf16_t)(v[3] + (float)xn[3]);
                         // channel nb lives in 16-B chunk nb/8, byte (nb % 8) * 2 of row t
                         *reinterpret_cast<bf16x4*>(aout + t * 128 + (((nb >> 3) ^ (t & 7)) << 4) + (nb & 7) * 2) = s;
                     }
                 }
             }
         }
-        if (j + 1 < a.nconv) store_weights((j + 1) & 1);
+        if (has_next) store_weights((j + 1) & 1);
+#pragma unroll
+        for (int r = 0; r < R2_ROUNDS; ++r)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) xcur[r][ni] = xnxt[r][ni];
         __syncthreads();
     }
 }
@@ -170,8 +188,8 @@ int vp_res2_chain_bf16(vp_ctx* ctx, const vp_tdnn_layer* layers, int nconv, cons
                        int C, int width, hipStream_t st) {
     if (width != R2_W || nconv < 1 || nconv > VP_MAX_RES2) return VP_EUNSUP;
     const int TP = (T + 15) / 16 * 16;
-    const size_t smem = (size_t)2 * TP * 128 + 2 * (size_t)R2_W * R2_K * 2;
-    if (smem > 160 * 1024 || T < 2) return VP_EUNSUP;
+    const size_t smem = (size_t)2 * TP * 128 + 2 * (size_t)R2_W * R2_K * 2 + (size_t)nconv * 192 * 4;
+    if (smem > 160 * 1024 || T < 2 || TP / 16 > R2_WAVES * R2_ROUNDS) return VP_EUNSUP;
     const int dil = layers[0].dil;
     Res2Args a;
     memset(&a, 0, sizeof(a));
