@@ -45,6 +45,10 @@ struct FbankArgs {
     int remove_dc;
 };
 
+// FFT work-buffer index with one padding slot every 16 complex points (the Stockham scatter strides
+// 4 / 16 / 64 points would otherwise hit the same LDS banks 8-16 ways)
+__device__ __forceinline__ int pidx(int i) { return i + (i >> 4); }
+
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
@@ -56,7 +60,7 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_frames_kernel(FbankArgs a
     __shared__ int s_mstart[FB_MAX_MEL + 1];
     __shared__ int s_mbin0[FB_MAX_MEL];
     __shared__ float s_frame[FB_WAVES][FB_MAX_WIN];
-    __shared__ float2 s_buf[FB_WAVES][2][FB_NC];
+    __shared__ float2 s_buf[FB_WAVES][2][FB_NC + FB_NC / 16];   // one pad slot per 16: breaks the power-of-2 strides
     __shared__ float s_pow[FB_WAVES][FB_NC];
     __shared__ float s_red[FB_WAVES][FB_MAX_MEL];
 
@@ -77,16 +81,30 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_frames_kernel(FbankArgs a
     float acc0 = 0.f, acc1 = 0.f;   // column sums for mel bins lane and lane+64
     float* fr = s_frame[wv];
 
+    // The NEXT frame's window is fetched into registers while the current frame is transformed:
+    // a wave has nothing else to overlap the ~2k-cycle global latency with.
+    constexpr int NLD = FB_MAX_WIN / 64;             // 8 samples per lane cover windows up to 512
+    float nxt[NLD];
+    auto fetch = [&](int t) {
+        const float* src = wav + (size_t)min(t, a.T - 1) * a.shift;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int i = lane + 64 * u;
+            nxt[u] = src[min(i, a.win - 1)];
+        }
+    };
+    fetch(tile * FRAMES_PER_WG + wv);
+
     for (int fi = wv; fi < FRAMES_PER_WG; fi += FB_WAVES) {
         const int t = tile * FRAMES_PER_WG + fi;
         if (t >= a.T) break;                         // wave-uniform
-        const float* src = wav + (size_t)t * a.shift;
         float part = 0.f;
-        for (int i = lane; i < a.win; i += 64) {
-            float v = src[i];
-            fr[i] = v;
-            part += v;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int i = lane + 64 * u;
+            if (i < a.win) { fr[i] = nxt[u]; part += nxt[u]; }
         }
+        fetch(t + FB_WAVES);                         // clamped; unused past the tile / utterance end
         float mean = a.remove_dc ? vp_wave_sum(part) / (float)a.win : 0.f;
         __builtin_amdgcn_wave_barrier();
         // even/odd pack: z[n] = x[2n] + i x[2n+1], zero beyond the window
@@ -107,7 +125,7 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_frames_kernel(FbankArgs a
                 float p = fr[i1 - 1] - mean;
                 im = (c - a.preemph * p) * s_win[i1];
             }
-            d0[n] = make_float2(re, im);
+            d0[pidx(n)] = make_float2(re, im);
         }
         __builtin_amdgcn_wave_barrier();
         // 256-point complex FFT: Stockham radix-4, Ns = 1, 4, 16, 64; thread j = lane
@@ -116,10 +134,10 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_frames_kernel(FbankArgs a
             const int Ns = 1 << (2 * s);
             const int jm = lane & (Ns - 1);
             const int twstep = (FB_NFFT / 4) >> (2 * s);     // 512 / (4 * Ns)
-            float2 v0 = d0[lane];
-            float2 v1 = d0[lane + 64];
-            float2 v2 = d0[lane + 128];
-            float2 v3 = d0[lane + 192];
+            float2 v0 = d0[pidx(lane)];
+            float2 v1 = d0[pidx(lane + 64)];
+            float2 v2 = d0[pidx(lane + 128)];
+            float2 v3 = d0[pidx(lane + 192)];
             v1 = cmul(v1, s_tw[(jm * twstep) & (FB_NFFT - 1)]);
             v2 = cmul(v2, s_tw[(2 * jm * twstep) & (FB_NFFT - 1)]);
             v3 = cmul(v3, s_tw[(3 * jm * twstep) & (FB_NFFT - 1)]);
@@ -133,10 +151,10 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_frames_kernel(FbankArgs a
             float2 o1 = make_float2(d02.x + d13.y, d02.y - d13.x);   // d02 - i*d13
             float2 o3 = make_float2(d02.x - d13.y, d02.y + d13.x);   // d02 + i*d13
             const int idx = ((lane >> (2 * s)) << (2 * s + 2)) + jm;  // (j/Ns)*Ns*4 + j%Ns
-            d1[idx] = o0;
-            d1[idx + Ns] = o1;
-            d1[idx + 2 * Ns] = o2;
-            d1[idx + 3 * Ns] = o3;
+            d1[pidx(idx)] = o0;
+            d1[pidx(idx + Ns)] = o1;
+            d1[pidx(idx + 2 * Ns)] = o2;
+            d1[pidx(idx + 3 * Ns)] = o3;
             __builtin_amdgcn_wave_barrier();
             float2* tmp = d0; d0 = d1; d1 = tmp;
         }
@@ -144,8 +162,8 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_frames_kernel(FbankArgs a
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int k = lane + 64 * r;
-            float2 zk = d0[k];
-            float2 zn = d0[(FB_NC - k) & (FB_NC - 1)];
+            float2 zk = d0[pidx(k)];
+            float2 zn = d0[pidx((FB_NC - k) & (FB_NC - 1))];
             float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
             float2 o = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));  // (zk - conj(zn)) / (2i)
             float2 wo = cmul(o, s_tw[k]);
@@ -155,9 +173,23 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_frames_kernel(FbankArgs a
         __builtin_amdgcn_wave_barrier();
         float* orow = a.out + ((size_t)b * a.T + t) * a.n_mels;
         for (int m = lane, it = 0; m < a.n_mels; m += 64, ++it) {
-            const int s0 = s_mstart[m], s1 = s_mstart[m + 1], k0 = s_mbin0[m];
+            const int s0 = s_mstart[m], n = s_mstart[m + 1] - s0, k0 = s_mbin0[m];
             float e = 0.f;
-            for (int q = s0; q < s1; ++q) e += s_melw[q] * s_pow[wv][k0 + (q - s0)];
+            // 4 taps per trip, loads independent of the accumulator: one LDS latency per 4 taps
+            for (int q = 0; q < n; q += 4) {
+                float wq[4], pq[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool in = q + u < n;
+                    const float wv_ = s_melw[min(s0 + q + u, a.nnz - 1)];
+                    wq[u] = in ? wv_ : 0.f;
+                    pq[u] = s_pow[wv][min(k0 + q + u, FB_NC - 1)];
+                }
+                e += wq[0] * pq[0];
+                e += wq[1] * pq[1];
+                e += wq[2] * pq[2];
+                e += wq[3] * pq[3];
+            }
             float v = logf(fmaxf(e, a.log_floor));
             orow[m] = v;
             if (it == 0) acc0 += v; else acc1 += v;
