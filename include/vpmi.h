@@ -75,7 +75,7 @@ int vp_fbank_cmn_f32(vp_ctx* ctx, const float* wav, const float* lens_ratio, int
  * (ecapa_tdnn.py:69-78) and AttentiveStatisticsPooling's global context (pooling.py:97-104) need.
  *
  *   y[b,t,n] = act2( bn( act( bias[n] + rowbias[b,n] + sum_{j<KW} sum_{c<Cin}
- *                    w[n][j*Cin+c] * x[b, src(t,j), c] ) ) )
+ *                    w[n][j*Cin+c] * pro(x[b, src(t,j), c]) ) ) * gate[b,seg(t),n] + res[b,t,n] )
  *   src(t,j) = t*stride - pad_left + j*dilation, reflected / zero-filled per pad_mode.
  * x, y, add_in, aux are (B*T, ld) row-major with a channel offset (so slices of a concat buffer
  * are addressed in place); output columns [0, ysplit) can additionally be stored to a second
@@ -88,21 +88,27 @@ int vp_fbank_cmn_f32(vp_ctx* ctx, const float* wav, const float* lens_ratio, int
 typedef struct {
     int dtype_in, dtype_out;
     int B, T_in, T_out;
-    int Cin, Cout, KW, dilation, stride, pad_left, pad_mode;
+    int Cin, Cout, KW, dilation, stride, pad_left, pad_mode;   /* KW = total taps (KT*KF for 2-D) */
     const void* x;   int ldx, xoff;
-    const void* w;                       /* [Cout][KW*Cin], dtype_in */
+    const void* w;                       /* [Cout][KW*Cin], dtype_in; 2-D: tap = kt*KF + kf */
     const float* bias;                   /* [Cout] or NULL */
     const float* rowbias;                /* [B][Cout] or NULL */
     int act;                             /* VP_ACT_NONE | VP_ACT_RELU, applied before BN */
     const float* bn_scale;               /* [Cout] or NULL: gamma / sqrt(var + eps) */
     const float* bn_shift;               /* [Cout] or NULL: beta - mean * scale */
-    int act2;                            /* VP_ACT_NONE | VP_ACT_TANH, applied after BN */
+    int act2;                            /* VP_ACT_NONE | VP_ACT_TANH | VP_ACT_RELU, applied last */
     void* y;         int ldy, yoff;
     void* y2;        int ldy2, y2off, ysplit;   /* columns [0, ysplit) are ALSO stored to y2 */
     const void* add_in; int ld_add, add_off;
     void* aux;       int ld_aux, aux_off;
     float* psum;
     float* psumsq;
+    /* --- extensions used by CAM++ (campplus.py); zero / NULL = off --------------------------------- */
+    int F_in, F_out, KF, stride_f, pad_f;        /* 2-D conv over (time, freq): rows are (b, t, f)      */
+    const float* pro_scale;              /* [Cin] BN-affine + ReLU on the INPUT channels (KW == 1)      */
+    const float* pro_shift;
+    const void* res; int ld_res, res_off;        /* residual added after BN, before act2 (dtype_out)     */
+    const float* gate; int gate_len, gate_nseg;  /* [B*gate_nseg][Cout]: y *= gate[b, t / gate_len, :]   */
 } vp_conv1d_desc;
 
 int vp_conv1d_tiles_m(int B, int T_out);            /* rows of the psum arrays                     */
@@ -195,6 +201,62 @@ typedef struct {
 size_t vp_tdnn_workspace_bytes(const vp_tdnn_weights* w, int B, int T);
 int vp_tdnn_fwd(vp_ctx* ctx, const vp_tdnn_weights* w, const void* feats, int B, int T, float* emb,
                 void* ws, size_t ws_bytes, vp_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * CAM++ backbone forward, eval mode -- replaces CAMPPlus.forward (models/campplus.py:331-335):
+ * FCM head (:246-281), TDNNLayer (:38-64), CAMDenseTDNNBlock x3 (:145-173) with CAMLayer context
+ * gating (:67-106), TransitLayer (:176-189), BN-ReLU + statistics_pooling (:24-30), DenseLayer (:192-208).
+ * 2-D conv weights: [Cout][tap*Cin + c] with tap = kt*3 + kf (time-major taps); vp_tdnn_layer.kw = 9
+ * for 3x3, 1 for the 1x1 shortcut.  tdnn.w is permuted so that its input channel index is f*32 + c.
+ * ---------------------------------------------------------------------------------------------- */
+#define VP_MAX_CAM_LAYERS 64
+#define VP_MAX_CAM_BLOCKS 4
+
+typedef struct {
+    vp_tdnn_layer conv1, conv2, shortcut;   /* BN folded to bn_scale/bn_shift of each */
+    int stride, has_shortcut;
+} vp_resblock;
+
+typedef struct {
+    const float* bn1_scale;   /* [cin]: nonlinear1 (BN) of the layer input, ReLU follows */
+    const float* bn1_shift;
+    vp_tdnn_layer linear1;    /* 1x1 cin -> bn_channels; bn_scale/shift = nonlinear2, ReLU follows */
+    vp_tdnn_layer local;      /* cam_layer.linear_local: k3, dilation, zero 'same' pad, bias only */
+    const float* ctx_w1;      /* [bn_channels/2][bn_channels] f32 */
+    const float* ctx_b1;
+    const float* ctx_w2;      /* [growth][bn_channels/2] f32 */
+    const float* ctx_b2;
+} vp_cam_layer;
+
+typedef struct {
+    const float* bn_scale;    /* [cin] */
+    const float* bn_shift;
+    vp_tdnn_layer linear;     /* 1x1 cin -> cin/2, bias */
+} vp_transit;
+
+typedef struct {
+    int dtype;
+    int feat_dim, embd_dim, m_channels, init_channels, growth, bn_channels, seg_len;
+    int n_blocks;
+    int block_layers[VP_MAX_CAM_BLOCKS];
+    const float* fcm1_w;      /* [32][9] f32, tap = kt*3 + kf */
+    const float* fcm1_b;
+    const float* fcm1_scale;
+    const float* fcm1_shift;
+    vp_resblock res[4];
+    vp_tdnn_layer fcm_conv2;
+    vp_tdnn_layer tdnn;
+    vp_cam_layer layers[VP_MAX_CAM_LAYERS];
+    vp_transit transit[VP_MAX_CAM_BLOCKS];
+    const float* out_bn_scale;
+    const float* out_bn_shift;
+    const float* dense_w;     /* [embd][2*C_final] f32 with the trailing BN folded in */
+    const float* dense_b;
+} vp_campplus_weights;
+
+size_t vp_campplus_workspace_bytes(const vp_campplus_weights* w, int B, int T);
+int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats, int B, int T, float* emb,
+                    void* ws, size_t ws_bytes, vp_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Cosine classifier + AAM-softmax loss -- replaces SpeakerIdentification.forward 'Cosine' branch

@@ -132,6 +132,26 @@ def main():
     cmp('tdnn eval emb', e_or, e_ref, 2e-5)
     out['tdnn_ref_small.npz'] = dict(x=x, emb_eval=e_ref.numpy(), param_seed=np.int64(1000))
 
+    # ---------------- CAM++ (configs/cam++.yml: embd_dim 192), F=80
+    from oracle import campplus as oc
+    ref_cam = importlib.import_module('ppvector.models.campplus')
+    pc = oc.campplus_params(input_size=F_, embd_dim=192, seed=1000)
+    cm = ref_cam.CAMPPlus(input_size=F_, embd_dim=192)
+    sdc = cm.state_dict()
+    assert set(sdc.keys()) == set(pc.keys()), sorted(set(sdc.keys()) ^ set(pc.keys()))[:10]
+    for k in sdc:
+        assert tuple(sdc[k].shape) == tuple(pc[k].shape), k
+    cm.load_state_dict(pc)
+    cm.eval()
+    nt, nb_ = om.count_params(pc)
+    print(f'CAM++ F=80 embd 192 params: trainable {nt}, buffers {nb_}')
+    xc = rng.standard_normal((2, 230, F_)).astype(np.float32) * 3.0       # 230 frames -> 115 after stride 2: 2 segments
+    with torch.no_grad():
+        ec_ref = cm(paddle_shim.to_tensor(xc))
+        ec_or = oc.campplus_forward(pc, torch.from_numpy(xc))
+    cmp('cam++ eval emb', ec_or, ec_ref, 2e-5)
+    out['campplus_ref_small.npz'] = dict(x=xc, emb_eval=ec_ref.numpy(), param_seed=np.int64(1000))
+
     # ---------------- real speech: 4 reference WAVs (3 s crops) -> oracle Fbank -> reference ECAPA graph
     names = ['a_1', 'a_2', 'b_1', 'b_2']
     pcm = np.stack([read_wav_16k_mono(f'{REF}/dataset/{n}.wav') for n in names])

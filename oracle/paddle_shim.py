@@ -56,6 +56,14 @@ class Tensor(torch.Tensor):
     def clip(self, min=None, max=None):
         return super().clamp(min=min, max=max)
 
+    def std(self, axis=None, unbiased=True, keepdim=False):
+        return super().std(dim=axis, unbiased=unbiased, keepdim=keepdim)
+
+    def reshape(self, *shape):
+        if len(shape) == 1 and isinstance(shape[0], (list, tuple)):
+            shape = tuple(shape[0])
+        return super().reshape(*shape)
+
     def flatten(self, start_axis=0, stop_axis=-1):
         return super().flatten(start_axis, stop_axis)
 
@@ -277,6 +285,13 @@ class LayerList(torch.nn.ModuleList):
     def forward(self, *a, **k):
         raise NotImplementedError
 
+    def add_sublayer(self, name, layer):
+        self.add_module(name, layer)
+        return layer
+
+    def __call__(self, *a, **k):
+        return _wrap(super().__call__(*a, **k))
+
 
 class Sequential(torch.nn.Sequential):
     def __init__(self, *layers):
@@ -318,6 +333,17 @@ def _normalize(x, p=2, axis=1, epsilon=1e-12):
     return _wrap(x / x.norm(p=p, dim=axis, keepdim=True).clamp(min=epsilon))
 
 
+def _avg_pool1d(x, kernel_size, stride=None, padding=0, exclusive=True, ceil_mode=False):
+    # Paddle default exclusive=True: a ceil-mode partial window averages over its valid elements only
+    assert padding == 0 and exclusive
+    stride = stride or kernel_size
+    T = x.shape[-1]
+    n = (T - kernel_size + stride - 1) // stride + 1 if ceil_mode else (T - kernel_size) // stride + 1
+    outs = [x[..., i * stride:min(i * stride + kernel_size, T)].mean(dim=-1, keepdim=True) for i in range(n)]
+    return _wrap(torch.cat(outs, dim=-1))
+
+
+F.avg_pool1d = _avg_pool1d
 F.pad = _pad
 F.normalize = _normalize
 F.relu = lambda x: _wrap(torch.relu(x))

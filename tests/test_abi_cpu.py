@@ -55,7 +55,7 @@ def test_no_cpu_fallback():
         m(torch.zeros(1, 50, 80))
 
 
-@pytest.mark.parametrize('cfg', ['ecapa_tdnn.yml', 'tdnn.yml'])
+@pytest.mark.parametrize('cfg', ['ecapa_tdnn.yml', 'tdnn.yml', 'cam++.yml'])
 def test_reference_configs_build(cfg):
     from ppvector.loss import build_loss
     from ppvector.models import build_model
@@ -67,7 +67,8 @@ def test_reference_configs_build(cfg):
     else:                           # same keys, restated (the reference tree does not travel)
         model = {'ecapa_tdnn.yml': dict(model='EcapaTdnn', model_args=dict(embd_dim=192, pooling_type='ASP',
                                                                            channels=[512, 512, 512, 512, 1536])),
-                 'tdnn.yml': dict(model='TDNN', model_args=dict(embd_dim=192, pooling_type='ASP'))}[cfg]
+                 'tdnn.yml': dict(model='TDNN', model_args=dict(embd_dim=192, pooling_type='ASP')),
+                 'cam++.yml': dict(model='CAMPPlus', model_args=dict(embd_dim=192))}[cfg]
         model['classifier'] = dict(classifier_type='Cosine', num_speakers=2796, num_blocks=0)
         raw = dict(preprocess_conf=dict(feature_method='Fbank', method_args=dict(sr=16000, n_mels=80)),
                    model_conf=model,
@@ -171,3 +172,25 @@ def test_ctx_path_does_not_deadlock(monkeypatch):
     t.start()
     t.join(30)
     assert res and 'vp_create' in res[0]
+
+
+def test_audio_segment_front_end(tmp_path):
+    """Host audio front end of the predictor (yeaudio semantics restated): WAV decode, stereo down-mix,
+    resample, dB normalisation."""
+    import wave
+    from ppvector.predict import AudioSegment
+    sr = 44100
+    t = np.arange(sr) / sr
+    x = (0.25 * np.sin(2 * np.pi * 440 * t)).astype(np.float32)
+    st = np.stack([x, 0.5 * x], axis=1)
+    p = str(tmp_path / 's.wav')
+    with wave.open(p, 'wb') as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(sr)
+        w.writeframes((st * 32767).astype(np.int16).tobytes())
+    seg = AudioSegment.from_file(p)
+    assert seg.sample_rate == sr and seg.samples.ndim == 1 and abs(seg.duration - 1.0) < 1e-3
+    assert np.max(np.abs(seg.samples - 0.75 * x)) < 1e-3
+    seg.resample(16000)
+    assert seg.sample_rate == 16000 and abs(len(seg.samples) - 16000) <= 1
+    seg.normalize(target_db=-20)
+    assert abs(seg.rms_db - (-20.0)) < 1e-3

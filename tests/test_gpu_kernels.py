@@ -370,3 +370,119 @@ def test_cosine_scores(N):
     a, b = g.standard_normal((37, 192)).astype(np.float32), g.standard_normal((9, 192)).astype(np.float32)
     got = cosine_score_matrix(dev(a), dev(b)).cpu().numpy()
     assert np.max(np.abs(got - osc.cosine_matrix(a.astype(np.float64), b.astype(np.float64)))) < 1e-6
+
+
+# --------------------------------------------------------------------------------------- conv extensions (CAM++)
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('stride_f,kw', [(1, 9), (2, 9), (2, 1)])
+def test_conv2d_resblock_epilogue(N, dtype, stride_f, kw):
+    """2-D conv over (time, freq) on (B,T,F,C) tensors with BN, residual add and ReLU
+    (BasicResBlock, campplus.py:238-243; shortcut 1x1 stride (2,1))."""
+    B, T, Fq, Cin, Cout = 2, 21, 12, 32, 32
+    tdt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    g = torch.Generator().manual_seed(5 + stride_f + kw)
+    x = torch.randn(B, T, Fq, Cin, generator=g, dtype=torch.float64)
+    k = 3 if kw == 9 else 1
+    w = torch.randn(Cout, Cin, k, k, generator=g, dtype=torch.float64) / (Cin * k * k) ** 0.5     # (Cout,Cin,kF,kT)
+    bias = torch.randn(Cout, generator=g, dtype=torch.float64)
+    sc = torch.rand(Cout, generator=g, dtype=torch.float64) + 0.5
+    sh = torch.randn(Cout, generator=g, dtype=torch.float64)
+    Fo = (Fq - 1) // stride_f + 1 if (kw == 9 or stride_f == 2) else Fq
+    res = torch.randn(B, T, Fo, Cout, generator=g, dtype=torch.float64)
+    xq, wq, rq = q(x, dtype), q(w, dtype), q(res, dtype)
+    ref = F.conv2d(xq.permute(0, 3, 2, 1), wq, bias, stride=(stride_f, 1), padding=1 if kw == 9 else 0)   # (B,C,F,T)
+    ref = torch.relu(ref.permute(0, 3, 2, 1) * sc + sh + rq)
+    lib, ctx = N.lib(), N.ctx(0)
+    xd = dev(x, tdt)
+    wd = dev(w.permute(0, 3, 2, 1).reshape(Cout, kw * Cin), tdt)
+    bd, scd, shd, rd = dev(bias, torch.float32), dev(sc, torch.float32), dev(sh, torch.float32), dev(res, tdt)
+    y = torch.zeros((B, T, Fo, Cout), dtype=tdt, device='cuda')
+    d = N.Conv1dDesc()
+    d.dtype_in = d.dtype_out = N.dtype_id(tdt)
+    d.B, d.T_in, d.T_out, d.Cin, d.Cout, d.KW, d.dilation, d.stride = B, T, T, Cin, Cout, kw, 1, 1
+    d.KF, d.F_in, d.F_out, d.stride_f = (3 if kw == 9 else 1), Fq, Fo, stride_f
+    d.pad_mode, d.pad_left, d.pad_f = N.VP_PAD_ZERO, (1 if kw == 9 else 0), (1 if kw == 9 else 0)
+    d.x, d.ldx, d.w, d.bias = xd.data_ptr(), Cin, wd.data_ptr(), bd.data_ptr()
+    d.bn_scale, d.bn_shift, d.act2 = scd.data_ptr(), shd.data_ptr(), N.VP_ACT_RELU
+    d.res, d.ld_res = rd.data_ptr(), Cout
+    d.y, d.ldy = y.data_ptr(), Cout
+    N.check(lib.vp_conv1d_fwd(ctx, C.byref(d), N.stream_ptr()), ctx)
+    torch.cuda.synchronize()
+    tol = 2e-4 + (2.0 ** -8 * ref.abs().max().item() if dtype == 'bf16' else 0.0)
+    assert (y.double().cpu() - ref).abs().max().item() < tol
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_conv1d_prologue_gate_stride(N, dtype):
+    """CAM++ 1-D pieces: input BN+ReLU prologue on a column slice of a wide buffer (campplus.py:137-143),
+    k3 dilated conv with the per-(utterance, 100-frame segment) gate (campplus.py:88-94), and the
+    k5 stride-2 zero-padded TDNN (campplus.py:299-305)."""
+    tdt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    lib, ctx = N.lib(), N.ctx(0)
+    g = torch.Generator().manual_seed(12)
+    B, T, Cw, Cin, Cout = 3, 131, 320, 192, 128
+    x = torch.randn(B, T, Cw, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, generator=g, dtype=torch.float64) / Cin ** 0.5
+    bias = torch.randn(Cout, generator=g, dtype=torch.float64)
+    ps = torch.rand(Cin, generator=g, dtype=torch.float64) + 0.5
+    ph = torch.randn(Cin, generator=g, dtype=torch.float64)
+    sc = torch.rand(Cout, generator=g, dtype=torch.float64) + 0.5
+    sh = torch.randn(Cout, generator=g, dtype=torch.float64)
+    xin = q(torch.relu(q(x[:, :, :Cin], dtype) * ps.float().double() + ph.float().double()), dtype)   # prologue output is re-quantised
+    ref = torch.relu((xin @ q(w, dtype).t() + bias) * sc + sh)
+    xd, wd = dev(x, tdt), dev(w, tdt)
+    keep = [dev(v, torch.float32) for v in (bias, ps, ph, sc, sh)]
+    y = torch.zeros((B, T, Cout), dtype=tdt, device='cuda')
+    d = N.Conv1dDesc()
+    d.dtype_in = d.dtype_out = N.dtype_id(tdt)
+    d.B, d.T_in, d.T_out, d.Cin, d.Cout, d.KW, d.dilation, d.stride, d.pad_mode = B, T, T, Cin, Cout, 1, 1, 1, N.VP_PAD_ZERO
+    d.x, d.ldx, d.w, d.bias = xd.data_ptr(), Cw, wd.data_ptr(), keep[0].data_ptr()
+    d.pro_scale, d.pro_shift, d.bn_scale, d.bn_shift, d.act2 = keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(), keep[4].data_ptr(), N.VP_ACT_RELU
+    d.y, d.ldy = y.data_ptr(), Cout
+    N.check(lib.vp_conv1d_fwd(ctx, C.byref(d), N.stream_ptr()), ctx)
+    torch.cuda.synchronize()
+    tol = 3e-4 + (2.0 ** -7 * ref.abs().max().item() if dtype == 'bf16' else 0.0)
+    assert (y.double().cpu() - ref).abs().max().item() < tol
+    # gated k3 dilated conv, 32 output channels written into a column slice
+    Cb, Cg, dil, seg = 128, 32, 2, 100
+    nseg = (T + seg - 1) // seg
+    h = torch.randn(B, T, Cb, generator=g, dtype=torch.float64)
+    wl = torch.randn(Cg, Cb, 3, generator=g, dtype=torch.float64) / (3 * Cb) ** 0.5
+    bl = torch.randn(Cg, generator=g, dtype=torch.float64)
+    gate = torch.rand(B, nseg, Cg, generator=g, dtype=torch.float64)
+    refc = conv_ref(q(h, dtype), q(wl, dtype), bl, 3, dil, 'zero')
+    segidx = torch.arange(T) // seg
+    refg = refc * gate.float().double()[:, segidx, :]
+    hd, wld = dev(h, tdt), dev(wl.permute(0, 2, 1).reshape(Cg, 3 * Cb), tdt)
+    bld, gd = dev(bl, torch.float32), dev(gate, torch.float32)
+    out = torch.zeros((B, T, 96), dtype=tdt, device='cuda')
+    d = N.Conv1dDesc()
+    d.dtype_in = d.dtype_out = N.dtype_id(tdt)
+    d.B, d.T_in, d.T_out, d.Cin, d.Cout, d.KW, d.dilation, d.stride = B, T, T, Cb, Cg, 3, dil, 1
+    d.pad_mode, d.pad_left = N.VP_PAD_ZERO, dil
+    d.x, d.ldx, d.w, d.bias = hd.data_ptr(), Cb, wld.data_ptr(), bld.data_ptr()
+    d.gate, d.gate_len, d.gate_nseg = gd.data_ptr(), seg, nseg
+    d.y, d.ldy, d.yoff = out.data_ptr(), 96, 64
+    N.check(lib.vp_conv1d_fwd(ctx, C.byref(d), N.stream_ptr()), ctx)
+    torch.cuda.synchronize()
+    tol = 2e-4 + (2.0 ** -8 * refg.abs().max().item() if dtype == 'bf16' else 0.0)
+    assert (out[:, :, 64:].double().cpu() - refg).abs().max().item() < tol
+    assert torch.all(out[:, :, :64] == 0)
+    # k5 stride-2 zero-pad-2
+    Ci, Co = 64, 128
+    xs = torch.randn(B, T, Ci, generator=g, dtype=torch.float64)
+    ws5 = torch.randn(Co, Ci, 5, generator=g, dtype=torch.float64) / (5 * Ci) ** 0.5
+    refs = F.conv1d(q(xs, dtype).transpose(1, 2), q(ws5, dtype), None, stride=2, padding=2).transpose(1, 2)
+    Tn = (T - 1) // 2 + 1
+    assert refs.shape[1] == Tn
+    xsd, wsd = dev(xs, tdt), dev(ws5.permute(0, 2, 1).reshape(Co, 5 * Ci), tdt)
+    ys = torch.zeros((B, Tn, Co), dtype=torch.float32, device='cuda') if dtype == 'f32' else torch.zeros((B, Tn, Co), dtype=tdt, device='cuda')
+    d = N.Conv1dDesc()
+    d.dtype_in = d.dtype_out = N.dtype_id(tdt)
+    d.B, d.T_in, d.T_out, d.Cin, d.Cout, d.KW, d.dilation, d.stride = B, T, Tn, Ci, Co, 5, 1, 2
+    d.pad_mode, d.pad_left = N.VP_PAD_ZERO, 2
+    d.x, d.ldx, d.w, d.y, d.ldy = xsd.data_ptr(), Ci, wsd.data_ptr(), ys.data_ptr(), Co
+    N.check(lib.vp_conv1d_fwd(ctx, C.byref(d), N.stream_ptr()), ctx)
+    torch.cuda.synchronize()
+    tol = 2e-4 + (2.0 ** -8 * refs.abs().max().item() if dtype == 'bf16' else 0.0)
+    assert (ys.double().cpu() - refs).abs().max().item() < tol

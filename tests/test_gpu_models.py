@@ -153,3 +153,94 @@ def test_long_utterance_falls_back_to_per_conv_path(ecapa):
             rel = np.linalg.norm(emb - ref) / np.linalg.norm(ref)
             print(f'[T={T} {dtype}] rel-L2 {rel:.3e}')
             assert rel < tol, (T, dtype, rel)
+
+
+def _cfg():
+    from ppvector.utils.utils import dict_to_object
+    return dict_to_object(dict(
+        dataset_conf=dict(dataset=dict(min_duration=0.3, max_duration=3, sample_rate=16000, use_dB_normalization=True,
+                                       target_dB=-20)),
+        preprocess_conf=dict(feature_method='Fbank', method_args=dict(sr=16000, n_mels=80)),
+        model_conf=dict(model='EcapaTdnn', model_args=dict(embd_dim=192, pooling_type='ASP',
+                                                           channels=[512, 512, 512, 512, 1536]))))
+
+
+def test_predictor_predict_batch_contrast(golden_dir, tmp_path):
+    """PPVectorPredictor.predict / predict_batch / contrast (predict.py:218-283) against the oracle run with
+    the same front end (dB normalisation to -20 dB, waveform zero-padding + ratio mask for the batch)."""
+    import wave
+    from ppvector.predict import PPVectorPredictor
+    g = np.load(f'{golden_dir}/wavs_3s.npz')
+    pcm = g['pcm']
+    lens = [48000, 30000, 41000, 20000]
+    paths = []
+    for i, n in enumerate(lens):
+        p = str(tmp_path / f'u{i}.wav')
+        with wave.open(p, 'wb') as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm[i, :n].tobytes())
+        paths.append(p)
+    state = {'0.' + k: v for k, v in om.ecapa_params(80, seed=1000).items()}
+    pred = PPVectorPredictor(_cfg(), model_path=state)
+
+    def norm(x):
+        x = x.astype(np.float32) / 32768.0
+        rms_db = 10.0 * np.log10(np.mean(x.astype(np.float64) ** 2))
+        return (x * (10.0 ** ((-20.0 - rms_db) / 20.0))).astype(np.float32)
+
+    waves = [norm(pcm[i, :n]) for i, n in enumerate(lens)]
+    p = om.ecapa_params(80, seed=1000)
+    refs = []
+    for w in waves:
+        f = ofb.featurize(w[None], method_args=dict(sr=16000, n_mels=80))
+        with torch.no_grad():
+            refs.append(om.ecapa_forward(p, torch.from_numpy(f)).numpy()[0])
+    for path, ref in zip(paths, refs):
+        e = pred.predict(path)
+        assert e.shape == (192,)
+        assert np.linalg.norm(e - ref) / np.linalg.norm(ref) < 2e-4
+    # batch: reference semantics = pad waveforms with zeros, featurize (CMN over the padded length), mask
+    padded = np.zeros((4, 48000), np.float32)
+    for i, w in enumerate(waves):
+        padded[i, :len(w)] = w
+    ratio = np.asarray([n / 48000 for n in lens], np.float32)
+    fb = ofb.featurize(padded, ratio, method_args=dict(sr=16000, n_mels=80))
+    with torch.no_grad():
+        ref_b = om.ecapa_forward(p, torch.from_numpy(fb)).numpy()
+    eb = pred.predict_batch(paths, batch_size=3)
+    assert eb.shape == (4, 192)
+    assert np.linalg.norm(eb - ref_b) / np.linalg.norm(ref_b) < 5e-4
+    c = pred.contrast(paths[0], paths[1])
+    cr = float(np.dot(refs[0], refs[1]) / (np.linalg.norm(refs[0]) * np.linalg.norm(refs[1])))
+    assert abs(c - cr) < 1e-4
+    # 1:N on the in-memory index
+    pred.register(paths[0], 'a')
+    pred.register(paths[2], 'b')
+    name, score = pred.recognition(paths[0], threshold=0.5)
+    assert name == 'a' and score > 0.99
+    assert pred.remove_user('a') and pred.get_users() == ['b']
+
+
+def test_campplus_matches_reference_golden(golden_dir):
+    """CAM++ (configs/cam++.yml: embd_dim 192) through the reference's class surface vs the output of
+    the reference's own campplus.py (golden), plus a 3 s batch vs the oracle."""
+    from oracle import campplus as oc
+    from ppvector.models.campplus import CAMPPlus
+    g = np.load(f'{golden_dir}/campplus_ref_small.npz')
+    p = oc.campplus_params(80, 192, seed=int(g['param_seed']))
+    m = CAMPPlus(80, embd_dim=192)
+    m.load_state_dict(p)
+    m = m.cuda().eval()
+    x = torch.from_numpy(g['x']).cuda()
+    ref = g['emb_eval']
+    for dtype, tol in (('float32', 3e-4), ('bfloat16', 8e-2)):
+        emb = m.engine(dtype).forward(x).cpu().numpy()
+        rel = np.linalg.norm(emb - ref) / np.linalg.norm(ref)
+        c = _cos_rows(emb, ref)
+        print(f'[cam++ {dtype}] rel-L2 {rel:.3e}  1-cos {1 - c.min():.3e}')
+        assert rel < tol, (dtype, rel)
+    w = ofb.synth_waves(3, 48000, seed=4, lowpass=0.9)
+    feats = ofb.featurize(w, method_args=dict(sr=16000, n_mels=80))
+    with torch.no_grad():
+        ref3 = oc.campplus_forward(p, torch.from_numpy(feats)).numpy()
+    e3 = m.engine('float32').forward(torch.from_numpy(feats).cuda()).cpu().numpy()
+    assert np.linalg.norm(e3 - ref3) / np.linalg.norm(ref3) < 3e-4

@@ -1,0 +1,346 @@
+// CAM++ backbone forward (eval mode): the kernels that are specific to it and the launch graph.
+//
+// Reference: CAMPPlus.forward (ppvector/models/campplus.py:331-335) = FCM head (:246-281, BasicResBlock
+// :211-243) -> TDNNLayer k5 s2 (:38-64) -> 3 x [CAMDenseTDNNBlock (:145-173) of CAMDenseTDNNLayer
+// (:109-142, CAMLayer :67-106) -> TransitLayer (:176-189)] -> BN-ReLU -> statistics_pooling (:24-30)
+// -> DenseLayer + BN (:192-208).
+// Layout: FCM activations are (B, T, F', 32) -- position-major with channels fastest -- so the 2-D
+// convs run on the conv GEMM (taps = row shifts in (t, f)), and the FCM output IS the (B, T, 320)
+// frame-major input of the TDNN (the reference's reshape (B, C*F', T) becomes a weight permutation
+// at pack time).  The DenseNet-style concat is ONE (B*T', Cmax) buffer per block: layer i reads
+// columns [0, C_i) through the conv GEMM's input prologue (its own BN + ReLU applied while staging)
+// and writes its 32 new channels in place -- none of the reference's 52 concat copies exist.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ FCM conv1: 1 -> 32 channels, 3x3, BN, ReLU
+// HBM-bound: reads (B,T,F) once, writes (B,T,F,32).  4 threads per position, 8 channels each.
+template <typename TI, typename TO>
+struct Fcm1Args {
+    const TI* x; TO* y; const float* w; const float* bias; const float* scale; const float* shift;   // w [32][9], tap = kt*3 + kf
+    int B, T, F; long long total;
+};
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void fcm_conv1_kernel(Fcm1Args<TI, TO> a) {
+    __shared__ float sw[32 * 9], sb[32], ss[32], sh[32];
+    for (int i = threadIdx.x; i < 32 * 9; i += 256) sw[i] = a.w[i];
+    if (threadIdx.x < 32) { sb[threadIdx.x] = a.bias[threadIdx.x]; ss[threadIdx.x] = a.scale[threadIdx.x]; sh[threadIdx.x] = a.shift[threadIdx.x]; }
+    __syncthreads();
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < a.total; idx += (long long)gridDim.x * 256) {
+        const long long pos = idx >> 2;
+        const int cg = (int)(idx & 3) * 8;
+        const int f = (int)(pos % a.F);
+        const long long bt = pos / a.F;
+        const int t = (int)(bt % a.T);
+        const long long b = bt / a.T;
+        float in[9];
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int kf = 0; kf < 3; ++kf) {
+                const int ts = t + kt - 1, fs = f + kf - 1;
+                const bool ok = ts >= 0 && ts < a.T && fs >= 0 && fs < a.F;
+                in[kt * 3 + kf] = ok ? vp_to_f32(a.x[(b * a.T + (ok ? ts : 0)) * a.F + (ok ? fs : 0)]) : 0.f;
+            }
+        TO out[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float s = sb[cg + c];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) s += sw[(cg + c) * 9 + k] * in[k];
+            out[c] = vp_from_f32<TO>(fmaxf(s * ss[cg + c] + sh[cg + c], 0.f));
+        }
+        TO* dst = a.y + pos * 32 + cg;
+        if constexpr (sizeof(TO) == 2) {
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(out);
+        } else {
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(out);
+            *reinterpret_cast<uint4*>(dst + 4) = *reinterpret_cast<const uint4*>(out + 4);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ CAM context: mean over time + segment means
+// campplus.py:92: context = x.mean(-1) + seg_pooling(x) (100-frame ceil-mode, exclusive average).
+// ctx[b*nseg + s][c] = mean_t x[b,t,c] + mean_{t in seg s} x[b,t,c].   One workgroup per utterance.
+template <typename T>
+struct CtxArgs { const T* x; float* ctx; int ldx, Tn, C, seg_len, nseg; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void cam_ctx_kernel(CtxArgs<T> a) {
+    extern __shared__ float sm[];                 // [groups][nseg][C]
+    const int b = blockIdx.x;
+    const int groups = 256 / a.C;                 // C <= 256 (host-checked), C divides 256
+    const int c = threadIdx.x % a.C, gq = threadIdx.x / a.C;
+    const T* xb = a.x + (size_t)b * a.Tn * a.ldx;
+    if (gq < groups) {
+        for (int s = 0; s < a.nseg; ++s) {
+            const int t0 = s * a.seg_len, t1 = min(t0 + a.seg_len, a.Tn);
+            float acc = 0.f;
+            for (int t = t0 + gq; t < t1; t += groups) acc += vp_to_f32(xb[(size_t)t * a.ldx + c]);
+            sm[(gq * a.nseg + s) * a.C + c] = acc;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < a.C) {
+        float tot = 0.f;
+        for (int s = 0; s < a.nseg; ++s) {
+            float v = 0.f;
+            for (int q = 0; q < groups; ++q) v += sm[(q * a.nseg + s) * a.C + c];
+            sm[s * a.C + c] = v;                  // group 0's slots now hold the segment sums
+            tot += v;
+        }
+        const float mean = tot / (float)a.Tn;
+        for (int s = 0; s < a.nseg; ++s) {
+            const int len = min(a.seg_len, a.Tn - s * a.seg_len);
+            a.ctx[((size_t)b * a.nseg + s) * a.C + c] = mean + sm[s * a.C + c] / (float)len;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ out_nonlinear (BN + ReLU) + statistics pooling
+// campplus.py:323-326: relu(bn(x)) -> mean and UNBIASED std over time -> (B, 2C)
+template <typename T>
+struct StatArgs { const T* x; const float* scale; const float* shift; float* out; int ldx, Tn, C; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_stats_kernel(StatArgs<T> a) {
+    __shared__ float sm[2][4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.y, c = blockIdx.x * 64 + lane;
+    const bool ok = c < a.C;
+    const int cc = ok ? c : 0;
+    const float sc = a.scale[cc], sh = a.shift[cc];
+    const T* xb = a.x + (size_t)b * a.Tn * a.ldx;
+    // centre on the first frame's value for a well-conditioned variance
+    const float c0 = fmaxf(vp_to_f32(xb[cc]) * sc + sh, 0.f);
+    float s1 = 0.f, s2 = 0.f;
+    for (int t = wv; t < a.Tn; t += 4) {
+        const float v = fmaxf(vp_to_f32(xb[(size_t)t * a.ldx + cc]) * sc + sh, 0.f) - c0;
+        s1 += v; s2 += v * v;
+    }
+    sm[0][wv][lane] = s1; sm[1][wv][lane] = s2;
+    __syncthreads();
+    if (wv == 0 && ok) {
+        const float t1 = sm[0][0][lane] + sm[0][1][lane] + sm[0][2][lane] + sm[0][3][lane];
+        const float t2 = sm[1][0][lane] + sm[1][1][lane] + sm[1][2][lane] + sm[1][3][lane];
+        const float n = (float)a.Tn;
+        const float md = t1 / n;
+        const float var = (t2 - t1 * md) / (n - 1.f);                    // unbiased (paddle std default)
+        a.out[(size_t)b * 2 * a.C + c] = c0 + md;
+        a.out[(size_t)b * 2 * a.C + a.C + c] = sqrtf(fmaxf(var, 0.f));
+    }
+}
+
+struct Carver {
+    char* base; size_t off;
+    explicit Carver(void* p) : base((char*)p), off(0) {}
+    void* take(size_t bytes) {
+        size_t o = off;
+        off += vp_align_up(bytes ? bytes : 1, 256);
+        return base ? (void*)(base + o) : nullptr;
+    }
+};
+
+struct CamPlan {
+    void *fa, *fb, *fc;                 // FCM ping-pong (B,T,F,32)
+    void *cat[2];                       // D-TDNN concat buffers (B*T', Cmax)
+    void* h2;                           // (B*T', bn_ch)
+    float *ctx, *c1, *gate, *stats;
+    size_t total;
+    int Tn, Cmax, nseg;
+};
+
+int cam_Tn(int T) { return (T - 1) / 2 + 1; }          // k5 s2 pad 2
+
+void plan_cam(const vp_campplus_weights* w, int B, int T, void* ws, CamPlan& p) {
+    const size_t es = vp_dtype_size(w->dtype);
+    p.Tn = cam_Tn(T);
+    int ch = w->init_channels, cmax = ch;
+    for (int b = 0; b < w->n_blocks; ++b) {
+        ch += w->block_layers[b] * w->growth;
+        if (ch > cmax) cmax = ch;
+        ch /= 2;
+    }
+    p.Cmax = cmax;
+    p.nseg = (p.Tn + w->seg_len - 1) / w->seg_len;
+    const size_t pos0 = (size_t)B * T * w->feat_dim;
+    Carver c(ws);
+    p.fa = c.take(pos0 * w->m_channels * es);
+    p.fb = c.take(pos0 / 2 * w->m_channels * es + 4096);
+    p.fc = c.take(pos0 / 2 * w->m_channels * es + 4096);
+    const size_t Mn = (size_t)B * p.Tn;
+    p.cat[0] = c.take(Mn * cmax * es);
+    p.cat[1] = c.take(Mn * cmax * es);
+    p.h2 = c.take(Mn * w->bn_channels * es);
+    p.ctx = (float*)c.take((size_t)B * p.nseg * w->bn_channels * 4);
+    p.c1 = (float*)c.take((size_t)B * p.nseg * (w->bn_channels / 2) * 4);
+    p.gate = (float*)c.take((size_t)B * p.nseg * w->growth * 4);
+    p.stats = (float*)c.take((size_t)B * 2 * cmax * 4);
+    p.total = c.off;
+}
+
+void conv2d_desc(vp_conv1d_desc& d, const vp_tdnn_layer& L, int dt, int B, int T, int F_in, int F_out, int stride_f) {
+    memset(&d, 0, sizeof(d));
+    d.dtype_in = dt; d.dtype_out = dt; d.B = B; d.T_in = T; d.T_out = T;
+    d.Cin = L.cin; d.Cout = L.cout; d.KW = L.kw; d.dilation = 1; d.stride = 1;
+    d.KF = L.kw == 9 ? 3 : 1;
+    d.pad_left = L.kw == 9 ? 1 : 0; d.pad_f = L.kw == 9 ? 1 : 0; d.pad_mode = VP_PAD_ZERO;
+    d.F_in = F_in; d.F_out = F_out; d.stride_f = stride_f;
+    d.ldx = L.cin; d.ldy = L.cout;
+    d.w = L.w; d.bias = L.bias; d.bn_scale = L.bn_scale; d.bn_shift = L.bn_shift;
+}
+
+template <typename TI, typename TO>
+int launch_fcm1(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats, void* out, int B, int T, hipStream_t st) {
+    Fcm1Args<TI, TO> a;
+    a.x = (const TI*)feats; a.y = (TO*)out; a.w = w->fcm1_w; a.bias = w->fcm1_b; a.scale = w->fcm1_scale; a.shift = w->fcm1_shift;
+    a.B = B; a.T = T; a.F = w->feat_dim; a.total = (long long)B * T * w->feat_dim * 4;
+    long long blocks = (a.total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL((fcm_conv1_kernel<TI, TO>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    VP_LAUNCH_CHECK(ctx, "fcm_conv1");
+    return VP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t vp_campplus_workspace_bytes(const vp_campplus_weights* w, int B, int T) {
+    if (!w || B <= 0 || T <= 0) return 0;
+    CamPlan p;
+    plan_cam(w, B, T, nullptr, p);
+    return p.total;
+}
+
+int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats, int B, int T, float* emb,
+                    void* ws, size_t ws_bytes, vp_stream stream) {
+    if (!ctx || !w || !feats || !emb || B <= 0 || T <= 0) VP_FAIL(ctx, VP_EINVAL, "campplus: bad arguments");
+    if (w->dtype != VP_F32 && w->dtype != VP_BF16) VP_FAIL(ctx, VP_EINVAL, "campplus: bad dtype");
+    if (w->m_channels != 32 || w->feat_dim % 8 || w->n_blocks < 1 || w->n_blocks > 4 || w->bn_channels > 256 ||
+        256 % w->bn_channels || w->seg_len < 1)
+        VP_FAIL(ctx, VP_EUNSUP, "campplus: geometry not built (m_channels 32, feat_dim %% 8 == 0, bn_channels | 256)");
+    if (B > 65535) VP_FAIL(ctx, VP_EINVAL, "campplus: batch too large");
+    CamPlan p;
+    plan_cam(w, B, T, ws, p);
+    if (!ws || ws_bytes < p.total) VP_FAIL(ctx, VP_EWORKSPACE, "campplus: workspace %zu < %zu", ws_bytes, p.total);
+    if (p.Tn < 2) VP_FAIL(ctx, VP_EINVAL, "campplus: %d frames are too few", T);
+    hipStream_t st = (hipStream_t)stream;
+    const int dt = w->dtype;
+    int rc;
+    vp_conv1d_desc d;
+
+    // ---- FCM head: conv1 (1 -> 32), 2 x [ResBlock s2, ResBlock s1], conv2 s2
+    if (dt == VP_BF16) rc = launch_fcm1<bf16_t, bf16_t>(ctx, w, feats, p.fa, B, T, st);
+    else rc = launch_fcm1<float, float>(ctx, w, feats, p.fa, B, T, st);
+    if (rc) return rc;
+    int F = w->feat_dim;
+    void* cur = p.fa;
+    void* t1 = p.fb;
+    void* t2 = p.fc;
+    for (int i = 0; i < 4; ++i) {
+        const vp_resblock& R = w->res[i];
+        const int Fo = R.stride == 2 ? (F - 1) / 2 + 1 : F;
+        // h = relu(bn1(conv1(x)))
+        conv2d_desc(d, R.conv1, dt, B, T, F, Fo, R.stride);
+        d.x = cur; d.y = t1; d.act2 = VP_ACT_RELU;
+        if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+        const void* sc = cur;
+        if (R.has_shortcut) {      // bn(conv1x1 stride (s,1))
+            conv2d_desc(d, R.shortcut, dt, B, T, F, Fo, R.stride);
+            d.x = cur; d.y = t2;
+            if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+            sc = t2;
+        }
+        // out = relu(bn2(conv2(h)) + shortcut)
+        void* outb = R.has_shortcut ? cur : t2;          // never the buffer that holds the shortcut
+        conv2d_desc(d, R.conv2, dt, B, T, Fo, Fo, 1);
+        d.x = t1; d.y = outb; d.res = sc; d.ld_res = R.conv2.cout; d.act2 = VP_ACT_RELU;
+        if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+        if (!R.has_shortcut) { void* tmp = cur; cur = t2; t2 = tmp; }
+        F = Fo;
+    }
+    {
+        const int Fo = (F - 1) / 2 + 1;
+        conv2d_desc(d, w->fcm_conv2, dt, B, T, F, Fo, 2);
+        d.x = cur; d.y = t1; d.act2 = VP_ACT_RELU;
+        if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+        F = Fo;
+    }
+    const int Cf = F * w->m_channels;                    // = tdnn.cin: (B, T, F', 32) read as (B, T, F'*32)
+    if (w->tdnn.cin != Cf) VP_FAIL(ctx, VP_EINVAL, "campplus: tdnn.cin %d != %d", w->tdnn.cin, Cf);
+
+    // ---- TDNN: conv k5 stride 2 zero-pad 2 -> BN -> ReLU, into columns [0, init) of cat[0]
+    const int Tn = p.Tn, ld = p.Cmax;
+    memset(&d, 0, sizeof(d));
+    d.dtype_in = dt; d.dtype_out = dt; d.B = B; d.T_in = T; d.T_out = Tn; d.Cin = Cf; d.Cout = w->tdnn.cout;
+    d.KW = w->tdnn.kw; d.dilation = 1; d.stride = 2; d.pad_left = (w->tdnn.kw - 1) / 2; d.pad_mode = VP_PAD_ZERO;
+    d.x = t1; d.ldx = Cf; d.w = w->tdnn.w; d.bias = w->tdnn.bias; d.bn_scale = w->tdnn.bn_scale; d.bn_shift = w->tdnn.bn_shift;
+    d.act2 = VP_ACT_RELU; d.y = p.cat[0]; d.ldy = ld;
+    if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+
+    // ---- D-TDNN blocks
+    int ch = w->init_channels, li = 0, cb = 0;
+    const int bnc = w->bn_channels, gr = w->growth, nseg = p.nseg;
+    for (int b = 0; b < w->n_blocks; ++b) {
+        void* cat = p.cat[cb];
+        for (int l = 0; l < w->block_layers[b]; ++l, ++li) {
+            const vp_cam_layer& L = w->layers[li];
+            // h2 = relu(bn2(linear1(relu(bn1(x[:, :ch])))))  -- bn1+relu is the conv's input prologue
+            memset(&d, 0, sizeof(d));
+            d.dtype_in = dt; d.dtype_out = dt; d.B = B; d.T_in = Tn; d.T_out = Tn; d.Cin = ch; d.Cout = bnc; d.KW = 1;
+            d.dilation = 1; d.stride = 1; d.pad_mode = VP_PAD_ZERO;
+            d.x = cat; d.ldx = ld; d.w = L.linear1.w; d.bias = L.linear1.bias; d.pro_scale = L.bn1_scale; d.pro_shift = L.bn1_shift;
+            d.bn_scale = L.linear1.bn_scale; d.bn_shift = L.linear1.bn_shift; d.act2 = VP_ACT_RELU; d.y = p.h2; d.ldy = bnc;
+            if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+            // context gate m = sigmoid(W2 relu(W1 (mean + segmean) + b1) + b2), one row per (utterance, segment)
+            const size_t smem = (size_t)(256 / bnc) * nseg * bnc * sizeof(float);
+            if (smem > 64 * 1024) VP_FAIL(ctx, VP_EUNSUP, "campplus: utterance too long for the context kernel");
+            if (dt == VP_BF16) {
+                CtxArgs<bf16_t> ca{(const bf16_t*)p.h2, p.ctx, bnc, Tn, bnc, w->seg_len, nseg};
+                hipLaunchKernelGGL(cam_ctx_kernel<bf16_t>, dim3(B), dim3(256), smem, st, ca);
+            } else {
+                CtxArgs<float> ca{(const float*)p.h2, p.ctx, bnc, Tn, bnc, w->seg_len, nseg};
+                hipLaunchKernelGGL(cam_ctx_kernel<float>, dim3(B), dim3(256), smem, st, ca);
+            }
+            VP_LAUNCH_CHECK(ctx, "cam_ctx");
+            if ((rc = vp_dense_f32_ex(ctx, p.ctx, bnc, L.ctx_w1, 0, L.ctx_b1, nullptr, nullptr, B * nseg, bnc / 2, bnc,
+                                      VP_ACT_RELU, p.c1, bnc / 2, st))) return rc;
+            if ((rc = vp_dense_f32_ex(ctx, p.c1, bnc / 2, L.ctx_w2, 0, L.ctx_b2, nullptr, nullptr, B * nseg, gr, bnc / 2,
+                                      VP_ACT_SIGMOID, p.gate, gr, st))) return rc;
+            // y = linear_local(h2) * m, written in place as the layer's new channels
+            memset(&d, 0, sizeof(d));
+            d.dtype_in = dt; d.dtype_out = dt; d.B = B; d.T_in = Tn; d.T_out = Tn; d.Cin = bnc; d.Cout = gr;
+            d.KW = L.local.kw; d.dilation = L.local.dil; d.stride = 1; d.pad_left = L.local.dil * (L.local.kw - 1) / 2;
+            d.pad_mode = VP_PAD_ZERO; d.x = p.h2; d.ldx = bnc; d.w = L.local.w; d.bias = L.local.bias;
+            d.gate = p.gate; d.gate_len = w->seg_len; d.gate_nseg = nseg; d.y = cat; d.ldy = ld; d.yoff = ch;
+            if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+            ch += gr;
+        }
+        // transit: linear(relu(bn(x))) -> ch/2, into the other concat buffer
+        const vp_transit& Tr = w->transit[b];
+        memset(&d, 0, sizeof(d));
+        d.dtype_in = dt; d.dtype_out = dt; d.B = B; d.T_in = Tn; d.T_out = Tn; d.Cin = ch; d.Cout = ch / 2; d.KW = 1;
+        d.dilation = 1; d.stride = 1; d.pad_mode = VP_PAD_ZERO; d.x = cat; d.ldx = ld; d.w = Tr.linear.w; d.bias = Tr.linear.bias;
+        d.pro_scale = Tr.bn_scale; d.pro_shift = Tr.bn_shift; d.y = p.cat[cb ^ 1]; d.ldy = ld;
+        if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+        cb ^= 1;
+        ch /= 2;
+    }
+    // ---- out_nonlinear + stats pooling + dense (+BN folded)
+    if (dt == VP_BF16) {
+        StatArgs<bf16_t> sa{(const bf16_t*)p.cat[cb], w->out_bn_scale, w->out_bn_shift, p.stats, ld, Tn, ch};
+        hipLaunchKernelGGL(bn_relu_stats_kernel<bf16_t>, dim3((ch + 63) / 64, B), dim3(256), 0, st, sa);
+    } else {
+        StatArgs<float> sa{(const float*)p.cat[cb], w->out_bn_scale, w->out_bn_shift, p.stats, ld, Tn, ch};
+        hipLaunchKernelGGL(bn_relu_stats_kernel<float>, dim3((ch + 63) / 64, B), dim3(256), 0, st, sa);
+    }
+    VP_LAUNCH_CHECK(ctx, "bn_relu_stats");
+    return vp_dense_f32_ex(ctx, p.stats, 2 * ch, w->dense_w, 0, w->dense_b, nullptr, nullptr, B, w->embd_dim, 2 * ch,
+                           VP_ACT_NONE, emb, w->embd_dim, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,6 @@
+// f32 instantiations of the conv GEMM (exact-f32 matrix cores).  Kernel: conv_gemm_impl.h.
+#include "conv_gemm_impl.h"
+
+int vp_conv_launch_f32_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st) {
+    return dispatch_conv<float, float, true>(ctx, *static_cast<const ConvArgs*>(args), bn, mode, st);
+}

@@ -1,0 +1,456 @@
+// conv GEMM kernel template (included by conv_gemm_bf16.hip / conv_gemm_f32.hip).
+// Design notes: conv_gemm.hip.
+#pragma once
+#include "common.h"
+
+namespace {
+
+constexpr int BM = VP_CONV_BM;
+constexpr int ROWB = 128;        // bytes of K per tile row per stage
+constexpr int NSEG_MAX = 8;
+
+// loader / prologue flavour of an instantiation
+constexpr int MODE_TAPS = 0;     // 1-D conv, KW taps along time (reflect / zero / none)
+constexpr int MODE_1X1 = 1;      // KW == 1: source row fixed, address hoisted out of the K loop
+constexpr int MODE_2D = 2;       // 2-D conv over (time, freq), zero padding, stride on freq
+constexpr int MODE_1X1_PRO = 3;  // 1x1 with BN-affine + ReLU applied to the INPUT channels while staging
+
+struct ConvArgs {
+    const void* x; const void* w;
+    const float* bias; const float* rowbias; const float* bn_scale; const float* bn_shift;
+    const float* pro_scale; const float* pro_shift; const float* gate;
+    void* y; void* y2; const void* add_in; void* aux; const void* res; float* psum; float* psumsq;
+    unsigned x_bytes, w_bytes;
+    int ldx, xoff, ldy, yoff, ldy2, y2off, ysplit, ld_add, add_off, ld_aux, aux_off, ld_res, res_off;
+    int M, N, K, KC, cpt, KT, Cin;
+    int T_in, T_out, dilation, stride, pad_left, pad_mode, act, act2;
+    int F_in, F_out, KF, stride_f, pad_f;
+    int gate_len, gate_nseg;
+    int tiles_m, tiles_n, nseg, group_m;
+};
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { bf16x8 v; };
+template <> struct Frag<float> { float4 lo, hi; };
+
+__device__ __forceinline__ void load_frag(const char* tile, int row, int ks, int g, Frag<bf16_t>& f) {
+    const int c = ks * 4 + g;
+    f.v = *reinterpret_cast<const bf16x8*>(tile + row * ROWB + ((c ^ (row & 7)) << 4));
+}
+__device__ __forceinline__ void load_frag(const char* tile, int row, int /*ks*/, int g, Frag<float>& f) {
+    const int c = 2 * g;
+    f.lo = *reinterpret_cast<const float4*>(tile + row * ROWB + ((c ^ (row & 7)) << 4));
+    f.hi = *reinterpret_cast<const float4*>(tile + row * ROWB + (((c + 1) ^ (row & 7)) << 4));
+}
+// D[n][m] += sum_k W[n][k] * X[m][k]: weights are the A operand (row = lane & 15 -> n), activations
+// the B operand (col = lane & 15 -> m); result register r of lane l = (n = (l >> 4) * 4 + r, m = l & 15).
+__device__ __forceinline__ void mma(const Frag<bf16_t>& w, const Frag<bf16_t>& x, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, x.v, c, 0, 0, 0);
+}
+__device__ __forceinline__ void mma(const Frag<float>& w, const Frag<float>& x, f32x4& c) {
+    // lane group g holds k = 8g .. 8g+7 of the 32-wide stage for BOTH operands; instruction e
+    // contracts the four k = 8g + e, the eight instructions cover the stage (exact f32 fma chain).
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(w.lo.x, x.lo.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(w.lo.y, x.lo.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(w.lo.z, x.lo.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(w.lo.w, x.lo.w, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(w.hi.x, x.hi.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(w.hi.y, x.hi.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(w.hi.z, x.hi.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(w.hi.w, x.hi.w, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void store4(float* p, const float v[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void store4(bf16_t* p, const float v[4]) {
+    bf16x4 o;
+    o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+__device__ __forceinline__ void load4(const float* p, float v[4]) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void load4(const bf16_t* p, float v[4]) {
+    bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+    v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+}
+
+// input prologue on one staged 16-byte chunk: x <- relu(x * s + h), per channel
+__device__ __forceinline__ u32x4 prologue_chunk(u32x4 v, const float (&s)[8], const float (&h)[8], bf16_t) {
+    u32x4 o;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float lo = __builtin_bit_cast(float, v[w] << 16);
+        const float hi = __builtin_bit_cast(float, v[w] & 0xffff0000u);
+        const bf16_t a = (bf16_t)fmaxf(lo * s[2 * w] + h[2 * w], 0.f);
+        const bf16_t b = (bf16_t)fmaxf(hi * s[2 * w + 1] + h[2 * w + 1], 0.f);
+        o[w] = (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+    }
+    return o;
+}
+__device__ __forceinline__ u32x4 prologue_chunk(u32x4 v, const float (&s)[8], const float (&h)[8], float) {
+    u32x4 o;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        o[w] = __builtin_bit_cast(unsigned, fmaxf(__builtin_bit_cast(float, v[w]) * s[w] + h[w], 0.f));
+    return o;
+}
+
+template <typename TI, typename TO, int BN, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
+    constexpr int EPC = 16 / (int)sizeof(TI);        // elements per 16-B chunk
+    constexpr int KSTEPS = (8 * EPC) / 32;           // MFMA k-steps per stage: bf16 2, f32 1
+    constexpr int NI = BN >= 64 ? 4 : BN / 16;       // 16-column MFMA tiles per wave
+    constexpr int WN = BN / (NI * 16);               // waves along N
+    constexpr int WM = 4 / WN;
+    constexpr int MI = BM / (WM * 16);
+    constexpr int WCOLS = NI * 16;
+    constexpr int BROWS = BN / 32;
+    constexpr int STAGE = (BM + BN) * ROWB;
+    constexpr bool PRO = MODE == MODE_1X1_PRO;
+    constexpr bool ONE = MODE == MODE_1X1 || MODE == MODE_1X1_PRO;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int wm = wv / WN, wn = wv % WN;
+    const int li = lane & 15, g = lane >> 4;
+
+    // Block -> tile map. (1) XCD-aware, bijective: block b runs on XCD b % 8, so each XCD gets a
+    // contiguous run of the tile order and keeps its own L2 working set.  (2) Grouped order inside
+    // the run: GM consecutive M-tiles x all N-tiles form a group, M fastest -- the ~64 workgroups an
+    // XCD runs at once then share GM activation panels and a few weight panels instead of streaming
+    // the whole weight matrix once per M-tile (measured on the MFA GEMM: 2.1 GB of L2 misses for a
+    // 0.47 GB problem with N-fastest order).
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int qq = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
+    const int swz = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    const int gsz = a.group_m * a.tiles_n;
+    const int grp = swz / gsz, rem = swz - grp * gsz;
+    const int gm = min(a.group_m, a.tiles_m - grp * a.group_m);      // M-tiles in this (maybe last) group
+    const int tn = rem / gm;
+    const int tm = grp * a.group_m + (rem - tn * gm);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // Operands are fetched with buffer loads through wave-uniform resource descriptors: a 32-bit
+    // byte offset per lane, and anything that must read as zero (rows past M, channels past K, zero
+    // padding, weight rows past N) gets an out-of-range offset -- the hardware returns 0, no branch,
+    // no select on the loaded value, so the loads stay in flight across the MFMA block.
+    constexpr unsigned ES = sizeof(TI);
+    constexpr unsigned OOB = 0xfffffff0u;      // every dword of the 16-B access is >= num_records, no wrap
+    const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.w_bytes, 0x00020000);
+
+    // global -> LDS staging assignment: 16-B chunk cc of rows r0 + 32 i
+    const int cc = tid & 7, r0 = tid >> 3;
+    const int pw = (cc ^ (r0 & 7)) << 4;
+    const bool zero_pad = a.pad_mode == VP_PAD_ZERO;
+    const unsigned ldxb = (unsigned)a.ldx * ES;
+    // per staged row: rowoff = byte offset of (utterance b, frame 0 [, freq 0]); tpos / fpos = the
+    // un-padded source position of tap 0; rowfix = the full row offset when there is a single tap
+    unsigned rowoff[4], rowfix[4], woff[BROWS];
+    int tpos[4], fpos[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        const bool ok = m < a.M;
+        int mm = ok ? m : 0;
+        int f = 0;
+        if constexpr (MODE == MODE_2D) {
+            const int bt = mm / a.F_out;
+            f = mm - bt * a.F_out;
+            mm = bt;
+        }
+        const int b = mm / a.T_out;
+        const int t = mm - b * a.T_out;
+        tpos[i] = t * a.stride - a.pad_left;
+        fpos[i] = f * a.stride_f - a.pad_f;
+        if constexpr (MODE == MODE_2D)
+            rowoff[i] = ok ? ((unsigned)(b * a.T_in) * (unsigned)a.F_in * (unsigned)a.ldx + (unsigned)a.xoff) * ES : OOB;
+        else
+            rowoff[i] = ok ? ((unsigned)(b * a.T_in) * (unsigned)a.ldx + (unsigned)a.xoff) * ES : OOB;
+        const int traw = tpos[i];
+        int ts = traw < 0 ? -traw : traw;
+        ts = ts >= a.T_in ? 2 * (a.T_in - 1) - ts : ts;
+        const bool inr = traw >= 0 && traw < a.T_in;
+        rowfix[i] = (rowoff[i] != OOB && (inr || !zero_pad)) ? rowoff[i] + (unsigned)ts * ldxb : OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) {
+        const int n = n0 + r0 + 32 * i;
+        woff[i] = n < a.N ? (unsigned)n * (unsigned)a.K * ES : OOB;
+    }
+
+    // TWO register stages: the loads of K-stage k+2 are issued while stage k is computed and are
+    // written to LDS at the end of stage k+1, so a fetch has two stages of MFMA work to land.
+    constexpr int NPRO = PRO ? 8 : 1;
+    u32x4 ra0[4], rb0[BROWS], ra1[4], rb1[BROWS];
+    float ps0[NPRO], ph0[NPRO], ps1[NPRO], ph1[NPRO];
+
+    auto gload = [&](int kt, u32x4 (&ra)[4], u32x4 (&rb)[BROWS], float (&ps)[NPRO], float (&ph)[NPRO]) {
+        const int q = kt * 8 + cc;
+        const bool kv = q < a.KC;
+        const unsigned kb = (unsigned)q * 16u;
+        if constexpr (ONE) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = kv && rowfix[i] != OOB;
+                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrd, ok ? rowfix[i] + kb : OOB, 0, 0);
+            }
+            if constexpr (PRO) {
+                const int c0 = min(q * EPC, a.Cin - EPC);               // clamp: K-tail chunks meet zero weights anyway
+#pragma unroll
+                for (int e = 0; e < EPC; e += 4) {
+                    const float4 s4 = *reinterpret_cast<const float4*>(a.pro_scale + c0 + e);
+                    const float4 h4 = *reinterpret_cast<const float4*>(a.pro_shift + c0 + e);
+                    ps[e] = s4.x; ps[e + 1] = s4.y; ps[e + 2] = s4.z; ps[e + 3] = s4.w;
+                    ph[e] = h4.x; ph[e + 1] = h4.y; ph[e + 2] = h4.z; ph[e + 3] = h4.w;
+                }
+            }
+        } else if constexpr (MODE == MODE_2D) {
+            const int j = q / a.cpt;
+            const unsigned cb = (unsigned)(q - j * a.cpt) * 16u;
+            const int kt_ = j / a.KF;
+            const int kf = j - kt_ * a.KF;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ts = tpos[i] + kt_ * a.dilation;
+                const int fs = fpos[i] + kf;
+                const bool ok = kv && rowoff[i] != OOB && ts >= 0 && ts < a.T_in && fs >= 0 && fs < a.F_in;
+                const unsigned off = rowoff[i] + ((unsigned)ts * (unsigned)a.F_in + (unsigned)fs) * ldxb + cb;
+                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrd, ok ? off : OOB, 0, 0);
+            }
+        } else {
+            const int j = q / a.cpt;
+            const unsigned cb = (unsigned)(q - j * a.cpt) * 16u;      // byte offset of the chunk in its tap
+            const int tj = j * a.dilation;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int traw = tpos[i] + tj;
+                int ts = traw < 0 ? -traw : traw;                      // reflect (identity when in range)
+                ts = ts >= a.T_in ? 2 * (a.T_in - 1) - ts : ts;
+                const bool inr = traw >= 0 && traw < a.T_in;
+                const bool ok = kv && rowoff[i] != OOB && (inr || !zero_pad);
+                const unsigned off = rowoff[i] + (unsigned)ts * ldxb + cb;
+                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrd, ok ? off : OOB, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) {
+            const bool ok = kv && woff[i] != OOB;
+            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wsrd, ok ? woff[i] + kb : OOB, 0, 0);
+        }
+    };
+    auto swrite = [&](int s, const u32x4 (&ra)[4], const u32x4 (&rb)[BROWS], const float (&ps)[NPRO],
+                      const float (&ph)[NPRO]) {
+        char* As = smem + s * STAGE;
+        char* Bs = As + BM * ROWB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x4 v = ra[i];
+            if constexpr (PRO) {
+                float s8[8], h8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s8[e] = ps[e % NPRO]; h8[e] = ph[e % NPRO]; }
+                v = prologue_chunk(v, s8, h8, TI{});
+            }
+            *reinterpret_cast<u32x4*>(As + (r0 + 32 * i) * ROWB + pw) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) *reinterpret_cast<u32x4*>(Bs + (r0 + 32 * i) * ROWB + pw) = rb[i];
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int s) {
+        const char* As = smem + s * STAGE;
+        const char* Bs = As + BM * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            Frag<TI> xf[MI], wf[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) load_frag(As, wm * (MI * 16) + mi * 16 + li, ks, g, xf[mi]);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) load_frag(Bs, wn * WCOLS + ni * 16 + li, ks, g, wf[ni]);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) mma(wf[ni], xf[mi], acc[mi][ni]);
+        }
+    };
+
+    // The loads inside the loop are UNCONDITIONAL (a stage past K is all out-of-range offsets: zeros,
+    // no memory traffic): with a condition around them hipcc can no longer count the outstanding
+    // loads and falls back to vmcnt(0) before every LDS write, which kills the two-stage distance.
+    const int KT = a.KT;
+    gload(0, ra0, rb0, ps0, ph0);
+    gload(1, ra1, rb1, ps1, ph1);
+    swrite(0, ra0, rb0, ps0, ph0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; kt += 2) {
+        // even stage kt on LDS[0]; set0 <- stage kt+2; set1 (stage kt+1) -> LDS[1]
+        gload(kt + 2, ra0, rb0, ps0, ph0);
+        compute(0);
+        swrite(1, ra1, rb1, ps1, ph1);
+        __syncthreads();
+        if (kt + 1 >= KT) break;
+        // odd stage kt+1 on LDS[1]; set1 <- stage kt+3; set0 (stage kt+2) -> LDS[0]
+        gload(kt + 3, ra1, rb1, ps1, ph1);
+        compute(1);
+        swrite(0, ra0, rb0, ps0, ph0);
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    // y = act2( bn( act( acc + bias + rowbias ) ) * gate + res );   aux = y + add_in
+    TO* __restrict__ Y = static_cast<TO*>(a.y);
+    TO* __restrict__ Y2 = static_cast<TO*>(a.y2);
+    const TO* __restrict__ ADD = static_cast<const TO*>(a.add_in);
+    const TO* __restrict__ RES = static_cast<const TO*>(a.res);
+    TO* __restrict__ AUX = static_cast<TO*>(a.aux);
+    const int bfirst = m0 / a.T_out;
+    int rowm[MI], rowb[MI], rowg[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        rowm[mi] = m0 + wm * (MI * 16) + mi * 16 + li;
+        const int mc = rowm[mi] < a.M ? rowm[mi] : (a.M - 1);
+        rowb[mi] = mc / a.T_out;
+        rowg[mi] = a.gate ? rowb[mi] * a.gate_nseg + (mc - rowb[mi] * a.T_out) / a.gate_len : 0;
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int nb = n0 + wn * WCOLS + ni * 16 + g * 4;
+        const bool nvalid = nb < a.N;
+        float bias4[4] = {0.f, 0.f, 0.f, 0.f}, sc4[4] = {1.f, 1.f, 1.f, 1.f}, sh4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (nvalid) {
+            if (a.bias) load4(a.bias + nb, bias4);
+            if (a.bn_scale) load4(a.bn_scale + nb, sc4);
+            if (a.bn_shift) load4(a.bn_shift + nb, sh4);
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = rowm[mi];
+            const bool ok = nvalid && m < a.M;
+            float v[4];
+            float rbias[4] = {0.f, 0.f, 0.f, 0.f}, gt[4] = {1.f, 1.f, 1.f, 1.f}, rs[4] = {0.f, 0.f, 0.f, 0.f};
+            if (ok && a.rowbias) load4(a.rowbias + (size_t)rowb[mi] * a.N + nb, rbias);
+            if (ok && a.gate) load4(a.gate + (size_t)rowg[mi] * a.N + nb, gt);
+            if (ok && RES) load4(RES + (size_t)m * a.ld_res + a.res_off + nb, rs);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = acc[mi][ni][r] + bias4[r] + rbias[r];
+                if (a.act == VP_ACT_RELU) t = fmaxf(t, 0.f);
+                t = (t * sc4[r] + sh4[r]) * gt[r] + rs[r];
+                if (a.act2 == VP_ACT_TANH) t = tanhf(t);
+                else if (a.act2 == VP_ACT_RELU) t = fmaxf(t, 0.f);
+                v[r] = t;
+            }
+            if (ok) {
+                store4(Y + (size_t)m * a.ldy + a.yoff + nb, v);
+                if (nb < a.ysplit) store4(Y2 + (size_t)m * a.ldy2 + a.y2off + nb, v);
+                if (AUX) {
+                    float ad[4];
+                    load4(ADD + (size_t)m * a.ld_add + a.add_off + nb, ad);
+                    float s4[4] = {v[0] + ad[0], v[1] + ad[1], v[2] + ad[2], v[3] + ad[3]};
+                    store4(AUX + (size_t)m * a.ld_aux + a.aux_off + nb, s4);
+                }
+            }
+            // keep (y - shift) for the column sums; zero for rows / columns outside the problem
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mi][ni][r] = ok ? (v[r] - sh4[r]) : 0.f;
+        }
+    }
+    if (a.psum) {
+        // per (M-tile, utterance segment) column sums, deterministic: lanes -> waves -> workgroup
+        float* red = reinterpret_cast<float*>(smem);          // [2][WM][NSEG_MAX][BN]
+        for (int s = 0; s < a.nseg; ++s) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const float d = (rowb[mi] - bfirst == s) ? acc[mi][ni][r] : 0.f;
+                        s1 += d;
+                        s2 += d * d;
+                    }
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) {
+                        s1 += __shfl_xor(s1, o);
+                        s2 += __shfl_xor(s2, o);
+                    }
+                    if (li == 0) {
+                        const int col = wn * WCOLS + ni * 16 + g * 4 + r;
+                        red[((0 * WM + wm) * NSEG_MAX + s) * BN + col] = s1;
+                        red[((1 * WM + wm) * NSEG_MAX + s) * BN + col] = s2;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < a.N) {
+            for (int s = 0; s < a.nseg; ++s) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) {
+                    s1 += red[((0 * WM + w) * NSEG_MAX + s) * BN + tid];
+                    s2 += red[((1 * WM + w) * NSEG_MAX + s) * BN + tid];
+                }
+                const size_t o = ((size_t)tm * a.nseg + s) * a.N + n0 + tid;
+                a.psum[o] = s1;
+                if (a.psumsq) a.psumsq[o] = s2;
+            }
+        }
+    }
+}
+
+template <typename TI, typename TO, int BN, int MODE>
+int launch_conv(vp_ctx* ctx, const ConvArgs& a, hipStream_t st) {
+    constexpr int smem = 2 * (BM + BN) * ROWB;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_kernel<TI, TO, BN, MODE>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_gemm_kernel<TI, TO, BN, MODE>), dim3(a.tiles_m * a.tiles_n), dim3(256), smem, st, a);
+    VP_LAUNCH_CHECK(ctx, "conv_gemm");
+    return VP_OK;
+}
+
+// dispatch over tile width and loader mode for one (TI, TO) pair
+template <typename TI, typename TO, bool SMALL_TILES>
+int dispatch_conv(vp_ctx* ctx, const ConvArgs& a, int bn, int mode, hipStream_t st) {
+    if (bn == 128) {
+        if (mode == MODE_TAPS) return launch_conv<TI, TO, 128, MODE_TAPS>(ctx, a, st);
+        if (mode == MODE_1X1) return launch_conv<TI, TO, 128, MODE_1X1>(ctx, a, st);
+        if constexpr (SMALL_TILES) { if (mode == MODE_2D) return launch_conv<TI, TO, 128, MODE_2D>(ctx, a, st); }
+    }
+    if constexpr (SMALL_TILES) {
+        if (bn == 64) {
+            if (mode == MODE_TAPS) return launch_conv<TI, TO, 64, MODE_TAPS>(ctx, a, st);
+            if (mode == MODE_1X1) return launch_conv<TI, TO, 64, MODE_1X1>(ctx, a, st);
+            if (mode == MODE_2D) return launch_conv<TI, TO, 64, MODE_2D>(ctx, a, st);
+            if (mode == MODE_1X1_PRO) return launch_conv<TI, TO, 64, MODE_1X1_PRO>(ctx, a, st);
+        }
+        if (bn == 32) {
+            if (mode == MODE_TAPS) return launch_conv<TI, TO, 32, MODE_TAPS>(ctx, a, st);
+            if (mode == MODE_1X1) return launch_conv<TI, TO, 32, MODE_1X1>(ctx, a, st);
+            if (mode == MODE_2D) return launch_conv<TI, TO, 32, MODE_2D>(ctx, a, st);
+            if (mode == MODE_1X1_PRO) return launch_conv<TI, TO, 32, MODE_1X1_PRO>(ctx, a, st);
+        }
+    }
+    VP_FAIL(ctx, VP_EUNSUP, "conv1d: no kernel for tile %d / mode %d", bn, mode);
+}
+
+}  // namespace

@@ -39,7 +39,11 @@ class Conv1dDesc(C.Structure):
                 ('y2', c_void_p), ('ldy2', c_int), ('y2off', c_int), ('ysplit', c_int),
                 ('add_in', c_void_p), ('ld_add', c_int), ('add_off', c_int),
                 ('aux', c_void_p), ('ld_aux', c_int), ('aux_off', c_int),
-                ('psum', c_void_p), ('psumsq', c_void_p)]
+                ('psum', c_void_p), ('psumsq', c_void_p),
+                ('F_in', c_int), ('F_out', c_int), ('KF', c_int), ('stride_f', c_int), ('pad_f', c_int),
+                ('pro_scale', c_void_p), ('pro_shift', c_void_p),
+                ('res', c_void_p), ('ld_res', c_int), ('res_off', c_int),
+                ('gate', c_void_p), ('gate_len', c_int), ('gate_nseg', c_int)]
 
 
 class TdnnLayer(C.Structure):
@@ -67,6 +71,33 @@ class EcapaWeights(C.Structure):
 class TdnnWeights(C.Structure):
     _fields_ = [('dtype', c_int), ('feat_dim', c_int), ('embd_dim', c_int), ('channels', c_int),
                 ('td', TdnnLayer * 5), ('asp', AspWeights), ('lin_w', c_void_p), ('lin_b', c_void_p)]
+
+
+VP_MAX_CAM_LAYERS, VP_MAX_CAM_BLOCKS = 64, 4
+
+
+class ResBlock(C.Structure):
+    _fields_ = [('conv1', TdnnLayer), ('conv2', TdnnLayer), ('shortcut', TdnnLayer), ('stride', c_int),
+                ('has_shortcut', c_int)]
+
+
+class CamLayer(C.Structure):
+    _fields_ = [('bn1_scale', c_void_p), ('bn1_shift', c_void_p), ('linear1', TdnnLayer), ('local', TdnnLayer),
+                ('ctx_w1', c_void_p), ('ctx_b1', c_void_p), ('ctx_w2', c_void_p), ('ctx_b2', c_void_p)]
+
+
+class Transit(C.Structure):
+    _fields_ = [('bn_scale', c_void_p), ('bn_shift', c_void_p), ('linear', TdnnLayer)]
+
+
+class CamppWeights(C.Structure):
+    _fields_ = [('dtype', c_int), ('feat_dim', c_int), ('embd_dim', c_int), ('m_channels', c_int),
+                ('init_channels', c_int), ('growth', c_int), ('bn_channels', c_int), ('seg_len', c_int),
+                ('n_blocks', c_int), ('block_layers', c_int * VP_MAX_CAM_BLOCKS),
+                ('fcm1_w', c_void_p), ('fcm1_b', c_void_p), ('fcm1_scale', c_void_p), ('fcm1_shift', c_void_p),
+                ('res', ResBlock * 4), ('fcm_conv2', TdnnLayer), ('tdnn', TdnnLayer),
+                ('layers', CamLayer * VP_MAX_CAM_LAYERS), ('transit', Transit * VP_MAX_CAM_BLOCKS),
+                ('out_bn_scale', c_void_p), ('out_bn_shift', c_void_p), ('dense_w', c_void_p), ('dense_b', c_void_p)]
 
 
 _PROTOS = {
@@ -97,6 +128,9 @@ _PROTOS = {
     'vp_tdnn_workspace_bytes': (c_size_t, [C.POINTER(TdnnWeights), c_int, c_int]),
     'vp_tdnn_fwd': (c_int, [c_void_p, C.POINTER(TdnnWeights), c_void_p, c_int, c_int, c_void_p, c_void_p,
                             c_size_t, c_void_p]),
+    'vp_campplus_workspace_bytes': (c_size_t, [C.POINTER(CamppWeights), c_int, c_int]),
+    'vp_campplus_fwd': (c_int, [c_void_p, C.POINTER(CamppWeights), c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                c_size_t, c_void_p]),
     'vp_cosine_logits_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'vp_cosine_logits_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                      c_size_t, c_void_p]),

@@ -149,6 +149,95 @@ class TdnnEngine(_Engine):
         return emb
 
 
+class CamppEngine(_Engine):
+    """Packs a CAMPPlus module into vp_campplus_weights (include/vpmi.h)."""
+
+    def conv_layer(self, L, conv, bn, kw_taps, w_packed, dil=1):
+        L.w = self._p(w_packed)
+        L.bias = self._p(f32(conv.bias))
+        if bn is not None:
+            sc, sh = bn.folded()
+            L.bn_scale, L.bn_shift = self._p(sc), self._p(sh)
+        L.cin, L.cout, L.kw, L.dil = w_packed.shape[1] // kw_taps, w_packed.shape[0], kw_taps, dil
+
+    def conv2d(self, L, conv, bn):
+        w = conv.weight.detach()                                  # (Cout, Cin, kF, kT)
+        kf, kt = w.shape[2], w.shape[3]
+        wp = w.permute(0, 3, 2, 1).reshape(w.shape[0], kt * kf * w.shape[1]).to(self.tdtype).contiguous()
+        self.conv_layer(L, conv, bn, kt * kf, wp)
+
+    def __init__(self, m, dtype_name):
+        super().__init__(m, dtype_name)
+        W = N.CamppWeights()
+        head, xv = m.head, m.xvector
+        W.dtype, W.feat_dim, W.embd_dim, W.m_channels = self.dt, m.input_size, m.embd_dim, head.conv1.weight.shape[0]
+        W.init_channels, W.growth, W.bn_channels, W.seg_len = m.init_channels, m.growth_rate, m.bn_size * m.growth_rate, 100
+        W.n_blocks = len(m.block_cfg)
+        for i, (nl, _, _) in enumerate(m.block_cfg):
+            W.block_layers[i] = nl
+        w1 = head.conv1.weight.detach()[:, 0]                       # (32, kF, kT)
+        W.fcm1_w = self._p(w1.permute(0, 2, 1).reshape(w1.shape[0], 9).float())
+        W.fcm1_b = self._p(f32(head.conv1.bias))
+        sc, sh = head.bn1.folded()
+        W.fcm1_scale, W.fcm1_shift = self._p(sc), self._p(sh)
+        blocks = list(head.layer1) + list(head.layer2)
+        for i, rb in enumerate(blocks):
+            R = W.res[i]
+            self.conv2d(R.conv1, rb.conv1, rb.bn1)
+            self.conv2d(R.conv2, rb.conv2, rb.bn2)
+            R.stride = rb.stride
+            R.has_shortcut = int(len(rb.shortcut) > 0)
+            if R.has_shortcut:
+                self.conv2d(R.shortcut, rb.shortcut[0], rb.shortcut[1])
+        self.conv2d(W.fcm_conv2, head.conv2, head.bn2)
+        # TDNN k5 s2: reference input channel = c * F' + f (reshape of (B, C, F', T)); ours = f * 32 + c
+        tw = xv.tdnn.linear.weight.detach()                         # (init, 32*F', 5)
+        C32 = W.m_channels
+        Fq = tw.shape[1] // C32
+        twp = tw.reshape(tw.shape[0], C32, Fq, tw.shape[2]).permute(0, 3, 2, 1).reshape(tw.shape[0], -1)
+        self.conv_layer(W.tdnn, xv.tdnn.linear, xv.tdnn.nonlinear.batchnorm, tw.shape[2], twp.to(self.tdtype).contiguous())
+        li = 0
+        for bi, (nl, k, d) in enumerate(m.block_cfg, start=1):
+            blk = getattr(xv, f'block{bi}')
+            for l in range(1, nl + 1):
+                lay = getattr(blk, f'tdnnd{l}')
+                L = W.layers[li]
+                s1, h1 = lay.nonlinear1.batchnorm.folded()
+                L.bn1_scale, L.bn1_shift = self._p(s1), self._p(h1)
+                self.conv_layer(L.linear1, lay.linear1, lay.nonlinear2.batchnorm, 1,
+                                lay.linear1.weight.detach()[:, :, 0].to(self.tdtype).contiguous())
+                cl = lay.cam_layer
+                self.conv_layer(L.local, cl.linear_local, None, k, pack_conv_weight(cl.linear_local.weight, self.tdtype), d)
+                L.ctx_w1 = self._p(cl.linear1.weight.detach()[:, :, 0].float())
+                L.ctx_b1 = self._p(f32(cl.linear1.bias))
+                L.ctx_w2 = self._p(cl.linear2.weight.detach()[:, :, 0].float())
+                L.ctx_b2 = self._p(f32(cl.linear2.bias))
+                li += 1
+            tr = getattr(xv, f'transit{bi}')
+            Tr = W.transit[bi - 1]
+            ts, th = tr.nonlinear.batchnorm.folded()
+            Tr.bn_scale, Tr.bn_shift = self._p(ts), self._p(th)
+            self.conv_layer(Tr.linear, tr.linear, None, 1, tr.linear.weight.detach()[:, :, 0].to(self.tdtype).contiguous())
+        os_, oh = xv.out_nonlinear.batchnorm.folded()
+        W.out_bn_scale, W.out_bn_shift = self._p(os_), self._p(oh)
+        ds, dh = xv.dense.nonlinear.batchnorm.folded()
+        dw = xv.dense.linear.weight.detach()[:, :, 0].float()
+        W.dense_w = self._p(dw * ds[:, None])
+        W.dense_b = self._p(xv.dense.linear.bias.detach().float() * ds + dh)
+        self.W = W
+
+    def forward(self, x):
+        xin = self.feats_in(x)
+        B, T, F = xin.shape
+        lib, ctx = N.lib(), N.ctx(xin.device)
+        emb = torch.empty((B, self.W.embd_dim), dtype=torch.float32, device=xin.device)
+        nws = lib.vp_campplus_workspace_bytes(C.byref(self.W), B, T)
+        ws = self.ws.get(nws, xin.device)
+        N.check(lib.vp_campplus_fwd(ctx, C.byref(self.W), xin.data_ptr(), B, T, emb.data_ptr(), ws.data_ptr(),
+                                    ws.numel(), N.stream_ptr()), ctx)
+        return emb
+
+
 class EngineMixin:
     """forward() of a backbone: eval-mode fused forward on the HIP engine."""
     _engine_cls = None
