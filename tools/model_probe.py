@@ -1,0 +1,33 @@
+"""Forward-time probe of the built backbones at a given batch (3 s utterances, T = 298, bf16 and f32)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'voiceprintrecognition-paddlepaddle_amd'))
+import torch  # noqa: E402
+from oracle import campplus as oc  # noqa: E402
+from oracle import models as om  # noqa: E402
+from ppvector.models.campplus import CAMPPlus  # noqa: E402
+from ppvector.models.ecapa_tdnn import EcapaTdnn  # noqa: E402
+from ppvector.models.tdnn import TDNN  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+x = torch.randn(B, 298, 80, device='cuda') * 3
+GF = {'EcapaTdnn': 2.857, 'TDNN': 1.47, 'CAMPPlus': 3.20}
+for name, cls, params in (('EcapaTdnn', EcapaTdnn, om.ecapa_params(80)), ('TDNN', TDNN, om.tdnn_params(80)),
+                          ('CAMPPlus', lambda f: CAMPPlus(f, embd_dim=192), oc.campplus_params(80, 192))):
+    m = cls(80)
+    m.load_state_dict(params)
+    m = m.cuda().eval()
+    for dt in ('bfloat16', 'float32'):
+        eng = m.engine(dt)
+        xin = x.to(torch.bfloat16) if dt == 'bfloat16' else x
+        for _ in range(2):
+            eng.forward(xin)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+        for a, b in evs:
+            a.record(); eng.forward(xin); b.record()
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in evs)[2]
+        print(f'{name:10s} {dt:9s} B={B}: {ms:8.3f} ms  {B / ms * 1e3:10.0f} utt/s  {B * GF[name] / ms:8.1f} TFLOP/s (algorithmic)', flush=True)

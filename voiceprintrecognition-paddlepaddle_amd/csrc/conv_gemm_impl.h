@@ -95,8 +95,10 @@ __device__ __forceinline__ u32x4 prologue_chunk(u32x4 v, const float (&s)[8], co
 __device__ __forceinline__ u32x4 prologue_chunk(u32x4 v, const float (&s)[8], const float (&h)[8], float) {
     u32x4 o;
 #pragma unroll
-    for (int w = 0; w < 4; ++w)
-        o[w] = __builtin_bit_cast(unsigned, fmaxf(__builtin_bit_cast(float, v[w]) * s[w] + h[w], 0.f));
+    for (int w = 0; w < 4; ++w) {
+        const unsigned u = v[w];          // NOT bit_cast(v[w]): on a vector-element lvalue hipcc reads element 0
+        o[w] = __builtin_bit_cast(unsigned, fmaxf(__builtin_bit_cast(float, u) * s[w] + h[w], 0.f));
+    }
     return o;
 }
 
