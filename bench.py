@@ -37,11 +37,12 @@ ALG_GFLOP_PER_UTT = 2.857          # ECAPA forward, algorithmic
 
 
 def conv_family_shapes(T):
-    """(Cin, Cout, KW, dil) of the launches of conv_gemm_kernel<bf16, bf16, 128> in one ECAPA step."""
-    s = [(80, 512, 5, 1)]
+    """(Cin, Cout, KW, dil, extras) of the launches of conv_gemm_kernel<bf16, bf16, 128> in one ECAPA step,
+    with the epilogue options each one carries inside the step."""
+    s = [(80, 512, 5, 1, ())]
     for d in (2, 3, 4):
-        s += [(512, 512, 1, 1), (512, 512, 1, 1)]          # tdnn1, tdnn2 of each SE-Res2 block
-    s += [(1536, 1536, 1, 1), (1536, 128, 1, 1)]           # MFA, ASP attention TDNN (x part)
+        s += [(512, 512, 1, 1, ('ysplit',)), (512, 512, 1, 1, ('psum',))]        # tdnn1, tdnn2 of each SE-Res2 block
+    s += [(1536, 1536, 1, 1, ('psum', 'psumsq')), (1536, 128, 1, 1, ('rowbias', 'tanh'))]   # MFA, ASP attention TDNN
     return s
 
 
@@ -55,7 +56,8 @@ def roofline_pass(reps):
     dev = torch.device('cuda')
     g = torch.Generator(device='cuda').manual_seed(1)
     total_ms, total_flop, per_shape = 0.0, 0.0, []
-    for (cin, cout, kw, dil) in conv_family_shapes(T):
+    tiles, nseg = lib.vp_conv1d_tiles_m(BATCH, T), lib.vp_conv1d_nseg(T)
+    for (cin, cout, kw, dil, extras) in conv_family_shapes(T):
         x = torch.randn((M, cin), device=dev, generator=g).to(torch.bfloat16)
         w = (torch.randn((cout, kw * cin), device=dev, generator=g) / (kw * cin) ** 0.5).to(torch.bfloat16)
         bias = torch.randn((cout,), device=dev, generator=g)
@@ -69,6 +71,18 @@ def roofline_pass(reps):
         d.x, d.ldx, d.w, d.bias = x.data_ptr(), cin, w.data_ptr(), bias.data_ptr()
         d.act, d.bn_scale, d.bn_shift = N.VP_ACT_RELU, sc.data_ptr(), sh.data_ptr()
         d.y, d.ldy = y.data_ptr(), cout
+        keep = []
+        if 'ysplit' in extras:
+            y2 = torch.empty((M, 64), device=dev, dtype=torch.bfloat16); keep.append(y2)
+            d.y2, d.ldy2, d.ysplit = y2.data_ptr(), 64, 64
+        if 'psum' in extras:
+            ps = torch.empty((tiles, nseg, cout), device=dev); keep.append(ps); d.psum = ps.data_ptr()
+        if 'psumsq' in extras:
+            pq = torch.empty((tiles, nseg, cout), device=dev); keep.append(pq); d.psumsq = pq.data_ptr()
+        if 'rowbias' in extras:
+            rbv = torch.randn((BATCH, cout), device=dev, generator=g); keep.append(rbv); d.rowbias = rbv.data_ptr()
+        if 'tanh' in extras:
+            d.act2 = N.VP_ACT_TANH
         for _ in range(2):
             N.check(lib.vp_conv1d_fwd(ctx, C.byref(d), N.stream_ptr()), ctx)
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
@@ -82,7 +96,7 @@ def roofline_pass(reps):
         total_ms += ms
         total_flop += flop
         per_shape.append({'cin': cin, 'cout': cout, 'kw': kw, 'ms': round(ms, 4), 'tflops': round(flop / ms / 1e9, 1)})
-        del x, w, y
+        del x, w, y, keep
     n = len(per_shape)
     achieved = total_flop / (total_ms * 1e-3) / 1e12
     traffic = None

@@ -12,7 +12,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(HERE)
-LIB_PATH = os.path.join(PKG_ROOT, 'lib', 'libvpmi.so')
+LIB_PATH = os.environ.get('VPMI_LIB') or os.path.join(PKG_ROOT, 'lib', 'libvpmi.so')   # VPMI_LIB: A/B a build
 
 VP_F32, VP_BF16 = 0, 1
 VP_PAD_NONE, VP_PAD_REFLECT, VP_PAD_ZERO = 0, 1, 2
