@@ -67,6 +67,28 @@ int vp_fbank_cmn_f32(vp_ctx* ctx, const float* wav, const float* lens_ratio, int
                      const vp_fbank_opts* o, float* out, void* out_bf16, void* ws, size_t ws_bytes,
                      vp_stream stream);
 
+/* MelSpectrogram + CMN -- replaces AudioFeaturizer.forward with feature_method 'MelSpectrogram' ->
+ * paddle.audio.features.MelSpectrogram(**method_args) (featurizer.py:22-23): centred STFT (reflect pad,
+ * periodic Hann, win_length <= n_fft), |X|^power, Slaney mel bank (htk=False, norm='slaney'), linear
+ * power; then transpose, time-mean subtraction, length mask as above.  n_fft in {512, 1024, 2048}. */
+typedef struct {
+    int sample_rate;        /* paddle default 22050 */
+    int n_fft;              /* 2048 */
+    int hop_length;         /* 512 */
+    int win_length;         /* 0 -> n_fft */
+    int n_mels;             /* 64 */
+    float f_min;            /* 50 */
+    float f_max;            /* 0 -> sample_rate / 2 */
+    float power;            /* 2 */
+} vp_mel_opts;
+
+void vp_mel_default_opts(vp_mel_opts* o);
+int vp_mel_num_frames(const vp_mel_opts* o, int n_samples);           /* 1 + L / hop              */
+size_t vp_mel_workspace_bytes(const vp_mel_opts* o, int B, int L);
+int vp_melspec_cmn_f32(vp_ctx* ctx, const float* wav, const float* lens_ratio, int B, int L,
+                       const vp_mel_opts* o, float* out, void* out_bf16, void* ws, size_t ws_bytes,
+                       vp_stream stream);
+
 /* ------------------------------------------------------------------------------------------------
  * conv1d as implicit GEMM with fused epilogue -- replaces, per launch, the reference chain
  *   Conv1d.forward (models/utils.py:65-93: reflect "same" pad + nn.Conv1D)  /  nn.Conv1D (tdnn.py:13-21)

@@ -166,3 +166,83 @@ def synth_waves(batch, n_samples=48000, seed=1000, lowpass=0.0):
     rms = np.sqrt((x.astype(np.float64) ** 2).mean(axis=1, keepdims=True))
     x = (x * (0.1 / rms)).astype(np.float32)
     return np.clip(x, -1.0, 1.0)
+
+
+# ----------------------------------------------------------------------------- MelSpectrogram
+# paddle.audio.features.MelSpectrogram (call site ppvector/data_utils/featurizer.py:22-23) is inside the
+# un-vendored paddle package; its published algorithm (librosa-compatible) is restated here [3P-memory]:
+# STFT (hann window, periodic, win_length <= n_fft zero-padded symmetrically; center=True with reflect
+# padding of n_fft//2; frames = 1 + L // hop) -> |X|**power -> Slaney-scale, Slaney-normalised mel bank
+# (htk=False, norm='slaney') -> (n_mels, frames), linear power (no log).  Class defaults: sr 22050,
+# n_fft 2048, hop_length 512, n_mels 64, f_min 50, f_max None (-> sr/2), power 2.0.
+MEL_DEFAULTS = dict(sr=22050, n_fft=2048, hop_length=512, win_length=None, window='hann', power=2.0, center=True,
+                    pad_mode='reflect', n_mels=64, f_min=50.0, f_max=None, htk=False, norm='slaney')
+
+
+def hz_to_mel_slaney(f):
+    f = np.asarray(f, dtype=np.float64)
+    f_sp = 200.0 / 3
+    mels = f / f_sp
+    min_log_hz, min_log_mel, logstep = 1000.0, 1000.0 / f_sp, math.log(6.4) / 27.0
+    return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-10) / min_log_hz) / logstep, mels)
+
+
+def mel_to_hz_slaney(m):
+    m = np.asarray(m, dtype=np.float64)
+    f_sp = 200.0 / 3
+    min_log_hz, min_log_mel, logstep = 1000.0, 1000.0 / f_sp, math.log(6.4) / 27.0
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def slaney_mel_bank(sr, n_fft, n_mels, f_min, f_max, dtype=np.float64):
+    """(n_mels, n_fft//2 + 1) weights, librosa.filters.mel(htk=False, norm='slaney')."""
+    if f_max is None:
+        f_max = sr / 2.0
+    fftfreqs = np.linspace(0.0, sr / 2.0, 1 + n_fft // 2)
+    mel_f = mel_to_hz_slaney(np.linspace(hz_to_mel_slaney(f_min), hz_to_mel_slaney(f_max), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fftfreqs[None, :]
+    w = np.zeros((n_mels, 1 + n_fft // 2))
+    for i in range(n_mels):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        w[i] = np.maximum(0.0, np.minimum(lower, upper))
+    enorm = 2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels])
+    return (w * enorm[:, None]).astype(dtype)
+
+
+def mel_spectrogram(wave, dtype=np.float32, **kwargs):
+    """One utterance: wave (L,) -> (frames, n_mels) linear mel power."""
+    o = dict(MEL_DEFAULTS)
+    o.update(kwargs)
+    assert o['window'] == 'hann' and o['center'] and o['pad_mode'] == 'reflect' and not o['htk'] and o['norm'] == 'slaney'
+    n_fft, hop = int(o['n_fft']), int(o['hop_length'])
+    win_length = int(o['win_length'] or n_fft)
+    x = np.asarray(wave, dtype=dtype).reshape(-1)
+    xp = np.pad(x, (n_fft // 2, n_fft // 2), mode='reflect')
+    T = 1 + x.shape[0] // hop
+    n = np.arange(win_length, dtype=np.float64)
+    win = (0.5 - 0.5 * np.cos(2.0 * math.pi * n / win_length))          # periodic hann
+    lpad = (n_fft - win_length) // 2
+    win = np.pad(win, (lpad, n_fft - win_length - lpad)).astype(dtype)
+    idx = np.arange(T)[:, None] * hop + np.arange(n_fft)[None, :]
+    fr = xp[idx] * win[None, :]
+    spec = np.fft.rfft(fr.astype(np.float64) if dtype == np.float64 else fr, axis=1)
+    mag = np.abs(spec).astype(dtype)
+    pw = mag * mag if o['power'] == 2.0 else mag ** dtype(o['power'])
+    bank = slaney_mel_bank(o['sr'], n_fft, o['n_mels'], o['f_min'], o['f_max'], dtype)
+    return (pw @ bank.T).astype(dtype)
+
+
+def featurize_mel(waves, input_lens_ratio=None, method_args=None, dtype=np.float32):
+    """AudioFeaturizer.forward with feature_method 'MelSpectrogram' (featurizer.py:22-23, :45-59)."""
+    waves = np.asarray(waves, dtype=dtype)
+    if waves.ndim == 1:
+        waves = waves[None, :]
+    feats = np.stack([mel_spectrogram(w, dtype=dtype, **dict(method_args or {})) for w in waves])
+    feats = feats - feats.mean(axis=1, keepdims=True, dtype=dtype)
+    if input_lens_ratio is not None:
+        T = feats.shape[1]
+        lens = (np.asarray(input_lens_ratio, np.float32) * np.float32(T)).astype(np.int32)
+        feats = np.where((np.arange(T)[None, :] < lens[:, None])[:, :, None], feats, np.zeros_like(feats))
+    return feats.astype(dtype)

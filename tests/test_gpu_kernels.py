@@ -486,3 +486,29 @@ def test_conv1d_prologue_gate_stride(N, dtype):
     torch.cuda.synchronize()
     tol = 2e-4 + (2.0 ** -8 * refs.abs().max().item() if dtype == 'bf16' else 0.0)
     assert (ys.double().cpu() - refs).abs().max().item() < tol
+
+
+# --------------------------------------------------------------------------------------- MelSpectrogram
+@pytest.mark.parametrize('args,L', [
+    (dict(sr=16000, n_fft=1024, hop_length=320, win_length=1024, n_mels=64, f_min=50.0), 48000),   # README.md:288-296
+    (dict(sr=16000, n_fft=512, hop_length=160, win_length=400, n_mels=80, f_min=20.0), 16000),
+    (dict(sr=22050, n_mels=64), 30000),                                                          # class defaults: n_fft 2048, hop 512
+])
+def test_melspectrogram_matches_oracle(N, args, L):
+    from ppvector.data_utils.featurizer import AudioFeaturizer
+    w = ofb.synth_waves(3, L, seed=L % 97, lowpass=0.9)
+    ref = ofb.featurize_mel(w, method_args=args, dtype=np.float64)
+    fz = AudioFeaturizer('MelSpectrogram', args)
+    assert fz.feature_dim == args['n_mels']
+    out = fz(dev(w), want_bf16=True)
+    got = out.cpu().numpy()
+    assert got.shape == ref.shape
+    # linear power features: tolerance relative to the utterance's dynamic range (f32 FFT round-off)
+    scale = np.max(np.abs(ref))
+    assert np.max(np.abs(got - ref)) < 2e-5 * scale, np.max(np.abs(got - ref)) / scale
+    ratio = np.asarray([1.0, 0.6, 0.31], np.float32)
+    refm = ofb.featurize_mel(w, ratio, method_args=args, dtype=np.float64)
+    gotm = fz(dev(w), dev(ratio)).cpu().numpy()
+    assert np.max(np.abs(gotm - refm)) < 2e-5 * scale
+    with pytest.raises(ValueError):
+        AudioFeaturizer('MelSpectrogram', dict(sr=16000, n_fft=1024, f_max=14000.0))   # above Nyquist (README's f_max)

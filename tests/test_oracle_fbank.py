@@ -108,3 +108,24 @@ def test_cmn_and_mask_semantics():
 def test_silence_hits_log_floor():
     f = ofb.kaldi_fbank(np.zeros(1600, np.float32), sr=16000, n_mels=80)
     assert np.allclose(f, math.log(1e-7))
+
+
+def test_melspectrogram_oracle_matches_transformers_librosa_semantics():
+    au = pytest.importorskip('transformers.audio_utils')
+    w = ofb.synth_waves(1, 16000, seed=21, lowpass=0.9)[0]
+    args = dict(sr=16000, n_fft=1024, hop_length=320, win_length=1024, n_mels=64, f_min=50.0)
+    mine = ofb.mel_spectrogram(w, dtype=np.float64, **args)
+    assert mine.shape == (1 + 16000 // 320, 64)
+    bank = au.mel_filter_bank(num_frequency_bins=513, num_mel_filters=64, min_frequency=50.0, max_frequency=8000.0,
+                              sampling_rate=16000, norm='slaney', mel_scale='slaney')
+    assert np.max(np.abs(bank.T - ofb.slaney_mel_bank(16000, 1024, 64, 50.0, None))) < 1e-9
+    window = au.window_function(1024, 'hann', periodic=True)
+    ref = au.spectrogram(w.astype(np.float64), window, frame_length=1024, hop_length=320, fft_length=1024, power=2.0,
+                         center=True, pad_mode='reflect', mel_filters=bank, mel_floor=0.0, dtype=np.float64).T
+    assert ref.shape == mine.shape
+    assert np.max(np.abs(ref - mine)) < 1e-6 * max(1.0, np.max(np.abs(ref)))    # their STFT accumulates in complex64
+    f = ofb.featurize_mel(w[None], method_args=args)
+    assert f.shape == (1, 51, 64) and np.max(np.abs(f.mean(axis=1))) < 1e-5
+    # win_length < n_fft: window is centred in the FFT frame
+    m2 = ofb.mel_spectrogram(w, dtype=np.float64, sr=16000, n_fft=1024, hop_length=160, win_length=400, n_mels=80, f_min=20.0)
+    assert m2.shape == (101, 80) and np.all(m2 >= 0)

@@ -20,6 +20,7 @@ vp_ctx* vp_create(int device) {
 void vp_destroy(vp_ctx* ctx) {
     if (!ctx) return;
     vp_fbank_release_tables(ctx);
+    vp_mel_release_tables(ctx);
     free(ctx);
 }
 

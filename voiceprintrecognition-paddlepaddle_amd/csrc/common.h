@@ -19,6 +19,14 @@ struct vp_ctx {
     int* fb_mel_start;    // [nmel + 1] CSR offsets into fb_mel_w
     int* fb_mel_bin0;     // [nmel] first FFT bin of each filter
     float* fb_mel_w;      // [nnz]
+    // MelSpectrogram tables
+    vp_mel_opts ms_opts;
+    int ms_valid, ms_nnz;
+    float* ms_window;     // [n_fft]
+    float2* ms_twiddle;   // [n_fft]
+    int* ms_mel_start;
+    int* ms_mel_bin0;
+    float* ms_mel_w;
 };
 
 #define VP_FAIL(ctx, code, ...)                                      \
@@ -87,3 +95,4 @@ int vp_row_inv_norm(vp_ctx* ctx, const float* x, int rows, int D, int ld, float 
 
 // kernels' host launchers (defined in the .hip files)
 int vp_fbank_release_tables(vp_ctx* ctx);
+int vp_mel_release_tables(vp_ctx* ctx);

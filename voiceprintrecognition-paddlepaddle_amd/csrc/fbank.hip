@@ -312,6 +312,20 @@ int build_tables(vp_ctx* ctx, const vp_fbank_opts* o) {
 
 }  // namespace
 
+// CMN pass shared by the Fbank and MelSpectrogram paths: subtract the per-utterance time mean (from the
+// per-tile column sums), apply the length mask, optionally emit the bf16 twin.
+int vp_feat_cmn(vp_ctx* ctx, float* out, void* out_bf16, const float* psum, const float* lens_ratio, int B, int T,
+                int tiles, int n_mels, hipStream_t st) {
+    CmnArgs c;
+    c.out = out; c.out_bf16 = (bf16_t*)out_bf16; c.psum = psum; c.lens_ratio = lens_ratio;
+    c.B = B; c.T = T; c.tiles = tiles; c.n_mels = n_mels;
+    int gx = (T * n_mels + 4095) / 4096;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(fbank_cmn_kernel, dim3(gx, B), dim3(256), 0, st, c);
+    VP_LAUNCH_CHECK(ctx, "feat_cmn");
+    return VP_OK;
+}
+
 int vp_fbank_release_tables(vp_ctx* ctx) {
     if (!ctx) return VP_OK;
     if (ctx->fb_window) (void)hipFree(ctx->fb_window);
@@ -364,14 +378,7 @@ int vp_fbank_cmn_f32(vp_ctx* ctx, const float* wav, const float* lens_ratio, int
     a.remove_dc = o->remove_dc;
     hipLaunchKernelGGL(fbank_frames_kernel, dim3(tiles, B), dim3(FB_WAVES * 64), 0, st, a);
     VP_LAUNCH_CHECK(ctx, "fbank_frames");
-    CmnArgs c;
-    c.out = out; c.out_bf16 = (bf16_t*)out_bf16; c.psum = (const float*)ws; c.lens_ratio = lens_ratio;
-    c.B = B; c.T = T; c.tiles = tiles; c.n_mels = o->n_mels;
-    int gx = (T * o->n_mels + 4095) / 4096;
-    if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(fbank_cmn_kernel, dim3(gx, B), dim3(256), 0, st, c);
-    VP_LAUNCH_CHECK(ctx, "fbank_cmn");
-    return VP_OK;
+    return vp_feat_cmn(ctx, out, out_bf16, (const float*)ws, lens_ratio, B, T, tiles, o->n_mels, st);
 }
 
 }  // extern "C"

@@ -28,6 +28,11 @@ class FbankOpts(C.Structure):
                 ('low_freq', c_float), ('high_freq', c_float), ('log_floor', c_float)]
 
 
+class MelOpts(C.Structure):
+    _fields_ = [('sample_rate', c_int), ('n_fft', c_int), ('hop_length', c_int), ('win_length', c_int),
+                ('n_mels', c_int), ('f_min', c_float), ('f_max', c_float), ('power', c_float)]
+
+
 class Conv1dDesc(C.Structure):
     _fields_ = [('dtype_in', c_int), ('dtype_out', c_int), ('B', c_int), ('T_in', c_int), ('T_out', c_int),
                 ('Cin', c_int), ('Cout', c_int), ('KW', c_int), ('dilation', c_int), ('stride', c_int),
@@ -110,6 +115,11 @@ _PROTOS = {
     'vp_fbank_workspace_bytes': (c_size_t, [C.POINTER(FbankOpts), c_int, c_int]),
     'vp_fbank_cmn_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, C.POINTER(FbankOpts), c_void_p,
                                  c_void_p, c_void_p, c_size_t, c_void_p]),
+    'vp_mel_default_opts': (None, [C.POINTER(MelOpts)]),
+    'vp_mel_num_frames': (c_int, [C.POINTER(MelOpts), c_int]),
+    'vp_mel_workspace_bytes': (c_size_t, [C.POINTER(MelOpts), c_int, c_int]),
+    'vp_melspec_cmn_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, C.POINTER(MelOpts), c_void_p,
+                                   c_void_p, c_void_p, c_size_t, c_void_p]),
     'vp_conv1d_tiles_m': (c_int, [c_int, c_int]),
     'vp_conv1d_nseg': (c_int, [c_int]),
     'vp_conv1d_fwd': (c_int, [c_void_p, C.POINTER(Conv1dDesc), c_void_p]),

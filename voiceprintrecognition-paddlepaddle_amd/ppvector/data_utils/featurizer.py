@@ -35,7 +35,9 @@ class AudioFeaturizer(nn.Module):
         self._feature_method = feature_method
         if feature_method == 'Fbank':
             self._opts = self._fbank_opts(method_args)
-        elif feature_method in ('LogMelSpectrogram', 'MelSpectrogram', 'Spectrogram', 'MFCC'):
+        elif feature_method == 'MelSpectrogram':
+            self._opts = self._mel_opts(method_args)
+        elif feature_method in ('LogMelSpectrogram', 'Spectrogram', 'MFCC'):
             self._opts = None       # known to the reference; not built on the HIP engine yet
         else:
             raise Exception(f'预处理方法 {self._feature_method} 不存在!')
@@ -55,7 +57,33 @@ class AudioFeaturizer(nn.Module):
                 raise TypeError(f"fbank() got an unexpected keyword argument '{k}'")
         return o
 
+    @staticmethod
+    def _mel_opts(method_args):
+        """paddle.audio.features.MelSpectrogram keyword surface (defaults: sr 22050, n_fft 2048, hop_length 512,
+        win_length None, window 'hann', power 2.0, center True, pad_mode 'reflect', n_mels 64, f_min 50.0,
+        f_max None, htk False, norm 'slaney')."""
+        o = N.MelOpts()
+        N.lib().vp_mel_default_opts(C.byref(o))
+        names = {'sr': 'sample_rate', 'n_fft': 'n_fft', 'hop_length': 'hop_length', 'win_length': 'win_length',
+                 'n_mels': 'n_mels', 'f_min': 'f_min', 'f_max': 'f_max', 'power': 'power'}
+        fixed = {'window': 'hann', 'center': True, 'pad_mode': 'reflect', 'htk': False, 'norm': 'slaney', 'dtype': 'float32'}
+        for k, v in dict(method_args).items():
+            if k in names:
+                if v is None:
+                    v = 0
+                setattr(o, names[k], type(getattr(o, names[k]))(v))
+            elif k in fixed:
+                if v != fixed[k]:
+                    raise NotImplementedError(f'MelSpectrogram option {k}={v} is not built on the HIP engine')
+            else:
+                raise TypeError(f"__init__() got an unexpected keyword argument '{k}'")
+        if o.f_max > 0.5 * o.sample_rate:
+            raise ValueError(f'f_max {o.f_max} is above the Nyquist frequency of sr {o.sample_rate}')
+        return o
+
     def num_frames(self, n_samples):
+        if self._feature_method == 'MelSpectrogram':
+            return N.lib().vp_mel_num_frames(C.byref(self._opts), int(n_samples))
         return N.lib().vp_fbank_num_frames(C.byref(self._opts), int(n_samples))
 
     def forward(self, waveforms, input_lens_ratio=None, want_bf16=False):
@@ -74,7 +102,8 @@ class AudioFeaturizer(nn.Module):
         wav = waveforms.contiguous().float()
         B, L = wav.shape
         lib, ctx = N.lib(), N.ctx(wav.device)
-        T = lib.vp_fbank_num_frames(C.byref(self._opts), L)
+        mel = self._feature_method == 'MelSpectrogram'
+        T = (lib.vp_mel_num_frames if mel else lib.vp_fbank_num_frames)(C.byref(self._opts), L)
         if T <= 0:
             raise ValueError(f'{L} samples are shorter than one analysis window')
         F = self._opts.n_mels
@@ -83,10 +112,11 @@ class AudioFeaturizer(nn.Module):
         ratio = None
         if input_lens_ratio is not None:
             ratio = input_lens_ratio.to(device=wav.device, dtype=torch.float32).contiguous()
-        nws = lib.vp_fbank_workspace_bytes(C.byref(self._opts), B, L)
+        nws = (lib.vp_mel_workspace_bytes if mel else lib.vp_fbank_workspace_bytes)(C.byref(self._opts), B, L)
         ws = self._ws.get(nws, wav.device)
-        N.check(lib.vp_fbank_cmn_f32(ctx, N.ptr(wav), N.ptr(ratio), B, L, C.byref(self._opts), N.ptr(out),
-                                     N.ptr(out16), N.ptr(ws), ws.numel(), N.stream_ptr()), ctx)
+        fn = lib.vp_melspec_cmn_f32 if mel else lib.vp_fbank_cmn_f32
+        N.check(fn(ctx, N.ptr(wav), N.ptr(ratio), B, L, C.byref(self._opts), N.ptr(out), N.ptr(out16), N.ptr(ws),
+                   ws.numel(), N.stream_ptr()), ctx)
         if out16 is not None:
             out._vp_bf16 = out16
         return out
