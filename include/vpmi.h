@@ -281,6 +281,40 @@ int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats
                     void* ws, size_t ws_bytes, vp_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * ResNetSE backbone forward, eval mode -- replaces ResNetSE.forward (models/resnet_se.py:121-139) with
+ * SEBottleneck (:8-45) / SELayer (:48-63) blocks and ASP pooling.  2-D conv weights as for CAM++
+ * ([Cout][tap*Cin + c], tap = kt*3 + kf).  SE Linear weights stay in Paddle's [in, out] layout.  The ASP /
+ * Linear weights are permuted by the host to the engine's channel order f*C + c (reference: c*F + f).
+ * ---------------------------------------------------------------------------------------------- */
+#define VP_MAX_RSE_BLOCKS 32
+
+typedef struct {
+    vp_tdnn_layer conv1, conv2, conv3, down;  /* 1x1, 3x3 (kw = 9, stride), 1x1, optional strided 1x1; BN folded */
+    const float* se_w1;       /* [C][C/8] f32 (Paddle Linear layout) */
+    const float* se_b1;
+    const float* se_w2;       /* [C/8][C] f32 */
+    const float* se_b2;
+    int stride, has_down;
+} vp_rse_block;
+
+typedef struct {
+    int dtype;
+    int feat_dim, embd_dim, n_blocks, c1_channels;
+    const float* c1_w;        /* [32][9] f32, tap = kt*3 + kf */
+    const float* c1_b;
+    const float* c1_scale;
+    const float* c1_shift;
+    vp_rse_block blk[VP_MAX_RSE_BLOCKS];
+    vp_asp_weights asp;       /* C = F/8 * C4 channels */
+    const float* lin_w;       /* [embd][2*C] f32, bn2 and bn3 folded */
+    const float* lin_b;
+} vp_resnetse_weights;
+
+size_t vp_resnetse_workspace_bytes(const vp_resnetse_weights* w, int B, int T);
+int vp_resnetse_fwd(vp_ctx* ctx, const vp_resnetse_weights* w, const void* feats, int B, int T, float* emb,
+                    void* ws, size_t ws_bytes, vp_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Cosine classifier + AAM-softmax loss -- replaces SpeakerIdentification.forward 'Cosine' branch
  * (models/fc.py:41-53) and AAMLoss.forward (loss/aamloss.py:28-47) incl. CrossEntropyLoss
  * (label_smoothing, mean reduction).  emb (B, D) f32; W (D, C) f32 (fc.py:31 layout); labels int64.

@@ -152,6 +152,26 @@ def main():
     cmp('cam++ eval emb', ec_or, ec_ref, 2e-5)
     out['campplus_ref_small.npz'] = dict(x=xc, emb_eval=ec_ref.numpy(), param_seed=np.int64(1000))
 
+    # ---------------- ResNetSE (configs/resnet_se.yml), F=80
+    from oracle import resnet_se as orn
+    ref_rn = importlib.import_module('ppvector.models.resnet_se')
+    pr = orn.resnetse_params(input_size=F_, embd_dim=192, seed=1000)
+    rm = ref_rn.ResNetSE(input_size=F_, embd_dim=192, pooling_type='ASP')
+    sdr = rm.state_dict()
+    assert set(sdr.keys()) == set(pr.keys()), sorted(set(sdr.keys()) ^ set(pr.keys()))[:10]
+    for k in sdr:
+        assert tuple(sdr[k].shape) == tuple(pr[k].shape), k
+    rm.load_state_dict(pr)
+    rm.eval()
+    nt, nb_ = om.count_params(pr)
+    print(f'ResNetSE F=80 params: trainable {nt}, buffers {nb_}')
+    xr = rng.standard_normal((2, 66, F_)).astype(np.float32) * 3.0
+    with torch.no_grad():
+        er_ref = rm(paddle_shim.to_tensor(xr))
+        er_or = orn.resnetse_forward(pr, torch.from_numpy(xr))
+    cmp('resnetse eval emb', er_or, er_ref, 2e-5)
+    out['resnetse_ref_small.npz'] = dict(x=xr, emb_eval=er_ref.numpy(), param_seed=np.int64(1000))
+
     # ---------------- real speech: 4 reference WAVs (3 s crops) -> oracle Fbank -> reference ECAPA graph
     names = ['a_1', 'a_2', 'b_1', 'b_2']
     pcm = np.stack([read_wav_16k_mono(f'{REF}/dataset/{n}.wav') for n in names])

@@ -281,6 +281,15 @@ class CrossEntropyLoss(Layer):
         return TF.cross_entropy(logits, labels.reshape(-1).long(), label_smoothing=self.label_smoothing)
 
 
+class AdaptiveAvgPool2D(Layer):
+    def __init__(self, output_size, **kw):
+        super().__init__()
+        assert output_size == 1
+
+    def forward(self, x):
+        return x.mean(dim=(2, 3), keepdim=True)
+
+
 class LayerList(torch.nn.ModuleList):
     def forward(self, *a, **k):
         raise NotImplementedError
@@ -316,7 +325,7 @@ _init.KaimingNormal = lambda *a, **k: None
 _init.Constant = lambda *a, **k: None
 
 for _n, _v in dict(Layer=Layer, Conv1D=Conv1D, Conv2D=Conv2D, BatchNorm1D=BatchNorm1D, BatchNorm2D=BatchNorm2D,
-                   Linear=Linear, ReLU=_act(torch.relu), Sigmoid=_act(torch.sigmoid), Tanh=_act(torch.tanh),
+                   Linear=Linear, AdaptiveAvgPool2D=AdaptiveAvgPool2D, ReLU=_act(torch.relu), Sigmoid=_act(torch.sigmoid), Tanh=_act(torch.tanh),
                    CrossEntropyLoss=CrossEntropyLoss, LayerList=LayerList, Sequential=Sequential,
                    initializer=_init).items():
     setattr(nn, _n, _v)

@@ -244,3 +244,30 @@ def test_campplus_matches_reference_golden(golden_dir):
         ref3 = oc.campplus_forward(p, torch.from_numpy(feats)).numpy()
     e3 = m.engine('float32').forward(torch.from_numpy(feats).cuda()).cpu().numpy()
     assert np.linalg.norm(e3 - ref3) / np.linalg.norm(ref3) < 3e-4
+
+
+def test_resnetse_matches_reference_golden(golden_dir):
+    """ResNetSE (configs/resnet_se.yml: embd_dim 256 there; default 192 here) vs the output of the reference's own
+    resnet_se.py (golden), plus a 1 s odd-length batch vs the oracle (stride-2 stages on odd T and F/8 = 10 bins)."""
+    from oracle import resnet_se as orse
+    from ppvector.models.resnet_se import ResNetSE
+    g = np.load(f'{golden_dir}/resnetse_ref_small.npz')
+    p = orse.resnetse_params(80, 192, seed=int(g['param_seed']))
+    m = ResNetSE(80, embd_dim=192)
+    m.load_state_dict(p)
+    m = m.cuda().eval()
+    x = torch.from_numpy(g['x']).cuda()
+    ref = g['emb_eval']
+    for dtype, tol in (('float32', 3e-4), ('bfloat16', 8e-2)):
+        emb = m.engine(dtype).forward(x).cpu().numpy()
+        rel = np.linalg.norm(emb - ref) / np.linalg.norm(ref)
+        c = _cos_rows(emb, ref)
+        print(f'[resnetse {dtype}] rel-L2 {rel:.3e}  1-cos {1 - c.min():.3e}')
+        assert rel < tol, (dtype, rel)
+    w = ofb.synth_waves(3, 16000 + 160 * 3, seed=6, lowpass=0.9)
+    feats = ofb.featurize(w, method_args=dict(sr=16000, n_mels=80))
+    assert feats.shape[1] % 8 != 0
+    with torch.no_grad():
+        ref3 = orse.resnetse_forward(p, torch.from_numpy(feats)).numpy()
+    e3 = m.engine('float32').forward(torch.from_numpy(feats).cuda()).cpu().numpy()
+    assert np.linalg.norm(e3 - ref3) / np.linalg.norm(ref3) < 3e-4

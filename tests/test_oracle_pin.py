@@ -58,6 +58,17 @@ def test_tdnn_oracle_matches_reference_golden(golden_dir):
     assert np.max(np.abs(emb - g['emb_eval'])) < 1e-4 * np.max(np.abs(g['emb_eval']))
 
 
+def test_campplus_resnetse_oracles_match_reference_golden(golden_dir):
+    from oracle import campplus as oc, resnet_se as orse
+    for name, params, fwd in (('campplus_ref_small.npz', oc.campplus_params, oc.campplus_forward),
+                              ('resnetse_ref_small.npz', orse.resnetse_params, orse.resnetse_forward)):
+        g = _load(golden_dir, name)
+        p = params(80, 192, seed=int(g['param_seed']))
+        with torch.no_grad():
+            emb = fwd(p, torch.from_numpy(g['x'])).numpy()
+        assert np.max(np.abs(emb - g['emb_eval'])) < 1e-4 * np.max(np.abs(g['emb_eval'])), name
+
+
 def test_real_speech_fixture(golden_dir):
     g = _load(golden_dir, 'wavs_3s.npz')
     wav = g['pcm'].astype(np.float32) / 32768.0

@@ -8,15 +8,20 @@ sys.path.insert(0, os.path.join(ROOT, 'voiceprintrecognition-paddlepaddle_amd'))
 import torch  # noqa: E402
 from oracle import campplus as oc  # noqa: E402
 from oracle import models as om  # noqa: E402
+from oracle import resnet_se as orse  # noqa: E402
 from ppvector.models.campplus import CAMPPlus  # noqa: E402
 from ppvector.models.ecapa_tdnn import EcapaTdnn  # noqa: E402
+from ppvector.models.resnet_se import ResNetSE  # noqa: E402
 from ppvector.models.tdnn import TDNN  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 x = torch.randn(B, 298, 80, device='cuda') * 3
-GF = {'EcapaTdnn': 2.857, 'TDNN': 1.47, 'CAMPPlus': 3.20}
+GF = {'EcapaTdnn': 2.857, 'TDNN': 1.47, 'CAMPPlus': 3.20, 'ResNetSE': 12.9}
 for name, cls, params in (('EcapaTdnn', EcapaTdnn, om.ecapa_params(80)), ('TDNN', TDNN, om.tdnn_params(80)),
-                          ('CAMPPlus', lambda f: CAMPPlus(f, embd_dim=192), oc.campplus_params(80, 192))):
+                          ('CAMPPlus', lambda f: CAMPPlus(f, embd_dim=192), oc.campplus_params(80, 192)),
+                          ('ResNetSE', ResNetSE, orse.resnetse_params(80, 192))):
+    if len(sys.argv) > 2 and name not in sys.argv[2:]:
+        continue
     m = cls(80)
     m.load_state_dict(params)
     m = m.cuda().eval()

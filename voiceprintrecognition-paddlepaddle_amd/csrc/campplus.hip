@@ -193,19 +193,25 @@ void conv2d_desc(vp_conv1d_desc& d, const vp_tdnn_layer& L, int dt, int B, int T
     d.w = L.w; d.bias = L.bias; d.bn_scale = L.bn_scale; d.bn_shift = L.bn_shift;
 }
 
-template <typename TI, typename TO>
-int launch_fcm1(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats, void* out, int B, int T, hipStream_t st) {
-    Fcm1Args<TI, TO> a;
-    a.x = (const TI*)feats; a.y = (TO*)out; a.w = w->fcm1_w; a.bias = w->fcm1_b; a.scale = w->fcm1_scale; a.shift = w->fcm1_shift;
-    a.B = B; a.T = T; a.F = w->feat_dim; a.total = (long long)B * T * w->feat_dim * 4;
-    long long blocks = (a.total + 255) / 256;
+}  // namespace
+
+// 3x3 conv of a single-channel (B, T, F) map to 32 channels + BN + ReLU -> (B, T, F, 32); shared by the
+// CAM++ FCM head (campplus.py:254-255,274) and ResNetSE's stem (resnet_se.py:72-74,124-126).
+int vp_conv3x3_c1(vp_ctx* ctx, int dtype, const void* feats, void* out, const float* w, const float* bias,
+                  const float* scale, const float* shift, int B, int T, int F, hipStream_t st) {
+    const long long total = (long long)B * T * F * 4;
+    long long blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL((fcm_conv1_kernel<TI, TO>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-    VP_LAUNCH_CHECK(ctx, "fcm_conv1");
+    if (dtype == VP_BF16) {
+        Fcm1Args<bf16_t, bf16_t> a{(const bf16_t*)feats, (bf16_t*)out, w, bias, scale, shift, B, T, F, total};
+        hipLaunchKernelGGL((fcm_conv1_kernel<bf16_t, bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    } else {
+        Fcm1Args<float, float> a{(const float*)feats, (float*)out, w, bias, scale, shift, B, T, F, total};
+        hipLaunchKernelGGL((fcm_conv1_kernel<float, float>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    }
+    VP_LAUNCH_CHECK(ctx, "conv3x3_c1");
     return VP_OK;
 }
-
-}  // namespace
 
 extern "C" {
 
@@ -234,9 +240,8 @@ int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats
     vp_conv1d_desc d;
 
     // ---- FCM head: conv1 (1 -> 32), 2 x [ResBlock s2, ResBlock s1], conv2 s2
-    if (dt == VP_BF16) rc = launch_fcm1<bf16_t, bf16_t>(ctx, w, feats, p.fa, B, T, st);
-    else rc = launch_fcm1<float, float>(ctx, w, feats, p.fa, B, T, st);
-    if (rc) return rc;
+    if ((rc = vp_conv3x3_c1(ctx, dt, feats, p.fa, w->fcm1_w, w->fcm1_b, w->fcm1_scale, w->fcm1_shift, B, T, w->feat_dim, st)))
+        return rc;
     int F = w->feat_dim;
     void* cur = p.fa;
     void* t1 = p.fb;

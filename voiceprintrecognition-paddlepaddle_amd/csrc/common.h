@@ -86,6 +86,16 @@ int vp_dense_f32_ex(vp_ctx* ctx, const float* a, int lda, const float* w, int w_
                     int ldo, hipStream_t st);
 int vp_asp_softmax_stats_ex(vp_ctx* ctx, int dtype, const float* logits, const void* x, int ldx, int xoff,
                             const float* center, int ldc, int B, int T, int C, float eps, float* pooled, hipStream_t st);
+struct VpAspBufs { void* h; float* e; float* psum; float* psumsq; float* stats; float* rowbias; float* pooled; };
+int vp_run_asp(vp_ctx* ctx, const vp_asp_weights& A, int dtype, const void* x, int ldx, const float* shift,
+               int B, int T, const VpAspBufs& w, hipStream_t st);
+int vp_conv3x3_c1(vp_ctx* ctx, int dtype, const void* feats, void* out, const float* w, const float* bias,
+                  const float* scale, const float* shift, int B, int T, int F, hipStream_t st);
+int vp_se_scale_residual_ex(vp_ctx* ctx, int dtype, const void* x, int ldx, int xoff, const float* s,
+                            const void* res, int ldr, int roff, void* out, int ldo, int ooff, int B, int T, int C,
+                            int relu, hipStream_t st);
+int vp_time_moments(vp_ctx* ctx, int dtype, const void* x, int ldx, int B, int T, int C, float eps, float* stats,
+                    hipStream_t st);
 int vp_res2_chain_bf16(vp_ctx* ctx, const vp_tdnn_layer* layers, int nconv, const void* t1, void* r2, int B, int T,
                        int C, int width, hipStream_t st);
 int vp_asp_fused_bf16(vp_ctx* ctx, const void* h, const void* w, const float* bias, const void* x, int ldx,

@@ -32,14 +32,17 @@ void tdnn_desc(vp_conv1d_desc& d, const vp_tdnn_layer& L, int dtype, int B, int 
     d.w = L.w; d.bias = L.bias; d.act = VP_ACT_RELU; d.bn_scale = L.bn_scale; d.bn_shift = L.bn_shift;
 }
 
-struct AspBufs { void* h; float* e; float* psum; float* psumsq; float* stats; float* rowbias; float* pooled; };
 
-// x: (B*T, C) activations already written with psum/psumsq partials (shift = the producing layer's
-// bn_shift or NULL).  Leaves pooled (B, 2C) = [mean | std].
-int run_asp(vp_ctx* ctx, const vp_asp_weights& A, int dtype, const void* x, int ldx, const float* shift,
-            int B, int T, const AspBufs& w, hipStream_t st) {
+}  // namespace
+
+// Attentive statistics pooling over x (B*T, C).  When w.psum != NULL the global-context mean/std come
+// from the producing conv's partial sums (shift = its bn_shift or NULL); otherwise w.stats must
+// already hold [mean | std] per utterance.  Leaves pooled (B, 2C) = [mean | std].
+int vp_run_asp(vp_ctx* ctx, const vp_asp_weights& A, int dtype, const void* x, int ldx, const float* shift,
+               int B, int T, const VpAspBufs& w, hipStream_t st) {
     const int C = A.C;
-    int rc = vp_moments_finalize(ctx, w.psum, w.psumsq, shift, B, T, C, 1e-12f, 1, w.stats, st);
+    int rc = VP_OK;
+    if (w.psum) rc = vp_moments_finalize(ctx, w.psum, w.psumsq, shift, B, T, C, 1e-12f, 1, w.stats, st);
     if (rc) return rc;
     if (A.w_ctx) {
         rc = vp_dense_f32_ex(ctx, w.stats, 2 * C, A.w_ctx, 0, nullptr, nullptr, nullptr, B, A.att, 2 * C, VP_ACT_NONE,
@@ -64,6 +67,8 @@ int run_asp(vp_ctx* ctx, const vp_asp_weights& A, int dtype, const void* x, int 
     if (rc) return rc;
     return vp_asp_softmax_stats_ex(ctx, dtype, w.e, x, ldx, 0, w.stats, 2 * C, B, T, C, 1e-12f, w.pooled, st);
 }
+
+namespace {
 
 struct EcapaPlan {
     void *cat0, *cat, *t1, *r2, *t2, *tmpA, *tmpB, *mfa, *h;
@@ -195,8 +200,8 @@ int vp_ecapa_fwd(vp_ctx* ctx, const vp_ecapa_weights* w, const void* feats, int 
     tdnn_desc(d, w->mfa, dt, B, T, T, VP_PAD_REFLECT);
     d.x = p.cat; d.ldx = ldcat; d.y = p.mfa; d.ldy = Cm; d.psum = p.psum; d.psumsq = p.psumsq;
     if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
-    AspBufs ab{p.h, p.e, p.psum, p.psumsq, p.stats, p.rowbias, p.pooled};
-    if ((rc = run_asp(ctx, w->asp, dt, p.mfa, Cm, w->mfa.bn_shift, B, T, ab, st))) return rc;
+    VpAspBufs ab{p.h, p.e, p.psum, p.psumsq, p.stats, p.rowbias, p.pooled};
+    if ((rc = vp_run_asp(ctx, w->asp, dt, p.mfa, Cm, w->mfa.bn_shift, B, T, ab, st))) return rc;
     // asp_bn (folded) + fc
     return vp_dense_f32_ex(ctx, p.pooled, 2 * Cm, w->fc_w, 0, w->fc_b, nullptr, nullptr, B, w->embd_dim, 2 * Cm,
                            VP_ACT_NONE, emb, w->embd_dim, st);
@@ -261,8 +266,8 @@ int vp_tdnn_fwd(vp_ctx* ctx, const vp_tdnn_weights* w, const void* feats, int B,
         if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
         x = outs[i]; ldx = C;
     }
-    AspBufs ab{p.h, p.e, p.psum, p.psumsq, p.stats, p.rowbias, p.pooled};
-    if ((rc = run_asp(ctx, w->asp, w->dtype, x, C, w->td[4].bn_shift, B, Ts[5], ab, st))) return rc;
+    VpAspBufs ab{p.h, p.e, p.psum, p.psumsq, p.stats, p.rowbias, p.pooled};
+    if ((rc = vp_run_asp(ctx, w->asp, w->dtype, x, C, w->td[4].bn_shift, B, Ts[5], ab, st))) return rc;
     return vp_dense_f32_ex(ctx, p.pooled, 2 * C, w->lin_w, 0, w->lin_b, nullptr, nullptr, B, w->embd_dim, 2 * C,
                            VP_ACT_NONE, emb, w->embd_dim, st);
 }

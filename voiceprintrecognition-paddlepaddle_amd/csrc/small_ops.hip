@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void row_inv_norm_kernel(const float* x, int r
 template <typename T>
 struct SeArgs {
     const T* x; const float* s; const T* res; T* out;
-    int ldx, xoff, ldr, roff, ldo, ooff, T_, C; long long total;
+    int ldx, xoff, ldr, roff, ldo, ooff, T_, C, relu; long long total;
 };
 
 template <typename T>
@@ -136,7 +136,11 @@ __global__ __launch_bounds__(256) void se_scale_residual_kernel(SeArgs<T> a) {
         uint4 o;
         T* oe = reinterpret_cast<T*>(&o);
 #pragma unroll
-        for (int e = 0; e < V; ++e) oe[e] = vp_from_f32<T>(vp_to_f32(xe[e]) * sp[e] + vp_to_f32(re[e]));
+        for (int e = 0; e < V; ++e) {
+            float v = vp_to_f32(xe[e]) * sp[e] + vp_to_f32(re[e]);
+            if (a.relu) v = fmaxf(v, 0.f);
+            oe[e] = vp_from_f32<T>(v);
+        }
         *reinterpret_cast<uint4*>(a.out + m * a.ldo + a.ooff + c) = o;
     }
 }
@@ -194,6 +198,75 @@ __global__ __launch_bounds__(256) void asp_softmax_stats_kernel(AspArgs<T> a) {
 
 }  // namespace
 
+int vp_se_scale_residual_ex(vp_ctx* ctx, int dtype, const void* x, int ldx, int xoff, const float* s,
+                            const void* res, int ldr, int roff, void* out, int ldo, int ooff, int B, int T, int C,
+                            int relu, hipStream_t st) {
+    if (!ctx || !x || !s || !res || !out || B <= 0 || T <= 0 || C <= 0) VP_FAIL(ctx, VP_EINVAL, "se: bad arguments");
+    const int V = dtype == VP_BF16 ? 8 : 4;
+    if (C % V || ldx % V || xoff % V || ldr % V || roff % V || ldo % V || ooff % V)
+        VP_FAIL(ctx, VP_EINVAL, "se: C/ld/off must be multiples of %d", V);
+    const long long total = (long long)B * T * (C / V);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (dtype == VP_BF16) {
+        SeArgs<bf16_t> a{(const bf16_t*)x, s, (const bf16_t*)res, (bf16_t*)out, ldx, xoff, ldr, roff, ldo, ooff, T, C, relu, total};
+        hipLaunchKernelGGL(se_scale_residual_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    } else if (dtype == VP_F32) {
+        SeArgs<float> a{(const float*)x, s, (const float*)res, (float*)out, ldx, xoff, ldr, roff, ldo, ooff, T, C, relu, total};
+        hipLaunchKernelGGL(se_scale_residual_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    } else {
+        VP_FAIL(ctx, VP_EINVAL, "se: bad dtype");
+    }
+    VP_LAUNCH_CHECK(ctx, "se_scale_residual");
+    return VP_OK;
+}
+
+// mean / std over time straight from the activations (small T): stats[b] = [mean(C) | sqrt(max(E[(x-m)^2], eps))]
+namespace {
+template <typename T>
+struct TmArgs { const T* x; float* stats; int ldx, Tn, C; float eps; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void time_moments_kernel(TmArgs<T> a) {
+    __shared__ float sm[2][4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.y, c = blockIdx.x * 64 + lane;
+    const bool ok = c < a.C;
+    const int cc = ok ? c : 0;
+    const T* xb = a.x + (size_t)b * a.Tn * a.ldx;
+    const float c0 = vp_to_f32(xb[cc]);
+    float s1 = 0.f, s2 = 0.f;
+    for (int t = wv; t < a.Tn; t += 4) {
+        const float v = vp_to_f32(xb[(size_t)t * a.ldx + cc]) - c0;
+        s1 += v; s2 += v * v;
+    }
+    sm[0][wv][lane] = s1; sm[1][wv][lane] = s2;
+    __syncthreads();
+    if (wv == 0 && ok) {
+        const float t1 = sm[0][0][lane] + sm[0][1][lane] + sm[0][2][lane] + sm[0][3][lane];
+        const float t2 = sm[1][0][lane] + sm[1][1][lane] + sm[1][2][lane] + sm[1][3][lane];
+        const float md = t1 / (float)a.Tn;
+        a.stats[(size_t)b * 2 * a.C + c] = c0 + md;
+        a.stats[(size_t)b * 2 * a.C + a.C + c] = sqrtf(fmaxf(t2 / (float)a.Tn - md * md, a.eps));
+    }
+}
+}  // namespace
+
+int vp_time_moments(vp_ctx* ctx, int dtype, const void* x, int ldx, int B, int T, int C, float eps, float* stats,
+                    hipStream_t st) {
+    if (B > 65535) VP_FAIL(ctx, VP_EINVAL, "time_moments: batch too large");
+    dim3 grid((C + 63) / 64, B);
+    if (dtype == VP_BF16) {
+        TmArgs<bf16_t> a{(const bf16_t*)x, stats, ldx, T, C, eps};
+        hipLaunchKernelGGL(time_moments_kernel<bf16_t>, grid, dim3(256), 0, st, a);
+    } else {
+        TmArgs<float> a{(const float*)x, stats, ldx, T, C, eps};
+        hipLaunchKernelGGL(time_moments_kernel<float>, grid, dim3(256), 0, st, a);
+    }
+    VP_LAUNCH_CHECK(ctx, "time_moments");
+    return VP_OK;
+}
+
 int vp_dense_f32_ex(vp_ctx* ctx, const float* a, int lda, const float* w, int w_is_kn, const float* bias,
                     const float* rowscale, const float* colscale, int M, int N, int K, int act, float* out,
                     int ldo, hipStream_t st) {
@@ -241,25 +314,7 @@ int vp_dense_f32(vp_ctx* ctx, const float* a, int lda, const float* w, int w_is_
 int vp_se_scale_residual(vp_ctx* ctx, int dtype, const void* x, int ldx, int xoff, const float* s,
                          const void* res, int ldr, int roff, void* out, int ldo, int ooff,
                          int B, int T, int C, vp_stream stream) {
-    if (!ctx || !x || !s || !res || !out || B <= 0 || T <= 0 || C <= 0) VP_FAIL(ctx, VP_EINVAL, "se: bad arguments");
-    const int V = dtype == VP_BF16 ? 8 : 4;
-    if (C % V || ldx % V || xoff % V || ldr % V || roff % V || ldo % V || ooff % V)
-        VP_FAIL(ctx, VP_EINVAL, "se: C/ld/off must be multiples of %d", V);
-    const long long total = (long long)B * T * (C / V);
-    long long blocks = (total + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == VP_BF16) {
-        SeArgs<bf16_t> a{(const bf16_t*)x, s, (const bf16_t*)res, (bf16_t*)out, ldx, xoff, ldr, roff, ldo, ooff, T, C, total};
-        hipLaunchKernelGGL(se_scale_residual_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, a);
-    } else if (dtype == VP_F32) {
-        SeArgs<float> a{(const float*)x, s, (const float*)res, (float*)out, ldx, xoff, ldr, roff, ldo, ooff, T, C, total};
-        hipLaunchKernelGGL(se_scale_residual_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, a);
-    } else {
-        VP_FAIL(ctx, VP_EINVAL, "se: bad dtype");
-    }
-    VP_LAUNCH_CHECK(ctx, "se_scale_residual");
-    return VP_OK;
+    return vp_se_scale_residual_ex(ctx, dtype, x, ldx, xoff, s, res, ldr, roff, out, ldo, ooff, B, T, C, 0, (hipStream_t)stream);
 }
 
 }  // extern "C"

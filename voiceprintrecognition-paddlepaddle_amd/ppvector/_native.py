@@ -105,6 +105,21 @@ class CamppWeights(C.Structure):
                 ('out_bn_scale', c_void_p), ('out_bn_shift', c_void_p), ('dense_w', c_void_p), ('dense_b', c_void_p)]
 
 
+VP_MAX_RSE_BLOCKS = 32
+
+
+class RseBlock(C.Structure):
+    _fields_ = [('conv1', TdnnLayer), ('conv2', TdnnLayer), ('conv3', TdnnLayer), ('down', TdnnLayer),
+                ('se_w1', c_void_p), ('se_b1', c_void_p), ('se_w2', c_void_p), ('se_b2', c_void_p),
+                ('stride', c_int), ('has_down', c_int)]
+
+
+class ResnetSeWeights(C.Structure):
+    _fields_ = [('dtype', c_int), ('feat_dim', c_int), ('embd_dim', c_int), ('n_blocks', c_int), ('c1_channels', c_int),
+                ('c1_w', c_void_p), ('c1_b', c_void_p), ('c1_scale', c_void_p), ('c1_shift', c_void_p),
+                ('blk', RseBlock * VP_MAX_RSE_BLOCKS), ('asp', AspWeights), ('lin_w', c_void_p), ('lin_b', c_void_p)]
+
+
 _PROTOS = {
     'vp_version': (c_int, []),
     'vp_create': (c_void_p, [c_int]),
@@ -140,6 +155,9 @@ _PROTOS = {
                             c_size_t, c_void_p]),
     'vp_campplus_workspace_bytes': (c_size_t, [C.POINTER(CamppWeights), c_int, c_int]),
     'vp_campplus_fwd': (c_int, [c_void_p, C.POINTER(CamppWeights), c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                c_size_t, c_void_p]),
+    'vp_resnetse_workspace_bytes': (c_size_t, [C.POINTER(ResnetSeWeights), c_int, c_int]),
+    'vp_resnetse_fwd': (c_int, [c_void_p, C.POINTER(ResnetSeWeights), c_void_p, c_int, c_int, c_void_p, c_void_p,
                                 c_size_t, c_void_p]),
     'vp_cosine_logits_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'vp_cosine_logits_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,

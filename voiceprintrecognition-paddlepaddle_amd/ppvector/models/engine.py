@@ -238,6 +238,76 @@ class CamppEngine(_Engine):
         return emb
 
 
+class ResNetSEEngine(CamppEngine):
+    """Packs a ResNetSE module into vp_resnetse_weights (include/vpmi.h)."""
+
+    def __init__(self, m, dtype_name):
+        _Engine.__init__(self, m, dtype_name)
+        W = N.ResnetSeWeights()
+        W.dtype, W.feat_dim, W.embd_dim, W.c1_channels = self.dt, m.input_size, m.embd_dim, m.conv1.weight.shape[0]
+        if m.input_size % 8:
+            raise NotImplementedError('ResNetSE on the HIP engine needs input_size % 8 == 0 (the reference sizes its '
+                                      'pooling for input_size // 8 bins)')
+        w1 = m.conv1.weight.detach()[:, 0]                          # (32, kF, kT)
+        W.c1_w = self._p(w1.permute(0, 2, 1).reshape(w1.shape[0], 9).float())
+        W.c1_b = self._p(f32(m.conv1.bias))
+        sc, sh = m.bn1.folded()
+        W.c1_scale, W.c1_shift = self._p(sc), self._p(sh)
+        blocks = [b for l in (m.layer1, m.layer2, m.layer3, m.layer4) for b in l]
+        if len(blocks) > N.VP_MAX_RSE_BLOCKS:
+            raise NotImplementedError(f'more than {N.VP_MAX_RSE_BLOCKS} bottleneck blocks')
+        W.n_blocks = len(blocks)
+        for i, b in enumerate(blocks):
+            R = W.blk[i]
+            self.conv2d(R.conv1, b.conv1, b.bn1)
+            self.conv2d(R.conv2, b.conv2, b.bn2)
+            self.conv2d(R.conv3, b.conv3, b.bn3)
+            R.se_w1, R.se_b1 = self._p(f32(b.se.fc[0].weight)), self._p(f32(b.se.fc[0].bias))
+            R.se_w2, R.se_b2 = self._p(f32(b.se.fc[2].weight)), self._p(f32(b.se.fc[2].bias))
+            st = b.stride[0] if isinstance(b.stride, (tuple, list)) else b.stride
+            R.stride, R.has_down = st, int(b.downsample is not None)
+            if R.has_down:
+                self.conv2d(R.down, b.downsample[0], b.downsample[1])
+        # reference channel index after reshape (B, C*F', T') is c * F' + f; the engine keeps (B, T', F', C): f * C + c
+        C4 = blocks[-1].conv3.weight.shape[0]
+        Fq = m.input_size // 8
+        Cc = C4 * Fq
+
+        def perm_cols(w):                                           # (..., k*Cc) columns c*Fq+f -> f*C4+c per Cc group
+            lead = w.shape[:-1]
+            k = w.shape[-1] // Cc
+            return w.reshape(*lead, k, C4, Fq).transpose(-1, -2).reshape(*lead, k * Cc)
+
+        asp, A = m.pooling, W.asp
+        w = perm_cols(asp.tdnn.conv.conv.weight.detach()[:, :, 0])  # (att, 3 Cc)
+        self.tdnn_layer(A.tdnn, asp.tdnn.conv.conv, asp.tdnn.norm.norm, 1, w_override=w[:, :Cc].to(self.tdtype).contiguous())
+        A.tdnn.cin, A.tdnn.kw = Cc, 1
+        A.w_ctx = self._p(w[:, Cc:].float().contiguous())
+        cw = asp.conv.conv.weight.detach()[:, :, 0]                 # (Cc, att): permute output rows
+        A.conv_w = self._p(cw.reshape(C4, Fq, -1).transpose(0, 1).reshape(Cc, -1).to(self.tdtype).contiguous())
+        A.conv_b = self._p(asp.conv.conv.bias.detach().float().reshape(C4, Fq).t().reshape(-1).contiguous())
+        A.C, A.att = Cc, asp.attention_channels
+        # bn3(linear(bn2(p))): fold both affines into one dense layer over the permuted pooled vector
+        s2, h2 = m.bn2.norm.folded()
+        s3, h3 = m.bn3.norm.folded()
+        lw = m.linear.weight.detach().float()                       # [2Cc, embd] (Paddle layout)
+        wt = (lw * s2[:, None]).t() * s3[:, None]                   # (embd, 2Cc)
+        W.lin_w = self._p(perm_cols(wt).contiguous())
+        W.lin_b = self._p(((h2 @ lw) + m.linear.bias.detach().float()) * s3 + h3)
+        self.W = W
+
+    def forward(self, x):
+        xin = self.feats_in(x)
+        B, T, F = xin.shape
+        lib, ctx = N.lib(), N.ctx(xin.device)
+        emb = torch.empty((B, self.W.embd_dim), dtype=torch.float32, device=xin.device)
+        nws = lib.vp_resnetse_workspace_bytes(C.byref(self.W), B, T)
+        ws = self.ws.get(nws, xin.device)
+        N.check(lib.vp_resnetse_fwd(ctx, C.byref(self.W), xin.data_ptr(), B, T, emb.data_ptr(), ws.data_ptr(),
+                                    ws.numel(), N.stream_ptr()), ctx)
+        return emb
+
+
 class EngineMixin:
     """forward() of a backbone: eval-mode fused forward on the HIP engine."""
     _engine_cls = None
