@@ -241,6 +241,59 @@ def test_conv1d_split_destination(N, dtype):
     assert torch.all(y2[:, :, :64] == 0)
 
 
+@pytest.mark.parametrize('case', [
+    # B, T, Cin, Cout, kw, dil, pad  -- M = B*T >= 16384 rows, Cin % 64 == 0, Cout >= 256: the 256 x 256 LDS-DMA kernel
+    (70, 241, 128, 320, 1, 1, 'reflect'),    # ragged M (not a multiple of 128), ragged N, utterances straddle tiles
+    (66, 250, 64, 256, 3, 2, 'reflect'),     # taps: one tap per 64-wide K step, reflect at both utterance ends
+    (64, 260, 128, 256, 3, 3, 'none'),       # un-padded (TDNN)
+    (65, 255, 64, 384, 5, 1, 'zero'),        # zero padding = out-of-range DMA offsets
+])
+def test_conv1d_wide_tiles_bf16(N, case):
+    B, T, Cin, Cout, kw, dil, pad = case
+    g = torch.Generator().manual_seed(77 + kw)
+    x = torch.randn(B, T, Cin, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, kw, generator=g, dtype=torch.float64) / (Cin * kw) ** 0.5
+    bias = torch.randn(Cout, generator=g, dtype=torch.float64)
+    rowbias = torch.randn(B, Cout, generator=g, dtype=torch.float64)
+    sc = torch.rand(Cout, generator=g, dtype=torch.float64) + 0.5
+    sh = torch.randn(Cout, generator=g, dtype=torch.float64)
+    z = conv_ref(q(x, 'bf16'), q(w, 'bf16'), bias, kw, dil, pad) + rowbias[:, None, :]
+    ref = torch.relu(z) * sc + sh
+    To = ref.shape[1]
+    add = torch.randn(B, To, Cout, generator=g, dtype=torch.float64)
+    y, aux, ps, pq = run_conv(N, x, w, bias, kw, dil, pad, 'bf16', relu=True, bn=(sc, sh), rowbias=rowbias, add_in=add,
+                              want_sums=True)
+    tol = 2e-4 + 2.0 ** -8 * ref.abs().max().item()
+    assert (y.double().cpu() - ref).abs().max().item() < tol
+    assert (aux.double().cpu() - (ref + q(add, 'bf16'))).abs().max().item() < 2 * tol
+    ps, pq = ps.double().cpu(), pq.double().cpu()
+    assert not torch.isnan(ps).any() and not torch.isnan(pq).any()
+    dref = ref - sh
+    for b in (0, 1, B // 2, B - 1):
+        s1 = torch.zeros(Cout, dtype=torch.float64)
+        s2 = torch.zeros(Cout, dtype=torch.float64)
+        for tm in range((b * To) // 128, ((b + 1) * To - 1) // 128 + 1):
+            s1 += ps[tm, b - (tm * 128) // To]
+            s2 += pq[tm, b - (tm * 128) // To]
+        assert (s1 - dref[b].sum(0)).abs().max().item() < 1e-4 * max(1.0, dref[b].sum(0).abs().max().item())
+        assert (s2 - (dref[b] ** 2).sum(0)).abs().max().item() < 1e-4 * (dref[b] ** 2).sum(0).abs().max().item()
+    ya, yb = run_conv(N, x, w, None, kw, dil, pad, 'bf16', ysplit=64)
+    assert torch.equal(yb[:, :, 64:], ya[:, :, :64])
+    assert (ya.double().cpu() - (z - rowbias[:, None, :] - bias)).abs().max().item() < tol
+    # per-channel terms only (the kernel's fast row loop) with the fused time sums
+    ref2 = torch.relu(z - rowbias[:, None, :]) * sc + sh
+    y, _, ps, pq = run_conv(N, x, w, bias, kw, dil, pad, 'bf16', relu=True, bn=(sc, sh), want_sums=True)
+    assert (y.double().cpu() - ref2).abs().max().item() < tol
+    ps, pq = ps.double().cpu(), pq.double().cpu()
+    assert not torch.isnan(ps).any() and not torch.isnan(pq).any()
+    dref = ref2 - sh
+    for b in (0, 1, B // 2, B - 1):
+        s1 = sum(ps[tm, b - (tm * 128) // To] for tm in range((b * To) // 128, ((b + 1) * To - 1) // 128 + 1))
+        s2 = sum(pq[tm, b - (tm * 128) // To] for tm in range((b * To) // 128, ((b + 1) * To - 1) // 128 + 1))
+        assert (s1 - dref[b].sum(0)).abs().max().item() < 1e-4 * max(1.0, dref[b].sum(0).abs().max().item())
+        assert (s2 - (dref[b] ** 2).sum(0)).abs().max().item() < 1e-4 * (dref[b] ** 2).sum(0).abs().max().item()
+
+
 def test_conv1d_rejects_bad_shapes(N):
     x = torch.randn(1, 8, 20, dtype=torch.float64)
     w = torch.randn(16, 20, 3, dtype=torch.float64)

@@ -27,6 +27,13 @@
 int vp_conv_launch_bf16_bf16(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
 int vp_conv_launch_bf16_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
 int vp_conv_launch_f32_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
+int vp_conv_launch256_bf16(vp_ctx* ctx, const void* args, int mode, hipStream_t st);
+
+static bool use_conv256() {          // VPMI_CONV256=0 pins the 128-wide kernel (A/B measurements)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VPMI_CONV256"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
 
 extern "C" {
 
@@ -106,6 +113,16 @@ int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream) {
     if (a.group_m > 16) a.group_m = 16;
     if (d->psum && a.nseg > NSEG_MAX) VP_FAIL(ctx, VP_EUNSUP, "conv1d: T_out %d too short for fused time sums", d->T_out);
     hipStream_t st = (hipStream_t)stream;
+    // wide bf16 layers: 256 x 256 tiles fed by LDS-DMA (conv_gemm256.hip)
+    if (d->dtype_in == VP_BF16 && d->dtype_out == VP_BF16 && (mode == MODE_1X1 || mode == MODE_TAPS) && d->Cin % 64 == 0 &&
+        d->Cout >= 256 && a.M >= 256 * 64 && !d->gate && (!d->psum || d->T_out >= 128) && use_conv256()) {
+        a.tiles_m = (a.M + 255) / 256;
+        a.tiles_n = (a.N + 255) / 256;
+        a.group_m = 32 / a.tiles_n;
+        if (a.group_m < 1) a.group_m = 1;
+        if (a.group_m > 16) a.group_m = 16;
+        return vp_conv_launch256_bf16(ctx, &a, mode, st);
+    }
     if (d->dtype_in == VP_BF16 && d->dtype_out == VP_BF16) return vp_conv_launch_bf16_bf16(ctx, &a, bn, mode, st);
     if (d->dtype_in == VP_BF16 && d->dtype_out == VP_F32) return vp_conv_launch_bf16_f32(ctx, &a, bn, mode, st);
     return vp_conv_launch_f32_f32(ctx, &a, bn, mode, st);

@@ -1,0 +1,373 @@
+// 256 x 256 x 64 conv GEMM for the wide bf16 layers (1x1 / tapped 1-D, Cin % 64 == 0).
+//
+// Why a second kernel: the 128 x 128 kernel (conv_gemm_impl.h) moves 64 FLOP per byte staged and
+// pays a ds_write_b128 pass (~79 B/clk/CU) for every byte, so its LDS pipe is as busy as its MFMA
+// pipe.  Here one workgroup of 8 waves owns a 256-position x 256-channel tile (128 FLOP per staged
+// byte), each wave a 64 x 128 sub-tile (128 accumulator VGPRs), and the operands go HBM/L2 -> LDS by
+// LDS-DMA (buffer_load_dwordx4 ... lds): no staging VGPRs and no ds_write pass.  The DMA writes a
+// wave's 64 x 16 B linearly, so the XOR swizzle that keeps ds_read_b128 conflict-free is applied to
+// the per-lane SOURCE chunk (and again on the read) instead of the destination.  Out-of-range rows /
+// padding taps use out-of-range buffer offsets: the DMA writes zeros.
+// Two LDS stages of 64 KB; per K-step: wait own DMAs -> barrier -> issue next stage -> 64 MFMAs/wave.
+// Epilogue semantics are those of conv_gemm_impl.h (same ConvArgs, same psum layout per 128 rows).
+#include "conv_gemm_impl.h"
+
+namespace {
+
+constexpr int T2 = 256;                      // tile edge (positions and channels)
+constexpr int STAGE2 = 2 * T2 * ROWB;        // X panel + W panel
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int MODE>
+__global__ __launch_bounds__(512) void conv_gemm256_kernel(const ConvArgs a) {
+    constexpr int MI = 4, NI = 8;            // per wave: 64 positions x 128 channels
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef VP_TIMING
+    const unsigned long long tk0 = wall_clock64();
+    unsigned long long tk1 = 0;
+#endif
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int li = lane & 15, g = lane >> 4;
+
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int qq = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
+    const int swz = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    const int gsz = a.group_m * a.tiles_n;
+    const int grp = swz / gsz, rem = swz - grp * gsz;
+    const int gm = min(a.group_m, a.tiles_m - grp * a.group_m);
+    const int tn = rem / gm;
+    const int tm = grp * a.group_m + (rem - tn * gm);
+    const int m0 = tm * T2, n0 = tn * T2;
+
+    constexpr unsigned OOB = 0xfffffff0u;
+    const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.w_bytes, 0x00020000);
+
+    // staging: wave wv fills rows [32 wv, 32 wv + 32) of both panels, 8 rows x 128 B per DMA; lane l
+    // lands at row (l >> 3), slot (l & 7) and therefore fetches chunk slot ^ row
+    const int srow = lane >> 3;
+    const unsigned cb = (unsigned)((lane & 7) ^ srow) << 4;
+    const bool zero_pad = a.pad_mode == VP_PAD_ZERO;
+    const unsigned ldxb = (unsigned)a.ldx * 2u;
+    unsigned rowoff[4], rowfix[4], woff[4];
+    int tpos[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wv * 32 + i * 8 + srow;
+        const bool ok = m < a.M;
+        const int mm = ok ? m : 0;
+        const int b = mm / a.T_out;
+        const int t = mm - b * a.T_out;
+        tpos[i] = t * a.stride - a.pad_left;
+        rowoff[i] = ok ? ((unsigned)(b * a.T_in) * (unsigned)a.ldx + (unsigned)a.xoff) * 2u : OOB;
+        const int traw = tpos[i];
+        int ts = traw < 0 ? -traw : traw;
+        ts = ts >= a.T_in ? 2 * (a.T_in - 1) - ts : ts;
+        const bool inr = traw >= 0 && traw < a.T_in;
+        rowfix[i] = (ok && (inr || !zero_pad)) ? rowoff[i] + (unsigned)ts * ldxb + cb : OOB;
+        const int n = n0 + wv * 32 + i * 8 + srow;
+        woff[i] = n < a.N ? (unsigned)n * (unsigned)a.K * 2u + cb : OOB;
+    }
+
+    auto stage = [&](int kt, int s) {
+        char* Xs = smem + s * STAGE2 + wv * (32 * ROWB);
+        char* Ws = Xs + T2 * ROWB;
+        const unsigned kb = (unsigned)kt * (unsigned)ROWB;
+        if constexpr (MODE == MODE_1X1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_ptr_t)(Xs + i * (8 * ROWB)), 16,
+                                                         rowfix[i] != OOB ? rowfix[i] + kb : OOB, 0, 0, 0);
+        } else {
+            const int k0 = kt * 64;                     // Cin % 64 == 0: one tap per K-step
+            const int j = k0 / a.Cin;
+            const unsigned cbase = (unsigned)(k0 - j * a.Cin) * 2u + cb;
+            const int tj = j * a.dilation;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int traw = tpos[i] + tj;
+                int ts = traw < 0 ? -traw : traw;
+                ts = ts >= a.T_in ? 2 * (a.T_in - 1) - ts : ts;
+                const bool inr = traw >= 0 && traw < a.T_in;
+                const bool ok = rowoff[i] != OOB && (inr || !zero_pad);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_ptr_t)(Xs + i * (8 * ROWB)), 16,
+                                                         ok ? rowoff[i] + (unsigned)ts * ldxb + cbase : OOB, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)(Ws + i * (8 * ROWB)), 16,
+                                                     woff[i] != OOB ? woff[i] + kb : OOB, 0, 0, 0);
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int s) {
+        const char* Xs = smem + s * STAGE2;
+        const char* Ws = Xs + T2 * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            Frag<bf16_t> xf[MI], wf[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) load_frag(Xs, wm * 64 + mi * 16 + li, ks, g, xf[mi]);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) load_frag(Ws, wn * 128 + ni * 16 + li, ks, g, wf[ni]);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) mma(wf[ni], xf[mi], acc[mi][ni]);
+        }
+    };
+
+    const int KT = a.K / 64;
+    stage(0, 0);
+    for (int kt = 0; kt < KT; ++kt) {
+        // own DMAs of stage kt have landed; after the barrier so have everyone's, and every wave
+        // is done reading the other buffer (stage kt-1), which the next DMAs overwrite
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#ifdef VP_TIMING
+        if (kt == 0) tk1 = wall_clock64();
+#endif
+        if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);
+        compute(kt & 1);
+    }
+#ifdef VP_TIMING
+    const unsigned long long tk2 = wall_clock64();
+#endif
+
+    // ------------------------------------------------------------------ epilogue
+    // y = act2( bn( act( acc + bias + rowbias ) ) + res );  aux = y + add_in;  psum/psumsq over (y - shift)
+    // (conv_gemm_impl.h semantics, no gate).  Written as ROLLED loops over an LDS image of the
+    // accumulators: the fully unrolled per-register form of the 128-wide kernel is ~25k instructions for
+    // 128 accumulators per lane and ran 15 us per tile on instruction fetch alone.  Per 64-channel half:
+    //   A. dump the wave's 64 x 64 f32 accumulators into its own LDS slab (row stride 272 B);
+    //   B. 16 iterations: lane = (row j*4 + lane/16, channels 4*(lane%16)..+3): math, 8-B store (16 lanes
+    //      cover 128 contiguous bytes of a position), (y - shift) written back to the slab;
+    //   C. column sums: lane = one channel, 64 rows, per utterance segment, into red[wm][seg][col].
+    constexpr int OROW = 272;
+    constexpr int SLABS = 8 * 64 * OROW;
+    __syncthreads();                                           // every wave is done reading the K panels
+#ifdef VP_TIMING
+    const unsigned long long te0 = wall_clock64();
+    unsigned long long te1 = 0, te1b = 0;
+    const unsigned long long ck0 = clock64();
+#endif
+    char* slab = smem + wv * (64 * OROW);
+    float* red = reinterpret_cast<float*>(smem + SLABS);       // [2 stats][4 wm][2 seg][256 col]
+    bf16_t* __restrict__ Y = static_cast<bf16_t*>(a.y);
+    bf16_t* __restrict__ Y2 = static_cast<bf16_t*>(a.y2);
+    const bf16_t* __restrict__ ADD = static_cast<const bf16_t*>(a.add_in);
+    const bf16_t* __restrict__ RES = static_cast<const bf16_t*>(a.res);
+    bf16_t* __restrict__ AUX = static_cast<bf16_t*>(a.aux);
+    const int mw = m0 + wm * 64;                               // first position of this wave
+    const int bfirst = (m0 + (wm >> 1) * 128) / a.T_out;       // first utterance of the 128-row half
+    const int q4 = lane >> 4, c4 = (lane & 15) * 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                *reinterpret_cast<f32x4*>(slab + (mi * 16 + li) * OROW + (ni * 16 + g * 4) * 4) = acc[mi][h * 4 + ni];
+#ifdef VP_TIMING
+        if (h == 0) te1b = wall_clock64();
+#endif
+        const int nb = n0 + wn * 128 + h * 64 + c4;
+        const bool nvalid = nb < a.N;
+        float bias4[4] = {0.f, 0.f, 0.f, 0.f}, sc4[4] = {1.f, 1.f, 1.f, 1.f}, sh4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (nvalid) {
+            if (a.bias) load4(a.bias + nb, bias4);
+            if (a.bn_scale) load4(a.bn_scale + nb, sc4);
+            if (a.bn_shift) load4(a.bn_shift + nb, sh4);
+        }
+        // FAST rows: the whole 64 x 64 block is inside the problem and only the per-channel terms are
+        // active (bias, ReLU, BN affine, ReLU) -- lane = (row 8j + lane/8, channels 8*(lane%8)..+7), one
+        // 16-B store per lane, 8 lanes = 128 contiguous bytes of a position.  ~40 VALU per 8 values; the
+        // general loop below spends ~25 per VALUE on masks and 64-bit addressing.
+        const int nh = n0 + wn * 128 + h * 64;
+        const bool fast = mw + 64 <= a.M && nh + 64 <= a.N && !a.rowbias && !RES && !AUX && a.act2 != VP_ACT_TANH &&
+                          (a.ysplit <= nh || a.ysplit >= nh + 64) && ((a.ldy | a.yoff) & 7) == 0 &&
+                          (reinterpret_cast<uintptr_t>(a.y) & 15) == 0 &&
+                          (a.ysplit <= nh || (((a.ldy2 | a.y2off) & 7) == 0 && (reinterpret_cast<uintptr_t>(a.y2) & 15) == 0));
+        if (fast) {
+            const int c8 = (lane & 7) * 8, q8 = lane >> 3;
+            const int nc = nh + c8;
+            float bs[8], sc[8], sh[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { bs[e] = 0.f; sc[e] = 1.f; sh[e] = 0.f; }
+            if (a.bias) { load4(a.bias + nc, bs); load4(a.bias + nc + 4, bs + 4); }
+            if (a.bn_scale) { load4(a.bn_scale + nc, sc); load4(a.bn_scale + nc + 4, sc + 4); }
+            if (a.bn_shift) { load4(a.bn_shift + nc, sh); load4(a.bn_shift + nc + 4, sh + 4); }
+            const float lo1 = a.act == VP_ACT_RELU ? 0.f : -INFINITY;
+            const float lo2 = a.act2 == VP_ACT_RELU ? 0.f : -INFINITY;
+            bf16_t* dst = Y + (size_t)(mw + q8) * a.ldy + a.yoff + nc;
+            const size_t dstep = (size_t)8 * a.ldy;
+            const bool split = a.ysplit > nh;
+            bf16_t* dst2 = split ? Y2 + (size_t)(mw + q8) * a.ldy2 + a.y2off + nc : nullptr;
+            const size_t dstep2 = (size_t)8 * a.ldy2;
+            const bool sums = a.psum != nullptr;
+            char* cell = slab + q8 * OROW + c8 * 4;
+#pragma unroll 2
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(cell);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(cell + 16);
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaxf(fmaxf(a0[e] + bs[e], lo1) * sc[e] + sh[e], lo2);
+                    v[e + 4] = fmaxf(fmaxf(a1[e] + bs[e + 4], lo1) * sc[e + 4] + sh[e + 4], lo2);
+                }
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+                *reinterpret_cast<bf16x8*>(dst) = o;
+                dst += dstep;
+                if (split) { *reinterpret_cast<bf16x8*>(dst2) = o; dst2 += dstep2; }
+                if (sums) {
+                    *reinterpret_cast<f32x4*>(cell) = f32x4{v[0] - sh[0], v[1] - sh[1], v[2] - sh[2], v[3] - sh[3]};
+                    *reinterpret_cast<f32x4*>(cell + 16) = f32x4{v[4] - sh[4], v[5] - sh[5], v[6] - sh[6], v[7] - sh[7]};
+                }
+                cell += 8 * OROW;
+            }
+        } else {
+        int m = mw + q4;
+        int b = (m < a.M ? m : a.M - 1) / a.T_out;
+        int t = m - b * a.T_out;                               // may run past T_out for rows >= M: never used then
+#pragma unroll 1
+        for (int j = 0; j < 16; ++j) {
+            char* cell = slab + (j * 4 + q4) * OROW + c4 * 4;
+            const f32x4 av = *reinterpret_cast<const f32x4*>(cell);
+            const bool ok = nvalid && m < a.M;
+            float v[4];
+            float rbias[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f};
+            if (ok && a.rowbias) load4(a.rowbias + (size_t)b * a.N + nb, rbias);
+            if (ok && RES) load4(RES + (size_t)m * a.ld_res + a.res_off + nb, rs);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = av[r] + bias4[r] + rbias[r];
+                if (a.act == VP_ACT_RELU) x = fmaxf(x, 0.f);
+                x = x * sc4[r] + sh4[r] + rs[r];
+                if (a.act2 == VP_ACT_TANH) x = tanhf(x);
+                else if (a.act2 == VP_ACT_RELU) x = fmaxf(x, 0.f);
+                v[r] = x;
+            }
+            if (ok) {
+                store4(Y + (size_t)m * a.ldy + a.yoff + nb, v);
+                if (nb < a.ysplit) store4(Y2 + (size_t)m * a.ldy2 + a.y2off + nb, v);
+                if (AUX) {
+                    float ad[4];
+                    load4(ADD + (size_t)m * a.ld_add + a.add_off + nb, ad);
+                    float s4[4] = {v[0] + ad[0], v[1] + ad[1], v[2] + ad[2], v[3] + ad[3]};
+                    store4(AUX + (size_t)m * a.ld_aux + a.aux_off + nb, s4);
+                }
+            }
+            if (a.psum)
+                *reinterpret_cast<f32x4*>(cell) = ok ? f32x4{v[0] - sh4[0], v[1] - sh4[1], v[2] - sh4[2], v[3] - sh4[3]}
+                                                     : f32x4{0.f, 0.f, 0.f, 0.f};
+            m += 4; t += 4;
+            while (t >= a.T_out) { t -= a.T_out; ++b; }
+        }
+        }
+#ifdef VP_TIMING
+        if (h == 0) te1 = wall_clock64();
+#endif
+        if (a.psum) {
+            // lane = channel h*64 + lane of this wave's 128.  T_out >= 128 > 64 rows: at most one utterance
+            // boundary inside the wave's rows, at the wave-uniform row rb
+            const int col = wn * 128 + h * 64 + lane;
+            const int bb = (mw < a.M ? mw : a.M - 1) / a.T_out;
+            const int rb = min(64, (bb + 1) * a.T_out - mw);     // rows [0, rb) belong to utterance bb
+            const char* colp = slab + lane * 4;
+            float s1 = 0.f, s2 = 0.f;
+            int r = 0;
+#pragma unroll 4
+            for (; r < rb; ++r) {
+                const float d = *reinterpret_cast<const float*>(colp + r * OROW);
+                s1 += d; s2 += d * d;
+            }
+            if (bb - bfirst < 2) {
+                red[((0 * 4 + wm) * 2 + (bb - bfirst)) * T2 + col] = s1;
+                red[((1 * 4 + wm) * 2 + (bb - bfirst)) * T2 + col] = s2;
+            }
+            if (rb < 64) {
+                s1 = 0.f; s2 = 0.f;
+#pragma unroll 4
+                for (; r < 64; ++r) {
+                    const float d = *reinterpret_cast<const float*>(colp + r * OROW);
+                    s1 += d; s2 += d * d;
+                }
+                if (bb + 1 - bfirst < 2) {
+                    red[((0 * 4 + wm) * 2 + (bb + 1 - bfirst)) * T2 + col] = s1;
+                    red[((1 * 4 + wm) * 2 + (bb + 1 - bfirst)) * T2 + col] = s2;
+                }
+            }
+        }
+    }
+    if (a.psum) {
+        // per 128-row half (= one M-tile of the 128-wide kernel's psum layout): the two waves' partials.
+        // T_out >= 128 (host-checked, nseg == 2): a wave's 64 rows touch at most two utterances and
+        // flush each (wave, segment) slot at most once; slots never flushed must read as zero.
+        __syncthreads();
+        const int col = tid & 255, half = tid >> 8;
+        if (n0 + col < a.N && m0 + half * 128 < a.M) {
+            const int bf = (m0 + half * 128) / a.T_out;
+            for (int sgi = 0; sgi < 2; ++sgi) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const int wmx = half * 2 + w;
+                    const int mlo = m0 + wmx * 64, mhi = min(mlo + 63, a.M - 1);
+                    // did wave wmx own rows of utterance bf + sgi?
+                    if (mlo < a.M && mlo / a.T_out <= bf + sgi && bf + sgi <= mhi / a.T_out) {
+                        s1 += red[((0 * 4 + wmx) * 2 + sgi) * T2 + col];
+                        s2 += red[((1 * 4 + wmx) * 2 + sgi) * T2 + col];
+                    }
+                }
+                const size_t o = ((size_t)(tm * 2 + half) * a.nseg + sgi) * a.N + n0 + col;
+                a.psum[o] = s1;
+                if (a.psumsq) a.psumsq[o] = s2;
+            }
+        }
+    }
+#ifdef VP_TIMING
+    if (!a.aux && a.add_in) {          // debug build only: per-workgroup phase stamps (100 MHz counter)
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long* o = (unsigned long long*)a.add_in + (size_t)blockIdx.x * 8;
+            o[0] = tk0; o[1] = tk1; o[2] = tk2; o[3] = wall_clock64(); o[4] = te0; o[5] = te1b; o[6] = te1; o[7] = clock64() - ck0;
+        }
+    }
+#endif
+}
+
+template <int MODE>
+int launch256(vp_ctx* ctx, const ConvArgs& a, hipStream_t st) {
+    constexpr int smem = 8 * 64 * 272 + 2 * 4 * 2 * T2 * 4;      // output slabs + column-sum partials (> the K panels)
+    static bool attr_set = false;
+    if (!attr_set) {
+        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm256_kernel<MODE>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_gemm256_kernel<MODE>), dim3(a.tiles_m * a.tiles_n), dim3(512), smem, st, a);
+    VP_LAUNCH_CHECK(ctx, "conv_gemm256");
+    return VP_OK;
+}
+
+}  // namespace
+
+// args: ConvArgs with tiles_m / tiles_n / group_m already set for 256-wide tiles
+int vp_conv_launch256_bf16(vp_ctx* ctx, const void* args, int mode, hipStream_t st) {
+    const ConvArgs& a = *static_cast<const ConvArgs*>(args);
+    if (mode == MODE_1X1) return launch256<MODE_1X1>(ctx, a, st);
+    if (mode == MODE_TAPS) return launch256<MODE_TAPS>(ctx, a, st);
+    VP_FAIL(ctx, VP_EUNSUP, "conv256: mode %d not built", mode);
+}
