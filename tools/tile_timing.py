@@ -32,6 +32,10 @@ for cin, cout in [(1536, 1536), (512, 512)]:
     print(f'{cin}x{cout}: tiles {ntile}  span {s[:, 3].max() - t0:.1f} us   prologue {pro.mean():.2f} (p90 {pro.quantile(0.9):.2f})  '
           f'k-loop {loop.mean():.2f} (p90 {loop.quantile(0.9):.2f})  epilogue {epi.mean():.2f} (p90 {epi.quantile(0.9):.2f})  '
           f'sum/tile {(s[:, 3] - s[:, 0]).mean():.2f}')
-    print(f'   epilogue: barrier {(s[:, 4] - s[:, 2]).mean():.2f}  dump0 {(s[:, 5] - s[:, 4]).mean():.2f}  half0 loop {(s[:, 6] - s[:, 5]).mean():.2f}  rest {(s[:, 3] - s[:, 6]).mean():.2f}   shader clock over epilogue {(s[:, 7] * 100.0 / ((s[:, 3] - s[:, 4]) * 100.0)).mean():.1f} MHz-ish (clock64 ticks per us)')
+    print(f'   epilogue: barrier {(s[:, 4] - s[:, 2]).mean():.2f}  to-half0-end {(s[:, 6] - s[:, 4]).mean():.2f}  rest {(s[:, 3] - s[:, 6]).mean():.2f}')
+    cyc = stamps[:, 5].cpu().double()
+    print(f'   shader clock over the k-loop: {(cyc / (s[:, 2] - s[:, 1])).mean():.0f} MHz   ({cyc.mean():.0f} cycles)')
+    raw = stamps[:, 7].cpu()
+    print(f'   k-loop waits (wave 0, steps 1..): vmcnt {((raw >> 32).double() / 100.0).mean():.2f} us   barrier {((raw & 0xffffffff).double() / 100.0).mean():.2f} us')
     starts = (s[:, 0] - t0).sort().values
     print('   start-time deciles (us):', ' '.join(f'{starts[int(q * (ntile - 1))]:.0f}' for q in (0, .1, .2, .3, .4, .5, .6, .7, .8, .9, 1)))

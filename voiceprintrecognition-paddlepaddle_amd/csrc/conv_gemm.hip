@@ -27,12 +27,12 @@
 int vp_conv_launch_bf16_bf16(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
 int vp_conv_launch_bf16_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
 int vp_conv_launch_f32_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
-int vp_conv_launch256_bf16(vp_ctx* ctx, const void* args, int mode, hipStream_t st);
+int vp_conv_launch256_bf16(vp_ctx* ctx, const void* args, int mode, int sched, hipStream_t st);
 
-static bool use_conv256() {          // VPMI_CONV256=0 pins the 128-wide kernel (A/B measurements)
+static int use_conv256() {          // VPMI_CONV256=0 pins the 128-wide kernel, 1 = simple K loop, 2 = ping-pong (A/B measurements)
     static int v = -1;
     if (v < 0) { const char* e = getenv("VPMI_CONV256"); v = e ? atoi(e) : 1; }
-    return v != 0;
+    return v;
 }
 
 extern "C" {
@@ -121,7 +121,7 @@ int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream) {
         a.group_m = 32 / a.tiles_n;
         if (a.group_m < 1) a.group_m = 1;
         if (a.group_m > 16) a.group_m = 16;
-        return vp_conv_launch256_bf16(ctx, &a, mode, st);
+        return vp_conv_launch256_bf16(ctx, &a, mode, use_conv256() - 1, st);
     }
     if (d->dtype_in == VP_BF16 && d->dtype_out == VP_BF16) return vp_conv_launch_bf16_bf16(ctx, &a, bn, mode, st);
     if (d->dtype_in == VP_BF16 && d->dtype_out == VP_F32) return vp_conv_launch_bf16_f32(ctx, &a, bn, mode, st);

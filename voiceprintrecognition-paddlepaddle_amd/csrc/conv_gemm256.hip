@@ -18,17 +18,17 @@ constexpr int T2 = 256;                      // tile edge (positions and channel
 constexpr int STAGE2 = 2 * T2 * ROWB;        // X panel + W panel
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int MODE>
+template <int MODE, int SCHED>
 __global__ __launch_bounds__(512) void conv_gemm256_kernel(const ConvArgs a) {
     constexpr int MI = 4, NI = 8;            // per wave: 64 positions x 128 channels
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef VP_TIMING
     const unsigned long long tk0 = wall_clock64();
-    unsigned long long tk1 = 0;
+    unsigned long long tk1 = 0, twait = 0, tbar = 0, ck1 = 0;
 #endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wv = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: scalar branches on the wave's role
     const int wm = wv >> 1, wn = wv & 1;
     const int li = lane & 15, g = lane >> 4;
 
@@ -72,35 +72,34 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(const ConvArgs a) {
         woff[i] = n < a.N ? (unsigned)n * (unsigned)a.K * 2u + cb : OOB;
     }
 
-    auto stage = [&](int kt, int s) {
+    // one DMA piece (8 rows x 128 B of one panel): pieces 0..3 = X rows 8i.., pieces 4..7 = W rows
+    auto stage_piece = [&](int kt, int s, int i) {
         char* Xs = smem + s * STAGE2 + wv * (32 * ROWB);
         char* Ws = Xs + T2 * ROWB;
         const unsigned kb = (unsigned)kt * (unsigned)ROWB;
-        if constexpr (MODE == MODE_1X1) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_ptr_t)(Xs + i * (8 * ROWB)), 16,
-                                                         rowfix[i] != OOB ? rowfix[i] + kb : OOB, 0, 0, 0);
+        if (i >= 4) {
+            const int w = i - 4;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)(Ws + w * (8 * ROWB)), 16,
+                                                     woff[w] != OOB ? woff[w] + kb : OOB, 0, 0, 0);
+        } else if constexpr (MODE == MODE_1X1) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_ptr_t)(Xs + i * (8 * ROWB)), 16,
+                                                     rowfix[i] != OOB ? rowfix[i] + kb : OOB, 0, 0, 0);
         } else {
             const int k0 = kt * 64;                     // Cin % 64 == 0: one tap per K-step
             const int j = k0 / a.Cin;
             const unsigned cbase = (unsigned)(k0 - j * a.Cin) * 2u + cb;
-            const int tj = j * a.dilation;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int traw = tpos[i] + tj;
-                int ts = traw < 0 ? -traw : traw;
-                ts = ts >= a.T_in ? 2 * (a.T_in - 1) - ts : ts;
-                const bool inr = traw >= 0 && traw < a.T_in;
-                const bool ok = rowoff[i] != OOB && (inr || !zero_pad);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_ptr_t)(Xs + i * (8 * ROWB)), 16,
-                                                         ok ? rowoff[i] + (unsigned)ts * ldxb + cbase : OOB, 0, 0, 0);
-            }
+            const int traw = tpos[i] + j * a.dilation;
+            int ts = traw < 0 ? -traw : traw;
+            ts = ts >= a.T_in ? 2 * (a.T_in - 1) - ts : ts;
+            const bool inr = traw >= 0 && traw < a.T_in;
+            const bool ok = rowoff[i] != OOB && (inr || !zero_pad);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_ptr_t)(Xs + i * (8 * ROWB)), 16,
+                                                     ok ? rowoff[i] + (unsigned)ts * ldxb + cbase : OOB, 0, 0, 0);
         }
+    };
+    auto stage = [&](int kt, int s) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)(Ws + i * (8 * ROWB)), 16,
-                                                     woff[i] != OOB ? woff[i] + kb : OOB, 0, 0, 0);
+        for (int i = 0; i < 8; ++i) stage_piece(kt, s, i);
     };
 
     f32x4 acc[MI][NI];
@@ -114,11 +113,19 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(const ConvArgs a) {
         const char* Ws = Xs + T2 * ROWB;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+#ifdef VP_EXP_NOLDS
+            Frag<bf16_t> xf[MI], wf[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) xf[mi].v = __builtin_bit_cast(bf16x8, u32x4{(unsigned)s, (unsigned)mi, 3u, 4u});
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) wf[ni].v = __builtin_bit_cast(bf16x8, u32x4{(unsigned)s, (unsigned)ni, 5u, (unsigned)lane});
+#else
             Frag<bf16_t> xf[MI], wf[NI];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) load_frag(Xs, wm * 64 + mi * 16 + li, ks, g, xf[mi]);
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) load_frag(Ws, wn * 128 + ni * 16 + li, ks, g, wf[ni]);
+#endif
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -128,19 +135,118 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(const ConvArgs a) {
 
     const int KT = a.K / 64;
     stage(0, 0);
+    if constexpr (SCHED == 0) {
     for (int kt = 0; kt < KT; ++kt) {
         // own DMAs of stage kt have landed; after the barrier so have everyone's, and every wave
         // is done reading the other buffer (stage kt-1), which the next DMAs overwrite
+#ifdef VP_TIMING
+        const unsigned long long tw0 = wall_clock64();
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef VP_TIMING
+        const unsigned long long tw1 = wall_clock64();
+#endif
         __syncthreads();
 #ifdef VP_TIMING
-        if (kt == 0) tk1 = wall_clock64();
+        if (kt == 0) { tk1 = wall_clock64(); ck1 = clock64(); }
+        else { twait += tw1 - tw0; tbar += wall_clock64() - tw1; }
 #endif
-        if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);
-        compute(kt & 1);
+        // the next stage's 8 DMA pieces are spread over this step's MFMA groups: the vector-memory path takes
+        // ~64 B/clk/CU, so a burst of all 64 pieces right after the barrier stalls every wave at issue
+        const bool more = kt + 1 < KT;
+        const char* Xs = smem + (kt & 1) * STAGE2;
+        const char* Ws = Xs + T2 * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            Frag<bf16_t> xf[MI], wf[NI];
+#ifdef VP_EXP_NOLDS
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) xf[mi].v = __builtin_bit_cast(bf16x8, u32x4{(unsigned)kt, (unsigned)mi, 3u, 4u});
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) wf[ni].v = __builtin_bit_cast(bf16x8, u32x4{(unsigned)kt, (unsigned)ni, 5u, (unsigned)lane});
+#else
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) load_frag(Xs, wm * 64 + mi * 16 + li, ks, g, xf[mi]);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) load_frag(Ws, wn * 128 + ni * 16 + li, ks, g, wf[ni]);
+#endif
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+#ifndef VP_EXP_NODMA
+                if (more) stage_piece(kt + 1, (kt + 1) & 1, ks * 4 + mi);
+#endif
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) mma(wf[ni], xf[mi], acc[mi][ni]);
+            }
+        }
+    }
+    } else {
+    // Ping-pong schedule.  Every K-step is four phases closed by a workgroup barrier; a wave alternates
+    // L phases (fetch the 12 fragments of one 32-deep half step from LDS, issue DMAs) and C phases (its 32
+    // MFMAs on those fragments).  Waves 4..7 -- the second wave of each SIMD -- run ONE phase behind waves
+    // 0..3, so while one wave of a SIMD waits on LDS its partner owns the MFMA pipe:
+    //   phase      4kt        4kt+1      4kt+2      4kt+3
+    //   waves 0-3  L(kt,0)    C(kt,0)    L(kt,1)    C(kt,1)
+    //   waves 4-7  C(kt-1,1)  L(kt,0)    C(kt,0)    L(kt,1)
+    // Buffer (kt+1)&1 was last read in phase 4kt-1, so stage kt+1 is issued in phase 4kt (waves 0-3) /
+    // 4kt+1 (waves 4-7), waited for (vmcnt) before the barrier that closes phase 4kt+3 and first read in
+    // phase 4kt+4.  Raw s_barrier: __syncthreads() would drain the DMAs in flight at every phase.
+    // Each role gets its own straight-line loop (one branch at the top): a single loop with per-phase role
+    // tests makes hipcc shuffle the 176 live accumulator / fragment registers through scratch.
+    Frag<bf16_t> xf[MI], wf[NI];
+    auto fetch = [&](int kt, int ks) {
+        const char* Xs = smem + (kt & 1) * STAGE2;
+        const char* Ws = Xs + T2 * ROWB;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) load_frag(Xs, wm * 64 + mi * 16 + li, ks, g, xf[mi]);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) load_frag(Ws, wn * 128 + ni * 16 + li, ks, g, wf[ni]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    auto mfmas = [&]() {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) mma(wf[ni], xf[mi], acc[mi][ni]);
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#ifdef VP_TIMING
+    tk1 = wall_clock64();
+#endif
+    if (wv < 4) {
+        for (int kt = 0; kt < KT; ++kt) {
+            if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);
+            fetch(kt, 0);
+            __builtin_amdgcn_s_barrier();
+            mfmas();
+            __builtin_amdgcn_s_barrier();
+            fetch(kt, 1);
+            __builtin_amdgcn_s_barrier();
+            mfmas();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_s_barrier();                          // phase 4 KT: the late waves' last MFMAs
+    } else {
+        __builtin_amdgcn_s_barrier();                          // phase 0: the early waves' first fetch
+        for (int kt = 0; kt < KT; ++kt) {
+            if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);
+            fetch(kt, 0);
+            __builtin_amdgcn_s_barrier();
+            mfmas();
+            __builtin_amdgcn_s_barrier();
+            fetch(kt, 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            mfmas();
+            __builtin_amdgcn_s_barrier();
+        }
+    }
     }
 #ifdef VP_TIMING
     const unsigned long long tk2 = wall_clock64();
+    const unsigned long long ck2 = clock64();
 #endif
 
     // ------------------------------------------------------------------ epilogue
@@ -158,7 +264,6 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(const ConvArgs a) {
 #ifdef VP_TIMING
     const unsigned long long te0 = wall_clock64();
     unsigned long long te1 = 0, te1b = 0;
-    const unsigned long long ck0 = clock64();
 #endif
     char* slab = smem + wv * (64 * OROW);
     float* red = reinterpret_cast<float*>(smem + SLABS);       // [2 stats][4 wm][2 seg][256 col]
@@ -342,22 +447,22 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(const ConvArgs a) {
         __syncthreads();
         if (tid == 0) {
             unsigned long long* o = (unsigned long long*)a.add_in + (size_t)blockIdx.x * 8;
-            o[0] = tk0; o[1] = tk1; o[2] = tk2; o[3] = wall_clock64(); o[4] = te0; o[5] = te1b; o[6] = te1; o[7] = clock64() - ck0;
+            o[0] = tk0; o[1] = tk1; o[2] = tk2; o[3] = wall_clock64(); o[4] = te0; o[5] = ck2 - ck1; o[6] = te1; o[7] = (twait << 32) | tbar;
         }
     }
 #endif
 }
 
-template <int MODE>
+template <int MODE, int SCHED>
 int launch256(vp_ctx* ctx, const ConvArgs& a, hipStream_t st) {
     constexpr int smem = 8 * 64 * 272 + 2 * 4 * 2 * T2 * 4;      // output slabs + column-sum partials (> the K panels)
     static bool attr_set = false;
     if (!attr_set) {
-        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm256_kernel<MODE>),
+        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm256_kernel<MODE, SCHED>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_gemm256_kernel<MODE>), dim3(a.tiles_m * a.tiles_n), dim3(512), smem, st, a);
+    hipLaunchKernelGGL((conv_gemm256_kernel<MODE, SCHED>), dim3(a.tiles_m * a.tiles_n), dim3(512), smem, st, a);
     VP_LAUNCH_CHECK(ctx, "conv_gemm256");
     return VP_OK;
 }
@@ -365,9 +470,14 @@ int launch256(vp_ctx* ctx, const ConvArgs& a, hipStream_t st) {
 }  // namespace
 
 // args: ConvArgs with tiles_m / tiles_n / group_m already set for 256-wide tiles
-int vp_conv_launch256_bf16(vp_ctx* ctx, const void* args, int mode, hipStream_t st) {
+int vp_conv_launch256_bf16(vp_ctx* ctx, const void* args, int mode, int sched, hipStream_t st) {
     const ConvArgs& a = *static_cast<const ConvArgs*>(args);
-    if (mode == MODE_1X1) return launch256<MODE_1X1>(ctx, a, st);
-    if (mode == MODE_TAPS) return launch256<MODE_TAPS>(ctx, a, st);
+    if (sched == 0) {
+        if (mode == MODE_1X1) return launch256<MODE_1X1, 0>(ctx, a, st);
+        if (mode == MODE_TAPS) return launch256<MODE_TAPS, 0>(ctx, a, st);
+    } else {
+        if (mode == MODE_1X1) return launch256<MODE_1X1, 1>(ctx, a, st);
+        if (mode == MODE_TAPS) return launch256<MODE_TAPS, 1>(ctx, a, st);
+    }
     VP_FAIL(ctx, VP_EUNSUP, "conv256: mode %d not built", mode);
 }
