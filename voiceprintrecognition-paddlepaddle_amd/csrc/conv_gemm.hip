@@ -29,9 +29,9 @@ int vp_conv_launch_bf16_f32(vp_ctx* ctx, const void* args, int bn, int mode, hip
 int vp_conv_launch_f32_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
 int vp_conv_launch256_bf16(vp_ctx* ctx, const void* args, int mode, int sched, hipStream_t st);
 
-static int use_conv256() {          // VPMI_CONV256=0 pins the 128-wide kernel, 1 = simple K loop, 2 = ping-pong (A/B measurements)
+static int use_conv256() {          // VPMI_CONV256: 0 pins the 128-wide kernel; 1 = interleaved DMA, 2 = ping-pong phases, 3 = role-split DMA (default)
     static int v = -1;
-    if (v < 0) { const char* e = getenv("VPMI_CONV256"); v = e ? atoi(e) : 1; }
+    if (v < 0) { const char* e = getenv("VPMI_CONV256"); v = e ? atoi(e) : 3; }
     return v;
 }
 

@@ -72,6 +72,59 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(const ConvArgs a) {
         woff[i] = n < a.N ? (unsigned)n * (unsigned)a.K * 2u + cb : OOB;
     }
 
+    // SCHED 2 staging roles: waves 0..3 stage the X panel (rows 64 (wv & 3) + 8 i), waves 4..7 the W panel, and
+    // each role issues its 8 pieces inside a different half of the K-step (see the loop below)
+    const bool w_role = wv >= 4;
+    unsigned qoff[8];
+    int qpos[8];
+    if constexpr (SCHED == 2) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = (wv & 3) * 64 + i * 8 + srow;
+            if (w_role) {
+                const int n = n0 + r;
+                qoff[i] = n < a.N ? (unsigned)n * (unsigned)a.K * 2u + cb : OOB;
+                qpos[i] = 0;
+            } else {
+                const int m = m0 + r;
+                const bool ok = m < a.M;
+                const int mm = ok ? m : 0;
+                const int b = mm / a.T_out;
+                const int t = mm - b * a.T_out;
+                qpos[i] = t * a.stride - a.pad_left;
+                const unsigned ro = ok ? ((unsigned)(b * a.T_in) * (unsigned)a.ldx + (unsigned)a.xoff) * 2u : OOB;
+                if constexpr (MODE == MODE_1X1) {
+                    const int traw = qpos[i];
+                    int ts = traw < 0 ? -traw : traw;
+                    ts = ts >= a.T_in ? 2 * (a.T_in - 1) - ts : ts;
+                    const bool inr = traw >= 0 && traw < a.T_in;
+                    qoff[i] = (ok && (inr || !zero_pad)) ? ro + (unsigned)ts * ldxb + cb : OOB;
+                } else {
+                    qoff[i] = ro;
+                }
+            }
+        }
+    }
+    auto role_piece = [&](int kt, int s, int i) {
+        char* dst = smem + s * STAGE2 + (w_role ? T2 * ROWB : 0) + ((wv & 3) * 64 + i * 8) * ROWB;
+        const unsigned kb = (unsigned)kt * (unsigned)ROWB;
+        if (w_role) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)dst, 16, qoff[i] != OOB ? qoff[i] + kb : OOB, 0, 0, 0);
+        } else if constexpr (MODE == MODE_1X1) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_ptr_t)dst, 16, qoff[i] != OOB ? qoff[i] + kb : OOB, 0, 0, 0);
+        } else {
+            const int k0 = kt * 64;
+            const int j = k0 / a.Cin;
+            const unsigned cbase = (unsigned)(k0 - j * a.Cin) * 2u + cb;
+            const int traw = qpos[i] + j * a.dilation;
+            int ts = traw < 0 ? -traw : traw;
+            ts = ts >= a.T_in ? 2 * (a.T_in - 1) - ts : ts;
+            const bool inr = traw >= 0 && traw < a.T_in;
+            const bool ok = qoff[i] != OOB && (inr || !zero_pad);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_ptr_t)dst, 16, ok ? qoff[i] + (unsigned)ts * ldxb + cbase : OOB, 0, 0, 0);
+        }
+    };
+
     // one DMA piece (8 rows x 128 B of one panel): pieces 0..3 = X rows 8i.., pieces 4..7 = W rows
     auto stage_piece = [&](int kt, int s, int i) {
         char* Xs = smem + s * STAGE2 + wv * (32 * ROWB);
@@ -134,6 +187,43 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(const ConvArgs a) {
     };
 
     const int KT = a.K / 64;
+    if constexpr (SCHED == 2) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) role_piece(0, 0, i);
+        // Role-split schedule: one barrier per K-step as in SCHED 0, but the two waves of a SIMD issue their
+        // DMA pieces in DIFFERENT halves of the step (waves 0..3: X panel during the ks = 0 MFMAs; waves 4..7:
+        // the L2-resident W panel during the ks = 1 MFMAs).  A wave stalls ~100 cycles per piece at issue (the
+        // vector-memory path takes ~64 B/clk/CU); while it does, its SIMD partner -- which has no DMA in this
+        // half -- keeps the MFMA pipe fed, instead of both stalling together.
+        const int my_half = w_role ? 1 : 0;
+        for (int kt = 0; kt < KT; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+#ifdef VP_TIMING
+            if (kt == 0) { tk1 = wall_clock64(); ck1 = clock64(); }
+#endif
+            const bool more = kt + 1 < KT;
+            const char* Xs = smem + (kt & 1) * STAGE2;
+            const char* Ws = Xs + T2 * ROWB;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                Frag<bf16_t> xf[MI], wf[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) load_frag(Xs, wm * 64 + mi * 16 + li, ks, g, xf[mi]);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) load_frag(Ws, wn * 128 + ni * 16 + li, ks, g, wf[ni]);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    if (more && ks == my_half) {
+                        role_piece(kt + 1, (kt + 1) & 1, 2 * mi);
+                        role_piece(kt + 1, (kt + 1) & 1, 2 * mi + 1);
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) mma(wf[ni], xf[mi], acc[mi][ni]);
+                }
+            }
+        }
+    } else {
     stage(0, 0);
     if constexpr (SCHED == 0) {
     for (int kt = 0; kt < KT; ++kt) {
@@ -242,6 +332,7 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(const ConvArgs a) {
             mfmas();
             __builtin_amdgcn_s_barrier();
         }
+    }
     }
     }
 #ifdef VP_TIMING
@@ -475,9 +566,12 @@ int vp_conv_launch256_bf16(vp_ctx* ctx, const void* args, int mode, int sched, h
     if (sched == 0) {
         if (mode == MODE_1X1) return launch256<MODE_1X1, 0>(ctx, a, st);
         if (mode == MODE_TAPS) return launch256<MODE_TAPS, 0>(ctx, a, st);
-    } else {
+    } else if (sched == 1) {
         if (mode == MODE_1X1) return launch256<MODE_1X1, 1>(ctx, a, st);
         if (mode == MODE_TAPS) return launch256<MODE_TAPS, 1>(ctx, a, st);
+    } else {
+        if (mode == MODE_1X1) return launch256<MODE_1X1, 2>(ctx, a, st);
+        if (mode == MODE_TAPS) return launch256<MODE_TAPS, 2>(ctx, a, st);
     }
     VP_FAIL(ctx, VP_EUNSUP, "conv256: mode %d not built", mode);
 }
