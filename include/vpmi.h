@@ -33,7 +33,9 @@ typedef void* vp_stream; /* hipStream_t */
 enum { VP_OK = 0, VP_EINVAL = -1, VP_ENOMEM = -2, VP_EHIP = -3, VP_EUNSUP = -4, VP_EWORKSPACE = -5 };
 enum { VP_F32 = 0, VP_BF16 = 1 };                  /* element type of activations / GEMM weights     */
 enum { VP_PAD_NONE = 0, VP_PAD_REFLECT = 1, VP_PAD_ZERO = 2 };
-enum { VP_ACT_NONE = 0, VP_ACT_RELU = 1, VP_ACT_SIGMOID = 2, VP_ACT_TANH = 3 };
+enum { VP_ACT_NONE = 0, VP_ACT_RELU = 1, VP_ACT_SIGMOID = 2, VP_ACT_TANH = 3,
+       VP_ACT_HARDTANH20 = 4,   /* clamp to [0, 20]: ERes2Net's "ReLU" (models/eres2net.py:12-20) */
+       VP_ACT_SILU = 5 };
 
 int vp_version(void);
 vp_ctx* vp_create(int device);                      /* NULL on failure                                */
@@ -118,7 +120,7 @@ typedef struct {
     int act;                             /* VP_ACT_NONE | VP_ACT_RELU, applied before BN */
     const float* bn_scale;               /* [Cout] or NULL: gamma / sqrt(var + eps) */
     const float* bn_shift;               /* [Cout] or NULL: beta - mean * scale */
-    int act2;                            /* VP_ACT_NONE | VP_ACT_TANH | VP_ACT_RELU, applied last */
+    int act2;                            /* VP_ACT_NONE | VP_ACT_TANH | VP_ACT_RELU | VP_ACT_HARDTANH20 | VP_ACT_SILU, applied last */
     void* y;         int ldy, yoff;
     void* y2;        int ldy2, y2off, ysplit;   /* columns [0, ysplit) are ALSO stored to y2 */
     const void* add_in; int ld_add, add_off;
@@ -312,6 +314,45 @@ typedef struct {
 
 size_t vp_resnetse_workspace_bytes(const vp_resnetse_weights* w, int B, int T);
 int vp_resnetse_fwd(vp_ctx* ctx, const vp_resnetse_weights* w, const void* feats, int B, int T, float* emb,
+                    void* ws, size_t ws_bytes, vp_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ERes2Net backbone forward, eval mode -- replaces ERes2Net.forward (models/eres2net.py:239-263) with
+ * BasicBlockERes2Net (:56-108), BasicBlockERes2Net_diff_AFF (:111-169), AFF (:33-53), the stride-2 stage
+ * fusion convs and TemporalStatsPool (models/pooling.py:128-146).  2-D conv weights [Cout][tap*Cin + c],
+ * tap = kt*3 + kf; BatchNorm folded to scale/shift; seg_1 permuted to the engine's (f*C + c) order.
+ * ---------------------------------------------------------------------------------------------- */
+#define VP_MAX_ERE_BLOCKS 40
+#define VP_MAX_ERE_SCALE 4
+
+typedef struct { vp_tdnn_layer c1, c2; } vp_aff_weights;   /* 1x1 (2C -> C/r, BN, SiLU), 1x1 (C/r -> C, BN) */
+
+typedef struct {
+    vp_tdnn_layer conv1;                      /* 1x1, stride on both axes, BN folded (Hardtanh(0,20) follows) */
+    vp_tdnn_layer convs[VP_MAX_ERE_SCALE];    /* 3x3 on `width` channels, BN folded */
+    vp_tdnn_layer conv3;                      /* 1x1 width*scale -> planes*expansion, BN folded */
+    vp_tdnn_layer shortcut;                   /* optional strided 1x1 + BN */
+    vp_aff_weights fuse[VP_MAX_ERE_SCALE - 1];
+    int stride, has_shortcut, use_aff, width, scale;
+} vp_ere_block;
+
+typedef struct {
+    int dtype;
+    int feat_dim, embd_dim, n_blocks, m_channels;
+    int stage_blocks[4];
+    const float* c1_w;        /* [m][9] f32, tap = kt*3 + kf */
+    const float* c1_b;
+    const float* c1_scale;
+    const float* c1_shift;
+    vp_ere_block blk[VP_MAX_ERE_BLOCKS];
+    vp_tdnn_layer down[3];    /* layer{1,2,3}_downsample: 3x3 stride 2, bias only */
+    vp_aff_weights fuse[3];   /* fuse_mode12 / 123 / 1234 */
+    const float* seg_w;       /* [embd][2 * F/8 * C] f32 */
+    const float* seg_b;
+} vp_eres2net_weights;
+
+size_t vp_eres2net_workspace_bytes(const vp_eres2net_weights* w, int B, int T);
+int vp_eres2net_fwd(vp_ctx* ctx, const vp_eres2net_weights* w, const void* feats, int B, int T, float* emb,
                     void* ws, size_t ws_bytes, vp_stream stream);
 
 /* ------------------------------------------------------------------------------------------------

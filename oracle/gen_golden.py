@@ -172,6 +172,26 @@ def main():
     cmp('resnetse eval emb', er_or, er_ref, 2e-5)
     out['resnetse_ref_small.npz'] = dict(x=xr, emb_eval=er_ref.numpy(), param_seed=np.int64(1000))
 
+    # ---------------- ERes2Net (configs/eres2net.yml: m_channels 32, embd 192), F=80
+    from oracle import eres2net as oer
+    ref_er = importlib.import_module('ppvector.models.eres2net')
+    pe = oer.eres2net_params(input_size=F_, embd_dim=192, seed=1000)
+    em = ref_er.ERes2Net(input_size=F_, embd_dim=192, m_channels=32)
+    sde = em.state_dict()
+    assert set(sde.keys()) == set(pe.keys()), sorted(set(sde.keys()) ^ set(pe.keys()))[:10]
+    for k in sde:
+        assert tuple(sde[k].shape) == tuple(pe[k].shape), k
+    em.load_state_dict(pe)
+    em.eval()
+    nt, nb_ = om.count_params(pe)
+    print(f'ERes2Net F=80 params: trainable {nt}, buffers {nb_}')
+    xe = rng.standard_normal((2, 70, F_)).astype(np.float32) * 3.0
+    with torch.no_grad():
+        ee_ref = em(paddle_shim.to_tensor(xe))
+        ee_or = oer.eres2net_forward(pe, torch.from_numpy(xe))
+    cmp('eres2net eval emb', ee_or, ee_ref, 2e-5)
+    out['eres2net_ref_small.npz'] = dict(x=xe, emb_eval=ee_ref.numpy(), param_seed=np.int64(1000))
+
     # ---------------- real speech: 4 reference WAVs (3 s crops) -> oracle Fbank -> reference ECAPA graph
     names = ['a_1', 'a_2', 'b_1', 'b_2']
     pcm = np.stack([read_wav_16k_mono(f'{REF}/dataset/{n}.wav') for n in names])

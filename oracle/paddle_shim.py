@@ -70,6 +70,9 @@ class Tensor(torch.Tensor):
     def unsqueeze(self, axis=None, dim=None):
         return super().unsqueeze(axis if dim is None else dim)
 
+    def unsqueeze_(self, axis):
+        return _wrap(torch.Tensor.unsqueeze(self, axis))
+
     def squeeze(self, axis=None, dim=None):
         a = axis if dim is None else dim
         return super().squeeze() if a is None else super().squeeze(a)
@@ -121,6 +124,15 @@ def stack(xs, axis=0):
 
 def chunk(x, chunks, axis=0):
     return [_wrap(c) for c in torch.chunk(x, chunks, dim=axis)]
+
+
+def split(x, num_or_sections, axis=0):
+    n = num_or_sections if isinstance(num_or_sections, int) else len(num_or_sections)
+    return [_wrap(t) for t in torch.chunk(x, n, dim=axis)]
+
+
+def multiply(a, b):
+    return _wrap(a * b)
 
 
 def where(cond, a, b):
@@ -272,6 +284,15 @@ def _act(fn):
     return _A
 
 
+class Hardtanh(Layer):
+    def __init__(self, min=-1.0, max=1.0, name=None):
+        super().__init__()
+        self.min, self.max = min, max
+
+    def forward(self, x):
+        return _wrap(torch.clamp(x, self.min, self.max))
+
+
 class CrossEntropyLoss(Layer):
     def __init__(self, label_smoothing=0.0, **kw):
         super().__init__()
@@ -325,7 +346,8 @@ _init.KaimingNormal = lambda *a, **k: None
 _init.Constant = lambda *a, **k: None
 
 for _n, _v in dict(Layer=Layer, Conv1D=Conv1D, Conv2D=Conv2D, BatchNorm1D=BatchNorm1D, BatchNorm2D=BatchNorm2D,
-                   Linear=Linear, AdaptiveAvgPool2D=AdaptiveAvgPool2D, ReLU=_act(torch.relu), Sigmoid=_act(torch.sigmoid), Tanh=_act(torch.tanh),
+                   Linear=Linear, AdaptiveAvgPool2D=AdaptiveAvgPool2D, ReLU=_act(torch.relu), Sigmoid=_act(torch.sigmoid), Tanh=_act(torch.tanh), Silu=_act(TF.silu), Identity=_act(lambda x: x),
+                   Hardtanh=Hardtanh,
                    CrossEntropyLoss=CrossEntropyLoss, LayerList=LayerList, Sequential=Sequential,
                    initializer=_init).items():
     setattr(nn, _n, _v)

@@ -271,3 +271,29 @@ def test_resnetse_matches_reference_golden(golden_dir):
         ref3 = orse.resnetse_forward(p, torch.from_numpy(feats)).numpy()
     e3 = m.engine('float32').forward(torch.from_numpy(feats).cuda()).cpu().numpy()
     assert np.linalg.norm(e3 - ref3) / np.linalg.norm(ref3) < 3e-4
+
+
+def test_eres2net_matches_reference_golden(golden_dir):
+    """ERes2Net (configs/eres2net.yml: m_channels 32, embd 192) vs the output of the reference's own eres2net.py
+    (golden), plus an odd-length batch vs the oracle (stride-2 stages and AFF fusion on odd T)."""
+    from oracle import eres2net as oer
+    from ppvector.models.eres2net import ERes2Net
+    g = np.load(f'{golden_dir}/eres2net_ref_small.npz')
+    p = oer.eres2net_params(80, 192, seed=int(g['param_seed']))
+    m = ERes2Net(80, embd_dim=192, m_channels=32)
+    m.load_state_dict(p)
+    m = m.cuda().eval()
+    x = torch.from_numpy(g['x']).cuda()
+    ref = g['emb_eval']
+    for dtype, tol in (('float32', 3e-4), ('bfloat16', 8e-2)):
+        emb = m.engine(dtype).forward(x).cpu().numpy()
+        rel = np.linalg.norm(emb - ref) / np.linalg.norm(ref)
+        c = _cos_rows(emb, ref)
+        print(f'[eres2net {dtype}] rel-L2 {rel:.3e}  1-cos {1 - c.min():.3e}')
+        assert rel < tol, (dtype, rel)
+    w = ofb.synth_waves(3, 16000 + 160 * 5, seed=8, lowpass=0.9)
+    feats = ofb.featurize(w, method_args=dict(sr=16000, n_mels=80))
+    with torch.no_grad():
+        ref3 = oer.eres2net_forward(p, torch.from_numpy(feats)).numpy()
+    e3 = m.engine('float32').forward(torch.from_numpy(feats).cuda()).cpu().numpy()
+    assert np.linalg.norm(e3 - ref3) / np.linalg.norm(ref3) < 3e-4

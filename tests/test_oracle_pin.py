@@ -58,10 +58,11 @@ def test_tdnn_oracle_matches_reference_golden(golden_dir):
     assert np.max(np.abs(emb - g['emb_eval'])) < 1e-4 * np.max(np.abs(g['emb_eval']))
 
 
-def test_campplus_resnetse_oracles_match_reference_golden(golden_dir):
-    from oracle import campplus as oc, resnet_se as orse
+def test_2d_backbone_oracles_match_reference_golden(golden_dir):
+    from oracle import campplus as oc, eres2net as oer, resnet_se as orse
     for name, params, fwd in (('campplus_ref_small.npz', oc.campplus_params, oc.campplus_forward),
-                              ('resnetse_ref_small.npz', orse.resnetse_params, orse.resnetse_forward)):
+                              ('resnetse_ref_small.npz', orse.resnetse_params, orse.resnetse_forward),
+                              ('eres2net_ref_small.npz', oer.eres2net_params, oer.eres2net_forward)):
         g = _load(golden_dir, name)
         p = params(80, 192, seed=int(g['param_seed']))
         with torch.no_grad():

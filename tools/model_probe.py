@@ -7,19 +7,22 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'voiceprintrecognition-paddlepaddle_amd'))
 import torch  # noqa: E402
 from oracle import campplus as oc  # noqa: E402
+from oracle import eres2net as oer  # noqa: E402
 from oracle import models as om  # noqa: E402
 from oracle import resnet_se as orse  # noqa: E402
 from ppvector.models.campplus import CAMPPlus  # noqa: E402
 from ppvector.models.ecapa_tdnn import EcapaTdnn  # noqa: E402
+from ppvector.models.eres2net import ERes2Net  # noqa: E402
 from ppvector.models.resnet_se import ResNetSE  # noqa: E402
 from ppvector.models.tdnn import TDNN  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 x = torch.randn(B, 298, 80, device='cuda') * 3
-GF = {'EcapaTdnn': 2.857, 'TDNN': 1.47, 'CAMPPlus': 3.20, 'ResNetSE': 12.9}
+GF = {'EcapaTdnn': 2.857, 'TDNN': 1.47, 'CAMPPlus': 3.20, 'ResNetSE': 11.07, 'ERes2Net': 10.2}
 for name, cls, params in (('EcapaTdnn', EcapaTdnn, om.ecapa_params(80)), ('TDNN', TDNN, om.tdnn_params(80)),
                           ('CAMPPlus', lambda f: CAMPPlus(f, embd_dim=192), oc.campplus_params(80, 192)),
-                          ('ResNetSE', ResNetSE, orse.resnetse_params(80, 192))):
+                          ('ResNetSE', ResNetSE, orse.resnetse_params(80, 192)),
+                          ('ERes2Net', ERes2Net, oer.eres2net_params(80, 192))):
     if len(sys.argv) > 2 and name not in sys.argv[2:]:
         continue
     m = cls(80)

@@ -19,18 +19,19 @@ namespace {
 template <typename TI, typename TO>
 struct Fcm1Args {
     const TI* x; TO* y; const float* w; const float* bias; const float* scale; const float* shift;   // w [32][9], tap = kt*3 + kf
-    int B, T, F; long long total;
+    int B, T, F, C; long long total;
 };
 
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void fcm_conv1_kernel(Fcm1Args<TI, TO> a) {
-    __shared__ float sw[32 * 9], sb[32], ss[32], sh[32];
-    for (int i = threadIdx.x; i < 32 * 9; i += 256) sw[i] = a.w[i];
-    if (threadIdx.x < 32) { sb[threadIdx.x] = a.bias[threadIdx.x]; ss[threadIdx.x] = a.scale[threadIdx.x]; sh[threadIdx.x] = a.shift[threadIdx.x]; }
+    __shared__ float sw[64 * 9], sb[64], ss[64], sh[64];
+    const int groups = a.C >> 3;
+    for (int i = threadIdx.x; i < a.C * 9; i += 256) sw[i] = a.w[i];
+    if (threadIdx.x < a.C) { sb[threadIdx.x] = a.bias[threadIdx.x]; ss[threadIdx.x] = a.scale[threadIdx.x]; sh[threadIdx.x] = a.shift[threadIdx.x]; }
     __syncthreads();
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < a.total; idx += (long long)gridDim.x * 256) {
-        const long long pos = idx >> 2;
-        const int cg = (int)(idx & 3) * 8;
+        const long long pos = idx / groups;
+        const int cg = (int)(idx - pos * groups) * 8;
         const int f = (int)(pos % a.F);
         const long long bt = pos / a.F;
         const int t = (int)(bt % a.T);
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void fcm_conv1_kernel(Fcm1Args<TI, TO> a) {
             for (int k = 0; k < 9; ++k) s += sw[(cg + c) * 9 + k] * in[k];
             out[c] = vp_from_f32<TO>(fmaxf(s * ss[cg + c] + sh[cg + c], 0.f));
         }
-        TO* dst = a.y + pos * 32 + cg;
+        TO* dst = a.y + pos * a.C + cg;
         if constexpr (sizeof(TO) == 2) {
             *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(out);
         } else {
@@ -198,15 +199,16 @@ void conv2d_desc(vp_conv1d_desc& d, const vp_tdnn_layer& L, int dt, int B, int T
 // 3x3 conv of a single-channel (B, T, F) map to 32 channels + BN + ReLU -> (B, T, F, 32); shared by the
 // CAM++ FCM head (campplus.py:254-255,274) and ResNetSE's stem (resnet_se.py:72-74,124-126).
 int vp_conv3x3_c1(vp_ctx* ctx, int dtype, const void* feats, void* out, const float* w, const float* bias,
-                  const float* scale, const float* shift, int B, int T, int F, hipStream_t st) {
-    const long long total = (long long)B * T * F * 4;
+                  const float* scale, const float* shift, int B, int T, int F, int C, hipStream_t st) {
+    if (C < 8 || C > 64 || C % 8) VP_FAIL(ctx, VP_EUNSUP, "conv3x3_c1: %d output channels (8..64, multiple of 8)", C);
+    const long long total = (long long)B * T * F * (C / 8);
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     if (dtype == VP_BF16) {
-        Fcm1Args<bf16_t, bf16_t> a{(const bf16_t*)feats, (bf16_t*)out, w, bias, scale, shift, B, T, F, total};
+        Fcm1Args<bf16_t, bf16_t> a{(const bf16_t*)feats, (bf16_t*)out, w, bias, scale, shift, B, T, F, C, total};
         hipLaunchKernelGGL((fcm_conv1_kernel<bf16_t, bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, a);
     } else {
-        Fcm1Args<float, float> a{(const float*)feats, (float*)out, w, bias, scale, shift, B, T, F, total};
+        Fcm1Args<float, float> a{(const float*)feats, (float*)out, w, bias, scale, shift, B, T, F, C, total};
         hipLaunchKernelGGL((fcm_conv1_kernel<float, float>), dim3((unsigned)blocks), dim3(256), 0, st, a);
     }
     VP_LAUNCH_CHECK(ctx, "conv3x3_c1");
@@ -240,7 +242,7 @@ int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats
     vp_conv1d_desc d;
 
     // ---- FCM head: conv1 (1 -> 32), 2 x [ResBlock s2, ResBlock s1], conv2 s2
-    if ((rc = vp_conv3x3_c1(ctx, dt, feats, p.fa, w->fcm1_w, w->fcm1_b, w->fcm1_scale, w->fcm1_shift, B, T, w->feat_dim, st)))
+    if ((rc = vp_conv3x3_c1(ctx, dt, feats, p.fa, w->fcm1_w, w->fcm1_b, w->fcm1_scale, w->fcm1_shift, B, T, w->feat_dim, 32, st)))
         return rc;
     int F = w->feat_dim;
     void* cur = p.fa;

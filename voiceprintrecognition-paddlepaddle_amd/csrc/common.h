@@ -63,6 +63,23 @@ __device__ __forceinline__ float vp_to_f32(bf16_t v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T vp_from_f32(float v);
 template <> __device__ __forceinline__ float vp_from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t vp_from_f32<bf16_t>(float v) { return (bf16_t)v; }
+// 4 consecutive elements (16 B f32 / 8 B bf16; the pointer must be aligned accordingly)
+__device__ __forceinline__ void vp_load4(const float* p, float v[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void vp_load4(const bf16_t* p, float v[4]) {
+    const bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+    v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+}
+__device__ __forceinline__ void vp_store4(float* p, const float v[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void vp_store4(bf16_t* p, const float v[4]) {
+    bf16x4 o;
+    o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
 
 __device__ __forceinline__ float vp_wave_sum(float v) {
 #pragma unroll
@@ -90,12 +107,16 @@ struct VpAspBufs { void* h; float* e; float* psum; float* psumsq; float* stats; 
 int vp_run_asp(vp_ctx* ctx, const vp_asp_weights& A, int dtype, const void* x, int ldx, const float* shift,
                int B, int T, const VpAspBufs& w, hipStream_t st);
 int vp_conv3x3_c1(vp_ctx* ctx, int dtype, const void* feats, void* out, const float* w, const float* bias,
-                  const float* scale, const float* shift, int B, int T, int F, hipStream_t st);
+                  const float* scale, const float* shift, int B, int T, int F, int C, hipStream_t st);
 int vp_se_scale_residual_ex(vp_ctx* ctx, int dtype, const void* x, int ldx, int xoff, const float* s,
                             const void* res, int ldr, int roff, void* out, int ldo, int ooff, int B, int T, int C,
                             int relu, hipStream_t st);
-int vp_time_moments(vp_ctx* ctx, int dtype, const void* x, int ldx, int B, int T, int C, float eps, float* stats,
-                    hipStream_t st);
+int vp_time_moments(vp_ctx* ctx, int dtype, const void* x, int ldx, int B, int T, int C, float eps, int unbiased,
+                    float* stats, hipStream_t st);
+int vp_copy_cols(vp_ctx* ctx, int dtype, const void* x, int ldx, int xoff, void* y, int ldy, int yoff, long long rows, int C,
+                 hipStream_t st);
+int vp_aff_combine(vp_ctx* ctx, int dtype, const void* t, int ldt, const void* x, int ldx, int xoff, const void* y, int ldy,
+                   int yoff, void* o, int ldo, int ooff, long long rows, int C, hipStream_t st);
 int vp_res2_chain_bf16(vp_ctx* ctx, const vp_tdnn_layer* layers, int nconv, const void* t1, void* r2, int B, int T,
                        int C, int width, hipStream_t st);
 int vp_asp_fused_bf16(vp_ctx* ctx, const void* h, const void* w, const float* bias, const void* x, int ldx,

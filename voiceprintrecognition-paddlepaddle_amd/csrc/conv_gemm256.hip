@@ -389,7 +389,7 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(const ConvArgs a) {
         // 16-B store per lane, 8 lanes = 128 contiguous bytes of a position.  ~40 VALU per 8 values; the
         // general loop below spends ~25 per VALUE on masks and 64-bit addressing.
         const int nh = n0 + wn * 128 + h * 64;
-        const bool fast = mw + 64 <= a.M && nh + 64 <= a.N && !a.rowbias && !RES && !AUX && a.act2 != VP_ACT_TANH &&
+        const bool fast = mw + 64 <= a.M && nh + 64 <= a.N && !a.rowbias && !RES && !AUX && a.act2 != VP_ACT_TANH && a.act2 != VP_ACT_SILU &&
                           (a.ysplit <= nh || a.ysplit >= nh + 64) && ((a.ldy | a.yoff) & 7) == 0 &&
                           (reinterpret_cast<uintptr_t>(a.y) & 15) == 0 &&
                           (a.ysplit <= nh || (((a.ldy2 | a.y2off) & 7) == 0 && (reinterpret_cast<uintptr_t>(a.y2) & 15) == 0));
@@ -403,7 +403,8 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(const ConvArgs a) {
             if (a.bn_scale) { load4(a.bn_scale + nc, sc); load4(a.bn_scale + nc + 4, sc + 4); }
             if (a.bn_shift) { load4(a.bn_shift + nc, sh); load4(a.bn_shift + nc + 4, sh + 4); }
             const float lo1 = a.act == VP_ACT_RELU ? 0.f : -INFINITY;
-            const float lo2 = a.act2 == VP_ACT_RELU ? 0.f : -INFINITY;
+            const float lo2 = (a.act2 == VP_ACT_RELU || a.act2 == VP_ACT_HARDTANH20) ? 0.f : -INFINITY;
+            const float hi2 = a.act2 == VP_ACT_HARDTANH20 ? 20.f : INFINITY;
             bf16_t* dst = Y + (size_t)(mw + q8) * a.ldy + a.yoff + nc;
             const size_t dstep = (size_t)8 * a.ldy;
             const bool split = a.ysplit > nh;
@@ -418,8 +419,8 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(const ConvArgs a) {
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = fmaxf(fmaxf(a0[e] + bs[e], lo1) * sc[e] + sh[e], lo2);
-                    v[e + 4] = fmaxf(fmaxf(a1[e] + bs[e + 4], lo1) * sc[e + 4] + sh[e + 4], lo2);
+                    v[e] = fminf(fmaxf(fmaxf(a0[e] + bs[e], lo1) * sc[e] + sh[e], lo2), hi2);
+                    v[e + 4] = fminf(fmaxf(fmaxf(a1[e] + bs[e + 4], lo1) * sc[e + 4] + sh[e + 4], lo2), hi2);
                 }
                 bf16x8 o;
 #pragma unroll
@@ -453,6 +454,8 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(const ConvArgs a) {
                 x = x * sc4[r] + sh4[r] + rs[r];
                 if (a.act2 == VP_ACT_TANH) x = tanhf(x);
                 else if (a.act2 == VP_ACT_RELU) x = fmaxf(x, 0.f);
+                else if (a.act2 == VP_ACT_HARDTANH20) x = fminf(fmaxf(x, 0.f), 20.f);
+                else if (a.act2 == VP_ACT_SILU) x = x / (1.f + __expf(-x));
                 v[r] = x;
             }
             if (ok) {

@@ -354,6 +354,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
                 t = (t * sc4[r] + sh4[r]) * gt[r] + rs[r];
                 if (a.act2 == VP_ACT_TANH) t = tanhf(t);
                 else if (a.act2 == VP_ACT_RELU) t = fmaxf(t, 0.f);
+                else if (a.act2 == VP_ACT_HARDTANH20) t = fminf(fmaxf(t, 0.f), 20.f);
+                else if (a.act2 == VP_ACT_SILU) t = t / (1.f + __expf(-t));
                 v[r] = t;
             }
             if (ok) {

@@ -96,7 +96,7 @@ int vp_resnetse_fwd(vp_ctx* ctx, const vp_resnetse_weights* w, const void* feats
     const int dt = w->dtype;
     int rc;
     vp_conv1d_desc d;
-    if ((rc = vp_conv3x3_c1(ctx, dt, feats, p.xa, w->c1_w, w->c1_b, w->c1_scale, w->c1_shift, B, T, w->feat_dim, st))) return rc;
+    if ((rc = vp_conv3x3_c1(ctx, dt, feats, p.xa, w->c1_w, w->c1_b, w->c1_scale, w->c1_shift, B, T, w->feat_dim, 32, st))) return rc;
     void* x = p.xa;
     void* xn = p.xb;
     int t = T, f = w->feat_dim;
@@ -136,7 +136,7 @@ int vp_resnetse_fwd(vp_ctx* ctx, const vp_resnetse_weights* w, const void* feats
     // ASP over time on (B, T4, F4*C4), then bn2 -> linear -> bn3 (folded + permuted at pack time)
     const int Casp = p.F4 * p.C4;
     if (w->asp.C != Casp) VP_FAIL(ctx, VP_EINVAL, "resnetse: asp.C %d != %d", w->asp.C, Casp);
-    if ((rc = vp_time_moments(ctx, dt, x, Casp, B, t, Casp, 1e-12f, p.stats, st))) return rc;
+    if ((rc = vp_time_moments(ctx, dt, x, Casp, B, t, Casp, 1e-12f, 0, p.stats, st))) return rc;
     VpAspBufs ab{p.h, p.e, nullptr, nullptr, p.stats, p.rowbias, p.pooled};
     if ((rc = vp_run_asp(ctx, w->asp, dt, x, Casp, nullptr, B, t, ab, st))) return rc;
     return vp_dense_f32_ex(ctx, p.pooled, 2 * Casp, w->lin_w, 0, w->lin_b, nullptr, nullptr, B, w->embd_dim, 2 * Casp,

@@ -224,7 +224,7 @@ int vp_se_scale_residual_ex(vp_ctx* ctx, int dtype, const void* x, int ldx, int 
 // mean / std over time straight from the activations (small T): stats[b] = [mean(C) | sqrt(max(E[(x-m)^2], eps))]
 namespace {
 template <typename T>
-struct TmArgs { const T* x; float* stats; int ldx, Tn, C; float eps; };
+struct TmArgs { const T* x; float* stats; int ldx, Tn, C; float eps; int unbiased; };
 
 template <typename T>
 __global__ __launch_bounds__(256) void time_moments_kernel(TmArgs<T> a) {
@@ -247,23 +247,93 @@ __global__ __launch_bounds__(256) void time_moments_kernel(TmArgs<T> a) {
         const float t2 = sm[1][0][lane] + sm[1][1][lane] + sm[1][2][lane] + sm[1][3][lane];
         const float md = t1 / (float)a.Tn;
         a.stats[(size_t)b * 2 * a.C + c] = c0 + md;
-        a.stats[(size_t)b * 2 * a.C + a.C + c] = sqrtf(fmaxf(t2 / (float)a.Tn - md * md, a.eps));
+        // ASP context: sqrt(clip(var_biased, eps)) (pooling.py:97-104); TSTP: sqrt(var_unbiased + eps) (pooling.py:141)
+        const float ss = fmaxf(t2 - (float)a.Tn * md * md, 0.f);
+        a.stats[(size_t)b * 2 * a.C + a.C + c] = a.unbiased ? sqrtf(ss / (float)(a.Tn > 1 ? a.Tn - 1 : 1) + a.eps)
+                                                            : sqrtf(fmaxf(ss / (float)a.Tn, a.eps));
     }
 }
 }  // namespace
 
-int vp_time_moments(vp_ctx* ctx, int dtype, const void* x, int ldx, int B, int T, int C, float eps, float* stats,
-                    hipStream_t st) {
+int vp_time_moments(vp_ctx* ctx, int dtype, const void* x, int ldx, int B, int T, int C, float eps, int unbiased,
+                    float* stats, hipStream_t st) {
     if (B > 65535) VP_FAIL(ctx, VP_EINVAL, "time_moments: batch too large");
     dim3 grid((C + 63) / 64, B);
     if (dtype == VP_BF16) {
-        TmArgs<bf16_t> a{(const bf16_t*)x, stats, ldx, T, C, eps};
+        TmArgs<bf16_t> a{(const bf16_t*)x, stats, ldx, T, C, eps, unbiased};
         hipLaunchKernelGGL(time_moments_kernel<bf16_t>, grid, dim3(256), 0, st, a);
     } else {
-        TmArgs<float> a{(const float*)x, stats, ldx, T, C, eps};
+        TmArgs<float> a{(const float*)x, stats, ldx, T, C, eps, unbiased};
         hipLaunchKernelGGL(time_moments_kernel<float>, grid, dim3(256), 0, st, a);
     }
     VP_LAUNCH_CHECK(ctx, "time_moments");
+    return VP_OK;
+}
+
+namespace {
+// out[r, ooff + c] = x[r, xoff + c]  (column block copy between row-major tensors; 4 elements per thread)
+template <typename T>
+struct CopyArgs { const T* x; T* y; int ldx, xoff, ldy, yoff, C4; long long total; };
+template <typename T>
+__global__ __launch_bounds__(256) void copy_cols_kernel(CopyArgs<T> a) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.total; i += (long long)gridDim.x * 256) {
+        const long long r = i / a.C4;
+        const int c = (int)(i - r * a.C4) * 4;
+        float v[4];
+        vp_load4(a.x + r * a.ldx + a.xoff + c, v);
+        vp_store4(a.y + r * a.ldy + a.yoff + c, v);
+    }
+}
+// AFF output (eres2net.py:48-51) from t = tanh(local_att(cat(x, y))):  x * (1 + t) + y * (1 - t)
+template <typename T>
+struct AffArgs { const T* t; const T* x; const T* y; T* o; int ldt, ldx, xoff, ldy, yoff, ldo, ooff, C4; long long total; };
+template <typename T>
+__global__ __launch_bounds__(256) void aff_combine_kernel(AffArgs<T> a) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.total; i += (long long)gridDim.x * 256) {
+        const long long r = i / a.C4;
+        const int c = (int)(i - r * a.C4) * 4;
+        float t[4], x[4], y[4], o[4];
+        vp_load4(a.t + r * a.ldt + c, t);
+        vp_load4(a.x + r * a.ldx + a.xoff + c, x);
+        vp_load4(a.y + r * a.ldy + a.yoff + c, y);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = x[e] * (1.f + t[e]) + y[e] * (1.f - t[e]);
+        vp_store4(a.o + r * a.ldo + a.ooff + c, o);
+    }
+}
+unsigned grid_for(long long total) {
+    long long b = (total + 255) / 256;
+    return (unsigned)(b > 256 * 64 ? 256 * 64 : (b < 1 ? 1 : b));
+}
+}  // namespace
+
+int vp_copy_cols(vp_ctx* ctx, int dtype, const void* x, int ldx, int xoff, void* y, int ldy, int yoff, long long rows, int C,
+                 hipStream_t st) {
+    if ((C | ldx | xoff | ldy | yoff) & 3) VP_FAIL(ctx, VP_EINVAL, "copy_cols: widths / offsets must be multiples of 4");
+    const long long total = rows * (C / 4);
+    if (dtype == VP_BF16) {
+        CopyArgs<bf16_t> a{(const bf16_t*)x, (bf16_t*)y, ldx, xoff, ldy, yoff, C / 4, total};
+        hipLaunchKernelGGL(copy_cols_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, a);
+    } else {
+        CopyArgs<float> a{(const float*)x, (float*)y, ldx, xoff, ldy, yoff, C / 4, total};
+        hipLaunchKernelGGL(copy_cols_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, a);
+    }
+    VP_LAUNCH_CHECK(ctx, "copy_cols");
+    return VP_OK;
+}
+
+int vp_aff_combine(vp_ctx* ctx, int dtype, const void* t, int ldt, const void* x, int ldx, int xoff, const void* y, int ldy,
+                   int yoff, void* o, int ldo, int ooff, long long rows, int C, hipStream_t st) {
+    if ((C | ldt | ldx | xoff | ldy | yoff | ldo | ooff) & 3) VP_FAIL(ctx, VP_EINVAL, "aff_combine: widths / offsets must be multiples of 4");
+    const long long total = rows * (C / 4);
+    if (dtype == VP_BF16) {
+        AffArgs<bf16_t> a{(const bf16_t*)t, (const bf16_t*)x, (const bf16_t*)y, (bf16_t*)o, ldt, ldx, xoff, ldy, yoff, ldo, ooff, C / 4, total};
+        hipLaunchKernelGGL(aff_combine_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, a);
+    } else {
+        AffArgs<float> a{(const float*)t, (const float*)x, (const float*)y, (float*)o, ldt, ldx, xoff, ldy, yoff, ldo, ooff, C / 4, total};
+        hipLaunchKernelGGL(aff_combine_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, a);
+    }
+    VP_LAUNCH_CHECK(ctx, "aff_combine");
     return VP_OK;
 }
 

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get('VPMI_LIB') or os.path.join(PKG_ROOT, 'lib', 'libvpmi.
 
 VP_F32, VP_BF16 = 0, 1
 VP_PAD_NONE, VP_PAD_REFLECT, VP_PAD_ZERO = 0, 1, 2
-VP_ACT_NONE, VP_ACT_RELU, VP_ACT_SIGMOID, VP_ACT_TANH = 0, 1, 2, 3
+VP_ACT_NONE, VP_ACT_RELU, VP_ACT_SIGMOID, VP_ACT_TANH, VP_ACT_HARDTANH20, VP_ACT_SILU = 0, 1, 2, 3, 4, 5
 VP_MAX_SE_BLOCKS, VP_MAX_RES2 = 8, 15
 
 c_void_p, c_int, c_float, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_size_t
@@ -120,6 +120,26 @@ class ResnetSeWeights(C.Structure):
                 ('blk', RseBlock * VP_MAX_RSE_BLOCKS), ('asp', AspWeights), ('lin_w', c_void_p), ('lin_b', c_void_p)]
 
 
+VP_MAX_ERE_BLOCKS, VP_MAX_ERE_SCALE = 40, 4
+
+
+class AffWeights(C.Structure):
+    _fields_ = [('c1', TdnnLayer), ('c2', TdnnLayer)]
+
+
+class EreBlock(C.Structure):
+    _fields_ = [('conv1', TdnnLayer), ('convs', TdnnLayer * VP_MAX_ERE_SCALE), ('conv3', TdnnLayer), ('shortcut', TdnnLayer),
+                ('fuse', AffWeights * (VP_MAX_ERE_SCALE - 1)), ('stride', c_int), ('has_shortcut', c_int), ('use_aff', c_int),
+                ('width', c_int), ('scale', c_int)]
+
+
+class Eres2netWeights(C.Structure):
+    _fields_ = [('dtype', c_int), ('feat_dim', c_int), ('embd_dim', c_int), ('n_blocks', c_int), ('m_channels', c_int),
+                ('stage_blocks', c_int * 4), ('c1_w', c_void_p), ('c1_b', c_void_p), ('c1_scale', c_void_p), ('c1_shift', c_void_p),
+                ('blk', EreBlock * VP_MAX_ERE_BLOCKS), ('down', TdnnLayer * 3), ('fuse', AffWeights * 3),
+                ('seg_w', c_void_p), ('seg_b', c_void_p)]
+
+
 _PROTOS = {
     'vp_version': (c_int, []),
     'vp_create': (c_void_p, [c_int]),
@@ -158,6 +178,9 @@ _PROTOS = {
                                 c_size_t, c_void_p]),
     'vp_resnetse_workspace_bytes': (c_size_t, [C.POINTER(ResnetSeWeights), c_int, c_int]),
     'vp_resnetse_fwd': (c_int, [c_void_p, C.POINTER(ResnetSeWeights), c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                c_size_t, c_void_p]),
+    'vp_eres2net_workspace_bytes': (c_size_t, [C.POINTER(Eres2netWeights), c_int, c_int]),
+    'vp_eres2net_fwd': (c_int, [c_void_p, C.POINTER(Eres2netWeights), c_void_p, c_int, c_int, c_void_p, c_void_p,
                                 c_size_t, c_void_p]),
     'vp_cosine_logits_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'vp_cosine_logits_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,

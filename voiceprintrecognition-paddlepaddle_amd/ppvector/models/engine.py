@@ -308,6 +308,75 @@ class ResNetSEEngine(CamppEngine):
         return emb
 
 
+class Eres2netEngine(CamppEngine):
+    """Packs an ERes2Net module into vp_eres2net_weights (include/vpmi.h)."""
+
+    def aff(self, A, m):
+        la = m.local_att
+        self.conv2d(A.c1, la[0], la[1])
+        self.conv2d(A.c2, la[3], la[4])
+
+    def __init__(self, m, dtype_name):
+        _Engine.__init__(self, m, dtype_name)
+        W = N.Eres2netWeights()
+        W.dtype, W.feat_dim, W.embd_dim, W.m_channels = self.dt, m.input_size, m.embd_dim, m.m_channels
+        if m.input_size % 8 or m.m_channels % 8 or m.m_channels > 64:
+            raise NotImplementedError('ERes2Net on the HIP engine needs input_size % 8 == 0 and m_channels in {8..64, % 8}')
+        w1 = m.conv1.weight.detach()[:, 0]                          # (m, kF, kT)
+        W.c1_w = self._p(w1.permute(0, 2, 1).reshape(w1.shape[0], 9).float())
+        W.c1_b = self._p(f32(m.conv1.bias))
+        sc, sh = m.bn1.folded()
+        W.c1_scale, W.c1_shift = self._p(sc), self._p(sh)
+        bi = 0
+        for s, layer in enumerate((m.layer1, m.layer2, m.layer3, m.layer4)):
+            W.stage_blocks[s] = len(layer)
+            for b in layer:
+                if bi >= N.VP_MAX_ERE_BLOCKS or b.scale > N.VP_MAX_ERE_SCALE:
+                    raise NotImplementedError(f'more than {N.VP_MAX_ERE_BLOCKS} blocks or scale > {N.VP_MAX_ERE_SCALE}')
+                if b.width % 8:
+                    raise NotImplementedError(f'chunk width {b.width} is not a multiple of 8 (bf16 16-byte channel chunks)')
+                R = W.blk[bi]
+                self.conv2d(R.conv1, b.conv1, b.bn1)
+                for i in range(b.scale):
+                    self.conv2d(R.convs[i], b.convs[i], b.bns[i])
+                self.conv2d(R.conv3, b.conv3, b.bn3)
+                R.has_shortcut = int(len(b.shortcut) > 0)
+                if R.has_shortcut:
+                    self.conv2d(R.shortcut, b.shortcut[0], b.shortcut[1])
+                R.use_aff = int(b.use_aff)
+                if b.use_aff:
+                    for i in range(b.scale - 1):
+                        self.aff(R.fuse[i], b.fuse_models[i])
+                R.stride, R.width, R.scale = b.stride, b.width, b.scale
+                bi += 1
+        W.n_blocks = bi
+        for k, (dn, fm) in enumerate(((m.layer1_downsample, m.fuse_mode12), (m.layer2_downsample, m.fuse_mode123),
+                                      (m.layer3_downsample, m.fuse_mode1234))):
+            self.conv2d(W.down[k], dn, None)
+            self.aff(W.fuse[k], fm)
+        # TSTP vector: reference index stat*(C*F8) + c*F8 + f  ->  engine stat*(F8*C) + f*C + c
+        C4 = m.layer3_downsample.weight.shape[0]
+        F8 = m.input_size // 8
+        lw = m.seg_1.weight.detach().float()                        # [2*C4*F8, embd] (Paddle layout)
+        if lw.shape[0] != 2 * C4 * F8:
+            raise NotImplementedError(f'seg_1 expects {lw.shape[0]} statistics, the backbone produces {2 * C4 * F8}')
+        wt = lw.t().reshape(-1, 2, C4, F8).transpose(2, 3).reshape(-1, 2 * C4 * F8)
+        W.seg_w = self._p(wt.contiguous())
+        W.seg_b = self._p(f32(m.seg_1.bias))
+        self.W = W
+
+    def forward(self, x):
+        xin = self.feats_in(x)
+        B, T, F = xin.shape
+        lib, ctx = N.lib(), N.ctx(xin.device)
+        emb = torch.empty((B, self.W.embd_dim), dtype=torch.float32, device=xin.device)
+        nws = lib.vp_eres2net_workspace_bytes(C.byref(self.W), B, T)
+        ws = self.ws.get(nws, xin.device)
+        N.check(lib.vp_eres2net_fwd(ctx, C.byref(self.W), xin.data_ptr(), B, T, emb.data_ptr(), ws.data_ptr(),
+                                    ws.numel(), N.stream_ptr()), ctx)
+        return emb
+
+
 class EngineMixin:
     """forward() of a backbone: eval-mode fused forward on the HIP engine."""
     _engine_cls = None

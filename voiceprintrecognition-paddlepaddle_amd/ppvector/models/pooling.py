@@ -40,5 +40,6 @@ class SelfAttentivePooling(_NotBuilt):
     pass
 
 
-class TemporalStatsPool(_NotBuilt):
-    pass
+class TemporalStatsPool(nn.Module):
+    """TSTP (pooling.py:128-146): parameter-free; runs inside the ERes2Net launch graph (csrc/eres2net.hip:
+    vp_time_moments with the unbiased variance + 1e-8)."""
