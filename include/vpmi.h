@@ -283,6 +283,21 @@ int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats
                     void* ws, size_t ws_bytes, vp_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Batch assembly around the featurizer.
+ * vp_spec_augment -- applies, in place, the masks the host drew for each utterance of a (B, T, F) batch; replaces the
+ *   per-sample yeaudio SpecAugmentor call at data_utils/reader.py:105-107 (parameters configs/augmentation.yml:36-48).
+ *   fmask [B][n_freq_masks][2] = (first bin, width), tmask [B][n_time_masks][2] = (first frame, width); width 0 = no
+ *   mask.  Frequency masks first, then time masks; each is filled with the mean of the utterance's feature as it is
+ *   at that moment, or with zero.
+ * vp_pad_batch -- collate_fn (data_utils/collate_fn.py:5-23): out[b] = srcs[b] (lens[b] x F) zero-padded to Tmax.
+ *   srcs is a DEVICE array of B device pointers.
+ * ---------------------------------------------------------------------------------------------- */
+int vp_spec_augment(vp_ctx* ctx, int dtype, void* feats, int B, int T, int F, const int32_t* fmask, int n_freq_masks,
+                    const int32_t* tmask, int n_time_masks, int replace_with_zero, vp_stream stream);
+int vp_pad_batch(vp_ctx* ctx, int dtype, const void* const* srcs, const int32_t* lens, int B, int Tmax, int F, void* out,
+                 vp_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
  * ResNetSE backbone forward, eval mode -- replaces ResNetSE.forward (models/resnet_se.py:121-139) with
  * SEBottleneck (:8-45) / SELayer (:48-63) blocks and ASP pooling.  2-D conv weights as for CAM++
  * ([Cout][tap*Cin + c], tap = kt*3 + kf).  SE Linear weights stay in Paddle's [in, out] layout.  The ASP /

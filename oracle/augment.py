@@ -1,0 +1,63 @@
+"""Oracle (CPU, NumPy): SpecAugment and batch collation.  TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+SpecAugment -- PARITY UNPINNED.  The reference calls yeaudio.augmentation.SpecAugmentor(**aug_conf.spec_aug)
+(ppvector/data_utils/reader.py:105-107,150-151; configs/augmentation.yml:36-48: prob 0.5, freq_mask_ratio 0.1,
+n_freq_masks 1, time_mask_ratio 0.05, n_time_masks 1, max_time_warp 0).  yeaudio (requirements.txt:12, >= 0.0.6) is
+not vendored and not installed, and the reference holds no test vectors for it, so this is a restatement of its
+published algorithm [3P-memory]: with probability `prob`: (time warp when max_time_warp > 0 -- not built), then
+n_freq_masks frequency masks, then n_time_masks time masks; a mask of width w = int(U(0, int(ratio * size))) starts
+at int(U(0, size - w)) and is filled with the CURRENT mean of the (T, F) feature (or zero when replace_with_zero).
+Draws come from Python's `random` in exactly this order, so a host that makes the same calls gets the same masks.
+
+collate_fn -- ppvector/data_utils/collate_fn.py:5-23: zero-pad to the longest feature; labels / lengths as int64.
+"""
+import random
+
+import numpy as np
+
+
+def draw_masks(n_frames, n_bins, prob=0.5, freq_mask_ratio=0.1, n_freq_masks=1, time_mask_ratio=0.05, n_time_masks=1,
+               rng=random):
+    """-> (apply, [(f0, fw)] * n_freq_masks, [(t0, tw)] * n_time_masks) for ONE utterance."""
+    if rng.random() > prob:
+        return False, [(0, 0)] * n_freq_masks, [(0, 0)] * n_time_masks
+    fm, tm = [], []
+    fmax = int(freq_mask_ratio * n_bins)
+    for _ in range(n_freq_masks):
+        f = int(rng.uniform(0, fmax))
+        f0 = int(rng.uniform(0, n_bins - f))
+        fm.append((f0, f))
+    tmax = int(time_mask_ratio * n_frames)
+    for _ in range(n_time_masks):
+        t = int(rng.uniform(0, tmax))
+        t0 = int(rng.uniform(0, n_frames - t))
+        tm.append((t0, t))
+    return True, fm, tm
+
+
+def apply_masks(x, fm, tm, replace_with_zero=False):
+    """x (T, F) float32 -> masked copy; each mask takes the mean of the tensor as it is at that moment."""
+    x = np.array(x, dtype=np.float32, copy=True)
+    for f0, f in fm:
+        if f > 0:
+            x[:, f0:f0 + f] = 0.0 if replace_with_zero else x.mean(dtype=np.float64)
+    for t0, t in tm:
+        if t > 0:
+            x[t0:t0 + t, :] = 0.0 if replace_with_zero else x.mean(dtype=np.float64)
+    return x
+
+
+def spec_augment(x, rng=random, **conf):
+    conf = {k: v for k, v in conf.items() if k != 'max_time_warp'}
+    rz = conf.pop('replace_with_zero', False)
+    ok, fm, tm = draw_masks(x.shape[0], x.shape[1], rng=rng, **conf)
+    return apply_masks(x, fm, tm, rz) if ok else np.array(x, dtype=np.float32, copy=True)
+
+
+def collate(batch):
+    """[(feature (T_i, F), label)] -> (features (B, Tmax, F) f32, labels int64, input_lens int64)."""
+    tmax = max(f.shape[0] for f, _ in batch)
+    out = np.zeros((len(batch), tmax, batch[0][0].shape[1]), np.float32)
+    for i, (f, _) in enumerate(batch):
+        out[i, :f.shape[0]] = f
+    return out, np.asarray([int(l) for _, l in batch], np.int64), np.asarray([f.shape[0] for f, _ in batch], np.int64)

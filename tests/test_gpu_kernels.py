@@ -565,3 +565,47 @@ def test_melspectrogram_matches_oracle(N, args, L):
     assert np.max(np.abs(gotm - refm)) < 2e-5 * scale
     with pytest.raises(ValueError):
         AudioFeaturizer('MelSpectrogram', dict(sr=16000, n_fft=1024, f_max=14000.0))   # above Nyquist (README's f_max)
+
+
+# --------------------------------------------------------------------------------------- batch assembly
+def test_spec_augment_matches_restatement(N):
+    """Same Python `random` draws on both sides -> same masks; the kernel fills with the running mean (f32 sum order
+    differs from NumPy's: tolerance 1e-5 on values of order 10)."""
+    import random
+    from oracle import augment as oa
+    from ppvector.data_utils.spec_aug import SpecAugmentor
+    conf = dict(prob=0.7, freq_mask_ratio=0.2, n_freq_masks=2, time_mask_ratio=0.1, n_time_masks=2, max_time_warp=0)
+    rng = np.random.RandomState(4)
+    x = (rng.standard_normal((9, 130, 80)) * 4 + 1).astype(np.float32)
+    random.seed(123)
+    ref = np.stack([oa.spec_augment(x[b], **conf) for b in range(x.shape[0])])
+    random.seed(123)
+    aug = SpecAugmentor(**conf)
+    got = aug.batch(dev(x)).cpu().numpy()
+    assert (ref != x).any() and np.max(np.abs(got - ref)) < 1e-5
+    random.seed(5)
+    refz = np.stack([oa.spec_augment(x[b], replace_with_zero=True, **conf) for b in range(x.shape[0])])
+    random.seed(5)
+    gotz = SpecAugmentor(replace_with_zero=True, **conf).batch(dev(x)).cpu().numpy()
+    assert np.array_equal(gotz, refz)
+    random.seed(9)                      # the reference's per-sample call form
+    one_ref = oa.spec_augment(x[0], **conf)
+    random.seed(9)
+    one = SpecAugmentor(**conf)(dev(x[0])).cpu().numpy()
+    assert np.max(np.abs(one - one_ref)) < 1e-5
+    random.seed(9)
+    one_np = SpecAugmentor(**conf)(x[0])                      # NumPy in -> NumPy out (reader.py:106)
+    assert isinstance(one_np, np.ndarray) and np.max(np.abs(one_np - one_ref)) < 1e-5
+    with pytest.raises(NotImplementedError):
+        SpecAugmentor(max_time_warp=5)
+
+
+def test_collate_fn_pads_like_reference(N):
+    from oracle import augment as oa
+    from ppvector.data_utils.collate_fn import collate_fn
+    rng = np.random.RandomState(2)
+    batch = [(rng.standard_normal((t, 80)).astype(np.float32), l) for t, l in ((298, 3), (120, 0), (1, 7), (297, 2))]
+    rf, rl, rn = oa.collate(batch)
+    f, l, n = collate_fn([(dev(x), lab) for x, lab in batch])
+    assert f.dtype == torch.float32 and l.dtype == torch.int64 and n.dtype == torch.int64
+    assert np.array_equal(f.cpu().numpy(), rf) and np.array_equal(l.cpu().numpy(), rl) and np.array_equal(n.cpu().numpy(), rn)

@@ -115,3 +115,28 @@ def test_eer_known_answer():
     assert 0.3 < e < 0.7
     sc, lab = osc.trial_scores(np.eye(3), [0, 1, 2], np.eye(3), [0, 1, 2])
     assert sc.shape == (9,) and lab.sum() == 3
+
+
+def test_spec_augment_restatement_properties():
+    """The SpecAugment restatement (parity unpinned, oracle/augment.py): mask geometry bounds of configs/augmentation.yml,
+    prob gating, fill value = current mean, and collation."""
+    import random
+    from oracle import augment as oa
+    conf = dict(prob=0.5, freq_mask_ratio=0.1, n_freq_masks=1, time_mask_ratio=0.05, n_time_masks=1)
+    random.seed(0)
+    applied = 0
+    for _ in range(400):
+        ok, fm, tm = oa.draw_masks(298, 80, **conf)
+        applied += ok
+        (f0, f), (t0, t) = fm[0], tm[0]
+        assert 0 <= f < 8 and 0 <= f0 <= 80 - f and 0 <= t < 14 and 0 <= t0 <= 298 - t
+    assert 150 < applied < 250
+    x = np.arange(12, dtype=np.float32).reshape(4, 3)
+    y = oa.apply_masks(x, [(1, 1)], [(2, 1)])
+    m1 = x.mean()
+    assert np.allclose(y[:, 1][[0, 1, 3]], m1)
+    x1 = x.copy(); x1[:, 1] = m1
+    assert np.allclose(y[2], x1.mean())
+    assert np.array_equal(oa.apply_masks(x, [(0, 0)], [(0, 0)]), x)
+    f, l, n = oa.collate([(np.ones((3, 2), np.float32), 5), (np.ones((1, 2), np.float32), 1)])
+    assert f.shape == (2, 3, 2) and f[1, 1:].sum() == 0 and list(l) == [5, 1] and list(n) == [3, 1]

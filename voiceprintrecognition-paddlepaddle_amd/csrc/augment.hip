@@ -1,0 +1,104 @@
+// Batch assembly either side of the featurizer: SpecAugment masks and zero-padded collation, on the GPU.
+//
+// SpecAugment: the reference calls yeaudio.SpecAugmentor(**aug_conf.spec_aug) on each (T, F) feature
+// (ppvector/data_utils/reader.py:105-107,150-151; parameters configs/augmentation.yml:36-48).  yeaudio is not
+// vendored; its published algorithm (frequency masks, then time masks, each filled with the CURRENT mean of the
+// feature -- or zero) is restated in oracle/augment.py.  The random draws stay on the host (same Python `random`
+// call sequence as the restatement); this kernel applies the drawn masks to the whole batch in place.
+// Collation: collate_fn (ppvector/data_utils/collate_fn.py:5-23) = zero-pad every (T_i, F) feature to T_max.
+#include "common.h"
+
+namespace {
+
+template <typename T>
+struct SaArgs { T* x; const int* fmask; const int* tmask; int Tn, F, nf, nt, zero; };
+
+// one workgroup per utterance; masks are applied in order, each with its own mean of the current tensor
+template <typename T>
+__global__ __launch_bounds__(256) void spec_augment_kernel(SaArgs<T> a) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    T* x = a.x + (size_t)b * a.Tn * a.F;
+    const int n = a.Tn * a.F;
+    for (int k = 0; k < a.nf + a.nt; ++k) {
+        const bool is_f = k < a.nf;
+        const int* mk = is_f ? a.fmask + ((size_t)b * a.nf + k) * 2 : a.tmask + ((size_t)b * a.nt + (k - a.nf)) * 2;
+        const int s0 = mk[0], wd = mk[1];
+        if (wd <= 0) continue;                                   // uniform per workgroup
+        float fill = 0.f;
+        if (!a.zero) {
+            float s = 0.f;
+            for (int i = tid; i < n; i += 256) s += vp_to_f32(x[i]);
+            s = vp_wave_sum(s);
+            if ((tid & 63) == 0) red[tid >> 6] = s;
+            __syncthreads();
+            fill = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+            __syncthreads();
+        }
+        const T fv = vp_from_f32<T>(fill);
+        if (is_f) {
+            for (int i = tid; i < a.Tn * wd; i += 256) x[(size_t)(i / wd) * a.F + s0 + i % wd] = fv;
+        } else {
+            for (int i = tid; i < wd * a.F; i += 256) x[(size_t)s0 * a.F + i] = fv;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+template <typename T>
+struct PadArgs { const T* const* src; const int* lens; T* out; int Tmax, F; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void pad_batch_kernel(PadArgs<T> a) {
+    const int b = blockIdx.y;
+    const T* s = a.src[b];
+    const long long nv = (long long)a.lens[b] * a.F, n = (long long)a.Tmax * a.F;
+    T* o = a.out + (size_t)b * n;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        o[i] = i < nv ? s[i] : vp_from_f32<T>(0.f);
+}
+
+}  // namespace
+
+extern "C" {
+
+int vp_spec_augment(vp_ctx* ctx, int dtype, void* feats, int B, int T, int F, const int32_t* fmask, int n_freq_masks,
+                    const int32_t* tmask, int n_time_masks, int replace_with_zero, vp_stream stream) {
+    if (!ctx || !feats || B <= 0 || T <= 0 || F <= 0 || n_freq_masks < 0 || n_time_masks < 0 ||
+        (n_freq_masks && !fmask) || (n_time_masks && !tmask))
+        VP_FAIL(ctx, VP_EINVAL, "spec_augment: bad arguments");
+    if (n_freq_masks + n_time_masks == 0) return VP_OK;
+    if (dtype == VP_BF16) {
+        SaArgs<bf16_t> a{(bf16_t*)feats, fmask, tmask, T, F, n_freq_masks, n_time_masks, replace_with_zero};
+        hipLaunchKernelGGL(spec_augment_kernel<bf16_t>, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+    } else if (dtype == VP_F32) {
+        SaArgs<float> a{(float*)feats, fmask, tmask, T, F, n_freq_masks, n_time_masks, replace_with_zero};
+        hipLaunchKernelGGL(spec_augment_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        VP_FAIL(ctx, VP_EINVAL, "spec_augment: bad dtype");
+    }
+    VP_LAUNCH_CHECK(ctx, "spec_augment");
+    return VP_OK;
+}
+
+int vp_pad_batch(vp_ctx* ctx, int dtype, const void* const* srcs, const int32_t* lens, int B, int Tmax, int F, void* out,
+                 vp_stream stream) {
+    if (!ctx || !srcs || !lens || !out || B <= 0 || Tmax <= 0 || F <= 0 || B > 65535) VP_FAIL(ctx, VP_EINVAL, "pad_batch: bad arguments");
+    const long long n = (long long)Tmax * F;
+    unsigned gx = (unsigned)((n + 255) / 256);
+    if (gx > 1024) gx = 1024;
+    if (dtype == VP_BF16) {
+        PadArgs<bf16_t> a{(const bf16_t* const*)srcs, lens, (bf16_t*)out, Tmax, F};
+        hipLaunchKernelGGL(pad_batch_kernel<bf16_t>, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, a);
+    } else if (dtype == VP_F32) {
+        PadArgs<float> a{(const float* const*)srcs, lens, (float*)out, Tmax, F};
+        hipLaunchKernelGGL(pad_batch_kernel<float>, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        VP_FAIL(ctx, VP_EINVAL, "pad_batch: bad dtype");
+    }
+    VP_LAUNCH_CHECK(ctx, "pad_batch");
+    return VP_OK;
+}
+
+}  // extern "C"

@@ -176,6 +176,8 @@ _PROTOS = {
     'vp_campplus_workspace_bytes': (c_size_t, [C.POINTER(CamppWeights), c_int, c_int]),
     'vp_campplus_fwd': (c_int, [c_void_p, C.POINTER(CamppWeights), c_void_p, c_int, c_int, c_void_p, c_void_p,
                                 c_size_t, c_void_p]),
+    'vp_spec_augment': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+    'vp_pad_batch': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'vp_resnetse_workspace_bytes': (c_size_t, [C.POINTER(ResnetSeWeights), c_int, c_int]),
     'vp_resnetse_fwd': (c_int, [c_void_p, C.POINTER(ResnetSeWeights), c_void_p, c_int, c_int, c_void_p, c_void_p,
                                 c_size_t, c_void_p]),
@@ -225,6 +227,13 @@ def load_library():
 
 def lib():
     return load_library()
+
+
+def default_device():
+    """The current HIP device as a torch.device; raises when none is visible (no CPU fallback)."""
+    if not torch.cuda.is_available():
+        raise VpmiError('no HIP device visible: the ppvector MI355X engine has no CPU fallback')
+    return torch.device('cuda', torch.cuda.current_device())
 
 
 def ctx(device=None):
