@@ -183,9 +183,9 @@ typedef struct {
     vp_tdnn_layer tdnn1;
     vp_tdnn_layer res2[VP_MAX_RES2];
     vp_tdnn_layer tdnn2;
-    const float* se_w1;       /* [se_ch][C]  f32 */
+    const float* se_w1;       /* [C][se_ch]  f32, input-major (Conv1D weight transposed) */
     const float* se_b1;       /* [se_ch] */
-    const float* se_w2;       /* [C][se_ch]  f32 */
+    const float* se_w2;       /* [se_ch][C]  f32, input-major */
     const float* se_b2;       /* [C] */
 } vp_se_res2_block;
 

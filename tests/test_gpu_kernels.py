@@ -247,6 +247,8 @@ def test_conv1d_split_destination(N, dtype):
     (66, 250, 64, 256, 3, 2, 'reflect'),     # taps: one tap per 64-wide K step, reflect at both utterance ends
     (64, 260, 128, 256, 3, 3, 'none'),       # un-padded (TDNN)
     (65, 255, 64, 384, 5, 1, 'zero'),        # zero padding = out-of-range DMA offsets
+    (70, 241, 80, 512, 5, 1, 'reflect'),     # ECAPA block0 geometry: Cin % 64 != 0, K-steps straddle taps, ragged K tail
+    (66, 250, 72, 256, 3, 2, 'zero'),
 ])
 def test_conv1d_wide_tiles_bf16(N, case):
     B, T, Cin, Cout, kw, dil, pad = case

@@ -113,6 +113,8 @@ int vp_se_scale_residual_ex(vp_ctx* ctx, int dtype, const void* x, int ldx, int 
                             int relu, hipStream_t st);
 int vp_time_moments(vp_ctx* ctx, int dtype, const void* x, int ldx, int B, int T, int C, float eps, int unbiased,
                     float* stats, hipStream_t st);
+int vp_se_gate(vp_ctx* ctx, const float* psum, const float* shift, int B, int T, int C, int H, const float* w1, const float* b1,
+               const float* w2, const float* b2, float* out, hipStream_t st);
 int vp_copy_cols(vp_ctx* ctx, int dtype, const void* x, int ldx, int xoff, void* y, int ldy, int yoff, long long rows, int C,
                  hipStream_t st);
 int vp_aff_combine(vp_ctx* ctx, int dtype, const void* t, int ldt, const void* x, int ldx, int xoff, const void* y, int ldy,

@@ -114,7 +114,8 @@ int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream) {
     if (d->psum && a.nseg > NSEG_MAX) VP_FAIL(ctx, VP_EUNSUP, "conv1d: T_out %d too short for fused time sums", d->T_out);
     hipStream_t st = (hipStream_t)stream;
     // wide bf16 layers: 256 x 256 tiles fed by LDS-DMA (conv_gemm256.hip)
-    if (d->dtype_in == VP_BF16 && d->dtype_out == VP_BF16 && (mode == MODE_1X1 || mode == MODE_TAPS) && d->Cin % 64 == 0 &&
+    if (d->dtype_in == VP_BF16 && d->dtype_out == VP_BF16 && (mode == MODE_1X1 || mode == MODE_TAPS) &&
+        (d->Cin % 64 == 0 || (mode == MODE_TAPS && use_conv256() == 3)) &&
         d->Cout >= 256 && a.M >= 256 * 64 && !d->gate && (!d->psum || d->T_out >= 128) && use_conv256()) {
         a.tiles_m = (a.M + 255) / 256;
         a.tiles_n = (a.N + 255) / 256;

@@ -15,6 +15,7 @@
 namespace {
 
 constexpr int T2 = 256;                      // tile edge (positions and channels)
+constexpr int MODE_TAPS_GEN = 4;             // tapped 1-D conv with Cin % 64 != 0: a K-step may straddle taps (role-split schedule only)
 constexpr int STAGE2 = 2 * T2 * ROWB;        // X panel + W panel
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -108,7 +109,23 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(const ConvArgs a) {
     auto role_piece = [&](int kt, int s, int i) {
         char* dst = smem + s * STAGE2 + (w_role ? T2 * ROWB : 0) + ((wv & 3) * 64 + i * 8) * ROWB;
         const unsigned kb = (unsigned)kt * (unsigned)ROWB;
-        if (w_role) {
+        if constexpr (MODE == MODE_TAPS_GEN) {
+            // this lane's 16-B chunk q of the K axis: tap j = q / (Cin / 8), channel chunk q - j * cpt; q >= KC reads zero
+            const int q = kt * 8 + (int)(cb >> 4);
+            const bool kv = q < a.KC;
+            if (w_role) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)dst, 16, (kv && qoff[i] != OOB) ? qoff[i] + kb : OOB, 0, 0, 0);
+            } else {
+                const int j = q / a.cpt;
+                const unsigned cbyte = (unsigned)(q - j * a.cpt) << 4;
+                const int traw = qpos[i] + j * a.dilation;
+                int ts = traw < 0 ? -traw : traw;
+                ts = ts >= a.T_in ? 2 * (a.T_in - 1) - ts : ts;
+                const bool inr = traw >= 0 && traw < a.T_in;
+                const bool ok = kv && qoff[i] != OOB && (inr || !zero_pad);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_ptr_t)dst, 16, ok ? qoff[i] + (unsigned)ts * ldxb + cbyte : OOB, 0, 0, 0);
+            }
+        } else if (w_role) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)dst, 16, qoff[i] != OOB ? qoff[i] + kb : OOB, 0, 0, 0);
         } else if constexpr (MODE == MODE_1X1) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_ptr_t)dst, 16, qoff[i] != OOB ? qoff[i] + kb : OOB, 0, 0, 0);
@@ -186,7 +203,7 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(const ConvArgs a) {
         }
     };
 
-    const int KT = a.K / 64;
+    const int KT = a.KT;
     if constexpr (SCHED == 2) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) role_piece(0, 0, i);
@@ -574,7 +591,7 @@ int vp_conv_launch256_bf16(vp_ctx* ctx, const void* args, int mode, int sched, h
         if (mode == MODE_TAPS) return launch256<MODE_TAPS, 1>(ctx, a, st);
     } else {
         if (mode == MODE_1X1) return launch256<MODE_1X1, 2>(ctx, a, st);
-        if (mode == MODE_TAPS) return launch256<MODE_TAPS, 2>(ctx, a, st);
+        if (mode == MODE_TAPS) return a.Cin % 64 == 0 ? launch256<MODE_TAPS, 2>(ctx, a, st) : launch256<MODE_TAPS_GEN, 2>(ctx, a, st);
     }
     VP_FAIL(ctx, VP_EUNSUP, "conv256: mode %d not built", mode);
 }

@@ -186,11 +186,8 @@ int vp_ecapa_fwd(vp_ctx* ctx, const vp_ecapa_weights* w, const void* feats, int 
         d.y = p.t2; d.ldy = C; d.psum = p.psum;
         if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
         // SE: mean over time -> 1x1 -> ReLU -> 1x1 -> sigmoid
-        if ((rc = vp_moments_finalize(ctx, p.psum, nullptr, blk.tdnn2.bn_shift, B, T, C, 0.f, 0, p.stats, st))) return rc;
-        if ((rc = vp_dense_f32_ex(ctx, p.stats, C, blk.se_w1, 0, blk.se_b1, nullptr, nullptr, B, w->se_ch, C, VP_ACT_RELU,
-                                  p.se_h, w->se_ch, st))) return rc;
-        if ((rc = vp_dense_f32_ex(ctx, p.se_h, w->se_ch, blk.se_w2, 0, blk.se_b2, nullptr, nullptr, B, C, w->se_ch,
-                                  VP_ACT_SIGMOID, p.se_s, C, st))) return rc;
+        if ((rc = vp_se_gate(ctx, p.psum, blk.tdnn2.bn_shift, B, T, C, w->se_ch, blk.se_w1, blk.se_b1, blk.se_w2, blk.se_b2,
+                             p.se_s, st))) return rc;
         // gate + residual, written straight into slice i of the MFA input
         if ((rc = vp_se_scale_residual(ctx, dt, p.t2, C, 0, p.se_s, xin, ld_in, off_in, p.cat, ldcat, i * C, B, T, C, st)))
             return rc;

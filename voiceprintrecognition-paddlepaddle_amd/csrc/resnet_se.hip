@@ -117,9 +117,8 @@ int vp_resnetse_fwd(vp_ctx* ctx, const vp_resnetse_weights* w, const void* feats
         base_desc(d, b.conv3, dt);
         d.B = B; d.T_in = to * fo; d.T_out = to * fo; d.x = p.o2; d.y = p.o3; d.psum = p.psum;
         if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
-        if ((rc = vp_moments_finalize(ctx, p.psum, nullptr, b.conv3.bn_shift, B, to * fo, C, 0.f, 0, p.stats, st))) return rc;
-        if ((rc = vp_dense_f32_ex(ctx, p.stats, C, b.se_w1, 1, b.se_b1, nullptr, nullptr, B, C / 8, C, VP_ACT_RELU, p.se_h, C / 8, st))) return rc;
-        if ((rc = vp_dense_f32_ex(ctx, p.se_h, C / 8, b.se_w2, 1, b.se_b2, nullptr, nullptr, B, C, C / 8, VP_ACT_SIGMOID, p.se_s, C, st))) return rc;
+        if ((rc = vp_se_gate(ctx, p.psum, b.conv3.bn_shift, B, to * fo, C, C / 8, b.se_w1, b.se_b1, b.se_w2, b.se_b2, p.se_s, st)))
+            return rc;
         const void* res = x;
         if (b.has_down) {          // bn(conv1x1 stride (s, s)(x))
             base_desc(d, b.down, dt);

@@ -337,6 +337,100 @@ int vp_aff_combine(vp_ctx* ctx, int dtype, const void* t, int ldt, const void* x
     return VP_OK;
 }
 
+// ---------------------------------------------------------------- SE gate in one launch
+// s[b, :] = sigmoid(W2 relu(W1 mean_t(y[b]) + b1) + b2), the mean taken from the producing conv's fused column sums
+// (SEBlock, ecapa_tdnn.py:69-82; SELayer, resnet_se.py:48-63).  One workgroup per utterance: the three dependent steps
+// (finalise the mean, C -> H, H -> C) were three launches of ~5 + 10 + 10 us on a (B, 512) problem.
+namespace {
+struct SeGateArgs {
+    const float* psum; const float* shift; const float* w1; const float* b1; const float* w2; const float* b2; float* out;
+    int B, T, C, H, nseg;
+};
+
+// out[n] = act(bias[n] + sum_k in[k] W[k][n]) for n < N; `in`, `out`, `part` (256 floats) live in LDS.  W is [K][N]
+// (input-major: consecutive threads read consecutive float4 column groups, the remaining threads split K); the k loop is
+// unrolled so every thread keeps 16 independent 16-byte loads in flight -- a dependent load-reduce chain per output
+// made this kernel 237 us on a 512-channel block.
+constexpr int SE_UPW = 4;             // utterances per workgroup: every workgroup streams both weight matrices once
+
+// out[u][n] = act(bias[n] + sum_k in[u][k] W[k][n]) for SE_UPW utterances; `in` (stride ldi), `out` (stride ldo), `part` in LDS
+__device__ __forceinline__ void se_matvec(const float* in, int ldi, int K, const float* W, int N, const float* bias, int sigmoid,
+                                          float* out, int ldo, float* part) {
+    const int tid = threadIdx.x;
+    const int nv = N >> 2;                            // float4 column groups (N % 4 == 0, N <= 1024: host-checked)
+    const int ns = 256 / nv;                          // K slices worked on in parallel
+    const int v = tid % nv, sl = tid / nv;
+    if (sl < ns) {
+        const int k0 = (int)((long long)K * sl / ns), k1 = (int)((long long)K * (sl + 1) / ns);
+        float4 acc[SE_UPW];
+#pragma unroll
+        for (int u = 0; u < SE_UPW; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* wp = W + 4 * v;
+#pragma unroll 8
+        for (int k = k0; k < k1; ++k) {
+            const float4 w = *reinterpret_cast<const float4*>(wp + (size_t)k * N);
+#pragma unroll
+            for (int u = 0; u < SE_UPW; ++u) {
+                const float x = in[u * ldi + k];
+                acc[u].x += x * w.x; acc[u].y += x * w.y; acc[u].z += x * w.z; acc[u].w += x * w.w;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SE_UPW; ++u) *reinterpret_cast<float4*>(part + (u * ns + sl) * N + 4 * v) = acc[u];
+    }
+    __syncthreads();
+    for (int i = tid; i < SE_UPW * N; i += 256) {
+        const int u = i / N, n = i - u * N;
+        float acc = bias ? bias[n] : 0.f;
+        for (int q = 0; q < ns; ++q) acc += part[(u * ns + q) * N + n];
+        out[u * ldo + n] = sigmoid ? 1.f / (1.f + __expf(-acc)) : fmaxf(acc, 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void se_gate_kernel(SeGateArgs a) {
+    extern __shared__ float sm[];        // mean[UPW][C] | h[UPW][H] | s[UPW][C] | part[UPW][<= 1024]
+    float* mean = sm;
+    float* h = mean + SE_UPW * a.C;
+    float* sg = h + SE_UPW * a.H;
+    float* part = sg + SE_UPW * a.C;
+    const int b0 = blockIdx.x * SE_UPW;
+    for (int i = threadIdx.x; i < SE_UPW * a.C; i += 256) {
+        const int u = i / a.C, c = i - u * a.C;
+        const int b = min(b0 + u, a.B - 1);
+        const int t0 = (int)(((long long)b * a.T) / VP_CONV_BM);
+        const int t1 = (int)(((long long)(b + 1) * a.T - 1) / VP_CONV_BM);
+        float s1 = 0.f;
+        for (int tm = t0; tm <= t1; ++tm) {
+            const int seg = b - (int)(((long long)tm * VP_CONV_BM) / a.T);
+            s1 += a.psum[((size_t)tm * a.nseg + seg) * a.C + c];
+        }
+        mean[i] = (a.shift ? a.shift[c] : 0.f) + s1 / (float)a.T;
+    }
+    __syncthreads();
+    se_matvec(mean, a.C, a.C, a.w1, a.H, a.b1, 0, h, a.H, part);
+    __syncthreads();
+    se_matvec(h, a.H, a.H, a.w2, a.C, a.b2, 1, sg, a.C, part);
+    __syncthreads();
+    for (int i = threadIdx.x; i < SE_UPW * a.C; i += 256) {
+        const int u = i / a.C;
+        if (b0 + u < a.B) a.out[(size_t)(b0 + u) * a.C + (i - u * a.C)] = sg[i];
+    }
+}
+}  // namespace
+
+// w1 [C][H], w2 [H][C]: input-major (Paddle Linear layout; Conv1D weights are transposed at pack time)
+int vp_se_gate(vp_ctx* ctx, const float* psum, const float* shift, int B, int T, int C, int H, const float* w1, const float* b1,
+               const float* w2, const float* b2, float* out, hipStream_t st) {
+    if (!psum || !w1 || !w2 || !out || B <= 0 || T <= 0 || C <= 0 || H <= 0) VP_FAIL(ctx, VP_EINVAL, "se_gate: bad arguments");
+    if ((C | H) & 3 || C > 1024 || H > 1024) VP_FAIL(ctx, VP_EUNSUP, "se_gate: C %d / H %d (multiples of 4, <= 1024)", C, H);
+    const size_t smem = (size_t)SE_UPW * (2 * C + H + 1024) * sizeof(float);
+    if (smem > 64 * 1024) VP_FAIL(ctx, VP_EUNSUP, "se_gate: %d channels do not fit the LDS budget", C);
+    SeGateArgs a{psum, shift, w1, b1, w2, b2, out, B, T, C, H, vp_conv1d_nseg(T)};
+    hipLaunchKernelGGL(se_gate_kernel, dim3((B + SE_UPW - 1) / SE_UPW), dim3(256), smem, st, a);
+    VP_LAUNCH_CHECK(ctx, "se_gate");
+    return VP_OK;
+}
+
 int vp_dense_f32_ex(vp_ctx* ctx, const float* a, int lda, const float* w, int w_is_kn, const float* bias,
                     const float* rowscale, const float* colscale, int M, int N, int K, int act, float* out,
                     int ldo, hipStream_t st) {

@@ -93,9 +93,9 @@ class EcapaEngine(_Engine):
             for j, rb in enumerate(blk.res2net_block.blocks):
                 self.tdnn_layer(S.res2[j], rb.conv.conv, rb.norm.norm, rb.conv.dilation)
             self.tdnn_layer(S.tdnn2, blk.tdnn2.conv.conv, blk.tdnn2.norm.norm, 1)
-            S.se_w1 = self._p(blk.se_block.conv1.conv.weight.detach()[:, :, 0].float())
+            S.se_w1 = self._p(blk.se_block.conv1.conv.weight.detach()[:, :, 0].float().t().contiguous())     # [C][se_ch]
             S.se_b1 = self._p(f32(blk.se_block.conv1.conv.bias))
-            S.se_w2 = self._p(blk.se_block.conv2.conv.weight.detach()[:, :, 0].float())
+            S.se_w2 = self._p(blk.se_block.conv2.conv.weight.detach()[:, :, 0].float().t().contiguous())     # [se_ch][C]
             S.se_b2 = self._p(f32(blk.se_block.conv2.conv.bias))
         self.tdnn_layer(W.mfa, m.mfa.conv.conv, m.mfa.norm.norm, m.mfa.conv.dilation)
         self.asp(W.asp, m.asp)
