@@ -3,8 +3,8 @@
 //   attn   = softmax over time           pooling.py:115-121 (mask of ones)
 //   mean, std = weighted statistics      pooling.py:122   -> pooled (B, 2C)
 // The (B*T, C) f32 logits never exist: each wave owns 32 channels of one utterance, keeps its 8
-// weight fragments (32 x att bf16) in registers, streams the utterance's frames through the matrix
-// cores 16 at a time and folds every 16x16 logit tile into a per-lane online softmax
+// weight fragments (32 x att bf16) in registers, streams the utterance's frames (staged 16 at a time through LDS by
+// coalesced loads) through the matrix cores and folds every 16x16 logit tile into a per-lane online softmax
 // (running max, sum p, sum p*x, sum p*x^2 with x centred on the plain time mean for conditioning).
 // Lanes that share a channel merge with two xor-shuffles at the end; waves never need to talk.
 // Roofline: HBM/L2 -- it must read x once (T*C*2 B per utterance = 0.92 MB) and h (T*att*2 B, L2-hot).
@@ -32,12 +32,18 @@ __device__ __forceinline__ void merge_state(float& m, float& s0, float& s1, floa
     s0 = s0 * f1 + a0 * f2; s1 = s1 * f1 + a1 * f2; s2 = s2 * f1 + a2 * f2; m = M;
 }
 
+constexpr int AF_HROW = 256;          // bytes per staged h row (128 att bf16), 16-B chunks XOR-swizzled by row
+constexpr int AF_XROW = 272;          // bytes per staged x row (128 channels bf16 + 16 pad: the 4 frame groups of a
+                                      // result-layout read land on disjoint banks)
+
 __global__ __launch_bounds__(256) void asp_fused_kernel(AspFusedArgs a) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ __attribute__((aligned(16))) char hs[2][16 * AF_HROW];
+    __shared__ __attribute__((aligned(16))) char xs[2][16 * AF_XROW];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
     const int b = blockIdx.y;
-    const int c0 = blockIdx.x * 128 + wv * 32;
-    if (c0 >= a.C) return;                                   // wave-uniform
+    const int cblk = blockIdx.x * 128;
+    const int c0 = cblk + wv * 32;
     const size_t row0 = (size_t)b * a.T;
 
     // B operand: weight rows (channels) c0 + ni*16 + li, k chunk ks*4 + g
@@ -56,28 +62,31 @@ __global__ __launch_bounds__(256) void asp_fused_kernel(AspFusedArgs a) {
     float mx[2] = {-INFINITY, -INFINITY}, s0[2] = {0.f, 0.f}, s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
 
     const int ntile = (a.T + 15) / 16;
-    // loads of frame tile mt+1 are issued before the MFMAs / exps of tile mt (register double buffer)
-    auto load_tile = [&](int mt, bf16x8 (&hf)[4], bf16_t (&xr)[2][4]) {
-        const int ta = min(mt * 16 + li, a.T - 1);                    // A operand: frames mt*16 + li of h
-        const bf16_t* hr = a.h + (row0 + ta) * AF_ATT;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) hf[ks] = *reinterpret_cast<const bf16x8*>(hr + (ks * 4 + g) * 8);
-        const int t0 = mt * 16 + g * 4;                                // result rows: frames t0 + r
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const size_t xo = (row0 + min(t0 + r, a.T - 1)) * a.ldx;
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) xr[ni][r] = a.x[xo + ch[ni]];
-        }
+    // Frame tile mt (16 frames): h (16 x 256 B, contiguous in memory) and this workgroup's x block (16 x 256 B) are each
+    // ONE 16-byte load per thread, 16 lanes per row -- fully coalesced -- staged through LDS and re-read in the MFMA
+    // operand / result layouts.  (Loading them directly in those layouts -- 2-byte and 16-row-strided accesses -- made
+    // the vector-memory path the bottleneck: 160 us for 30 GFLOP.)
+    const int srow = tid >> 4, schunk = tid & 15;
+    const int xcol = min(cblk + schunk * 8, a.C - 8);                  // clamped: columns past C feed lanes that never store
+    auto gload = [&](int mt, uint4& hv, uint4& xv) {
+        const size_t t = row0 + min(mt * 16 + srow, a.T - 1);
+        hv = *reinterpret_cast<const uint4*>(a.h + t * AF_ATT + schunk * 8);
+        xv = *reinterpret_cast<const uint4*>(a.x + t * a.ldx + xcol);
     };
-    auto compute_tile = [&](int mt, const bf16x8 (&hf)[4], const bf16_t (&xr)[2][4]) {
+    auto swrite = [&](int buf, const uint4& hv, const uint4& xv) {
+        *reinterpret_cast<uint4*>(hs[buf] + srow * AF_HROW + ((schunk ^ srow) << 4)) = hv;
+        *reinterpret_cast<uint4*>(xs[buf] + srow * AF_XROW + (schunk << 4)) = xv;
+    };
+    auto compute_tile = [&](int mt, int buf) {
         const int t0 = mt * 16 + g * 4;
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hs[buf] + li * AF_HROW + (((ks * 4 + g) ^ li) << 4));
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
-                acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf[ks], wf[ni][ks], acc[ni], 0, 0, 0);
+                acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf, wf[ni][ks], acc[ni], 0, 0, 0);
+        }
         // acc[ni][r] = logit(frame t0 + r, channel ch[ni]) - bias
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
@@ -96,23 +105,23 @@ __global__ __launch_bounds__(256) void asp_fused_kernel(AspFusedArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float p = expf(e[r] - mx[ni]);              // exp(-inf) = 0 for frames past T
-                    const float xv = (float)xr[ni][r] - mu0[ni];
+                    const bf16_t xb = *reinterpret_cast<const bf16_t*>(xs[buf] + (g * 4 + r) * AF_XROW + (wv * 32 + ni * 16 + li) * 2);
+                    const float xv = (float)xb - mu0[ni];
                     s0[ni] += p; s1[ni] += p * xv; s2[ni] += p * xv * xv;
                 }
             }
         }
     };
-    bf16x8 h0[4], h1[4];
-    bf16_t x0[2][4], x1[2][4];
-    load_tile(0, h0, x0);
-    for (int mt = 0; mt < ntile; mt += 2) {
-        const bool odd = mt + 1 < ntile;
-        if (odd) load_tile(mt + 1, h1, x1);
-        compute_tile(mt, h0, x0);
-        if (odd) {
-            if (mt + 2 < ntile) load_tile(mt + 2, h0, x0);
-            compute_tile(mt + 1, h1, x1);
-        }
+    uint4 hv, xv;
+    gload(0, hv, xv);
+    swrite(0, hv, xv);
+    __syncthreads();
+    for (int mt = 0; mt < ntile; ++mt) {
+        const bool more = mt + 1 < ntile;
+        if (more) gload(mt + 1, hv, xv);
+        compute_tile(mt, mt & 1);
+        if (more) swrite((mt + 1) & 1, hv, xv);
+        __syncthreads();
     }
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
@@ -134,7 +143,8 @@ __global__ __launch_bounds__(256) void asp_fused_kernel(AspFusedArgs a) {
 int vp_asp_fused_bf16(vp_ctx* ctx, const void* h, const void* w, const float* bias, const void* x, int ldx,
                       const float* center, int ldc, int B, int T, int C, int att, float eps, float* pooled,
                       hipStream_t st) {
-    if (att != AF_ATT || B > 65535 || T < 1) return VP_EUNSUP;
+    if (att != AF_ATT || B > 65535 || T < 1 || C < 8 || (C | ldx) & 7 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(h)) & 15))
+        return VP_EUNSUP;
     AspFusedArgs a;
     a.h = (const bf16_t*)h; a.w = (const bf16_t*)w; a.bias = bias; a.x = (const bf16_t*)x; a.center = center;
     a.pooled = pooled; a.ldx = ldx; a.ldc = ldc; a.T = T; a.C = C; a.eps = eps;

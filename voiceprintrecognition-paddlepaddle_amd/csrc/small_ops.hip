@@ -351,7 +351,7 @@ struct SeGateArgs {
 // (input-major: consecutive threads read consecutive float4 column groups, the remaining threads split K); the k loop is
 // unrolled so every thread keeps 16 independent 16-byte loads in flight -- a dependent load-reduce chain per output
 // made this kernel 237 us on a 512-channel block.
-constexpr int SE_UPW = 4;             // utterances per workgroup: every workgroup streams both weight matrices once
+constexpr int SE_UPW = 1;             // utterances per workgroup: every workgroup streams both weight matrices once
 
 // out[u][n] = act(bias[n] + sum_k in[u][k] W[k][n]) for SE_UPW utterances; `in` (stride ldi), `out` (stride ldo), `part` in LDS
 __device__ __forceinline__ void se_matvec(const float* in, int ldi, int K, const float* W, int N, const float* bias, int sigmoid,
