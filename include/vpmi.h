@@ -388,6 +388,59 @@ int vp_cosine_aam_ce_fwd(vp_ctx* ctx, const float* emb, const float* W, const in
                          float* loss, float* logits, float* row_loss, void* ws, size_t ws_bytes,
                          vp_stream stream);
 
+/* Backward of head + loss (the autograd the reference gets from paddle for fc.py:41-53 + aamloss.py:28-47; called per
+ * step by PPVectorTrainer.__train_epoch, trainer.py:213-219): demb (B, D) = d loss / d emb, dW (D, C) = d loss / d W,
+ * both f32 and both scaled by grad_scale (1.0 for plain backward); loss (1) optional (the forward value, recomputed). */
+size_t vp_cosine_aam_ce_bwd_workspace_bytes(int B, int D, int C);
+int vp_cosine_aam_ce_bwd(vp_ctx* ctx, const float* emb, const float* W, const int64_t* labels, int B, int D, int C, float margin,
+                         float scale, float label_smoothing, int easy_margin, float grad_scale, float* demb, float* dW,
+                         float* loss, void* ws, size_t ws_bytes, vp_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Training-side building blocks (f32 engine) -- what paddle's autograd and optimiser run under
+ * PPVectorTrainer.__train_epoch (trainer.py:202-274) for the layers of models/utils.py:22-148.
+ *
+ * vp_conv1d_wgrad_f32: dW[n][tap*Cin + c] = sum over (b, t) of dz[b,t,n] * x[b, src(t, tap), c], src = the forward's tap
+ *   index rule (reflect / zero / none).  `d` is the FORWARD conv's descriptor (x, ldx, xoff, geometry).  The data gradient
+ *   needs no new kernel: it is vp_conv1d_fwd over dz with the taps reversed and the channel roles swapped
+ *   (W'[c][(KW-1-j)*Cout + n] = W[n][j*Cin + c], zero padding dil*(KW-1) - pad_left), see ppvector/train/functions.py.
+ * vp_col_sums_f32: sums[0][c] = sum_m a[m][c]; sums[1][c] = sum_m a[m][c] * (b[m][c] - bmean[c]) * bscale[c] (when b):
+ *   the two reductions of BatchNorm backward (d beta, d gamma), and the conv bias gradient.
+ * vp_bn_train_finalize: batch mean / biased variance from a conv's fused column sums (all nparts = tiles * nseg partial
+ *   rows), folded scale/shift for the apply pass, saved mean / invstd, running statistics updated in place
+ *   (running = momentum * running + (1 - momentum) * batch; utils.py:108-115, momentum 0.9).
+ * vp_affine_rows_f32: y = z * scale + shift.   vp_bn_relu_bwd_f32: dz through BN (batch statistics) and the ReLU before it.
+ * vp_adam_step_f32: Adam with coupled L2 (optimizer/__init__.py:12-18), bias-corrected, on a flat f32 buffer.
+ * ---------------------------------------------------------------------------------------------- */
+size_t vp_conv1d_wgrad_workspace_bytes(const vp_conv1d_desc* d);
+int vp_conv1d_wgrad_f32(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int lddz, float* dW, void* ws, size_t ws_bytes,
+                        vp_stream stream);
+size_t vp_col_sums_workspace_bytes(long long M, int C);
+int vp_col_sums_f32(vp_ctx* ctx, const float* a, int lda, const float* b, int ldb, const float* bmean, const float* bscale,
+                    long long M, int C, float* sums, void* ws, size_t ws_bytes, vp_stream stream);
+int vp_bn_train_finalize(vp_ctx* ctx, const float* psum, const float* psumsq, int nparts, long long M, int C, const float* gamma,
+                         const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                         float* invstd, float* scale, float* shift, vp_stream stream);
+int vp_affine_rows_f32(vp_ctx* ctx, const float* z, int ldz, const float* scale, const float* shift, long long M, int C, float* y,
+                       int ldy, vp_stream stream);
+int vp_bn_relu_bwd_f32(vp_ctx* ctx, const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* invstd,
+                       const float* gamma, const float* sums, long long M, int C, int relu_mask, float* dz, int lddz,
+                       vp_stream stream);
+int vp_adam_step_f32(vp_ctx* ctx, float* param, const float* grad, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int step, float grad_scale, vp_stream stream);
+
+/* ASP in training (models/pooling.py:69-125): per-utterance sums (gradient of the context bias), the global-context
+ * statistics [mean | sqrt(max(var, eps))] and their backward, the backward of softmax-over-time + weighted mean/std
+ * (forward = vp_asp_softmax_stats), tanh and its backward.  e (B*T, C) f32 logits, x (B*T, ldx) f32, pooled (B, 2C). */
+int vp_utt_sums_f32(vp_ctx* ctx, const float* a, int lda, int B, int T, int C, float* out, vp_stream stream);
+int vp_time_stats_f32(vp_ctx* ctx, const float* x, int ldx, int B, int T, int C, float eps, float* stats, vp_stream stream);
+int vp_time_stats_bwd_f32(vp_ctx* ctx, const float* x, int ldx, const float* stats, const float* dstats, int B, int T, int C, float eps,
+                          float* dx, int lddx, vp_stream stream);
+int vp_attn_stats_bwd_f32(vp_ctx* ctx, const float* e, const float* x, int ldx, const float* pooled, const float* dpooled, int B, int T,
+                          int C, float eps, float* de, float* dx, int lddx, vp_stream stream);
+int vp_tanh_f32(vp_ctx* ctx, const float* x, long long n, float* y, vp_stream stream);
+int vp_tanh_bwd_f32(vp_ctx* ctx, const float* dy, const float* y, long long n, float* dz, vp_stream stream);
+
 /* Trial scoring -- replaces the per-trial sklearn cosine_similarity loop of
  * PPVectorTrainer.evaluate (trainer.py:416-423) and PPVectorPredictor.contrast (predict.py:282):
  * scores[i][j] = <a_i, b_j> / (|a_i| |b_j|). */

@@ -1,0 +1,198 @@
+"""GPU parity tests of the training path (f32 engine): every backward entry point and the whole TDNN training step
+against PyTorch autograd over the CPU oracle graph (float64 where cheap).  Run with -m gpu on an MI355X."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import models as om
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def N():
+    from ppvector import _native as N
+    if not torch.cuda.is_available():
+        pytest.fail('no GPU visible: these tests must run on an MI355X (no CPU fallback exists)')
+    N.ctx(0)
+    return N
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp(min=1e-30)).item()
+
+
+@pytest.mark.parametrize('case', [
+    # B, T, Cin, Cout, kw, dil, pad
+    (3, 50, 80, 64, 5, 1, 'none'),        # TDNN layer 1 geometry (Cin % 64 != 0: k-column tiles straddle taps)
+    (2, 41, 64, 128, 3, 2, 'none'),
+    (2, 37, 128, 64, 3, 3, 'none'),
+    (4, 33, 64, 192, 1, 1, 'none'),
+    (2, 45, 64, 64, 3, 2, 'zero'),
+    (70, 131, 64, 64, 3, 1, 'none'),      # many row splits
+])
+def test_conv_block_grads_vs_autograd(N, case):
+    """conv (+bias) -> ReLU -> BatchNorm(batch statistics): output, running statistics and all five gradients."""
+    from ppvector.train.functions import ConvBlock
+    B, T, Cin, Cout, kw, dil, pad = case
+    g = torch.Generator().manual_seed(5 + kw + dil)
+    x = torch.randn(B, T, Cin, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Cout, Cin, kw, generator=g, dtype=torch.float64) / (Cin * kw) ** 0.5).requires_grad_()
+    b = torch.randn(Cout, generator=g, dtype=torch.float64, requires_grad=True)
+    ga = (torch.rand(Cout, generator=g, dtype=torch.float64) + 0.5).requires_grad_()
+    be = torch.randn(Cout, generator=g, dtype=torch.float64, requires_grad=True)
+    p = dil * (kw - 1) // 2 if pad == 'zero' else 0
+    z = F.relu(F.conv1d(x.transpose(1, 2), w, b, dilation=dil, padding=p))
+    mean, var = z.mean(dim=(0, 2)), z.var(dim=(0, 2), unbiased=False)
+    y = ((z - mean[None, :, None]) / torch.sqrt(var[None, :, None] + 1e-5) * ga[None, :, None] + be[None, :, None]).transpose(1, 2)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    xd = x.detach().float().reshape(B * T, Cin).cuda().requires_grad_()
+    wd, bd = w.detach().float().cuda().requires_grad_(), b.detach().float().cuda().requires_grad_()
+    gd, hd = ga.detach().float().cuda().requires_grad_(), be.detach().float().cuda().requires_grad_()
+    rm, rv = torch.zeros(Cout, device='cuda'), torch.ones(Cout, device='cuda')
+    out = ConvBlock.apply(xd, wd, bd, None, gd, hd, rm, rv, dict(B=B, T=T, dilation=dil, pad=pad, relu=True))
+    out.backward(dy.float().reshape(-1, Cout).cuda())
+    To = y.shape[1]
+    assert rel(out.reshape(B, To, Cout), y.detach()) < 2e-6
+    assert rel(rm, 0.1 * mean.detach()) < 2e-6 and rel(rv, 0.9 + 0.1 * var.detach()) < 2e-6
+    for name, got, ref in (('dx', xd.grad.reshape(B, T, Cin), x.grad), ('dW', wd.grad, w.grad), ('dbias', bd.grad, b.grad),
+                           ('dgamma', gd.grad, ga.grad), ('dbeta', hd.grad, be.grad)):
+        assert rel(got, ref) < 2e-5, (name, rel(got, ref))
+
+
+def test_asp_pieces_vs_autograd(N):
+    from ppvector.train.functions import AttnStats, BNRows, TimeStats
+    B, T, Cc = 3, 47, 96
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, T, Cc, generator=g, dtype=torch.float64, requires_grad=True)
+    e = (torch.randn(B, T, Cc, generator=g, dtype=torch.float64) * 2).requires_grad_()
+    al = torch.softmax(e, dim=1)
+    mu = (al * x).sum(1)
+    sd = torch.sqrt(((al * (x - mu[:, None]) ** 2).sum(1)).clamp(min=1e-12))
+    m0 = x.mean(1)
+    s0 = torch.sqrt((((x - m0[:, None]) ** 2).mean(1)).clamp(min=1e-12))
+    dp, ds = torch.randn(B, 2 * Cc, generator=g, dtype=torch.float64), torch.randn(B, 2 * Cc, generator=g, dtype=torch.float64)
+    (torch.cat([mu, sd], 1) * dp).sum().backward(retain_graph=True)
+    gx_attn, ge = x.grad.clone(), e.grad.clone()
+    x.grad = None
+    (torch.cat([m0, s0], 1) * ds).sum().backward()
+    gx_stats = x.grad.clone()
+    xd = x.detach().float().reshape(B * T, Cc).cuda().requires_grad_()
+    ed = e.detach().float().reshape(B * T, Cc).cuda().requires_grad_()
+    pooled = AttnStats.apply(ed, xd, B, T)
+    assert rel(pooled, torch.cat([mu, sd], 1).detach()) < 2e-6
+    pooled.backward(dp.float().cuda())
+    assert rel(ed.grad.reshape(B, T, Cc), ge) < 2e-5 and rel(xd.grad.reshape(B, T, Cc), gx_attn) < 2e-5
+    xd2 = x.detach().float().reshape(B * T, Cc).cuda().requires_grad_()
+    st = TimeStats.apply(xd2, B, T)
+    assert rel(st, torch.cat([m0, s0], 1).detach()) < 2e-6
+    st.backward(ds.float().cuda())
+    assert rel(xd2.grad.reshape(B, T, Cc), gx_stats) < 2e-5
+    # BatchNorm1D on (B, C) rows
+    v = torch.randn(16, 64, generator=g, dtype=torch.float64, requires_grad=True)
+    ga = (torch.rand(64, generator=g, dtype=torch.float64) + 0.5).requires_grad_()
+    be = torch.randn(64, generator=g, dtype=torch.float64, requires_grad=True)
+    yv = (v - v.mean(0)) / torch.sqrt(v.var(0, unbiased=False) + 1e-5) * ga + be
+    dv = torch.randn(16, 64, generator=g, dtype=torch.float64)
+    yv.backward(dv)
+    vd, gd, hd = (t.detach().float().cuda().requires_grad_() for t in (v, ga, be))
+    rm, rv = torch.zeros(64, device='cuda'), torch.ones(64, device='cuda')
+    yo = BNRows.apply(vd, gd, hd, rm, rv, 0.9, 1e-5)
+    yo.backward(dv.float().cuda())
+    assert rel(yo, yv.detach()) < 2e-6 and rel(vd.grad, v.grad) < 2e-5 and rel(gd.grad, ga.grad) < 2e-5 and rel(hd.grad, be.grad) < 2e-5
+
+
+@pytest.mark.parametrize('cfg', [(0.2, 0.0, False), (0.3, 0.1, False), (0.2, 0.0, True), (0.0, 0.0, False)])
+def test_head_loss_grads_vs_autograd(N, cfg):
+    from ppvector.train.functions import HeadLoss
+    margin, ls, easy = cfg
+    B, D, Cc = 24, 192, 500
+    g = torch.Generator().manual_seed(3)
+    emb = torch.randn(B, D, generator=g, dtype=torch.float64, requires_grad=True)
+    W = torch.randn(D, Cc, generator=g, dtype=torch.float64, requires_grad=True)
+    labels = torch.randint(0, Cc, (B,), generator=g)
+    loss = om.aam_loss(om.cosine_head(emb, W), labels, margin, 32.0, easy, ls)
+    loss.backward()
+    ed, Wd = emb.detach().float().cuda().requires_grad_(), W.detach().float().cuda().requires_grad_()
+    lo = HeadLoss.apply(ed, Wd, labels.cuda(), margin, 32.0, ls, easy)
+    (lo * 1.0).backward()
+    assert abs(lo.item() - loss.item()) < 1e-4 * max(1.0, abs(loss.item()))
+    assert rel(ed.grad, emb.grad) < 5e-5 and rel(Wd.grad, W.grad) < 5e-5
+
+
+def test_adam_matches_formula(N):
+    from ppvector.optimizer.adam import Adam
+    g = torch.Generator().manual_seed(9)
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g).cuda()) for s in ((7, 5), (33,), (4, 3, 2))]
+    ref = [p.detach().double().cpu().clone() for p in ps]
+    m = [torch.zeros_like(r) for r in ref]
+    v = [torch.zeros_like(r) for r in ref]
+    opt = Adam(ps, learning_rate=1e-2, weight_decay=1e-3)
+    for t in range(1, 4):
+        opt.clear_grad()
+        grads = [torch.randn(p.shape, generator=g) for p in ps]
+        for p, gr in zip(ps, grads):
+            p.grad.copy_(gr.cuda())
+        opt.step()
+        for i, gr in enumerate(grads):
+            gg = gr.double() + 1e-3 * ref[i]
+            m[i] = 0.9 * m[i] + 0.1 * gg
+            v[i] = 0.999 * v[i] + 0.001 * gg * gg
+            ref[i] = ref[i] - 1e-2 * (m[i] / (1 - 0.9 ** t)) / (torch.sqrt(v[i] / (1 - 0.999 ** t)) + 1e-8)
+    for p, r in zip(ps, ref):
+        assert rel(p.detach(), r) < 1e-6
+
+
+def test_tdnn_training_step_vs_oracle_autograd(N):
+    """Whole training step of configs/tdnn.yml's model: loss, every parameter gradient and the running statistics
+    against autograd over the oracle graph (train-mode BatchNorm), then one Adam step."""
+    from ppvector.models.fc import SpeakerIdentification
+    from ppvector.models.tdnn import TDNN
+    from ppvector.optimizer.adam import Adam
+    from ppvector.train.functions import HeadLoss
+    B, T, Cc = 6, 70, 40
+    p = om.tdnn_params(80, seed=11)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, T, 80, generator=g) * 2
+    labels = torch.randint(0, Cc, (B,), generator=g)
+    Wh = om.head_params(192, Cc, seed=4)
+    pr = {k: v.clone().double().requires_grad_(v.dtype.is_floating_point and not k.endswith(('_mean', '_variance'))) for k, v in p.items()}
+    Wr = Wh.clone().double().requires_grad_()
+    stats = {}
+    emb_ref = om.tdnn_forward(pr, x.double(), training=True, stats_out=stats)
+    loss_ref = om.aam_loss(om.cosine_head(emb_ref, Wr), labels, 0.2, 32.0, False, 0.0)
+    loss_ref.backward()
+    m = TDNN(80)
+    m.load_state_dict(p)
+    m = m.cuda().train()
+    head = SpeakerIdentification(192, Cc).cuda()
+    with torch.no_grad():
+        head.weight.copy_(Wh.cuda())
+    emb = m(x.cuda())
+    assert rel(emb, emb_ref.detach()) < 2e-5
+    loss = HeadLoss.apply(emb, head.weight, labels.cuda(), 0.2, 32.0, 0.0, False)
+    assert abs(loss.item() - loss_ref.item()) < 2e-4 * abs(loss_ref.item())
+    loss.backward()
+    worst = 0.0
+    for k, v in m.named_parameters():
+        if pr[k].grad.norm().item() < 1e-9:        # softmax over time ignores its logits' bias: the true gradient is 0
+            assert v.grad.abs().max().item() < 1e-5, k
+            continue
+        r = rel(v.grad, pr[k].grad)
+        worst = max(worst, r)
+        assert r < 5e-4, (k, r)
+    assert rel(head.weight.grad, Wr.grad) < 5e-4
+    print(f'[tdnn train] loss {loss.item():.5f} (oracle {loss_ref.item():.5f}); worst parameter-gradient rel-L2 {worst:.2e}')
+    mean1, var1 = stats['bn1.']
+    assert rel(m.bn1._mean, 0.9 * p['bn1._mean'] + 0.1 * mean1) < 1e-5
+    assert rel(m.bn1._variance, 0.9 * p['bn1._variance'] + 0.1 * var1) < 1e-5
+    opt = Adam(list(m.parameters()) + list(head.parameters()), learning_rate=1e-3, weight_decay=1e-6)
+    before = m.td_layer1.weight.detach().clone()
+    opt.step()
+    assert (m.td_layer1.weight.detach() - before).abs().max().item() > 0
+    m.eval()
+    with torch.no_grad():
+        assert torch.isfinite(m(x.cuda())).all()

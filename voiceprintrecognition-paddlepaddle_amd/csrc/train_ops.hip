@@ -1,0 +1,463 @@
+// Training-side kernels (f32 engine): conv weight gradient, BatchNorm with batch statistics (forward finalise /
+// apply, backward reduce / apply with the ReLU mask), column sums, Adam.
+//
+// Reference: what paddle's autograd + optimiser run for PPVectorTrainer.__train_epoch (ppvector/trainer.py:202-274):
+// Conv1D backward (models/utils.py:65-93 layers), BatchNorm1D in train mode (utils.py:96-119: batch statistics over
+// (B, T); running = 0.9 running + 0.1 batch), ReLU, and Adam with coupled L2 (optimizer/__init__.py:12-18,
+// configs/*.yml weight_decay 1e-6).  Activations are position-major (M = B*T rows, C contiguous) like everywhere else;
+// every reduction is two-stage and fixed-order (no atomics): results are bit-reproducible run to run.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------- conv weight gradient
+// dW[n][j*Cin + c] = sum_{b,t} dz[b, t, n] * x[b, src(t, j), c],  src = the forward's tap index (reflect / zero / none).
+// One workgroup = a 64 (n) x 64 (k-column) tile of dW over a slice of the rows; 4 waves of 32 x 32; v_mfma_f32_16x16x4_f32
+// with dz^T as the A operand and the shifted x rows as B -- both operands are read row-wise (16 lanes = 64 contiguous
+// bytes), the reduction dimension (rows) is the MFMA k.  Partials [S][Cout][K] are summed by wgrad_reduce_kernel.
+struct WgradArgs {
+    const float* x; const float* dz; float* part;
+    int ldx, xoff, lddz, M, N, K, Cin, T_in, T_out, dilation, stride, pad_left, pad_mode, rows_per_split;
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = lane & 15, kk = lane >> 4;
+    const int wn = wv & 1, wk = wv >> 1;
+    const int n0 = blockIdx.y * 64 + wn * 32, k0 = blockIdx.x * 64 + wk * 32;
+    const int m_begin = blockIdx.z * a.rows_per_split;
+    const int m_end = min(a.M, m_begin + a.rows_per_split);
+    int nidx[2], kc[2], tapoff[2], ccol[2];
+    bool nok[2], kok[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        nidx[q] = n0 + q * 16 + i; nok[q] = nidx[q] < a.N;
+        kc[q] = k0 + q * 16 + i; kok[q] = kc[q] < a.K;
+        const int j = kok[q] ? kc[q] / a.Cin : 0;
+        ccol[q] = kok[q] ? kc[q] - j * a.Cin : 0;
+        tapoff[q] = j * a.dilation - a.pad_left;
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int m = m_begin + kk;                       // this lane's row of the current 4-row step
+    int b = m / a.T_out, t = m - b * a.T_out;
+    for (int ms = m_begin; ms < m_end; ms += 4) {
+        const bool rok = m < m_end;
+        float av[2], bv[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            av[q] = (rok && nok[q]) ? a.dz[(size_t)m * a.lddz + nidx[q]] : 0.f;
+            const int traw = t * a.stride + tapoff[q];
+            int ts = traw;
+            bool ok = rok && kok[q];
+            if (a.pad_mode == VP_PAD_REFLECT) {
+                ts = ts < 0 ? -ts : ts;
+                ts = ts >= a.T_in ? 2 * (a.T_in - 1) - ts : ts;
+            } else {
+                ok = ok && traw >= 0 && traw < a.T_in;
+                ts = ok ? ts : 0;
+            }
+            bv[q] = ok ? a.x[((size_t)b * a.T_in + ts) * a.ldx + a.xoff + ccol[q]] : 0.f;
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[p], bv[q], acc[p][q], 0, 0, 0);
+        m += 4; t += 4;
+        while (t >= a.T_out) { t -= a.T_out; ++b; }
+    }
+    float* out = a.part + (size_t)blockIdx.z * a.N * a.K;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int col = k0 + q * 16 + i;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + p * 16 + kk * 4 + r;
+                if (n < a.N && col < a.K) out[(size_t)n * a.K + col] = acc[p][q][r];
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* part, int S, long long n, float* out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += part[(size_t)k * n + i];
+    out[i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------- column sums over rows
+// part[chunk][which][c]: which 0 = sum_m a[m][c], 1 = sum_m a[m][c] * (b[m][c] - bmean[c]) * bscale[c]  (second only when b)
+struct ColSumArgs { const float* a; const float* b; const float* bmean; const float* bscale; float* part; int lda, ldb, M, C, rows_per_chunk; };
+
+__global__ __launch_bounds__(256) void col_sums_kernel(ColSumArgs p) {
+    __shared__ float sm[2][4][64];
+    const int lc = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lc;
+    const int m0 = blockIdx.y * p.rows_per_chunk, m1 = min(p.M, m0 + p.rows_per_chunk);
+    float s1 = 0.f, s2 = 0.f;
+    if (c < p.C) {
+        const float mu = p.b ? p.bmean[c] : 0.f, sc = p.b ? p.bscale[c] : 0.f;
+        for (int m = m0 + rg; m < m1; m += 4) {
+            const float av = p.a[(size_t)m * p.lda + c];
+            s1 += av;
+            if (p.b) s2 += av * (p.b[(size_t)m * p.ldb + c] - mu) * sc;
+        }
+    }
+    sm[0][rg][lc] = s1; sm[1][rg][lc] = s2;
+    __syncthreads();
+    if (rg == 0 && c < p.C) {
+        float* o = p.part + (size_t)blockIdx.y * 2 * p.C;
+        o[c] = sm[0][0][lc] + sm[0][1][lc] + sm[0][2][lc] + sm[0][3][lc];
+        o[p.C + c] = sm[1][0][lc] + sm[1][1][lc] + sm[1][2][lc] + sm[1][3][lc];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- BatchNorm, batch statistics
+// from the producing conv's fused sums: mean / biased variance over all M rows, the folded affine for the apply pass,
+// the saved mean / inverse std for backward, and the running statistics (Paddle: running = mom * running + (1 - mom) * batch).
+struct BnFinArgs {
+    const float* psum; const float* psumsq; int nparts; int M, C;
+    const float* gamma; const float* beta; float* run_mean; float* run_var; float momentum, eps;
+    float* mean; float* invstd; float* scale; float* shift;
+};
+
+__global__ __launch_bounds__(256) void bn_train_finalize_kernel(BnFinArgs a) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= a.C) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < a.nparts; ++k) { s1 += a.psum[(size_t)k * a.C + c]; s2 += a.psumsq[(size_t)k * a.C + c]; }
+    const float mu = s1 / (float)a.M;
+    const float var = fmaxf(s2 / (float)a.M - mu * mu, 0.f);
+    const float is = rsqrtf(var + a.eps);
+    a.mean[c] = mu; a.invstd[c] = is;
+    const float g = a.gamma ? a.gamma[c] : 1.f, be = a.beta ? a.beta[c] : 0.f;
+    a.scale[c] = g * is;
+    a.shift[c] = be - mu * g * is;
+    if (a.run_mean) a.run_mean[c] = a.momentum * a.run_mean[c] + (1.f - a.momentum) * mu;
+    if (a.run_var) a.run_var[c] = a.momentum * a.run_var[c] + (1.f - a.momentum) * var;
+}
+
+// y = z * scale + shift
+__global__ __launch_bounds__(256) void affine_rows_kernel(const float* z, int ldz, const float* scale, const float* shift, long long M,
+                                                          int C4, float* y, int ldy) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < M * C4; i += (long long)gridDim.x * 256) {
+        const long long m = i / C4;
+        const int c = (int)(i - m * C4) * 4;
+        float v[4], s[4], h[4];
+        vp_load4(z + m * ldz + c, v); vp_load4(scale + c, s); vp_load4(shift + c, h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * s[e] + h[e];
+        vp_store4(y + m * ldy + c, v);
+    }
+}
+
+// dz = [z > 0] * gamma * invstd * (dy - sum_dy / M - zhat * sum_dy_zhat / M),  zhat = (z - mean) * invstd
+// (BatchNorm backward through y = BN(z), then the ReLU that produced z; relu_mask = 0 skips the mask)
+struct BnBwdArgs {
+    const float* dy; const float* z; const float* mean; const float* invstd; const float* gamma; const float* sums;   // sums [2][C]
+    float* dz; int lddy, ldz, lddz, C4, relu_mask; long long M;
+};
+
+__global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdArgs a) {
+    const float invM = 1.f / (float)a.M;
+    const int C = a.C4 * 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.M * a.C4; i += (long long)gridDim.x * 256) {
+        const long long m = i / a.C4;
+        const int c = (int)(i - m * a.C4) * 4;
+        float dy[4], z[4], mu[4], is[4], g[4], s1[4], s2[4], o[4];
+        vp_load4(a.dy + m * a.lddy + c, dy); vp_load4(a.z + m * a.ldz + c, z);
+        vp_load4(a.mean + c, mu); vp_load4(a.invstd + c, is); vp_load4(a.sums + c, s1); vp_load4(a.sums + C + c, s2);
+        if (a.gamma) vp_load4(a.gamma + c, g); else { g[0] = g[1] = g[2] = g[3] = 1.f; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float zh = (z[e] - mu[e]) * is[e];
+            const float v = g[e] * is[e] * (dy[e] - s1[e] * invM - zh * s2[e] * invM);
+            o[e] = (a.relu_mask && !(z[e] > 0.f)) ? 0.f : v;
+        }
+        vp_store4(a.dz + m * a.lddz + c, o);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- Adam (coupled L2)
+// paddle.optimizer.Adam(weight_decay=L2Decay-style float): g += wd * p;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+// p -= lr * (m / (1 - b1^t)) / (sqrt(v / (1 - b2^t)) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2,
+                                                   float eps, float wd, float c1, float c2, float gscale) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float pv = p[i];
+        const float gr = g[i] * gscale + wd * pv;
+        const float mn = b1 * m[i] + (1.f - b1) * gr;
+        const float vn = b2 * v[i] + (1.f - b2) * gr * gr;
+        m[i] = mn; v[i] = vn;
+        p[i] = pv - lr * (mn / c1) / (sqrtf(vn / c2) + eps);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- per-utterance pieces (ASP)
+// out[b][c] = sum_t a[b, t, c]   (gradient of a per-utterance bias; one workgroup = 64 channels of one utterance)
+__global__ __launch_bounds__(256) void utt_sums_kernel(const float* a, int lda, int T, int C, float* out) {
+    __shared__ float sm[4][64];
+    const int lc = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int b = blockIdx.y, c = blockIdx.x * 64 + lc;
+    float s = 0.f;
+    if (c < C)
+        for (int t = rg; t < T; t += 4) s += a[((size_t)b * T + t) * lda + c];
+    sm[rg][lc] = s;
+    __syncthreads();
+    if (rg == 0 && c < C) out[(size_t)b * C + c] = sm[0][lc] + sm[1][lc] + sm[2][lc] + sm[3][lc];
+}
+
+// Backward of stats[b] = [mean_t x | sqrt(max(var_biased_t x, eps))] (pooling.py:97-104 with a mask of ones):
+// dx[b,t,c] = dmean / T + [var > eps] * dstd / std * (x - mean) / T
+struct TsBwdArgs { const float* x; const float* stats; const float* dstats; float* dx; int ldx, lddx, T, C4; float eps; long long total; };
+__global__ __launch_bounds__(256) void time_stats_bwd_kernel(TsBwdArgs a) {
+    const int C = a.C4 * 4;
+    const float invT = 1.f / (float)a.T;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.total; i += (long long)gridDim.x * 256) {
+        const long long m = i / a.C4;
+        const int c = (int)(i - m * a.C4) * 4;
+        const long long b = m / a.T;
+        float x[4], mu[4], sd[4], dm[4], ds[4], o[4];
+        vp_load4(a.x + m * a.ldx + c, x);
+        vp_load4(a.stats + b * 2 * C + c, mu); vp_load4(a.stats + b * 2 * C + C + c, sd);
+        vp_load4(a.dstats + b * 2 * C + c, dm); vp_load4(a.dstats + b * 2 * C + C + c, ds);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            o[e] = dm[e] * invT + ((sd[e] * sd[e] > a.eps) ? ds[e] / sd[e] * (x[e] - mu[e]) * invT : 0.f);
+        vp_store4(a.dx + m * a.lddx + c, o);
+    }
+}
+
+// Backward of attentive statistics (pooling.py:114-123): alpha = softmax_t(e), mu = sum alpha x, sd = sqrt(max(sum alpha (x-mu)^2, eps)).
+//   dv = [sd^2 > eps] dsd / (2 sd);  dalpha_t = dmu x_t + dv (x_t - mu)^2;  S = sum_t alpha_t dalpha_t
+//   de_t = alpha_t (dalpha_t - S);   dx_t = alpha_t (dmu + 2 dv (x_t - mu))
+// One workgroup = 64 channels of one utterance, three passes over its frames (max; normaliser and S; outputs).
+struct AsBwdArgs { const float* e; const float* x; const float* pooled; const float* dpooled; float* de; float* dx; int ldx, lddx, T, C; float eps; };
+__global__ __launch_bounds__(256) void attn_stats_bwd_kernel(AsBwdArgs a) {
+    __shared__ float sm[2][4][64];
+    const int lc = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int b = blockIdx.y, c = blockIdx.x * 64 + lc;
+    const bool ok = c < a.C;
+    const int cc = ok ? c : 0;
+    const float* eb = a.e + (size_t)b * a.T * a.C + cc;
+    const float* xb = a.x + (size_t)b * a.T * a.ldx + cc;
+    const float mu = a.pooled[(size_t)b * 2 * a.C + cc], sd = a.pooled[(size_t)b * 2 * a.C + a.C + cc];
+    const float dmu = a.dpooled[(size_t)b * 2 * a.C + cc], dsd = a.dpooled[(size_t)b * 2 * a.C + a.C + cc];
+    const float dv = (sd * sd > a.eps) ? dsd / (2.f * sd) : 0.f;
+    float mx = -INFINITY;
+    for (int t = rg; t < a.T; t += 4) mx = fmaxf(mx, eb[(size_t)t * a.C]);
+    sm[0][rg][lc] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(sm[0][0][lc], sm[0][1][lc]), fmaxf(sm[0][2][lc], sm[0][3][lc]));
+    __syncthreads();
+    float z = 0.f, u = 0.f;
+    for (int t = rg; t < a.T; t += 4) {
+        const float p = expf(eb[(size_t)t * a.C] - mx);
+        const float xv = xb[(size_t)t * a.ldx], d = xv - mu;
+        z += p; u += p * (dmu * xv + dv * d * d);
+    }
+    sm[0][rg][lc] = z; sm[1][rg][lc] = u;
+    __syncthreads();
+    z = sm[0][0][lc] + sm[0][1][lc] + sm[0][2][lc] + sm[0][3][lc];
+    u = sm[1][0][lc] + sm[1][1][lc] + sm[1][2][lc] + sm[1][3][lc];
+    const float S = u / z;
+    if (!ok) return;
+    for (int t = rg; t < a.T; t += 4) {
+        const float al = expf(eb[(size_t)t * a.C] - mx) / z;
+        const float xv = xb[(size_t)t * a.ldx], d = xv - mu;
+        a.de[((size_t)b * a.T + t) * a.C + c] = al * (dmu * xv + dv * d * d - S);
+        a.dx[((size_t)b * a.T + t) * a.lddx + c] = al * (dmu + 2.f * dv * d);
+    }
+}
+
+// dz = dy * (1 - y^2)   (tanh backward from its output)
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* dy, const float* y, long long n4, float* dz) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float g[4], v[4];
+        vp_load4(dy + i * 4, g); vp_load4(y + i * 4, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] *= 1.f - v[e] * v[e];
+        vp_store4(dz + i * 4, g);
+    }
+}
+__global__ __launch_bounds__(256) void tanh_fwd_kernel(const float* x, long long n4, float* y) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float v[4];
+        vp_load4(x + i * 4, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+        vp_store4(y + i * 4, v);
+    }
+}
+
+unsigned grid1d(long long total) {
+    long long b = (total + 255) / 256;
+    return (unsigned)(b > 256 * 64 ? 256 * 64 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t vp_conv1d_wgrad_workspace_bytes(const vp_conv1d_desc* d) {
+    if (!d || d->Cout <= 0 || d->KW <= 0 || d->Cin <= 0) return 0;
+    const long long M = (long long)d->B * d->T_out;
+    const int K = d->KW * d->Cin;
+    const int tiles = ((d->Cout + 63) / 64) * ((K + 63) / 64);
+    int S = 2048 / tiles;
+    if (S < 1) S = 1;
+    if (S > 256) S = 256;
+    if ((long long)S * 64 > M) S = (int)((M + 63) / 64);
+    return (size_t)S * d->Cout * K * sizeof(float) + 256;
+}
+
+// d: the FORWARD conv's descriptor (x / ldx / xoff and the geometry; w, y, epilogue fields ignored).  dz (B*T_out, lddz) f32.
+int vp_conv1d_wgrad_f32(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int lddz, float* dW, void* ws, size_t ws_bytes,
+                        vp_stream stream) {
+    if (!ctx || !d || !d->x || !dz || !dW) VP_FAIL(ctx, VP_EINVAL, "wgrad: null argument");
+    if (d->dtype_in != VP_F32) VP_FAIL(ctx, VP_EUNSUP, "wgrad: f32 engine only");
+    if (d->KF > 1 || d->F_in > 1 || d->F_out > 1) VP_FAIL(ctx, VP_EUNSUP, "wgrad: 1-D convs only");
+    if (d->B <= 0 || d->T_in <= 0 || d->T_out <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KW <= 0 || d->stride <= 0 || d->dilation <= 0)
+        VP_FAIL(ctx, VP_EINVAL, "wgrad: bad shape");
+    const size_t need = vp_conv1d_wgrad_workspace_bytes(d);
+    if (!ws || ws_bytes < need) VP_FAIL(ctx, VP_EWORKSPACE, "wgrad: workspace %zu < %zu", ws_bytes, need);
+    const long long M = (long long)d->B * d->T_out;
+    if (M > 0x7fffffffLL / 2) VP_FAIL(ctx, VP_EINVAL, "wgrad: too many rows");
+    const int K = d->KW * d->Cin;
+    const int tn = (d->Cout + 63) / 64, tk = (K + 63) / 64;
+    int S = 2048 / (tn * tk);
+    if (S < 1) S = 1;
+    if (S > 256) S = 256;
+    if ((long long)S * 64 > M) S = (int)((M + 63) / 64);
+    int rps = (int)((M + S - 1) / S);
+    rps = (rps + 3) / 4 * 4;
+    S = (int)((M + rps - 1) / rps);
+    WgradArgs a;
+    a.x = (const float*)d->x; a.dz = dz; a.part = (float*)ws;
+    a.ldx = d->ldx; a.xoff = d->xoff; a.lddz = lddz; a.M = (int)M; a.N = d->Cout; a.K = K; a.Cin = d->Cin;
+    a.T_in = d->T_in; a.T_out = d->T_out; a.dilation = d->dilation; a.stride = d->stride; a.pad_left = d->pad_left;
+    a.pad_mode = d->pad_mode; a.rows_per_split = rps;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tk, tn, S), dim3(256), 0, st, a);
+    VP_LAUNCH_CHECK(ctx, "conv_wgrad");
+    const long long n = (long long)d->Cout * K;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)ws, S, n, dW);
+    VP_LAUNCH_CHECK(ctx, "wgrad_reduce");
+    return VP_OK;
+}
+
+size_t vp_col_sums_workspace_bytes(long long M, int C) {
+    long long chunks = (M + 511) / 512;
+    if (chunks > 1024) chunks = 1024;
+    return (size_t)chunks * 2 * C * sizeof(float) + 256;
+}
+
+// sums [2][C]: sum_m a[m][c] and (when b) sum_m a[m][c] * (b[m][c] - bmean[c]) * bscale[c]
+int vp_col_sums_f32(vp_ctx* ctx, const float* a, int lda, const float* b, int ldb, const float* bmean, const float* bscale,
+                    long long M, int C, float* sums, void* ws, size_t ws_bytes, vp_stream stream) {
+    if (!ctx || !a || !sums || M <= 0 || C <= 0 || (b && (!bmean || !bscale))) VP_FAIL(ctx, VP_EINVAL, "col_sums: bad arguments");
+    if (!ws || ws_bytes < vp_col_sums_workspace_bytes(M, C)) VP_FAIL(ctx, VP_EWORKSPACE, "col_sums: workspace too small");
+    long long chunks = (M + 511) / 512;
+    if (chunks > 1024) chunks = 1024;
+    const int rpc = (int)((M + chunks - 1) / chunks);
+    chunks = (M + rpc - 1) / rpc;
+    ColSumArgs p{a, b, bmean, bscale, (float*)ws, lda, ldb, (int)M, C, rpc};
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(col_sums_kernel, dim3((C + 63) / 64, (unsigned)chunks), dim3(256), 0, st, p);
+    VP_LAUNCH_CHECK(ctx, "col_sums");
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, (const float*)ws, (int)chunks, (long long)2 * C, sums);
+    VP_LAUNCH_CHECK(ctx, "col_sums_reduce");
+    return VP_OK;
+}
+
+int vp_bn_train_finalize(vp_ctx* ctx, const float* psum, const float* psumsq, int nparts, long long M, int C, const float* gamma,
+                         const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                         float* invstd, float* scale, float* shift, vp_stream stream) {
+    if (!ctx || !psum || !psumsq || nparts <= 0 || M <= 0 || C <= 0 || !mean || !invstd || !scale || !shift)
+        VP_FAIL(ctx, VP_EINVAL, "bn_finalize: bad arguments");
+    BnFinArgs a{psum, psumsq, nparts, (int)M, C, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift};
+    hipLaunchKernelGGL(bn_train_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    VP_LAUNCH_CHECK(ctx, "bn_train_finalize");
+    return VP_OK;
+}
+
+int vp_affine_rows_f32(vp_ctx* ctx, const float* z, int ldz, const float* scale, const float* shift, long long M, int C, float* y,
+                       int ldy, vp_stream stream) {
+    if (!ctx || !z || !scale || !shift || !y || M <= 0 || C <= 0 || (C | ldz | ldy) & 3) VP_FAIL(ctx, VP_EINVAL, "affine_rows: bad arguments");
+    hipLaunchKernelGGL(affine_rows_kernel, dim3(grid1d(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, z, ldz, scale, shift, M, C / 4, y, ldy);
+    VP_LAUNCH_CHECK(ctx, "affine_rows");
+    return VP_OK;
+}
+
+int vp_bn_relu_bwd_f32(vp_ctx* ctx, const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* invstd,
+                       const float* gamma, const float* sums, long long M, int C, int relu_mask, float* dz, int lddz,
+                       vp_stream stream) {
+    if (!ctx || !dy || !z || !mean || !invstd || !sums || !dz || M <= 0 || C <= 0 || (C | lddy | ldz | lddz) & 3)
+        VP_FAIL(ctx, VP_EINVAL, "bn_relu_bwd: bad arguments");
+    BnBwdArgs a{dy, z, mean, invstd, gamma, sums, dz, lddy, ldz, lddz, C / 4, relu_mask, M};
+    hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(grid1d(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
+    VP_LAUNCH_CHECK(ctx, "bn_relu_bwd");
+    return VP_OK;
+}
+
+int vp_adam_step_f32(vp_ctx* ctx, float* param, const float* grad, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int step, float grad_scale, vp_stream stream) {
+    if (!ctx || !param || !grad || !m || !v || n <= 0 || step < 1) VP_FAIL(ctx, VP_EINVAL, "adam: bad arguments");
+    const float c1 = 1.f - powf(beta1, (float)step), c2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, lr, beta1, beta2, eps,
+                       weight_decay, c1, c2, grad_scale);
+    VP_LAUNCH_CHECK(ctx, "adam");
+    return VP_OK;
+}
+
+int vp_utt_sums_f32(vp_ctx* ctx, const float* a, int lda, int B, int T, int C, float* out, vp_stream stream) {
+    if (!ctx || !a || !out || B <= 0 || T <= 0 || C <= 0 || B > 65535) VP_FAIL(ctx, VP_EINVAL, "utt_sums: bad arguments");
+    hipLaunchKernelGGL(utt_sums_kernel, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, a, lda, T, C, out);
+    VP_LAUNCH_CHECK(ctx, "utt_sums");
+    return VP_OK;
+}
+
+int vp_time_stats_f32(vp_ctx* ctx, const float* x, int ldx, int B, int T, int C, float eps, float* stats, vp_stream stream) {
+    if (!ctx || !x || !stats || B <= 0 || T <= 0 || C <= 0) VP_FAIL(ctx, VP_EINVAL, "time_stats: bad arguments");
+    return vp_time_moments(ctx, VP_F32, x, ldx, B, T, C, eps, 0, stats, (hipStream_t)stream);
+}
+
+int vp_time_stats_bwd_f32(vp_ctx* ctx, const float* x, int ldx, const float* stats, const float* dstats, int B, int T, int C, float eps,
+                          float* dx, int lddx, vp_stream stream) {
+    if (!ctx || !x || !stats || !dstats || !dx || B <= 0 || T <= 0 || C <= 0 || (C | ldx | lddx) & 3) VP_FAIL(ctx, VP_EINVAL, "time_stats_bwd: bad arguments");
+    TsBwdArgs a{x, stats, dstats, dx, ldx, lddx, T, C / 4, eps, (long long)B * T * (C / 4)};
+    hipLaunchKernelGGL(time_stats_bwd_kernel, dim3(grid1d(a.total)), dim3(256), 0, (hipStream_t)stream, a);
+    VP_LAUNCH_CHECK(ctx, "time_stats_bwd");
+    return VP_OK;
+}
+
+int vp_attn_stats_bwd_f32(vp_ctx* ctx, const float* e, const float* x, int ldx, const float* pooled, const float* dpooled, int B, int T,
+                          int C, float eps, float* de, float* dx, int lddx, vp_stream stream) {
+    if (!ctx || !e || !x || !pooled || !dpooled || !de || !dx || B <= 0 || T <= 0 || C <= 0 || B > 65535) VP_FAIL(ctx, VP_EINVAL, "attn_stats_bwd: bad arguments");
+    AsBwdArgs a{e, x, pooled, dpooled, de, dx, ldx, lddx, T, C, eps};
+    hipLaunchKernelGGL(attn_stats_bwd_kernel, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, a);
+    VP_LAUNCH_CHECK(ctx, "attn_stats_bwd");
+    return VP_OK;
+}
+
+int vp_tanh_f32(vp_ctx* ctx, const float* x, long long n, float* y, vp_stream stream) {
+    if (!ctx || !x || !y || n <= 0 || n & 3) VP_FAIL(ctx, VP_EINVAL, "tanh: bad arguments");
+    hipLaunchKernelGGL(tanh_fwd_kernel, dim3(grid1d(n / 4)), dim3(256), 0, (hipStream_t)stream, x, n / 4, y);
+    VP_LAUNCH_CHECK(ctx, "tanh");
+    return VP_OK;
+}
+
+int vp_tanh_bwd_f32(vp_ctx* ctx, const float* dy, const float* y, long long n, float* dz, vp_stream stream) {
+    if (!ctx || !dy || !y || !dz || n <= 0 || n & 3) VP_FAIL(ctx, VP_EINVAL, "tanh_bwd: bad arguments");
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid1d(n / 4)), dim3(256), 0, (hipStream_t)stream, dy, y, n / 4, dz);
+    VP_LAUNCH_CHECK(ctx, "tanh_bwd");
+    return VP_OK;
+}
+
+}  // extern "C"

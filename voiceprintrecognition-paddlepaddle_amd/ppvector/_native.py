@@ -192,6 +192,28 @@ _PROTOS = {
     'vp_cosine_aam_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'vp_cosine_aam_ce_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float,
                                      c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'vp_cosine_aam_ce_bwd_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'vp_cosine_aam_ce_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_int,
+                                     c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'vp_conv1d_wgrad_workspace_bytes': (c_size_t, [C.POINTER(Conv1dDesc)]),
+    'vp_conv1d_wgrad_f32': (c_int, [c_void_p, C.POINTER(Conv1dDesc), c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'vp_col_sums_workspace_bytes': (c_size_t, [C.c_longlong, c_int]),
+    'vp_col_sums_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, C.c_longlong, c_int, c_void_p,
+                                c_void_p, c_size_t, c_void_p]),
+    'vp_bn_train_finalize': (c_int, [c_void_p, c_void_p, c_void_p, c_int, C.c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'vp_affine_rows_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, C.c_longlong, c_int, c_void_p, c_int, c_void_p]),
+    'vp_bn_relu_bwd_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, C.c_longlong,
+                                   c_int, c_int, c_void_p, c_int, c_void_p]),
+    'vp_adam_step_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_longlong, c_float, c_float, c_float, c_float,
+                                 c_float, c_int, c_float, c_void_p]),
+    'vp_utt_sums_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'vp_time_stats_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    'vp_time_stats_bwd_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
+    'vp_attn_stats_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
+                                      c_void_p, c_int, c_void_p]),
+    'vp_tanh_f32': (c_int, [c_void_p, c_void_p, C.c_longlong, c_void_p, c_void_p]),
+    'vp_tanh_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, C.c_longlong, c_void_p, c_void_p]),
     'vp_cosine_scores_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'vp_cosine_scores_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                      c_size_t, c_void_p]),

@@ -396,7 +396,10 @@ class EngineMixin:
             raise NotImplementedError('lengths= is never passed by the reference entry points (trainer.py:210); '
                                       'the masked branches are not built')
         if self.training:
-            raise NotImplementedError('training-mode (batch-statistics) forward/backward on the HIP engine is the '
-                                      'next scope row (DESIGN.md); call .eval() for embedding extraction')
+            fwd = getattr(self, '_train_forward', None)
+            if fwd is None:
+                raise NotImplementedError('training-mode (batch-statistics) forward/backward on the HIP engine is built for TDNN '
+                                          'only so far (DESIGN.md section 0, row a25); call .eval() for embedding extraction')
+            return fwd(x)
         with torch.no_grad():
             return self.engine().forward(x)

@@ -50,3 +50,11 @@ class TDNN(EngineMixin, nn.Module):
             raise NotImplementedError(f'pooling_type {pooling_type} is not built on the HIP engine (ASP is)')
         else:
             raise Exception(f'没有{pooling_type}池化层！')
+
+    def _train_forward(self, x):
+        """Training mode: batch-statistics BatchNorm, autograd through libvpmi's backward entry points (f32 engine)."""
+        from ppvector.train.tdnn_train import tdnn_forward_train
+        if not x.is_cuda:
+            from ppvector import _native as N
+            raise N.VpmiError('model input must be a GPU tensor: the engine has no CPU fallback')
+        return tdnn_forward_train(self, x.float().contiguous())

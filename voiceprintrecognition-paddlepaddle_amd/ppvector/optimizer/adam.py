@@ -1,0 +1,60 @@
+"""Adam with coupled L2 on the MI355X engine (paddle.optimizer.Adam(parameters, learning_rate, weight_decay) as built by
+ppvector/optimizer/__init__.py:12-18; configs/*.yml: weight_decay 1e-6).
+
+All parameters live in ONE flat f32 buffer (their .data are views into it) with flat gradient / moment buffers beside
+it: one kernel launch per step (csrc/train_ops.hip: vp_adam_step_f32), and the data-parallel gradient average is one
+all-reduce over the flat gradient buffer (ppvector/train/ddp.py)."""
+import torch
+
+from ppvector import _native as N
+
+
+class Adam:
+    def __init__(self, parameters, learning_rate=1e-3, beta1=0.9, beta2=0.999, epsilon=1e-8, weight_decay=0.0):
+        self.params = [p for p in parameters if p.requires_grad]
+        if not self.params:
+            raise ValueError('Adam: no trainable parameters')
+        dev = self.params[0].device
+        if dev.type != 'cuda':
+            raise N.VpmiError('Adam runs on the GPU: the engine has no CPU fallback')
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + k].view_as(p.data)
+            p.grad = self.grad[off:off + k].view_as(p.data)
+            off += k
+        self.lr = learning_rate
+        self.beta1, self.beta2, self.eps, self.wd = beta1, beta2, epsilon, float(weight_decay or 0.0)
+        self.t = 0
+
+    def get_lr(self):
+        return self.lr() if callable(self.lr) else (self.lr.get_lr() if hasattr(self.lr, 'get_lr') else float(self.lr))
+
+    def clear_grad(self):
+        self.grad.zero_()
+
+    def step(self, grad_scale=1.0):
+        for p in self.params:                      # autograd may have re-bound .grad; gradients must sit in the flat buffer
+            if p.grad is not None and p.grad.data_ptr() != (self.grad.data_ptr() + 4 * self._offset(p)):
+                self.grad[self._offset(p):self._offset(p) + p.numel()].copy_(p.grad.reshape(-1))
+                p.grad = self.grad[self._offset(p):self._offset(p) + p.numel()].view_as(p.data)
+        self.t += 1
+        ctx = N.ctx(self.flat.device)
+        N.check(N.lib().vp_adam_step_f32(ctx, self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                         self.flat.numel(), float(self.get_lr()), self.beta1, self.beta2, self.eps, self.wd, self.t,
+                                         float(grad_scale), N.stream_ptr()), ctx)
+
+    def _offset(self, p):
+        return (p.data.data_ptr() - self.flat.data_ptr()) // 4
+
+    def state_dict(self):
+        return {'m': self.m, 'v': self.v, 't': self.t}
+
+    def set_state_dict(self, sd):
+        self.m.copy_(sd['m']); self.v.copy_(sd['v']); self.t = int(sd['t'])

@@ -1,0 +1,265 @@
+"""torch.autograd.Function wrappers: forward AND backward of each op run in libvpmi (f32 engine).
+
+Activations are position-major 2-D tensors (B*T, C) as everywhere in the engine.  What paddle's autograd provides the
+reference for free (ppvector/trainer.py:213-219: loss.backward()) is spelled out here per op:
+  ConvBlock   conv1d (+ per-utterance bias) (+ ReLU) (+ BatchNorm with batch statistics) (+ tanh)
+              -- Conv1D / TDNNBlock of models/utils.py:22-148 and the Conv1D + ReLU + BatchNorm1D chain of models/tdnn.py:46-60
+  TimeStats   [mean | sqrt(clip(var))] over time       (models/pooling.py:97-104, mask of ones)
+  AttnStats   softmax over time + weighted mean / std   (models/pooling.py:114-123)
+  BNRows      BatchNorm1D on (B, C)                     (models/utils.py:96-119)
+  HeadLoss    cosine classifier + AAM-softmax loss      (models/fc.py:41-53, loss/aamloss.py:28-47)
+"""
+import ctypes as C
+
+import torch
+
+from ppvector import _native as N
+
+_PAD = {'none': N.VP_PAD_NONE, 'zero': N.VP_PAD_ZERO}
+
+
+def _chk(rc, ctx):
+    N.check(rc, ctx)
+
+
+def _bytes(n, dev):
+    return torch.empty(max(int(n), 256), dtype=torch.uint8, device=dev)
+
+
+def _f32c(t):
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise N.VpmiError('training functions take f32 GPU tensors (no CPU fallback)')
+    return t.contiguous()
+
+
+def _conv_desc(x, B, T_in, T_out, Cin, Cout, KW, dil, pad_mode, pad_left, w, bias=None, rowbias=None, relu=False):
+    d = N.Conv1dDesc()
+    d.dtype_in = d.dtype_out = N.VP_F32
+    d.B, d.T_in, d.T_out, d.Cin, d.Cout, d.KW, d.dilation, d.stride = B, T_in, T_out, Cin, Cout, KW, dil, 1
+    d.pad_mode, d.pad_left = pad_mode, pad_left
+    d.x, d.ldx, d.xoff = x.data_ptr(), Cin, 0
+    d.w = w.data_ptr()
+    if bias is not None:
+        d.bias = bias.data_ptr()
+    if rowbias is not None:
+        d.rowbias = rowbias.data_ptr()
+    d.act = N.VP_ACT_RELU if relu else N.VP_ACT_NONE
+    d.ldy = Cout
+    return d
+
+
+def col_sums(a, b=None, bmean=None, bscale=None):
+    """-> (2, C): sum_m a and (when b) sum_m a * (b - bmean) * bscale."""
+    lib, ctx = N.lib(), N.ctx(a.device)
+    M, Cc = a.shape
+    out = torch.empty((2, Cc), dtype=torch.float32, device=a.device)
+    ws = _bytes(lib.vp_col_sums_workspace_bytes(M, Cc), a.device)
+    _chk(lib.vp_col_sums_f32(ctx, a.data_ptr(), Cc, b.data_ptr() if b is not None else None, Cc,
+                             bmean.data_ptr() if b is not None else None, bscale.data_ptr() if b is not None else None,
+                             M, Cc, out.data_ptr(), ws.data_ptr(), ws.numel(), N.stream_ptr()), ctx)
+    return out
+
+
+class ConvBlock(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, rowbias, gamma, beta, run_mean, run_var, cfg):
+        lib, hctx = N.lib(), N.ctx(x.device)
+        x, weight = _f32c(x), _f32c(weight)
+        B, T_in, dil = cfg['B'], cfg['T'], cfg.get('dilation', 1)
+        Cout, Cin, KW = weight.shape
+        pad = cfg.get('pad', 'none')
+        pad_left = 0 if pad == 'none' else dil * (KW - 1) // 2
+        T_out = T_in - dil * (KW - 1) if pad == 'none' else T_in
+        relu, bn, tanh = cfg.get('relu', False), gamma is not None, cfg.get('tanh', False)
+        if x.shape != (B * T_in, Cin) or T_out < 1:
+            raise ValueError(f'ConvBlock: x {tuple(x.shape)} does not match B {B}, T {T_in}, Cin {Cin}')
+        wp = weight.permute(0, 2, 1).reshape(Cout, KW * Cin).contiguous()
+        z = torch.empty((B * T_out, Cout), dtype=torch.float32, device=x.device)
+        d = _conv_desc(x, B, T_in, T_out, Cin, Cout, KW, dil, _PAD[pad], pad_left, wp, bias, rowbias, relu)
+        d.y = z.data_ptr()
+        ps = pq = None
+        if bn:
+            tiles, nseg = lib.vp_conv1d_tiles_m(B, T_out), lib.vp_conv1d_nseg(T_out)
+            ps = torch.empty((tiles * nseg, Cout), dtype=torch.float32, device=x.device)
+            pq = torch.empty_like(ps)
+            d.psum, d.psumsq = ps.data_ptr(), pq.data_ptr()
+        _chk(lib.vp_conv1d_fwd(hctx, C.byref(d), N.stream_ptr()), hctx)
+        mean = invstd = None
+        y = z
+        if bn:
+            mean, invstd, scale, shift = (torch.empty(Cout, dtype=torch.float32, device=x.device) for _ in range(4))
+            _chk(lib.vp_bn_train_finalize(hctx, ps.data_ptr(), pq.data_ptr(), ps.shape[0], B * T_out, Cout, gamma.data_ptr(),
+                                          beta.data_ptr(), run_mean.data_ptr() if run_mean is not None else None,
+                                          run_var.data_ptr() if run_var is not None else None, cfg.get('momentum', 0.9),
+                                          cfg.get('eps', 1e-5), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
+                                          shift.data_ptr(), N.stream_ptr()), hctx)
+            y = torch.empty_like(z)
+            _chk(lib.vp_affine_rows_f32(hctx, z.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(), B * T_out, Cout,
+                                        y.data_ptr(), Cout, N.stream_ptr()), hctx)
+        if tanh:
+            yt = torch.empty_like(y)
+            _chk(lib.vp_tanh_f32(hctx, y.data_ptr(), y.numel(), yt.data_ptr(), N.stream_ptr()), hctx)
+            y = yt
+        ctx.save_for_backward(x, weight, z, mean, invstd, gamma, y if tanh else None)
+        ctx.geom = (B, T_in, T_out, Cin, Cout, KW, dil, pad, pad_left, relu, bn, tanh, bias is not None, rowbias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, z, mean, invstd, gamma, yt = ctx.saved_tensors
+        B, T_in, T_out, Cin, Cout, KW, dil, pad, pad_left, relu, bn, tanh, has_bias, has_rb = ctx.geom
+        lib, hctx = N.lib(), N.ctx(x.device)
+        dev = x.device
+        dy = _f32c(dy)
+        M = B * T_out
+        if tanh:
+            t = torch.empty_like(dy)
+            _chk(lib.vp_tanh_bwd_f32(hctx, dy.data_ptr(), yt.data_ptr(), dy.numel(), t.data_ptr(), N.stream_ptr()), hctx)
+            dy = t
+        dgamma = dbeta = None
+        if bn or relu:
+            if bn:
+                sums = col_sums(dy, z, mean, invstd)
+                dgamma, dbeta = sums[1].clone(), sums[0].clone()
+                mu, istd, g = mean, invstd, gamma
+            else:                                   # ReLU alone: the BN backward formula with identity statistics
+                sums = torch.zeros((2, Cout), dtype=torch.float32, device=dev)
+                mu = torch.zeros(Cout, dtype=torch.float32, device=dev)
+                istd = torch.ones(Cout, dtype=torch.float32, device=dev)
+                g = None
+            dz = torch.empty_like(dy)
+            _chk(lib.vp_bn_relu_bwd_f32(hctx, dy.data_ptr(), Cout, z.data_ptr(), Cout, mu.data_ptr(), istd.data_ptr(),
+                                        g.data_ptr() if g is not None else None, sums.data_ptr(), M, Cout, int(relu),
+                                        dz.data_ptr(), Cout, N.stream_ptr()), hctx)
+        else:
+            dz = dy
+        dbias = col_sums(dz)[0].clone() if has_bias else None
+        drb = None
+        if has_rb:
+            drb = torch.empty((B, Cout), dtype=torch.float32, device=dev)
+            _chk(lib.vp_utt_sums_f32(hctx, dz.data_ptr(), Cout, B, T_out, Cout, drb.data_ptr(), N.stream_ptr()), hctx)
+        # weight gradient
+        d = _conv_desc(x, B, T_in, T_out, Cin, Cout, KW, dil, _PAD[pad], pad_left, weight)
+        dwp = torch.empty((Cout, KW * Cin), dtype=torch.float32, device=dev)
+        ws = _bytes(lib.vp_conv1d_wgrad_workspace_bytes(C.byref(d)), dev)
+        _chk(lib.vp_conv1d_wgrad_f32(hctx, C.byref(d), dz.data_ptr(), Cout, dwp.data_ptr(), ws.data_ptr(), ws.numel(),
+                                     N.stream_ptr()), hctx)
+        dW = dwp.view(Cout, KW, Cin).permute(0, 2, 1).contiguous()
+        # data gradient: the forward kernel over dz with reversed taps and swapped channel roles
+        dx = None
+        if ctx.needs_input_grad[0]:
+            w2 = weight.flip(2).permute(1, 2, 0).reshape(Cin, KW * Cout).contiguous()
+            dx = torch.empty((B * T_in, Cin), dtype=torch.float32, device=dev)
+            d2 = _conv_desc(dz, B, T_out, T_in, Cout, Cin, KW, dil, N.VP_PAD_ZERO, dil * (KW - 1) - pad_left, w2)
+            d2.y = dx.data_ptr()
+            _chk(lib.vp_conv1d_fwd(hctx, C.byref(d2), N.stream_ptr()), hctx)
+        return dx, dW, dbias, drb, dgamma, dbeta, None, None, None
+
+
+class TimeStats(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, B, T):
+        lib, hctx = N.lib(), N.ctx(x.device)
+        x = _f32c(x)
+        Cc = x.shape[1]
+        stats = torch.empty((B, 2 * Cc), dtype=torch.float32, device=x.device)
+        _chk(lib.vp_time_stats_f32(hctx, x.data_ptr(), Cc, B, T, Cc, 1e-12, stats.data_ptr(), N.stream_ptr()), hctx)
+        ctx.save_for_backward(x, stats)
+        ctx.geom = (B, T)
+        return stats
+
+    @staticmethod
+    def backward(ctx, ds):
+        x, stats = ctx.saved_tensors
+        B, T = ctx.geom
+        lib, hctx = N.lib(), N.ctx(x.device)
+        Cc = x.shape[1]
+        dx = torch.empty_like(x)
+        _chk(lib.vp_time_stats_bwd_f32(hctx, x.data_ptr(), Cc, stats.data_ptr(), _f32c(ds).data_ptr(), B, T, Cc, 1e-12,
+                                       dx.data_ptr(), Cc, N.stream_ptr()), hctx)
+        return dx, None, None
+
+
+class AttnStats(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, e, x, B, T):
+        lib, hctx = N.lib(), N.ctx(x.device)
+        e, x = _f32c(e), _f32c(x)
+        Cc = x.shape[1]
+        pooled = torch.empty((B, 2 * Cc), dtype=torch.float32, device=x.device)
+        _chk(lib.vp_asp_softmax_stats(hctx, N.VP_F32, e.data_ptr(), x.data_ptr(), Cc, 0, B, T, Cc, 1e-12, pooled.data_ptr(),
+                                      N.stream_ptr()), hctx)
+        ctx.save_for_backward(e, x, pooled)
+        ctx.geom = (B, T)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dp):
+        e, x, pooled = ctx.saved_tensors
+        B, T = ctx.geom
+        lib, hctx = N.lib(), N.ctx(x.device)
+        Cc = x.shape[1]
+        de, dx = torch.empty_like(e), torch.empty_like(x)
+        _chk(lib.vp_attn_stats_bwd_f32(hctx, e.data_ptr(), x.data_ptr(), Cc, pooled.data_ptr(), _f32c(dp).data_ptr(), B, T, Cc,
+                                       1e-12, de.data_ptr(), dx.data_ptr(), Cc, N.stream_ptr()), hctx)
+        return de, dx, None, None
+
+
+class BNRows(torch.autograd.Function):
+    """BatchNorm1D with batch statistics on a (M, C) tensor."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, run_mean, run_var, momentum, eps):
+        lib, hctx = N.lib(), N.ctx(x.device)
+        x = _f32c(x)
+        M, Cc = x.shape
+        zeros = torch.zeros(Cc, dtype=torch.float32, device=x.device)
+        ones = torch.ones(Cc, dtype=torch.float32, device=x.device)
+        sums = col_sums(x, x, zeros, ones)                     # [sum x | sum x^2]
+        mean, invstd, scale, shift = (torch.empty(Cc, dtype=torch.float32, device=x.device) for _ in range(4))
+        _chk(lib.vp_bn_train_finalize(hctx, sums[0].data_ptr(), sums[1].data_ptr(), 1, M, Cc, gamma.data_ptr(), beta.data_ptr(),
+                                      run_mean.data_ptr() if run_mean is not None else None,
+                                      run_var.data_ptr() if run_var is not None else None, momentum, eps, mean.data_ptr(),
+                                      invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), N.stream_ptr()), hctx)
+        y = torch.empty_like(x)
+        _chk(lib.vp_affine_rows_f32(hctx, x.data_ptr(), Cc, scale.data_ptr(), shift.data_ptr(), M, Cc, y.data_ptr(), Cc,
+                                    N.stream_ptr()), hctx)
+        ctx.save_for_backward(x, mean, invstd, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, invstd, gamma = ctx.saved_tensors
+        lib, hctx = N.lib(), N.ctx(x.device)
+        dy = _f32c(dy)
+        M, Cc = x.shape
+        sums = col_sums(dy, x, mean, invstd)
+        dx = torch.empty_like(x)
+        _chk(lib.vp_bn_relu_bwd_f32(hctx, dy.data_ptr(), Cc, x.data_ptr(), Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                                    sums.data_ptr(), M, Cc, 0, dx.data_ptr(), Cc, N.stream_ptr()), hctx)
+        return dx, sums[1].clone(), sums[0].clone(), None, None, None, None
+
+
+class HeadLoss(torch.autograd.Function):
+    """loss = AAMLoss(cosine_classifier(emb, W), labels); the kernels produce d emb and d W with the forward value."""
+
+    @staticmethod
+    def forward(ctx, emb, W, labels, margin, scale, label_smoothing, easy_margin):
+        lib, hctx = N.lib(), N.ctx(emb.device)
+        emb, W = _f32c(emb), _f32c(W)
+        B, D = emb.shape
+        Cc = W.shape[1]
+        demb, dW = torch.empty_like(emb), torch.empty_like(W)
+        loss = torch.empty(1, dtype=torch.float32, device=emb.device)
+        ws = _bytes(lib.vp_cosine_aam_ce_bwd_workspace_bytes(B, D, Cc), emb.device)
+        lab = labels.to(torch.int64).contiguous()
+        _chk(lib.vp_cosine_aam_ce_bwd(hctx, emb.data_ptr(), W.data_ptr(), lab.data_ptr(), B, D, Cc, float(margin), float(scale),
+                                      float(label_smoothing), int(easy_margin), 1.0, demb.data_ptr(), dW.data_ptr(),
+                                      loss.data_ptr(), ws.data_ptr(), ws.numel(), N.stream_ptr()), hctx)
+        ctx.save_for_backward(demb, dW)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        demb, dW = ctx.saved_tensors
+        return demb * g, dW * g, None, None, None, None, None
