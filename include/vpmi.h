@@ -431,15 +431,20 @@ int vp_adam_step_f32(vp_ctx* ctx, float* param, const float* grad, float* m, flo
 
 /* ASP in training (models/pooling.py:69-125): per-utterance sums (gradient of the context bias), the global-context
  * statistics [mean | sqrt(max(var, eps))] and their backward, the backward of softmax-over-time + weighted mean/std
- * (forward = vp_asp_softmax_stats), tanh and its backward.  e (B*T, C) f32 logits, x (B*T, ldx) f32, pooled (B, 2C). */
+ * (forward = vp_asp_softmax_stats), tanh / sigmoid and their backward.  e (B*T, C) f32 logits, x (B*T, ldx) f32, pooled (B, 2C). */
 int vp_utt_sums_f32(vp_ctx* ctx, const float* a, int lda, int B, int T, int C, float* out, vp_stream stream);
 int vp_time_stats_f32(vp_ctx* ctx, const float* x, int ldx, int B, int T, int C, float eps, float* stats, vp_stream stream);
 int vp_time_stats_bwd_f32(vp_ctx* ctx, const float* x, int ldx, const float* stats, const float* dstats, int B, int T, int C, float eps,
                           float* dx, int lddx, vp_stream stream);
 int vp_attn_stats_bwd_f32(vp_ctx* ctx, const float* e, const float* x, int ldx, const float* pooled, const float* dpooled, int B, int T,
                           int C, float eps, float* de, float* dx, int lddx, vp_stream stream);
-int vp_tanh_f32(vp_ctx* ctx, const float* x, long long n, float* y, vp_stream stream);
-int vp_tanh_bwd_f32(vp_ctx* ctx, const float* dy, const float* y, long long n, float* dz, vp_stream stream);
+int vp_act_f32(vp_ctx* ctx, int act /* VP_ACT_TANH | VP_ACT_SIGMOID */, const float* x, long long n, float* y, vp_stream stream);
+int vp_act_bwd_f32(vp_ctx* ctx, int act, const float* dy, const float* y, long long n, float* dz, vp_stream stream);
+/* vp_reflect_fold_f32: adjoint of the reflect padding of Conv1d (models/utils.py:89-91): dxp (B, T + 2 pad, C) -> dx (B, T, C).
+ * vp_scale_rows_bwd_f32: backward of the SE gate x * s (ecapa_tdnn.py:82): dx = dy * s, ds[b] = sum_t dy * x. */
+int vp_reflect_fold_f32(vp_ctx* ctx, const float* dxp, int B, int T, int pad, int C, float* dx, vp_stream stream);
+int vp_scale_rows_bwd_f32(vp_ctx* ctx, const float* dy, const float* x, const float* s, int B, int T, int C, float* dx, float* ds,
+                          vp_stream stream);
 
 /* Trial scoring -- replaces the per-trial sklearn cosine_similarity loop of
  * PPVectorTrainer.evaluate (trainer.py:416-423) and PPVectorPredictor.contrast (predict.py:282):

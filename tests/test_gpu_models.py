@@ -130,13 +130,12 @@ def test_full_size_batch_invariance(ecapa):
             assert np.linalg.norm(e32[r] - ref[i]) / np.linalg.norm(ref[i]) < 2e-4
 
 
-def test_training_mode_is_refused_not_faked(ecapa):
-    ecapa.train()
-    try:
-        with pytest.raises(NotImplementedError):
-            ecapa(torch.zeros(2, 64, 80, device='cuda'))
-    finally:
-        ecapa.eval()
+def test_training_mode_is_refused_where_not_built():
+    """CAM++ / ResNetSE / ERes2Net have no training path yet: train-mode forward must refuse, never fake it."""
+    from ppvector.models.campplus import CAMPPlus
+    m = CAMPPlus(80, embd_dim=192).cuda().train()
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(2, 64, 80, device='cuda'))
 
 
 def test_long_utterance_falls_back_to_per_conv_path(ecapa):

@@ -32,6 +32,8 @@ def rel(a, b):
     (4, 33, 64, 192, 1, 1, 'none'),
     (2, 45, 64, 64, 3, 2, 'zero'),
     (70, 131, 64, 64, 3, 1, 'none'),      # many row splits
+    (3, 40, 64, 64, 3, 4, 'reflect'),     # ECAPA Res2 conv: reflect padding (adjoint = full conv + mirror fold)
+    (2, 33, 80, 128, 5, 1, 'reflect'),    # ECAPA block0
 ])
 def test_conv_block_grads_vs_autograd(N, case):
     """conv (+bias) -> ReLU -> BatchNorm(batch statistics): output, running statistics and all five gradients."""
@@ -44,7 +46,10 @@ def test_conv_block_grads_vs_autograd(N, case):
     ga = (torch.rand(Cout, generator=g, dtype=torch.float64) + 0.5).requires_grad_()
     be = torch.randn(Cout, generator=g, dtype=torch.float64, requires_grad=True)
     p = dil * (kw - 1) // 2 if pad == 'zero' else 0
-    z = F.relu(F.conv1d(x.transpose(1, 2), w, b, dilation=dil, padding=p))
+    xt = x.transpose(1, 2)
+    if pad == 'reflect':
+        xt = F.pad(xt, (dil * (kw - 1) // 2,) * 2, mode='reflect')
+    z = F.relu(F.conv1d(xt, w, b, dilation=dil, padding=p))
     mean, var = z.mean(dim=(0, 2)), z.var(dim=(0, 2), unbiased=False)
     y = ((z - mean[None, :, None]) / torch.sqrt(var[None, :, None] + 1e-5) * ga[None, :, None] + be[None, :, None]).transpose(1, 2)
     dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
@@ -196,3 +201,41 @@ def test_tdnn_training_step_vs_oracle_autograd(N):
     m.eval()
     with torch.no_grad():
         assert torch.isfinite(m(x.cuda())).all()
+
+
+def test_ecapa_training_step_vs_oracle_autograd(N):
+    """ECAPA-TDNN (configs/ecapa_tdnn.yml) training step: loss and every parameter gradient vs autograd over the oracle graph."""
+    from ppvector.models.ecapa_tdnn import EcapaTdnn
+    from ppvector.train.functions import HeadLoss
+    B, T, Cc = 4, 50, 30
+    p = om.ecapa_params(80, seed=21)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(B, T, 80, generator=g) * 2
+    labels = torch.randint(0, Cc, (B,), generator=g)
+    Wh = om.head_params(192, Cc, seed=5)
+    pr = {k: v.clone().double().requires_grad_(not k.endswith(('_mean', '_variance'))) for k, v in p.items()}
+    Wr = Wh.clone().double().requires_grad_()
+    emb_ref = om.ecapa_forward(pr, x.double(), training=True)
+    loss_ref = om.aam_loss(om.cosine_head(emb_ref, Wr), labels, 0.2, 32.0, False, 0.0)
+    loss_ref.backward()
+    m = EcapaTdnn(80)
+    m.load_state_dict(p)
+    m = m.cuda().train()
+    Wd = Wh.cuda().requires_grad_()
+    emb = m(x.cuda())
+    assert rel(emb, emb_ref.detach()) < 5e-5
+    loss = HeadLoss.apply(emb, Wd, labels.cuda(), 0.2, 32.0, 0.0, False)
+    assert abs(loss.item() - loss_ref.item()) < 2e-4 * abs(loss_ref.item())
+    loss.backward()
+    worst, wk = 0.0, ''
+    for k, v in m.named_parameters():
+        if pr[k].grad.norm().item() < 1e-9:
+            assert v.grad.abs().max().item() < 1e-5, k
+            continue
+        r = rel(v.grad, pr[k].grad)
+        if r > worst:
+            worst, wk = r, k
+        assert r < 2e-3, (k, r)
+    assert rel(Wd.grad, Wr.grad) < 1e-3
+    print(f'[ecapa train] loss {loss.item():.5f} (oracle {loss_ref.item():.5f}); worst parameter-gradient rel-L2 {worst:.2e} ({wk})')
+    m.eval()

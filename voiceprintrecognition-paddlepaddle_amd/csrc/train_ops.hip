@@ -276,22 +276,71 @@ __global__ __launch_bounds__(256) void attn_stats_bwd_kernel(AsBwdArgs a) {
     }
 }
 
+// Adjoint of reflect padding: dxp (B, T + 2p, C) is the gradient w.r.t. the reflect-padded input (from the zero-padded
+// "full" data-gradient conv); frames 1..p and T-1-p..T-2 also receive their mirror images' gradients.
+struct FoldArgs { const float* dxp; float* dx; int T, p, C4; long long total; };
+__global__ __launch_bounds__(256) void reflect_fold_kernel(FoldArgs a) {
+    const int Tp = a.T + 2 * a.p;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.total; i += (long long)gridDim.x * 256) {
+        const long long m = i / a.C4;
+        const int c = (int)(i - m * a.C4) * 4;
+        const long long b = m / a.T;
+        const int t = (int)(m - b * a.T);
+        const float* base = a.dxp + (size_t)b * Tp * a.C4 * 4 + c;
+        float v[4], w[4];
+        vp_load4(base + (size_t)(t + a.p) * a.C4 * 4, v);
+        if (t >= 1 && t <= a.p) {
+            vp_load4(base + (size_t)(a.p - t) * a.C4 * 4, w);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += w[e];
+        }
+        if (t <= a.T - 2 && t >= a.T - 1 - a.p) {
+            vp_load4(base + (size_t)(2 * (a.T - 1) - t + a.p) * a.C4 * 4, w);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += w[e];
+        }
+        vp_store4(a.dx + m * a.C4 * 4 + c, v);
+    }
+}
+
+// Backward of out[b,t,c] = x[b,t,c] * s[b,c] (+ res): dx = dy * s;  ds[b,c] = sum_t dy * x.  One workgroup = 64 channels
+// of one utterance.
+__global__ __launch_bounds__(256) void scale_rows_bwd_kernel(const float* dy, const float* x, const float* s, int T, int C, float* dx,
+                                                             float* ds) {
+    __shared__ float sm[4][64];
+    const int lc = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int b = blockIdx.y, c = blockIdx.x * 64 + lc;
+    float acc = 0.f;
+    if (c < C) {
+        const float sv = s[(size_t)b * C + c];
+        for (int t = rg; t < T; t += 4) {
+            const size_t o = ((size_t)b * T + t) * C + c;
+            const float g = dy[o];
+            acc += g * x[o];
+            dx[o] = g * sv;
+        }
+    }
+    sm[rg][lc] = acc;
+    __syncthreads();
+    if (rg == 0 && c < C) ds[(size_t)b * C + c] = sm[0][lc] + sm[1][lc] + sm[2][lc] + sm[3][lc];
+}
+
 // dz = dy * (1 - y^2)   (tanh backward from its output)
-__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* dy, const float* y, long long n4, float* dz) {
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* dy, const float* y, long long n4, float* dz, int sigmoid) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         float g[4], v[4];
         vp_load4(dy + i * 4, g); vp_load4(y + i * 4, v);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) g[e] *= 1.f - v[e] * v[e];
+        for (int e = 0; e < 4; ++e) g[e] *= sigmoid ? v[e] * (1.f - v[e]) : 1.f - v[e] * v[e];
         vp_store4(dz + i * 4, g);
     }
 }
-__global__ __launch_bounds__(256) void tanh_fwd_kernel(const float* x, long long n4, float* y) {
+__global__ __launch_bounds__(256) void tanh_fwd_kernel(const float* x, long long n4, float* y, int sigmoid) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         float v[4];
         vp_load4(x + i * 4, v);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+        for (int e = 0; e < 4; ++e) v[e] = sigmoid ? 1.f / (1.f + expf(-v[e])) : tanhf(v[e]);
         vp_store4(y + i * 4, v);
     }
 }
@@ -446,17 +495,33 @@ int vp_attn_stats_bwd_f32(vp_ctx* ctx, const float* e, const float* x, int ldx, 
     return VP_OK;
 }
 
-int vp_tanh_f32(vp_ctx* ctx, const float* x, long long n, float* y, vp_stream stream) {
-    if (!ctx || !x || !y || n <= 0 || n & 3) VP_FAIL(ctx, VP_EINVAL, "tanh: bad arguments");
-    hipLaunchKernelGGL(tanh_fwd_kernel, dim3(grid1d(n / 4)), dim3(256), 0, (hipStream_t)stream, x, n / 4, y);
-    VP_LAUNCH_CHECK(ctx, "tanh");
+int vp_act_f32(vp_ctx* ctx, int act, const float* x, long long n, float* y, vp_stream stream) {
+    if (!ctx || !x || !y || n <= 0 || n & 3 || (act != VP_ACT_TANH && act != VP_ACT_SIGMOID)) VP_FAIL(ctx, VP_EINVAL, "act: bad arguments");
+    hipLaunchKernelGGL(tanh_fwd_kernel, dim3(grid1d(n / 4)), dim3(256), 0, (hipStream_t)stream, x, n / 4, y, act == VP_ACT_SIGMOID);
+    VP_LAUNCH_CHECK(ctx, "act");
     return VP_OK;
 }
 
-int vp_tanh_bwd_f32(vp_ctx* ctx, const float* dy, const float* y, long long n, float* dz, vp_stream stream) {
-    if (!ctx || !dy || !y || !dz || n <= 0 || n & 3) VP_FAIL(ctx, VP_EINVAL, "tanh_bwd: bad arguments");
-    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid1d(n / 4)), dim3(256), 0, (hipStream_t)stream, dy, y, n / 4, dz);
-    VP_LAUNCH_CHECK(ctx, "tanh_bwd");
+int vp_act_bwd_f32(vp_ctx* ctx, int act, const float* dy, const float* y, long long n, float* dz, vp_stream stream) {
+    if (!ctx || !dy || !y || !dz || n <= 0 || n & 3 || (act != VP_ACT_TANH && act != VP_ACT_SIGMOID)) VP_FAIL(ctx, VP_EINVAL, "act_bwd: bad arguments");
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid1d(n / 4)), dim3(256), 0, (hipStream_t)stream, dy, y, n / 4, dz, act == VP_ACT_SIGMOID);
+    VP_LAUNCH_CHECK(ctx, "act_bwd");
+    return VP_OK;
+}
+
+int vp_reflect_fold_f32(vp_ctx* ctx, const float* dxp, int B, int T, int pad, int C, float* dx, vp_stream stream) {
+    if (!ctx || !dxp || !dx || B <= 0 || T <= 0 || pad < 0 || pad >= T || C <= 0 || C & 3) VP_FAIL(ctx, VP_EINVAL, "reflect_fold: bad arguments");
+    FoldArgs a{dxp, dx, T, pad, C / 4, (long long)B * T * (C / 4)};
+    hipLaunchKernelGGL(reflect_fold_kernel, dim3(grid1d(a.total)), dim3(256), 0, (hipStream_t)stream, a);
+    VP_LAUNCH_CHECK(ctx, "reflect_fold");
+    return VP_OK;
+}
+
+int vp_scale_rows_bwd_f32(vp_ctx* ctx, const float* dy, const float* x, const float* s, int B, int T, int C, float* dx, float* ds,
+                          vp_stream stream) {
+    if (!ctx || !dy || !x || !s || !dx || !ds || B <= 0 || T <= 0 || C <= 0 || B > 65535) VP_FAIL(ctx, VP_EINVAL, "scale_rows_bwd: bad arguments");
+    hipLaunchKernelGGL(scale_rows_bwd_kernel, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, dy, x, s, T, C, dx, ds);
+    VP_LAUNCH_CHECK(ctx, "scale_rows_bwd");
     return VP_OK;
 }
 

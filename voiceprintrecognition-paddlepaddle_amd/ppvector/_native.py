@@ -212,8 +212,10 @@ _PROTOS = {
     'vp_time_stats_bwd_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
     'vp_attn_stats_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
                                       c_void_p, c_int, c_void_p]),
-    'vp_tanh_f32': (c_int, [c_void_p, c_void_p, C.c_longlong, c_void_p, c_void_p]),
-    'vp_tanh_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, C.c_longlong, c_void_p, c_void_p]),
+    'vp_act_f32': (c_int, [c_void_p, c_int, c_void_p, C.c_longlong, c_void_p, c_void_p]),
+    'vp_act_bwd_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, C.c_longlong, c_void_p, c_void_p]),
+    'vp_reflect_fold_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'vp_scale_rows_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'vp_cosine_scores_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'vp_cosine_scores_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                      c_size_t, c_void_p]),

@@ -77,3 +77,11 @@ class EcapaTdnn(EngineMixin, nn.Module):
                                       'reference wires SAP/TAP/TSP shape-inconsistently (SURVEY.md section 2 row 4)')
         else:
             raise Exception(f'没有{pooling_type}池化层！')
+
+    def _train_forward(self, x):
+        """Training mode: batch-statistics BatchNorm, autograd through libvpmi's backward entry points (f32 engine)."""
+        from ppvector import _native as N
+        from ppvector.train.ecapa_train import ecapa_forward_train
+        if not x.is_cuda:
+            raise N.VpmiError('model input must be a GPU tensor: the engine has no CPU fallback')
+        return ecapa_forward_train(self, x.float().contiguous())

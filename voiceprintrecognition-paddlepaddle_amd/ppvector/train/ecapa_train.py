@@ -1,0 +1,60 @@
+"""Training-mode forward of ECAPA-TDNN (ppvector/models/ecapa_tdnn.py:245-276) through the autograd functions of
+functions.py.  Every conv / BatchNorm / SE gate / ASP / projection runs in libvpmi (forward and backward); the Res2Net
+chunking, the hand-off adds (y_{i-1} + x_i) and the two concatenations are tensor slicing / torch.cat / `+` on 2-D
+(B*T, C) tensors -- data movement and three elementwise adds per block that PyTorch's tape needs to see.
+Input (B, T, F) f32 on the GPU -> embeddings (B, embd_dim)."""
+import torch
+
+from ppvector.train.functions import BNRows, ConvBlock, SEScale, TimeStats
+from ppvector.train.tdnn_train import asp_forward
+
+
+def tdnn_block(blk, x, B, T):
+    """TDNNBlock (models/utils.py:122-148): BN(ReLU(Conv1d 'same' reflect))."""
+    conv, norm = blk.conv.conv, blk.norm.norm
+    return ConvBlock.apply(x, conv.weight, conv.bias, None, norm.weight, norm.bias, norm._mean, norm._variance,
+                           dict(B=B, T=T, dilation=blk.conv.dilation, pad='reflect', relu=True, momentum=norm.momentum, eps=norm.eps))
+
+
+def res2net_block(r2, x, B, T):
+    ys, y = [], None
+    for i, xi in enumerate(torch.chunk(x, r2.scale, dim=1)):
+        if i == 0:
+            y = xi
+        elif i == 1:
+            y = tdnn_block(r2.blocks[i - 1], xi, B, T)
+        else:
+            y = tdnn_block(r2.blocks[i - 1], xi + y, B, T)
+        ys.append(y)
+    return torch.cat(ys, dim=1)
+
+
+def se_res2net_block(blk, x, B, T):
+    if blk.shortcut is not None:
+        raise NotImplementedError('SERes2NetBlock with a shortcut conv is not built')
+    residual = x
+    h = tdnn_block(blk.tdnn1, x, B, T)
+    h = res2net_block(blk.res2net_block, h, B, T)
+    h = tdnn_block(blk.tdnn2, h, B, T)
+    se = blk.se_block
+    Cc = h.shape[1]
+    mean = TimeStats.apply(h, B, T)[:, :Cc]                     # SEBlock squeeze (ecapa_tdnn.py:78)
+    s = ConvBlock.apply(mean, se.conv1.conv.weight, se.conv1.conv.bias, None, None, None, None, None, dict(B=B, T=1, relu=True))
+    s = ConvBlock.apply(s, se.conv2.conv.weight, se.conv2.conv.bias, None, None, None, None, None, dict(B=B, T=1, sigmoid=True))
+    return SEScale.apply(h, s, residual, B, T)
+
+
+def ecapa_forward_train(m, feats):
+    B, T, F = feats.shape
+    x = feats.reshape(B * T, F)
+    x = tdnn_block(m.blocks[0], x, B, T)
+    outs = []
+    for blk in list(m.blocks)[1:]:
+        x = se_res2net_block(blk, x, B, T)
+        outs.append(x)
+    x = tdnn_block(m.mfa, torch.cat(outs, dim=1), B, T)
+    p = asp_forward(m.asp, x, B, T)
+    n = m.asp_bn.norm
+    p = BNRows.apply(p, n.weight, n.bias, n._mean, n._variance, n.momentum, n.eps)
+    fc = m.fc.conv
+    return ConvBlock.apply(p, fc.weight, fc.bias, None, None, None, None, None, dict(B=B, T=1))

@@ -15,7 +15,7 @@ import torch
 
 from ppvector import _native as N
 
-_PAD = {'none': N.VP_PAD_NONE, 'zero': N.VP_PAD_ZERO}
+_PAD = {'none': N.VP_PAD_NONE, 'zero': N.VP_PAD_ZERO, 'reflect': N.VP_PAD_REFLECT}
 
 
 def _chk(rc, ctx):
@@ -70,7 +70,8 @@ class ConvBlock(torch.autograd.Function):
         pad = cfg.get('pad', 'none')
         pad_left = 0 if pad == 'none' else dil * (KW - 1) // 2
         T_out = T_in - dil * (KW - 1) if pad == 'none' else T_in
-        relu, bn, tanh = cfg.get('relu', False), gamma is not None, cfg.get('tanh', False)
+        relu, bn = cfg.get('relu', False), gamma is not None
+        tanh = N.VP_ACT_TANH if cfg.get('tanh', False) else (N.VP_ACT_SIGMOID if cfg.get('sigmoid', False) else 0)
         if x.shape != (B * T_in, Cin) or T_out < 1:
             raise ValueError(f'ConvBlock: x {tuple(x.shape)} does not match B {B}, T {T_in}, Cin {Cin}')
         wp = weight.permute(0, 2, 1).reshape(Cout, KW * Cin).contiguous()
@@ -98,7 +99,7 @@ class ConvBlock(torch.autograd.Function):
                                         y.data_ptr(), Cout, N.stream_ptr()), hctx)
         if tanh:
             yt = torch.empty_like(y)
-            _chk(lib.vp_tanh_f32(hctx, y.data_ptr(), y.numel(), yt.data_ptr(), N.stream_ptr()), hctx)
+            _chk(lib.vp_act_f32(hctx, tanh, y.data_ptr(), y.numel(), yt.data_ptr(), N.stream_ptr()), hctx)
             y = yt
         ctx.save_for_backward(x, weight, z, mean, invstd, gamma, y if tanh else None)
         ctx.geom = (B, T_in, T_out, Cin, Cout, KW, dil, pad, pad_left, relu, bn, tanh, bias is not None, rowbias is not None)
@@ -114,7 +115,7 @@ class ConvBlock(torch.autograd.Function):
         M = B * T_out
         if tanh:
             t = torch.empty_like(dy)
-            _chk(lib.vp_tanh_bwd_f32(hctx, dy.data_ptr(), yt.data_ptr(), dy.numel(), t.data_ptr(), N.stream_ptr()), hctx)
+            _chk(lib.vp_act_bwd_f32(hctx, tanh, dy.data_ptr(), yt.data_ptr(), dy.numel(), t.data_ptr(), N.stream_ptr()), hctx)
             dy = t
         dgamma = dbeta = None
         if bn or relu:
@@ -150,10 +151,47 @@ class ConvBlock(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             w2 = weight.flip(2).permute(1, 2, 0).reshape(Cin, KW * Cout).contiguous()
             dx = torch.empty((B * T_in, Cin), dtype=torch.float32, device=dev)
-            d2 = _conv_desc(dz, B, T_out, T_in, Cout, Cin, KW, dil, N.VP_PAD_ZERO, dil * (KW - 1) - pad_left, w2)
-            d2.y = dx.data_ptr()
-            _chk(lib.vp_conv1d_fwd(hctx, C.byref(d2), N.stream_ptr()), hctx)
+            if pad == 'reflect' and pad_left > 0:
+                # gradient w.r.t. the reflect-PADDED input (a "full" zero-padded conv), then fold the mirrored frames back
+                Tp = T_in + 2 * pad_left
+                dxp = torch.empty((B * Tp, Cin), dtype=torch.float32, device=dev)
+                d2 = _conv_desc(dz, B, T_out, Tp, Cout, Cin, KW, dil, N.VP_PAD_ZERO, dil * (KW - 1), w2)
+                d2.y = dxp.data_ptr()
+                _chk(lib.vp_conv1d_fwd(hctx, C.byref(d2), N.stream_ptr()), hctx)
+                _chk(lib.vp_reflect_fold_f32(hctx, dxp.data_ptr(), B, T_in, pad_left, Cin, dx.data_ptr(), N.stream_ptr()), hctx)
+            else:
+                d2 = _conv_desc(dz, B, T_out, T_in, Cout, Cin, KW, dil, N.VP_PAD_ZERO, dil * (KW - 1) - pad_left, w2)
+                d2.y = dx.data_ptr()
+                _chk(lib.vp_conv1d_fwd(hctx, C.byref(d2), N.stream_ptr()), hctx)
         return dx, dW, dbias, drb, dgamma, dbeta, None, None, None
+
+
+class SEScale(torch.autograd.Function):
+    """out = x * s[b] + res  (SEBlock gate, ecapa_tdnn.py:82, and the block residual, :139-141)."""
+
+    @staticmethod
+    def forward(ctx, x, s, res, B, T):
+        lib, hctx = N.lib(), N.ctx(x.device)
+        x, s, res = _f32c(x), _f32c(s), _f32c(res)
+        Cc = x.shape[1]
+        out = torch.empty_like(x)
+        _chk(lib.vp_se_scale_residual(hctx, N.VP_F32, x.data_ptr(), Cc, 0, s.data_ptr(), res.data_ptr(), Cc, 0, out.data_ptr(), Cc, 0,
+                                      B, T, Cc, N.stream_ptr()), hctx)
+        ctx.save_for_backward(x, s)
+        ctx.geom = (B, T)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, s = ctx.saved_tensors
+        B, T = ctx.geom
+        lib, hctx = N.lib(), N.ctx(x.device)
+        dy = _f32c(dy)
+        Cc = x.shape[1]
+        dx, ds = torch.empty_like(x), torch.empty_like(s)
+        _chk(lib.vp_scale_rows_bwd_f32(hctx, dy.data_ptr(), x.data_ptr(), s.data_ptr(), B, T, Cc, dx.data_ptr(), ds.data_ptr(),
+                                       N.stream_ptr()), hctx)
+        return dx, ds, dy, None, None
 
 
 class TimeStats(torch.autograd.Function):
