@@ -396,6 +396,15 @@ int vp_cosine_aam_ce_bwd(vp_ctx* ctx, const float* emb, const float* W, const in
                          float scale, float label_smoothing, int easy_margin, float grad_scale, float* demb, float* dW,
                          float* loss, void* ws, size_t ws_bytes, vp_stream stream);
 
+/* The same backward split at the reference's module boundary (classifier and loss are separate objects there:
+ * models/fc.py and loss/aamloss.py): dlogits from the loss, then demb / dW from dlogits. */
+int vp_aam_ce_bwd(vp_ctx* ctx, const float* logits, const int64_t* labels, int B, int C, float margin, float scale,
+                  float label_smoothing, int easy_margin, float grad_scale, float* dlogits, float* loss, float* row_loss,
+                  vp_stream stream);
+size_t vp_cosine_logits_bwd_workspace_bytes(int B, int D, int C);
+int vp_cosine_logits_bwd(vp_ctx* ctx, const float* emb, const float* W, const float* dcos, int B, int D, int C, float* demb,
+                         float* dW, void* ws, size_t ws_bytes, vp_stream stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Training-side building blocks (f32 engine) -- what paddle's autograd and optimiser run under
  * PPVectorTrainer.__train_epoch (trainer.py:202-274) for the layers of models/utils.py:22-148.

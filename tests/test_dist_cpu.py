@@ -1,6 +1,7 @@
 """world_size-2 gloo test (CPU) of the N>1 bench path: the forward path shards by utterance with no
 data-path collective, so what N>1 adds is the barrier-bracketed timing and the max-over-ranks
-reduction.  (RCCL gradient all-reduce belongs to the training row, not built yet.)"""
+reduction -- and of the training path's data-parallel pieces: contiguous batch sharding and the bucketed all-reduce
+average over a flat gradient buffer (ppvector/train/ddp.py; RCCL on the GPUs, gloo here)."""
 import os
 import sys
 import time
@@ -46,3 +47,33 @@ def test_two_rank_timing_is_max_over_ranks():
     assert abs(dt0 - dt1) < 1e-9                           # both report the reduced (max) time
     assert dt0 >= 5 * 0.02 * 0.9                           # ... which is the slow rank's
     assert s0 != s1                                        # distinct data shards
+
+
+def _ddp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'voiceprintrecognition-paddlepaddle_amd'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ppvector.train.ddp import allreduce_mean_, shard_batch
+    idx = list(shard_batch(11, rank, world))
+    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)          # rank r holds (r + 1) * [0 .. 999]
+    allreduce_mean_(g, bucket_bytes=1024)                             # 4 buckets of 256 floats
+    q.put((rank, idx, g[:3].tolist(), float(g[999])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_average_and_sharding():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, i0, h0, t0), (_, i1, h1, t1) = res
+    assert i0 == [0, 1, 2, 3, 4, 5] and i1 == [6, 7, 8, 9, 10]        # contiguous split, last shard short
+    assert h0 == h1 == [0.0, 1.5, 3.0] and t0 == t1 == 999 * 1.5     # mean of 1x and 2x

@@ -239,3 +239,50 @@ def test_ecapa_training_step_vs_oracle_autograd(N):
     assert rel(Wd.grad, Wr.grad) < 1e-3
     print(f'[ecapa train] loss {loss.item():.5f} (oracle {loss_ref.item():.5f}); worst parameter-gradient rel-L2 {worst:.2e} ({wk})')
     m.eval()
+
+
+def test_reference_shaped_train_loop_overfits_a_batch(N):
+    """The reference's loop body (trainer.py:206-274) over its own object graph -- nn.Sequential(backbone, classifier),
+    build_loss, build_optimizer, build_lr_scheduler, MarginScheduler -- on one fixed batch: the first loss equals the
+    oracle's, and a few Adam steps drive it down."""
+    from ppvector.loss import build_loss
+    from ppvector.models import build_model
+    from ppvector.models.fc import SpeakerIdentification
+    from ppvector.optimizer import MarginScheduler, build_lr_scheduler, build_optimizer
+    from ppvector.train.step import TrainStep
+    from ppvector.utils.utils import dict_to_object
+    configs = dict_to_object(dict(
+        model_conf=dict(model='TDNN', model_args=dict(embd_dim=192, pooling_type='ASP'),
+                        classifier=dict(classifier_type='Cosine', num_speakers=12, num_blocks=0)),
+        loss_conf=dict(loss='AAMLoss', loss_args=dict(margin=0.2, scale=32, easy_margin=False, label_smoothing=0.0)),
+        optimizer_conf=dict(optimizer='Adam', optimizer_args=dict(weight_decay=1e-6), scheduler='WarmupCosineSchedulerLR',
+                            scheduler_args=dict(learning_rate=2e-3, min_lr=1e-5, warmup_epoch=1)),
+        train_conf=dict(max_epoch=4)))
+    torch.manual_seed(1000)
+    backbone = build_model(input_size=80, configs=configs)
+    p = om.tdnn_params(80, seed=3)
+    backbone.load_state_dict(p)
+    classifier = SpeakerIdentification(input_dim=backbone.embd_dim, **{k: v for k, v in configs.model_conf.classifier.items()})
+    model = torch.nn.Sequential(backbone, classifier).cuda()
+    criterion = build_loss(configs)
+    spe = 5
+    scheduler = build_lr_scheduler(step_per_epoch=spe, configs=configs)
+    optimizer = build_optimizer(parameters=model.parameters(), learning_rate=scheduler, configs=configs)
+    margin = MarginScheduler(criterion, increase_start_epoch=1, fix_epoch=3, step_per_epoch=spe, initial_margin=0.0, final_margin=0.3)
+    step = TrainStep(model, criterion, optimizer, scheduler, margin)
+    g = torch.Generator().manual_seed(8)
+    x = (torch.randn(8, 64, 80, generator=g) * 2).cuda()
+    y = torch.randint(0, 12, (8,), generator=g).cuda()
+    with torch.no_grad():
+        W0 = classifier.weight.detach().cpu().double()
+    ref0 = om.aam_loss(om.cosine_head(om.tdnn_forward({k: v.double() for k, v in p.items()}, x.cpu().double(), training=True), W0),
+                       y.cpu(), 0.0, 32.0, False, 0.0).item()
+    losses = []
+    for _ in range(12):
+        loss, acc = step(x, y)
+        losses.append(loss.item())
+    assert abs(losses[0] - ref0) < 2e-4 * abs(ref0), (losses[0], ref0)
+    assert scheduler.get_lr() > 0 and criterion.margin > 0          # both schedules moved
+    assert losses[1] == losses[0]                                   # warm-up: the table's lr[0] is 0 (scheduler.py:6-40)
+    print('[train loop] losses', ' '.join(f'{v:.3f}' for v in losses), ' final acc', float(acc))
+    assert losses[4] < losses[0] - 0.05                             # before the margin ramp starts (epoch 1 = step 5)

@@ -151,8 +151,13 @@ __global__ __launch_bounds__(256) void aam_ce_bwd_rows_kernel(AamBwdArgs a) {
         float dm;
         const float o = out_of(c, row[c], dm);
         const float q = qoff + (c == y ? 1.f - a.ls : 0.f);
-        g[c] = k * (expf(o - lse) - q) * dm * a.cinv[c];
+        g[c] = k * (expf(o - lse) - q) * dm * (a.cinv ? a.cinv[c] : 1.f);
     }
+}
+
+// g[b][c] = d[b][c] * cinv[c]
+__global__ __launch_bounds__(256) void scale_cols_kernel(const float* d, const float* cinv, long long n, int C, float* g) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) g[i] = d[i] * cinv[i % C];
 }
 
 // xnT[d][b] = x[b][d] * rinv[b]
@@ -286,6 +291,66 @@ int vp_cosine_aam_ce_bwd(vp_ctx* ctx, const float* emb, const float* W, const in
         VP_LAUNCH_CHECK(ctx, "mean");
     }
     // d xn = (G cinv) W^T;  d wn' = xn^T (G cinv)
+    if ((rc = vp_dense_f32_ex(ctx, G, C, W, /*w_is_kn=*/0, nullptr, nullptr, nullptr, B, D, C, VP_ACT_NONE, dxn, D, st))) return rc;
+    hipLaunchKernelGGL(transpose_scale_kernel, dim3((B * D + 255) / 256), dim3(256), 0, st, emb, rinv, B, D, xnT);
+    VP_LAUNCH_CHECK(ctx, "transpose_scale");
+    if ((rc = vp_dense_f32_ex(ctx, xnT, B, G, /*w_is_kn=*/1, nullptr, nullptr, nullptr, D, C, B, VP_ACT_NONE, dwn, C, st))) return rc;
+    hipLaunchKernelGGL(row_normalize_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, emb, dxn, rinv, B, D, demb);
+    VP_LAUNCH_CHECK(ctx, "row_normalize_bwd");
+    hipLaunchKernelGGL(col_normalize_bwd_kernel, dim3((C + 63) / 64), dim3(256), 0, st, W, dwn, cinv, D, C, dW);
+    VP_LAUNCH_CHECK(ctx, "col_normalize_bwd");
+    return VP_OK;
+}
+
+// Backward of AAMLoss alone (aamloss.py:28-47): dlogits (B, C) = grad_scale * d loss / d cos.  loss (1) optional.
+int vp_aam_ce_bwd(vp_ctx* ctx, const float* logits, const int64_t* labels, int B, int C, float margin, float scale,
+                  float label_smoothing, int easy_margin, float grad_scale, float* dlogits, float* loss, float* row_loss,
+                  vp_stream stream) {
+    if (!ctx || !logits || !labels || !dlogits || B <= 0 || C <= 0 || (loss && !row_loss)) VP_FAIL(ctx, VP_EINVAL, "aam_ce_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    AamBwdArgs a;
+    a.logits = logits; a.labels = (const long long*)labels; a.cinv = nullptr; a.G = dlogits; a.row_loss = loss ? row_loss : nullptr;
+    a.B = B; a.C = C;
+    a.cos_m = (float)cos((double)margin); a.sin_m = (float)sin((double)margin);
+    a.th = (float)cos(M_PI - (double)margin); a.mmm = (float)(1.0 + cos(M_PI - (double)margin));
+    a.scale = scale; a.ls = label_smoothing; a.gscale = grad_scale; a.easy = easy_margin;
+    hipLaunchKernelGGL(aam_ce_bwd_rows_kernel, dim3(B), dim3(256), 0, st, a);
+    VP_LAUNCH_CHECK(ctx, "aam_ce_bwd_rows");
+    if (loss) {
+        hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, st, row_loss, B, loss);
+        VP_LAUNCH_CHECK(ctx, "mean");
+    }
+    return VP_OK;
+}
+
+size_t vp_cosine_logits_bwd_workspace_bytes(int B, int D, int C) {
+    return vp_cosine_logits_workspace_bytes(B, D, C) + vp_align_up((size_t)B * C * 4, 256) + vp_align_up((size_t)D * C * 4, 256) +
+           2 * vp_align_up((size_t)B * D * 4, 256);
+}
+
+// Backward of the cosine classifier alone (fc.py:41-53): demb (B, D), dW (D, C) from dcos (B, C).
+int vp_cosine_logits_bwd(vp_ctx* ctx, const float* emb, const float* W, const float* dcos, int B, int D, int C, float* demb,
+                         float* dW, void* ws, size_t ws_bytes, vp_stream stream) {
+    if (!ctx || !emb || !W || !dcos || !demb || !dW || B <= 0 || D <= 0 || C <= 0) VP_FAIL(ctx, VP_EINVAL, "cosine_logits_bwd: bad arguments");
+    if (!ws || ws_bytes < vp_cosine_logits_bwd_workspace_bytes(B, D, C)) VP_FAIL(ctx, VP_EWORKSPACE, "cosine_logits_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    char* p = (char*)ws;
+    float* rinv = (float*)p;
+    float* cinv = (float*)(p + vp_align_up((size_t)B * 4, 256));
+    p += vp_cosine_logits_workspace_bytes(B, D, C);
+    float* G = (float*)p; p += vp_align_up((size_t)B * C * 4, 256);
+    float* dwn = (float*)p; p += vp_align_up((size_t)D * C * 4, 256);
+    float* xnT = (float*)p; p += vp_align_up((size_t)B * D * 4, 256);
+    float* dxn = (float*)p;
+    int rc = vp_row_inv_norm(ctx, emb, B, D, D, 1e-12f, rinv, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(col_inv_norm_kernel, dim3((C + 63) / 64), dim3(256), 0, st, W, D, C, 1e-12f, cinv);
+    VP_LAUNCH_CHECK(ctx, "col_inv_norm");
+    const long long n = (long long)B * C;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(scale_cols_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dcos, cinv, n, C, G);
+    VP_LAUNCH_CHECK(ctx, "scale_cols");
     if ((rc = vp_dense_f32_ex(ctx, G, C, W, /*w_is_kn=*/0, nullptr, nullptr, nullptr, B, D, C, VP_ACT_NONE, dxn, D, st))) return rc;
     hipLaunchKernelGGL(transpose_scale_kernel, dim3((B * D + 255) / 256), dim3(256), 0, st, emb, rinv, B, D, xnT);
     VP_LAUNCH_CHECK(ctx, "transpose_scale");

@@ -216,6 +216,11 @@ _PROTOS = {
     'vp_act_bwd_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, C.c_longlong, c_void_p, c_void_p]),
     'vp_reflect_fold_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'vp_scale_rows_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'vp_aam_ce_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_float, c_void_p,
+                              c_void_p, c_void_p, c_void_p]),
+    'vp_cosine_logits_bwd_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'vp_cosine_logits_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                     c_size_t, c_void_p]),
     'vp_cosine_scores_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'vp_cosine_scores_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                      c_size_t, c_void_p]),

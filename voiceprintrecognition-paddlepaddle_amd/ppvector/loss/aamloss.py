@@ -25,6 +25,9 @@ class AAMLoss(nn.Module):
         features, logits = inputs['features'], inputs['logits']
         if not logits.is_cuda:
             raise N.VpmiError('AAMLoss needs GPU tensors: the engine has no CPU fallback')
+        if torch.is_grad_enabled() and logits.requires_grad:            # training: loss with its backward (csrc/head.hip)
+            from ppvector.train.functions import AamCe
+            return AamCe.apply(logits, labels, self.margin, self.scale, self.label_smoothing, self.easy_margin)
         logits = logits.contiguous().float()
         labels = labels.to(device=logits.device, dtype=torch.int64).reshape(-1).contiguous()
         B, Cn = logits.shape

@@ -32,6 +32,9 @@ class SpeakerIdentification(nn.Module):
         x = features
         if not x.is_cuda:
             raise N.VpmiError('SpeakerIdentification needs GPU tensors: the engine has no CPU fallback')
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad) and self.training:
+            from ppvector.train.functions import CosineLogits       # training: logits with their backward (csrc/head.hip)
+            return {"features": features, "logits": CosineLogits.apply(x.float(), self.weight)}
         x = x.contiguous().float()
         W = self.weight.detach().contiguous().float()
         B, D = x.shape

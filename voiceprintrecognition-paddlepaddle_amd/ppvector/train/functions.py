@@ -301,3 +301,55 @@ class HeadLoss(torch.autograd.Function):
     def backward(ctx, g):
         demb, dW = ctx.saved_tensors
         return demb * g, dW * g, None, None, None, None, None
+
+
+class CosineLogits(torch.autograd.Function):
+    """cos = normalize(emb, axis=1) @ normalize(W, axis=0)  (SpeakerIdentification 'Cosine', models/fc.py:41-53)."""
+
+    @staticmethod
+    def forward(ctx, emb, W):
+        lib, hctx = N.lib(), N.ctx(emb.device)
+        emb, W = _f32c(emb), _f32c(W)
+        B, D = emb.shape
+        Cc = W.shape[1]
+        logits = torch.empty((B, Cc), dtype=torch.float32, device=emb.device)
+        ws = _bytes(lib.vp_cosine_logits_workspace_bytes(B, D, Cc), emb.device)
+        _chk(lib.vp_cosine_logits_f32(hctx, emb.data_ptr(), W.data_ptr(), B, D, Cc, logits.data_ptr(), ws.data_ptr(), ws.numel(),
+                                      N.stream_ptr()), hctx)
+        ctx.save_for_backward(emb, W)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dcos):
+        emb, W = ctx.saved_tensors
+        lib, hctx = N.lib(), N.ctx(emb.device)
+        B, D = emb.shape
+        Cc = W.shape[1]
+        demb, dW = torch.empty_like(emb), torch.empty_like(W)
+        ws = _bytes(lib.vp_cosine_logits_bwd_workspace_bytes(B, D, Cc), emb.device)
+        _chk(lib.vp_cosine_logits_bwd(hctx, emb.data_ptr(), W.data_ptr(), _f32c(dcos).data_ptr(), B, D, Cc, demb.data_ptr(),
+                                      dW.data_ptr(), ws.data_ptr(), ws.numel(), N.stream_ptr()), hctx)
+        return demb, dW
+
+
+class AamCe(torch.autograd.Function):
+    """loss = CrossEntropy(label_smoothing)(scale * margin(cos), labels)  (AAMLoss.forward, loss/aamloss.py:28-47)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, margin, scale, label_smoothing, easy_margin):
+        lib, hctx = N.lib(), N.ctx(logits.device)
+        logits = _f32c(logits)
+        B, Cc = logits.shape
+        lab = labels.to(device=logits.device, dtype=torch.int64).reshape(-1).contiguous()
+        dl = torch.empty_like(logits)
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+        row = torch.empty(B, dtype=torch.float32, device=logits.device)
+        _chk(lib.vp_aam_ce_bwd(hctx, logits.data_ptr(), lab.data_ptr(), B, Cc, float(margin), float(scale), float(label_smoothing),
+                               int(bool(easy_margin)), 1.0, dl.data_ptr(), loss.data_ptr(), row.data_ptr(), N.stream_ptr()), hctx)
+        ctx.save_for_backward(dl)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None, None, None, None, None
