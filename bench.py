@@ -227,7 +227,7 @@ def main():
     model = model.to(dev).eval()
     head = SpeakerIdentification(EMBD, N_CLASSES)
     head.load_state_dict({'weight': om.head_params(EMBD, N_CLASSES, seed=1001)})
-    head = head.to(dev)
+    head = head.to(dev).eval()            # eval-mode forward: logits without the autograd tape
     crit = AAMLoss(margin=0.2, scale=32, easy_margin=False, label_smoothing=0.0)
     eng = model.engine(args.dtype)
     want16 = args.dtype == 'bfloat16'

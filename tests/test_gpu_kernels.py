@@ -384,7 +384,7 @@ def test_cosine_head_and_aam_golden(N, golden_dir):
     W = om.head_params(192, 2796, seed=int(g['head_seed']))
     head = SpeakerIdentification(input_dim=192, num_speakers=2796, classifier_type='Cosine')
     head.load_state_dict({'weight': W})
-    head.cuda()
+    head.cuda().eval()                  # eval: plain logits (in train mode they carry the autograd tape, tests/test_gpu_train.py)
     out = head(dev(g['emb_eval']))
     assert out['features'].shape == (2, 192)
     assert np.max(np.abs(out['logits'].cpu().numpy() - g['logits'])) < 1e-6
