@@ -418,7 +418,7 @@ int vp_cosine_logits_bwd(vp_ctx* ctx, const float* emb, const float* W, const fl
  * vp_bn_train_finalize: batch mean / biased variance from a conv's fused column sums (all nparts = tiles * nseg partial
  *   rows), folded scale/shift for the apply pass, saved mean / invstd, running statistics updated in place
  *   (running = momentum * running + (1 - momentum) * batch; utils.py:108-115, momentum 0.9).
- * vp_affine_rows_f32: y = z * scale + shift.   vp_bn_relu_bwd_f32: dz through BN (batch statistics) and the ReLU before it.
+ * vp_affine_rows_f32: y = z * scale + shift (then ReLU when relu: the conv -> BN -> ReLU order of the 2-D models).   vp_bn_relu_bwd_f32: dz through BN (batch statistics) and the ReLU before it.
  * vp_adam_step_f32: Adam with coupled L2 (optimizer/__init__.py:12-18), bias-corrected, on a flat f32 buffer.
  * ---------------------------------------------------------------------------------------------- */
 size_t vp_conv1d_wgrad_workspace_bytes(const vp_conv1d_desc* d);
@@ -431,7 +431,7 @@ int vp_bn_train_finalize(vp_ctx* ctx, const float* psum, const float* psumsq, in
                          const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* mean,
                          float* invstd, float* scale, float* shift, vp_stream stream);
 int vp_affine_rows_f32(vp_ctx* ctx, const float* z, int ldz, const float* scale, const float* shift, long long M, int C, float* y,
-                       int ldy, vp_stream stream);
+                       int ldy, int relu, vp_stream stream);
 int vp_bn_relu_bwd_f32(vp_ctx* ctx, const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* invstd,
                        const float* gamma, const float* sums, long long M, int C, int relu_mask, float* dz, int lddz,
                        vp_stream stream);
@@ -447,10 +447,15 @@ int vp_time_stats_bwd_f32(vp_ctx* ctx, const float* x, int ldx, const float* sta
                           float* dx, int lddx, vp_stream stream);
 int vp_attn_stats_bwd_f32(vp_ctx* ctx, const float* e, const float* x, int ldx, const float* pooled, const float* dpooled, int B, int T,
                           int C, float eps, float* de, float* dx, int lddx, vp_stream stream);
-int vp_act_f32(vp_ctx* ctx, int act /* VP_ACT_TANH | VP_ACT_SIGMOID */, const float* x, long long n, float* y, vp_stream stream);
+int vp_act_f32(vp_ctx* ctx, int act /* VP_ACT_TANH | VP_ACT_SIGMOID | VP_ACT_RELU */, const float* x, long long n, float* y, vp_stream stream);
 int vp_act_bwd_f32(vp_ctx* ctx, int act, const float* dy, const float* y, long long n, float* dz, vp_stream stream);
 /* vp_reflect_fold_f32: adjoint of the reflect padding of Conv1d (models/utils.py:89-91): dxp (B, T + 2 pad, C) -> dx (B, T, C).
  * vp_scale_rows_bwd_f32: backward of the SE gate x * s (ecapa_tdnn.py:82): dx = dy * s, ds[b] = sum_t dy * x. */
+/* vp_zero_insert_2d_f32: dz (B, T_out, F_out, C) -> up (B, T_in, F_in, C), zeros between the samples: the data gradient of a
+ * stride-s 2-D conv is then a stride-1 vp_conv1d_fwd over `up`.  vp_relu_bwd_f32: dz = [y > 0] dy. */
+int vp_zero_insert_2d_f32(vp_ctx* ctx, const float* dz, int B, int T_out, int F_out, int C, int T_in, int F_in, int stride, float* up,
+                          vp_stream stream);
+int vp_relu_bwd_f32(vp_ctx* ctx, const float* dy, const float* y, long long n, float* dz, vp_stream stream);
 int vp_reflect_fold_f32(vp_ctx* ctx, const float* dxp, int B, int T, int pad, int C, float* dx, vp_stream stream);
 int vp_scale_rows_bwd_f32(vp_ctx* ctx, const float* dy, const float* x, const float* s, int B, int T, int C, float* dx, float* ds,
                           vp_stream stream);

@@ -20,36 +20,36 @@ LAYERS = [3, 4, 6, 3]
 FILTERS = [32, 64, 128, 256]
 
 
-def _block(x, p, pre, stride):
-    out = F.relu(_bn(F.conv2d(x, p[pre + 'conv1.weight'], p[pre + 'conv1.bias']), p, pre + 'bn1.'))
-    out = F.relu(_bn(F.conv2d(out, p[pre + 'conv2.weight'], p[pre + 'conv2.bias'], stride=stride, padding=1), p, pre + 'bn2.'))
-    out = _bn(F.conv2d(out, p[pre + 'conv3.weight'], p[pre + 'conv3.bias']), p, pre + 'bn3.')
+def _block(x, p, pre, stride, training=False):
+    out = F.relu(_bn(F.conv2d(x, p[pre + 'conv1.weight'], p[pre + 'conv1.bias']), p, pre + 'bn1.', training))
+    out = F.relu(_bn(F.conv2d(out, p[pre + 'conv2.weight'], p[pre + 'conv2.bias'], stride=stride, padding=1), p, pre + 'bn2.', training))
+    out = _bn(F.conv2d(out, p[pre + 'conv3.weight'], p[pre + 'conv3.bias']), p, pre + 'bn3.', training)
     y = out.mean(dim=(2, 3))
     y = F.relu(y @ p[pre + 'se.fc.0.weight'] + p[pre + 'se.fc.0.bias'])
     y = torch.sigmoid(y @ p[pre + 'se.fc.2.weight'] + p[pre + 'se.fc.2.bias'])
     out = out * y[:, :, None, None]
     if (pre + 'downsample.0.weight') in p:
-        res = _bn(F.conv2d(x, p[pre + 'downsample.0.weight'], p[pre + 'downsample.0.bias'], stride=stride), p, pre + 'downsample.1.')
+        res = _bn(F.conv2d(x, p[pre + 'downsample.0.weight'], p[pre + 'downsample.0.bias'], stride=stride), p, pre + 'downsample.1.', training)
     else:
         res = x
     return F.relu(out + res)
 
 
-def resnetse_forward(p, x, prefix='', layers=LAYERS, taps=None):
+def resnetse_forward(p, x, prefix='', layers=LAYERS, taps=None, training=False):
     """ResNetSE.forward (resnet_se.py:121-139), pooling_type ASP, eval mode.  x (B, T, F) -> (B, embd)."""
     x = x.transpose(1, 2).unsqueeze(1)
-    x = F.relu(_bn(F.conv2d(x, p[prefix + 'conv1.weight'], p[prefix + 'conv1.bias'], padding=1), p, prefix + 'bn1.'))
+    x = F.relu(_bn(F.conv2d(x, p[prefix + 'conv1.weight'], p[prefix + 'conv1.bias'], padding=1), p, prefix + 'bn1.', training))
     for li, n in enumerate(layers, start=1):
         for bi in range(n):
             stride = 2 if (li > 1 and bi == 0) else 1
-            x = _block(x, p, f'{prefix}layer{li}.{bi}.', stride)
+            x = _block(x, p, f'{prefix}layer{li}.{bi}.', stride, training)
     if taps is not None:
         taps['layer4'] = x
     x = x.reshape(x.shape[0], -1, x.shape[-1])
-    x = asp(x, p, prefix + 'pooling.', True)
-    x = batchnorm(x, p, prefix + 'bn2.norm.')
+    x = asp(x, p, prefix + 'pooling.', True, training)
+    x = batchnorm(x, p, prefix + 'bn2.norm.', training)
     x = x @ p[prefix + 'linear.weight'] + p[prefix + 'linear.bias']
-    return batchnorm(x, p, prefix + 'bn3.norm.')
+    return batchnorm(x, p, prefix + 'bn3.norm.', training)
 
 
 def resnetse_params(input_size=80, embd_dim=192, layers=LAYERS, filters=FILTERS, seed=1000, randomize_stats=True,

@@ -286,3 +286,82 @@ def test_reference_shaped_train_loop_overfits_a_batch(N):
     assert losses[1] == losses[0]                                   # warm-up: the table's lr[0] is 0 (scheduler.py:6-40)
     print('[train loop] losses', ' '.join(f'{v:.3f}' for v in losses), ' final acc', float(acc))
     assert losses[4] < losses[0] - 0.05                             # before the margin ramp starts (epoch 1 = step 5)
+
+
+@pytest.mark.parametrize('case', [
+    # B, T, F, Cin, Cout, k, stride, relu
+    (2, 13, 10, 8, 16, 3, 1, True),
+    (2, 13, 10, 16, 8, 3, 2, True),      # odd T, even F: zero-insertion data gradient
+    (3, 8, 9, 8, 12, 1, 2, False),       # strided 1x1 (the bottleneck's downsample branch)
+    (2, 6, 7, 12, 8, 1, 1, True),
+])
+def test_conv2d_block_grads_vs_autograd(N, case):
+    """Conv2D -> BatchNorm2D(batch statistics) -> [ReLU] over (B, T, F, C) positions: output and all gradients."""
+    from ppvector.train.functions import Conv2dBlock
+    B, T, Fq, Cin, Cout, k, s, relu = case
+    g = torch.Generator().manual_seed(31 + k + s)
+    x = torch.randn(B, Cin, Fq, T, generator=g, dtype=torch.float64, requires_grad=True)          # the reference's (B, C, F, T)
+    w = (torch.randn(Cout, Cin, k, k, generator=g, dtype=torch.float64) / (Cin * k * k) ** 0.5).requires_grad_()
+    b = torch.randn(Cout, generator=g, dtype=torch.float64, requires_grad=True)
+    ga = (torch.rand(Cout, generator=g, dtype=torch.float64) + 0.5).requires_grad_()
+    be = torch.randn(Cout, generator=g, dtype=torch.float64, requires_grad=True)
+    z = F.conv2d(x, w, b, stride=s, padding=(k - 1) // 2)
+    mean, var = z.mean(dim=(0, 2, 3)), z.var(dim=(0, 2, 3), unbiased=False)
+    y = (z - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + 1e-5) * ga[None, :, None, None] + be[None, :, None, None]
+    if relu:
+        y = F.relu(y)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    to2d = lambda t: t.permute(0, 3, 2, 1).reshape(-1, t.shape[1])                                # (B, C, F, T) -> (B*T*F, C)
+    xd = to2d(x.detach()).float().cuda().requires_grad_()
+    wd, bd = w.detach().float().cuda().requires_grad_(), b.detach().float().cuda().requires_grad_()
+    gd, hd = ga.detach().float().cuda().requires_grad_(), be.detach().float().cuda().requires_grad_()
+    rm, rv = torch.zeros(Cout, device='cuda'), torch.ones(Cout, device='cuda')
+    out = Conv2dBlock.apply(xd, wd, bd, gd, hd, rm, rv, dict(B=B, T=T, F=Fq, stride=s, relu=relu))
+    out.backward(to2d(dy).float().cuda())
+    assert rel(out, to2d(y.detach())) < 2e-6
+    for name, got, ref in (('dx', xd.grad, to2d(x.grad)), ('dW', wd.grad, w.grad), ('dbias', bd.grad, b.grad),
+                           ('dgamma', gd.grad, ga.grad), ('dbeta', hd.grad, be.grad)):
+        if ref.norm().item() < 1e-9:
+            assert got.abs().max().item() < 1e-5, name        # a bias before BatchNorm has zero gradient
+            continue
+        assert rel(got, ref) < 3e-5, (name, rel(got, ref))
+
+
+def test_resnetse_training_step_vs_oracle_autograd(N):
+    """ResNetSE (configs/resnet_se.yml architecture, one bottleneck per stage to keep the float64 oracle quick)."""
+    from oracle import resnet_se as orse
+    from ppvector.models.resnet_se import ResNetSE
+    from ppvector.train.functions import HeadLoss
+    B, T, Fdim, Cc = 3, 26, 16, 10
+    layers = [1, 1, 1, 1]
+    p = orse.resnetse_params(Fdim, 192, layers=layers, seed=9)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(B, T, Fdim, generator=g) * 2
+    labels = torch.randint(0, Cc, (B,), generator=g)
+    Wh = om.head_params(192, Cc, seed=2)
+    pr = {k: v.clone().double().requires_grad_(not k.endswith(('_mean', '_variance'))) for k, v in p.items()}
+    Wr = Wh.clone().double().requires_grad_()
+    emb_ref = orse.resnetse_forward(pr, x.double(), layers=layers, training=True)
+    loss_ref = om.aam_loss(om.cosine_head(emb_ref, Wr), labels, 0.2, 32.0, False, 0.0)
+    loss_ref.backward()
+    m = ResNetSE(Fdim, layers=layers)
+    m.load_state_dict(p)
+    m = m.cuda().train()
+    Wd = Wh.cuda().requires_grad_()
+    emb = m(x.cuda())
+    assert rel(emb, emb_ref.detach()) < 1e-4
+    loss = HeadLoss.apply(emb, Wd, labels.cuda(), 0.2, 32.0, 0.0, False)
+    assert abs(loss.item() - loss_ref.item()) < 5e-4 * abs(loss_ref.item())
+    loss.backward()
+    worst, wk = 0.0, ''
+    for k, v in m.named_parameters():
+        if pr[k].grad.norm().item() < 1e-9:
+            assert v.grad.abs().max().item() < 1e-4, k
+            continue
+        r = rel(v.grad, pr[k].grad)
+        if r > worst:
+            worst, wk = r, k
+        assert r < 5e-3, (k, r)
+    print(f'[resnetse train] loss {loss.item():.5f} (oracle {loss_ref.item():.5f}); worst parameter-gradient rel-L2 {worst:.2e} ({wk})')
+    m.eval()

@@ -18,6 +18,7 @@ namespace {
 struct WgradArgs {
     const float* x; const float* dz; float* part;
     int ldx, xoff, lddz, M, N, K, Cin, T_in, T_out, dilation, stride, pad_left, pad_mode, rows_per_split;
+    int F_in, F_out, KF, stride_f, pad_f;        // 2-D convs (zero padding): rows are (b, t, f), taps (kt, kf); F_in = F_out = KF = 1 for 1-D
 };
 
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
@@ -27,7 +28,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int n0 = blockIdx.y * 64 + wn * 32, k0 = blockIdx.x * 64 + wk * 32;
     const int m_begin = blockIdx.z * a.rows_per_split;
     const int m_end = min(a.M, m_begin + a.rows_per_split);
-    int nidx[2], kc[2], tapoff[2], ccol[2];
+    int nidx[2], kc[2], tapoff[2], tapf[2], ccol[2];
     bool nok[2], kok[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -35,7 +36,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         kc[q] = k0 + q * 16 + i; kok[q] = kc[q] < a.K;
         const int j = kok[q] ? kc[q] / a.Cin : 0;
         ccol[q] = kok[q] ? kc[q] - j * a.Cin : 0;
-        tapoff[q] = j * a.dilation - a.pad_left;
+        const int kt = j / a.KF;
+        tapoff[q] = kt * a.dilation - a.pad_left;
+        tapf[q] = (j - kt * a.KF) - a.pad_f;
     }
     f32x4 acc[2][2];
 #pragma unroll
@@ -43,7 +46,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
     int m = m_begin + kk;                       // this lane's row of the current 4-row step
-    int b = m / a.T_out, t = m - b * a.T_out;
+    int bt = m / a.F_out, f = m - bt * a.F_out;
+    int b = bt / a.T_out, t = bt - b * a.T_out;
     for (int ms = m_begin; ms < m_end; ms += 4) {
         const bool rok = m < m_end;
         float av[2], bv[2];
@@ -51,22 +55,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         for (int q = 0; q < 2; ++q) {
             av[q] = (rok && nok[q]) ? a.dz[(size_t)m * a.lddz + nidx[q]] : 0.f;
             const int traw = t * a.stride + tapoff[q];
+            const int fs = f * a.stride_f + tapf[q];
             int ts = traw;
-            bool ok = rok && kok[q];
+            bool ok = rok && kok[q] && fs >= 0 && fs < a.F_in;
             if (a.pad_mode == VP_PAD_REFLECT) {
                 ts = ts < 0 ? -ts : ts;
                 ts = ts >= a.T_in ? 2 * (a.T_in - 1) - ts : ts;
             } else {
                 ok = ok && traw >= 0 && traw < a.T_in;
-                ts = ok ? ts : 0;
             }
-            bv[q] = ok ? a.x[((size_t)b * a.T_in + ts) * a.ldx + a.xoff + ccol[q]] : 0.f;
+            bv[q] = ok ? a.x[(((size_t)b * a.T_in + ts) * a.F_in + fs) * a.ldx + a.xoff + ccol[q]] : 0.f;
         }
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
             for (int q = 0; q < 2; ++q) acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[p], bv[q], acc[p][q], 0, 0, 0);
-        m += 4; t += 4;
+        m += 4; f += 4;
+        while (f >= a.F_out) { f -= a.F_out; ++t; }
         while (t >= a.T_out) { t -= a.T_out; ++b; }
     }
     float* out = a.part + (size_t)blockIdx.z * a.N * a.K;
@@ -127,11 +132,21 @@ struct BnFinArgs {
     float* mean; float* invstd; float* scale; float* shift;
 };
 
+// One workgroup = 16 channels x 16 part-lanes: the nparts partial rows (tiles x segments: ~1200 at B = 256 x 3 s) are
+// summed 16 at a time with independent loads, then across the 16 lanes in fixed order.  (One thread per channel walking all
+// the parts serially took 336 us per call -- 10 ms of a 54 ms training step.)
 __global__ __launch_bounds__(256) void bn_train_finalize_kernel(BnFinArgs a) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= a.C) return;
+    __shared__ float sm[2][16][17];
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float s1 = 0.f, s2 = 0.f;
-    for (int k = 0; k < a.nparts; ++k) { s1 += a.psum[(size_t)k * a.C + c]; s2 += a.psumsq[(size_t)k * a.C + c]; }
+    if (c < a.C)
+        for (int k = pl; k < a.nparts; k += 16) { s1 += a.psum[(size_t)k * a.C + c]; s2 += a.psumsq[(size_t)k * a.C + c]; }
+    sm[0][pl][cl] = s1; sm[1][pl][cl] = s2;
+    __syncthreads();
+    if (pl != 0 || c >= a.C) return;
+    s1 = 0.f; s2 = 0.f;
+    for (int k = 0; k < 16; ++k) { s1 += sm[0][k][cl]; s2 += sm[1][k][cl]; }
     const float mu = s1 / (float)a.M;
     const float var = fmaxf(s2 / (float)a.M - mu * mu, 0.f);
     const float is = rsqrtf(var + a.eps);
@@ -145,14 +160,14 @@ __global__ __launch_bounds__(256) void bn_train_finalize_kernel(BnFinArgs a) {
 
 // y = z * scale + shift
 __global__ __launch_bounds__(256) void affine_rows_kernel(const float* z, int ldz, const float* scale, const float* shift, long long M,
-                                                          int C4, float* y, int ldy) {
+                                                          int C4, float* y, int ldy, int relu) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < M * C4; i += (long long)gridDim.x * 256) {
         const long long m = i / C4;
         const int c = (int)(i - m * C4) * 4;
         float v[4], s[4], h[4];
         vp_load4(z + m * ldz + c, v); vp_load4(scale + c, s); vp_load4(shift + c, h);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] * s[e] + h[e];
+        for (int e = 0; e < 4; ++e) { v[e] = v[e] * s[e] + h[e]; if (relu) v[e] = fmaxf(v[e], 0.f); }
         vp_store4(y + m * ldy + c, v);
     }
 }
@@ -325,13 +340,42 @@ __global__ __launch_bounds__(256) void scale_rows_bwd_kernel(const float* dy, co
     if (rg == 0 && c < C) ds[(size_t)b * C + c] = sm[0][lc] + sm[1][lc] + sm[2][lc] + sm[3][lc];
 }
 
+// up[b, t, f, :] = dz[b, t / s, f / s, :] when t and f are multiples of s (and in range), else 0: the zero-insertion that turns
+// the data gradient of a stride-s conv into a stride-1 conv over `up` (T_in x F_in positions).
+struct ZiArgs { const float* dz; float* up; int T_out, F_out, T_in, F_in, s, C4; long long total; };
+__global__ __launch_bounds__(256) void zero_insert_kernel(ZiArgs a) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.total; i += (long long)gridDim.x * 256) {
+        const long long pos = i / a.C4;
+        const int c = (int)(i - pos * a.C4) * 4;
+        const long long bt = pos / a.F_in;
+        const int f = (int)(pos - bt * a.F_in);
+        const long long b = bt / a.T_in;
+        const int t = (int)(bt - b * a.T_in);
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (t % a.s == 0 && f % a.s == 0 && t / a.s < a.T_out && f / a.s < a.F_out)
+            vp_load4(a.dz + (((size_t)b * a.T_out + t / a.s) * a.F_out + f / a.s) * a.C4 * 4 + c, v);
+        vp_store4(a.up + pos * a.C4 * 4 + c, v);
+    }
+}
+
+// dz = [y > 0] * dy   (ReLU backward from its output)
+__global__ __launch_bounds__(256) void relu_mask_kernel(const float* dy, const float* y, long long n4, float* dz) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float g[4], v[4];
+        vp_load4(dy + i * 4, g); vp_load4(y + i * 4, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = v[e] > 0.f ? g[e] : 0.f;
+        vp_store4(dz + i * 4, g);
+    }
+}
+
 // dz = dy * (1 - y^2)   (tanh backward from its output)
 __global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* dy, const float* y, long long n4, float* dz, int sigmoid) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         float g[4], v[4];
         vp_load4(dy + i * 4, g); vp_load4(y + i * 4, v);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) g[e] *= sigmoid ? v[e] * (1.f - v[e]) : 1.f - v[e] * v[e];
+        for (int e = 0; e < 4; ++e) g[e] *= sigmoid == 2 ? (v[e] > 0.f ? 1.f : 0.f) : (sigmoid ? v[e] * (1.f - v[e]) : 1.f - v[e] * v[e]);
         vp_store4(dz + i * 4, g);
     }
 }
@@ -340,7 +384,7 @@ __global__ __launch_bounds__(256) void tanh_fwd_kernel(const float* x, long long
         float v[4];
         vp_load4(x + i * 4, v);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = sigmoid ? 1.f / (1.f + expf(-v[e])) : tanhf(v[e]);
+        for (int e = 0; e < 4; ++e) v[e] = sigmoid == 2 ? fmaxf(v[e], 0.f) : (sigmoid ? 1.f / (1.f + expf(-v[e])) : tanhf(v[e]));
         vp_store4(y + i * 4, v);
     }
 }
@@ -356,7 +400,7 @@ extern "C" {
 
 size_t vp_conv1d_wgrad_workspace_bytes(const vp_conv1d_desc* d) {
     if (!d || d->Cout <= 0 || d->KW <= 0 || d->Cin <= 0) return 0;
-    const long long M = (long long)d->B * d->T_out;
+    const long long M = (long long)d->B * d->T_out * ((d->KF > 1 || d->F_in > 1 || d->F_out > 1) ? d->F_out : 1);
     const int K = d->KW * d->Cin;
     const int tiles = ((d->Cout + 63) / 64) * ((K + 63) / 64);
     int S = 2048 / tiles;
@@ -371,12 +415,14 @@ int vp_conv1d_wgrad_f32(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, i
                         vp_stream stream) {
     if (!ctx || !d || !d->x || !dz || !dW) VP_FAIL(ctx, VP_EINVAL, "wgrad: null argument");
     if (d->dtype_in != VP_F32) VP_FAIL(ctx, VP_EUNSUP, "wgrad: f32 engine only");
-    if (d->KF > 1 || d->F_in > 1 || d->F_out > 1) VP_FAIL(ctx, VP_EUNSUP, "wgrad: 1-D convs only");
+    const bool two_d = d->KF > 1 || d->F_in > 1 || d->F_out > 1;
+    if (two_d && (d->KF < 1 || d->KW % d->KF || d->F_in < 1 || d->F_out < 1 || d->stride_f < 1 || d->pad_mode != VP_PAD_ZERO))
+        VP_FAIL(ctx, VP_EINVAL, "wgrad: bad 2-D geometry (zero padding only)");
     if (d->B <= 0 || d->T_in <= 0 || d->T_out <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KW <= 0 || d->stride <= 0 || d->dilation <= 0)
         VP_FAIL(ctx, VP_EINVAL, "wgrad: bad shape");
     const size_t need = vp_conv1d_wgrad_workspace_bytes(d);
     if (!ws || ws_bytes < need) VP_FAIL(ctx, VP_EWORKSPACE, "wgrad: workspace %zu < %zu", ws_bytes, need);
-    const long long M = (long long)d->B * d->T_out;
+    const long long M = (long long)d->B * d->T_out * (two_d ? d->F_out : 1);
     if (M > 0x7fffffffLL / 2) VP_FAIL(ctx, VP_EINVAL, "wgrad: too many rows");
     const int K = d->KW * d->Cin;
     const int tn = (d->Cout + 63) / 64, tk = (K + 63) / 64;
@@ -392,6 +438,8 @@ int vp_conv1d_wgrad_f32(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, i
     a.ldx = d->ldx; a.xoff = d->xoff; a.lddz = lddz; a.M = (int)M; a.N = d->Cout; a.K = K; a.Cin = d->Cin;
     a.T_in = d->T_in; a.T_out = d->T_out; a.dilation = d->dilation; a.stride = d->stride; a.pad_left = d->pad_left;
     a.pad_mode = d->pad_mode; a.rows_per_split = rps;
+    a.F_in = two_d ? d->F_in : 1; a.F_out = two_d ? d->F_out : 1; a.KF = two_d ? d->KF : 1;
+    a.stride_f = two_d ? d->stride_f : 1; a.pad_f = two_d ? d->pad_f : 0;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tk, tn, S), dim3(256), 0, st, a);
     VP_LAUNCH_CHECK(ctx, "conv_wgrad");
@@ -431,15 +479,15 @@ int vp_bn_train_finalize(vp_ctx* ctx, const float* psum, const float* psumsq, in
     if (!ctx || !psum || !psumsq || nparts <= 0 || M <= 0 || C <= 0 || !mean || !invstd || !scale || !shift)
         VP_FAIL(ctx, VP_EINVAL, "bn_finalize: bad arguments");
     BnFinArgs a{psum, psumsq, nparts, (int)M, C, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift};
-    hipLaunchKernelGGL(bn_train_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(bn_train_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, a);
     VP_LAUNCH_CHECK(ctx, "bn_train_finalize");
     return VP_OK;
 }
 
 int vp_affine_rows_f32(vp_ctx* ctx, const float* z, int ldz, const float* scale, const float* shift, long long M, int C, float* y,
-                       int ldy, vp_stream stream) {
+                       int ldy, int relu, vp_stream stream) {
     if (!ctx || !z || !scale || !shift || !y || M <= 0 || C <= 0 || (C | ldz | ldy) & 3) VP_FAIL(ctx, VP_EINVAL, "affine_rows: bad arguments");
-    hipLaunchKernelGGL(affine_rows_kernel, dim3(grid1d(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, z, ldz, scale, shift, M, C / 4, y, ldy);
+    hipLaunchKernelGGL(affine_rows_kernel, dim3(grid1d(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, z, ldz, scale, shift, M, C / 4, y, ldy, relu);
     VP_LAUNCH_CHECK(ctx, "affine_rows");
     return VP_OK;
 }
@@ -496,15 +544,15 @@ int vp_attn_stats_bwd_f32(vp_ctx* ctx, const float* e, const float* x, int ldx, 
 }
 
 int vp_act_f32(vp_ctx* ctx, int act, const float* x, long long n, float* y, vp_stream stream) {
-    if (!ctx || !x || !y || n <= 0 || n & 3 || (act != VP_ACT_TANH && act != VP_ACT_SIGMOID)) VP_FAIL(ctx, VP_EINVAL, "act: bad arguments");
-    hipLaunchKernelGGL(tanh_fwd_kernel, dim3(grid1d(n / 4)), dim3(256), 0, (hipStream_t)stream, x, n / 4, y, act == VP_ACT_SIGMOID);
+    if (!ctx || !x || !y || n <= 0 || n & 3 || (act != VP_ACT_TANH && act != VP_ACT_SIGMOID && act != VP_ACT_RELU)) VP_FAIL(ctx, VP_EINVAL, "act: bad arguments");
+    hipLaunchKernelGGL(tanh_fwd_kernel, dim3(grid1d(n / 4)), dim3(256), 0, (hipStream_t)stream, x, n / 4, y, act == VP_ACT_SIGMOID ? 1 : (act == VP_ACT_RELU ? 2 : 0));
     VP_LAUNCH_CHECK(ctx, "act");
     return VP_OK;
 }
 
 int vp_act_bwd_f32(vp_ctx* ctx, int act, const float* dy, const float* y, long long n, float* dz, vp_stream stream) {
-    if (!ctx || !dy || !y || !dz || n <= 0 || n & 3 || (act != VP_ACT_TANH && act != VP_ACT_SIGMOID)) VP_FAIL(ctx, VP_EINVAL, "act_bwd: bad arguments");
-    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid1d(n / 4)), dim3(256), 0, (hipStream_t)stream, dy, y, n / 4, dz, act == VP_ACT_SIGMOID);
+    if (!ctx || !dy || !y || !dz || n <= 0 || n & 3 || (act != VP_ACT_TANH && act != VP_ACT_SIGMOID && act != VP_ACT_RELU)) VP_FAIL(ctx, VP_EINVAL, "act_bwd: bad arguments");
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid1d(n / 4)), dim3(256), 0, (hipStream_t)stream, dy, y, n / 4, dz, act == VP_ACT_SIGMOID ? 1 : (act == VP_ACT_RELU ? 2 : 0));
     VP_LAUNCH_CHECK(ctx, "act_bwd");
     return VP_OK;
 }
@@ -522,6 +570,23 @@ int vp_scale_rows_bwd_f32(vp_ctx* ctx, const float* dy, const float* x, const fl
     if (!ctx || !dy || !x || !s || !dx || !ds || B <= 0 || T <= 0 || C <= 0 || B > 65535) VP_FAIL(ctx, VP_EINVAL, "scale_rows_bwd: bad arguments");
     hipLaunchKernelGGL(scale_rows_bwd_kernel, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, dy, x, s, T, C, dx, ds);
     VP_LAUNCH_CHECK(ctx, "scale_rows_bwd");
+    return VP_OK;
+}
+
+int vp_zero_insert_2d_f32(vp_ctx* ctx, const float* dz, int B, int T_out, int F_out, int C, int T_in, int F_in, int stride, float* up,
+                          vp_stream stream) {
+    if (!ctx || !dz || !up || B <= 0 || T_out <= 0 || F_out <= 0 || T_in <= 0 || F_in <= 0 || stride < 1 || C <= 0 || C & 3)
+        VP_FAIL(ctx, VP_EINVAL, "zero_insert: bad arguments");
+    ZiArgs a{dz, up, T_out, F_out, T_in, F_in, stride, C / 4, (long long)B * T_in * F_in * (C / 4)};
+    hipLaunchKernelGGL(zero_insert_kernel, dim3(grid1d(a.total)), dim3(256), 0, (hipStream_t)stream, a);
+    VP_LAUNCH_CHECK(ctx, "zero_insert");
+    return VP_OK;
+}
+
+int vp_relu_bwd_f32(vp_ctx* ctx, const float* dy, const float* y, long long n, float* dz, vp_stream stream) {
+    if (!ctx || !dy || !y || !dz || n <= 0 || n & 3) VP_FAIL(ctx, VP_EINVAL, "relu_bwd: bad arguments");
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(grid1d(n / 4)), dim3(256), 0, (hipStream_t)stream, dy, y, n / 4, dz);
+    VP_LAUNCH_CHECK(ctx, "relu_bwd");
     return VP_OK;
 }
 

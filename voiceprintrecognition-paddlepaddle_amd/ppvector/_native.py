@@ -202,7 +202,7 @@ _PROTOS = {
                                 c_void_p, c_size_t, c_void_p]),
     'vp_bn_train_finalize': (c_int, [c_void_p, c_void_p, c_void_p, c_int, C.c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    'vp_affine_rows_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, C.c_longlong, c_int, c_void_p, c_int, c_void_p]),
+    'vp_affine_rows_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, C.c_longlong, c_int, c_void_p, c_int, c_int, c_void_p]),
     'vp_bn_relu_bwd_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, C.c_longlong,
                                    c_int, c_int, c_void_p, c_int, c_void_p]),
     'vp_adam_step_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_longlong, c_float, c_float, c_float, c_float,
@@ -214,6 +214,8 @@ _PROTOS = {
                                       c_void_p, c_int, c_void_p]),
     'vp_act_f32': (c_int, [c_void_p, c_int, c_void_p, C.c_longlong, c_void_p, c_void_p]),
     'vp_act_bwd_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, C.c_longlong, c_void_p, c_void_p]),
+    'vp_zero_insert_2d_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'vp_relu_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, C.c_longlong, c_void_p, c_void_p]),
     'vp_reflect_fold_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'vp_scale_rows_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'vp_aam_ce_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_float, c_void_p,

@@ -93,3 +93,11 @@ class ResNetSE(EngineMixin, nn.Module):
         for _ in range(1, blocks):
             layers.append(block(self.inplanes, planes))
         return nn.Sequential(*layers)
+
+    def _train_forward(self, x):
+        """Training mode: batch-statistics BatchNorm, autograd through libvpmi's backward entry points (f32 engine)."""
+        from ppvector import _native as N
+        from ppvector.train.resnetse_train import resnetse_forward_train
+        if not x.is_cuda:
+            raise N.VpmiError('model input must be a GPU tensor: the engine has no CPU fallback')
+        return resnetse_forward_train(self, x.float().contiguous())

@@ -79,12 +79,17 @@ class ConvBlock(torch.autograd.Function):
         d = _conv_desc(x, B, T_in, T_out, Cin, Cout, KW, dil, _PAD[pad], pad_left, wp, bias, rowbias, relu)
         d.y = z.data_ptr()
         ps = pq = None
-        if bn:
+        if bn and lib.vp_conv1d_nseg(T_out) <= 8:              # the conv's fused column sums (utterances >= ~19 frames)
             tiles, nseg = lib.vp_conv1d_tiles_m(B, T_out), lib.vp_conv1d_nseg(T_out)
             ps = torch.empty((tiles * nseg, Cout), dtype=torch.float32, device=x.device)
             pq = torch.empty_like(ps)
             d.psum, d.psumsq = ps.data_ptr(), pq.data_ptr()
         _chk(lib.vp_conv1d_fwd(hctx, C.byref(d), N.stream_ptr()), hctx)
+        if bn and ps is None:                                   # very short utterances: a separate column-sum pass
+            zeros = torch.zeros(Cout, dtype=torch.float32, device=x.device)
+            ones = torch.ones(Cout, dtype=torch.float32, device=x.device)
+            sums = col_sums(z, z, zeros, ones)
+            ps, pq = sums[0:1], sums[1:2]
         mean = invstd = None
         y = z
         if bn:
@@ -96,7 +101,7 @@ class ConvBlock(torch.autograd.Function):
                                           shift.data_ptr(), N.stream_ptr()), hctx)
             y = torch.empty_like(z)
             _chk(lib.vp_affine_rows_f32(hctx, z.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(), B * T_out, Cout,
-                                        y.data_ptr(), Cout, N.stream_ptr()), hctx)
+                                        y.data_ptr(), Cout, 0, N.stream_ptr()), hctx)
         if tanh:
             yt = torch.empty_like(y)
             _chk(lib.vp_act_f32(hctx, tanh, y.data_ptr(), y.numel(), yt.data_ptr(), N.stream_ptr()), hctx)
@@ -260,7 +265,7 @@ class BNRows(torch.autograd.Function):
                                       run_var.data_ptr() if run_var is not None else None, momentum, eps, mean.data_ptr(),
                                       invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), N.stream_ptr()), hctx)
         y = torch.empty_like(x)
-        _chk(lib.vp_affine_rows_f32(hctx, x.data_ptr(), Cc, scale.data_ptr(), shift.data_ptr(), M, Cc, y.data_ptr(), Cc,
+        _chk(lib.vp_affine_rows_f32(hctx, x.data_ptr(), Cc, scale.data_ptr(), shift.data_ptr(), M, Cc, y.data_ptr(), Cc, 0,
                                     N.stream_ptr()), hctx)
         ctx.save_for_backward(x, mean, invstd, gamma)
         return y
@@ -353,3 +358,90 @@ class AamCe(torch.autograd.Function):
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
         return dl * g, None, None, None, None, None
+
+
+class Conv2dBlock(torch.autograd.Function):
+    """2-D conv over (B, T, F, C) positions (zero padding (k-1)/2, stride s on both axes) [-> BatchNorm (batch statistics)]
+    [-> ReLU]: the Conv2D -> BatchNorm2D -> ReLU units of models/resnet_se.py:8-45,72-74 (BN BEFORE the ReLU, unlike TDNNBlock).
+    x (B*T*F, Cin) f32, weight (Cout, Cin, kF, kT) as stored by the reference."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, run_mean, run_var, cfg):
+        lib, hctx = N.lib(), N.ctx(x.device)
+        x, weight = _f32c(x), _f32c(weight)
+        B, T, Fq, s = cfg['B'], cfg['T'], cfg['F'], cfg.get('stride', 1)
+        Cout, Cin, KF, KT = weight.shape
+        if KF != KT or KF not in (1, 3):
+            raise NotImplementedError('Conv2dBlock: 1x1 and 3x3 kernels only')
+        pad = (KF - 1) // 2
+        To, Fo = (T + 2 * pad - KT) // s + 1, (Fq + 2 * pad - KF) // s + 1
+        relu, bn = cfg.get('relu', False), gamma is not None
+        wp = weight.permute(0, 3, 2, 1).reshape(Cout, KT * KF * Cin).contiguous()
+        z = torch.empty((B * To * Fo, Cout), dtype=torch.float32, device=x.device)
+        d = _conv_desc(x, B, T, To, Cin, Cout, KT * KF, 1, N.VP_PAD_ZERO, pad, wp, bias)
+        d.F_in, d.F_out, d.KF, d.stride, d.stride_f, d.pad_f = Fq, Fo, KF, s, s, pad
+        d.y = z.data_ptr()
+        _chk(lib.vp_conv1d_fwd(hctx, C.byref(d), N.stream_ptr()), hctx)
+        mean = invstd = None
+        y = z
+        if bn:
+            zeros = torch.zeros(Cout, dtype=torch.float32, device=x.device)
+            ones = torch.ones(Cout, dtype=torch.float32, device=x.device)
+            sums = col_sums(z, z, zeros, ones)
+            mean, invstd, scale, shift = (torch.empty(Cout, dtype=torch.float32, device=x.device) for _ in range(4))
+            _chk(lib.vp_bn_train_finalize(hctx, sums[0].data_ptr(), sums[1].data_ptr(), 1, z.shape[0], Cout, gamma.data_ptr(),
+                                          beta.data_ptr(), run_mean.data_ptr() if run_mean is not None else None,
+                                          run_var.data_ptr() if run_var is not None else None, cfg.get('momentum', 0.9),
+                                          cfg.get('eps', 1e-5), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
+                                          shift.data_ptr(), N.stream_ptr()), hctx)
+            y = torch.empty_like(z)
+            _chk(lib.vp_affine_rows_f32(hctx, z.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(), z.shape[0], Cout, y.data_ptr(),
+                                        Cout, int(relu), N.stream_ptr()), hctx)
+        elif relu:
+            y = torch.empty_like(z)
+            _chk(lib.vp_act_f32(hctx, N.VP_ACT_RELU, z.data_ptr(), z.numel(), y.data_ptr(), N.stream_ptr()), hctx)
+        ctx.save_for_backward(x, weight, z, mean, invstd, gamma, y if relu else None)
+        ctx.geom = (B, T, Fq, To, Fo, Cin, Cout, KT, KF, s, pad, relu, bn, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, z, mean, invstd, gamma, yr = ctx.saved_tensors
+        B, T, Fq, To, Fo, Cin, Cout, KT, KF, s, pad, relu, bn, has_bias = ctx.geom
+        lib, hctx = N.lib(), N.ctx(x.device)
+        dev = x.device
+        dy = _f32c(dy)
+        M = B * To * Fo
+        if relu:
+            t = torch.empty_like(dy)
+            _chk(lib.vp_act_bwd_f32(hctx, N.VP_ACT_RELU, dy.data_ptr(), yr.data_ptr(), dy.numel(), t.data_ptr(), N.stream_ptr()), hctx)
+            dy = t
+        dgamma = dbeta = None
+        dz = dy
+        if bn:
+            sums = col_sums(dy, z, mean, invstd)
+            dgamma, dbeta = sums[1].clone(), sums[0].clone()
+            dz = torch.empty_like(dy)
+            _chk(lib.vp_bn_relu_bwd_f32(hctx, dy.data_ptr(), Cout, z.data_ptr(), Cout, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                                        sums.data_ptr(), M, Cout, 0, dz.data_ptr(), Cout, N.stream_ptr()), hctx)
+        dbias = col_sums(dz)[0].clone() if has_bias else None
+        d = _conv_desc(x, B, T, To, Cin, Cout, KT * KF, 1, N.VP_PAD_ZERO, pad, weight)
+        d.F_in, d.F_out, d.KF, d.stride, d.stride_f, d.pad_f = Fq, Fo, KF, s, s, pad
+        dwp = torch.empty((Cout, KT * KF * Cin), dtype=torch.float32, device=dev)
+        ws = _bytes(lib.vp_conv1d_wgrad_workspace_bytes(C.byref(d)), dev)
+        _chk(lib.vp_conv1d_wgrad_f32(hctx, C.byref(d), dz.data_ptr(), Cout, dwp.data_ptr(), ws.data_ptr(), ws.numel(), N.stream_ptr()), hctx)
+        dW = dwp.view(Cout, KT, KF, Cin).permute(0, 3, 2, 1).contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            src = dz
+            if s > 1:                                   # zero-insertion: the stride-s data gradient as a stride-1 conv
+                src = torch.empty((B * T * Fq, Cout), dtype=torch.float32, device=dev)
+                _chk(lib.vp_zero_insert_2d_f32(hctx, dz.data_ptr(), B, To, Fo, Cout, T, Fq, s, src.data_ptr(), N.stream_ptr()), hctx)
+            w2 = weight.flip(2, 3).permute(1, 3, 2, 0).reshape(Cin, KT * KF * Cout).contiguous()
+            dx = torch.empty((B * T * Fq, Cin), dtype=torch.float32, device=dev)
+            Ts, Fs = (T, Fq) if s > 1 else (To, Fo)
+            d2 = _conv_desc(src, B, Ts, T, Cout, Cin, KT * KF, 1, N.VP_PAD_ZERO, KT - 1 - pad, w2)
+            d2.F_in, d2.F_out, d2.KF, d2.stride, d2.stride_f, d2.pad_f = Fs, Fq, KF, 1, 1, KF - 1 - pad
+            d2.y = dx.data_ptr()
+            _chk(lib.vp_conv1d_fwd(hctx, C.byref(d2), N.stream_ptr()), hctx)
+        return dx, dW, dbias, dgamma, dbeta, None, None, None
