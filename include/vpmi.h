@@ -442,12 +442,13 @@ int vp_adam_step_f32(vp_ctx* ctx, float* param, const float* grad, float* m, flo
  * statistics [mean | sqrt(max(var, eps))] and their backward, the backward of softmax-over-time + weighted mean/std
  * (forward = vp_asp_softmax_stats), tanh / sigmoid and their backward.  e (B*T, C) f32 logits, x (B*T, ldx) f32, pooled (B, 2C). */
 int vp_utt_sums_f32(vp_ctx* ctx, const float* a, int lda, int B, int T, int C, float* out, vp_stream stream);
-int vp_time_stats_f32(vp_ctx* ctx, const float* x, int ldx, int B, int T, int C, float eps, float* stats, vp_stream stream);
+int vp_time_stats_f32(vp_ctx* ctx, const float* x, int ldx, int B, int T, int C, float eps, int unbiased /* 1: TSTP, sqrt(var_unbiased + eps) */,
+                      float* stats, vp_stream stream);
 int vp_time_stats_bwd_f32(vp_ctx* ctx, const float* x, int ldx, const float* stats, const float* dstats, int B, int T, int C, float eps,
-                          float* dx, int lddx, vp_stream stream);
+                          int unbiased, float* dx, int lddx, vp_stream stream);
 int vp_attn_stats_bwd_f32(vp_ctx* ctx, const float* e, const float* x, int ldx, const float* pooled, const float* dpooled, int B, int T,
                           int C, float eps, float* de, float* dx, int lddx, vp_stream stream);
-int vp_act_f32(vp_ctx* ctx, int act /* VP_ACT_TANH | VP_ACT_SIGMOID | VP_ACT_RELU */, const float* x, long long n, float* y, vp_stream stream);
+int vp_act_f32(vp_ctx* ctx, int act /* VP_ACT_RELU .. VP_ACT_SILU; the backward takes the OUTPUT y, except SiLU: the input */, const float* x, long long n, float* y, vp_stream stream);
 int vp_act_bwd_f32(vp_ctx* ctx, int act, const float* dy, const float* y, long long n, float* dz, vp_stream stream);
 /* vp_reflect_fold_f32: adjoint of the reflect padding of Conv1d (models/utils.py:89-91): dxp (B, T + 2 pad, C) -> dx (B, T, C).
  * vp_scale_rows_bwd_f32: backward of the SE gate x * s (ecapa_tdnn.py:82): dx = dy * s, ds[b] = sum_t dy * x. */
@@ -456,6 +457,10 @@ int vp_act_bwd_f32(vp_ctx* ctx, int act, const float* dy, const float* y, long l
 int vp_zero_insert_2d_f32(vp_ctx* ctx, const float* dz, int B, int T_out, int F_out, int C, int T_in, int F_in, int stride, float* up,
                           vp_stream stream);
 int vp_relu_bwd_f32(vp_ctx* ctx, const float* dy, const float* y, long long n, float* dz, vp_stream stream);
+/* AFF output (eres2net.py:48-51) and its backward: o = x (1 + t) + y (1 - t) on dense (rows, C) f32 tensors. */
+int vp_aff_combine_f32(vp_ctx* ctx, const float* t, const float* x, const float* y, long long rows, int C, float* out, vp_stream stream);
+int vp_aff_combine_bwd_f32(vp_ctx* ctx, const float* g, const float* t, const float* x, const float* y, long long n, float* dx, float* dy,
+                           float* dt, vp_stream stream);
 int vp_reflect_fold_f32(vp_ctx* ctx, const float* dxp, int B, int T, int pad, int C, float* dx, vp_stream stream);
 int vp_scale_rows_bwd_f32(vp_ctx* ctx, const float* dy, const float* x, const float* s, int B, int T, int C, float* dx, float* ds,
                           vp_stream stream);

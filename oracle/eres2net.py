@@ -28,17 +28,17 @@ def _c2d(x, p, pre, stride=1, padding=0):
     return F.conv2d(x, p[pre + 'weight'], p[pre + 'bias'], stride=stride, padding=padding)
 
 
-def aff(x, y, p, pre):
+def aff(x, y, p, pre, training=False):
     a = torch.cat((x, y), dim=1)
-    a = _bn(_c2d(a, p, pre + 'local_att.0.'), p, pre + 'local_att.1.')
+    a = _bn(_c2d(a, p, pre + 'local_att.0.'), p, pre + 'local_att.1.', training)
     a = a * torch.sigmoid(a)
-    a = _bn(_c2d(a, p, pre + 'local_att.3.'), p, pre + 'local_att.4.')
+    a = _bn(_c2d(a, p, pre + 'local_att.3.'), p, pre + 'local_att.4.', training)
     att = 1.0 + torch.tanh(a)
     return x * att + y * (2.0 - att)
 
 
-def block(x, p, pre, stride, width, scale, fuse):
-    out = _ht(_bn(_c2d(x, p, pre + 'conv1.', stride=stride), p, pre + 'bn1.'))
+def block(x, p, pre, stride, width, scale, fuse, training=False):
+    out = _ht(_bn(_c2d(x, p, pre + 'conv1.', stride=stride), p, pre + 'bn1.', training))
     spx = torch.split(out, width, dim=1)
     outs = []
     sp = None
@@ -46,14 +46,14 @@ def block(x, p, pre, stride, width, scale, fuse):
         if i == 0:
             sp = spx[0]
         elif fuse:
-            sp = aff(sp, spx[i], p, f'{pre}fuse_models.{i - 1}.')
+            sp = aff(sp, spx[i], p, f'{pre}fuse_models.{i - 1}.', training)
         else:
             sp = sp + spx[i]
-        sp = _ht(_bn(_c2d(sp, p, f'{pre}convs.{i}.', padding=1), p, f'{pre}bns.{i}.'))
+        sp = _ht(_bn(_c2d(sp, p, f'{pre}convs.{i}.', padding=1), p, f'{pre}bns.{i}.', training))
         outs.append(sp)
-    out = _bn(_c2d(torch.cat(outs, dim=1), p, pre + 'conv3.'), p, pre + 'bn3.')
+    out = _bn(_c2d(torch.cat(outs, dim=1), p, pre + 'conv3.'), p, pre + 'bn3.', training)
     if (pre + 'shortcut.0.weight') in p:
-        res = _bn(_c2d(x, p, pre + 'shortcut.0.', stride=stride), p, pre + 'shortcut.1.')
+        res = _bn(_c2d(x, p, pre + 'shortcut.0.', stride=stride), p, pre + 'shortcut.1.', training)
     else:
         res = x
     return _ht(out + res)
@@ -65,21 +65,21 @@ def tstp(x):
     return torch.cat((mean.flatten(1), std.flatten(1)), dim=1)
 
 
-def eres2net_forward(p, x, num_blocks=(3, 4, 6, 3), m_channels=32, expansion=2, base_width=32, scale=2, taps=None):
+def eres2net_forward(p, x, num_blocks=(3, 4, 6, 3), m_channels=32, expansion=2, base_width=32, scale=2, taps=None, training=False):
     """ERes2Net.forward (eres2net.py:239-263), TSTP, two_emb_layer=False, eval mode.  x (B, T, F) -> (B, embd)."""
     x = x.transpose(1, 2).unsqueeze(1)
-    out = F.relu(_bn(_c2d(x, p, 'conv1.', padding=1), p, 'bn1.'))
+    out = F.relu(_bn(_c2d(x, p, 'conv1.', padding=1), p, 'bn1.', training))
     stage = []
     for li, (n, mult) in enumerate(zip(num_blocks, (1, 2, 4, 8)), start=1):
         planes = m_channels * mult
         width = int(math.floor(planes * (base_width / 64.0)))
         for bi in range(n):
-            out = block(out, p, f'layer{li}.{bi}.', (1 if li == 1 else 2) if bi == 0 else 1, width, scale, fuse=li >= 3)
+            out = block(out, p, f'layer{li}.{bi}.', (1 if li == 1 else 2) if bi == 0 else 1, width, scale, li >= 3, training)
         stage.append(out)
     o1, o2, o3, o4 = stage
-    f12 = aff(o2, _c2d(o1, p, 'layer1_downsample.', stride=2, padding=1), p, 'fuse_mode12.')
-    f123 = aff(o3, _c2d(f12, p, 'layer2_downsample.', stride=2, padding=1), p, 'fuse_mode123.')
-    f1234 = aff(o4, _c2d(f123, p, 'layer3_downsample.', stride=2, padding=1), p, 'fuse_mode1234.')
+    f12 = aff(o2, _c2d(o1, p, 'layer1_downsample.', stride=2, padding=1), p, 'fuse_mode12.', training)
+    f123 = aff(o3, _c2d(f12, p, 'layer2_downsample.', stride=2, padding=1), p, 'fuse_mode123.', training)
+    f1234 = aff(o4, _c2d(f123, p, 'layer3_downsample.', stride=2, padding=1), p, 'fuse_mode1234.', training)
     if taps is not None:
         taps.update(o1=o1, o2=o2, o3=o3, o4=o4, f12=f12, f123=f123, f1234=f1234)
     stats = tstp(f1234)

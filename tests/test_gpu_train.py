@@ -365,3 +365,43 @@ def test_resnetse_training_step_vs_oracle_autograd(N):
         assert r < 5e-3, (k, r)
     print(f'[resnetse train] loss {loss.item():.5f} (oracle {loss_ref.item():.5f}); worst parameter-gradient rel-L2 {worst:.2e} ({wk})')
     m.eval()
+
+
+def test_eres2net_training_step_vs_oracle_autograd(N):
+    """ERes2Net (configs/eres2net.yml architecture, one block per stage): both block kinds, the AFFs, the stride-2 fusion
+    convs and TSTP, against autograd over the oracle graph."""
+    from oracle import eres2net as oer
+    from ppvector.models.eres2net import ERes2Net
+    from ppvector.train.functions import HeadLoss
+    B, T, Fdim, Cc = 3, 20, 16, 10
+    nb = (1, 1, 1, 1)
+    p = oer.eres2net_params(Fdim, 192, num_blocks=nb, seed=13)
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(B, T, Fdim, generator=g) * 2
+    labels = torch.randint(0, Cc, (B,), generator=g)
+    Wh = om.head_params(192, Cc, seed=3)
+    pr = {k: v.clone().double().requires_grad_(not k.endswith(('_mean', '_variance'))) for k, v in p.items()}
+    Wr = Wh.clone().double().requires_grad_()
+    emb_ref = oer.eres2net_forward(pr, x.double(), num_blocks=nb, training=True)
+    loss_ref = om.aam_loss(om.cosine_head(emb_ref, Wr), labels, 0.2, 32.0, False, 0.0)
+    loss_ref.backward()
+    m = ERes2Net(Fdim, num_blocks=list(nb))
+    m.load_state_dict(p)
+    m = m.cuda().train()
+    Wd = Wh.cuda().requires_grad_()
+    emb = m(x.cuda())
+    assert rel(emb, emb_ref.detach()) < 1e-4
+    loss = HeadLoss.apply(emb, Wd, labels.cuda(), 0.2, 32.0, 0.0, False)
+    assert abs(loss.item() - loss_ref.item()) < 5e-4 * abs(loss_ref.item())
+    loss.backward()
+    worst, wk = 0.0, ''
+    for k, v in m.named_parameters():
+        if pr[k].grad is None or pr[k].grad.norm().item() < 1e-9:
+            assert v.grad is None or v.grad.abs().max().item() < 1e-4, k
+            continue
+        r = rel(v.grad, pr[k].grad)
+        if r > worst:
+            worst, wk = r, k
+        assert r < 5e-3, (k, r)
+    print(f'[eres2net train] loss {loss.item():.5f} (oracle {loss_ref.item():.5f}); worst parameter-gradient rel-L2 {worst:.2e} ({wk})')
+    m.eval()

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void utt_sums_kernel(const float* a, int lda, 
 
 // Backward of stats[b] = [mean_t x | sqrt(max(var_biased_t x, eps))] (pooling.py:97-104 with a mask of ones):
 // dx[b,t,c] = dmean / T + [var > eps] * dstd / std * (x - mean) / T
-struct TsBwdArgs { const float* x; const float* stats; const float* dstats; float* dx; int ldx, lddx, T, C4; float eps; long long total; };
+struct TsBwdArgs { const float* x; const float* stats; const float* dstats; float* dx; int ldx, lddx, T, C4; float eps; long long total; int unbiased; };
 __global__ __launch_bounds__(256) void time_stats_bwd_kernel(TsBwdArgs a) {
     const int C = a.C4 * 4;
     const float invT = 1.f / (float)a.T;
@@ -244,7 +244,8 @@ __global__ __launch_bounds__(256) void time_stats_bwd_kernel(TsBwdArgs a) {
         vp_load4(a.dstats + b * 2 * C + c, dm); vp_load4(a.dstats + b * 2 * C + C + c, ds);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            o[e] = dm[e] * invT + ((sd[e] * sd[e] > a.eps) ? ds[e] / sd[e] * (x[e] - mu[e]) * invT : 0.f);
+            o[e] = a.unbiased ? dm[e] * invT + ds[e] / sd[e] * (x[e] - mu[e]) / (float)(a.T > 1 ? a.T - 1 : 1)      // sd = sqrt(var_unbiased + eps)
+                              : dm[e] * invT + ((sd[e] * sd[e] > a.eps) ? ds[e] / sd[e] * (x[e] - mu[e]) * invT : 0.f);
         vp_store4(a.dx + m * a.lddx + c, o);
     }
 }
@@ -369,13 +370,32 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(const float* dy, const f
     }
 }
 
+// Backward of the AFF output o = x (1 + t) + y (1 - t) (eres2net.py:48-51, t = tanh(local_att)): dx = g (1 + t), dy = g (1 - t), dt = g (x - y)
+__global__ __launch_bounds__(256) void aff_combine_bwd_kernel(const float* g, const float* t, const float* x, const float* y, long long n4,
+                                                              float* dx, float* dy, float* dt) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float gv[4], tv[4], xv[4], yv[4], a[4], b[4], c[4];
+        vp_load4(g + i * 4, gv); vp_load4(t + i * 4, tv); vp_load4(x + i * 4, xv); vp_load4(y + i * 4, yv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = gv[e] * (1.f + tv[e]); b[e] = gv[e] * (1.f - tv[e]); c[e] = gv[e] * (xv[e] - yv[e]); }
+        vp_store4(dx + i * 4, a); vp_store4(dy + i * 4, b); vp_store4(dt + i * 4, c);
+    }
+}
+
 // dz = dy * (1 - y^2)   (tanh backward from its output)
 __global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* dy, const float* y, long long n4, float* dz, int sigmoid) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         float g[4], v[4];
         vp_load4(dy + i * 4, g); vp_load4(y + i * 4, v);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) g[e] *= sigmoid == 2 ? (v[e] > 0.f ? 1.f : 0.f) : (sigmoid ? v[e] * (1.f - v[e]) : 1.f - v[e] * v[e]);
+        for (int e = 0; e < 4; ++e) {
+            float d;
+            if (sigmoid == 2) d = v[e] > 0.f ? 1.f : 0.f;
+            else if (sigmoid == 3) d = (v[e] > 0.f && v[e] < 20.f) ? 1.f : 0.f;
+            else if (sigmoid == 4) { const float sg = 1.f / (1.f + expf(-v[e])); d = sg * (1.f + v[e] * (1.f - sg)); }   // v = the INPUT
+            else d = sigmoid ? v[e] * (1.f - v[e]) : 1.f - v[e] * v[e];
+            g[e] *= d;
+        }
         vp_store4(dz + i * 4, g);
     }
 }
@@ -384,9 +404,18 @@ __global__ __launch_bounds__(256) void tanh_fwd_kernel(const float* x, long long
         float v[4];
         vp_load4(x + i * 4, v);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = sigmoid == 2 ? fmaxf(v[e], 0.f) : (sigmoid ? 1.f / (1.f + expf(-v[e])) : tanhf(v[e]));
+        for (int e = 0; e < 4; ++e) {
+            if (sigmoid == 2) v[e] = fmaxf(v[e], 0.f);
+            else if (sigmoid == 3) v[e] = fminf(fmaxf(v[e], 0.f), 20.f);
+            else if (sigmoid == 4) v[e] = v[e] / (1.f + expf(-v[e]));
+            else v[e] = sigmoid ? 1.f / (1.f + expf(-v[e])) : tanhf(v[e]);
+        }
         vp_store4(y + i * 4, v);
     }
+}
+
+int act_kind(int act) {
+    return act == VP_ACT_SIGMOID ? 1 : act == VP_ACT_RELU ? 2 : act == VP_ACT_HARDTANH20 ? 3 : act == VP_ACT_SILU ? 4 : 0;
 }
 
 unsigned grid1d(long long total) {
@@ -520,15 +549,15 @@ int vp_utt_sums_f32(vp_ctx* ctx, const float* a, int lda, int B, int T, int C, f
     return VP_OK;
 }
 
-int vp_time_stats_f32(vp_ctx* ctx, const float* x, int ldx, int B, int T, int C, float eps, float* stats, vp_stream stream) {
+int vp_time_stats_f32(vp_ctx* ctx, const float* x, int ldx, int B, int T, int C, float eps, int unbiased, float* stats, vp_stream stream) {
     if (!ctx || !x || !stats || B <= 0 || T <= 0 || C <= 0) VP_FAIL(ctx, VP_EINVAL, "time_stats: bad arguments");
-    return vp_time_moments(ctx, VP_F32, x, ldx, B, T, C, eps, 0, stats, (hipStream_t)stream);
+    return vp_time_moments(ctx, VP_F32, x, ldx, B, T, C, eps, unbiased, stats, (hipStream_t)stream);
 }
 
 int vp_time_stats_bwd_f32(vp_ctx* ctx, const float* x, int ldx, const float* stats, const float* dstats, int B, int T, int C, float eps,
-                          float* dx, int lddx, vp_stream stream) {
+                          int unbiased, float* dx, int lddx, vp_stream stream) {
     if (!ctx || !x || !stats || !dstats || !dx || B <= 0 || T <= 0 || C <= 0 || (C | ldx | lddx) & 3) VP_FAIL(ctx, VP_EINVAL, "time_stats_bwd: bad arguments");
-    TsBwdArgs a{x, stats, dstats, dx, ldx, lddx, T, C / 4, eps, (long long)B * T * (C / 4)};
+    TsBwdArgs a{x, stats, dstats, dx, ldx, lddx, T, C / 4, eps, (long long)B * T * (C / 4), unbiased};
     hipLaunchKernelGGL(time_stats_bwd_kernel, dim3(grid1d(a.total)), dim3(256), 0, (hipStream_t)stream, a);
     VP_LAUNCH_CHECK(ctx, "time_stats_bwd");
     return VP_OK;
@@ -544,15 +573,15 @@ int vp_attn_stats_bwd_f32(vp_ctx* ctx, const float* e, const float* x, int ldx, 
 }
 
 int vp_act_f32(vp_ctx* ctx, int act, const float* x, long long n, float* y, vp_stream stream) {
-    if (!ctx || !x || !y || n <= 0 || n & 3 || (act != VP_ACT_TANH && act != VP_ACT_SIGMOID && act != VP_ACT_RELU)) VP_FAIL(ctx, VP_EINVAL, "act: bad arguments");
-    hipLaunchKernelGGL(tanh_fwd_kernel, dim3(grid1d(n / 4)), dim3(256), 0, (hipStream_t)stream, x, n / 4, y, act == VP_ACT_SIGMOID ? 1 : (act == VP_ACT_RELU ? 2 : 0));
+    if (!ctx || !x || !y || n <= 0 || n & 3 || act < VP_ACT_RELU || act > VP_ACT_SILU) VP_FAIL(ctx, VP_EINVAL, "act: bad arguments");
+    hipLaunchKernelGGL(tanh_fwd_kernel, dim3(grid1d(n / 4)), dim3(256), 0, (hipStream_t)stream, x, n / 4, y, act_kind(act));
     VP_LAUNCH_CHECK(ctx, "act");
     return VP_OK;
 }
 
 int vp_act_bwd_f32(vp_ctx* ctx, int act, const float* dy, const float* y, long long n, float* dz, vp_stream stream) {
-    if (!ctx || !dy || !y || !dz || n <= 0 || n & 3 || (act != VP_ACT_TANH && act != VP_ACT_SIGMOID && act != VP_ACT_RELU)) VP_FAIL(ctx, VP_EINVAL, "act_bwd: bad arguments");
-    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid1d(n / 4)), dim3(256), 0, (hipStream_t)stream, dy, y, n / 4, dz, act == VP_ACT_SIGMOID ? 1 : (act == VP_ACT_RELU ? 2 : 0));
+    if (!ctx || !dy || !y || !dz || n <= 0 || n & 3 || act < VP_ACT_RELU || act > VP_ACT_SILU) VP_FAIL(ctx, VP_EINVAL, "act_bwd: bad arguments");
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid1d(n / 4)), dim3(256), 0, (hipStream_t)stream, dy, y, n / 4, dz, act_kind(act));
     VP_LAUNCH_CHECK(ctx, "act_bwd");
     return VP_OK;
 }
@@ -587,6 +616,19 @@ int vp_relu_bwd_f32(vp_ctx* ctx, const float* dy, const float* y, long long n, f
     if (!ctx || !dy || !y || !dz || n <= 0 || n & 3) VP_FAIL(ctx, VP_EINVAL, "relu_bwd: bad arguments");
     hipLaunchKernelGGL(relu_mask_kernel, dim3(grid1d(n / 4)), dim3(256), 0, (hipStream_t)stream, dy, y, n / 4, dz);
     VP_LAUNCH_CHECK(ctx, "relu_bwd");
+    return VP_OK;
+}
+
+int vp_aff_combine_f32(vp_ctx* ctx, const float* t, const float* x, const float* y, long long rows, int C, float* out, vp_stream stream) {
+    if (!ctx || !t || !x || !y || !out || rows <= 0 || C <= 0 || C & 3) VP_FAIL(ctx, VP_EINVAL, "aff_combine: bad arguments");
+    return vp_aff_combine(ctx, VP_F32, t, C, x, C, 0, y, C, 0, out, C, 0, rows, C, (hipStream_t)stream);
+}
+
+int vp_aff_combine_bwd_f32(vp_ctx* ctx, const float* g, const float* t, const float* x, const float* y, long long n, float* dx, float* dy,
+                           float* dt, vp_stream stream) {
+    if (!ctx || !g || !t || !x || !y || !dx || !dy || !dt || n <= 0 || n & 3) VP_FAIL(ctx, VP_EINVAL, "aff_combine_bwd: bad arguments");
+    hipLaunchKernelGGL(aff_combine_bwd_kernel, dim3(grid1d(n / 4)), dim3(256), 0, (hipStream_t)stream, g, t, x, y, n / 4, dx, dy, dt);
+    VP_LAUNCH_CHECK(ctx, "aff_combine_bwd");
     return VP_OK;
 }
 

@@ -208,14 +208,16 @@ _PROTOS = {
     'vp_adam_step_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_longlong, c_float, c_float, c_float, c_float,
                                  c_float, c_int, c_float, c_void_p]),
     'vp_utt_sums_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    'vp_time_stats_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
-    'vp_time_stats_bwd_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
+    'vp_time_stats_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
+    'vp_time_stats_bwd_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_int, c_void_p]),
     'vp_attn_stats_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
                                       c_void_p, c_int, c_void_p]),
     'vp_act_f32': (c_int, [c_void_p, c_int, c_void_p, C.c_longlong, c_void_p, c_void_p]),
     'vp_act_bwd_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, C.c_longlong, c_void_p, c_void_p]),
     'vp_zero_insert_2d_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'vp_relu_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, C.c_longlong, c_void_p, c_void_p]),
+    'vp_aff_combine_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_longlong, c_int, c_void_p, c_void_p]),
+    'vp_aff_combine_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_longlong, c_void_p, c_void_p, c_void_p, c_void_p]),
     'vp_reflect_fold_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'vp_scale_rows_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'vp_aam_ce_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_float, c_void_p,

@@ -119,6 +119,15 @@ class ERes2Net(EngineMixin, nn.Module):
         return nn.Sequential(*layers)
 
 
+    def _train_forward(self, x):
+        """Training mode: batch-statistics BatchNorm, autograd through libvpmi's backward entry points (f32 engine)."""
+        from ppvector import _native as N
+        from ppvector.train.eres2net_train import eres2net_forward_train
+        if not x.is_cuda:
+            raise N.VpmiError('model input must be a GPU tensor: the engine has no CPU fallback')
+        return eres2net_forward_train(self, x.float().contiguous())
+
+
 class ERes2NetV2(nn.Module):
     def __init__(self, *a, **k):
         super().__init__()

@@ -200,27 +200,31 @@ class SEScale(torch.autograd.Function):
 
 
 class TimeStats(torch.autograd.Function):
+    """[mean | std] over time.  tstp=False: sqrt(clip(var_biased, 1e-12)) (ASP context, pooling.py:97-104);
+    tstp=True: sqrt(var_unbiased + 1e-8) (TemporalStatsPool, pooling.py:128-146)."""
+
     @staticmethod
-    def forward(ctx, x, B, T):
+    def forward(ctx, x, B, T, tstp=False):
         lib, hctx = N.lib(), N.ctx(x.device)
         x = _f32c(x)
         Cc = x.shape[1]
+        eps = 1e-8 if tstp else 1e-12
         stats = torch.empty((B, 2 * Cc), dtype=torch.float32, device=x.device)
-        _chk(lib.vp_time_stats_f32(hctx, x.data_ptr(), Cc, B, T, Cc, 1e-12, stats.data_ptr(), N.stream_ptr()), hctx)
+        _chk(lib.vp_time_stats_f32(hctx, x.data_ptr(), Cc, B, T, Cc, eps, int(tstp), stats.data_ptr(), N.stream_ptr()), hctx)
         ctx.save_for_backward(x, stats)
-        ctx.geom = (B, T)
+        ctx.geom = (B, T, eps, int(tstp))
         return stats
 
     @staticmethod
     def backward(ctx, ds):
         x, stats = ctx.saved_tensors
-        B, T = ctx.geom
+        B, T, eps, tstp = ctx.geom
         lib, hctx = N.lib(), N.ctx(x.device)
         Cc = x.shape[1]
         dx = torch.empty_like(x)
-        _chk(lib.vp_time_stats_bwd_f32(hctx, x.data_ptr(), Cc, stats.data_ptr(), _f32c(ds).data_ptr(), B, T, Cc, 1e-12,
+        _chk(lib.vp_time_stats_bwd_f32(hctx, x.data_ptr(), Cc, stats.data_ptr(), _f32c(ds).data_ptr(), B, T, Cc, eps, tstp,
                                        dx.data_ptr(), Cc, N.stream_ptr()), hctx)
-        return dx, None, None
+        return dx, None, None, None
 
 
 class AttnStats(torch.autograd.Function):
@@ -375,7 +379,9 @@ class Conv2dBlock(torch.autograd.Function):
             raise NotImplementedError('Conv2dBlock: 1x1 and 3x3 kernels only')
         pad = (KF - 1) // 2
         To, Fo = (T + 2 * pad - KT) // s + 1, (Fq + 2 * pad - KF) // s + 1
-        relu, bn = cfg.get('relu', False), gamma is not None
+        act = {None: 0, 'relu': N.VP_ACT_RELU, 'hardtanh': N.VP_ACT_HARDTANH20, 'silu': N.VP_ACT_SILU, 'tanh': N.VP_ACT_TANH}[
+            cfg.get('act', 'relu' if cfg.get('relu', False) else None)]
+        relu, bn = act != 0, gamma is not None
         wp = weight.permute(0, 3, 2, 1).reshape(Cout, KT * KF * Cin).contiguous()
         z = torch.empty((B * To * Fo, Cout), dtype=torch.float32, device=x.device)
         d = _conv_desc(x, B, T, To, Cin, Cout, KT * KF, 1, N.VP_PAD_ZERO, pad, wp, bias)
@@ -396,12 +402,13 @@ class Conv2dBlock(torch.autograd.Function):
                                           shift.data_ptr(), N.stream_ptr()), hctx)
             y = torch.empty_like(z)
             _chk(lib.vp_affine_rows_f32(hctx, z.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(), z.shape[0], Cout, y.data_ptr(),
-                                        Cout, int(relu), N.stream_ptr()), hctx)
-        elif relu:
-            y = torch.empty_like(z)
-            _chk(lib.vp_act_f32(hctx, N.VP_ACT_RELU, z.data_ptr(), z.numel(), y.data_ptr(), N.stream_ptr()), hctx)
-        ctx.save_for_backward(x, weight, z, mean, invstd, gamma, y if relu else None)
-        ctx.geom = (B, T, Fq, To, Fo, Cin, Cout, KT, KF, s, pad, relu, bn, bias is not None)
+                                        Cout, int(act == N.VP_ACT_RELU), N.stream_ptr()), hctx)
+        pre = y                                       # the activation's input (SiLU's backward needs it)
+        if act and not (bn and act == N.VP_ACT_RELU):
+            y = torch.empty_like(pre)
+            _chk(lib.vp_act_f32(hctx, act, pre.data_ptr(), pre.numel(), y.data_ptr(), N.stream_ptr()), hctx)
+        ctx.save_for_backward(x, weight, z, mean, invstd, gamma, (pre if act == N.VP_ACT_SILU else y) if act else None)
+        ctx.geom = (B, T, Fq, To, Fo, Cin, Cout, KT, KF, s, pad, act, bn, bias is not None)
         return y
 
     @staticmethod
@@ -412,9 +419,9 @@ class Conv2dBlock(torch.autograd.Function):
         dev = x.device
         dy = _f32c(dy)
         M = B * To * Fo
-        if relu:
+        if relu:                                      # `relu` holds the activation code here
             t = torch.empty_like(dy)
-            _chk(lib.vp_act_bwd_f32(hctx, N.VP_ACT_RELU, dy.data_ptr(), yr.data_ptr(), dy.numel(), t.data_ptr(), N.stream_ptr()), hctx)
+            _chk(lib.vp_act_bwd_f32(hctx, relu, dy.data_ptr(), yr.data_ptr(), dy.numel(), t.data_ptr(), N.stream_ptr()), hctx)
             dy = t
         dgamma = dbeta = None
         dz = dy
@@ -445,3 +452,50 @@ class Conv2dBlock(torch.autograd.Function):
             d2.y = dx.data_ptr()
             _chk(lib.vp_conv1d_fwd(hctx, C.byref(d2), N.stream_ptr()), hctx)
         return dx, dW, dbias, dgamma, dbeta, None, None, None
+
+
+class AffCombine(torch.autograd.Function):
+    """o = x (1 + t) + y (1 - t)  (AFF, models/eres2net.py:48-51; t = tanh of the local attention)."""
+
+    @staticmethod
+    def forward(ctx, t, x, y):
+        lib, hctx = N.lib(), N.ctx(x.device)
+        t, x, y = _f32c(t), _f32c(x), _f32c(y)
+        out = torch.empty_like(x)
+        _chk(lib.vp_aff_combine_f32(hctx, t.data_ptr(), x.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), N.stream_ptr()), hctx)
+        ctx.save_for_backward(t, x, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        t, x, y = ctx.saved_tensors
+        lib, hctx = N.lib(), N.ctx(x.device)
+        g = _f32c(g)
+        dx, dy, dt = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        _chk(lib.vp_aff_combine_bwd_f32(hctx, g.data_ptr(), t.data_ptr(), x.data_ptr(), y.data_ptr(), x.numel(), dx.data_ptr(), dy.data_ptr(),
+                                        dt.data_ptr(), N.stream_ptr()), hctx)
+        return dt, dx, dy
+
+
+class Act(torch.autograd.Function):
+    """Elementwise activation with its backward in libvpmi ('relu' | 'hardtanh' = clamp(0, 20))."""
+
+    @staticmethod
+    def forward(ctx, x, kind):
+        lib, hctx = N.lib(), N.ctx(x.device)
+        x = _f32c(x)
+        code = {'relu': N.VP_ACT_RELU, 'hardtanh': N.VP_ACT_HARDTANH20}[kind]
+        y = torch.empty_like(x)
+        _chk(lib.vp_act_f32(hctx, code, x.data_ptr(), x.numel(), y.data_ptr(), N.stream_ptr()), hctx)
+        ctx.save_for_backward(y)
+        ctx.code = code
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        lib, hctx = N.lib(), N.ctx(y.device)
+        g = _f32c(g)
+        dz = torch.empty_like(g)
+        _chk(lib.vp_act_bwd_f32(hctx, ctx.code, g.data_ptr(), y.data_ptr(), g.numel(), dz.data_ptr(), N.stream_ptr()), hctx)
+        return dz, None

@@ -3,7 +3,7 @@ Activations are (B*T*F, C) position-major; the reference's reshape (B, C*F/8, T/
 of a small tensor (data movement).  Input (B, T, F) f32 on the GPU -> embeddings (B, embd_dim)."""
 import torch
 
-from ppvector.train.functions import BNRows, Conv2dBlock, ConvBlock, SEScale, TimeStats
+from ppvector.train.functions import Act, BNRows, Conv2dBlock, ConvBlock, SEScale, TimeStats
 from ppvector.train.tdnn_train import asp_forward
 
 
@@ -33,7 +33,7 @@ def bottleneck(b, x, B, T, F):
         dconv, dbn = b.downsample[0], b.downsample[1]
         res = Conv2dBlock.apply(x, dconv.weight, dconv.bias, *_bn(dbn), _cfg(B, T, F, dbn, stride=s))
     out = SEScale.apply(out, y, res, B, To * Fo)
-    return torch.relu(out), To, Fo
+    return Act.apply(out, 'relu'), To, Fo
 
 
 def resnetse_forward_train(m, feats):
