@@ -454,9 +454,16 @@ int vp_act_bwd_f32(vp_ctx* ctx, int act, const float* dy, const float* y, long l
  * vp_scale_rows_bwd_f32: backward of the SE gate x * s (ecapa_tdnn.py:82): dx = dy * s, ds[b] = sum_t dy * x. */
 /* vp_zero_insert_2d_f32: dz (B, T_out, F_out, C) -> up (B, T_in, F_in, C), zeros between the samples: the data gradient of a
  * stride-s 2-D conv is then a stride-1 vp_conv1d_fwd over `up`.  vp_relu_bwd_f32: dz = [y > 0] dy. */
-int vp_zero_insert_2d_f32(vp_ctx* ctx, const float* dz, int B, int T_out, int F_out, int C, int T_in, int F_in, int stride, float* up,
-                          vp_stream stream);
+int vp_zero_insert_2d_f32(vp_ctx* ctx, const float* dz, int B, int T_out, int F_out, int C, int T_in, int F_in, int stride_t, int stride_f,
+                          float* up, vp_stream stream);
 int vp_relu_bwd_f32(vp_ctx* ctx, const float* dy, const float* y, long long n, float* dz, vp_stream stream);
+/* CAM++ context gate in training (models/campplus.py:88-106): ctx (B, nseg, C) = mean_t x + per-100-frame-segment mean;
+ * the gate y * m[b, seg(t)]; and their backward.  x, y (B*T, C) dense f32; nseg = ceil(T / seg_len). */
+int vp_seg_ctx_f32(vp_ctx* ctx, const float* x, int B, int T, int C, int seg_len, float* out, vp_stream stream);
+int vp_seg_ctx_bwd_f32(vp_ctx* ctx, const float* dctx, int B, int T, int C, int seg_len, float* dx, vp_stream stream);
+int vp_seg_scale_f32(vp_ctx* ctx, const float* y, const float* m, int B, int T, int C, int seg_len, float* out, vp_stream stream);
+int vp_seg_scale_bwd_f32(vp_ctx* ctx, const float* g, const float* y, const float* m, int B, int T, int C, int seg_len, float* dy, float* dm,
+                         vp_stream stream);
 /* AFF output (eres2net.py:48-51) and its backward: o = x (1 + t) + y (1 - t) on dense (rows, C) f32 tensors. */
 int vp_aff_combine_f32(vp_ctx* ctx, const float* t, const float* x, const float* y, long long rows, int C, float* out, vp_stream stream);
 int vp_aff_combine_bwd_f32(vp_ctx* ctx, const float* g, const float* t, const float* x, const float* y, long long n, float* dx, float* dy,

@@ -35,25 +35,25 @@ def _bn(x, p, pre, training=False):
     return (x - m.view(sh)) / torch.sqrt(v.view(sh) + BN_EPS) * w.view(sh) + b.view(sh)
 
 
-def _resblock(x, p, pre, stride):
+def _resblock(x, p, pre, stride, training=False):
     out = F.relu(_bn(F.conv2d(x, p[pre + 'conv1.weight'], p[pre + 'conv1.bias'], stride=(stride, 1), padding=1),
-                     p, pre + 'bn1.'))
-    out = _bn(F.conv2d(out, p[pre + 'conv2.weight'], p[pre + 'conv2.bias'], padding=1), p, pre + 'bn2.')
+                     p, pre + 'bn1.', training))
+    out = _bn(F.conv2d(out, p[pre + 'conv2.weight'], p[pre + 'conv2.bias'], padding=1), p, pre + 'bn2.', training)
     if (pre + 'shortcut.0.weight') in p:
         sc = _bn(F.conv2d(x, p[pre + 'shortcut.0.weight'], p[pre + 'shortcut.0.bias'], stride=(stride, 1)),
-                 p, pre + 'shortcut.1.')
+                 p, pre + 'shortcut.1.', training)
     else:
         sc = x
     return F.relu(out + sc)
 
 
-def fcm(x, p, pre='head.'):
+def fcm(x, p, pre='head.', training=False):
     """x (B, F, T) -> (B, 32 * ceil(F/8), T)."""
-    out = F.relu(_bn(F.conv2d(x.unsqueeze(1), p[pre + 'conv1.weight'], p[pre + 'conv1.bias'], padding=1), p, pre + 'bn1.'))
+    out = F.relu(_bn(F.conv2d(x.unsqueeze(1), p[pre + 'conv1.weight'], p[pre + 'conv1.bias'], padding=1), p, pre + 'bn1.', training))
     for layer in ('layer1.', 'layer2.'):
-        out = _resblock(out, p, pre + layer + '0.', 2)
-        out = _resblock(out, p, pre + layer + '1.', 1)
-    out = F.relu(_bn(F.conv2d(out, p[pre + 'conv2.weight'], p[pre + 'conv2.bias'], stride=(2, 1), padding=1), p, pre + 'bn2.'))
+        out = _resblock(out, p, pre + layer + '0.', 2, training)
+        out = _resblock(out, p, pre + layer + '1.', 1, training)
+    out = F.relu(_bn(F.conv2d(out, p[pre + 'conv2.weight'], p[pre + 'conv2.bias'], stride=(2, 1), padding=1), p, pre + 'bn2.', training))
     B, C, Fq, T = out.shape
     return out.reshape(B, C * Fq, T)
 
@@ -75,31 +75,31 @@ def cam_layer(x, p, pre, dilation):
     return y * m
 
 
-def campplus_forward(p, x, prefix='', taps=None):
+def campplus_forward(p, x, prefix='', taps=None, training=False):
     """CAMPPlus.forward (campplus.py:331-335), eval mode.  x (B, T, F) -> (B, embd)."""
-    x = fcm(x.transpose(1, 2), p, prefix + 'head.')
+    x = fcm(x.transpose(1, 2), p, prefix + 'head.', training)
     if taps is not None:
         taps['fcm'] = x
     xv = prefix + 'xvector.'
     x = F.conv1d(x, p[xv + 'tdnn.linear.weight'], p[xv + 'tdnn.linear.bias'], stride=2, padding=2)
-    x = F.relu(_bn(x, p, xv + 'tdnn.nonlinear.batchnorm.'))
+    x = F.relu(_bn(x, p, xv + 'tdnn.nonlinear.batchnorm.', training))
     if taps is not None:
         taps['tdnn'] = x
     for bi, (nl, k, d) in enumerate(BLOCKS, start=1):
         for li in range(1, nl + 1):
             lp = f'{xv}block{bi}.tdnnd{li}.'
-            h = F.relu(_bn(x, p, lp + 'nonlinear1.batchnorm.'))
+            h = F.relu(_bn(x, p, lp + 'nonlinear1.batchnorm.', training))
             h = F.conv1d(h, p[lp + 'linear1.weight'], p[lp + 'linear1.bias'])
-            h = F.relu(_bn(h, p, lp + 'nonlinear2.batchnorm.'))
+            h = F.relu(_bn(h, p, lp + 'nonlinear2.batchnorm.', training))
             x = torch.cat([x, cam_layer(h, p, lp + 'cam_layer.', d)], dim=1)
         tp = f'{xv}transit{bi}.'
-        x = F.conv1d(F.relu(_bn(x, p, tp + 'nonlinear.batchnorm.')), p[tp + 'linear.weight'], p[tp + 'linear.bias'])
+        x = F.conv1d(F.relu(_bn(x, p, tp + 'nonlinear.batchnorm.', training)), p[tp + 'linear.weight'], p[tp + 'linear.bias'])
         if taps is not None:
             taps[f'transit{bi}'] = x
-    x = F.relu(_bn(x, p, xv + 'out_nonlinear.batchnorm.'))
+    x = F.relu(_bn(x, p, xv + 'out_nonlinear.batchnorm.', training))
     stats = torch.cat([x.mean(dim=-1), x.std(dim=-1, unbiased=True)], dim=-1)
     y = F.conv1d(stats.unsqueeze(-1), p[xv + 'dense.linear.weight'], p[xv + 'dense.linear.bias']).squeeze(-1)
-    return _bn(y, p, xv + 'dense.nonlinear.batchnorm.')
+    return _bn(y, p, xv + 'dense.nonlinear.batchnorm.', training)
 
 
 def _conv(prefix, shape, rng):

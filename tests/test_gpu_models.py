@@ -130,12 +130,13 @@ def test_full_size_batch_invariance(ecapa):
             assert np.linalg.norm(e32[r] - ref[i]) / np.linalg.norm(ref[i]) < 2e-4
 
 
-def test_training_mode_is_refused_where_not_built():
-    """CAM++ / ResNetSE / ERes2Net have no training path yet: train-mode forward must refuse, never fake it."""
-    from ppvector.models.campplus import CAMPPlus
-    m = CAMPPlus(80, embd_dim=192).cuda().train()
+def test_unbuilt_model_variants_refuse():
+    """What is not built refuses at construction, never a silent fallback."""
+    from ppvector.models.eres2net import ERes2Net, ERes2NetV2
     with pytest.raises(NotImplementedError):
-        m(torch.zeros(2, 64, 80, device='cuda'))
+        ERes2NetV2(80)
+    with pytest.raises(NotImplementedError):
+        ERes2Net(80, two_emb_layer=True)
 
 
 def test_long_utterance_falls_back_to_per_conv_path(ecapa):

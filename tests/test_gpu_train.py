@@ -405,3 +405,44 @@ def test_eres2net_training_step_vs_oracle_autograd(N):
         assert r < 5e-3, (k, r)
     print(f'[eres2net train] loss {loss.item():.5f} (oracle {loss_ref.item():.5f}); worst parameter-gradient rel-L2 {worst:.2e} ({wk})')
     m.eval()
+
+
+def test_campplus_training_step_vs_oracle_autograd(N):
+    """CAM++ (configs/cam++.yml: embd 192): FCM with stride on the frequency axis, the stride-2 TDNN, 52 CAM dense layers with
+    two context segments (115 frames after the stride), transit layers, unbiased statistics pooling."""
+    from oracle import campplus as oc
+    from ppvector.models.campplus import CAMPPlus
+    from ppvector.train.functions import HeadLoss
+    B, T, Cc = 3, 230, 8
+    p = oc.campplus_params(80, 192, seed=17)
+    g = torch.Generator().manual_seed(18)
+    x = torch.randn(B, T, 80, generator=g) * 2
+    labels = torch.randint(0, Cc, (B,), generator=g)
+    Wh = om.head_params(192, Cc, seed=6)
+    pr = {k: v.clone().double().requires_grad_(not k.endswith(('_mean', '_variance'))) for k, v in p.items()}
+    Wr = Wh.clone().double().requires_grad_()
+    emb_ref = oc.campplus_forward(pr, x.double(), training=True)
+    loss_ref = om.aam_loss(om.cosine_head(emb_ref, Wr), labels, 0.2, 32.0, False, 0.0)
+    loss_ref.backward()
+    m = CAMPPlus(80, embd_dim=192)
+    m.load_state_dict(p)
+    m = m.cuda().train()
+    Wd = Wh.cuda().requires_grad_()
+    emb = m(x.cuda())
+    # the closing BatchNorm over a batch of 3 divides by a tiny batch variance: f32-vs-f64 noise is amplified there
+    assert rel(emb, emb_ref.detach()) < 2e-3
+    loss = HeadLoss.apply(emb, Wd, labels.cuda(), 0.2, 32.0, 0.0, False)
+    assert abs(loss.item() - loss_ref.item()) < 2e-3 * abs(loss_ref.item())
+    loss.backward()
+    worst, wk = 0.0, ''
+    gscale = max(v.grad.abs().max().item() for v in pr.values() if v.grad is not None)
+    for k, v in m.named_parameters():
+        if pr[k].grad is None or pr[k].grad.norm().item() < 1e-9:        # a bias in front of a BatchNorm: true gradient 0
+            assert v.grad is None or v.grad.abs().max().item() < 1e-3 * gscale, k
+            continue
+        r = rel(v.grad, pr[k].grad)
+        if r > worst:
+            worst, wk = r, k
+        assert r < 3e-2, (k, r)
+    print(f'[cam++ train] loss {loss.item():.5f} (oracle {loss_ref.item():.5f}); worst parameter-gradient rel-L2 {worst:.2e} ({wk})')
+    m.eval()

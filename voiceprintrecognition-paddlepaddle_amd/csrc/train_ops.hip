@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void scale_rows_bwd_kernel(const float* dy, co
 
 // up[b, t, f, :] = dz[b, t / s, f / s, :] when t and f are multiples of s (and in range), else 0: the zero-insertion that turns
 // the data gradient of a stride-s conv into a stride-1 conv over `up` (T_in x F_in positions).
-struct ZiArgs { const float* dz; float* up; int T_out, F_out, T_in, F_in, s, C4; long long total; };
+struct ZiArgs { const float* dz; float* up; int T_out, F_out, T_in, F_in, st, sf, C4; long long total; };
 __global__ __launch_bounds__(256) void zero_insert_kernel(ZiArgs a) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.total; i += (long long)gridDim.x * 256) {
         const long long pos = i / a.C4;
@@ -353,8 +353,8 @@ __global__ __launch_bounds__(256) void zero_insert_kernel(ZiArgs a) {
         const long long b = bt / a.T_in;
         const int t = (int)(bt - b * a.T_in);
         float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (t % a.s == 0 && f % a.s == 0 && t / a.s < a.T_out && f / a.s < a.F_out)
-            vp_load4(a.dz + (((size_t)b * a.T_out + t / a.s) * a.F_out + f / a.s) * a.C4 * 4 + c, v);
+        if (t % a.st == 0 && f % a.sf == 0 && t / a.st < a.T_out && f / a.sf < a.F_out)
+            vp_load4(a.dz + (((size_t)b * a.T_out + t / a.st) * a.F_out + f / a.sf) * a.C4 * 4 + c, v);
         vp_store4(a.up + pos * a.C4 * 4 + c, v);
     }
 }
@@ -379,6 +379,85 @@ __global__ __launch_bounds__(256) void aff_combine_bwd_kernel(const float* g, co
 #pragma unroll
         for (int e = 0; e < 4; ++e) { a[e] = gv[e] * (1.f + tv[e]); b[e] = gv[e] * (1.f - tv[e]); c[e] = gv[e] * (xv[e] - yv[e]); }
         vp_store4(dx + i * 4, a); vp_store4(dy + i * 4, b); vp_store4(dt + i * 4, c);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- CAM++ context (campplus.py:88-106)
+// ctx[b, s, c] = mean_t x[b, t, c] + mean_{t in segment s} x[b, t, c]  (100-frame segments, the last one over its valid frames);
+// backward: dx[b, t, c] = sum_s dctx[b, s, c] / T + dctx[b, seg(t), c] / len(seg(t)).  One workgroup = 64 channels of one utterance.
+__global__ __launch_bounds__(256) void seg_ctx_kernel(const float* x, int T, int C, int seg_len, int nseg, float* ctx) {
+    __shared__ float sm[4][64];
+    const int lc = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int b = blockIdx.y, c = blockIdx.x * 64 + lc;
+    const bool ok = c < C;
+    float tot = 0.f;
+    for (int s = 0; s < nseg; ++s) {
+        const int t0 = s * seg_len, t1 = min(T, t0 + seg_len);
+        float acc = 0.f;
+        if (ok) for (int t = t0 + rg; t < t1; t += 4) acc += x[((size_t)b * T + t) * C + c];
+        sm[rg][lc] = acc;
+        __syncthreads();
+        const float ssum = sm[0][lc] + sm[1][lc] + sm[2][lc] + sm[3][lc];
+        __syncthreads();
+        tot += ssum;
+        if (rg == 0 && ok) ctx[((size_t)b * nseg + s) * C + c] = ssum / (float)(t1 - t0);
+    }
+    if (rg == 0 && ok)
+        for (int s = 0; s < nseg; ++s) ctx[((size_t)b * nseg + s) * C + c] += tot / (float)T;
+}
+
+__global__ __launch_bounds__(256) void seg_ctx_bwd_kernel(const float* dctx, int T, int C, int seg_len, int nseg, float* dx) {
+    const int lc = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int b = blockIdx.y, c = blockIdx.x * 64 + lc;
+    if (c >= C) return;
+    float tot = 0.f;
+    for (int s = 0; s < nseg; ++s) tot += dctx[((size_t)b * nseg + s) * C + c];
+    tot /= (float)T;
+    for (int t = rg; t < T; t += 4) {
+        const int s = t / seg_len;
+        const int len = min(T, (s + 1) * seg_len) - s * seg_len;
+        dx[((size_t)b * T + t) * C + c] = tot + dctx[((size_t)b * nseg + s) * C + c] / (float)len;
+    }
+}
+
+// out[b, t, c] = y[b, t, c] * m[b, seg(t), c];  backward: dy = g * m,  dm[b, s, c] = sum_{t in s} g * y
+__global__ __launch_bounds__(256) void seg_scale_kernel(const float* y, const float* m, int T, int C4, int seg_len, int nseg, long long total,
+                                                        float* out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / C4;
+        const int c = (int)(i - r * C4) * 4;
+        const long long b = r / T;
+        const int t = (int)(r - b * T);
+        float v[4], g[4];
+        vp_load4(y + r * C4 * 4 + c, v);
+        vp_load4(m + (b * nseg + t / seg_len) * C4 * 4 + c, g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= g[e];
+        vp_store4(out + r * C4 * 4 + c, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void seg_scale_bwd_kernel(const float* g, const float* y, const float* m, int T, int C, int seg_len, int nseg,
+                                                            float* dy, float* dm) {
+    __shared__ float sm[4][64];
+    const int lc = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int b = blockIdx.y, c = blockIdx.x * 64 + lc;
+    const bool ok = c < C;
+    for (int s = 0; s < nseg; ++s) {
+        const int t0 = s * seg_len, t1 = min(T, t0 + seg_len);
+        const float mv = ok ? m[((size_t)b * nseg + s) * C + c] : 0.f;
+        float acc = 0.f;
+        if (ok)
+            for (int t = t0 + rg; t < t1; t += 4) {
+                const size_t o = ((size_t)b * T + t) * C + c;
+                const float gv = g[o];
+                acc += gv * y[o];
+                dy[o] = gv * mv;
+            }
+        sm[rg][lc] = acc;
+        __syncthreads();
+        if (rg == 0 && ok) dm[((size_t)b * nseg + s) * C + c] = sm[0][lc] + sm[1][lc] + sm[2][lc] + sm[3][lc];
+        __syncthreads();
     }
 }
 
@@ -602,11 +681,11 @@ int vp_scale_rows_bwd_f32(vp_ctx* ctx, const float* dy, const float* x, const fl
     return VP_OK;
 }
 
-int vp_zero_insert_2d_f32(vp_ctx* ctx, const float* dz, int B, int T_out, int F_out, int C, int T_in, int F_in, int stride, float* up,
-                          vp_stream stream) {
-    if (!ctx || !dz || !up || B <= 0 || T_out <= 0 || F_out <= 0 || T_in <= 0 || F_in <= 0 || stride < 1 || C <= 0 || C & 3)
+int vp_zero_insert_2d_f32(vp_ctx* ctx, const float* dz, int B, int T_out, int F_out, int C, int T_in, int F_in, int stride_t, int stride_f,
+                          float* up, vp_stream stream) {
+    if (!ctx || !dz || !up || B <= 0 || T_out <= 0 || F_out <= 0 || T_in <= 0 || F_in <= 0 || stride_t < 1 || stride_f < 1 || C <= 0 || C & 3)
         VP_FAIL(ctx, VP_EINVAL, "zero_insert: bad arguments");
-    ZiArgs a{dz, up, T_out, F_out, T_in, F_in, stride, C / 4, (long long)B * T_in * F_in * (C / 4)};
+    ZiArgs a{dz, up, T_out, F_out, T_in, F_in, stride_t, stride_f, C / 4, (long long)B * T_in * F_in * (C / 4)};
     hipLaunchKernelGGL(zero_insert_kernel, dim3(grid1d(a.total)), dim3(256), 0, (hipStream_t)stream, a);
     VP_LAUNCH_CHECK(ctx, "zero_insert");
     return VP_OK;
@@ -629,6 +708,36 @@ int vp_aff_combine_bwd_f32(vp_ctx* ctx, const float* g, const float* t, const fl
     if (!ctx || !g || !t || !x || !y || !dx || !dy || !dt || n <= 0 || n & 3) VP_FAIL(ctx, VP_EINVAL, "aff_combine_bwd: bad arguments");
     hipLaunchKernelGGL(aff_combine_bwd_kernel, dim3(grid1d(n / 4)), dim3(256), 0, (hipStream_t)stream, g, t, x, y, n / 4, dx, dy, dt);
     VP_LAUNCH_CHECK(ctx, "aff_combine_bwd");
+    return VP_OK;
+}
+
+int vp_seg_ctx_f32(vp_ctx* ctx, const float* x, int B, int T, int C, int seg_len, float* out, vp_stream stream) {
+    if (!ctx || !x || !out || B <= 0 || T <= 0 || C <= 0 || seg_len <= 0 || B > 65535) VP_FAIL(ctx, VP_EINVAL, "seg_ctx: bad arguments");
+    hipLaunchKernelGGL(seg_ctx_kernel, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, x, T, C, seg_len, (T + seg_len - 1) / seg_len, out);
+    VP_LAUNCH_CHECK(ctx, "seg_ctx");
+    return VP_OK;
+}
+
+int vp_seg_ctx_bwd_f32(vp_ctx* ctx, const float* dctx, int B, int T, int C, int seg_len, float* dx, vp_stream stream) {
+    if (!ctx || !dctx || !dx || B <= 0 || T <= 0 || C <= 0 || seg_len <= 0 || B > 65535) VP_FAIL(ctx, VP_EINVAL, "seg_ctx_bwd: bad arguments");
+    hipLaunchKernelGGL(seg_ctx_bwd_kernel, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, dctx, T, C, seg_len, (T + seg_len - 1) / seg_len, dx);
+    VP_LAUNCH_CHECK(ctx, "seg_ctx_bwd");
+    return VP_OK;
+}
+
+int vp_seg_scale_f32(vp_ctx* ctx, const float* y, const float* m, int B, int T, int C, int seg_len, float* out, vp_stream stream) {
+    if (!ctx || !y || !m || !out || B <= 0 || T <= 0 || C <= 0 || C & 3 || seg_len <= 0) VP_FAIL(ctx, VP_EINVAL, "seg_scale: bad arguments");
+    const long long total = (long long)B * T * (C / 4);
+    hipLaunchKernelGGL(seg_scale_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, y, m, T, C / 4, seg_len, (T + seg_len - 1) / seg_len, total, out);
+    VP_LAUNCH_CHECK(ctx, "seg_scale");
+    return VP_OK;
+}
+
+int vp_seg_scale_bwd_f32(vp_ctx* ctx, const float* g, const float* y, const float* m, int B, int T, int C, int seg_len, float* dy, float* dm,
+                         vp_stream stream) {
+    if (!ctx || !g || !y || !m || !dy || !dm || B <= 0 || T <= 0 || C <= 0 || seg_len <= 0 || B > 65535) VP_FAIL(ctx, VP_EINVAL, "seg_scale_bwd: bad arguments");
+    hipLaunchKernelGGL(seg_scale_bwd_kernel, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, g, y, m, T, C, seg_len, (T + seg_len - 1) / seg_len, dy, dm);
+    VP_LAUNCH_CHECK(ctx, "seg_scale_bwd");
     return VP_OK;
 }
 

@@ -214,7 +214,11 @@ _PROTOS = {
                                       c_void_p, c_int, c_void_p]),
     'vp_act_f32': (c_int, [c_void_p, c_int, c_void_p, C.c_longlong, c_void_p, c_void_p]),
     'vp_act_bwd_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, C.c_longlong, c_void_p, c_void_p]),
-    'vp_zero_insert_2d_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'vp_zero_insert_2d_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'vp_seg_ctx_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'vp_seg_ctx_bwd_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'vp_seg_scale_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'vp_seg_scale_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'vp_relu_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, C.c_longlong, c_void_p, c_void_p]),
     'vp_aff_combine_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_longlong, c_int, c_void_p, c_void_p]),
     'vp_aff_combine_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_longlong, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -173,3 +173,11 @@ class CAMPPlus(EngineMixin, nn.Module):
         self.xvector.add_module('out_nonlinear', get_nonlinear(config_str, channels))
         self.xvector.add_module('stats', StatsPool())
         self.xvector.add_module('dense', DenseLayer(channels * 2, embd_dim, config_str='batchnorm_'))
+
+    def _train_forward(self, x):
+        """Training mode: batch-statistics BatchNorm, autograd through libvpmi's backward entry points (f32 engine)."""
+        from ppvector import _native as N
+        from ppvector.train.campplus_train import campplus_forward_train
+        if not x.is_cuda:
+            raise N.VpmiError('model input must be a GPU tensor: the engine has no CPU fallback')
+        return campplus_forward_train(self, x.float().contiguous())

@@ -1,0 +1,92 @@
+"""Training-mode forward of CAM++ (ppvector/models/campplus.py:331-335) through the autograd functions of functions.py.
+Activations are position-major: (B*T*F, C) in the FCM head, (B*T, C) in the D-TDNN.  The DenseNet concatenations are
+torch.cat; every conv / BatchNorm / activation / context gate / pooling runs in libvpmi.
+Input (B, T, F) f32 on the GPU -> embeddings (B, embd_dim)."""
+import torch
+
+from ppvector.train.functions import Act, BNRows, Conv2dBlock, ConvBlock, SegCtx, SegScale, TimeStats
+
+SEG_LEN = 100       # CAMLayer.seg_pooling default (campplus.py:96)
+
+
+def _bn(p):
+    return p.weight, p.bias, p._mean, p._variance
+
+
+def _c2(x, conv, bn, B, T, F, act=None, stride_f=1):
+    args = _bn(bn) if bn is not None else (None, None, None, None)
+    cfg = dict(B=B, T=T, F=F, act=act, stride_t=1, stride_f=stride_f)
+    if bn is not None:
+        cfg.update(momentum=bn.momentum, eps=bn.eps)
+    return Conv2dBlock.apply(x, conv.weight, conv.bias, *args, cfg)
+
+
+def _bnrelu(x, bn, relu=True):
+    return BNRows.apply(x, bn.weight, bn.bias, bn._mean, bn._variance, bn.momentum, bn.eps, relu)
+
+
+def _c1x1(x, conv, B, T, relu=False, sigmoid=False):
+    return ConvBlock.apply(x, conv.weight, conv.bias, None, None, None, None, None, dict(B=B, T=T, relu=relu, sigmoid=sigmoid))
+
+
+def res_block(b, x, B, T, F):
+    s = b.stride
+    out = _c2(x, b.conv1, b.bn1, B, T, F, act='relu', stride_f=s)
+    Fo = (F - 1) // s + 1
+    out = _c2(out, b.conv2, b.bn2, B, T, Fo)
+    sc = x
+    if len(b.shortcut) > 0:
+        sc = _c2(x, b.shortcut[0], b.shortcut[1], B, T, F, stride_f=s)
+    return Act.apply(out + sc, 'relu'), Fo
+
+
+def fcm(head, feats):
+    B, T, F = feats.shape
+    x = torch.zeros((B * T * F, 4), dtype=torch.float32, device=feats.device)       # single input channel padded to 4
+    x[:, 0] = feats.reshape(-1)
+    w = head.conv1.weight
+    w4 = torch.cat([w, torch.zeros((w.shape[0], 3, 3, 3), dtype=w.dtype, device=w.device)], dim=1)
+    x = Conv2dBlock.apply(x, w4, head.conv1.bias, *_bn(head.bn1), dict(B=B, T=T, F=F, act='relu', momentum=head.bn1.momentum, eps=head.bn1.eps))
+    for layer in (head.layer1, head.layer2):
+        for b in layer:
+            x, F = res_block(b, x, B, T, F)
+    x = _c2(x, head.conv2, head.bn2, B, T, F, act='relu', stride_f=2)
+    F = (F - 1) // 2 + 1
+    Cc = x.shape[1]
+    return x.reshape(B, T, F, Cc).permute(0, 1, 3, 2).reshape(B * T, Cc * F), T     # channel index c*F' + f (campplus.py:279-280)
+
+
+def cam_dense_layer(lay, x, B, T):
+    h = _bnrelu(x, lay.nonlinear1.batchnorm)
+    h = _c1x1(h, lay.linear1, B, T)
+    h = _bnrelu(h, lay.nonlinear2.batchnorm)
+    cl = lay.cam_layer
+    wl = cl.linear_local.weight                                          # (out, bn, k)
+    y = Conv2dBlock.apply(h, wl.unsqueeze(2), cl.linear_local.bias, None, None, None, None,
+                          dict(B=B, T=T, F=1, dilation=cl.dilation, act=None))
+    nseg = (T + SEG_LEN - 1) // SEG_LEN
+    ctx = SegCtx.apply(h, B, T, SEG_LEN)                                 # (B*nseg, bn)
+    ctx = _c1x1(ctx, cl.linear1, B * nseg, 1, relu=True)
+    m = _c1x1(ctx, cl.linear2, B * nseg, 1, sigmoid=True)
+    return SegScale.apply(y, m, B, T, SEG_LEN)
+
+
+def campplus_forward_train(m, feats):
+    B = feats.shape[0]
+    x, T = fcm(m.head, feats)
+    xv = m.xvector
+    td = xv.tdnn
+    x = Conv2dBlock.apply(x, td.linear.weight.unsqueeze(2), td.linear.bias, *_bn(td.nonlinear.batchnorm),
+                          dict(B=B, T=T, F=1, stride_t=td.stride, stride_f=1, act='relu', momentum=td.nonlinear.batchnorm.momentum,
+                               eps=td.nonlinear.batchnorm.eps))
+    T = (T + 2 * 2 - 4 - 1) // td.stride + 1
+    for bi, (nl, _, _) in enumerate(m.block_cfg, start=1):
+        blk = getattr(xv, f'block{bi}')
+        for l in range(1, nl + 1):
+            x = torch.cat([x, cam_dense_layer(getattr(blk, f'tdnnd{l}'), x, B, T)], dim=1)
+        tr = getattr(xv, f'transit{bi}')
+        x = _c1x1(_bnrelu(x, tr.nonlinear.batchnorm), tr.linear, B, T)
+    x = _bnrelu(x, xv.out_nonlinear.batchnorm)
+    stats = TimeStats.apply(x, B, T, True, 0.0)                          # mean | unbiased std (campplus.py:24-30)
+    y = _c1x1(stats, xv.dense.linear, B, 1)
+    return _bnrelu(y, xv.dense.nonlinear.batchnorm, relu=False)

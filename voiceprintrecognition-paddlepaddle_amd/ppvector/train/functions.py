@@ -204,11 +204,11 @@ class TimeStats(torch.autograd.Function):
     tstp=True: sqrt(var_unbiased + 1e-8) (TemporalStatsPool, pooling.py:128-146)."""
 
     @staticmethod
-    def forward(ctx, x, B, T, tstp=False):
+    def forward(ctx, x, B, T, tstp=False, eps=None):
         lib, hctx = N.lib(), N.ctx(x.device)
         x = _f32c(x)
         Cc = x.shape[1]
-        eps = 1e-8 if tstp else 1e-12
+        eps = eps if eps is not None else (1e-8 if tstp else 1e-12)
         stats = torch.empty((B, 2 * Cc), dtype=torch.float32, device=x.device)
         _chk(lib.vp_time_stats_f32(hctx, x.data_ptr(), Cc, B, T, Cc, eps, int(tstp), stats.data_ptr(), N.stream_ptr()), hctx)
         ctx.save_for_backward(x, stats)
@@ -224,7 +224,7 @@ class TimeStats(torch.autograd.Function):
         dx = torch.empty_like(x)
         _chk(lib.vp_time_stats_bwd_f32(hctx, x.data_ptr(), Cc, stats.data_ptr(), _f32c(ds).data_ptr(), B, T, Cc, eps, tstp,
                                        dx.data_ptr(), Cc, N.stream_ptr()), hctx)
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
 class AttnStats(torch.autograd.Function):
@@ -256,7 +256,7 @@ class BNRows(torch.autograd.Function):
     """BatchNorm1D with batch statistics on a (M, C) tensor."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, run_mean, run_var, momentum, eps):
+    def forward(ctx, x, gamma, beta, run_mean, run_var, momentum, eps, relu=False):
         lib, hctx = N.lib(), N.ctx(x.device)
         x = _f32c(x)
         M, Cc = x.shape
@@ -269,22 +269,26 @@ class BNRows(torch.autograd.Function):
                                       run_var.data_ptr() if run_var is not None else None, momentum, eps, mean.data_ptr(),
                                       invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), N.stream_ptr()), hctx)
         y = torch.empty_like(x)
-        _chk(lib.vp_affine_rows_f32(hctx, x.data_ptr(), Cc, scale.data_ptr(), shift.data_ptr(), M, Cc, y.data_ptr(), Cc, 0,
+        _chk(lib.vp_affine_rows_f32(hctx, x.data_ptr(), Cc, scale.data_ptr(), shift.data_ptr(), M, Cc, y.data_ptr(), Cc, int(relu),
                                     N.stream_ptr()), hctx)
-        ctx.save_for_backward(x, mean, invstd, gamma)
+        ctx.save_for_backward(x, mean, invstd, gamma, y if relu else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, mean, invstd, gamma = ctx.saved_tensors
+        x, mean, invstd, gamma, yr = ctx.saved_tensors
         lib, hctx = N.lib(), N.ctx(x.device)
         dy = _f32c(dy)
         M, Cc = x.shape
+        if yr is not None:
+            t = torch.empty_like(dy)
+            _chk(lib.vp_act_bwd_f32(hctx, N.VP_ACT_RELU, dy.data_ptr(), yr.data_ptr(), dy.numel(), t.data_ptr(), N.stream_ptr()), hctx)
+            dy = t
         sums = col_sums(dy, x, mean, invstd)
         dx = torch.empty_like(x)
         _chk(lib.vp_bn_relu_bwd_f32(hctx, dy.data_ptr(), Cc, x.data_ptr(), Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
                                     sums.data_ptr(), M, Cc, 0, dx.data_ptr(), Cc, N.stream_ptr()), hctx)
-        return dx, sums[1].clone(), sums[0].clone(), None, None, None, None
+        return dx, sums[1].clone(), sums[0].clone(), None, None, None, None, None
 
 
 class HeadLoss(torch.autograd.Function):
@@ -373,19 +377,20 @@ class Conv2dBlock(torch.autograd.Function):
     def forward(ctx, x, weight, bias, gamma, beta, run_mean, run_var, cfg):
         lib, hctx = N.lib(), N.ctx(x.device)
         x, weight = _f32c(x), _f32c(weight)
-        B, T, Fq, s = cfg['B'], cfg['T'], cfg['F'], cfg.get('stride', 1)
+        B, T, Fq = cfg['B'], cfg['T'], cfg['F']
+        st, sf = cfg.get('stride_t', cfg.get('stride', 1)), cfg.get('stride_f', cfg.get('stride', 1))
+        dil = cfg.get('dilation', 1)                       # along time
         Cout, Cin, KF, KT = weight.shape
-        if KF != KT or KF not in (1, 3):
-            raise NotImplementedError('Conv2dBlock: 1x1 and 3x3 kernels only')
-        pad = (KF - 1) // 2
-        To, Fo = (T + 2 * pad - KT) // s + 1, (Fq + 2 * pad - KF) // s + 1
+        pad, padf = dil * (KT - 1) // 2, (KF - 1) // 2
+        To, Fo = (T + 2 * pad - dil * (KT - 1) - 1) // st + 1, (Fq + 2 * padf - (KF - 1) - 1) // sf + 1
+        s = (st, sf, dil, padf)
         act = {None: 0, 'relu': N.VP_ACT_RELU, 'hardtanh': N.VP_ACT_HARDTANH20, 'silu': N.VP_ACT_SILU, 'tanh': N.VP_ACT_TANH}[
             cfg.get('act', 'relu' if cfg.get('relu', False) else None)]
         relu, bn = act != 0, gamma is not None
         wp = weight.permute(0, 3, 2, 1).reshape(Cout, KT * KF * Cin).contiguous()
         z = torch.empty((B * To * Fo, Cout), dtype=torch.float32, device=x.device)
-        d = _conv_desc(x, B, T, To, Cin, Cout, KT * KF, 1, N.VP_PAD_ZERO, pad, wp, bias)
-        d.F_in, d.F_out, d.KF, d.stride, d.stride_f, d.pad_f = Fq, Fo, KF, s, s, pad
+        d = _conv_desc(x, B, T, To, Cin, Cout, KT * KF, dil, N.VP_PAD_ZERO, pad, wp, bias)
+        d.F_in, d.F_out, d.KF, d.stride, d.stride_f, d.pad_f = Fq, Fo, KF, st, sf, padf
         d.y = z.data_ptr()
         _chk(lib.vp_conv1d_fwd(hctx, C.byref(d), N.stream_ptr()), hctx)
         mean = invstd = None
@@ -432,8 +437,9 @@ class Conv2dBlock(torch.autograd.Function):
             _chk(lib.vp_bn_relu_bwd_f32(hctx, dy.data_ptr(), Cout, z.data_ptr(), Cout, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
                                         sums.data_ptr(), M, Cout, 0, dz.data_ptr(), Cout, N.stream_ptr()), hctx)
         dbias = col_sums(dz)[0].clone() if has_bias else None
-        d = _conv_desc(x, B, T, To, Cin, Cout, KT * KF, 1, N.VP_PAD_ZERO, pad, weight)
-        d.F_in, d.F_out, d.KF, d.stride, d.stride_f, d.pad_f = Fq, Fo, KF, s, s, pad
+        st, sf, dil, padf = s
+        d = _conv_desc(x, B, T, To, Cin, Cout, KT * KF, dil, N.VP_PAD_ZERO, pad, weight)
+        d.F_in, d.F_out, d.KF, d.stride, d.stride_f, d.pad_f = Fq, Fo, KF, st, sf, padf
         dwp = torch.empty((Cout, KT * KF * Cin), dtype=torch.float32, device=dev)
         ws = _bytes(lib.vp_conv1d_wgrad_workspace_bytes(C.byref(d)), dev)
         _chk(lib.vp_conv1d_wgrad_f32(hctx, C.byref(d), dz.data_ptr(), Cout, dwp.data_ptr(), ws.data_ptr(), ws.numel(), N.stream_ptr()), hctx)
@@ -441,14 +447,15 @@ class Conv2dBlock(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             src = dz
-            if s > 1:                                   # zero-insertion: the stride-s data gradient as a stride-1 conv
+            strided = st > 1 or sf > 1
+            if strided:                                 # zero-insertion: the strided data gradient as a stride-1 conv
                 src = torch.empty((B * T * Fq, Cout), dtype=torch.float32, device=dev)
-                _chk(lib.vp_zero_insert_2d_f32(hctx, dz.data_ptr(), B, To, Fo, Cout, T, Fq, s, src.data_ptr(), N.stream_ptr()), hctx)
+                _chk(lib.vp_zero_insert_2d_f32(hctx, dz.data_ptr(), B, To, Fo, Cout, T, Fq, st, sf, src.data_ptr(), N.stream_ptr()), hctx)
             w2 = weight.flip(2, 3).permute(1, 3, 2, 0).reshape(Cin, KT * KF * Cout).contiguous()
             dx = torch.empty((B * T * Fq, Cin), dtype=torch.float32, device=dev)
-            Ts, Fs = (T, Fq) if s > 1 else (To, Fo)
-            d2 = _conv_desc(src, B, Ts, T, Cout, Cin, KT * KF, 1, N.VP_PAD_ZERO, KT - 1 - pad, w2)
-            d2.F_in, d2.F_out, d2.KF, d2.stride, d2.stride_f, d2.pad_f = Fs, Fq, KF, 1, 1, KF - 1 - pad
+            Ts, Fs = (T, Fq) if strided else (To, Fo)
+            d2 = _conv_desc(src, B, Ts, T, Cout, Cin, KT * KF, dil, N.VP_PAD_ZERO, dil * (KT - 1) - pad, w2)
+            d2.F_in, d2.F_out, d2.KF, d2.stride, d2.stride_f, d2.pad_f = Fs, Fq, KF, 1, 1, KF - 1 - padf
             d2.y = dx.data_ptr()
             _chk(lib.vp_conv1d_fwd(hctx, C.byref(d2), N.stream_ptr()), hctx)
         return dx, dW, dbias, dgamma, dbeta, None, None, None
@@ -499,3 +506,53 @@ class Act(torch.autograd.Function):
         dz = torch.empty_like(g)
         _chk(lib.vp_act_bwd_f32(hctx, ctx.code, g.data_ptr(), y.data_ptr(), g.numel(), dz.data_ptr(), N.stream_ptr()), hctx)
         return dz, None
+
+
+class SegCtx(torch.autograd.Function):
+    """ctx[b, s] = mean_t x[b] + mean over 100-frame segment s of x[b]  (CAMLayer context, models/campplus.py:88-106)."""
+
+    @staticmethod
+    def forward(ctx, x, B, T, seg_len):
+        lib, hctx = N.lib(), N.ctx(x.device)
+        x = _f32c(x)
+        Cc = x.shape[1]
+        nseg = (T + seg_len - 1) // seg_len
+        out = torch.empty((B * nseg, Cc), dtype=torch.float32, device=x.device)
+        _chk(lib.vp_seg_ctx_f32(hctx, x.data_ptr(), B, T, Cc, seg_len, out.data_ptr(), N.stream_ptr()), hctx)
+        ctx.geom = (B, T, Cc, seg_len)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, T, Cc, seg_len = ctx.geom
+        lib, hctx = N.lib(), N.ctx(g.device)
+        g = _f32c(g)
+        dx = torch.empty((B * T, Cc), dtype=torch.float32, device=g.device)
+        _chk(lib.vp_seg_ctx_bwd_f32(hctx, g.data_ptr(), B, T, Cc, seg_len, dx.data_ptr(), N.stream_ptr()), hctx)
+        return dx, None, None, None
+
+
+class SegScale(torch.autograd.Function):
+    """out[b, t] = y[b, t] * m[b, seg(t)]  (CAMLayer gate, models/campplus.py:94)."""
+
+    @staticmethod
+    def forward(ctx, y, m, B, T, seg_len):
+        lib, hctx = N.lib(), N.ctx(y.device)
+        y, m = _f32c(y), _f32c(m)
+        Cc = y.shape[1]
+        out = torch.empty_like(y)
+        _chk(lib.vp_seg_scale_f32(hctx, y.data_ptr(), m.data_ptr(), B, T, Cc, seg_len, out.data_ptr(), N.stream_ptr()), hctx)
+        ctx.save_for_backward(y, m)
+        ctx.geom = (B, T, seg_len)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        y, m = ctx.saved_tensors
+        B, T, seg_len = ctx.geom
+        lib, hctx = N.lib(), N.ctx(y.device)
+        g = _f32c(g)
+        dy, dm = torch.empty_like(y), torch.empty_like(m)
+        _chk(lib.vp_seg_scale_bwd_f32(hctx, g.data_ptr(), y.data_ptr(), m.data_ptr(), B, T, y.shape[1], seg_len, dy.data_ptr(), dm.data_ptr(),
+                                      N.stream_ptr()), hctx)
+        return dy, dm, None, None, None
