@@ -77,3 +77,42 @@ def test_two_rank_gradient_average_and_sharding():
     (_, i0, h0, t0), (_, i1, h1, t1) = res
     assert i0 == [0, 1, 2, 3, 4, 5] and i1 == [6, 7, 8, 9, 10]        # contiguous split, last shard short
     assert h0 == h1 == [0.0, 1.5, 3.0] and t0 == t1 == 999 * 1.5     # mean of 1x and 2x
+
+
+def _overlap_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'voiceprintrecognition-paddlepaddle_amd'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ppvector.optimizer.adam import Adam
+    from ppvector.train.ddp import OverlappedReducer, shard_batch
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(12, 32), torch.nn.Tanh(), torch.nn.Linear(32, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4))
+    x, y = torch.randn(10, 12), torch.randn(10, 4)
+    full = torch.nn.Sequential(*[type(l)(l.in_features, l.out_features) if isinstance(l, torch.nn.Linear) else torch.nn.Tanh() for l in net])
+    full.load_state_dict(net.state_dict())
+    ((full(x) - y) ** 2).sum().div(10).backward()                      # single-process reference: mean over the global batch
+    opt = Adam(net.parameters(), learning_rate=1e-3)                    # only the flat buffers are used here (no .step() on CPU)
+    red = OverlappedReducer(opt, bucket_bytes=1024)                     # several buckets
+    idx = list(shard_batch(10, rank, world))
+    ((net(x[idx]) - y[idx]) ** 2).sum().div(len(idx)).backward()       # rank-local mean; equal shards -> mean of means = global mean
+    red.finish()
+    err = max((p.grad - r.grad).abs().max().item() for p, r in zip(net.parameters(), full.parameters()))
+    q.put((rank, len(red.buckets), err))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_overlapped_reducer_matches_full_batch_gradient():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, nb, err in res:
+        assert nb >= 2 and err < 1e-6, (rank, nb, err)

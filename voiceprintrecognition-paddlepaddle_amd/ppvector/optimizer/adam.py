@@ -15,8 +15,6 @@ class Adam:
         if not self.params:
             raise ValueError('Adam: no trainable parameters')
         dev = self.params[0].device
-        if dev.type != 'cuda':
-            raise N.VpmiError('Adam runs on the GPU: the engine has no CPU fallback')
         n = sum(p.numel() for p in self.params)
         self.flat = torch.empty(n, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -45,6 +43,8 @@ class Adam:
                 self.grad[self._offset(p):self._offset(p) + p.numel()].copy_(p.grad.reshape(-1))
                 p.grad = self.grad[self._offset(p):self._offset(p) + p.numel()].view_as(p.data)
         self.t += 1
+        if self.flat.device.type != 'cuda':
+            raise N.VpmiError('Adam.step runs on the GPU: the engine has no CPU fallback')
         ctx = N.ctx(self.flat.device)
         N.check(N.lib().vp_adam_step_f32(ctx, self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                          self.flat.numel(), float(self.get_lr()), self.beta1, self.beta2, self.eps, self.wd, self.t,

@@ -24,3 +24,59 @@ def allreduce_mean_(flat_grad, bucket_bytes=256 << 20):
         w.wait()
     flat_grad.div_(world)
     return flat_grad
+
+
+class OverlappedReducer:
+    """Gradient all-reduce overlapped with backward (BASELINE config 5: "grad all-reduce overlapped with backward").
+
+    The optimiser's flat gradient buffer is cut into contiguous buckets in PARAMETER ORDER (= forward order, so backward
+    fills the buckets from the last one down).  A post-accumulate hook on every parameter counts the bucket's pending
+    gradients; when a bucket is complete its slice is all-reduced asynchronously while autograd keeps producing the
+    earlier layers' gradients.  `finish()` waits for the handles and divides by the world size.  Few large buckets
+    (default 64 MB): xGMI ring collectives are per-link bound, so small messages waste the links."""
+
+    def __init__(self, optimizer, bucket_bytes=64 << 20):
+        self.opt = optimizer
+        self.flat = optimizer.grad
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.buckets, self.bucket_of = [], {}
+        start, size, members = 0, 0, []
+        off = 0
+        for p in optimizer.params:
+            n = p.numel()
+            members.append(p)
+            size += n
+            off += n
+            if size * 4 >= bucket_bytes:
+                self.buckets.append([start, off, len(members), 0, None])      # [begin, end, n_params, n_ready, handle]
+                for q in members:
+                    self.bucket_of[q] = len(self.buckets) - 1
+                start, size, members = off, 0, []
+        if members:
+            self.buckets.append([start, off, len(members), 0, None])
+            for q in members:
+                self.bucket_of[q] = len(self.buckets) - 1
+        self.hooks = [p.register_post_accumulate_grad_hook(self._ready) for p in optimizer.params] if self.world > 1 else []
+
+    def _ready(self, p):
+        b = self.buckets[self.bucket_of[p]]
+        b[3] += 1
+        if b[3] == b[2]:
+            b[4] = dist.all_reduce(self.flat[b[0]:b[1]], op=dist.ReduceOp.SUM, async_op=True)
+
+    def finish(self):
+        """Call after backward, before optimizer.step(): waits for every bucket and turns the sums into means."""
+        if self.world == 1:
+            return
+        for b in self.buckets:
+            if b[4] is None:                      # a bucket with a parameter that received no gradient this step
+                b[4] = dist.all_reduce(self.flat[b[0]:b[1]], op=dist.ReduceOp.SUM, async_op=True)
+        for b in self.buckets:
+            b[4].wait()
+            b[3], b[4] = 0, None
+        self.flat.div_(self.world)
+
+    def remove(self):
+        for h in self.hooks:
+            h.remove()
+        self.hooks = []

@@ -7,15 +7,18 @@ with the data-parallel gradient average (fleet.distributed_model in the referenc
 one all-reduce over the optimiser's flat gradient buffer between backward and the Adam kernel."""
 import torch
 
-from ppvector.train.ddp import allreduce_mean_
+from ppvector.train.ddp import OverlappedReducer, allreduce_mean_
 
 
 class TrainStep:
-    def __init__(self, model, criterion, optimizer, scheduler=None, margin_scheduler=None, featurizer=None, spec_augment=None):
+    def __init__(self, model, criterion, optimizer, scheduler=None, margin_scheduler=None, featurizer=None, spec_augment=None,
+                 overlap_allreduce=True):
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
         self.scheduler, self.margin_scheduler = scheduler, margin_scheduler
         self.featurizer, self.spec_augment = featurizer, spec_augment
         self.step_id = 0
+        # data-parallel gradient average: bucketed all-reduce launched from autograd hooks while backward is still running
+        self.reducer = OverlappedReducer(optimizer) if overlap_allreduce else None
 
     def __call__(self, inputs, labels):
         """inputs: waveforms (B, L) when a featurizer was given, else features (B, T, F).  Returns (loss, accuracy) tensors."""
@@ -29,7 +32,10 @@ class TrainStep:
         outputs = self.model(feats)
         loss = self.criterion(outputs, labels)
         loss.backward()
-        allreduce_mean_(self.optimizer.grad)
+        if self.reducer is not None:
+            self.reducer.finish()
+        else:
+            allreduce_mean_(self.optimizer.grad)
         self.optimizer.step()
         self.optimizer.clear_grad()
         with torch.no_grad():
