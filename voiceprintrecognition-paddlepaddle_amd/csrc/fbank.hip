@@ -54,12 +54,10 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
 }
 
 __global__ __launch_bounds__(FB_WAVES * 64) void fbank_frames_kernel(FbankArgs a) {
-    __shared__ float2 s_tw[FB_NFFT];
     __shared__ float s_win[FB_MAX_WIN];
     __shared__ float s_melw[FB_MAX_NNZ];
     __shared__ int s_mstart[FB_MAX_MEL + 1];
     __shared__ int s_mbin0[FB_MAX_MEL];
-    __shared__ float s_frame[FB_WAVES][FB_MAX_WIN];
     __shared__ float2 s_buf[FB_WAVES][2][FB_NC + FB_NC / 16];   // one pad slot per 16: breaks the power-of-2 strides
     __shared__ float s_pow[FB_WAVES][FB_NC];
     __shared__ float s_red[FB_WAVES][FB_MAX_MEL];
@@ -70,27 +68,38 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_frames_kernel(FbankArgs a
     const int tile = blockIdx.x;
     const int b = blockIdx.y;
 
-    for (int i = tid; i < FB_NFFT; i += FB_WAVES * 64) s_tw[i] = a.tw[i];
     for (int i = tid; i < a.win; i += FB_WAVES * 64) s_win[i] = a.window[i];
     for (int i = tid; i < a.nnz; i += FB_WAVES * 64) s_melw[i] = a.mel_w[i];
     for (int i = tid; i <= a.n_mels; i += FB_WAVES * 64) s_mstart[i] = a.mel_start[i];
     for (int i = tid; i < a.n_mels; i += FB_WAVES * 64) s_mbin0[i] = a.mel_bin0[i];
+    // The kernel is bound by LDS instruction issue (~160 per lane per frame in its first version), so everything that is
+    // constant per lane lives in registers: the three twiddles of FFT stages 1..3 (stage 0's are 1) and the four
+    // real-FFT unpack twiddles.  The frame itself never goes through LDS: a lane loads the two samples of each of its
+    // packed points straight from global memory (fully coalesced) and gets the pre-emphasis neighbour by a lane shift.
+    float2 twr[3][3], twu[4];
+#pragma unroll
+    for (int s = 1; s < 4; ++s) {
+        const int jm = lane & ((1 << (2 * s)) - 1);
+        const int twstep = (FB_NFFT / 4) >> (2 * s);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) twr[s - 1][q] = a.tw[((q + 1) * jm * twstep) & (FB_NFFT - 1)];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) twu[r] = a.tw[lane + 64 * r];
     __syncthreads();
 
     const float* wav = a.wav + (size_t)b * a.L;
     float acc0 = 0.f, acc1 = 0.f;   // column sums for mel bins lane and lane+64
-    float* fr = s_frame[wv];
 
-    // The NEXT frame's window is fetched into registers while the current frame is transformed:
-    // a wave has nothing else to overlap the ~2k-cycle global latency with.
-    constexpr int NLD = FB_MAX_WIN / 64;             // 8 samples per lane cover windows up to 512
-    float nxt[NLD];
+    // packed point n = lane + 64 r holds samples 2n, 2n+1; the NEXT frame's samples are fetched while this one is transformed
+    float nx0[4], nx1[4];
     auto fetch = [&](int t) {
         const float* src = wav + (size_t)min(t, a.T - 1) * a.shift;
 #pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            const int i = lane + 64 * u;
-            nxt[u] = src[min(i, a.win - 1)];
+        for (int r = 0; r < 4; ++r) {
+            const int i0 = 2 * (lane + 64 * r);
+            nx0[r] = src[min(i0, a.win - 1)];
+            nx1[r] = src[min(i0 + 1, a.win - 1)];
         }
     };
     fetch(tile * FRAMES_PER_WG + wv);
@@ -98,33 +107,29 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_frames_kernel(FbankArgs a
     for (int fi = wv; fi < FRAMES_PER_WG; fi += FB_WAVES) {
         const int t = tile * FRAMES_PER_WG + fi;
         if (t >= a.T) break;                         // wave-uniform
+        float x0[4], x1[4];
         float part = 0.f;
 #pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            const int i = lane + 64 * u;
-            if (i < a.win) { fr[i] = nxt[u]; part += nxt[u]; }
+        for (int r = 0; r < 4; ++r) {
+            const int i0 = 2 * (lane + 64 * r);
+            x0[r] = nx0[r]; x1[r] = nx1[r];
+            part += (i0 < a.win ? x0[r] : 0.f) + (i0 + 1 < a.win ? x1[r] : 0.f);
         }
         fetch(t + FB_WAVES);                         // clamped; unused past the tile / utterance end
-        float mean = a.remove_dc ? vp_wave_sum(part) / (float)a.win : 0.f;
-        __builtin_amdgcn_wave_barrier();
-        // even/odd pack: z[n] = x[2n] + i x[2n+1], zero beyond the window
+        const float mean = a.remove_dc ? vp_wave_sum(part) / (float)a.win : 0.f;
+        // even/odd pack: z[n] = y[2n] + i y[2n+1], y[i] = ((x[i] - mean) - preemph (x[max(i-1,0)] - mean)) window[i], zero past the window
         float2* d0 = s_buf[wv][0];
         float2* d1 = s_buf[wv][1];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = lane + 64 * r;
-            float re = 0.f, im = 0.f;
             const int i0 = 2 * n, i1 = 2 * n + 1;
-            if (i0 < a.win) {
-                float c = fr[i0] - mean;
-                float p = fr[i0 > 0 ? i0 - 1 : 0] - mean;
-                re = (c - a.preemph * p) * s_win[i0];
-            }
-            if (i1 < a.win) {
-                float c = fr[i1] - mean;
-                float p = fr[i1 - 1] - mean;
-                im = (c - a.preemph * p) * s_win[i1];
-            }
+            float prev = __shfl_up(x1[r], 1);                                   // x[2n - 1] lives in the lane below
+            const float wrap = r > 0 ? __shfl(x1[r > 0 ? r - 1 : 0], 63) : x0[0];   // lane 0: last sample of the previous 64-point chunk
+            if (lane == 0) prev = r > 0 ? wrap : x0[0];                         // frame start: replicate sample 0
+            float re = 0.f, im = 0.f;
+            if (i0 < a.win) re = ((x0[r] - mean) - a.preemph * (prev - mean)) * s_win[i0];
+            if (i1 < a.win) im = ((x1[r] - mean) - a.preemph * (x0[r] - mean)) * s_win[i1];
             d0[pidx(n)] = make_float2(re, im);
         }
         __builtin_amdgcn_wave_barrier();
@@ -133,14 +138,15 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_frames_kernel(FbankArgs a
         for (int s = 0; s < 4; ++s) {
             const int Ns = 1 << (2 * s);
             const int jm = lane & (Ns - 1);
-            const int twstep = (FB_NFFT / 4) >> (2 * s);     // 512 / (4 * Ns)
             float2 v0 = d0[pidx(lane)];
             float2 v1 = d0[pidx(lane + 64)];
             float2 v2 = d0[pidx(lane + 128)];
             float2 v3 = d0[pidx(lane + 192)];
-            v1 = cmul(v1, s_tw[(jm * twstep) & (FB_NFFT - 1)]);
-            v2 = cmul(v2, s_tw[(2 * jm * twstep) & (FB_NFFT - 1)]);
-            v3 = cmul(v3, s_tw[(3 * jm * twstep) & (FB_NFFT - 1)]);
+            if (s > 0) {
+                v1 = cmul(v1, twr[s > 0 ? s - 1 : 0][0]);
+                v2 = cmul(v2, twr[s > 0 ? s - 1 : 0][1]);
+                v3 = cmul(v3, twr[s > 0 ? s - 1 : 0][2]);
+            }
             // radix-4 butterfly, forward (W4 = -i)
             float2 s02 = make_float2(v0.x + v2.x, v0.y + v2.y);
             float2 d02 = make_float2(v0.x - v2.x, v0.y - v2.y);
@@ -166,21 +172,26 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_frames_kernel(FbankArgs a
             float2 zn = d0[pidx((FB_NC - k) & (FB_NC - 1))];
             float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
             float2 o = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));  // (zk - conj(zn)) / (2i)
-            float2 wo = cmul(o, s_tw[k]);
+            float2 wo = cmul(o, twu[r]);
             float xr = e.x + wo.x, xi = e.y + wo.y;
             s_pow[wv][k] = xr * xr + xi * xi;
         }
         __builtin_amdgcn_wave_barrier();
         float* orow = a.out + ((size_t)b * a.T + t) * a.n_mels;
-        for (int m = lane, it = 0; m < a.n_mels; m += 64, ++it) {
+        // mel bins 0..63: one lane per filter.  Bins 64.. are the few widest filters (up to ~20 taps at 80 mels): 4 (or 2) lanes
+        // share one of them, a quarter of the taps each, and add up in fixed order -- instead of 16 lanes walking 20 taps
+        // while 48 idle.
+        auto mel_dot = [&](int m, int sub, int nsub) {
             const int s0 = s_mstart[m], n = s_mstart[m + 1] - s0, k0 = s_mbin0[m];
+            const int per = (n + nsub - 1) / nsub;
+            const int q0 = sub * per, q1 = min(n, q0 + per);
             float e = 0.f;
             // 4 taps per trip, loads independent of the accumulator: one LDS latency per 4 taps
-            for (int q = 0; q < n; q += 4) {
+            for (int q = q0; q < q1; q += 4) {
                 float wq[4], pq[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const bool in = q + u < n;
+                    const bool in = q + u < q1;
                     const float wv_ = s_melw[min(s0 + q + u, a.nnz - 1)];
                     wq[u] = in ? wv_ : 0.f;
                     pq[u] = s_pow[wv][min(k0 + q + u, FB_NC - 1)];
@@ -190,9 +201,25 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_frames_kernel(FbankArgs a
                 e += wq[2] * pq[2];
                 e += wq[3] * pq[3];
             }
-            float v = logf(fmaxf(e, a.log_floor));
-            orow[m] = v;
-            if (it == 0) acc0 += v; else acc1 += v;
+            return e;
+        };
+        if (lane < a.n_mels) {
+            const float v = logf(fmaxf(mel_dot(lane, 0, 1), a.log_floor));
+            orow[lane] = v;
+            acc0 += v;
+        }
+        if (a.n_mels > 64) {
+            const int nb2 = a.n_mels - 64;
+            const int lpb = nb2 <= 16 ? 4 : (nb2 <= 32 ? 2 : 1);         // lanes per bin (wave-uniform)
+            const int m = 64 + lane / lpb, sub = lane % lpb;
+            float e = m < a.n_mels ? mel_dot(m, sub, lpb) : 0.f;
+            if (lpb >= 2) e += __shfl_xor(e, 1);
+            if (lpb >= 4) e += __shfl_xor(e, 2);
+            const float v = logf(fmaxf(e, a.log_floor));
+            if (m < a.n_mels && sub == 0) orow[m] = v;
+            // column sum slot lane + 64 belongs to bin 64 + lane: hand the value to that lane
+            const float vv = __shfl(v, (lane * lpb) & 63);
+            if (lane < nb2) acc1 += vv;
         }
         __builtin_amdgcn_wave_barrier();
     }
