@@ -305,6 +305,36 @@ def test_conv1d_rejects_bad_shapes(N):
     w = torch.randn(16, 16, 3, dtype=torch.float64)
     with pytest.raises(N.VpmiError):
         run_conv(N, x, w, None, 3, 4, 'reflect', 'f32')             # reflect pad >= T
+    # maximum sizes: an operand past the 32-bit buffer-offset range (4 GiB) is refused before any launch
+    lib, ctx = N.lib(), N.ctx(0)
+    small = torch.zeros(64, dtype=torch.bfloat16, device='cuda')
+    d = N.Conv1dDesc()
+    d.dtype_in = d.dtype_out = N.VP_BF16
+    d.B, d.T_in, d.T_out, d.Cin, d.Cout, d.KW, d.dilation, d.stride = 4096, 4096, 4096, 512, 512, 1, 1, 1
+    d.pad_mode = N.VP_PAD_REFLECT
+    d.x, d.ldx, d.w, d.y, d.ldy = small.data_ptr(), 512, small.data_ptr(), small.data_ptr(), 512
+    rc = lib.vp_conv1d_fwd(ctx, C.byref(d), N.stream_ptr())
+    assert rc == N.VP_EUNSUP and b'4 GiB' in lib.vp_last_error(ctx)
+    d.B = 0                                                          # empty batch
+    assert lib.vp_conv1d_fwd(ctx, C.byref(d), N.stream_ptr()) == N.VP_EINVAL
+
+
+def test_empty_and_degenerate_inputs_are_refused(N):
+    """Empty batches, utterances shorter than one analysis window and single-frame pooling are errors with a message,
+    as in the reference (featurizer.py asserts / paddle shape errors) -- never a silent zero-size launch."""
+    from ppvector.data_utils.featurizer import AudioFeaturizer
+    from ppvector.models.ecapa_tdnn import EcapaTdnn
+    fz = AudioFeaturizer('Fbank', dict(sr=16000, n_mels=80))
+    with pytest.raises((ValueError, N.VpmiError)):
+        fz(torch.zeros((0, 16000), device='cuda'))
+    with pytest.raises((ValueError, N.VpmiError)):
+        fz(torch.zeros((2, 399), device='cuda'))                    # < one 25 ms window
+    assert fz(torch.zeros((1, 400), device='cuda')).shape == (1, 1, 80)
+    m = EcapaTdnn(80).cuda().eval()
+    with pytest.raises((ValueError, N.VpmiError)):
+        m(torch.zeros((0, 50, 80), device='cuda'))
+    one = m(torch.randn((1, 30, 80), device='cuda'))                # B = 1 works
+    assert one.shape == (1, 192) and torch.isfinite(one).all()
 
 
 # --------------------------------------------------------------------------------------- small ops

@@ -15,6 +15,7 @@ PKG_ROOT = os.path.dirname(HERE)
 LIB_PATH = os.environ.get('VPMI_LIB') or os.path.join(PKG_ROOT, 'lib', 'libvpmi.so')   # VPMI_LIB: A/B a build
 
 VP_F32, VP_BF16 = 0, 1
+VP_OK, VP_EINVAL, VP_ENOMEM, VP_EHIP, VP_EUNSUP, VP_EWORKSPACE = 0, -1, -2, -3, -4, -5
 VP_PAD_NONE, VP_PAD_REFLECT, VP_PAD_ZERO = 0, 1, 2
 VP_ACT_NONE, VP_ACT_RELU, VP_ACT_SIGMOID, VP_ACT_TANH, VP_ACT_HARDTANH20, VP_ACT_SILU = 0, 1, 2, 3, 4, 5
 VP_MAX_SE_BLOCKS, VP_MAX_RES2 = 8, 15
