@@ -314,6 +314,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
 
     // ------------------------------------------------------------------ epilogue
     // y = act2( bn( act( acc + bias + rowbias ) ) * gate + res );   aux = y + add_in
+    // y goes out through a wave-private LDS slab (the staging buffers are free now): the accumulator layout would store
+    // 8 bytes per lane, 16 rows per instruction -- the vector-memory path handles that a lane at a time -- while the slab
+    // is copied out 16 bytes per lane, whole rows contiguous.  Row stride = row bytes + 16: conflict-free ds_write_b64.
+    constexpr int SLAB_ROW = WCOLS * (int)sizeof(TO) + 16;
+    char* slab = smem + wv * (MI * 16 * SLAB_ROW);
     TO* __restrict__ Y = static_cast<TO*>(a.y);
     TO* __restrict__ Y2 = static_cast<TO*>(a.y2);
     const TO* __restrict__ ADD = static_cast<const TO*>(a.add_in);
@@ -358,8 +363,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
                 else if (a.act2 == VP_ACT_SILU) t = t / (1.f + __expf(-t));
                 v[r] = t;
             }
+            store4(reinterpret_cast<TO*>(slab + (mi * 16 + li) * SLAB_ROW) + ni * 16 + g * 4, v);
             if (ok) {
-                store4(Y + (size_t)m * a.ldy + a.yoff + nb, v);
                 if (nb < a.ysplit) store4(Y2 + (size_t)m * a.ldy2 + a.y2off + nb, v);
                 if (AUX) {
                     float ad[4];
@@ -373,7 +378,34 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
             for (int r = 0; r < 4; ++r) acc[mi][ni][r] = ok ? (v[r] - sh4[r]) : 0.f;
         }
     }
+    {
+        constexpr int EPL = 16 / (int)sizeof(TO);              // elements per 16-byte lane chunk
+        constexpr int LPR = WCOLS / EPL;                       // lanes per row
+        constexpr int RPI = 64 / LPR;                          // rows per wave-instruction
+        const int cl = (lane % LPR) * EPL, rl = lane / LPR;
+        const int nc = n0 + wn * WCOLS + cl;
+        const bool vec16 = ((a.ldy * (int)sizeof(TO)) & 15) == 0 && ((a.yoff * (int)sizeof(TO)) & 15) == 0 &&
+                           (reinterpret_cast<uintptr_t>(a.y) & 15) == 0;
+#pragma unroll
+        for (int j = 0; j < MI * 16 / RPI; ++j) {
+            const int r = j * RPI + rl;
+            const int m = m0 + wm * (MI * 16) + r;
+            const u32x4 o = *reinterpret_cast<const u32x4*>(slab + r * SLAB_ROW + cl * (int)sizeof(TO));
+            if (m < a.M) {
+                TO* dst = Y + (size_t)m * a.ldy + a.yoff + nc;
+                if (vec16 && nc + EPL <= a.N) {
+                    *reinterpret_cast<u32x4*>(dst) = o;
+                } else if constexpr (sizeof(TO) == 2) {        // 8-byte halves (N % 4 == 0, 8-byte alignment guaranteed)
+                    if (nc < a.N) *reinterpret_cast<uint2*>(dst) = make_uint2(o[0], o[1]);
+                    if (nc + 4 < a.N) *reinterpret_cast<uint2*>(dst + 4) = make_uint2(o[2], o[3]);
+                } else {
+                    if (nc < a.N) *reinterpret_cast<u32x4*>(dst) = o;     // f32: 4 elements = 16 bytes, always aligned (ldy, yoff % 4)
+                }
+            }
+        }
+    }
     if (a.psum) {
+        __syncthreads();                                       // slabs are read out before `red` reuses the memory
         // per (M-tile, utterance segment) column sums, deterministic: lanes -> waves -> workgroup
         float* red = reinterpret_cast<float*>(smem);          // [2][WM][NSEG_MAX][BN]
         for (int s = 0; s < a.nseg; ++s) {
@@ -420,7 +452,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
 
 template <typename TI, typename TO, int BN, int MODE>
 int launch_conv(vp_ctx* ctx, const ConvArgs& a, hipStream_t st) {
-    constexpr int smem = 2 * (BM + BN) * ROWB;
+    constexpr int NI_ = BN >= 64 ? 4 : BN / 16, WN_ = BN / (NI_ * 16), MI_ = BM / ((4 / WN_) * 16);
+    constexpr int slab_ = 4 * MI_ * 16 * (NI_ * 16 * (int)sizeof(TO) + 16);              // output slabs of the epilogue
+    constexpr int smem = 2 * (BM + BN) * ROWB > slab_ ? 2 * (BM + BN) * ROWB : slab_;
     static bool attr_set = false;
     if (!attr_set) {
         VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_kernel<TI, TO, BN, MODE>),
