@@ -246,9 +246,9 @@ typedef struct {
     const float* bn1_shift;
     vp_tdnn_layer linear1;    /* 1x1 cin -> bn_channels; bn_scale/shift = nonlinear2, ReLU follows */
     vp_tdnn_layer local;      /* cam_layer.linear_local: k3, dilation, zero 'same' pad, bias only */
-    const float* ctx_w1;      /* [bn_channels/2][bn_channels] f32 */
+    const float* ctx_w1;      /* [bn_channels][bn_channels/2] f32, input-major (Conv1D weight transposed) */
     const float* ctx_b1;
-    const float* ctx_w2;      /* [growth][bn_channels/2] f32 */
+    const float* ctx_w2;      /* [bn_channels/2][growth] f32, input-major */
     const float* ctx_b2;
 } vp_cam_layer;
 

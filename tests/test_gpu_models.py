@@ -297,3 +297,27 @@ def test_eres2net_matches_reference_golden(golden_dir):
         ref3 = oer.eres2net_forward(p, torch.from_numpy(feats)).numpy()
     e3 = m.engine('float32').forward(torch.from_numpy(feats).cuda()).cpu().numpy()
     assert np.linalg.norm(e3 - ref3) / np.linalg.norm(ref3) < 3e-4
+
+
+def test_graph_mode_replays_identical_embeddings(golden_dir):
+    """ppvector.set_graph_mode(True): the eval forward replayed from a captured HIP graph gives bit-identical embeddings, also
+    for a second batch of the same shape (static buffers are refreshed) and a new shape (a second graph)."""
+    import ppvector
+    from oracle import campplus as oc
+    from ppvector.models.campplus import CAMPPlus
+    m = CAMPPlus(80, embd_dim=192)
+    m.load_state_dict(oc.campplus_params(80, 192, seed=1000))
+    m = m.cuda().eval()
+    ppvector.set_compute_dtype('bfloat16')
+    try:
+        g = torch.Generator().manual_seed(5)
+        xs = [torch.randn(4, 150, 80, generator=g).cuda() * 2, torch.randn(4, 150, 80, generator=g).cuda() * 2,
+              torch.randn(3, 220, 80, generator=g).cuda() * 2]
+        ref = [m(x).clone() for x in xs]
+        ppvector.set_graph_mode(True)
+        for _ in range(2):
+            for x, r in zip(xs, ref):
+                assert torch.equal(m(x), r)
+    finally:
+        ppvector.set_graph_mode(False)
+        ppvector.set_compute_dtype('float32')

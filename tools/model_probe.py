@@ -38,4 +38,18 @@ for name, cls, params in (('EcapaTdnn', EcapaTdnn, om.ecapa_params(80)), ('TDNN'
             a.record(); eng.forward(xin); b.record()
         torch.cuda.synchronize()
         ms = sorted(a.elapsed_time(b) for a, b in evs)[2]
+        import ppvector
+        gms = None
+        if os.environ.get('VP_GRAPH') == '1':
+            ppvector.set_compute_dtype(dt); ppvector.set_graph_mode(True)
+            for _ in range(2):
+                m(xin)
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+            for a, b in evs:
+                a.record(); m(xin); b.record()
+            torch.cuda.synchronize()
+            gms = sorted(a.elapsed_time(b) for a, b in evs)[2]
+            ppvector.set_graph_mode(False); ppvector.set_compute_dtype('float32')
+        if gms is not None:
+            print(f'{name:10s} {dt:9s} B={B}: graph replay {gms:8.3f} ms  {B / gms * 1e3:10.0f} utt/s', flush=True)
         print(f'{name:10s} {dt:9s} B={B}: {ms:8.3f} ms  {B / ms * 1e3:10.0f} utt/s  {B * GF[name] / ms:8.1f} TFLOP/s (algorithmic)', flush=True)

@@ -101,6 +101,83 @@ __global__ __launch_bounds__(256) void cam_ctx_kernel(CtxArgs<T> a) {
     }
 }
 
+// ------------------------------------------------------------------ CAM context gate in one launch
+// gate[b, s, :] = sigmoid(W2 relu(W1 (mean_t x[b] + mean_{t in seg s} x[b]) + b1) + b2)   (campplus.py:88-94).
+// One workgroup per utterance.  Phase 1 reads the utterance's (T, C) block with 16-byte loads, 16 lanes per frame and 16
+// frame groups in flight (the first version walked ~75 frames per thread with dependent 2-byte loads: 20 us, plus two
+// dense launches of ~5 us each per layer, 52 layers).  Phases 2 / 3: a thread per output, weights input-major [in][out].
+template <typename T>
+struct GateArgs { const T* x; const float* w1; const float* b1; const float* w2; const float* b2; float* gate; int ldx, Tn, C, H, G, seg_len, nseg; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void cam_gate_kernel(GateArgs<T> a) {
+    extern __shared__ float sm[];                 // part[16][nseg][C] | ctx[nseg][C] | h[nseg][H] | w1[C][H] | w2[H][G]
+    constexpr int V = 16 / (int)sizeof(T);        // channels per 16-byte load
+    float* part = sm;
+    float* cx = part + 16 * a.nseg * a.C;
+    float* hh = cx + a.nseg * a.C;
+    float* w1s = hh + a.nseg * a.H;
+    float* w2s = w1s + a.C * a.H;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    // both weight matrices into LDS with one round of independent 16-byte loads (read per output from global, each of the
+    // C + H loop trips paid a memory latency: 72 us per layer)
+    for (int i = tid; i < a.C * a.H / 4; i += 256) reinterpret_cast<float4*>(w1s)[i] = reinterpret_cast<const float4*>(a.w1)[i];
+    for (int i = tid; i < a.H * a.G / 4; i += 256) reinterpret_cast<float4*>(w2s)[i] = reinterpret_cast<const float4*>(a.w2)[i];
+    const int lpr = a.C / V;                      // lanes per frame (host: lpr divides 256, lpr <= 16 ... 32)
+    const int rgs = min(256 / lpr, 16);           // frame groups in flight (threads past 16 groups idle in phase 1)
+    const int cq = (tid % lpr) * V, rg = tid / lpr;
+    const T* xb = a.x + (size_t)b * a.Tn * a.ldx;
+    for (int s = 0; s < a.nseg; ++s) {
+        const int t0 = s * a.seg_len, t1 = min(t0 + a.seg_len, a.Tn);
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+#pragma unroll 4
+        for (int t = t0 + rg; t < t1 && rg < rgs; t += rgs) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(xb + (size_t)t * a.ldx + cq);
+            const T* v = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] += vp_to_f32(v[e]);
+        }
+        if (rg < rgs) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) part[(rg * a.nseg + s) * a.C + cq + e] = acc[e];
+        }
+    }
+    __syncthreads();
+    const int ng = rgs;
+    for (int c = tid; c < a.C; c += 256) {
+        float tot = 0.f;
+        for (int s = 0; s < a.nseg; ++s) {
+            float v = 0.f;
+            for (int q = 0; q < ng; ++q) v += part[(q * a.nseg + s) * a.C + c];
+            cx[s * a.C + c] = v;
+            tot += v;
+        }
+        const float mean = tot / (float)a.Tn;
+        for (int s = 0; s < a.nseg; ++s) {
+            const int len = min(a.seg_len, a.Tn - s * a.seg_len);
+            cx[s * a.C + c] = mean + cx[s * a.C + c] / (float)len;
+        }
+    }
+    __syncthreads();
+    for (int o = tid; o < a.nseg * a.H; o += 256) {
+        const int s = o / a.H, j = o - s * a.H;
+        float acc = a.b1[j];
+#pragma unroll 16
+        for (int k = 0; k < a.C; ++k) acc += cx[s * a.C + k] * w1s[k * a.H + j];
+        hh[o] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    for (int o = tid; o < a.nseg * a.G; o += 256) {
+        const int s = o / a.G, j = o - s * a.G;
+        float acc = a.b2[j];
+#pragma unroll 16
+        for (int k = 0; k < a.H; ++k) acc += hh[s * a.H + k] * w2s[k * a.G + j];
+        a.gate[((size_t)b * a.nseg + s) * a.G + j] = 1.f / (1.f + __expf(-acc));
+    }
+}
+
 // ------------------------------------------------------------------ out_nonlinear (BN + ReLU) + statistics pooling
 // campplus.py:323-326: relu(bn(x)) -> mean and UNBIASED std over time -> (B, 2C)
 template <typename T>
@@ -304,20 +381,26 @@ int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats
             d.bn_scale = L.linear1.bn_scale; d.bn_shift = L.linear1.bn_shift; d.act2 = VP_ACT_RELU; d.y = p.h2; d.ldy = bnc;
             if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
             // context gate m = sigmoid(W2 relu(W1 (mean + segmean) + b1) + b2), one row per (utterance, segment)
-            const size_t smem = (size_t)(256 / bnc) * nseg * bnc * sizeof(float);
-            if (smem > 64 * 1024) VP_FAIL(ctx, VP_EUNSUP, "campplus: utterance too long for the context kernel");
-            if (dt == VP_BF16) {
-                CtxArgs<bf16_t> ca{(const bf16_t*)p.h2, p.ctx, bnc, Tn, bnc, w->seg_len, nseg};
-                hipLaunchKernelGGL(cam_ctx_kernel<bf16_t>, dim3(B), dim3(256), smem, st, ca);
-            } else {
-                CtxArgs<float> ca{(const float*)p.h2, p.ctx, bnc, Tn, bnc, w->seg_len, nseg};
-                hipLaunchKernelGGL(cam_ctx_kernel<float>, dim3(B), dim3(256), smem, st, ca);
+            {
+                const int V = dt == VP_BF16 ? 8 : 4, lpr = bnc / V;
+                const size_t smem = (size_t)(16 * nseg * bnc + nseg * bnc + nseg * (bnc / 2) + bnc * (bnc / 2) + (bnc / 2) * gr) * sizeof(float);
+                static bool gate_attr = false;
+                if (!gate_attr) {
+                    VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(cam_gate_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                    VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(cam_gate_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                    gate_attr = true;
+                }
+                if (smem > 128 * 1024 || bnc % V || lpr > 256 || 256 % lpr || (bnc * (bnc / 2)) % 4 || ((bnc / 2) * gr) % 4)
+                    VP_FAIL(ctx, VP_EUNSUP, "campplus: utterance too long / bottleneck width not supported by the context-gate kernel");
+                if (dt == VP_BF16) {
+                    GateArgs<bf16_t> ga{(const bf16_t*)p.h2, L.ctx_w1, L.ctx_b1, L.ctx_w2, L.ctx_b2, p.gate, bnc, Tn, bnc, bnc / 2, gr, w->seg_len, nseg};
+                    hipLaunchKernelGGL(cam_gate_kernel<bf16_t>, dim3(B), dim3(256), smem, st, ga);
+                } else {
+                    GateArgs<float> ga{(const float*)p.h2, L.ctx_w1, L.ctx_b1, L.ctx_w2, L.ctx_b2, p.gate, bnc, Tn, bnc, bnc / 2, gr, w->seg_len, nseg};
+                    hipLaunchKernelGGL(cam_gate_kernel<float>, dim3(B), dim3(256), smem, st, ga);
+                }
+                VP_LAUNCH_CHECK(ctx, "cam_gate");
             }
-            VP_LAUNCH_CHECK(ctx, "cam_ctx");
-            if ((rc = vp_dense_f32_ex(ctx, p.ctx, bnc, L.ctx_w1, 0, L.ctx_b1, nullptr, nullptr, B * nseg, bnc / 2, bnc,
-                                      VP_ACT_RELU, p.c1, bnc / 2, st))) return rc;
-            if ((rc = vp_dense_f32_ex(ctx, p.c1, bnc / 2, L.ctx_w2, 0, L.ctx_b2, nullptr, nullptr, B * nseg, gr, bnc / 2,
-                                      VP_ACT_SIGMOID, p.gate, gr, st))) return rc;
             // y = linear_local(h2) * m, written in place as the layer's new channels
             memset(&d, 0, sizeof(d));
             d.dtype_in = dt; d.dtype_out = dt; d.B = B; d.T_in = Tn; d.T_out = Tn; d.Cin = bnc; d.Cout = gr;

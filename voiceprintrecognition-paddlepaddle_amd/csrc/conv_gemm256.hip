@@ -178,7 +178,7 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(const ConvArgs a) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](int s) {
+    [[maybe_unused]] auto compute = [&](int s) {
         const char* Xs = smem + s * STAGE2;
         const char* Ws = Xs + T2 * ROWB;
 #pragma unroll

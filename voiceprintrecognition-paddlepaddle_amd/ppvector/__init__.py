@@ -1,7 +1,8 @@
 """MI355X-native drop-in for the hot path of ``ppvector`` (yeyupiaoling/VoiceprintRecognition-PaddlePaddle).
 
 Same module paths, class names and call signatures as the reference package for the path
-Fbank -> ECAPA-TDNN / TDNN -> cosine head -> AAMLoss -> scoring; compute runs in libvpmi.so
+Fbank / MelSpectrogram -> ECAPA-TDNN / TDNN / CAM++ / ResNetSE / ERes2Net -> cosine head -> AAMLoss -> scoring, and the
+training step of the same models; compute runs in libvpmi.so
 (hand-written HIP for gfx950, include/vpmi.h).  PyTorch is used for device memory and streams.
 """
 __version__ = "1.1.1+mi355x.0"
@@ -20,3 +21,17 @@ def set_compute_dtype(name):
 
 def get_compute_dtype():
     return _COMPUTE_DTYPE
+
+
+_GRAPH_MODE = False
+
+
+def set_graph_mode(on):
+    """Eval-mode backbones replay their launch sequence from a captured HIP graph (one per input shape and dtype) instead of
+    issuing ~50-400 launches from the host: pays for the launch-bound models (CAM++: 52 dense layers of small kernels)."""
+    global _GRAPH_MODE
+    _GRAPH_MODE = bool(on)
+
+
+def get_graph_mode():
+    return _GRAPH_MODE
