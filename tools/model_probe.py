@@ -28,7 +28,7 @@ for name, cls, params in (('EcapaTdnn', EcapaTdnn, om.ecapa_params(80)), ('TDNN'
     m = cls(80)
     m.load_state_dict(params)
     m = m.cuda().eval()
-    for dt in ('bfloat16', 'float32'):
+    for dt in (('bfloat16',) if os.environ.get('VP_BF16_ONLY') == '1' else ('bfloat16', 'float32')):
         eng = m.engine(dt)
         xin = x.to(torch.bfloat16) if dt == 'bfloat16' else x
         for _ in range(2):
