@@ -1,25 +1,25 @@
-"""build_loss registry (ppvector/loss/__init__.py:16-22): class by ``configs.loss_conf.loss``,
-kwargs from ``configs.loss_conf.loss_args``."""
-import importlib
+"""Loss factory.  Same contract as the reference's ``build_loss(configs)`` (ppvector/loss/__init__.py:16-22): the class is
+named by ``configs.loss_conf.loss`` and built with ``configs.loss_conf.loss_args``; an unknown name is an AttributeError on
+this module, a known-but-unbuilt one says so."""
 import logging
 
 from .aamloss import AAMLoss
 
-logger = logging.getLogger('ppvector')
-
 __all__ = ['build_loss']
 
-_NOT_BUILT = ('AMLoss', 'ARMLoss', 'CELoss', 'SphereFace2', 'SubCenterLoss', 'TripletAngularMarginLoss')
+_LOG = logging.getLogger('ppvector')
+_BUILT = {'AAMLoss': AAMLoss}
+_REFERENCE_ONLY = frozenset(('AMLoss', 'ARMLoss', 'CELoss', 'SphereFace2', 'SubCenterLoss', 'TripletAngularMarginLoss'))
 
 
 def build_loss(configs):
-    use_loss = configs.loss_conf.get('loss', 'AAMLoss')
-    loss_args = configs.loss_conf.get('loss_args', {})
-    los = importlib.import_module(__name__)
-    if not hasattr(los, use_loss):
-        if use_loss in _NOT_BUILT:
-            raise NotImplementedError(f'{use_loss} is not built on the HIP engine yet (AAMLoss is)')
-        raise AttributeError(f"module '{__name__}' has no attribute '{use_loss}'")
-    loss = getattr(los, use_loss)(**loss_args)
-    logger.info(f'成功创建损失函数：{use_loss}，参数为：{loss_args}')
-    return loss
+    conf = configs.loss_conf
+    name, kwargs = conf.get('loss', 'AAMLoss'), dict(conf.get('loss_args', {}) or {})
+    cls = _BUILT.get(name)
+    if cls is None:
+        if name in _REFERENCE_ONLY:
+            raise NotImplementedError(f'{name} is not built on the HIP engine yet (AAMLoss is)')
+        raise AttributeError(f"module '{__name__}' has no attribute '{name}'")
+    criterion = cls(**kwargs)
+    _LOG.info('成功创建损失函数：%s，参数为：%s', name, kwargs)
+    return criterion

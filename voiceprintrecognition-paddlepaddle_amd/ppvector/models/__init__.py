@@ -1,6 +1,6 @@
-"""build_model registry (ppvector/models/__init__.py:15-21): class by name from
-``configs.model_conf.model``, kwargs from ``configs.model_conf.model_args``."""
-import importlib
+"""Backbone factory.  Same contract as the reference's ``build_model(input_size, configs)`` (ppvector/models/__init__.py:15-21):
+the class is named by ``configs.model_conf.model`` (default 'CAMPPlus') and receives ``input_size`` plus
+``configs.model_conf.model_args``; the result exposes ``.embd_dim`` and maps (B, T, F) features to (B, embd_dim)."""
 import logging
 
 from .campplus import CAMPPlus
@@ -9,21 +9,21 @@ from .eres2net import ERes2Net
 from .resnet_se import ResNetSE
 from .tdnn import TDNN
 
-logger = logging.getLogger('ppvector')
-
 __all__ = ['build_model']
 
-_NOT_BUILT = ('ERes2NetV2', 'Res2Net')
+_LOG = logging.getLogger('ppvector')
+_BUILT = {cls.__name__: cls for cls in (CAMPPlus, EcapaTdnn, ERes2Net, ResNetSE, TDNN)}
+_REFERENCE_ONLY = frozenset(('ERes2NetV2', 'Res2Net'))
 
 
 def build_model(input_size, configs):
-    use_model = configs.model_conf.get('model', 'CAMPPlus')
-    model_args = configs.model_conf.get('model_args', {})
-    mod = importlib.import_module(__name__)
-    if not hasattr(mod, use_model):
-        if use_model in _NOT_BUILT:
-            raise NotImplementedError(f'{use_model} is not built on the HIP engine yet (EcapaTdnn, TDNN, CAMPPlus, ResNetSE and ERes2Net are)')
-        raise AttributeError(f"module '{__name__}' has no attribute '{use_model}'")
-    model = getattr(mod, use_model)(input_size=input_size, **model_args)
-    logger.info(f'成功创建模型：{use_model}，参数为：{model_args}')
-    return model
+    conf = configs.model_conf
+    name, kwargs = conf.get('model', 'CAMPPlus'), dict(conf.get('model_args', {}) or {})
+    cls = _BUILT.get(name)
+    if cls is None:
+        if name in _REFERENCE_ONLY:
+            raise NotImplementedError(f'{name} is not built on the HIP engine yet ({", ".join(sorted(_BUILT))} are)')
+        raise AttributeError(f"module '{__name__}' has no attribute '{name}'")
+    backbone = cls(input_size=input_size, **kwargs)
+    _LOG.info('成功创建模型：%s，参数为：%s', name, kwargs)
+    return backbone
