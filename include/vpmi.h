@@ -334,7 +334,8 @@ int vp_resnetse_fwd(vp_ctx* ctx, const vp_resnetse_weights* w, const void* feats
 /* ------------------------------------------------------------------------------------------------
  * ERes2Net backbone forward, eval mode -- replaces ERes2Net.forward (models/eres2net.py:239-263) with
  * BasicBlockERes2Net (:56-108), BasicBlockERes2Net_diff_AFF (:111-169), AFF (:33-53), the stride-2 stage
- * fusion convs and TemporalStatsPool (models/pooling.py:128-146).  2-D conv weights [Cout][tap*Cin + c],
+ * fusion convs and TemporalStatsPool (models/pooling.py:128-146); ERes2NetV2 (:266-462) is the same graph with one fusion and
+ * chunk widths 13 / 26 / 52 / 104, which the host zero-pads to multiples of 8.  2-D conv weights [Cout][tap*Cin + c],
  * tap = kt*3 + kf; BatchNorm folded to scale/shift; seg_1 permuted to the engine's (f*C + c) order.
  * ---------------------------------------------------------------------------------------------- */
 #define VP_MAX_ERE_BLOCKS 40
@@ -355,6 +356,7 @@ typedef struct {
     int dtype;
     int feat_dim, embd_dim, n_blocks, m_channels;
     int stage_blocks[4];
+    int first_fuse;           /* 0: ERes2Net (three bottom-up fusions, down / fuse [0..2]); 2: ERes2NetV2 (layer3_ds + fuse34 only, slot 2) */
     const float* c1_w;        /* [m][9] f32, tap = kt*3 + kf */
     const float* c1_b;
     const float* c1_scale;

@@ -86,6 +86,22 @@ def eres2net_forward(p, x, num_blocks=(3, 4, 6, 3), m_channels=32, expansion=2, 
     return stats @ p['seg_1.weight'] + p['seg_1.bias']
 
 
+def eres2netv2_forward(p, x, num_blocks=(3, 4, 6, 3), m_channels=32, expansion=2, base_width=26, scale=2, training=False):
+    """ERes2NetV2.forward (eres2net.py:441-462): same blocks with base_width 26 (chunk widths 13 / 26 / 52 / 104), ONE bottom-up
+    fusion (layer3_ds + fuse34), TSTP, Linear."""
+    x = x.transpose(1, 2).unsqueeze(1)
+    out = F.relu(_bn(_c2d(x, p, 'conv1.', padding=1), p, 'bn1.', training))
+    stage = []
+    for li, (n, mult) in enumerate(zip(num_blocks, (1, 2, 4, 8)), start=1):
+        planes = m_channels * mult
+        width = int(math.floor(planes * (base_width / 64.0)))
+        for bi in range(n):
+            out = block(out, p, f'layer{li}.{bi}.', (1 if li == 1 else 2) if bi == 0 else 1, width, scale, li >= 3, training)
+        stage.append(out)
+    f34 = aff(stage[3], _c2d(stage[2], p, 'layer3_ds.', stride=2, padding=1), p, 'fuse34.', training)
+    return tstp(f34) @ p['seg_1.weight'] + p['seg_1.bias']
+
+
 def _aff_params(p, pre, channels, rng, randomize_stats, r=4):
     inter = channels // r
     p.update(_conv(pre + 'local_att.0.', (inter, channels * 2, 1, 1), rng)); p.update(_bn_keys(pre + 'local_att.1.', inter, rng, randomize_stats))
@@ -93,7 +109,7 @@ def _aff_params(p, pre, channels, rng, randomize_stats, r=4):
 
 
 def eres2net_params(input_size=80, embd_dim=192, num_blocks=(3, 4, 6, 3), m_channels=32, mul_channel=1, expansion=2, base_width=32,
-                    scale=2, seed=1000, randomize_stats=True, dtype=torch.float32):
+                    scale=2, seed=1000, randomize_stats=True, dtype=torch.float32, v2=False):
     """Random ERes2Net parameters keyed with the reference's Paddle names (configs/eres2net.yml: m_channels 32, embd 192)."""
     rng = np.random.RandomState(seed)
     p = {}
@@ -117,12 +133,16 @@ def eres2net_params(input_size=80, embd_dim=192, num_blocks=(3, 4, 6, 3), m_chan
                 p.update(_bn_keys(pre + 'shortcut.1.', planes * expansion, rng, randomize_stats))
             inpl = planes * expansion
     m = m_channels * mul_channel
-    p.update(_conv('layer1_downsample.', (m * 4, m * 2, 3, 3), rng))
-    p.update(_conv('layer2_downsample.', (m * 8, m * 4, 3, 3), rng))
-    p.update(_conv('layer3_downsample.', (m * 16, m * 8, 3, 3), rng))
-    _aff_params(p, 'fuse_mode12.', m * 4, rng, randomize_stats)
-    _aff_params(p, 'fuse_mode123.', m * 8, rng, randomize_stats)
-    _aff_params(p, 'fuse_mode1234.', m * 16, rng, randomize_stats)
+    if v2:
+        p.update(_conv('layer3_ds.', (m * 16, m * 8, 3, 3), rng))
+        _aff_params(p, 'fuse34.', m * 16, rng, randomize_stats)
+    else:
+      p.update(_conv('layer1_downsample.', (m * 4, m * 2, 3, 3), rng))
+      p.update(_conv('layer2_downsample.', (m * 8, m * 4, 3, 3), rng))
+      p.update(_conv('layer3_downsample.', (m * 16, m * 8, 3, 3), rng))
+      _aff_params(p, 'fuse_mode12.', m * 4, rng, randomize_stats)
+      _aff_params(p, 'fuse_mode123.', m * 8, rng, randomize_stats)
+      _aff_params(p, 'fuse_mode1234.', m * 16, rng, randomize_stats)
     stats_dim = int(input_size / 8) * m_channels * 8
     fin = stats_dim * expansion * 2
     b = 1.0 / math.sqrt(fin)

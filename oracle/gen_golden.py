@@ -192,6 +192,24 @@ def main():
     cmp('eres2net eval emb', ee_or, ee_ref, 2e-5)
     out['eres2net_ref_small.npz'] = dict(x=xe, emb_eval=ee_ref.numpy(), param_seed=np.int64(1000))
 
+    # ---------------- ERes2NetV2 (base_width 26), F=80
+    pv = oer.eres2net_params(input_size=F_, embd_dim=192, base_width=26, seed=1000, v2=True)
+    vm = ref_er.ERes2NetV2(input_size=F_, embd_dim=192, m_channels=32)
+    sdv = vm.state_dict()
+    assert set(sdv.keys()) == set(pv.keys()), sorted(set(sdv.keys()) ^ set(pv.keys()))[:10]
+    for k in sdv:
+        assert tuple(sdv[k].shape) == tuple(pv[k].shape), k
+    vm.load_state_dict(pv)
+    vm.eval()
+    nt, nb_ = om.count_params(pv)
+    print(f'ERes2NetV2 F=80 params: trainable {nt}, buffers {nb_}')
+    xv2 = rng.standard_normal((2, 70, F_)).astype(np.float32) * 3.0
+    with torch.no_grad():
+        ev_ref = vm(paddle_shim.to_tensor(xv2))
+        ev_or = oer.eres2netv2_forward(pv, torch.from_numpy(xv2))
+    cmp('eres2netv2 eval emb', ev_or, ev_ref, 2e-5)
+    out['eres2netv2_ref_small.npz'] = dict(x=xv2, emb_eval=ev_ref.numpy(), param_seed=np.int64(1000))
+
     # ---------------- real speech: 4 reference WAVs (3 s crops) -> oracle Fbank -> reference ECAPA graph
     names = ['a_1', 'a_2', 'b_1', 'b_2']
     pcm = np.stack([read_wav_16k_mono(f'{REF}/dataset/{n}.wav') for n in names])

@@ -55,7 +55,7 @@ def test_no_cpu_fallback():
         m(torch.zeros(1, 50, 80))
 
 
-@pytest.mark.parametrize('cfg', ['ecapa_tdnn.yml', 'tdnn.yml', 'cam++.yml', 'resnet_se.yml', 'eres2net.yml'])
+@pytest.mark.parametrize('cfg', ['ecapa_tdnn.yml', 'tdnn.yml', 'cam++.yml', 'resnet_se.yml', 'eres2net.yml', 'eres2netv2.yml'])
 def test_reference_configs_build(cfg):
     from ppvector.loss import build_loss
     from ppvector.models import build_model
@@ -70,7 +70,8 @@ def test_reference_configs_build(cfg):
                  'tdnn.yml': dict(model='TDNN', model_args=dict(embd_dim=192, pooling_type='ASP')),
                  'cam++.yml': dict(model='CAMPPlus', model_args=dict(embd_dim=192)),
                  'resnet_se.yml': dict(model='ResNetSE', model_args=dict(embd_dim=192, pooling_type='ASP')),
-                 'eres2net.yml': dict(model='ERes2Net', model_args=dict(embd_dim=192, m_channels=32))}[cfg]
+                 'eres2net.yml': dict(model='ERes2Net', model_args=dict(embd_dim=192, m_channels=32)),
+                 'eres2netv2.yml': dict(model='ERes2NetV2', model_args=dict(embd_dim=192, m_channels=32))}[cfg]
         model['classifier'] = dict(classifier_type='Cosine', num_speakers=2796, num_blocks=0)
         raw = dict(preprocess_conf=dict(feature_method='Fbank', method_args=dict(sr=16000, n_mels=80)),
                    model_conf=model,
@@ -104,10 +105,10 @@ def test_state_dict_names_match_reference_scheme():
     t.load_state_dict(pt)
     from oracle import campplus as oc, eres2net as oer, resnet_se as orse
     from ppvector.models.campplus import CAMPPlus
-    from ppvector.models.eres2net import ERes2Net
+    from ppvector.models.eres2net import ERes2Net, ERes2NetV2
     from ppvector.models.resnet_se import ResNetSE
     for mod, pp in ((CAMPPlus(80, embd_dim=192), oc.campplus_params(80, 192)), (ResNetSE(80), orse.resnetse_params(80, 192)),
-                    (ERes2Net(80), oer.eres2net_params(80, 192))):
+                    (ERes2Net(80), oer.eres2net_params(80, 192)), (ERes2NetV2(80), oer.eres2net_params(80, 192, base_width=26, v2=True))):
         assert set(mod.state_dict().keys()) == set(pp.keys())
         mod.load_state_dict(pp)
     # nn.Sequential(backbone, classifier) key scheme of the reference checkpoints: "0.<...>", "1.weight"

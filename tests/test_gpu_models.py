@@ -134,9 +134,10 @@ def test_unbuilt_model_variants_refuse():
     """What is not built refuses at construction, never a silent fallback."""
     from ppvector.models.eres2net import ERes2Net, ERes2NetV2
     with pytest.raises(NotImplementedError):
-        ERes2NetV2(80)
-    with pytest.raises(NotImplementedError):
         ERes2Net(80, two_emb_layer=True)
+    m = ERes2NetV2(80).cuda().train()                  # V2 has the eval engine only so far
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(2, 32, 80, device='cuda'))
 
 
 def test_long_utterance_falls_back_to_per_conv_path(ecapa):
@@ -321,3 +322,29 @@ def test_graph_mode_replays_identical_embeddings(golden_dir):
     finally:
         ppvector.set_graph_mode(False)
         ppvector.set_compute_dtype('float32')
+
+
+def test_eres2netv2_matches_reference_golden(golden_dir):
+    """ERes2NetV2 (models/eres2net.py:376-462; base_width 26 -> chunk widths 13 / 26 / 52 / 104, zero-padded to multiples of 8 in the
+    engine) vs the output of the reference's own eres2net.py (golden), plus an odd-length batch vs the oracle."""
+    from oracle import eres2net as oer
+    from ppvector.models.eres2net import ERes2NetV2
+    g = np.load(f'{golden_dir}/eres2netv2_ref_small.npz')
+    p = oer.eres2net_params(80, 192, base_width=26, seed=int(g['param_seed']), v2=True)
+    m = ERes2NetV2(80, embd_dim=192, m_channels=32)
+    m.load_state_dict(p)
+    m = m.cuda().eval()
+    x = torch.from_numpy(g['x']).cuda()
+    ref = g['emb_eval']
+    for dtype, tol in (('float32', 3e-4), ('bfloat16', 8e-2)):
+        emb = m.engine(dtype).forward(x).cpu().numpy()
+        rel = np.linalg.norm(emb - ref) / np.linalg.norm(ref)
+        c = _cos_rows(emb, ref)
+        print(f'[eres2netv2 {dtype}] rel-L2 {rel:.3e}  1-cos {1 - c.min():.3e}')
+        assert rel < tol, (dtype, rel)
+    w = ofb.synth_waves(3, 16000 + 160 * 7, seed=9, lowpass=0.9)
+    feats = ofb.featurize(w, method_args=dict(sr=16000, n_mels=80))
+    with torch.no_grad():
+        ref3 = oer.eres2netv2_forward(p, torch.from_numpy(feats)).numpy()
+    e3 = m.engine('float32').forward(torch.from_numpy(feats).cuda()).cpu().numpy()
+    assert np.linalg.norm(e3 - ref3) / np.linalg.norm(ref3) < 3e-4

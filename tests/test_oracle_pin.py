@@ -62,7 +62,9 @@ def test_2d_backbone_oracles_match_reference_golden(golden_dir):
     from oracle import campplus as oc, eres2net as oer, resnet_se as orse
     for name, params, fwd in (('campplus_ref_small.npz', oc.campplus_params, oc.campplus_forward),
                               ('resnetse_ref_small.npz', orse.resnetse_params, orse.resnetse_forward),
-                              ('eres2net_ref_small.npz', oer.eres2net_params, oer.eres2net_forward)):
+                              ('eres2net_ref_small.npz', oer.eres2net_params, oer.eres2net_forward),
+                              ('eres2netv2_ref_small.npz', lambda f, e, seed: oer.eres2net_params(f, e, base_width=26, seed=seed, v2=True),
+                               oer.eres2netv2_forward)):
         g = _load(golden_dir, name)
         p = params(80, 192, seed=int(g['param_seed']))
         with torch.no_grad():

@@ -194,10 +194,12 @@ int vp_eres2net_fwd(vp_ctx* ctx, const vp_eres2net_weights* w, const void* feats
             x = dst;
         }
     }
-    // bottom-up fusion: f12 = AFF(o2, down1(o1)); f123 = AFF(o3, down2(f12)); f1234 = AFF(o4, down3(f123))
-    const void* low = p.stage[0];
+    // bottom-up fusion: f12 = AFF(o2, down1(o1)); f123 = AFF(o3, down2(f12)); f1234 = AFF(o4, down3(f123));
+    // ERes2NetV2 (first_fuse = 2): only AFF(o4, layer3_ds(o3))
+    if (w->first_fuse < 0 || w->first_fuse > 2) VP_FAIL(ctx, VP_EINVAL, "eres2net: first_fuse %d", w->first_fuse);
+    const void* low = p.stage[w->first_fuse];
     void* fout = nullptr;
-    for (int k = 0; k < 3; ++k) {
+    for (int k = w->first_fuse; k < 3; ++k) {
         const int C = w->down[k].cout;
         const long long P = (long long)B * p.t[k + 2] * p.f[k + 2];
         conv_desc(d, w->down[k], dt);

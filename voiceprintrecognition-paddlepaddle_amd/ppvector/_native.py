@@ -136,7 +136,7 @@ class EreBlock(C.Structure):
 
 class Eres2netWeights(C.Structure):
     _fields_ = [('dtype', c_int), ('feat_dim', c_int), ('embd_dim', c_int), ('n_blocks', c_int), ('m_channels', c_int),
-                ('stage_blocks', c_int * 4), ('c1_w', c_void_p), ('c1_b', c_void_p), ('c1_scale', c_void_p), ('c1_shift', c_void_p),
+                ('stage_blocks', c_int * 4), ('first_fuse', c_int), ('c1_w', c_void_p), ('c1_b', c_void_p), ('c1_scale', c_void_p), ('c1_shift', c_void_p),
                 ('blk', EreBlock * VP_MAX_ERE_BLOCKS), ('down', TdnnLayer * 3), ('fuse', AffWeights * 3),
                 ('seg_w', c_void_p), ('seg_b', c_void_p)]
 

@@ -5,15 +5,15 @@ import logging
 
 from .campplus import CAMPPlus
 from .ecapa_tdnn import EcapaTdnn
-from .eres2net import ERes2Net
+from .eres2net import ERes2Net, ERes2NetV2
 from .resnet_se import ResNetSE
 from .tdnn import TDNN
 
 __all__ = ['build_model']
 
 _LOG = logging.getLogger('ppvector')
-_BUILT = {cls.__name__: cls for cls in (CAMPPlus, EcapaTdnn, ERes2Net, ResNetSE, TDNN)}
-_REFERENCE_ONLY = frozenset(('ERes2NetV2', 'Res2Net'))
+_BUILT = {cls.__name__: cls for cls in (CAMPPlus, EcapaTdnn, ERes2Net, ERes2NetV2, ResNetSE, TDNN)}
+_REFERENCE_ONLY = frozenset(('Res2Net',))
 
 
 def build_model(input_size, configs):

@@ -308,13 +308,52 @@ class ResNetSEEngine(CamppEngine):
         return emb
 
 
-class Eres2netEngine(CamppEngine):
-    """Packs an ERes2Net module into vp_eres2net_weights (include/vpmi.h)."""
+def _ceil8(v):
+    return (v + 7) // 8 * 8
 
-    def aff(self, A, m):
+
+def _chunk_map(width, wp, nchunk):
+    """old channel i*width + j  ->  padded channel i*wp + j  (Res2 chunks padded to a multiple of 8 channels)."""
+    return torch.cat([torch.arange(width) + i * wp for i in range(nchunk)])
+
+
+class Eres2netEngine(CamppEngine):
+    """Packs an ERes2Net / ERes2NetV2 module into vp_eres2net_weights (include/vpmi.h).  Chunk widths that are not multiples
+    of 8 (V2: 13 / 26 / 52 / 104) are zero-padded: padded channels carry zero weights, zero bias and a zero BN affine, so they
+    stay exactly 0 through Hardtanh / SiLU / tanh and the AFF combine, and meet zero weight columns downstream."""
+
+    def conv2d_pad(self, L, conv, bn, in_map=None, cin_p=None, out_map=None, cout_p=None):
+        w = conv.weight.detach().float()                            # (Cout, Cin, kF, kT)
+        cout, cin, kf, kt = w.shape
+        cin_p, cout_p = cin_p or cin, cout_p or cout
+        in_map = torch.arange(cin) if in_map is None else in_map
+        out_map = torch.arange(cout) if out_map is None else out_map
+        wpad = torch.zeros((cout_p, cin_p, kf, kt), dtype=torch.float32, device=w.device)
+        wpad[out_map.to(w.device)[:, None], in_map.to(w.device)[None, :]] = w
+        packed = wpad.permute(0, 3, 2, 1).reshape(cout_p, kt * kf * cin_p).to(self.tdtype).contiguous()
+        L.w = self._p(packed)
+        bias = torch.zeros(cout_p, dtype=torch.float32, device=w.device)
+        bias[out_map.to(w.device)] = conv.bias.detach().float()
+        L.bias = self._p(bias)
+        if bn is not None:
+            sc, sh = bn.folded()
+            scp = torch.zeros(cout_p, dtype=torch.float32, device=w.device)
+            shp = torch.zeros(cout_p, dtype=torch.float32, device=w.device)
+            scp[out_map.to(w.device)] = sc
+            shp[out_map.to(w.device)] = sh
+            L.bn_scale, L.bn_shift = self._p(scp), self._p(shp)
+        L.cin, L.cout, L.kw, L.dil = cin_p, cout_p, kt * kf, 1
+
+    def aff(self, A, m, width=None, wp=None):
         la = m.local_att
-        self.conv2d(A.c1, la[0], la[1])
-        self.conv2d(A.c2, la[3], la[4])
+        if width is None:                                           # stage-level AFF: channel counts are multiples of 64
+            self.conv2d_pad(A.c1, la[0], la[1])
+            self.conv2d_pad(A.c2, la[3], la[4])
+            return
+        inter = la[0].weight.shape[0]
+        ip = _ceil8(inter)
+        self.conv2d_pad(A.c1, la[0], la[1], in_map=_chunk_map(width, wp, 2), cin_p=2 * wp, cout_p=ip)
+        self.conv2d_pad(A.c2, la[3], la[4], cin_p=ip, cout_p=wp)
 
     def __init__(self, m, dtype_name):
         _Engine.__init__(self, m, dtype_name)
@@ -333,29 +372,36 @@ class Eres2netEngine(CamppEngine):
             for b in layer:
                 if bi >= N.VP_MAX_ERE_BLOCKS or b.scale > N.VP_MAX_ERE_SCALE:
                     raise NotImplementedError(f'more than {N.VP_MAX_ERE_BLOCKS} blocks or scale > {N.VP_MAX_ERE_SCALE}')
-                if b.width % 8:
-                    raise NotImplementedError(f'chunk width {b.width} is not a multiple of 8 (bf16 16-byte channel chunks)')
                 R = W.blk[bi]
-                self.conv2d(R.conv1, b.conv1, b.bn1)
+                wd, wp = b.width, _ceil8(b.width)
+                cmap = _chunk_map(wd, wp, b.scale)
+                self.conv2d_pad(R.conv1, b.conv1, b.bn1, out_map=cmap, cout_p=wp * b.scale)
                 for i in range(b.scale):
-                    self.conv2d(R.convs[i], b.convs[i], b.bns[i])
-                self.conv2d(R.conv3, b.conv3, b.bn3)
+                    self.conv2d_pad(R.convs[i], b.convs[i], b.bns[i], cin_p=wp, cout_p=wp)
+                self.conv2d_pad(R.conv3, b.conv3, b.bn3, in_map=cmap, cin_p=wp * b.scale)
                 R.has_shortcut = int(len(b.shortcut) > 0)
                 if R.has_shortcut:
-                    self.conv2d(R.shortcut, b.shortcut[0], b.shortcut[1])
+                    self.conv2d_pad(R.shortcut, b.shortcut[0], b.shortcut[1])
                 R.use_aff = int(b.use_aff)
                 if b.use_aff:
                     for i in range(b.scale - 1):
-                        self.aff(R.fuse[i], b.fuse_models[i])
-                R.stride, R.width, R.scale = b.stride, b.width, b.scale
+                        self.aff(R.fuse[i], b.fuse_models[i], wd, wp)
+                R.stride, R.width, R.scale = b.stride, wp, b.scale
                 bi += 1
         W.n_blocks = bi
-        for k, (dn, fm) in enumerate(((m.layer1_downsample, m.fuse_mode12), (m.layer2_downsample, m.fuse_mode123),
-                                      (m.layer3_downsample, m.fuse_mode1234))):
-            self.conv2d(W.down[k], dn, None)
-            self.aff(W.fuse[k], fm)
+        if getattr(m, 'v2', False):                                 # ERes2NetV2: one fusion, kept in slot 2
+            W.first_fuse = 2
+            self.conv2d_pad(W.down[2], m.layer3_ds, None)
+            self.aff(W.fuse[2], m.fuse34)
+            C4 = m.layer3_ds.weight.shape[0]
+        else:
+            W.first_fuse = 0
+            for k, (dn, fm) in enumerate(((m.layer1_downsample, m.fuse_mode12), (m.layer2_downsample, m.fuse_mode123),
+                                          (m.layer3_downsample, m.fuse_mode1234))):
+                self.conv2d_pad(W.down[k], dn, None)
+                self.aff(W.fuse[k], fm)
+            C4 = m.layer3_downsample.weight.shape[0]
         # TSTP vector: reference index stat*(C*F8) + c*F8 + f  ->  engine stat*(F8*C) + f*C + c
-        C4 = m.layer3_downsample.weight.shape[0]
         F8 = m.input_size // 8
         lw = m.seg_1.weight.detach().float()                        # [2*C4*F8, embd] (Paddle layout)
         if lw.shape[0] != 2 * C4 * F8:
@@ -422,8 +468,9 @@ class EngineMixin:
         if self.training:
             fwd = getattr(self, '_train_forward', None)
             if fwd is None:
-                raise NotImplementedError('training-mode (batch-statistics) forward/backward on the HIP engine is built for TDNN '
-                                          'only so far (DESIGN.md section 0, row a25); call .eval() for embedding extraction')
+                raise NotImplementedError(f'training-mode forward/backward on the HIP engine is not built for {type(self).__name__} '
+                                          '(TDNN, EcapaTdnn, CAMPPlus, ResNetSE and ERes2Net are: DESIGN.md section 7a); '
+                                          'call .eval() for embedding extraction')
             return fwd(x)
         with torch.no_grad():
             eng = self.engine()

@@ -3,7 +3,8 @@
 Same constructor surface, ``embd_dim`` attribute and state-dict keys as ppvector/models/eres2net.py
 (ReLU = Hardtanh(0, 20) :12-20, AFF :33-53, BasicBlockERes2Net :56-108, BasicBlockERes2Net_diff_AFF :111-169,
 ERes2Net :172-263).  The modules are parameter containers; ``forward`` runs the whole graph through libvpmi
-(csrc/eres2net.hip: vp_eres2net_fwd).  ERes2NetV2 (:266-462) is not built yet.
+(csrc/eres2net.hip: vp_eres2net_fwd).  ERes2NetV2 (:266-462) shares the launch graph: its chunk widths (13 / 26 / 52 / 104) are
+zero-padded to multiples of 8 at pack time.  Training mode is built for ERes2Net only.
 """
 import math
 
@@ -128,7 +129,49 @@ class ERes2Net(EngineMixin, nn.Module):
         return eres2net_forward_train(self, x.float().contiguous())
 
 
-class ERes2NetV2(nn.Module):
-    def __init__(self, *a, **k):
+class BasicBlockERes2NetV2(BasicBlockERes2Net):
+    """models/eres2net.py:266-318: the V1 block with base_width 26 by default."""
+
+    def __init__(self, expansion, in_planes, planes, stride=1, base_width=26, scale=2):
+        super().__init__(expansion, in_planes, planes, stride, base_width, scale)
+
+
+class BasicBlockERes2NetV2_AFF(BasicBlockERes2NetV2):
+    use_aff = True
+
+
+class ERes2NetV2(EngineMixin, nn.Module):
+    """models/eres2net.py:376-462: four stages of V2 blocks, ONE bottom-up fusion (layer3_ds + fuse34), TSTP, Linear."""
+    _engine_cls = Eres2netEngine
+    v2 = True
+
+    def __init__(self, input_size, block=BasicBlockERes2NetV2, block_fuse=BasicBlockERes2NetV2_AFF, num_blocks=[3, 4, 6, 3],
+                 m_channels=32, expansion=2, base_width=26, scale=2, embd_dim=192, pooling_type='TSTP', two_emb_layer=False):
         super().__init__()
-        raise NotImplementedError('ERes2NetV2 is not built on the HIP engine yet (ERes2Net is)')
+        self.in_planes = m_channels
+        self.expansion = expansion
+        self.input_size = input_size
+        self.embd_dim = embd_dim
+        self.stats_dim = int(input_size / 8) * m_channels * 8
+        self.two_emb_layer = two_emb_layer
+        self.m_channels, self.num_blocks = m_channels, list(num_blocks)
+        self.conv1 = _ConvNd(1, m_channels, 3, 3)
+        self.bn1 = _BNParams(m_channels)
+        self.layer1 = self._make_layer(block, m_channels, num_blocks[0], 1, base_width, scale)
+        self.layer2 = self._make_layer(block, m_channels * 2, num_blocks[1], 2, base_width, scale)
+        self.layer3 = self._make_layer(block_fuse, m_channels * 4, num_blocks[2], 2, base_width, scale)
+        self.layer4 = self._make_layer(block_fuse, m_channels * 8, num_blocks[3], 2, base_width, scale)
+        self.layer3_ds = _ConvNd(m_channels * 8, m_channels * 16, 3, 3)
+        self.fuse34 = AFF(channels=m_channels * 16, r=4)
+        self.n_stats = 1 if pooling_type == 'TAP' else 2
+        if pooling_type == "TSTP":
+            self.pooling = TemporalStatsPool()
+        else:
+            raise Exception(f'没有{pooling_type}池化层！')
+        self.seg_1 = _LinearParams(self.stats_dim * self.expansion * self.n_stats, embd_dim)
+        if self.two_emb_layer:
+            raise NotImplementedError('two_emb_layer=True (ReLU -> BatchNorm -> second Linear) is not built on the HIP engine')
+        self.seg_bn_1 = nn.Identity()
+        self.seg_2 = nn.Identity()
+
+    _make_layer = ERes2Net._make_layer
