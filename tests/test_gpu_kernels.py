@@ -457,6 +457,25 @@ def test_cosine_scores(N):
     assert np.max(np.abs(got - osc.cosine_matrix(a.astype(np.float64), b.astype(np.float64)))) < 1e-6
 
 
+def test_evaluate_trials_matches_reference_loop(N):
+    """evaluate_trials vs the reference's per-trial loop restated in oracle/scoring.py (trainer.py:416-431, metrics.py:4-37)."""
+    from oracle import scoring as osc
+    from ppvector.metric.metrics import evaluate_trials
+    g = np.random.RandomState(3)
+    spk = g.standard_normal((6, 192))
+    el = np.repeat(np.arange(6), 3)
+    tl = g.randint(0, 6, 40)
+    enroll = (spk[el] + 0.8 * g.standard_normal((len(el), 192))).astype(np.float32)
+    trials = (spk[tl] + 0.8 * g.standard_normal((len(tl), 192))).astype(np.float32)
+    sc, lab = osc.trial_scores(trials, tl, enroll, el)
+    fnr, fpr = osc.fnr_fpr(sc, lab)[:2]
+    ref_eer = osc.eer(fnr, fpr, sc)
+    ref_eer = ref_eer[0] if isinstance(ref_eer, tuple) else ref_eer
+    ref_dcf = osc.min_dcf(fnr, fpr)
+    eer, dcf, thr = evaluate_trials(dev(enroll), el, dev(trials), tl)
+    assert abs(eer - float(ref_eer)) < 1e-4 and abs(dcf - float(ref_dcf)) < 1e-4 and -1.0 < thr < 1.0
+
+
 # --------------------------------------------------------------------------------------- conv extensions (CAM++)
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 @pytest.mark.parametrize('stride_f,kw', [(1, 9), (2, 9), (2, 1)])

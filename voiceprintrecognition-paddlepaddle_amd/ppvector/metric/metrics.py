@@ -51,3 +51,20 @@ def cosine_score_matrix(trials, enroll):
     N.check(lib.vp_cosine_scores_f32(ctx, a.data_ptr(), b.data_ptr(), a.shape[0], b.shape[0], a.shape[1],
                                      out.data_ptr(), ws.data_ptr(), ws.numel(), N.stream_ptr()), ctx)
     return out
+
+
+def evaluate_trials(enroll_features, enroll_labels, trials_features, trials_labels):
+    """The scoring half of PPVectorTrainer.evaluate (ppvector/trainer.py:412-431): every trial embedding against every enrolled
+    one (one cosine GEMM on the GPU instead of a Python loop of sklearn calls), target / non-target labels in the same
+    trial-major order, then the reference's fnr/fpr -> EER / minDCF arithmetic on the host.  Returns (eer, min_dcf, threshold)."""
+    import numpy as np
+    import torch
+    scores = cosine_score_matrix(torch.as_tensor(trials_features), torch.as_tensor(enroll_features)).cpu().numpy()
+    el = np.asarray(enroll_labels).astype(np.int32)
+    tl = np.asarray(trials_labels).astype(np.int32)
+    all_score = scores.astype(np.float32).reshape(-1)
+    all_labels = (el[None, :] == tl[:, None]).astype(np.int32).reshape(-1)
+    fnr, fpr, thresholds = compute_fnr_fpr(all_score, all_labels)
+    eer, threshold = compute_eer(fnr, fpr, all_score)
+    min_dcf = compute_dcf(fnr, fpr)
+    return float(eer), float(min_dcf), float(threshold)
