@@ -291,11 +291,20 @@ int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats
  *   at that moment, or with zero.
  * vp_pad_batch -- collate_fn (data_utils/collate_fn.py:5-23): out[b] = srcs[b] (lens[b] x F) zero-padded to Tmax.
  *   srcs is a DEVICE array of B device pointers.
+ * vp_wave_batch_f32 -- the waveform side of the same assembly, the step in front of the featurizer: decibel normalisation
+ *   over the WHOLE utterance (data_utils/reader.py:97-98, yeaudio AudioSegment.normalize(target_db): gain =
+ *   10^((target_db - 10 log10(mean x^2)) / 20); a silent source keeps gain 1), then the crop to max_duration
+ *   (reader.py:100-101: starts[b] = the host's random start in training, 0 otherwise; NULL = 0) and the zero padding to
+ *   L that predict_batch applies to ragged waveforms (predict.py:246-254).  normalize = 0 applies gain_db[b] instead
+ *   (VolumePerturbAugmentor's draw, reader.py:155-156; NULL = unity).  n_valid[b] (optional) = samples kept, the
+ *   numerator of predict_batch's input_lens_ratio.  srcs: DEVICE array of B device pointers, lens: samples per source.
  * ---------------------------------------------------------------------------------------------- */
 int vp_spec_augment(vp_ctx* ctx, int dtype, void* feats, int B, int T, int F, const int32_t* fmask, int n_freq_masks,
                     const int32_t* tmask, int n_time_masks, int replace_with_zero, vp_stream stream);
 int vp_pad_batch(vp_ctx* ctx, int dtype, const void* const* srcs, const int32_t* lens, int B, int Tmax, int F, void* out,
                  vp_stream stream);
+int vp_wave_batch_f32(vp_ctx* ctx, const float* const* srcs, const int32_t* lens, const int32_t* starts, int B, int L,
+                      int normalize, float target_db, const float* gain_db, float* out, int32_t* n_valid, vp_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * ResNetSE backbone forward, eval mode -- replaces ResNetSE.forward (models/resnet_se.py:121-139) with
@@ -406,6 +415,30 @@ int vp_aam_ce_bwd(vp_ctx* ctx, const float* logits, const int64_t* labels, int B
 size_t vp_cosine_logits_bwd_workspace_bytes(int B, int D, int C);
 int vp_cosine_logits_bwd(vp_ctx* ctx, const float* emb, const float* W, const float* dcos, int B, int D, int C, float* demb,
                          float* dW, void* ws, size_t ws_bytes, vp_stream stream);
+
+/* The rest of the reference's loss package over the same (B, C) head logits (build_loss, loss/__init__.py:16-22;
+ * trainer.py:180,213), forward and backward, one pass per row with an online log-sum-exp -- no one-hot / margin tensors:
+ *   VP_LOSS_AAM        loss/aamloss.py:28-47        (same arithmetic as vp_aam_ce_*)
+ *   VP_LOSS_AM         loss/amloss.py:14-25         out = scale * (cos - margin * onehot)
+ *   VP_LOSS_ARM        loss/armloss.py:14-31        out = where(z - z[label] < 0, 0, z), z as AM
+ *   VP_LOSS_CE         loss/celoss.py:11-19         out = logits (margin / scale ignored)
+ *   VP_LOSS_SUBCENTER  loss/subcenterloss.py:32-54  logits (B, C*K), class value = max over its K columns c*K .. c*K+K-1,
+ *                                                   then the AAM margin; the gradient goes to the winning sub-centre
+ * then CrossEntropyLoss(label_smoothing), mean over the batch.  K must be 1 except for VP_LOSS_SUBCENTER.
+ * _bwd: dlogits (B, C*K) = grad_scale * d loss / d logits; loss (1) + row_loss (B) optional. */
+enum { VP_LOSS_AAM = 0, VP_LOSS_AM = 1, VP_LOSS_ARM = 2, VP_LOSS_CE = 3, VP_LOSS_SUBCENTER = 4 };
+int vp_margin_ce_fwd(vp_ctx* ctx, const float* logits, const int64_t* labels, int B, int C, int K, int kind, float margin,
+                     float scale, float label_smoothing, int easy_margin, float* loss, float* row_loss, vp_stream stream);
+int vp_margin_ce_bwd(vp_ctx* ctx, const float* logits, const int64_t* labels, int B, int C, int K, int kind, float margin,
+                     float scale, float label_smoothing, int easy_margin, float grad_scale, float* dlogits, float* loss,
+                     float* row_loss, vp_stream stream);
+/* SphereFace2.forward (loss/sphereface2.py:47-69): loss = mean_b sum_c [ onehot * lanbuda * log(1 + exp(-P)) +
+ * (1 - onehot) * (1 - lanbuda) * log(1 + exp(N)) ], P / N = scale * (g(cos) -/+ margin) + bias for margin type 'C'
+ * (margin_type_a = 0) or the arc forms for 'A'; g(z) = 2 ((z + 1) / 2)^t - 1.  bias: device pointer to the module's (1, 1)
+ * parameter (NULL = 0).  dlogits (B, C) / dbias (1) + row_dbias (B) optional, both scaled by grad_scale. */
+int vp_sphereface2(vp_ctx* ctx, const float* logits, const int64_t* labels, const float* bias, int B, int C, float margin,
+                   float scale, float lanbuda, int t, int margin_type_a, float grad_scale, float* loss, float* row_loss,
+                   float* dlogits, float* dbias, float* row_dbias, vp_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Training-side building blocks (f32 engine) -- what paddle's autograd and optimiser run under

@@ -61,3 +61,27 @@ def collate(batch):
     for i, (f, _) in enumerate(batch):
         out[i, :f.shape[0]] = f
     return out, np.asarray([int(l) for _, l in batch], np.int64), np.asarray([f.shape[0] for f, _ in batch], np.int64)
+
+
+def wave_batch(waves, L=None, starts=None, normalize=True, target_db=-20.0, gains_db=None):
+    """The waveform side of batch assembly, per utterance as the reference's workers do it (data_utils/reader.py:97-101):
+    AudioSegment.normalize(target_db) over the whole utterance (yeaudio, third party: gain_dB = target_db - 10 log10(mean x^2),
+    samples *= 10^(gain_dB / 20); restated from its published behaviour, silent input keeps gain 1), crop at starts[b], then
+    predict_batch's zero padding (predict.py:246-254).  Returns (batch (B, L) f32, n_valid (B,) int32)."""
+    L = L or max(len(w) for w in waves)
+    out = np.zeros((len(waves), L), np.float32)
+    nv = np.zeros(len(waves), np.int32)
+    for b, w in enumerate(waves):
+        w = np.asarray(w, np.float64)
+        gain = 1.0
+        if normalize:
+            ms = float(np.mean(w ** 2)) if len(w) else 0.0
+            if ms > 0:
+                gain = 10.0 ** ((target_db - 10.0 * np.log10(ms)) / 20.0)
+        elif gains_db is not None:
+            gain = 10.0 ** (float(gains_db[b]) / 20.0)
+        st = min(max(int(starts[b]) if starts is not None else 0, 0), len(w))
+        n = min(L, len(w) - st)
+        out[b, :n] = (w[st:st + n] * gain).astype(np.float32)
+        nv[b] = n
+    return out, nv

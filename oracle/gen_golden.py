@@ -210,6 +210,44 @@ def main():
     cmp('eres2netv2 eval emb', ev_or, ev_ref, 2e-5)
     out['eres2netv2_ref_small.npz'] = dict(x=xv2, emb_eval=ev_ref.numpy(), param_seed=np.int64(1000))
 
+    # ---------------- the other classification losses (loss/{amloss,armloss,celoss,subcenterloss,sphereface2}.py)
+    from oracle import losses as ol
+    ref_l = {n: importlib.import_module('ppvector.loss.' + n) for n in ('amloss', 'armloss', 'celoss', 'subcenterloss', 'sphereface2')}
+    lr_ = np.random.RandomState(77)
+    Bq, Dq, Cq, Kq = 6, 32, 12, 3
+    embq = torch.from_numpy(lr_.standard_normal((Bq, Dq)).astype(np.float32))
+    labq = lr_.randint(0, Cq, size=(Bq,)).astype(np.int64)
+    lg1 = om.cosine_head(embq, torch.from_numpy(lr_.standard_normal((Dq, Cq)).astype(np.float32)))
+    lgk = om.cosine_head(embq, torch.from_numpy(lr_.standard_normal((Dq, Cq * Kq)).astype(np.float32)))
+    lg1[0, labq[0]] = -0.995                 # a target below th = cos(pi - m): the (cos - mmm) branch
+    lgk[0, labq[0] * Kq:(labq[0] + 1) * Kq] = torch.tensor([-0.997, -0.995, -0.996])   # no ties: max-backward picks one
+    cases = [('AMLoss', lambda: ref_l['amloss'].AMLoss(margin=0.2, scale=30, label_smoothing=0.0), lambda l, y: ol.am_loss(l, y, 0.2, 30.0, 0.0), lg1),
+             ('AMLoss_ls', lambda: ref_l['amloss'].AMLoss(margin=0.35, scale=30, label_smoothing=0.1), lambda l, y: ol.am_loss(l, y, 0.35, 30.0, 0.1), lg1),
+             ('ARMLoss', lambda: ref_l['armloss'].ARMLoss(margin=0.2, scale=30, label_smoothing=0.0), lambda l, y: ol.arm_loss(l, y, 0.2, 30.0, 0.0), lg1),
+             ('ARMLoss_ls', lambda: ref_l['armloss'].ARMLoss(margin=0.1, scale=20, label_smoothing=0.1), lambda l, y: ol.arm_loss(l, y, 0.1, 20.0, 0.1), lg1),
+             ('CELoss', lambda: ref_l['celoss'].CELoss(label_smoothing=0.0), lambda l, y: ol.ce_loss(l, y, 0.0), lg1),
+             ('CELoss_ls', lambda: ref_l['celoss'].CELoss(label_smoothing=0.2), lambda l, y: ol.ce_loss(l, y, 0.2), lg1),
+             ('SubCenterLoss', lambda: ref_l['subcenterloss'].SubCenterLoss(margin=0.2, scale=32, K=3), lambda l, y: ol.subcenter_loss(l, y, 0.2, 32.0, False, 3, 0.0), lgk),
+             ('SubCenterLoss_easy_ls', lambda: ref_l['subcenterloss'].SubCenterLoss(margin=0.3, scale=32, easy_margin=True, K=3, label_smoothing=0.1),
+              lambda l, y: ol.subcenter_loss(l, y, 0.3, 32.0, True, 3, 0.1), lgk),
+             ('SphereFace2_C', lambda: ref_l['sphereface2'].SphereFace2(margin=0.2, scale=32.0, lanbuda=0.7, t=3, margin_type='C'),
+              lambda l, y: ol.sphereface2_loss(l, y, torch.zeros(()), 0.2, 32.0, 0.7, 3, 'C'), lg1),
+             ('SphereFace2_A', lambda: ref_l['sphereface2'].SphereFace2(margin=0.15, scale=32.0, lanbuda=0.7, t=3, margin_type='A'),
+              lambda l, y: ol.sphereface2_loss(l, y, torch.zeros(()), 0.15, 32.0, 0.7, 3, 'A'), lg1)]
+    gl = dict(labels=labq, logits=lg1.numpy(), logits_k=lgk.numpy(), names=np.asarray([c[0] for c in cases]))
+    for name, mk, orc, lg in cases:
+        a = lg.clone().requires_grad_(True)
+        l_ref = mk()({'features': embq, 'logits': paddle_shim._wrap(a)}, paddle_shim.to_tensor(labq))
+        g_ref, = torch.autograd.grad(l_ref, a)
+        b = lg.clone().requires_grad_(True)
+        l_or = orc(b, torch.from_numpy(labq))
+        g_or, = torch.autograd.grad(l_or, b)
+        cmp(f'{name} loss', l_or, l_ref, 1e-5)
+        cmp(f'{name} dlogits', g_or, g_ref, 1e-5)
+        gl[name + '_loss'] = np.float64(float(l_ref))
+        gl[name + '_dlogits'] = g_ref.numpy()
+    out['losses_ref.npz'] = gl
+
     # ---------------- real speech: 4 reference WAVs (3 s crops) -> oracle Fbank -> reference ECAPA graph
     names = ['a_1', 'a_2', 'b_1', 'b_2']
     pcm = np.stack([read_wav_16k_mono(f'{REF}/dataset/{n}.wav') for n in names])

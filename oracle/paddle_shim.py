@@ -151,6 +151,14 @@ def tanh(x):
     return _wrap(torch.tanh(x))
 
 
+def exp(x):
+    return _wrap(torch.exp(x))
+
+
+def log(x):
+    return _wrap(torch.log(x))
+
+
 def mean(x, axis=None, keepdim=False):
     return _wrap(torch.mean(x) if axis is None else torch.mean(x, dim=axis, keepdim=keepdim))
 
@@ -181,8 +189,9 @@ class ParamAttr:
 
 
 def create_parameter(shape, dtype='float32', attr=None, **kw):
-    p = torch.nn.Parameter(torch.empty(list(shape), dtype=_dtype(dtype)))
-    torch.nn.init.xavier_uniform_(p)
+    p = torch.nn.Parameter(torch.zeros(list(shape), dtype=_dtype(dtype)))
+    if not kw.get('is_bias', False):                     # Paddle: bias parameters start at zero
+        torch.nn.init.xavier_uniform_(p)
     return p
 
 
@@ -294,12 +303,13 @@ class Hardtanh(Layer):
 
 
 class CrossEntropyLoss(Layer):
-    def __init__(self, label_smoothing=0.0, **kw):
+    def __init__(self, label_smoothing=0.0, reduction='mean', **kw):
         super().__init__()
-        self.label_smoothing = label_smoothing
+        self.label_smoothing, self.reduction = label_smoothing, reduction
 
     def forward(self, logits, labels):
-        return TF.cross_entropy(logits, labels.reshape(-1).long(), label_smoothing=self.label_smoothing)
+        return _wrap(TF.cross_entropy(logits, labels.reshape(-1).long(), label_smoothing=self.label_smoothing,
+                                      reduction=self.reduction))
 
 
 class AdaptiveAvgPool2D(Layer):

@@ -651,6 +651,35 @@ def test_spec_augment_matches_restatement(N):
         SpecAugmentor(max_time_warp=5)
 
 
+def test_assemble_waves_normalises_crops_and_pads(N):
+    """reader.py:97-101 + predict.py:246-254 as one launch: dB normalisation over the whole utterance, crop, zero pad."""
+    from oracle import augment as oa
+    from ppvector.data_utils.wave_batch import assemble_waves
+    rng = np.random.RandomState(5)
+    lens = (48000, 16001, 7, 80000, 31999)
+    waves = [(rng.standard_normal(n) * s).astype(np.float32) for n, s in zip(lens, (0.1, 0.01, 0.5, 0.3, 1e-4))]
+    waves.append(np.zeros(1000, np.float32))                                   # silence: gain stays 1, no NaN
+    # predict_batch geometry: no crop, pad to the longest
+    ref, nv = oa.wave_batch(waves, normalize=True, target_db=-20.0)
+    out, ratio = assemble_waves([dev(w) for w in waves], use_dB_normalization=True, target_dB=-20.0)
+    assert out.shape == ref.shape and np.max(np.abs(out.cpu().numpy() - ref)) < 5e-6 * np.max(np.abs(ref))
+    assert np.allclose(ratio.cpu().numpy(), nv / ref.shape[1], atol=1e-7)
+    rms_db = 10 * np.log10(np.mean(out[0, :48000].double().cpu().numpy() ** 2))
+    assert abs(rms_db + 20.0) < 1e-3
+    assert not torch.isnan(out).any() and float(out[5].abs().max()) == 0.0
+    # training geometry: random crop starts, fixed 3 s rows; and the un-normalised volume-perturbation path
+    starts = [0, 16001 - 5, 3, 80000 - 48000, 100, 0]
+    ref, nv = oa.wave_batch(waves, L=48000, starts=starts, normalize=True, target_db=-23.5)
+    out, ratio = assemble_waves([dev(w) for w in waves], max_len=48000, starts=starts, target_dB=-23.5)
+    assert np.max(np.abs(out.cpu().numpy() - ref)) < 5e-6 * np.max(np.abs(ref)) and np.array_equal((ratio.cpu().numpy() * 48000).round().astype(np.int32), nv)
+    gains = [-15.0, 0.0, 6.0, 15.0, -3.0, 1.0]
+    ref, _ = oa.wave_batch(waves, L=20000, normalize=False, gains_db=gains)
+    out, _ = assemble_waves([dev(w) for w in waves], max_len=20000, use_dB_normalization=False, gains_dB=gains)
+    assert np.max(np.abs(out.cpu().numpy() - ref)) < 5e-6 * np.max(np.abs(ref))
+    with pytest.raises(N.VpmiError):
+        assemble_waves([torch.zeros(10)])
+
+
 def test_collate_fn_pads_like_reference(N):
     from oracle import augment as oa
     from ppvector.data_utils.collate_fn import collate_fn

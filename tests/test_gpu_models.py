@@ -181,7 +181,11 @@ def test_predictor_predict_batch_contrast(golden_dir, tmp_path):
             w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm[i, :n].tobytes())
         paths.append(p)
     state = {'0.' + k: v for k, v in om.ecapa_params(80, seed=1000).items()}
-    pred = PPVectorPredictor(_cfg(), model_path=state)
+    from ppvector.utils.checkpoint import save_pdparams
+    mdir = tmp_path / 'EcapaTdnn_Fbank' / 'best_model'                 # the reference's checkpoint directory layout
+    mdir.mkdir(parents=True)
+    save_pdparams(state, str(mdir / 'model.pdparams'))
+    pred = PPVectorPredictor(_cfg(), model_path=str(mdir))
 
     def norm(x):
         x = x.astype(np.float32) / 32768.0

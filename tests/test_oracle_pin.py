@@ -142,3 +142,32 @@ def test_spec_augment_restatement_properties():
     assert np.array_equal(oa.apply_masks(x, [(0, 0)], [(0, 0)]), x)
     f, l, n = oa.collate([(np.ones((3, 2), np.float32), 5), (np.ones((1, 2), np.float32), 1)])
     assert f.shape == (2, 3, 2) and f[1, 1:].sum() == 0 and list(l) == [5, 1] and list(n) == [3, 1]
+
+
+def _loss_cases():
+    from oracle import losses as ol
+    z = torch.zeros(())
+    return {'AMLoss': (lambda l, y: ol.am_loss(l, y, 0.2, 30.0, 0.0), False),
+            'AMLoss_ls': (lambda l, y: ol.am_loss(l, y, 0.35, 30.0, 0.1), False),
+            'ARMLoss': (lambda l, y: ol.arm_loss(l, y, 0.2, 30.0, 0.0), False),
+            'ARMLoss_ls': (lambda l, y: ol.arm_loss(l, y, 0.1, 20.0, 0.1), False),
+            'CELoss': (lambda l, y: ol.ce_loss(l, y, 0.0), False),
+            'CELoss_ls': (lambda l, y: ol.ce_loss(l, y, 0.2), False),
+            'SubCenterLoss': (lambda l, y: ol.subcenter_loss(l, y, 0.2, 32.0, False, 3, 0.0), True),
+            'SubCenterLoss_easy_ls': (lambda l, y: ol.subcenter_loss(l, y, 0.3, 32.0, True, 3, 0.1), True),
+            'SphereFace2_C': (lambda l, y: ol.sphereface2_loss(l, y, z, 0.2, 32.0, 0.7, 3, 'C'), False),
+            'SphereFace2_A': (lambda l, y: ol.sphereface2_loss(l, y, z, 0.15, 32.0, 0.7, 3, 'A'), False)}
+
+
+def test_loss_family_oracle_matches_reference_golden(golden_dir):
+    """loss/{amloss,armloss,celoss,subcenterloss,sphereface2}.py run through the shim: value and d loss / d logits."""
+    g = _load(golden_dir, 'losses_ref.npz')
+    y = torch.from_numpy(g['labels'])
+    cases = _loss_cases()
+    assert sorted(cases) == sorted(str(n) for n in g['names'])
+    for name, (fn, use_k) in cases.items():
+        l = torch.from_numpy(g['logits_k' if use_k else 'logits']).clone().requires_grad_(True)
+        loss = fn(l, y)
+        grad, = torch.autograd.grad(loss, l)
+        assert abs(float(loss.detach()) - float(g[name + '_loss'])) < 1e-5 * max(1.0, abs(float(g[name + '_loss']))), name
+        assert np.max(np.abs(grad.numpy() - g[name + '_dlogits'])) < 1e-5 * max(1.0, np.max(np.abs(g[name + '_dlogits']))), name

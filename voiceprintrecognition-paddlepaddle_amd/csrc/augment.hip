@@ -59,6 +59,38 @@ __global__ __launch_bounds__(256) void pad_batch_kernel(PadArgs<T> a) {
         o[i] = i < nv ? s[i] : vp_from_f32<T>(0.f);
 }
 
+// One workgroup per utterance: mean square over the WHOLE source (the reference normalises before it crops), then the
+// gained crop, zero-padded to L.  Fixed-order reduction (256 strided partials, wave shuffles, 4 waves).
+struct WaveArgs {
+    const float* const* src; const int* lens; const int* starts; const float* gain_db; float* out; int* n_valid;
+    int L, normalize; float target_db;
+};
+
+__global__ __launch_bounds__(256) void wave_batch_kernel(WaveArgs a) {
+    __shared__ float sm[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* s = a.src[b];
+    const int n = a.lens[b];
+    float gain = 1.f;
+    if (a.normalize) {
+        float ss = 0.f;
+        for (int i = tid; i < n; i += 256) { const float v = s[i]; ss += v * v; }
+        ss = vp_wave_sum(ss);
+        if ((tid & 63) == 0) sm[tid >> 6] = ss;
+        __syncthreads();
+        const float ms = (sm[0] + sm[1] + sm[2] + sm[3]) / (float)(n > 0 ? n : 1);
+        if (ms > 0.f) gain = exp10f((a.target_db - 10.f * log10f(ms)) * 0.05f);
+    } else if (a.gain_db) {
+        gain = exp10f(a.gain_db[b] * 0.05f);
+    }
+    int st = a.starts ? a.starts[b] : 0;
+    st = st < 0 ? 0 : (st > n ? n : st);
+    const int nv = n - st < a.L ? n - st : a.L;
+    float* o = a.out + (size_t)b * a.L;
+    for (int i = tid; i < a.L; i += 256) o[i] = i < nv ? s[st + i] * gain : 0.f;
+    if (tid == 0 && a.n_valid) a.n_valid[b] = nv;
+}
+
 }  // namespace
 
 extern "C" {
@@ -98,6 +130,15 @@ int vp_pad_batch(vp_ctx* ctx, int dtype, const void* const* srcs, const int32_t*
         VP_FAIL(ctx, VP_EINVAL, "pad_batch: bad dtype");
     }
     VP_LAUNCH_CHECK(ctx, "pad_batch");
+    return VP_OK;
+}
+
+int vp_wave_batch_f32(vp_ctx* ctx, const float* const* srcs, const int32_t* lens, const int32_t* starts, int B, int L, int normalize,
+                      float target_db, const float* gain_db, float* out, int32_t* n_valid, vp_stream stream) {
+    if (!ctx || !srcs || !lens || !out || B <= 0 || L <= 0) VP_FAIL(ctx, VP_EINVAL, "wave_batch: bad arguments");
+    WaveArgs a{srcs, lens, starts, gain_db, out, n_valid, L, normalize, target_db};
+    hipLaunchKernelGGL(wave_batch_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+    VP_LAUNCH_CHECK(ctx, "wave_batch");
     return VP_OK;
 }
 

@@ -18,6 +18,7 @@ VP_F32, VP_BF16 = 0, 1
 VP_OK, VP_EINVAL, VP_ENOMEM, VP_EHIP, VP_EUNSUP, VP_EWORKSPACE = 0, -1, -2, -3, -4, -5
 VP_PAD_NONE, VP_PAD_REFLECT, VP_PAD_ZERO = 0, 1, 2
 VP_ACT_NONE, VP_ACT_RELU, VP_ACT_SIGMOID, VP_ACT_TANH, VP_ACT_HARDTANH20, VP_ACT_SILU = 0, 1, 2, 3, 4, 5
+VP_LOSS_AAM, VP_LOSS_AM, VP_LOSS_ARM, VP_LOSS_CE, VP_LOSS_SUBCENTER = 0, 1, 2, 3, 4
 VP_MAX_SE_BLOCKS, VP_MAX_RES2 = 8, 15
 
 c_void_p, c_int, c_float, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_size_t
@@ -179,6 +180,8 @@ _PROTOS = {
                                 c_size_t, c_void_p]),
     'vp_spec_augment': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     'vp_pad_batch': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'vp_wave_batch_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
+                                  c_void_p]),
     'vp_resnetse_workspace_bytes': (c_size_t, [C.POINTER(ResnetSeWeights), c_int, c_int]),
     'vp_resnetse_fwd': (c_int, [c_void_p, C.POINTER(ResnetSeWeights), c_void_p, c_int, c_int, c_void_p, c_void_p,
                                 c_size_t, c_void_p]),
@@ -227,6 +230,12 @@ _PROTOS = {
     'vp_scale_rows_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'vp_aam_ce_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_float, c_void_p,
                               c_void_p, c_void_p, c_void_p]),
+    'vp_margin_ce_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int,
+                                 c_void_p, c_void_p, c_void_p]),
+    'vp_margin_ce_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int, c_float,
+                                 c_void_p, c_void_p, c_void_p, c_void_p]),
+    'vp_sphereface2': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_int, c_float,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'vp_cosine_logits_bwd_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'vp_cosine_logits_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                      c_size_t, c_void_p]),

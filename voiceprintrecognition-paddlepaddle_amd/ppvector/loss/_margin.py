@@ -1,0 +1,32 @@
+"""Shared body of the margin-softmax criteria (AM / ARM / CE / SubCenter): argument checks, the eval-time forward through
+vp_margin_ce_fwd and the training-time forward + backward through ppvector.train.functions.MarginCe (csrc/losses.hip)."""
+import torch
+from torch import nn
+
+from ppvector import _native as N
+
+
+class MarginSoftmax(nn.Module):
+    kind = None                                   # one of N.VP_LOSS_*
+    K = 1
+
+    def _loss(self, inputs, labels, margin, scale, label_smoothing, easy_margin=False):
+        logits = inputs['logits']
+        if not logits.is_cuda:
+            raise N.VpmiError(f'{type(self).__name__} needs GPU tensors: the engine has no CPU fallback')
+        if logits.shape[1] % self.K:
+            raise ValueError(f'logits have {logits.shape[1]} columns, not a multiple of K={self.K}')
+        if torch.is_grad_enabled() and logits.requires_grad:
+            from ppvector.train.functions import MarginCe
+            return MarginCe.apply(logits, labels, self.kind, self.K, margin, scale, label_smoothing, easy_margin)
+        logits = logits.contiguous().float()
+        labels = labels.to(device=logits.device, dtype=torch.int64).reshape(-1).contiguous()
+        B, CK = logits.shape
+        lib, ctx = N.lib(), N.ctx(logits.device)
+        loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
+        row = torch.empty((B,), dtype=torch.float32, device=logits.device)
+        N.check(lib.vp_margin_ce_fwd(ctx, logits.data_ptr(), labels.data_ptr(), B, CK // self.K, self.K, self.kind, float(margin),
+                                     float(scale), float(label_smoothing), int(bool(easy_margin)), loss.data_ptr(), row.data_ptr(),
+                                     N.stream_ptr()), ctx)
+        self.row_loss = row
+        return loss[0]

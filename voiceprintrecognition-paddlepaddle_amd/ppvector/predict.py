@@ -100,10 +100,11 @@ class PPVectorPredictor:
         else:
             if not os.path.exists(model_path):
                 raise Exception("模型文件不存在，请检查{}是否存在！".format(model_path))
-            if os.path.isdir(model_path):
-                model_path = os.path.join(model_path, 'model.pth')
+            if os.path.isdir(model_path):                      # the reference's checkpoint directory (predict.py:61-62)
+                model_path = os.path.join(model_path, 'model.pdparams')
             assert os.path.exists(model_path), f"{model_path} 模型不存在！"
-            state = torch.load(model_path, map_location='cpu')
+            from ppvector.utils.checkpoint import load_pdparams
+            state = load_pdparams(model_path)
         state = {k: torch.as_tensor(np.asarray(v)) if not isinstance(v, torch.Tensor) else v for k, v in state.items()}
         own = self.predictor.state_dict()
         # load_pretrained semantics (utils/checkpoint.py:11-42): keep what matches by name and shape

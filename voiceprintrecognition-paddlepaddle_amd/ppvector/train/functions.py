@@ -368,6 +368,55 @@ class AamCe(torch.autograd.Function):
         return dl * g, None, None, None, None, None
 
 
+class MarginCe(torch.autograd.Function):
+    """The AM / ARM / CE / SubCenter (/ AAM) losses over the head's logits (loss/amloss.py:14-25, armloss.py:14-31,
+    celoss.py:11-19, subcenterloss.py:32-54): value and d loss / d logits from one launch (csrc/losses.hip)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, kind, K, margin, scale, label_smoothing, easy_margin):
+        lib, hctx = N.lib(), N.ctx(logits.device)
+        logits = _f32c(logits)
+        B, CK = logits.shape
+        lab = labels.to(device=logits.device, dtype=torch.int64).reshape(-1).contiguous()
+        dl = torch.empty_like(logits)
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+        row = torch.empty(B, dtype=torch.float32, device=logits.device)
+        _chk(lib.vp_margin_ce_bwd(hctx, logits.data_ptr(), lab.data_ptr(), B, CK // K, K, kind, float(margin), float(scale),
+                                  float(label_smoothing), int(bool(easy_margin)), 1.0, dl.data_ptr(), loss.data_ptr(), row.data_ptr(),
+                                  N.stream_ptr()), hctx)
+        ctx.save_for_backward(dl)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None, None, None, None, None, None, None
+
+
+class SphereFace2Fn(torch.autograd.Function):
+    """SphereFace2.forward (loss/sphereface2.py:47-69) with its gradients w.r.t. the logits and the bias parameter."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, bias, margin, scale, lanbuda, t, type_a):
+        lib, hctx = N.lib(), N.ctx(logits.device)
+        logits, bias = _f32c(logits), _f32c(bias)
+        B, Cc = logits.shape
+        lab = labels.to(device=logits.device, dtype=torch.int64).reshape(-1).contiguous()
+        dl = torch.empty_like(logits)
+        out = torch.empty(2 + 2 * B, dtype=torch.float32, device=logits.device)       # loss, dbias, row_loss, row_dbias
+        _chk(lib.vp_sphereface2(hctx, logits.data_ptr(), lab.data_ptr(), bias.data_ptr(), B, Cc, float(margin), float(scale),
+                                float(lanbuda), int(t), int(bool(type_a)), 1.0, out.data_ptr(), out[2:].data_ptr(), dl.data_ptr(),
+                                out[1:].data_ptr(), out[2 + B:].data_ptr(), N.stream_ptr()), hctx)
+        ctx.save_for_backward(dl, out)
+        ctx.bias_shape = bias.shape
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        dl, out = ctx.saved_tensors
+        return dl * g, None, (out[1] * g).reshape(ctx.bias_shape), None, None, None, None, None
+
+
 class Conv2dBlock(torch.autograd.Function):
     """2-D conv over (B, T, F, C) positions (zero padding (k-1)/2, stride s on both axes) [-> BatchNorm (batch statistics)]
     [-> ReLU]: the Conv2D -> BatchNorm2D -> ReLU units of models/resnet_se.py:8-45,72-74 (BN BEFORE the ReLU, unlike TDNNBlock).
