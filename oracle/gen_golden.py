@@ -248,6 +248,29 @@ def main():
         gl[name + '_dlogits'] = g_ref.numpy()
     out['losses_ref.npz'] = gl
 
+    # ---------------- classifier head variants (fc.py:6-87): DenseLayer('batchnorm') blocks, 'Linear' output
+    hr = np.random.RandomState(91)
+    embh = torch.from_numpy(hr.standard_normal((5, 24)).astype(np.float32))
+    gh = dict(emb=embh.numpy())
+    for tag, ctype, nb in (('cos_b2', 'Cosine', 2), ('lin_b0', 'Linear', 0), ('lin_b1', 'Linear', 1)):
+        ph = om.classifier_params(24, 9, ctype, 1, nb, 16, seed=1002)
+        hm = ref_fc.SpeakerIdentification(input_dim=24, num_speakers=9, classifier_type=ctype, num_blocks=nb, inter_dim=16)
+        sdh = hm.state_dict()
+        assert set(sdh) == set(ph), (sorted(set(sdh) ^ set(ph)))
+        hm.load_state_dict(ph)
+        hm.eval()
+        with torch.no_grad():
+            lr_ev = hm(paddle_shim.to_tensor(embh.numpy()))['logits']
+            lo_ev = om.classifier_head(embh, ph, ctype, nb)
+        cmp(f'head {tag} eval logits', lo_ev, lr_ev, 1e-5)
+        hm.train()
+        with torch.no_grad():
+            lr_tr = hm(paddle_shim.to_tensor(embh.numpy()))['logits']
+            lo_tr = om.classifier_head(embh, ph, ctype, nb, training=True)
+        cmp(f'head {tag} train logits', lo_tr, lr_tr, 1e-5)
+        gh[tag + '_eval'], gh[tag + '_train'] = lr_ev.numpy(), lr_tr.numpy()
+    out['head_variants_ref.npz'] = gh
+
     # ---------------- real speech: 4 reference WAVs (3 s crops) -> oracle Fbank -> reference ECAPA graph
     names = ['a_1', 'a_2', 'b_1', 'b_2']
     pcm = np.stack([read_wav_16k_mono(f'{REF}/dataset/{n}.wav') for n in names])

@@ -165,6 +165,35 @@ def cosine_head(emb, weight):
     return xn @ wn
 
 
+def classifier_head(emb, p, classifier_type='Cosine', num_blocks=0, training=False, stats_out=None, prefix=''):
+    """SpeakerIdentification.forward (fc.py:41-53) with its DenseLayer('batchnorm') stages (fc.py:27-29, :56-71):
+    x -> [Conv1D(k=1) -> BatchNorm1D] * num_blocks -> cosine / linear logits.  p: the head's state dict."""
+    x = emb
+    for i in range(num_blocks):
+        w = p[f'{prefix}blocks.{i}.linear.weight']
+        x = x @ w.reshape(w.shape[0], -1).t() + p[f'{prefix}blocks.{i}.linear.bias']
+        x = batchnorm(x, p, f'{prefix}blocks.{i}.nonlinear.batchnorm.', training, stats_out)
+    if classifier_type == 'Cosine':
+        return cosine_head(x, p[prefix + 'weight'])
+    return x @ p[prefix + 'output.weight'] + p[prefix + 'output.bias']
+
+
+def classifier_params(input_dim=192, num_speakers=20, classifier_type='Cosine', K=1, num_blocks=0, inter_dim=512, seed=1002,
+                      dtype=torch.float32):
+    rng = np.random.RandomState(seed)
+    p, d = {}, input_dim
+    for i in range(num_blocks):
+        p.update(_conv_keys(f'blocks.{i}.linear.', inter_dim, d, 1, rng))
+        p.update(_bn_keys(f'blocks.{i}.nonlinear.batchnorm.', inter_dim, rng, True))
+        d = inter_dim
+    if classifier_type == 'Cosine':
+        p['weight'] = rng.standard_normal((d, num_speakers * K)) / np.sqrt(d)
+    else:
+        p['output.weight'] = rng.standard_normal((d, num_speakers)) / np.sqrt(d)
+        p['output.bias'] = 0.1 * rng.standard_normal(num_speakers)
+    return {k: torch.as_tensor(np.asarray(v), dtype=dtype) for k, v in p.items()}
+
+
 def aam_margins(margin):
     """aamloss.py:22-25 / :49-53."""
     return dict(cos_m=math.cos(margin), sin_m=math.sin(margin), th=math.cos(math.pi - margin),

@@ -122,3 +122,46 @@ def test_loss_argument_errors(N):
         _build('NoSuchLoss')
     with pytest.raises(N.VpmiError):
         _build('AMLoss')({'features': None, 'logits': torch.zeros(2, 6)}, torch.zeros(2, dtype=torch.int64))
+
+
+@pytest.mark.parametrize('case', [('cos_b2', 'Cosine', 2), ('lin_b0', 'Linear', 0), ('lin_b1', 'Linear', 1)], ids=lambda c: c[0])
+def test_head_variants_match_reference_golden_and_autograd(N, golden_dir, case):
+    """SpeakerIdentification with DenseLayer('batchnorm') blocks / the 'Linear' output (fc.py:6-87): the reference's state
+    dict loads unchanged; eval and train-mode logits against the golden file; gradients and BatchNorm running statistics
+    against float64 autograd over the oracle."""
+    from ppvector.models.fc import SpeakerIdentification
+    tag, ctype, nb = case
+    g = np.load(os.path.join(golden_dir, 'head_variants_ref.npz'), allow_pickle=False)
+    p = om.classifier_params(24, 9, ctype, 1, nb, 16, seed=1002)
+    head = SpeakerIdentification(24, 9, classifier_type=ctype, num_blocks=nb, inter_dim=16)
+    head.load_state_dict(p)                                              # strict: same keys as the reference's module
+    head = head.cuda().eval()
+    emb = torch.from_numpy(g['emb']).cuda()
+    with torch.no_grad():
+        ev = head(emb)['logits']
+    assert np.max(np.abs(ev.cpu().numpy() - g[tag + '_eval'])) < 2e-5 * max(1.0, np.max(np.abs(g[tag + '_eval'])))
+    head.train()
+    ed = emb.clone().requires_grad_()
+    out = head(ed)
+    assert out['features'] is ed
+    assert np.max(np.abs(out['logits'].detach().cpu().numpy() - g[tag + '_train'])) < 5e-5 * max(1.0, np.max(np.abs(g[tag + '_train'])))
+    gl = torch.randn(out['logits'].shape, generator=torch.Generator().manual_seed(5), dtype=torch.float64)
+    out['logits'].backward(gl.float().cuda())
+    pd = {k: v.double().requires_grad_(v.dtype.is_floating_point and not k.endswith(('_mean', '_variance'))) for k, v in p.items()}
+    e64 = torch.from_numpy(g['emb']).double().requires_grad_()
+    stats = {}
+    om.classifier_head(e64, pd, ctype, nb, training=True, stats_out=stats).backward(gl)
+
+    def rel(a, b):
+        a, b = a.double().cpu(), b.double().cpu()
+        return ((a - b).norm() / b.norm().clamp(min=1e-30)).item()
+    assert rel(ed.grad, e64.grad) < 1e-4
+    for k, v in head.named_parameters():
+        if pd[k].grad is not None and pd[k].grad.abs().max() > 1e-9:
+            assert rel(v.grad, pd[k].grad) < 2e-4, k
+    for i in range(nb):                                                   # Paddle momentum 0.9, biased batch variance
+        pre = f'blocks.{i}.nonlinear.batchnorm.'
+        mean, var = stats[pre]
+        bn = head.blocks[i].nonlinear.batchnorm
+        assert rel(bn._mean, 0.9 * p[pre + '_mean'].double() + 0.1 * mean) < 1e-5
+        assert rel(bn._variance, 0.9 * p[pre + '_variance'].double() + 0.1 * var) < 1e-5

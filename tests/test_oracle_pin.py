@@ -171,3 +171,16 @@ def test_loss_family_oracle_matches_reference_golden(golden_dir):
         grad, = torch.autograd.grad(loss, l)
         assert abs(float(loss.detach()) - float(g[name + '_loss'])) < 1e-5 * max(1.0, abs(float(g[name + '_loss']))), name
         assert np.max(np.abs(grad.numpy() - g[name + '_dlogits'])) < 1e-5 * max(1.0, np.max(np.abs(g[name + '_dlogits']))), name
+
+
+def test_head_variants_oracle_matches_reference_golden(golden_dir):
+    """fc.py:6-87 run through the shim: DenseLayer('batchnorm') blocks in front of the cosine head, 'Linear' output."""
+    g = _load(golden_dir, 'head_variants_ref.npz')
+    emb = torch.from_numpy(g['emb'])
+    for tag, ctype, nb in (('cos_b2', 'Cosine', 2), ('lin_b0', 'Linear', 0), ('lin_b1', 'Linear', 1)):
+        p = om.classifier_params(24, 9, ctype, 1, nb, 16, seed=1002)
+        with torch.no_grad():
+            ev = om.classifier_head(emb, p, ctype, nb).numpy()
+            tr = om.classifier_head(emb, p, ctype, nb, training=True).numpy()
+        assert np.max(np.abs(ev - g[tag + '_eval'])) < 1e-5 * max(1.0, np.max(np.abs(g[tag + '_eval']))), tag
+        assert np.max(np.abs(tr - g[tag + '_train'])) < 1e-5 * max(1.0, np.max(np.abs(g[tag + '_train']))), tag

@@ -368,6 +368,44 @@ class AamCe(torch.autograd.Function):
         return dl * g, None, None, None, None, None
 
 
+class Dense(torch.autograd.Function):
+    """y (M, N) = x (M, K) @ W (K, N) + bias in exact f32 (vp_dense_f32) with its three backward products -- the Linear
+    output and the DenseLayer stages of the classifier head (models/fc.py:27-29, :36-37, :56-71); any N, K."""
+
+    @staticmethod
+    def forward(ctx, x, w_kn, bias):
+        lib, hctx = N.lib(), N.ctx(x.device)
+        x, w_kn = _f32c(x), _f32c(w_kn)
+        M, K = x.shape
+        Nn = w_kn.shape[1]
+        y = torch.empty((M, Nn), dtype=torch.float32, device=x.device)
+        _chk(lib.vp_dense_f32(hctx, x.data_ptr(), K, w_kn.data_ptr(), 1, bias.data_ptr() if bias is not None else None, M, Nn, K,
+                              N.VP_ACT_NONE, y.data_ptr(), Nn, N.stream_ptr()), hctx)
+        ctx.save_for_backward(x, w_kn)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_kn = ctx.saved_tensors
+        lib, hctx = N.lib(), N.ctx(x.device)
+        dy = _f32c(dy)
+        M, K = x.shape
+        Nn = w_kn.shape[1]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)                                   # dy @ W^T: W read as [N' = K][K' = N]
+            _chk(lib.vp_dense_f32(hctx, dy.data_ptr(), Nn, w_kn.data_ptr(), 0, None, M, K, Nn, N.VP_ACT_NONE, dx.data_ptr(), K,
+                                  N.stream_ptr()), hctx)
+        if ctx.needs_input_grad[1]:
+            xt = x.t().contiguous()                                    # x^T @ dy
+            dw = torch.empty_like(w_kn)
+            _chk(lib.vp_dense_f32(hctx, xt.data_ptr(), M, dy.data_ptr(), 1, None, K, Nn, M, N.VP_ACT_NONE, dw.data_ptr(), Nn,
+                                  N.stream_ptr()), hctx)
+        db = col_sums(dy)[0].clone() if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
 class MarginCe(torch.autograd.Function):
     """The AM / ARM / CE / SubCenter (/ AAM) losses over the head's logits (loss/amloss.py:14-25, armloss.py:14-31,
     celoss.py:11-19, subcenterloss.py:32-54): value and d loss / d logits from one launch (csrc/losses.hip)."""
