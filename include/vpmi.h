@@ -68,6 +68,13 @@ size_t vp_fbank_workspace_bytes(const vp_fbank_opts* o, int B, int L);
 int vp_fbank_cmn_f32(vp_ctx* ctx, const float* wav, const float* lens_ratio, int B, int L,
                      const vp_fbank_opts* o, float* out, void* out_bf16, void* ws, size_t ws_bytes,
                      vp_stream stream);
+/* Ragged batch, the training loader's semantics: the reference featurises every utterance on its own (AudioFeaturizer on
+ * one waveform, time mean over ITS frames, data_utils/reader.py:102-103) and collate_fn zero-pads the features
+ * (collate_fn.py:5-23).  wav (B, L) holds utterance b in its first n_samples[b] samples; frames [0, n_frames[b]),
+ * n_frames[b] = snip-edges count of n_samples[b], are mean-normalised over that range and the remaining rows are zero.
+ * n_frames (B) is written for the caller (collate_fn's input_lens). */
+int vp_fbank_cmn_ragged_f32(vp_ctx* ctx, const float* wav, const int32_t* n_samples, int B, int L, const vp_fbank_opts* o,
+                            float* out, void* out_bf16, int32_t* n_frames, void* ws, size_t ws_bytes, vp_stream stream);
 
 /* MelSpectrogram + CMN -- replaces AudioFeaturizer.forward with feature_method 'MelSpectrogram' ->
  * paddle.audio.features.MelSpectrogram(**method_args) (featurizer.py:22-23): centred STFT (reflect pad,

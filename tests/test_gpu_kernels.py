@@ -70,6 +70,33 @@ def test_fbank_mask_and_1d(N):
     assert np.max(np.abs(f23(dev(w[:1])).cpu().numpy() - r23)) < 2e-3
 
 
+def test_fbank_ragged_is_per_utterance_featurise_then_collate(N):
+    """The training loader's semantics (reader.py:102-103 + collate_fn.py:5-23) in one batched launch: every utterance
+    featurised alone (time mean over its own frames), features zero-padded to the longest."""
+    from oracle import augment as oa
+    from ppvector.data_utils.featurizer import AudioFeaturizer
+    lens = [48000, 30000, 16001, 400, 47999]
+    w = ofb.synth_waves(len(lens), 48000, seed=21)
+    garbage = w.copy()
+    for b, n in enumerate(lens):
+        garbage[b, n:] = 7.0                                                   # samples past the utterance must not matter
+    per = [ofb.featurize(w[b:b + 1, :n], method_args=dict(sr=16000, n_mels=80))[0] for b, n in enumerate(lens)]
+    ref, _, ref_lens = oa.collate([(f, 0) for f in per])
+    fz = AudioFeaturizer('Fbank', dict(sr=16000, n_mels=80))
+    got, got_lens = fz.forward_ragged(dev(garbage), torch.tensor(lens), want_bf16=True)
+    assert got_lens.dtype == torch.int64 and np.array_equal(got_lens.cpu().numpy(), ref_lens)
+    g = got.cpu().numpy()
+    assert g.shape == ref.shape and np.max(np.abs(g - ref)) < 2e-3 and np.mean(np.abs(g - ref)) < 2e-5
+    for b, n in enumerate(ref_lens):
+        assert np.all(g[b, n:] == 0) and abs(float(g[b, :n].mean(axis=0).max())) < 1e-4       # own-frame CMN
+    assert np.max(np.abs(got._vp_bf16.float().cpu().numpy() - g)) <= np.max(np.abs(g)) * 2 ** -8 + 1e-6
+    # other feature methods take the per-utterance route with the same contract
+    mz = AudioFeaturizer('MelSpectrogram', dict(sr=16000, n_fft=1024, hop_length=320, win_length=1024, n_mels=64, f_min=50.0))
+    mg, ml = mz.forward_ragged(dev(w[:2]), torch.tensor([48000, 20000]))
+    alone = mz(dev(w[1:2, :20000]))
+    assert mg.shape[0] == 2 and int(ml[1]) == alone.shape[1] and torch.equal(mg[1, :alone.shape[1]], alone[0]) and float(mg[1, alone.shape[1]:].abs().max()) == 0.0
+
+
 def test_fbank_real_speech_golden(N, golden_dir):
     from ppvector.data_utils.featurizer import AudioFeaturizer
     g = np.load(f'{golden_dir}/wavs_3s.npz')

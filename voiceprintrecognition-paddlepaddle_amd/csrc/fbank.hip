@@ -269,6 +269,46 @@ __global__ __launch_bounds__(256) void fbank_cmn_kernel(CmnArgs a) {
     }
 }
 
+// Ragged batch: utterance b owns frames [0, n_frames[b]); its time mean is taken over those frames only and the rest of
+// its rows are zero -- per-utterance featurisation followed by collate_fn's zero padding (reader.py:102-103 +
+// collate_fn.py:5-23).  One workgroup per utterance: column means (each thread strides the rows of its mel bin group), then
+// the subtraction.  Fixed-order sums.
+struct CmnRaggedArgs { float* out; bf16_t* out_bf16; const int* n_frames; int T, n_mels; };
+
+__global__ __launch_bounds__(256) void fbank_cmn_ragged_kernel(CmnRaggedArgs a) {
+    __shared__ float s_part[4][FB_MAX_MEL];
+    __shared__ float s_mean[FB_MAX_MEL];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int valid = min(max(a.n_frames[b], 0), a.T);
+    float* o = a.out + (size_t)b * a.T * a.n_mels;
+    bf16_t* ob = a.out_bf16 ? a.out_bf16 + (size_t)b * a.T * a.n_mels : nullptr;
+    const int m = tid & 63, rg = tid >> 6;                         // 64 mel bins per pass x 4 row groups
+    for (int m0 = 0; m0 < a.n_mels; m0 += 64) {
+        float s = 0.f;
+        if (m0 + m < a.n_mels)
+            for (int t = rg; t < valid; t += 4) s += o[(size_t)t * a.n_mels + m0 + m];
+        if (m0 + m < a.n_mels) s_part[rg][m0 + m] = s;
+    }
+    __syncthreads();
+    if (tid < a.n_mels) s_mean[tid] = (s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid]) / (float)(valid > 0 ? valid : 1);
+    __syncthreads();
+    const int n = a.T * a.n_mels;
+    for (int e = tid; e < n; e += 256) {
+        const int t = e / a.n_mels;
+        const float v = (t < valid) ? (o[e] - s_mean[e - t * a.n_mels]) : 0.f;
+        o[e] = v;
+        if (ob) ob[e] = (bf16_t)v;
+    }
+}
+
+__global__ void frames_of_samples_kernel(const int* n_samples, int B, int win, int shift, int T, int* n_frames) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const int n = n_samples[b];
+    const int f = n < win ? 0 : 1 + (n - win) / shift;
+    n_frames[b] = f < T ? f : T;
+}
+
 double mel_of(double f) { return 1127.0 * log(1.0 + f / 700.0); }
 
 bool same_opts(const vp_fbank_opts& x, const vp_fbank_opts& y) { return memcmp(&x, &y, sizeof(x)) == 0; }
@@ -406,6 +446,33 @@ int vp_fbank_cmn_f32(vp_ctx* ctx, const float* wav, const float* lens_ratio, int
     hipLaunchKernelGGL(fbank_frames_kernel, dim3(tiles, B), dim3(FB_WAVES * 64), 0, st, a);
     VP_LAUNCH_CHECK(ctx, "fbank_frames");
     return vp_feat_cmn(ctx, out, out_bf16, (const float*)ws, lens_ratio, B, T, tiles, o->n_mels, st);
+}
+
+int vp_fbank_cmn_ragged_f32(vp_ctx* ctx, const float* wav, const int32_t* n_samples, int B, int L, const vp_fbank_opts* o, float* out,
+                            void* out_bf16, int32_t* n_frames, void* ws, size_t ws_bytes, vp_stream stream) {
+    if (!ctx || !wav || !n_samples || !n_frames || !o || !out || B <= 0) VP_FAIL(ctx, VP_EINVAL, "fbank_ragged: bad arguments");
+    const int T = vp_fbank_num_frames(o, L);
+    if (T <= 0) VP_FAIL(ctx, VP_EINVAL, "fbank: %d samples give no frame", L);
+    if (B > 65535) VP_FAIL(ctx, VP_EINVAL, "fbank: batch %d > 65535", B);
+    int rc = build_tables(ctx, o);
+    if (rc != VP_OK) return rc;
+    if (!ws || ws_bytes < vp_fbank_workspace_bytes(o, B, L)) VP_FAIL(ctx, VP_EWORKSPACE, "fbank: workspace too small");
+    const int tiles = (T + FRAMES_PER_WG - 1) / FRAMES_PER_WG;
+    hipStream_t st = (hipStream_t)stream;
+    FbankArgs a;
+    a.wav = wav; a.out = out; a.psum = (float*)ws; a.window = ctx->fb_window; a.tw = ctx->fb_twiddle;
+    a.mel_start = ctx->fb_mel_start; a.mel_bin0 = ctx->fb_mel_bin0; a.mel_w = ctx->fb_mel_w;
+    a.B = B; a.L = L; a.T = T; a.tiles = tiles; a.win = ctx->fb_win; a.shift = ctx->fb_shift;
+    a.n_mels = o->n_mels; a.nnz = ctx->fb_nnz; a.preemph = o->preemph; a.log_floor = o->log_floor;
+    a.remove_dc = o->remove_dc;
+    hipLaunchKernelGGL(fbank_frames_kernel, dim3(tiles, B), dim3(FB_WAVES * 64), 0, st, a);
+    VP_LAUNCH_CHECK(ctx, "fbank_frames");
+    hipLaunchKernelGGL(frames_of_samples_kernel, dim3((B + 255) / 256), dim3(256), 0, st, n_samples, B, ctx->fb_win, ctx->fb_shift, T, n_frames);
+    VP_LAUNCH_CHECK(ctx, "frames_of_samples");
+    CmnRaggedArgs c{out, (bf16_t*)out_bf16, n_frames, T, o->n_mels};
+    hipLaunchKernelGGL(fbank_cmn_ragged_kernel, dim3(B), dim3(256), 0, st, c);
+    VP_LAUNCH_CHECK(ctx, "fbank_cmn_ragged");
+    return VP_OK;
 }
 
 }  // extern "C"

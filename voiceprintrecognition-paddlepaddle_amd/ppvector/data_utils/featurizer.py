@@ -121,6 +121,36 @@ class AudioFeaturizer(nn.Module):
             out._vp_bf16 = out16
         return out
 
+    def forward_ragged(self, waveforms, n_samples, want_bf16=False):
+        """The training loader's semantics for a ragged batch: utterance b occupies the first n_samples[b] samples of row b;
+        it is featurised as if alone (time mean over ITS frames -- the reference's per-utterance call, reader.py:102-103) and
+        the rows past its last frame are zero (collate_fn.py:5-23).  Returns (features (B, T, F), input_lens (B,) int64).
+        One batched launch for 'Fbank'; other methods run utterance by utterance and are packed by vp_pad_batch."""
+        if not waveforms.is_cuda:
+            raise N.VpmiError('AudioFeaturizer needs GPU tensors: the engine has no CPU fallback')
+        wav = waveforms.contiguous().float()
+        B, L = wav.shape
+        ns = torch.as_tensor(n_samples).to(device=wav.device, dtype=torch.int32).contiguous()
+        if self._feature_method != 'Fbank':
+            from ppvector.data_utils.collate_fn import collate_fn
+            feats = [self.forward(wav[b, :int(n)])[0] for b, n in enumerate(ns.tolist())]
+            out, _, lens = collate_fn([(f, 0) for f in feats])
+            return out, lens
+        lib, ctx = N.lib(), N.ctx(wav.device)
+        T = lib.vp_fbank_num_frames(C.byref(self._opts), L)
+        if T <= 0:
+            raise ValueError(f'{L} samples are shorter than one analysis window')
+        F = self._opts.n_mels
+        out = torch.empty((B, T, F), dtype=torch.float32, device=wav.device)
+        out16 = torch.empty((B, T, F), dtype=torch.bfloat16, device=wav.device) if want_bf16 else None
+        nf = torch.empty((B,), dtype=torch.int32, device=wav.device)
+        ws = self._ws.get(lib.vp_fbank_workspace_bytes(C.byref(self._opts), B, L), wav.device)
+        N.check(lib.vp_fbank_cmn_ragged_f32(ctx, N.ptr(wav), N.ptr(ns), B, L, C.byref(self._opts), N.ptr(out), N.ptr(out16), N.ptr(nf),
+                                            N.ptr(ws), ws.numel(), N.stream_ptr()), ctx)
+        if out16 is not None:
+            out._vp_bf16 = out16
+        return out, nf.to(torch.int64)
+
     @property
     def feature_dim(self):
         """返回特征大小"""

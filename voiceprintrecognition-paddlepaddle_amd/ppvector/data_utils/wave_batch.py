@@ -7,11 +7,11 @@ import torch
 from ppvector import _native as N
 
 
-def assemble_waves(waves, max_len=None, starts=None, use_dB_normalization=True, target_dB=-20.0, gains_dB=None):
+def assemble_waves(waves, max_len=None, starts=None, use_dB_normalization=True, target_dB=-20.0, gains_dB=None, with_valid=False):
     """waves: list of 1-D float GPU tensors (ragged).  Returns (batch (B, L) f32, input_lens_ratio (B,) f32) -- what
     AudioFeaturizer.forward(waveforms, input_lens_ratio) takes.  L = max_len or the longest utterance after its crop start.
     starts: per-utterance crop start in samples (the training-mode random crop; None = 0).  gains_dB: per-utterance gain when
-    normalisation is off (the volume perturbation's draw)."""
+    normalisation is off (the volume perturbation's draw).  with_valid adds the kept sample counts (B,) int32."""
     waves = [torch.as_tensor(w) for w in waves]
     if not waves or not all(w.is_cuda for w in waves):
         raise N.VpmiError('assemble_waves packs GPU waveforms: the engine has no CPU fallback')
@@ -33,4 +33,5 @@ def assemble_waves(waves, max_len=None, starts=None, use_dB_normalization=True, 
     N.check(N.lib().vp_wave_batch_f32(ctx, ptrs.data_ptr(), lens_d.data_ptr(), st_d.data_ptr(), B, L, int(bool(use_dB_normalization)),
                                       float(target_dB), None if g is None else g.data_ptr(), out.data_ptr(), nv.data_ptr(),
                                       N.stream_ptr()), ctx)
-    return out, nv.float() / float(L)
+    ratio = nv.float() / float(L)
+    return (out, ratio, nv) if with_valid else (out, ratio)
