@@ -135,9 +135,11 @@ def test_unbuilt_model_variants_refuse():
     from ppvector.models.eres2net import ERes2Net, ERes2NetV2
     with pytest.raises(NotImplementedError):
         ERes2Net(80, two_emb_layer=True)
-    m = ERes2NetV2(80).cuda().train()                  # V2 has the eval engine only so far
     with pytest.raises(NotImplementedError):
-        m(torch.zeros(2, 32, 80, device='cuda'))
+        ERes2NetV2(80, two_emb_layer=True)
+    from ppvector.models.fc import DenseLayer
+    with pytest.raises(NotImplementedError):
+        DenseLayer(8, 8, config_str='batchnorm-prelu')
 
 
 def test_long_utterance_falls_back_to_per_conv_path(ecapa):

@@ -407,6 +407,52 @@ def test_eres2net_training_step_vs_oracle_autograd(N):
     m.eval()
 
 
+def test_eres2netv2_training_step_vs_oracle_autograd(N):
+    """ERes2NetV2 (base_width 26: chunk widths 13 / 26 / 52 / 104 -- the first two run on zero-padded chunks; one bottom-up
+    fusion) against autograd over the oracle graph; running statistics land in the reference-shaped buffers."""
+    from oracle import eres2net as oer
+    from ppvector.models.eres2net import ERes2NetV2
+    from ppvector.train.functions import HeadLoss
+    B, T, Fdim, Cc = 3, 20, 16, 10
+    nb = (1, 2, 1, 1)
+    p = oer.eres2net_params(Fdim, 192, num_blocks=nb, base_width=26, seed=17, v2=True)
+    g = torch.Generator().manual_seed(15)
+    x = torch.randn(B, T, Fdim, generator=g) * 2
+    labels = torch.randint(0, Cc, (B,), generator=g)
+    Wh = om.head_params(192, Cc, seed=3)
+    pr = {k: v.clone().double().requires_grad_(not k.endswith(('_mean', '_variance'))) for k, v in p.items()}
+    Wr = Wh.clone().double().requires_grad_()
+    emb_ref = oer.eres2netv2_forward(pr, x.double(), num_blocks=nb, training=True)
+    loss_ref = om.aam_loss(om.cosine_head(emb_ref, Wr), labels, 0.2, 32.0, False, 0.0)
+    loss_ref.backward()
+    m = ERes2NetV2(Fdim, num_blocks=list(nb))
+    m.load_state_dict(p)
+    m = m.cuda().train()
+    assert m.layer1[0].width == 13 and m.layer2[0].width == 26
+    Wd = Wh.cuda().requires_grad_()
+    emb = m(x.cuda())
+    assert rel(emb, emb_ref.detach()) < 1e-4
+    loss = HeadLoss.apply(emb, Wd, labels.cuda(), 0.2, 32.0, 0.0, False)
+    assert abs(loss.item() - loss_ref.item()) < 5e-4 * abs(loss_ref.item())
+    loss.backward()
+    worst, wk = 0.0, ''
+    for k, v in m.named_parameters():
+        if pr[k].grad is None or pr[k].grad.norm().item() < 1e-9:
+            assert v.grad is None or v.grad.abs().max().item() < 1e-4, k
+            continue
+        r = rel(v.grad, pr[k].grad)
+        if r > worst:
+            worst, wk = r, k
+        assert r < 5e-3, (k, r)
+    # running statistics of a padded-chunk BatchNorm: Paddle momentum 0.9 on the batch mean of the pre-BN conv output
+    xin = torch.nn.functional.relu(oer._bn(oer._c2d(x.transpose(1, 2).unsqueeze(1), p, 'conv1.', padding=1), p, 'bn1.', True))
+    z = oer._c2d(xin, p, 'layer1.0.conv1.')
+    want = 0.9 * p['layer1.0.bn1._mean'] + 0.1 * z.mean(dim=(0, 2, 3))
+    assert rel(m.layer1[0].bn1._mean, want) < 1e-5
+    print(f'[eres2netv2 train] loss {loss.item():.5f} (oracle {loss_ref.item():.5f}); worst parameter-gradient rel-L2 {worst:.2e} ({wk})')
+    m.eval()
+
+
 def test_campplus_training_step_vs_oracle_autograd(N):
     """CAM++ (configs/cam++.yml: embd 192): FCM with stride on the frequency axis, the stride-2 TDNN, 52 CAM dense layers with
     two context segments (115 frames after the stride), transit layers, unbiased statistics pooling."""

@@ -469,7 +469,7 @@ class EngineMixin:
             fwd = getattr(self, '_train_forward', None)
             if fwd is None:
                 raise NotImplementedError(f'training-mode forward/backward on the HIP engine is not built for {type(self).__name__} '
-                                          '(TDNN, EcapaTdnn, CAMPPlus, ResNetSE and ERes2Net are: DESIGN.md section 7a); '
+                                          '(TDNN, EcapaTdnn, CAMPPlus, ResNetSE, ERes2Net and ERes2NetV2 are: DESIGN.md section 7a); '
                                           'call .eval() for embedding extraction')
             return fwd(x)
         with torch.no_grad():

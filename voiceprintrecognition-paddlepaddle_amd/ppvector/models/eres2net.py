@@ -175,3 +175,11 @@ class ERes2NetV2(EngineMixin, nn.Module):
         self.seg_2 = nn.Identity()
 
     _make_layer = ERes2Net._make_layer
+
+    def _train_forward(self, x):
+        """Training mode (f32 engine); stages 1-2 run on zero-padded chunk widths (train/eres2net_train.py)."""
+        from ppvector import _native as N
+        from ppvector.train.eres2net_train import eres2netv2_forward_train
+        if not x.is_cuda:
+            raise N.VpmiError('model input must be a GPU tensor: the engine has no CPU fallback')
+        return eres2netv2_forward_train(self, x.float().contiguous())
