@@ -116,3 +116,38 @@ def test_two_rank_overlapped_reducer_matches_full_batch_gradient():
         assert p.exitcode == 0
     for rank, nb, err in res:
         assert nb >= 2 and err < 1e-6, (rank, nb, err)
+
+
+def test_batch_loader_shards_like_distributed_batch_sampler():
+    """The trainer's index batching (ppvector/trainer.py mirror of paddle.io.DistributedBatchSampler, trainer.py:105-107):
+    every rank sees the same shuffled order, takes a contiguous 1/world shard (padded by wrapping), equal batch counts."""
+    from ppvector.trainer import _BatchLoader
+
+    class DS:
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+        def __getitem__(self, i):
+            return i
+
+    n, world, bs = 103, 4, 8
+    loaders = [_BatchLoader(DS(n), batch_size=bs, shuffle=True, drop_last=True, num_workers=2, rank=r, world=world) for r in range(world)]
+    assert len({len(l) for l in loaders}) == 1 and len(loaders[0]) == ((n + world - 1) // world) // bs
+    for epoch in range(2):
+        seen = []
+        for l in loaders:
+            batches = list(l)
+            assert len(batches) == len(l) and all(len(b) == bs for b in batches)
+            seen.append([i for b in batches for i in b])
+        flat = [i for s in seen for i in s]
+        assert len(set(flat)) >= len(flat) - (world * ((n + world - 1) // world) - n)      # disjoint except the wrap padding
+        if epoch == 0:
+            first = seen
+    assert first != seen                                                                   # reshuffled per epoch
+    again = [_BatchLoader(DS(n), batch_size=bs, shuffle=True, drop_last=True, rank=r, world=world) for r in range(world)]
+    assert [[i for b in l for i in b] for l in again] == first                             # deterministic per (seed, epoch)
+    tail = _BatchLoader(DS(10), batch_size=4, shuffle=False, drop_last=False)
+    assert [b for b in tail] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9]] and len(tail) == 3
