@@ -54,7 +54,39 @@ __global__ __launch_bounds__(256) void dense_f32_kernel(DenseArgs p) {
     const bool aok = am < p.M, bok = bn < p.N;
     const float* arow = p.a + (size_t)(aok ? am : 0) * p.lda;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int kk = kbeg; kk < kend; kk += 16) {
+    // Aligned operands: four 16-wide k-steps of loads in flight before their MFMAs.  The loads are unconditional (addresses
+    // clamped into range, values zeroed by a select): one dependent load -> MFMA round trip per k-step made the M = batch-size
+    // layers of the heads pure latency chains (48 round trips for K = 3072).  Same MFMA order as the plain loop: same bits.
+    const bool fast = p.vec_ok && (p.K & 3) == 0 && (p.w_is_kn || p.wvec_ok);
+    int kk0 = kbeg;
+    if (fast) {
+        const float* wrow = p.w + (p.w_is_kn ? (size_t)(bok ? bn : 0) : (size_t)(bok ? bn : 0) * p.K);
+        for (; kk0 < kend; kk0 += 64) {
+            float av[4][4], bv[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = kk0 + 16 * u + 4 * g;
+                const bool in = k < kend;
+                const int kc = in ? k : 0;
+                const float4 ta = *reinterpret_cast<const float4*>(arow + kc);
+                float4 tb;
+                if (p.w_is_kn) {
+                    tb.x = wrow[(size_t)kc * p.N]; tb.y = wrow[(size_t)(kc + 1) * p.N];
+                    tb.z = wrow[(size_t)(kc + 2) * p.N]; tb.w = wrow[(size_t)(kc + 3) * p.N];
+                } else {
+                    tb = *reinterpret_cast<const float4*>(wrow + kc);
+                }
+                const bool ia = in && aok, ib = in && bok;
+                av[u][0] = ia ? ta.x : 0.f; av[u][1] = ia ? ta.y : 0.f; av[u][2] = ia ? ta.z : 0.f; av[u][3] = ia ? ta.w : 0.f;
+                bv[u][0] = ib ? tb.x : 0.f; bv[u][1] = ib ? tb.y : 0.f; bv[u][2] = ib ? tb.z : 0.f; bv[u][3] = ib ? tb.w : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][e], bv[u][e], acc, 0, 0, 0);
+        }
+    }
+    for (int kk = kk0; kk < kend; kk += 16) {
         const int k = kk + 4 * g;
         float av[4] = {0.f, 0.f, 0.f, 0.f}, bv[4] = {0.f, 0.f, 0.f, 0.f};
         if (aok) {
