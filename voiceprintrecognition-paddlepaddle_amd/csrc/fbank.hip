@@ -255,11 +255,27 @@ __global__ __launch_bounds__(256) void fbank_cmn_kernel(CmnArgs a) {
     __syncthreads();
     int valid = a.T;
     if (a.lens_ratio) valid = (int)(a.lens_ratio[b] * (float)a.T);      // astype(int32): truncation
-    const int per_blk = (a.T * a.n_mels + gridDim.x - 1) / gridDim.x;
+    const int per_blk = (((a.T * a.n_mels + gridDim.x - 1) / gridDim.x) + 3) & ~3;
     const int e0 = blockIdx.x * per_blk;
     const int e1 = min(e0 + per_blk, a.T * a.n_mels);
     float* o = a.out + (size_t)b * a.T * a.n_mels;
     bf16_t* ob = a.out_bf16 ? a.out_bf16 + (size_t)b * a.T * a.n_mels : nullptr;
+    if ((a.n_mels & 3) == 0) {               // 16-byte accesses: 4 consecutive mel bins of one frame
+        for (int e = e0 + 4 * tid; e < e1; e += 1024) {
+            const int t = e / a.n_mels;
+            const int m = e - t * a.n_mels;
+            float4 v = *reinterpret_cast<const float4*>(o + e);
+            const bool keep = t < valid;
+            v.x = keep ? v.x - s_mean[m] : 0.f; v.y = keep ? v.y - s_mean[m + 1] : 0.f;
+            v.z = keep ? v.z - s_mean[m + 2] : 0.f; v.w = keep ? v.w - s_mean[m + 3] : 0.f;
+            *reinterpret_cast<float4*>(o + e) = v;
+            if (ob) {
+                bf16_t q[4] = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
+                *reinterpret_cast<uint2*>(ob + e) = *reinterpret_cast<const uint2*>(q);
+            }
+        }
+        return;
+    }
     for (int e = e0 + tid; e < e1; e += 256) {
         const int t = e / a.n_mels;
         const int m = e - t * a.n_mels;
