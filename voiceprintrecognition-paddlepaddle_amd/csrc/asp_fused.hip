@@ -13,6 +13,7 @@
 namespace {
 
 constexpr int AF_ATT = 128;
+constexpr float AF_LOG2E = 1.4426950408889634f;
 
 struct AspFusedArgs {
     const bf16_t* h;        // (B*T, att)
@@ -27,8 +28,8 @@ struct AspFusedArgs {
 __device__ __forceinline__ void merge_state(float& m, float& s0, float& s1, float& s2, int off) {
     const float m2 = __shfl_xor(m, off), a0 = __shfl_xor(s0, off), a1 = __shfl_xor(s1, off), a2 = __shfl_xor(s2, off);
     const float M = fmaxf(m, m2);
-    const float f1 = (m == -INFINITY) ? 0.f : expf(m - M);
-    const float f2 = (m2 == -INFINITY) ? 0.f : expf(m2 - M);
+    const float f1 = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - M);       // maxima are kept in the log2 domain
+    const float f2 = (m2 == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m2 - M);
     s0 = s0 * f1 + a0 * f2; s1 = s1 * f1 + a1 * f2; s2 = s2 * f1 + a2 * f2; m = M;
 }
 
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256) void asp_fused_kernel(AspFusedArgs a) {
 
     // B operand: weight rows (channels) c0 + ni*16 + li, k chunk ks*4 + g
     bf16x8 wf[2][4];
-    float bias[2], mu0[2];
+    float biasl[2], mu0[2];
     int ch[2];
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void asp_fused_kernel(AspFusedArgs a) {
         const bf16_t* wr = a.w + (size_t)ch[ni] * AF_ATT;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) wf[ni][ks] = *reinterpret_cast<const bf16x8*>(wr + (ks * 4 + g) * 8);
-        bias[ni] = a.bias[ch[ni]];
+        biasl[ni] = a.bias[ch[ni]] * AF_LOG2E;
         mu0[ni] = a.center ? a.center[(size_t)b * a.ldc + ch[ni]] : 0.f;
     }
     float mx[2] = {-INFINITY, -INFINITY}, s0[2] = {0.f, 0.f}, s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
@@ -87,29 +88,29 @@ __global__ __launch_bounds__(256) void asp_fused_kernel(AspFusedArgs a) {
             for (int ni = 0; ni < 2; ++ni)
                 acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf, wf[ni][ks], acc[ni], 0, 0, 0);
         }
-        // acc[ni][r] = logit(frame t0 + r, channel ch[ni]) - bias
+        // acc[ni][r] = logit(frame t0 + r, channel ch[ni]) - bias.  The softmax runs in the log2 domain (logits pre-multiplied by
+        // log2 e, v_exp_f32 directly) and without branches: the kernel is VALU-bound (~4 cycles per instruction, 4 waves per
+        // SIMD), and expf's range reduction plus the divergent "new maximum" paths were half of its ~320 instructions per tile.
+        const int tlim = a.T - t0;                                   // frames r < tlim exist
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             float e[4];
-            float m4 = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) e[r] = (r < tlim) ? fmaf(acc[ni][r], AF_LOG2E, biasl[ni]) : -INFINITY;
+            const float m4 = fmaxf(fmaxf(e[0], e[1]), fmaxf(e[2], e[3]));
+            const float mnew = fmaxf(fmaxf(mx[ni], m4), -1e30f);       // finite even when every frame so far is masked
+            const float f = __builtin_amdgcn_exp2f(mx[ni] - mnew);      // exp2(-inf) = 0 on the first tile
+            mx[ni] = mnew;
+            float p0 = 0.f, p1 = 0.f, p2 = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                e[r] = (t0 + r < a.T) ? acc[ni][r] + bias[ni] : -INFINITY;
-                m4 = fmaxf(m4, e[r]);
+                const float pr = __builtin_amdgcn_exp2f(e[r] - mnew);    // 0 for frames past T
+                const bf16_t xb = *reinterpret_cast<const bf16_t*>(xs[buf] + (g * 4 + r) * AF_XROW + (wv * 32 + ni * 16 + li) * 2);
+                const float xv = (float)xb - mu0[ni];
+                const float t = pr * xv;
+                p0 += pr; p1 += t; p2 = fmaf(t, xv, p2);
             }
-            if (m4 > mx[ni]) {
-                const float f = (mx[ni] == -INFINITY) ? 0.f : expf(mx[ni] - m4);
-                s0[ni] *= f; s1[ni] *= f; s2[ni] *= f; mx[ni] = m4;
-            }
-            if (mx[ni] != -INFINITY) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = expf(e[r] - mx[ni]);              // exp(-inf) = 0 for frames past T
-                    const bf16_t xb = *reinterpret_cast<const bf16_t*>(xs[buf] + (g * 4 + r) * AF_XROW + (wv * 32 + ni * 16 + li) * 2);
-                    const float xv = (float)xb - mu0[ni];
-                    s0[ni] += p; s1[ni] += p * xv; s2[ni] += p * xv * xv;
-                }
-            }
+            s0[ni] = fmaf(s0[ni], f, p0); s1[ni] = fmaf(s1[ni], f, p1); s2[ni] = fmaf(s2[ni], f, p2);
         }
     };
     uint4 hv, xv;
