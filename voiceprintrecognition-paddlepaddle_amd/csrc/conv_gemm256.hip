@@ -12,6 +12,8 @@
 // Epilogue semantics are those of conv_gemm_impl.h (same ConvArgs, same psum layout per 128 rows).
 #include "conv_gemm_impl.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int T2 = 256;                      // tile edge (positions and channels)
@@ -429,28 +431,38 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(const ConvArgs a) {
             const size_t dstep2 = (size_t)8 * a.ldy2;
             const bool sums = a.psum != nullptr;
             char* cell = slab + q8 * OROW + c8 * 4;
+            // two instances of the row loop: without a second activation (conv -> ReLU -> BN, the TDNN block) the clamp pair is
+            // dead work -- 16 of ~44 VALU instructions per 8 values in a loop that is VALU-bound
+            auto rows = [&](auto clamp2) {
 #pragma unroll 2
-            for (int j = 0; j < 8; ++j) {
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(cell);
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(cell + 16);
-                float v[8];
+                for (int j = 0; j < 8; ++j) {
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(cell);
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(cell + 16);
+                    float v[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = fminf(fmaxf(fmaxf(a0[e] + bs[e], lo1) * sc[e] + sh[e], lo2), hi2);
-                    v[e + 4] = fminf(fmaxf(fmaxf(a1[e] + bs[e + 4], lo1) * sc[e + 4] + sh[e + 4], lo2), hi2);
-                }
-                bf16x8 o;
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = fmaxf(a0[e] + bs[e], lo1) * sc[e] + sh[e];
+                        v[e + 4] = fmaxf(a1[e] + bs[e + 4], lo1) * sc[e + 4] + sh[e + 4];
+                        if constexpr (decltype(clamp2)::value) {
+                            v[e] = fminf(fmaxf(v[e], lo2), hi2);
+                            v[e + 4] = fminf(fmaxf(v[e + 4], lo2), hi2);
+                        }
+                    }
+                    bf16x8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-                *reinterpret_cast<bf16x8*>(dst) = o;
-                dst += dstep;
-                if (split) { *reinterpret_cast<bf16x8*>(dst2) = o; dst2 += dstep2; }
-                if (sums) {
-                    *reinterpret_cast<f32x4*>(cell) = f32x4{v[0] - sh[0], v[1] - sh[1], v[2] - sh[2], v[3] - sh[3]};
-                    *reinterpret_cast<f32x4*>(cell + 16) = f32x4{v[4] - sh[4], v[5] - sh[5], v[6] - sh[6], v[7] - sh[7]};
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+                    *reinterpret_cast<bf16x8*>(dst) = o;
+                    dst += dstep;
+                    if (split) { *reinterpret_cast<bf16x8*>(dst2) = o; dst2 += dstep2; }
+                    if (sums) {
+                        *reinterpret_cast<f32x4*>(cell) = f32x4{v[0] - sh[0], v[1] - sh[1], v[2] - sh[2], v[3] - sh[3]};
+                        *reinterpret_cast<f32x4*>(cell + 16) = f32x4{v[4] - sh[4], v[5] - sh[5], v[6] - sh[6], v[7] - sh[7]};
+                    }
+                    cell += 8 * OROW;
                 }
-                cell += 8 * OROW;
-            }
+            };
+            if (a.act2 == VP_ACT_NONE) rows(std::false_type{});
+            else rows(std::true_type{});
         } else {
         int m = mw + q4;
         int b = (m < a.M ? m : a.M - 1) / a.T_out;
