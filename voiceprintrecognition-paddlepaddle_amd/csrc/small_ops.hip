@@ -3,6 +3,8 @@
 // All HBM/L2-bound or tiny; kept in f32 so that they add no error on top of the f32 reference.
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 // ---------------------------------------------------------------- moments from conv partial sums
@@ -43,8 +45,12 @@ struct DenseArgs {
     int lda, ldo, M, N, K, w_is_kn, act, kper, vec_ok, wvec_ok;
 };
 
-__global__ __launch_bounds__(256) void dense_f32_kernel(DenseArgs p) {
-    __shared__ float red[4][16][17];
+// K is split over the workgroup's waves (4, or 16 when K >= 1024: the M = batch-size layers of the heads are chains of
+// dependent load -> MFMA round trips on a handful of workgroups, so the chain is cut 16 ways); partial tiles are summed in
+// wave order.
+__global__ __launch_bounds__(1024) void dense_f32_kernel(DenseArgs p) {
+    __shared__ float red[16][16][17];
+    const int nw = blockDim.x >> 6;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
@@ -61,30 +67,38 @@ __global__ __launch_bounds__(256) void dense_f32_kernel(DenseArgs p) {
     int kk0 = kbeg;
     if (fast) {
         const float* wrow = p.w + (p.w_is_kn ? (size_t)(bok ? bn : 0) : (size_t)(bok ? bn : 0) * p.K);
-        for (; kk0 < kend; kk0 += 64) {
-            float av[4][4], bv[4][4];
+        // one loop instance per weight layout: a layout branch inside the loop made hipcc sink the last k-step's loads behind
+        // the MFMAs (load -> vmcnt(0) -> MFMA, four times over)
+        auto run = [&](auto kn) {
+            for (; kk0 < kend; kk0 += 64) {
+                float4 ta[4], tb[4];
+                bool in[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = kk0 + 16 * u + 4 * g;
-                const bool in = k < kend;
-                const int kc = in ? k : 0;
-                const float4 ta = *reinterpret_cast<const float4*>(arow + kc);
-                float4 tb;
-                if (p.w_is_kn) {
-                    tb.x = wrow[(size_t)kc * p.N]; tb.y = wrow[(size_t)(kc + 1) * p.N];
-                    tb.z = wrow[(size_t)(kc + 2) * p.N]; tb.w = wrow[(size_t)(kc + 3) * p.N];
-                } else {
-                    tb = *reinterpret_cast<const float4*>(wrow + kc);
+                for (int u = 0; u < 4; ++u) {
+                    const int k = kk0 + 16 * u + 4 * g;
+                    in[u] = k < kend;
+                    const int kc = in[u] ? k : 0;
+                    ta[u] = *reinterpret_cast<const float4*>(arow + kc);
+                    if constexpr (decltype(kn)::value) {
+                        tb[u].x = wrow[(size_t)kc * p.N]; tb[u].y = wrow[(size_t)(kc + 1) * p.N];
+                        tb[u].z = wrow[(size_t)(kc + 2) * p.N]; tb[u].w = wrow[(size_t)(kc + 3) * p.N];
+                    } else {
+                        tb[u] = *reinterpret_cast<const float4*>(wrow + kc);
+                    }
                 }
-                const bool ia = in && aok, ib = in && bok;
-                av[u][0] = ia ? ta.x : 0.f; av[u][1] = ia ? ta.y : 0.f; av[u][2] = ia ? ta.z : 0.f; av[u][3] = ia ? ta.w : 0.f;
-                bv[u][0] = ib ? tb.x : 0.f; bv[u][1] = ib ? tb.y : 0.f; bv[u][2] = ib ? tb.z : 0.f; bv[u][3] = ib ? tb.w : 0.f;
+                __builtin_amdgcn_sched_barrier(0);             // all four k-steps' loads issue before the first MFMA
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool ia = in[u] && aok, ib = in[u] && bok;
+                    const float av[4] = {ia ? ta[u].x : 0.f, ia ? ta[u].y : 0.f, ia ? ta[u].z : 0.f, ia ? ta[u].w : 0.f};
+                    const float bv[4] = {ib ? tb[u].x : 0.f, ib ? tb[u].y : 0.f, ib ? tb[u].z : 0.f, ib ? tb[u].w : 0.f};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], acc, 0, 0, 0);
+                }
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][e], bv[u][e], acc, 0, 0, 0);
-        }
+        };
+        if (p.w_is_kn) run(std::true_type{});
+        else run(std::false_type{});
     }
     for (int kk = kk0; kk < kend; kk += 16) {
         const int k = kk + 4 * g;
@@ -121,10 +135,11 @@ __global__ __launch_bounds__(256) void dense_f32_kernel(DenseArgs p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wv][4 * g + r][li] = acc[r];
     __syncthreads();
-    const int mm = tid >> 4, nn = tid & 15;
+    const int mm = (tid >> 4) & 15, nn = tid & 15;
     const int m = m0 + mm, n = n0 + nn;
-    if (m < p.M && n < p.N) {
-        float v = red[0][mm][nn] + red[1][mm][nn] + red[2][mm][nn] + red[3][mm][nn];
+    if (tid < 256 && m < p.M && n < p.N) {
+        float v = red[0][mm][nn];
+        for (int w = 1; w < nw; ++w) v += red[w][mm][nn];
         if (p.rowscale) v *= p.rowscale[m];
         if (p.colscale) v *= p.colscale[n];
         if (p.bias) v += p.bias[n];
@@ -470,12 +485,13 @@ int vp_dense_f32_ex(vp_ctx* ctx, const float* a, int lda, const float* w, int w_
     DenseArgs p;
     p.a = a; p.w = w; p.bias = bias; p.rowscale = rowscale; p.colscale = colscale; p.out = out;
     p.lda = lda; p.ldo = ldo; p.M = M; p.N = N; p.K = K; p.w_is_kn = w_is_kn; p.act = act;
-    p.kper = ((K + 3) / 4 + 15) / 16 * 16;
+    const int nw = K >= 1024 ? 16 : 4;
+    p.kper = ((K + nw - 1) / nw + 15) / 16 * 16;
     p.vec_ok = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
     p.wvec_ok = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
     dim3 grid((N + 15) / 16, (M + 15) / 16);
     if (grid.y > 65535) VP_FAIL(ctx, VP_EINVAL, "dense: M too large");
-    hipLaunchKernelGGL(dense_f32_kernel, grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL(dense_f32_kernel, grid, dim3(64 * nw), 0, st, p);
     VP_LAUNCH_CHECK(ctx, "dense_f32");
     return VP_OK;
 }
