@@ -403,9 +403,9 @@ constexpr int SE_UPW = 1;             // utterances per workgroup: every workgro
 // out[u][n] = act(bias[n] + sum_k in[u][k] W[k][n]) for SE_UPW utterances; `in` (stride ldi), `out` (stride ldo), `part` in LDS
 __device__ __forceinline__ void se_matvec(const float* in, int ldi, int K, const float* W, int N, const float* bias, int sigmoid,
                                           float* out, int ldo, float* part) {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nt = blockDim.x;
     const int nv = N >> 2;                            // float4 column groups (N % 4 == 0, N <= 1024: host-checked)
-    const int ns = 256 / nv;                          // K slices worked on in parallel
+    const int ns = nt / nv;                           // K slices worked on in parallel (1024 threads: 32 / 8 slices at 128 / 512 outputs)
     const int v = tid % nv, sl = tid / nv;
     if (sl < ns) {
         const int k0 = (int)((long long)K * sl / ns), k1 = (int)((long long)K * (sl + 1) / ns);
@@ -426,7 +426,7 @@ __device__ __forceinline__ void se_matvec(const float* in, int ldi, int K, const
         for (int u = 0; u < SE_UPW; ++u) *reinterpret_cast<float4*>(part + (u * ns + sl) * N + 4 * v) = acc[u];
     }
     __syncthreads();
-    for (int i = tid; i < SE_UPW * N; i += 256) {
+    for (int i = tid; i < SE_UPW * N; i += nt) {
         const int u = i / N, n = i - u * N;
         float acc = bias ? bias[n] : 0.f;
         for (int q = 0; q < ns; ++q) acc += part[(u * ns + q) * N + n];
@@ -434,14 +434,16 @@ __device__ __forceinline__ void se_matvec(const float* in, int ldi, int K, const
     }
 }
 
-__global__ __launch_bounds__(256) void se_gate_kernel(SeGateArgs a) {
-    extern __shared__ float sm[];        // mean[UPW][C] | h[UPW][H] | s[UPW][C] | part[UPW][<= 1024]
+// 1024 threads: the two matvecs are chains of dependent 16-byte weight loads (64 per thread at 256 threads); four times the
+// threads cut the chains to 16.
+__global__ __launch_bounds__(1024) void se_gate_kernel(SeGateArgs a) {
+    extern __shared__ float sm[];        // mean[UPW][C] | h[UPW][H] | s[UPW][C] | part[UPW][4 * blockDim.x]
     float* mean = sm;
     float* h = mean + SE_UPW * a.C;
     float* sg = h + SE_UPW * a.H;
     float* part = sg + SE_UPW * a.C;
     const int b0 = blockIdx.x * SE_UPW;
-    for (int i = threadIdx.x; i < SE_UPW * a.C; i += 256) {
+    for (int i = threadIdx.x; i < SE_UPW * a.C; i += blockDim.x) {
         const int u = i / a.C, c = i - u * a.C;
         const int b = min(b0 + u, a.B - 1);
         const int t0 = (int)(((long long)b * a.T) / VP_CONV_BM);
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(256) void se_gate_kernel(SeGateArgs a) {
     __syncthreads();
     se_matvec(h, a.H, a.H, a.w2, a.C, a.b2, 1, sg, a.C, part);
     __syncthreads();
-    for (int i = threadIdx.x; i < SE_UPW * a.C; i += 256) {
+    for (int i = threadIdx.x; i < SE_UPW * a.C; i += blockDim.x) {
         const int u = i / a.C;
         if (b0 + u < a.B) a.out[(size_t)(b0 + u) * a.C + (i - u * a.C)] = sg[i];
     }
@@ -470,10 +472,11 @@ int vp_se_gate(vp_ctx* ctx, const float* psum, const float* shift, int B, int T,
                const float* w2, const float* b2, float* out, hipStream_t st) {
     if (!psum || !w1 || !w2 || !out || B <= 0 || T <= 0 || C <= 0 || H <= 0) VP_FAIL(ctx, VP_EINVAL, "se_gate: bad arguments");
     if ((C | H) & 3 || C > 1024 || H > 1024) VP_FAIL(ctx, VP_EUNSUP, "se_gate: C %d / H %d (multiples of 4, <= 1024)", C, H);
-    const size_t smem = (size_t)SE_UPW * (2 * C + H + 1024) * sizeof(float);
+    constexpr int SE_THREADS = 1024;
+    const size_t smem = (size_t)SE_UPW * (2 * C + H + 4 * SE_THREADS) * sizeof(float);
     if (smem > 64 * 1024) VP_FAIL(ctx, VP_EUNSUP, "se_gate: %d channels do not fit the LDS budget", C);
     SeGateArgs a{psum, shift, w1, b1, w2, b2, out, B, T, C, H, vp_conv1d_nseg(T)};
-    hipLaunchKernelGGL(se_gate_kernel, dim3((B + SE_UPW - 1) / SE_UPW), dim3(256), smem, st, a);
+    hipLaunchKernelGGL(se_gate_kernel, dim3((B + SE_UPW - 1) / SE_UPW), dim3(SE_THREADS), smem, st, a);
     VP_LAUNCH_CHECK(ctx, "se_gate");
     return VP_OK;
 }
