@@ -129,3 +129,22 @@ int vp_row_inv_norm(vp_ctx* ctx, const float* x, int rows, int D, int ld, float 
 // kernels' host launchers (defined in the .hip files)
 int vp_fbank_release_tables(vp_ctx* ctx);
 int vp_mel_release_tables(vp_ctx* ctx);
+
+// tanh for an epilogue whose result is stored as TO: bf16 outputs (8 mantissa bits) take 1 - 2 / (2^(2 x log2 e) + 1) on the
+// hardware exp2 / rcp (5 instructions, |error| ~1e-7); f32 outputs keep tanhf (~40 instructions: the parity instrument).
+template <typename TO>
+__device__ __forceinline__ float vp_tanh_for(float x) {
+    if constexpr (sizeof(TO) == 2) {
+        const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+        return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+    } else {
+        return tanhf(x);
+    }
+}
+
+// x * sigmoid(x) likewise: hardware exp2 / rcp for bf16 outputs, the exact division for f32 outputs
+template <typename TO>
+__device__ __forceinline__ float vp_silu_for(float x) {
+    if constexpr (sizeof(TO) == 2) return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+    else return x / (1.f + __expf(-x));
+}

@@ -481,10 +481,10 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(const ConvArgs a) {
                 float x = av[r] + bias4[r] + rbias[r];
                 if (a.act == VP_ACT_RELU) x = fmaxf(x, 0.f);
                 x = x * sc4[r] + sh4[r] + rs[r];
-                if (a.act2 == VP_ACT_TANH) x = tanhf(x);
+                if (a.act2 == VP_ACT_TANH) x = vp_tanh_for<bf16_t>(x);
                 else if (a.act2 == VP_ACT_RELU) x = fmaxf(x, 0.f);
                 else if (a.act2 == VP_ACT_HARDTANH20) x = fminf(fmaxf(x, 0.f), 20.f);
-                else if (a.act2 == VP_ACT_SILU) x = x / (1.f + __expf(-x));
+                else if (a.act2 == VP_ACT_SILU) x = vp_silu_for<bf16_t>(x);
                 v[r] = x;
             }
             if (ok) {

@@ -357,10 +357,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
                 float t = acc[mi][ni][r] + bias4[r] + rbias[r];
                 if (a.act == VP_ACT_RELU) t = fmaxf(t, 0.f);
                 t = (t * sc4[r] + sh4[r]) * gt[r] + rs[r];
-                if (a.act2 == VP_ACT_TANH) t = tanhf(t);
+                if (a.act2 == VP_ACT_TANH) t = vp_tanh_for<TO>(t);
                 else if (a.act2 == VP_ACT_RELU) t = fmaxf(t, 0.f);
                 else if (a.act2 == VP_ACT_HARDTANH20) t = fminf(fmaxf(t, 0.f), 20.f);
-                else if (a.act2 == VP_ACT_SILU) t = t / (1.f + __expf(-t));
+                else if (a.act2 == VP_ACT_SILU) t = vp_silu_for<TO>(t);
                 v[r] = t;
             }
             store4(reinterpret_cast<TO*>(slab + (mi * 16 + li) * SLAB_ROW) + ni * 16 + g * 4, v);
