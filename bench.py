@@ -121,9 +121,38 @@ def roofline_pass(reps):
             'launches': per_shape}
 
 
-def cpu_baseline(target_s=15.0):
+def synth_waves(batch, n_samples, seed):
+    """SURVEY.md section 8(d) synthetic input: Gaussian noise scaled per utterance to -20 dBFS RMS (sigma = 0.1), clipped."""
+    rng = np.random.RandomState(seed)
+    x = rng.standard_normal((batch, n_samples)).astype(np.float32)
+    rms = np.sqrt((x.astype(np.float64) ** 2).mean(axis=1, keepdims=True))
+    return np.clip((x * (0.1 / rms)).astype(np.float32), -1.0, 1.0)
+
+
+def random_state(module, seed):
+    """Random-init weights of the named architecture (no checkpoints exist offline): fan-in scaled normal weights, small
+    biases, BatchNorm affine around (1, 0) and RANDOMISED running statistics so eval-mode BN is not an identity."""
+    rng = np.random.RandomState(seed)
+    out = {}
+    for k, v in module.state_dict().items():
+        shp = tuple(v.shape)
+        if k.endswith('_variance'):
+            a = rng.uniform(0.5, 1.5, shp)
+        elif k.endswith('_mean'):
+            a = 0.1 * rng.standard_normal(shp)
+        elif 'norm' in k.split('.')[-2:][0] or '.bn' in k or k.startswith('bn'):
+            a = (1.0 if k.endswith('weight') else 0.0) + 0.1 * rng.standard_normal(shp)
+        elif v.dim() >= 2:
+            a = rng.standard_normal(shp) / np.sqrt(max(1, int(np.prod(shp[1:]))))
+        else:
+            a = 0.1 * rng.standard_normal(shp)
+        out[k] = torch.as_tensor(np.asarray(a), dtype=torch.float32)
+    return out
+
+
+def cpu_baseline(state, W, target_s=15.0):
     """CPU oracle on the host cores: Fbank+CMN (NumPy f32) -> ECAPA-TDNN (PyTorch-CPU f32, eval) ->
-    cosine head + AAMLoss, same synthetic inputs, bounded sample."""
+    cosine head + AAMLoss, same synthetic inputs and weights, bounded sample.  The ONLY place this file touches oracle/."""
     from oracle import fbank as ofb
     from oracle import models as om
     try:
@@ -132,11 +161,11 @@ def cpu_baseline(target_s=15.0):
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 32))           # oneDNN/OpenMP oversubscribe badly beyond this on big hosts
     torch.set_num_threads(cores)
-    p = om.ecapa_params(N_MELS, seed=1000)
-    W = om.head_params(EMBD, N_CLASSES, seed=1001)
+    p = {k: v.detach().cpu().float() for k, v in state.items()}
+    W = W.detach().cpu().float()
 
     def run(n):
-        w = ofb.synth_waves(n, N_SAMPLES, seed=1000)
+        w = synth_waves(n, N_SAMPLES, seed=1000)
         labels = torch.arange(n) % N_CLASSES
         t0 = time.perf_counter()
         feats = ofb.featurize(w, method_args=dict(sr=16000, n_mels=N_MELS))
@@ -210,8 +239,6 @@ def main():
         dist.init_process_group(backend='nccl')          # RCCL
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE {world}'
 
-    from oracle import fbank as ofb
-    from oracle import models as om
     from ppvector.data_utils.featurizer import AudioFeaturizer
     from ppvector.loss.aamloss import AAMLoss
     from ppvector.models.ecapa_tdnn import EcapaTdnn
@@ -219,14 +246,16 @@ def main():
 
     dev = torch.device('cuda', local_rank)
     # synthetic inputs, resident in HBM before the timed region (seed per rank: distinct shards)
-    wav = torch.from_numpy(ofb.synth_waves(BATCH, N_SAMPLES, seed=shard_seed(1000, rank))).to(dev)
+    wav = torch.from_numpy(synth_waves(BATCH, N_SAMPLES, seed=shard_seed(1000, rank))).to(dev)
     labels = (torch.arange(BATCH, device=dev) * 7 + rank) % N_CLASSES
     fz = AudioFeaturizer('Fbank', dict(sr=16000, n_mels=N_MELS))
     model = EcapaTdnn(N_MELS, embd_dim=EMBD, pooling_type='ASP', channels=[512, 512, 512, 512, 1536])
-    model.load_state_dict(om.ecapa_params(N_MELS, seed=1000))      # random init, BN stats randomised
+    state = random_state(model, seed=1000)                          # random init, BN running stats randomised
+    model.load_state_dict(state)
     model = model.to(dev).eval()
     head = SpeakerIdentification(EMBD, N_CLASSES)
-    head.load_state_dict({'weight': om.head_params(EMBD, N_CLASSES, seed=1001)})
+    head_w = random_state(head, seed=1001)['weight']
+    head.load_state_dict({'weight': head_w})
     head = head.to(dev).eval()            # eval-mode forward: logits without the autograd tape
     crit = AAMLoss(margin=0.2, scale=32, easy_margin=False, label_smoothing=0.0)
     eng = model.engine(args.dtype)
@@ -259,7 +288,7 @@ def main():
         if world == 1 and not args.no_roofline and want16:
             out['roofline'] = roofline_pass(reps=10)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
+            out['cpu_baseline'] = cpu_baseline(state, head_w)
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()
