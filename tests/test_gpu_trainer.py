@@ -88,6 +88,23 @@ def test_trainer_end_to_end(golden_dir, tmp_path):
     tr2.train(save_model_path=save, do_eval=False)
     assert tr2.train_step == 16 and tr2.optimizer.t == 16 and tr2.scheduler.i == 16
     assert sorted(os.listdir(fam)) == ['best_model', 'epoch_2', 'epoch_3', 'epoch_4', 'last_model']
+    # extract_features (trainer.py:134-160) dumps per-utterance features + '<list>_features.txt'; a trainer on those lists takes
+    # the .npy route (reader.py:78-83: crop to the max_duration frame count) through collate_fn's zero padding
+    tr2.extract_features(save_dir=f'{root}/features', max_duration=100)
+    lines = open(f'{root}/train_list_features.txt').read().strip().split('\n')
+    assert len(lines) == 16 and all(l.split('\t')[0].endswith('.npy') for l in lines)
+    f0 = np.load(lines[0].split('\t')[0])
+    x0 = pcm[0, 0:48000].astype(np.float32) / 32768.0
+    x0 = x0 * 10.0 ** ((-20.0 - 10.0 * np.log10(np.mean(x0.astype(np.float64) ** 2))) / 20.0)
+    ref0 = ofb.featurize(x0[None].astype(np.float32), feature_method='Fbank', method_args=dict(sr=16000, n_mels=80))[0]
+    assert f0.shape == ref0.shape == (298, 80) and np.max(np.abs(f0 - ref0)) < 5e-3
+    cfg_f = _configs(root, 1)
+    for k in ('train', 'enroll', 'trials'):
+        cfg_f['dataset_conf'][f'{k}_list'] = f'{root}/{k}_list_features.txt'
+    tr3 = PPVectorTrainer(cfg_f, use_gpu=True, data_augment_configs=aug)
+    tr3.train(save_model_path=f'{root}/models_f', do_eval=True)
+    assert tr3.train_step == 4 and np.isfinite(tr3.train_loss) and 0.0 <= tr3.eval_eer <= 1.0
+    assert tr3.train_dataset.max_feature_len == 198                          # frames of a 2 s crop
     # cooperative stop flags (trainer.py:81, :424)
     tr2.stop_eval = True
     assert tr2.evaluate() == (-1, -1, -1)
