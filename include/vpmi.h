@@ -312,6 +312,12 @@ int vp_pad_batch(vp_ctx* ctx, int dtype, const void* const* srcs, const int32_t*
                  vp_stream stream);
 int vp_wave_batch_f32(vp_ctx* ctx, const float* const* srcs, const int32_t* lens, const int32_t* starts, int B, int L,
                       int normalize, float target_db, const float* gain_db, float* out, int32_t* n_valid, vp_stream stream);
+/* Speed perturbation (SpeedPerturbAugmentor -> AudioSegment.change_speed, call site data_utils/reader.py:155-156;
+ * configs/augmentation.yml:1-6; yeaudio is third party: resampling by linear interpolation, dst[b][i] = interp of srcs[b] at
+ * i * lens[b] / (new_lens[b] - 1), the tail clamped to the last sample; the host draws the rate from {1.0, 0.9, 1.1} and passes
+ * new_lens[b] = int(lens[b] / rate)).  srcs / dsts: DEVICE arrays of B device pointers. */
+int vp_speed_perturb_f32(vp_ctx* ctx, const float* const* srcs, const int32_t* lens, const int32_t* new_lens,
+                         float* const* dsts, int B, int max_new_len, vp_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * ResNetSE backbone forward, eval mode -- replaces ResNetSE.forward (models/resnet_se.py:121-139) with

@@ -85,3 +85,14 @@ def wave_batch(waves, L=None, starts=None, normalize=True, target_db=-20.0, gain
         out[b, :n] = (w[st:st + n] * gain).astype(np.float32)
         nv[b] = n
     return out, nv
+
+
+def change_speed(samples, speed_rate):
+    """yeaudio AudioSegment.change_speed (third party, restated from its published behaviour; call site reader.py:155-156 via
+    SpeedPerturbAugmentor): linear-interpolation resampling to int(len / rate) points spread over [0, len]."""
+    if speed_rate == 1.0:
+        return np.asarray(samples, np.float32)
+    old_length = len(samples)
+    new_length = int(old_length / speed_rate)
+    new_indices = np.linspace(start=0, stop=old_length, num=new_length)
+    return np.interp(new_indices, np.arange(old_length), samples).astype(np.float32)

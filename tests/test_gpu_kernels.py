@@ -707,6 +707,23 @@ def test_assemble_waves_normalises_crops_and_pads(N):
         assemble_waves([torch.zeros(10)])
 
 
+def test_speed_perturb_matches_linear_interpolation_restatement(N):
+    """SpeedPerturbAugmentor -> AudioSegment.change_speed (reader.py:155-156): np.interp onto int(len / rate) points."""
+    from oracle import augment as oa
+    from ppvector.data_utils.wave_batch import speed_perturb
+    rng = np.random.RandomState(9)
+    waves = [rng.standard_normal(n).astype(np.float32) * 0.1 for n in (48000, 16001, 33333, 9, 70000)]
+    rates = [0.9, 1.0, 1.1, 0.9, 1.1]
+    out = speed_perturb([dev(w) for w in waves], rates)
+    for w, r, o in zip(waves, rates, out):
+        ref = oa.change_speed(w, r)
+        assert o.shape == ref.shape and o.dtype == torch.float32
+        assert np.max(np.abs(o.cpu().numpy() - ref)) < 1e-6
+    assert out[1].data_ptr() != 0 and torch.equal(out[1].cpu(), torch.from_numpy(waves[1]))        # rate 1.0: untouched
+    with pytest.raises(N.VpmiError):
+        speed_perturb([torch.zeros(10)], [0.9])
+
+
 def test_collate_fn_pads_like_reference(N):
     from oracle import augment as oa
     from ppvector.data_utils.collate_fn import collate_fn

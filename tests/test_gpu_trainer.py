@@ -105,6 +105,12 @@ def test_trainer_end_to_end(golden_dir, tmp_path):
     tr3.train(save_model_path=f'{root}/models_f', do_eval=True)
     assert tr3.train_step == 4 and np.isfinite(tr3.train_loss) and 0.0 <= tr3.eval_eer <= 1.0
     assert tr3.train_dataset.max_feature_len == 198                          # frames of a 2 s crop
+    # the reference's default augmentation: speed perturbation on every utterance, here with the 3-class label offset
+    # (trainer.py:171-173: the classifier grows to 3 x num_speakers)
+    aug_s = dict(aug, speed=dict(prob=1.0, speed_perturb_3_class=True))
+    tr4 = PPVectorTrainer(_configs(root, 1), use_gpu=True, data_augment_configs=aug_s)
+    tr4.train(save_model_path=f'{root}/models_s', do_eval=False)
+    assert tr4.model[1].weight.shape == (192, 6) and tr4.train_step == 4 and np.isfinite(tr4.train_loss)
     # cooperative stop flags (trainer.py:81, :424)
     tr2.stop_eval = True
     assert tr2.evaluate() == (-1, -1, -1)

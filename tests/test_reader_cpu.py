@@ -28,7 +28,7 @@ def test_dataset_items_crops_sort_and_npy(tmp_path):
         rows.append(f'{tmp_path}/u{i}.wav\t{i % 3}')
     lst = tmp_path / 'list.txt'
     lst.write_text('\n'.join(rows) + '\n\n')
-    aug = dict_to_object(dict(speed=dict(prob=1.0), volume=dict(prob=1.0, min_gain_dBFS=-15, max_gain_dBFS=15), noise=dict(prob=0.5),
+    aug = dict_to_object(dict(speed=dict(prob=0.0), volume=dict(prob=1.0, min_gain_dBFS=-15, max_gain_dBFS=15), noise=dict(prob=0.5),
                               reverb=dict(prob=0.5), spec_aug=dict(prob=0.5, freq_mask_ratio=0.1, n_freq_masks=1, time_mask_ratio=0.05,
                                                                    n_time_masks=1, max_time_warp=0)))
     ds = PPVectorDataset(str(lst), fz, max_duration=3, min_duration=0.3, mode='train', aug_conf=aug, num_speakers=3)
@@ -43,6 +43,18 @@ def test_dataset_items_crops_sort_and_npy(tmp_path):
     assert short['samples'].shape == (70000,) and short['label'] == 2
     starts = {ds[2]['start'] for _ in range(20)}                    # 70000 samples > max: uniform random crop start
     assert len(starts) > 5 and all(0 <= s <= 70000 - 48000 for s in starts)
+    # speed perturbation: rate drawn from {1.0, 0.9, 1.1}; 3-class mode offsets the label; the crop start lives on the new length
+    aug3 = dict_to_object(dict(speed=dict(prob=1.0, speed_perturb_3_class=True), volume=None, noise=None, reverb=None, spec_aug=None))
+    d3 = PPVectorDataset(str(lst), fz, max_duration=3, min_duration=0.3, mode='train', aug_conf=aug3, num_speakers=3)
+    seen = set()
+    for _ in range(40):
+        it = d3[0]
+        k = {1.0: 0, 0.9: 1, 1.1: 2}[it['speed']]
+        seen.add(k)
+        assert it['label'] == 0 + 3 * k and it['samples'].shape == (48000,)          # samples stay raw: the GPU resamples
+        new_n = 48000 if k == 0 else int(48000 / it['speed'])
+        assert 0 <= it['start'] <= max(0, new_n - 48000)
+    assert seen == {0, 1, 2}
     # eval: sorted by duration, crop starts at 0, no augmentation objects
     ev = PPVectorDataset(str(lst), fz, max_duration=20, min_duration=0.3, mode='eval')
     assert [ev[i]['samples'].shape[0] for i in range(5)] == sorted(lens) and all(ev[i]['start'] == 0 and ev[i]['gain_dB'] == 0.0 for i in range(5))

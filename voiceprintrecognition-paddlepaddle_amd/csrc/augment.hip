@@ -91,6 +91,31 @@ __global__ __launch_bounds__(256) void wave_batch_kernel(WaveArgs a) {
     if (tid == 0 && a.n_valid) a.n_valid[b] = nv;
 }
 
+// Speed perturbation = resampling by linear interpolation onto new_len points spread over [0, len] (yeaudio
+// AudioSegment.change_speed: np.interp(np.linspace(0, len, new_len), arange(len), samples)); positions in f64 as numpy has them,
+// the last points clamp to the final sample.
+struct SpeedArgs { const float* const* src; const int* lens; const int* new_lens; float* const* dst; };
+
+__global__ __launch_bounds__(256) void speed_perturb_kernel(SpeedArgs a) {
+    const int b = blockIdx.y;
+    const int n = a.lens[b], m = a.new_lens[b];
+    const float* s = a.src[b];
+    float* o = a.dst[b];
+    const double step = m > 1 ? (double)n / (double)(m - 1) : 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) {
+        const double p = (double)i * step;
+        int j = (int)p;
+        float v;
+        if (j >= n - 1) {
+            v = s[n - 1];
+        } else {
+            const double y0 = (double)s[j], y1 = (double)s[j + 1];
+            v = (float)((y1 - y0) * (p - (double)j) + y0);
+        }
+        o[i] = v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -139,6 +164,18 @@ int vp_wave_batch_f32(vp_ctx* ctx, const float* const* srcs, const int32_t* lens
     WaveArgs a{srcs, lens, starts, gain_db, out, n_valid, L, normalize, target_db};
     hipLaunchKernelGGL(wave_batch_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
     VP_LAUNCH_CHECK(ctx, "wave_batch");
+    return VP_OK;
+}
+
+int vp_speed_perturb_f32(vp_ctx* ctx, const float* const* srcs, const int32_t* lens, const int32_t* new_lens, float* const* dsts,
+                         int B, int max_new_len, vp_stream stream) {
+    if (!ctx || !srcs || !lens || !new_lens || !dsts || B <= 0 || B > 65535 || max_new_len <= 0)
+        VP_FAIL(ctx, VP_EINVAL, "speed_perturb: bad arguments");
+    unsigned gx = (unsigned)((max_new_len + 1023) / 1024);
+    if (gx > 256) gx = 256;
+    SpeedArgs a{srcs, lens, new_lens, dsts};
+    hipLaunchKernelGGL(speed_perturb_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, a);
+    VP_LAUNCH_CHECK(ctx, "speed_perturb");
     return VP_OK;
 }
 

@@ -184,6 +184,7 @@ _PROTOS = {
     'vp_pad_batch': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'vp_wave_batch_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                   c_void_p]),
+    'vp_speed_perturb_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'vp_resnetse_workspace_bytes': (c_size_t, [C.POINTER(ResnetSeWeights), c_int, c_int]),
     'vp_resnetse_fwd': (c_int, [c_void_p, C.POINTER(ResnetSeWeights), c_void_p, c_int, c_int, c_void_p, c_void_p,
                                 c_size_t, c_void_p]),

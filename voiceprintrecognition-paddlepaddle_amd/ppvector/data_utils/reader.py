@@ -5,18 +5,21 @@ normalisation -> crop -> Fbank -> SpecAugment (reader.py:72-109).  Here the work
 the random numbers (crop start, volume gain); everything from the dB normalisation on runs batched on the MI355X
 (data_utils/wave_batch.py -> AudioFeaturizer -> SpecAugmentor.batch).  __getitem__ therefore returns the RAW utterance:
 
-    audio list entry  -> dict(samples float32 (n,), start int, gain_dB float, label int)
+    audio list entry  -> dict(samples float32 (n,), speed float, start int, gain_dB float, label int)
     '.npy' list entry -> dict(feature float32 (T, F) cropped to max_feature_len (:78-83), label int)
 
 List format, min_duration skipping (:89-91), the eval-mode length sort (:121-139), train-mode random crop (yeaudio
-AudioSegment.crop: a uniform random start, 0 otherwise) follow the reference.  Speed / noise / reverb perturbation
-(yeaudio DSP on CPU) are not built: a configured prob > 0 is reported once and skipped, never silently emulated.
+AudioSegment.crop: a uniform random start, 0 otherwise) follow the reference.  Speed perturbation (SpeedPerturbAugmentor:
+rate drawn from {1.0, 0.9, 1.1}, optional 3-class label offset) is drawn here and applied on the GPU; the crop start is drawn on
+the PERTURBED length, as the reference crops after it augments.  Noise / reverb perturbation (need external audio
+libraries, yeaudio DSP on CPU) are not built: a configured prob > 0 is reported once and skipped, never silently emulated.
 """
 import logging
 import random
 
 import numpy as np
 
+from ppvector.data_utils.wave_batch import SPEEDS
 from ppvector.predict import AudioSegment
 
 _LOG = logging.getLogger('ppvector')
@@ -32,7 +35,7 @@ class PPVectorDataset:
         self._use_dB_normalization, self._target_dB = use_dB_normalization, target_dB
         self.num_speakers = num_speakers
         self.audio_featurizer = audio_featurizer
-        self.volume_conf = self.spec_augment = None
+        self.volume_conf = self.spec_augment = self.speed_conf = None
         self.max_samples = int(self.max_duration * self._target_sample_rate)
         self.max_feature_len = self.get_crop_feature_len()
         with open(self.data_list_path, 'r', encoding='utf-8') as f:
@@ -61,14 +64,19 @@ class PPVectorDataset:
         seg = self._decode(data_path)
         if self.mode in ('train', 'extract_feature') and seg.duration < self.min_duration:
             return self.__getitem__(idx + 1 if idx < len(self.lines) - 1 else 0)
-        gain = 0.0
+        speed, gain = 1.0, 0.0
+        if self.mode == 'train' and self.speed_conf is not None and random.random() < self.speed_conf['prob']:
+            speed_idx = random.randint(0, 2)
+            speed = SPEEDS[speed_idx]
+            if self.speed_conf['speed_perturb_3_class']:
+                spk_id = spk_id + self.num_speakers * speed_idx
         if self.mode == 'train' and self.volume_conf is not None and random.random() < self.volume_conf['prob']:
             gain = random.uniform(self.volume_conf['min_gain_dBFS'], self.volume_conf['max_gain_dBFS'])
         start = 0
-        n = seg.samples.shape[0]
-        if self.mode != 'extract_feature' and n > self.max_samples and self.mode == 'train':
-            start = int(random.uniform(0.0, seg.duration - self.max_duration) * self._target_sample_rate)
-        return dict(samples=seg.samples, start=start, gain_dB=gain, label=spk_id)
+        n = seg.samples.shape[0] if speed == 1.0 else int(seg.samples.shape[0] / speed)      # length after the speed change
+        if self.mode == 'train' and n > self.max_samples:
+            start = int(random.uniform(0.0, n / float(self._target_sample_rate) - self.max_duration) * self._target_sample_rate)
+        return dict(samples=seg.samples, speed=speed, start=start, gain_dB=gain, label=spk_id)
 
     def __len__(self):
         return len(self.lines)
@@ -90,7 +98,10 @@ class PPVectorDataset:
 
     def get_augmentor(self, aug_conf):
         from ppvector.data_utils.spec_aug import SpecAugmentor
-        for name in ('speed', 'noise', 'reverb'):
+        spd = aug_conf.get('speed')
+        if spd is not None and float(spd.get('prob', 0.0)) > 0:
+            self.speed_conf = dict(prob=float(spd['prob']), speed_perturb_3_class=bool(spd.get('speed_perturb_3_class', False)))
+        for name in ('noise', 'reverb'):
             c = aug_conf.get(name) if hasattr(aug_conf, 'get') else None
             if c is not None and float(c.get('prob', 0.0)) > 0:
                 _LOG.warning('%s perturbation (prob %s) is not built on the MI355X engine: skipped', name, c.get('prob'))

@@ -35,3 +35,35 @@ def assemble_waves(waves, max_len=None, starts=None, use_dB_normalization=True, 
                                       N.stream_ptr()), ctx)
     ratio = nv.float() / float(L)
     return (out, ratio, nv) if with_valid else (out, ratio)
+
+
+SPEEDS = (1.0, 0.9, 1.1)          # yeaudio SpeedPerturbAugmentor's rates; index = the class offset of speed_perturb_3_class
+
+
+def speed_perturb(waves, rates):
+    """Speed perturbation of a ragged batch on the GPU (SpeedPerturbAugmentor / AudioSegment.change_speed, reader.py:155-156):
+    utterance b is resampled by linear interpolation to int(len / rates[b]) samples; rate 1.0 passes through untouched.
+    waves: list of 1-D float GPU tensors.  Returns a list of the same length."""
+    waves = [torch.as_tensor(w) for w in waves]
+    if not waves or not all(w.is_cuda for w in waves):
+        raise N.VpmiError('speed_perturb takes GPU waveforms: the engine has no CPU fallback')
+    idx = [b for b, r in enumerate(rates) if float(r) != 1.0]
+    out = list(waves)
+    if not idx:
+        return out
+    src = [waves[b].reshape(-1).contiguous().float() for b in idx]
+    lens = [int(w.numel()) for w in src]
+    new_lens = [int(n / float(rates[b])) for n, b in zip(lens, idx)]
+    if min(new_lens) <= 0:
+        raise ValueError('speed_perturb: an utterance would become empty')
+    dev = src[0].device
+    dst = [torch.empty(m, dtype=torch.float32, device=dev) for m in new_lens]
+    meta = torch.tensor([[w.data_ptr() for w in src], [w.data_ptr() for w in dst], lens, new_lens], dtype=torch.int64)
+    sp, dp = meta[0].to(dev), meta[1].to(dev)
+    ld, nd = meta[2].to(torch.int32).to(dev), meta[3].to(torch.int32).to(dev)
+    ctx = N.ctx(dev)
+    N.check(N.lib().vp_speed_perturb_f32(ctx, sp.data_ptr(), ld.data_ptr(), nd.data_ptr(), dp.data_ptr(), len(idx), max(new_lens),
+                                         N.stream_ptr()), ctx)
+    for b, w in zip(idx, dst):
+        out[b] = w
+    return out

@@ -5,7 +5,7 @@
 What moved: the reference builds features one utterance at a time on CPU DataLoader workers (reader.py:72-109) and feeds
 (B, T, F) tensors to the device; here worker THREADS only decode audio, and one step is
 
-    decoded waves --H2D--> assemble_waves (dB normalise, crop, pad: 1 launch) -> AudioFeaturizer (Fbank / Mel + CMN)
+    decoded waves --H2D--> speed_perturb -> assemble_waves (dB normalise, crop, pad: 1 launch) -> AudioFeaturizer (Fbank / Mel + CMN)
       -> SpecAugmentor.batch -> nn.Sequential(backbone, classifier) train-mode forward -> criterion -> backward
       -> bucketed gradient all-reduce over RCCL (one process per GPU, torch.distributed) -> flat Adam step
 
@@ -29,7 +29,7 @@ from torch import nn
 
 from ppvector.data_utils.featurizer import AudioFeaturizer
 from ppvector.data_utils.reader import PPVectorDataset
-from ppvector.data_utils.wave_batch import assemble_waves
+from ppvector.data_utils.wave_batch import assemble_waves, speed_perturb
 from ppvector.loss import build_loss
 from ppvector.metric.metrics import evaluate_trials
 from ppvector.models import build_model
@@ -139,6 +139,7 @@ class PPVectorTrainer(object):
             feats, _, _ = collate_fn([(torch.from_numpy(it['feature']).to(self.device), it['label']) for it in items])
             return feats, labels
         waves = [torch.from_numpy(np.ascontiguousarray(it['samples'])).to(self.device, non_blocking=True) for it in items]
+        waves = speed_perturb(waves, [it.get('speed', 1.0) for it in items])
         longest = max(min(int(w.numel()) - int(it['start']), dataset.max_samples) if dataset.mode != 'extract_feature'
                       else int(w.numel()) for w, it in zip(waves, items))
         batch, _, n_valid = assemble_waves(waves, max_len=longest, starts=[it['start'] for it in items],
@@ -178,6 +179,10 @@ class PPVectorTrainer(object):
         if is_train:
             if self.configs.train_conf.get('enable_amp', False):
                 raise NotImplementedError('enable_amp: the MI355X training engine is f32 (every shipped config sets enable_amp: False)')
+            num_class = self.configs.model_conf.classifier.num_speakers
+            spd = self.data_augment_configs.get('speed') if self.data_augment_configs is not None else None
+            if spd is not None and spd.get('prob', 0.0) > 0 and spd.get('speed_perturb_3_class', False):
+                self.configs.model_conf.classifier.num_speakers = num_class * 3       # trainer.py:171-173
             classifier = SpeakerIdentification(input_dim=self.backbone.embd_dim, **dict(self.configs.model_conf.classifier))
             self.model = nn.Sequential(self.backbone, classifier).to(self.device)
             self.loss = build_loss(configs=self.configs)
