@@ -89,6 +89,10 @@ typedef struct {
     float f_min;            /* 50 */
     float f_max;            /* 0 -> sample_rate / 2 */
     float power;            /* 2 */
+    int log_db;             /* 0: linear power (MelSpectrogram); 1: LogMelSpectrogram (featurizer.py:20-21) =
+                             * power_to_db: 10 log10(max(x, amin)) - 10 log10(max(ref_value, amin)), top_db None */
+    float amin;             /* 1e-10 */
+    float ref_value;        /* 1.0 */
 } vp_mel_opts;
 
 void vp_mel_default_opts(vp_mel_opts* o);

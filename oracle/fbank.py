@@ -234,12 +234,23 @@ def mel_spectrogram(wave, dtype=np.float32, **kwargs):
     return (pw @ bank.T).astype(dtype)
 
 
-def featurize_mel(waves, input_lens_ratio=None, method_args=None, dtype=np.float32):
-    """AudioFeaturizer.forward with feature_method 'MelSpectrogram' (featurizer.py:22-23, :45-59)."""
+def log_mel_spectrogram(wave, dtype=np.float32, ref_value=1.0, amin=1e-10, top_db=None, **kwargs):
+    """paddle.audio.features.LogMelSpectrogram (call site featurizer.py:20-21; third party, restated [3P-memory]): the mel
+    spectrogram above with n_fft defaulting to 512, through power_to_db: 10 log10(max(x, amin)) - 10 log10(max(ref_value, amin))
+    (top_db=None: no floor relative to the peak)."""
+    assert top_db is None
+    kwargs.setdefault('n_fft', 512)
+    m = mel_spectrogram(wave, dtype=np.float64, **kwargs)
+    return (10.0 * np.log10(np.maximum(m, amin)) - 10.0 * np.log10(max(ref_value, amin))).astype(dtype)
+
+
+def featurize_mel(waves, input_lens_ratio=None, method_args=None, dtype=np.float32, log=False):
+    """AudioFeaturizer.forward with feature_method 'MelSpectrogram' / 'LogMelSpectrogram' (featurizer.py:20-23, :45-59)."""
     waves = np.asarray(waves, dtype=dtype)
     if waves.ndim == 1:
         waves = waves[None, :]
-    feats = np.stack([mel_spectrogram(w, dtype=dtype, **dict(method_args or {})) for w in waves])
+    fn = log_mel_spectrogram if log else mel_spectrogram
+    feats = np.stack([fn(w, dtype=dtype, **dict(method_args or {})) for w in waves])
     feats = feats - feats.mean(axis=1, keepdims=True, dtype=dtype)
     if input_lens_ratio is not None:
         T = feats.shape[1]

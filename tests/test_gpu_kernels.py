@@ -97,6 +97,24 @@ def test_fbank_ragged_is_per_utterance_featurise_then_collate(N):
     assert mg.shape[0] == 2 and int(ml[1]) == alone.shape[1] and torch.equal(mg[1, :alone.shape[1]], alone[0]) and float(mg[1, alone.shape[1]:].abs().max()) == 0.0
 
 
+def test_log_mel_spectrogram_matches_restatement(N):
+    """feature_method 'LogMelSpectrogram' (featurizer.py:20-21): the mel kernel with the power_to_db epilogue."""
+    from ppvector.data_utils.featurizer import AudioFeaturizer
+    w = ofb.synth_waves(3, 24000, seed=31, lowpass=0.5)
+    w[2, 12000:] = 0.0                                                     # digital silence: the amin floor (-100 dB)
+    for args in (dict(sr=16000, n_fft=1024, hop_length=320, win_length=1024, n_mels=64, f_min=50.0),
+                 dict(sr=16000, hop_length=160, n_mels=80, ref_value=0.5, amin=1e-8)):      # n_fft defaults to 512 here
+        ref = ofb.featurize_mel(w, method_args=args, log=True)
+        fz = AudioFeaturizer('LogMelSpectrogram', args)
+        got = fz(dev(w)).cpu().numpy()
+        assert fz.feature_dim == args['n_mels'] and got.shape == ref.shape
+        d = np.abs(got - ref)
+        assert d.max() < 5e-2 and d.mean() < 1e-3, (d.max(), d.mean())    # dB of f32-FFT mel energies; the floor rows are exact
+    with pytest.raises(NotImplementedError):
+        AudioFeaturizer('LogMelSpectrogram', dict(top_db=80.0))
+    assert AudioFeaturizer('LogMelSpectrogram', {}).feature_dim == 128        # the reference's default (featurizer.py:69-70)
+
+
 def test_fbank_real_speech_golden(N, golden_dir):
     from ppvector.data_utils.featurizer import AudioFeaturizer
     g = np.load(f'{golden_dir}/wavs_3s.npz')

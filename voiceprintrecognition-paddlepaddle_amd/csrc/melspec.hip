@@ -31,6 +31,7 @@ struct MelArgs {
     const int* mel_start; const int* mel_bin0; const float* mel_w;
     int B, L, T, tiles, hop, n_mels, nnz;
     float power;
+    int log_db; float amin, db_off;      // LogMelSpectrogram: 10 log10(max(e, amin)) - db_off
 };
 
 __device__ __forceinline__ int pidx(int i) { return i + (i >> 4); }
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(WAVES * 64) void melspec_frames_kernel(MelArgs a) {
                 }
                 e += wq[0] * pq[0]; e += wq[1] * pq[1]; e += wq[2] * pq[2]; e += wq[3] * pq[3];
             }
+            if (a.log_db) e = 10.f * log10f(fmaxf(e, a.amin)) - a.db_off;
             orow[m] = e;
             if (it == 0) acc0 += e; else acc1 += e;
         }
@@ -283,7 +285,7 @@ extern "C" {
 
 void vp_mel_default_opts(vp_mel_opts* o) {
     o->sample_rate = 22050; o->n_fft = 2048; o->hop_length = 512; o->win_length = 0; o->n_mels = 64;
-    o->f_min = 50.f; o->f_max = 0.f; o->power = 2.f;
+    o->f_min = 50.f; o->f_max = 0.f; o->power = 2.f; o->log_db = 0; o->amin = 1e-10f; o->ref_value = 1.f;
 }
 
 int vp_mel_num_frames(const vp_mel_opts* o, int n_samples) { return o->hop_length > 0 ? 1 + n_samples / o->hop_length : 0; }
@@ -310,6 +312,7 @@ int vp_melspec_cmn_f32(vp_ctx* ctx, const float* wav, const float* lens_ratio, i
     a.mel_start = ctx->ms_mel_start; a.mel_bin0 = ctx->ms_mel_bin0; a.mel_w = ctx->ms_mel_w;
     a.B = B; a.L = L; a.T = T; a.tiles = tiles; a.hop = o->hop_length; a.n_mels = o->n_mels; a.nnz = ctx->ms_nnz;
     a.power = o->power;
+    a.log_db = o->log_db; a.amin = o->amin; a.db_off = 10.f * log10f(fmaxf(o->ref_value, o->amin));
     if (o->n_fft == 512) rc = launch_mel<256, 4>(ctx, a, st);
     else if (o->n_fft == 1024) rc = launch_mel<512, 4>(ctx, a, st);
     else rc = launch_mel<1024, 2>(ctx, a, st);

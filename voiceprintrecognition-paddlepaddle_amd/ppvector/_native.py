@@ -32,7 +32,8 @@ class FbankOpts(C.Structure):
 
 class MelOpts(C.Structure):
     _fields_ = [('sample_rate', c_int), ('n_fft', c_int), ('hop_length', c_int), ('win_length', c_int),
-                ('n_mels', c_int), ('f_min', c_float), ('f_max', c_float), ('power', c_float)]
+                ('n_mels', c_int), ('f_min', c_float), ('f_max', c_float), ('power', c_float),
+                ('log_db', c_int), ('amin', c_float), ('ref_value', c_float)]
 
 
 class Conv1dDesc(C.Structure):

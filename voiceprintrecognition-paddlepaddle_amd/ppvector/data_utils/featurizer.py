@@ -37,7 +37,9 @@ class AudioFeaturizer(nn.Module):
             self._opts = self._fbank_opts(method_args)
         elif feature_method == 'MelSpectrogram':
             self._opts = self._mel_opts(method_args)
-        elif feature_method in ('LogMelSpectrogram', 'Spectrogram', 'MFCC'):
+        elif feature_method == 'LogMelSpectrogram':
+            self._opts = self._mel_opts(method_args, log=True)
+        elif feature_method in ('Spectrogram', 'MFCC'):
             self._opts = None       # known to the reference; not built on the HIP engine yet
         else:
             raise Exception(f'预处理方法 {self._feature_method} 不存在!')
@@ -58,15 +60,22 @@ class AudioFeaturizer(nn.Module):
         return o
 
     @staticmethod
-    def _mel_opts(method_args):
+    def _mel_opts(method_args, log=False):
         """paddle.audio.features.MelSpectrogram keyword surface (defaults: sr 22050, n_fft 2048, hop_length 512,
         win_length None, window 'hann', power 2.0, center True, pad_mode 'reflect', n_mels 64, f_min 50.0,
-        f_max None, htk False, norm 'slaney')."""
+        f_max None, htk False, norm 'slaney').  log=True: paddle.audio.features.LogMelSpectrogram (featurizer.py:20-21) =
+        the same mel spectrogram through power_to_db(ref_value=1.0, amin=1e-10, top_db=None); its n_fft default is 512."""
         o = N.MelOpts()
         N.lib().vp_mel_default_opts(C.byref(o))
+        if log:
+            o.log_db, o.n_fft = 1, 512
         names = {'sr': 'sample_rate', 'n_fft': 'n_fft', 'hop_length': 'hop_length', 'win_length': 'win_length',
                  'n_mels': 'n_mels', 'f_min': 'f_min', 'f_max': 'f_max', 'power': 'power'}
+        if log:
+            names.update(ref_value='ref_value', amin='amin')
         fixed = {'window': 'hann', 'center': True, 'pad_mode': 'reflect', 'htk': False, 'norm': 'slaney', 'dtype': 'float32'}
+        if log:
+            fixed['top_db'] = None
         for k, v in dict(method_args).items():
             if k in names:
                 if v is None:
@@ -82,7 +91,7 @@ class AudioFeaturizer(nn.Module):
         return o
 
     def num_frames(self, n_samples):
-        if self._feature_method == 'MelSpectrogram':
+        if self._feature_method in ('MelSpectrogram', 'LogMelSpectrogram'):
             return N.lib().vp_mel_num_frames(C.byref(self._opts), int(n_samples))
         return N.lib().vp_fbank_num_frames(C.byref(self._opts), int(n_samples))
 
@@ -102,7 +111,7 @@ class AudioFeaturizer(nn.Module):
         wav = waveforms.contiguous().float()
         B, L = wav.shape
         lib, ctx = N.lib(), N.ctx(wav.device)
-        mel = self._feature_method == 'MelSpectrogram'
+        mel = self._feature_method in ('MelSpectrogram', 'LogMelSpectrogram')
         T = (lib.vp_mel_num_frames if mel else lib.vp_fbank_num_frames)(C.byref(self._opts), L)
         if T <= 0:
             raise ValueError(f'{L} samples are shorter than one analysis window')
@@ -156,7 +165,7 @@ class AudioFeaturizer(nn.Module):
         """返回特征大小"""
         if self._feature_method == 'LogMelSpectrogram':
             return self._method_args.get('n_mels', 128)
-        elif self._feature_method == 'MelSpectrogram':
+        elif self._feature_method in ('MelSpectrogram', 'LogMelSpectrogram'):
             return self._method_args.get('n_mels', 64)
         elif self._feature_method == 'Spectrogram':
             return self._method_args.get('n_fft', 512) // 2 + 1
