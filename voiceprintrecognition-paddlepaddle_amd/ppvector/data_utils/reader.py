@@ -15,6 +15,7 @@ the PERTURBED length, as the reference crops after it augments.  Noise / reverb 
 libraries, yeaudio DSP on CPU) are not built: a configured prob > 0 is reported once and skipped, never silently emulated.
 """
 import logging
+import os
 import random
 
 import numpy as np
@@ -103,8 +104,12 @@ class PPVectorDataset:
             self.speed_conf = dict(prob=float(spd['prob']), speed_perturb_3_class=bool(spd.get('speed_perturb_3_class', False)))
         for name in ('noise', 'reverb'):
             c = aug_conf.get(name) if hasattr(aug_conf, 'get') else None
-            if c is not None and float(c.get('prob', 0.0)) > 0:
-                _LOG.warning('%s perturbation (prob %s) is not built on the MI355X engine: skipped', name, c.get('prob'))
+            if c is None or float(c.get('prob', 0.0)) <= 0:
+                continue
+            lib_dir = c.get(f'{name}_dir', '')
+            if not lib_dir or not os.path.isdir(lib_dir) or not os.listdir(lib_dir):
+                continue      # as upstream: without its library of noise / impulse-response files the augmentor is a no-op
+            _LOG.warning('%s perturbation (prob %s, %s) is not built on the MI355X engine: skipped', name, c.get('prob'), lib_dir)
         vol = aug_conf.get('volume')
         if vol is not None and float(vol.get('prob', 0.0)) > 0:
             self.volume_conf = dict(prob=float(vol['prob']), min_gain_dBFS=float(vol.get('min_gain_dBFS', -15)),
