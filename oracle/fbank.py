@@ -216,8 +216,9 @@ def mel_spectrogram(wave, dtype=np.float32, **kwargs):
     o = dict(MEL_DEFAULTS)
     o.update(kwargs)
     assert o['window'] == 'hann' and o['center'] and o['pad_mode'] == 'reflect' and not o['htk'] and o['norm'] == 'slaney'
-    n_fft, hop = int(o['n_fft']), int(o['hop_length'])
+    n_fft = int(o['n_fft'])
     win_length = int(o['win_length'] or n_fft)
+    hop = int(o['hop_length']) if kwargs.get('hop_length') is not None else win_length // 4     # paddle's default rule
     x = np.asarray(wave, dtype=dtype).reshape(-1)
     xp = np.pad(x, (n_fft // 2, n_fft // 2), mode='reflect')
     T = 1 + x.shape[0] // hop
@@ -244,12 +245,26 @@ def log_mel_spectrogram(wave, dtype=np.float32, ref_value=1.0, amin=1e-10, top_d
     return (10.0 * np.log10(np.maximum(m, amin)) - 10.0 * np.log10(max(ref_value, amin))).astype(dtype)
 
 
+def mfcc(wave, dtype=np.float32, n_mfcc=40, **kwargs):
+    """paddle.audio.features.MFCC (call site featurizer.py:26-27; third party, restated [3P-memory]): log-mel (above) times
+    create_dct(n_mfcc, n_mels, norm='ortho') = cos(pi / n_mels (n + 0.5) k), row 0 scaled by 1/sqrt(2), all by sqrt(2 / n_mels)."""
+    lm = log_mel_spectrogram(wave, dtype=np.float64, **kwargs)                       # (T, n_mels)
+    n_mels = lm.shape[1]
+    assert n_mfcc <= n_mels
+    n = np.arange(n_mels, dtype=np.float64)
+    k = np.arange(n_mfcc, dtype=np.float64)[:, None]
+    dct = np.cos(math.pi / n_mels * (n + 0.5) * k)
+    dct[0] *= 1.0 / math.sqrt(2.0)
+    dct *= math.sqrt(2.0 / n_mels)
+    return (lm @ dct.T).astype(dtype)
+
+
 def featurize_mel(waves, input_lens_ratio=None, method_args=None, dtype=np.float32, log=False):
     """AudioFeaturizer.forward with feature_method 'MelSpectrogram' / 'LogMelSpectrogram' (featurizer.py:20-23, :45-59)."""
     waves = np.asarray(waves, dtype=dtype)
     if waves.ndim == 1:
         waves = waves[None, :]
-    fn = log_mel_spectrogram if log else mel_spectrogram
+    fn = {False: mel_spectrogram, True: log_mel_spectrogram, 'mfcc': mfcc}[log]
     feats = np.stack([fn(w, dtype=dtype, **dict(method_args or {})) for w in waves])
     feats = feats - feats.mean(axis=1, keepdims=True, dtype=dtype)
     if input_lens_ratio is not None:

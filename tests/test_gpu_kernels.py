@@ -115,6 +115,24 @@ def test_log_mel_spectrogram_matches_restatement(N):
     assert AudioFeaturizer('LogMelSpectrogram', {}).feature_dim == 128        # the reference's default (featurizer.py:69-70)
 
 
+def test_mfcc_matches_restatement(N):
+    """feature_method 'MFCC' (featurizer.py:26-27): log-mel -> orthonormal DCT-II, then the featurizer's CMN and mask."""
+    from ppvector.data_utils.featurizer import AudioFeaturizer
+    w = ofb.synth_waves(3, 16000, seed=41, lowpass=0.6)
+    ratio = np.asarray([1.0, 0.6, 0.31], np.float32)
+    for args in (dict(sr=16000, n_mfcc=20, n_fft=512, hop_length=160, n_mels=40, f_min=20.0), dict(sr=16000)):
+        ref = ofb.featurize_mel(w, ratio, method_args=args, log='mfcc')
+        fz = AudioFeaturizer('MFCC', args)
+        got = fz(dev(w), dev(ratio), want_bf16=True)
+        g = got.cpu().numpy()
+        assert fz.feature_dim == args.get('n_mfcc', 40) and g.shape == ref.shape
+        d = np.abs(g - ref)
+        assert d.max() < 0.2 and d.mean() < 5e-3, (d.max(), d.mean())       # sums of 40-64 dB values from f32-FFT mel energies
+        assert np.max(np.abs(got._vp_bf16.float().cpu().numpy() - g)) <= np.max(np.abs(g)) * 2 ** -8 + 1e-6
+    with pytest.raises(AssertionError):
+        AudioFeaturizer('MFCC', dict(n_mfcc=80, n_mels=64))
+
+
 def test_fbank_real_speech_golden(N, golden_dir):
     from ppvector.data_utils.featurizer import AudioFeaturizer
     g = np.load(f'{golden_dir}/wavs_3s.npz')

@@ -6,6 +6,7 @@ runs in one fused HIP pipeline (csrc/fbank.hip): framing, DC removal, pre-emphas
 512-point FFT, Kaldi mel bank, log, time-mean subtraction and the length mask.
 """
 import ctypes as C
+import math
 
 import torch
 from torch import nn
@@ -39,7 +40,14 @@ class AudioFeaturizer(nn.Module):
             self._opts = self._mel_opts(method_args)
         elif feature_method == 'LogMelSpectrogram':
             self._opts = self._mel_opts(method_args, log=True)
-        elif feature_method in ('Spectrogram', 'MFCC'):
+        elif feature_method == 'MFCC':
+            args = dict(method_args)
+            self._n_mfcc = int(args.pop('n_mfcc', 40))
+            self._opts = self._mel_opts(args, log=True)
+            if self._n_mfcc > self._opts.n_mels:
+                raise AssertionError('n_mfcc cannot be larger than n_mels: %d vs %d' % (self._n_mfcc, self._opts.n_mels))
+            self._dct = None
+        elif feature_method == 'Spectrogram':
             self._opts = None       # known to the reference; not built on the HIP engine yet
         else:
             raise Exception(f'预处理方法 {self._feature_method} 不存在!')
@@ -86,12 +94,14 @@ class AudioFeaturizer(nn.Module):
                     raise NotImplementedError(f'MelSpectrogram option {k}={v} is not built on the HIP engine')
             else:
                 raise TypeError(f"__init__() got an unexpected keyword argument '{k}'")
+        if dict(method_args).get('hop_length') is None:              # paddle: hop_length defaults to win_length // 4
+            o.hop_length = (o.win_length or o.n_fft) // 4
         if o.f_max > 0.5 * o.sample_rate:
             raise ValueError(f'f_max {o.f_max} is above the Nyquist frequency of sr {o.sample_rate}')
         return o
 
     def num_frames(self, n_samples):
-        if self._feature_method in ('MelSpectrogram', 'LogMelSpectrogram'):
+        if self._feature_method in ('MelSpectrogram', 'LogMelSpectrogram', 'MFCC'):
             return N.lib().vp_mel_num_frames(C.byref(self._opts), int(n_samples))
         return N.lib().vp_fbank_num_frames(C.byref(self._opts), int(n_samples))
 
@@ -111,7 +121,7 @@ class AudioFeaturizer(nn.Module):
         wav = waveforms.contiguous().float()
         B, L = wav.shape
         lib, ctx = N.lib(), N.ctx(wav.device)
-        mel = self._feature_method in ('MelSpectrogram', 'LogMelSpectrogram')
+        mel = self._feature_method in ('MelSpectrogram', 'LogMelSpectrogram', 'MFCC')
         T = (lib.vp_mel_num_frames if mel else lib.vp_fbank_num_frames)(C.byref(self._opts), L)
         if T <= 0:
             raise ValueError(f'{L} samples are shorter than one analysis window')
@@ -126,6 +136,21 @@ class AudioFeaturizer(nn.Module):
         fn = lib.vp_melspec_cmn_f32 if mel else lib.vp_fbank_cmn_f32
         N.check(fn(ctx, N.ptr(wav), N.ptr(ratio), B, L, C.byref(self._opts), N.ptr(out), N.ptr(out16), N.ptr(ws),
                    ws.numel(), N.stream_ptr()), ctx)
+        if self._feature_method == 'MFCC':
+            # paddle.audio.features.MFCC (featurizer.py:26-27): log-mel @ create_dct(n_mfcc, n_mels, norm='ortho').  The DCT is
+            # linear, so it commutes with the mean subtraction and the zeroed rows already applied to the log-mel features.
+            if self._dct is None or self._dct.device != wav.device:
+                n = torch.arange(F, dtype=torch.float64)
+                k = torch.arange(self._n_mfcc, dtype=torch.float64).unsqueeze(1)
+                dct = torch.cos(math.pi / F * (n + 0.5) * k)
+                dct[0] *= 1.0 / math.sqrt(2.0)
+                self._dct = (dct * math.sqrt(2.0 / F)).t().contiguous().float().to(wav.device)        # (n_mels, n_mfcc)
+            mf = torch.empty((B, T, self._n_mfcc), dtype=torch.float32, device=wav.device)
+            N.check(lib.vp_dense_f32(ctx, N.ptr(out), F, N.ptr(self._dct), 1, None, B * T, self._n_mfcc, F, N.VP_ACT_NONE, N.ptr(mf),
+                                     self._n_mfcc, N.stream_ptr()), ctx)
+            out, out16 = mf, (torch.empty_like(mf, dtype=torch.bfloat16) if want_bf16 else None)
+            if out16 is not None:
+                N.check(lib.vp_cast_f32_bf16(ctx, N.ptr(out), N.ptr(out16), out.numel(), N.stream_ptr()), ctx)
         if out16 is not None:
             out._vp_bf16 = out16
         return out
@@ -165,7 +190,7 @@ class AudioFeaturizer(nn.Module):
         """返回特征大小"""
         if self._feature_method == 'LogMelSpectrogram':
             return self._method_args.get('n_mels', 128)
-        elif self._feature_method in ('MelSpectrogram', 'LogMelSpectrogram'):
+        elif self._feature_method == 'MelSpectrogram':
             return self._method_args.get('n_mels', 64)
         elif self._feature_method == 'Spectrogram':
             return self._method_args.get('n_fft', 512) // 2 + 1
