@@ -61,7 +61,9 @@ class _BatchLoader:
         return idx
 
     def __len__(self):
-        n = len(self._indices())
+        n = len(self.dataset)
+        if self.world > 1:
+            n = (n + self.world - 1) // self.world                # every rank's shard has the same (wrap-padded) size
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
     def __iter__(self):
