@@ -313,7 +313,16 @@ def test_conv1d_split_destination(N, dtype):
     (70, 241, 80, 512, 5, 1, 'reflect'),     # ECAPA block0 geometry: Cin % 64 != 0, K-steps straddle taps, ragged K tail
     (66, 250, 72, 256, 3, 2, 'zero'),
 ])
-def test_conv1d_wide_tiles_bf16(N, case):
+@pytest.mark.parametrize('sched', [3, 4, 5, 7, 9])     # 3 = two-stage role-split schedule; 4 + 2 v + r = half-tile ring variant v, r = resident workgroups
+def test_conv1d_wide_tiles_bf16(N, case, sched):
+    prev = N.lib().vp_conv256_select(sched)
+    try:
+        _wide_tiles_case(N, case)
+    finally:
+        N.lib().vp_conv256_select(prev)
+
+
+def _wide_tiles_case(N, case):
     B, T, Cin, Cout, kw, dil, pad = case
     g = torch.Generator().manual_seed(77 + kw)
     x = torch.randn(B, T, Cin, generator=g, dtype=torch.float64)

@@ -492,3 +492,50 @@ def test_campplus_training_step_vs_oracle_autograd(N):
         assert r < 3e-2, (k, r)
     print(f'[cam++ train] loss {loss.item():.5f} (oracle {loss_ref.item():.5f}); worst parameter-gradient rel-L2 {worst:.2e} ({wk})')
     m.eval()
+
+
+def test_eval_engine_follows_training_updates(N):
+    """The packed eval engine (and its HIP graph) must not survive a training step: Adam and the BatchNorm running statistics
+    are written through raw pointers, which torch's version counters never see (PPVectorTrainer.train(do_eval=True) evaluates
+    after every epoch, trainer.py:340-360).  eval -> train steps -> eval: the second embedding must be the oracle's on the
+    UPDATED state dict, for the f32 engine, the bf16 engine and the captured graph."""
+    import ppvector
+    from ppvector.models.tdnn import TDNN
+    from ppvector.optimizer.adam import Adam
+    from ppvector.train.functions import HeadLoss
+    p = om.tdnn_params(80, seed=31)
+    m = TDNN(80)
+    m.load_state_dict(p)
+    m = m.cuda()
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn(6, 70, 80, generator=g) * 2).cuda()
+    y = torch.randint(0, 9, (6,), generator=g).cuda()
+    W = om.head_params(192, 9, seed=4).cuda().requires_grad_()
+    opt = Adam(list(m.parameters()) + [W], learning_rate=5e-3)
+
+    def oracle_emb():
+        sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+        return om.tdnn_forward(sd, x.cpu().double())
+
+    m.eval()
+    ppvector.set_graph_mode(True)
+    try:
+        e0 = {dt: m.engine(dt).forward(x).clone() for dt in ('float32', 'bfloat16')}
+        eg0 = m(x).clone()
+        assert rel(e0['float32'], oracle_emb()) < 1e-5
+        m.train()
+        for _ in range(3):
+            opt.clear_grad()
+            loss = HeadLoss.apply(m(x), W, y, 0.2, 32.0, 0.0, False)
+            loss.backward()
+            opt.step()
+        m.eval()
+        ref1 = oracle_emb()
+        assert rel(ref1, e0['float32']) > 1e-3                              # the weights did move
+        e1 = {dt: m.engine(dt).forward(x) for dt in ('float32', 'bfloat16')}
+        eg1 = m(x)
+    finally:
+        ppvector.set_graph_mode(False)
+    assert rel(e1['float32'], ref1) < 1e-5, rel(e1['float32'], ref1)
+    assert rel(eg1, ref1) < 1e-5 and rel(eg1, eg0) > 1e-3
+    assert rel(e1['bfloat16'], ref1) < 2e-2 and rel(e1['bfloat16'], e0['bfloat16']) > 1e-3

@@ -1,0 +1,10 @@
+#!/bin/bash
+# round 2, call 1: ring-schedule correctness + A/B timing, tile phases, stream split probe, bench
+mkdir -p gpurun_out; export TMPDIR=/tmp
+PKG=voiceprintrecognition-paddlepaddle_amd
+timeout 600 python -m pytest tests/test_gpu_kernels.py -q -x -k "conv1d" -p no:cacheprovider --timeout 200 > gpurun_out/c1_pytest.log 2>&1; echo "pytest rc=$?"; tail -n 3 gpurun_out/c1_pytest.log
+timeout 300 python tools/gemm_probe.py 5 3,4 > gpurun_out/c1_gemm.log 2>&1; echo "gemm rc=$?"; cat gpurun_out/c1_gemm.log
+VPMI_LIB=$PWD/$PKG/lib/libvpmi_timing.so timeout 200 python tools/tile_timing.py > gpurun_out/c1_tiles_ring.log 2>&1; cat gpurun_out/c1_tiles_ring.log
+VPMI_CONV256=3 VPMI_LIB=$PWD/$PKG/lib/libvpmi_timing.so timeout 200 python tools/tile_timing.py > gpurun_out/c1_tiles_s3.log 2>&1; cat gpurun_out/c1_tiles_s3.log
+timeout 300 python tools/stream_probe.py > gpurun_out/c1_streams.log 2>&1; echo "streams rc=$?"; cat gpurun_out/c1_streams.log
+timeout 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline > gpurun_out/c1_bench.log 2>&1; echo "bench rc=$?"; tail -n 1 gpurun_out/c1_bench.log | cut -c 1-1500

@@ -29,13 +29,24 @@ int vp_conv_launch_bf16_f32(vp_ctx* ctx, const void* args, int bn, int mode, hip
 int vp_conv_launch_f32_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
 int vp_conv_launch256_bf16(vp_ctx* ctx, const void* args, int mode, int sched, hipStream_t st);
 
-static int use_conv256() {          // VPMI_CONV256: 0 pins the 128-wide kernel; 1 = interleaved DMA, 2 = ping-pong phases, 3 = role-split DMA (default)
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("VPMI_CONV256"); v = e ? atoi(e) : 3; }
-    return v;
+// Schedule of the 256-wide kernel: 0 pins the 128-wide kernel; 1 = interleaved DMA, 2 = ping-pong phases, 3 = role-split
+// DMA (two 64 KB stages), 4 + 2 v + r = half-tile ring, variant v (0..2), r = 1: resident workgroups.  Default (-1): per
+// launch -- the ring (9) from 16 K-steps up, the two-stage schedule (3) for shorter contractions, whose tiles are mostly
+// prologue and epilogue (measured, MI355X: 1536 -> 1536 314 vs 346 us; 512 -> 512 66 vs 63 us).
+// VPMI_CONV256 presets it; vp_conv256_select() switches at run time (A/B in one process).
+static int g_conv256 = -2;
+static int use_conv256() {
+    if (g_conv256 == -2) { const char* e = getenv("VPMI_CONV256"); g_conv256 = e ? atoi(e) : -1; }
+    return g_conv256;
 }
 
 extern "C" {
+
+int vp_conv256_select(int schedule) {
+    const int prev = use_conv256();
+    if (schedule >= -1 && schedule <= 9) g_conv256 = schedule;
+    return prev;
+}
 
 int vp_conv1d_tiles_m(int B, int T_out) { return (int)(((long long)B * T_out + BM - 1) / BM); }
 int vp_conv1d_nseg(int T_out) { return T_out > 0 ? (BM - 1) / T_out + 2 : 0; }
@@ -115,14 +126,15 @@ int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream) {
     hipStream_t st = (hipStream_t)stream;
     // wide bf16 layers: 256 x 256 tiles fed by LDS-DMA (conv_gemm256.hip)
     if (d->dtype_in == VP_BF16 && d->dtype_out == VP_BF16 && (mode == MODE_1X1 || mode == MODE_TAPS) &&
-        (d->Cin % 64 == 0 || (mode == MODE_TAPS && use_conv256() == 3)) &&
+        (d->Cin % 64 == 0 || (mode == MODE_TAPS && (use_conv256() >= 3 || use_conv256() < 0))) &&
         d->Cout >= 256 && a.M >= 256 * 64 && !d->gate && (!d->psum || d->T_out >= 128) && use_conv256()) {
         a.tiles_m = (a.M + 255) / 256;
         a.tiles_n = (a.N + 255) / 256;
         a.group_m = 32 / a.tiles_n;
         if (a.group_m < 1) a.group_m = 1;
         if (a.group_m > 16) a.group_m = 16;
-        return vp_conv_launch256_bf16(ctx, &a, mode, use_conv256() - 1, st);
+        const int sched = use_conv256() < 0 ? (a.KT >= 16 ? 9 : 3) : use_conv256();
+        return vp_conv_launch256_bf16(ctx, &a, mode, sched - 1, st);
     }
     if (d->dtype_in == VP_BF16 && d->dtype_out == VP_BF16) return vp_conv_launch_bf16_bf16(ctx, &a, bn, mode, st);
     if (d->dtype_in == VP_BF16 && d->dtype_out == VP_F32) return vp_conv_launch_bf16_f32(ctx, &a, bn, mode, st);

@@ -21,6 +21,212 @@ constexpr int MODE_TAPS_GEN = 4;             // tapped 1-D conv with Cin % 64 !=
 constexpr int STAGE2 = 2 * T2 * ROWB;        // X panel + W panel
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// Epilogue of one 256 x 256 tile, shared by every K-loop schedule.  Entered by all 512 threads with the wave's 64 x 128
+// accumulators in registers; the K panels in LDS are dead (the function's first barrier orders that).
+__device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8], char* smem, int tid, int tm, int m0, int n0) {
+    constexpr int MI = 4;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const int li = lane & 15, g = lane >> 4;
+    // ------------------------------------------------------------------ epilogue
+    // y = act2( bn( act( acc + bias + rowbias ) ) + res );  aux = y + add_in;  psum/psumsq over (y - shift)
+    // (conv_gemm_impl.h semantics, no gate).  Written as ROLLED loops over an LDS image of the
+    // accumulators: the fully unrolled per-register form of the 128-wide kernel is ~25k instructions for
+    // 128 accumulators per lane and ran 15 us per tile on instruction fetch alone.  Per 64-channel half:
+    //   A. dump the wave's 64 x 64 f32 accumulators into its own LDS slab (row stride 272 B);
+    //   B. 16 iterations: lane = (row j*4 + lane/16, channels 4*(lane%16)..+3): math, 8-B store (16 lanes
+    //      cover 128 contiguous bytes of a position), (y - shift) written back to the slab;
+    //   C. column sums: lane = one channel, 64 rows, per utterance segment, into red[wm][seg][col].
+    constexpr int OROW = 272;
+    constexpr int SLABS = 8 * 64 * OROW;
+    __syncthreads();                                           // every wave is done reading the K panels
+    char* slab = smem + wv * (64 * OROW);
+    float* red = reinterpret_cast<float*>(smem + SLABS);       // [2 stats][4 wm][2 seg][256 col]
+    bf16_t* __restrict__ Y = static_cast<bf16_t*>(a.y);
+    bf16_t* __restrict__ Y2 = static_cast<bf16_t*>(a.y2);
+    const bf16_t* __restrict__ ADD = static_cast<const bf16_t*>(a.add_in);
+    const bf16_t* __restrict__ RES = static_cast<const bf16_t*>(a.res);
+    bf16_t* __restrict__ AUX = static_cast<bf16_t*>(a.aux);
+    const int mw = m0 + wm * 64;                               // first position of this wave
+    const int bfirst = (m0 + (wm >> 1) * 128) / a.T_out;       // first utterance of the 128-row half
+    const int q4 = lane >> 4, c4 = (lane & 15) * 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                *reinterpret_cast<f32x4*>(slab + (mi * 16 + li) * OROW + (ni * 16 + g * 4) * 4) = acc[mi][h * 4 + ni];
+        const int nb = n0 + wn * 128 + h * 64 + c4;
+        const bool nvalid = nb < a.N;
+        float bias4[4] = {0.f, 0.f, 0.f, 0.f}, sc4[4] = {1.f, 1.f, 1.f, 1.f}, sh4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (nvalid) {
+            if (a.bias) load4(a.bias + nb, bias4);
+            if (a.bn_scale) load4(a.bn_scale + nb, sc4);
+            if (a.bn_shift) load4(a.bn_shift + nb, sh4);
+        }
+        // FAST rows: the whole 64 x 64 block is inside the problem and only the per-channel terms are
+        // active (bias, ReLU, BN affine, ReLU) -- lane = (row 8j + lane/8, channels 8*(lane%8)..+7), one
+        // 16-B store per lane, 8 lanes = 128 contiguous bytes of a position.  ~40 VALU per 8 values; the
+        // general loop below spends ~25 per VALUE on masks and 64-bit addressing.
+        const int nh = n0 + wn * 128 + h * 64;
+        const bool fast = mw + 64 <= a.M && nh + 64 <= a.N && !a.rowbias && !RES && !AUX && a.act2 != VP_ACT_TANH && a.act2 != VP_ACT_SILU &&
+                          (a.ysplit <= nh || a.ysplit >= nh + 64) && ((a.ldy | a.yoff) & 7) == 0 &&
+                          (reinterpret_cast<uintptr_t>(a.y) & 15) == 0 &&
+                          (a.ysplit <= nh || (((a.ldy2 | a.y2off) & 7) == 0 && (reinterpret_cast<uintptr_t>(a.y2) & 15) == 0));
+        if (fast) {
+            const int c8 = (lane & 7) * 8, q8 = lane >> 3;
+            const int nc = nh + c8;
+            float bs[8], sc[8], sh[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { bs[e] = 0.f; sc[e] = 1.f; sh[e] = 0.f; }
+            if (a.bias) { load4(a.bias + nc, bs); load4(a.bias + nc + 4, bs + 4); }
+            if (a.bn_scale) { load4(a.bn_scale + nc, sc); load4(a.bn_scale + nc + 4, sc + 4); }
+            if (a.bn_shift) { load4(a.bn_shift + nc, sh); load4(a.bn_shift + nc + 4, sh + 4); }
+            const float lo1 = a.act == VP_ACT_RELU ? 0.f : -INFINITY;
+            const float lo2 = (a.act2 == VP_ACT_RELU || a.act2 == VP_ACT_HARDTANH20) ? 0.f : -INFINITY;
+            const float hi2 = a.act2 == VP_ACT_HARDTANH20 ? 20.f : INFINITY;
+            bf16_t* dst = Y + (size_t)(mw + q8) * a.ldy + a.yoff + nc;
+            const size_t dstep = (size_t)8 * a.ldy;
+            const bool split = a.ysplit > nh;
+            bf16_t* dst2 = split ? Y2 + (size_t)(mw + q8) * a.ldy2 + a.y2off + nc : nullptr;
+            const size_t dstep2 = (size_t)8 * a.ldy2;
+            const bool sums = a.psum != nullptr;
+            char* cell = slab + q8 * OROW + c8 * 4;
+            // two instances of the row loop: without a second activation (conv -> ReLU -> BN, the TDNN block) the clamp pair is
+            // dead work -- 16 of ~44 VALU instructions per 8 values in a loop that is VALU-bound
+            auto rows = [&](auto clamp2) {
+#pragma unroll 2
+                for (int j = 0; j < 8; ++j) {
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(cell);
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(cell + 16);
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = fmaxf(a0[e] + bs[e], lo1) * sc[e] + sh[e];
+                        v[e + 4] = fmaxf(a1[e] + bs[e + 4], lo1) * sc[e + 4] + sh[e + 4];
+                        if constexpr (decltype(clamp2)::value) {
+                            v[e] = fminf(fmaxf(v[e], lo2), hi2);
+                            v[e + 4] = fminf(fmaxf(v[e + 4], lo2), hi2);
+                        }
+                    }
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+                    *reinterpret_cast<bf16x8*>(dst) = o;
+                    dst += dstep;
+                    if (split) { *reinterpret_cast<bf16x8*>(dst2) = o; dst2 += dstep2; }
+                    if (sums) {
+                        *reinterpret_cast<f32x4*>(cell) = f32x4{v[0] - sh[0], v[1] - sh[1], v[2] - sh[2], v[3] - sh[3]};
+                        *reinterpret_cast<f32x4*>(cell + 16) = f32x4{v[4] - sh[4], v[5] - sh[5], v[6] - sh[6], v[7] - sh[7]};
+                    }
+                    cell += 8 * OROW;
+                }
+            };
+            if (a.act2 == VP_ACT_NONE) rows(std::false_type{});
+            else rows(std::true_type{});
+        } else {
+        int m = mw + q4;
+        int b = (m < a.M ? m : a.M - 1) / a.T_out;
+        int t = m - b * a.T_out;                               // may run past T_out for rows >= M: never used then
+#pragma unroll 1
+        for (int j = 0; j < 16; ++j) {
+            char* cell = slab + (j * 4 + q4) * OROW + c4 * 4;
+            const f32x4 av = *reinterpret_cast<const f32x4*>(cell);
+            const bool ok = nvalid && m < a.M;
+            float v[4];
+            float rbias[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f};
+            if (ok && a.rowbias) load4(a.rowbias + (size_t)b * a.N + nb, rbias);
+            if (ok && RES) load4(RES + (size_t)m * a.ld_res + a.res_off + nb, rs);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = av[r] + bias4[r] + rbias[r];
+                if (a.act == VP_ACT_RELU) x = fmaxf(x, 0.f);
+                x = x * sc4[r] + sh4[r] + rs[r];
+                if (a.act2 == VP_ACT_TANH) x = vp_tanh_for<bf16_t>(x);
+                else if (a.act2 == VP_ACT_RELU) x = fmaxf(x, 0.f);
+                else if (a.act2 == VP_ACT_HARDTANH20) x = fminf(fmaxf(x, 0.f), 20.f);
+                else if (a.act2 == VP_ACT_SILU) x = vp_silu_for<bf16_t>(x);
+                v[r] = x;
+            }
+            if (ok) {
+                store4(Y + (size_t)m * a.ldy + a.yoff + nb, v);
+                if (nb < a.ysplit) store4(Y2 + (size_t)m * a.ldy2 + a.y2off + nb, v);
+                if (AUX) {
+                    float ad[4];
+                    load4(ADD + (size_t)m * a.ld_add + a.add_off + nb, ad);
+                    float s4[4] = {v[0] + ad[0], v[1] + ad[1], v[2] + ad[2], v[3] + ad[3]};
+                    store4(AUX + (size_t)m * a.ld_aux + a.aux_off + nb, s4);
+                }
+            }
+            if (a.psum)
+                *reinterpret_cast<f32x4*>(cell) = ok ? f32x4{v[0] - sh4[0], v[1] - sh4[1], v[2] - sh4[2], v[3] - sh4[3]}
+                                                     : f32x4{0.f, 0.f, 0.f, 0.f};
+            m += 4; t += 4;
+            while (t >= a.T_out) { t -= a.T_out; ++b; }
+        }
+        }
+        if (a.psum) {
+            // lane = channel h*64 + lane of this wave's 128.  T_out >= 128 > 64 rows: at most one utterance
+            // boundary inside the wave's rows, at the wave-uniform row rb
+            const int col = wn * 128 + h * 64 + lane;
+            const int bb = (mw < a.M ? mw : a.M - 1) / a.T_out;
+            const int rb = min(64, (bb + 1) * a.T_out - mw);     // rows [0, rb) belong to utterance bb
+            const char* colp = slab + lane * 4;
+            float s1 = 0.f, s2 = 0.f;
+            int r = 0;
+#pragma unroll 4
+            for (; r < rb; ++r) {
+                const float d = *reinterpret_cast<const float*>(colp + r * OROW);
+                s1 += d; s2 += d * d;
+            }
+            if (bb - bfirst < 2) {
+                red[((0 * 4 + wm) * 2 + (bb - bfirst)) * T2 + col] = s1;
+                red[((1 * 4 + wm) * 2 + (bb - bfirst)) * T2 + col] = s2;
+            }
+            if (rb < 64) {
+                s1 = 0.f; s2 = 0.f;
+#pragma unroll 4
+                for (; r < 64; ++r) {
+                    const float d = *reinterpret_cast<const float*>(colp + r * OROW);
+                    s1 += d; s2 += d * d;
+                }
+                if (bb + 1 - bfirst < 2) {
+                    red[((0 * 4 + wm) * 2 + (bb + 1 - bfirst)) * T2 + col] = s1;
+                    red[((1 * 4 + wm) * 2 + (bb + 1 - bfirst)) * T2 + col] = s2;
+                }
+            }
+        }
+    }
+    if (a.psum) {
+        // per 128-row half (= one M-tile of the 128-wide kernel's psum layout): the two waves' partials.
+        // T_out >= 128 (host-checked, nseg == 2): a wave's 64 rows touch at most two utterances and
+        // flush each (wave, segment) slot at most once; slots never flushed must read as zero.
+        __syncthreads();
+        const int col = tid & 255, half = tid >> 8;
+        if (n0 + col < a.N && m0 + half * 128 < a.M) {
+            const int bf = (m0 + half * 128) / a.T_out;
+            for (int sgi = 0; sgi < 2; ++sgi) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const int wmx = half * 2 + w;
+                    const int mlo = m0 + wmx * 64, mhi = min(mlo + 63, a.M - 1);
+                    // did wave wmx own rows of utterance bf + sgi?
+                    if (mlo < a.M && mlo / a.T_out <= bf + sgi && bf + sgi <= mhi / a.T_out) {
+                        s1 += red[((0 * 4 + wmx) * 2 + sgi) * T2 + col];
+                        s2 += red[((1 * 4 + wmx) * 2 + sgi) * T2 + col];
+                    }
+                }
+                const size_t o = ((size_t)(tm * 2 + half) * a.nseg + sgi) * a.N + n0 + col;
+                a.psum[o] = s1;
+                if (a.psumsq) a.psumsq[o] = s2;
+            }
+        }
+    }
+}
+
 template <int MODE, int SCHED>
 __global__ __launch_bounds__(512) void conv_gemm256_kernel(const ConvArgs a) {
     constexpr int MI = 4, NI = 8;            // per wave: 64 positions x 128 channels
@@ -359,221 +565,346 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(const ConvArgs a) {
     const unsigned long long ck2 = clock64();
 #endif
 
-    // ------------------------------------------------------------------ epilogue
-    // y = act2( bn( act( acc + bias + rowbias ) ) + res );  aux = y + add_in;  psum/psumsq over (y - shift)
-    // (conv_gemm_impl.h semantics, no gate).  Written as ROLLED loops over an LDS image of the
-    // accumulators: the fully unrolled per-register form of the 128-wide kernel is ~25k instructions for
-    // 128 accumulators per lane and ran 15 us per tile on instruction fetch alone.  Per 64-channel half:
-    //   A. dump the wave's 64 x 64 f32 accumulators into its own LDS slab (row stride 272 B);
-    //   B. 16 iterations: lane = (row j*4 + lane/16, channels 4*(lane%16)..+3): math, 8-B store (16 lanes
-    //      cover 128 contiguous bytes of a position), (y - shift) written back to the slab;
-    //   C. column sums: lane = one channel, 64 rows, per utterance segment, into red[wm][seg][col].
-    constexpr int OROW = 272;
-    constexpr int SLABS = 8 * 64 * OROW;
-    __syncthreads();                                           // every wave is done reading the K panels
 #ifdef VP_TIMING
     const unsigned long long te0 = wall_clock64();
-    unsigned long long te1 = 0, te1b = 0;
 #endif
-    char* slab = smem + wv * (64 * OROW);
-    float* red = reinterpret_cast<float*>(smem + SLABS);       // [2 stats][4 wm][2 seg][256 col]
-    bf16_t* __restrict__ Y = static_cast<bf16_t*>(a.y);
-    bf16_t* __restrict__ Y2 = static_cast<bf16_t*>(a.y2);
-    const bf16_t* __restrict__ ADD = static_cast<const bf16_t*>(a.add_in);
-    const bf16_t* __restrict__ RES = static_cast<const bf16_t*>(a.res);
-    bf16_t* __restrict__ AUX = static_cast<bf16_t*>(a.aux);
-    const int mw = m0 + wm * 64;                               // first position of this wave
-    const int bfirst = (m0 + (wm >> 1) * 128) / a.T_out;       // first utterance of the 128-row half
-    const int q4 = lane >> 4, c4 = (lane & 15) * 4;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-                *reinterpret_cast<f32x4*>(slab + (mi * 16 + li) * OROW + (ni * 16 + g * 4) * 4) = acc[mi][h * 4 + ni];
-#ifdef VP_TIMING
-        if (h == 0) te1b = wall_clock64();
-#endif
-        const int nb = n0 + wn * 128 + h * 64 + c4;
-        const bool nvalid = nb < a.N;
-        float bias4[4] = {0.f, 0.f, 0.f, 0.f}, sc4[4] = {1.f, 1.f, 1.f, 1.f}, sh4[4] = {0.f, 0.f, 0.f, 0.f};
-        if (nvalid) {
-            if (a.bias) load4(a.bias + nb, bias4);
-            if (a.bn_scale) load4(a.bn_scale + nb, sc4);
-            if (a.bn_shift) load4(a.bn_shift + nb, sh4);
-        }
-        // FAST rows: the whole 64 x 64 block is inside the problem and only the per-channel terms are
-        // active (bias, ReLU, BN affine, ReLU) -- lane = (row 8j + lane/8, channels 8*(lane%8)..+7), one
-        // 16-B store per lane, 8 lanes = 128 contiguous bytes of a position.  ~40 VALU per 8 values; the
-        // general loop below spends ~25 per VALUE on masks and 64-bit addressing.
-        const int nh = n0 + wn * 128 + h * 64;
-        const bool fast = mw + 64 <= a.M && nh + 64 <= a.N && !a.rowbias && !RES && !AUX && a.act2 != VP_ACT_TANH && a.act2 != VP_ACT_SILU &&
-                          (a.ysplit <= nh || a.ysplit >= nh + 64) && ((a.ldy | a.yoff) & 7) == 0 &&
-                          (reinterpret_cast<uintptr_t>(a.y) & 15) == 0 &&
-                          (a.ysplit <= nh || (((a.ldy2 | a.y2off) & 7) == 0 && (reinterpret_cast<uintptr_t>(a.y2) & 15) == 0));
-        if (fast) {
-            const int c8 = (lane & 7) * 8, q8 = lane >> 3;
-            const int nc = nh + c8;
-            float bs[8], sc[8], sh[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { bs[e] = 0.f; sc[e] = 1.f; sh[e] = 0.f; }
-            if (a.bias) { load4(a.bias + nc, bs); load4(a.bias + nc + 4, bs + 4); }
-            if (a.bn_scale) { load4(a.bn_scale + nc, sc); load4(a.bn_scale + nc + 4, sc + 4); }
-            if (a.bn_shift) { load4(a.bn_shift + nc, sh); load4(a.bn_shift + nc + 4, sh + 4); }
-            const float lo1 = a.act == VP_ACT_RELU ? 0.f : -INFINITY;
-            const float lo2 = (a.act2 == VP_ACT_RELU || a.act2 == VP_ACT_HARDTANH20) ? 0.f : -INFINITY;
-            const float hi2 = a.act2 == VP_ACT_HARDTANH20 ? 20.f : INFINITY;
-            bf16_t* dst = Y + (size_t)(mw + q8) * a.ldy + a.yoff + nc;
-            const size_t dstep = (size_t)8 * a.ldy;
-            const bool split = a.ysplit > nh;
-            bf16_t* dst2 = split ? Y2 + (size_t)(mw + q8) * a.ldy2 + a.y2off + nc : nullptr;
-            const size_t dstep2 = (size_t)8 * a.ldy2;
-            const bool sums = a.psum != nullptr;
-            char* cell = slab + q8 * OROW + c8 * 4;
-            // two instances of the row loop: without a second activation (conv -> ReLU -> BN, the TDNN block) the clamp pair is
-            // dead work -- 16 of ~44 VALU instructions per 8 values in a loop that is VALU-bound
-            auto rows = [&](auto clamp2) {
-#pragma unroll 2
-                for (int j = 0; j < 8; ++j) {
-                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(cell);
-                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(cell + 16);
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = fmaxf(a0[e] + bs[e], lo1) * sc[e] + sh[e];
-                        v[e + 4] = fmaxf(a1[e] + bs[e + 4], lo1) * sc[e + 4] + sh[e + 4];
-                        if constexpr (decltype(clamp2)::value) {
-                            v[e] = fminf(fmaxf(v[e], lo2), hi2);
-                            v[e + 4] = fminf(fmaxf(v[e + 4], lo2), hi2);
-                        }
-                    }
-                    bf16x8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-                    *reinterpret_cast<bf16x8*>(dst) = o;
-                    dst += dstep;
-                    if (split) { *reinterpret_cast<bf16x8*>(dst2) = o; dst2 += dstep2; }
-                    if (sums) {
-                        *reinterpret_cast<f32x4*>(cell) = f32x4{v[0] - sh[0], v[1] - sh[1], v[2] - sh[2], v[3] - sh[3]};
-                        *reinterpret_cast<f32x4*>(cell + 16) = f32x4{v[4] - sh[4], v[5] - sh[5], v[6] - sh[6], v[7] - sh[7]};
-                    }
-                    cell += 8 * OROW;
-                }
-            };
-            if (a.act2 == VP_ACT_NONE) rows(std::false_type{});
-            else rows(std::true_type{});
-        } else {
-        int m = mw + q4;
-        int b = (m < a.M ? m : a.M - 1) / a.T_out;
-        int t = m - b * a.T_out;                               // may run past T_out for rows >= M: never used then
-#pragma unroll 1
-        for (int j = 0; j < 16; ++j) {
-            char* cell = slab + (j * 4 + q4) * OROW + c4 * 4;
-            const f32x4 av = *reinterpret_cast<const f32x4*>(cell);
-            const bool ok = nvalid && m < a.M;
-            float v[4];
-            float rbias[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f};
-            if (ok && a.rowbias) load4(a.rowbias + (size_t)b * a.N + nb, rbias);
-            if (ok && RES) load4(RES + (size_t)m * a.ld_res + a.res_off + nb, rs);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = av[r] + bias4[r] + rbias[r];
-                if (a.act == VP_ACT_RELU) x = fmaxf(x, 0.f);
-                x = x * sc4[r] + sh4[r] + rs[r];
-                if (a.act2 == VP_ACT_TANH) x = vp_tanh_for<bf16_t>(x);
-                else if (a.act2 == VP_ACT_RELU) x = fmaxf(x, 0.f);
-                else if (a.act2 == VP_ACT_HARDTANH20) x = fminf(fmaxf(x, 0.f), 20.f);
-                else if (a.act2 == VP_ACT_SILU) x = vp_silu_for<bf16_t>(x);
-                v[r] = x;
-            }
-            if (ok) {
-                store4(Y + (size_t)m * a.ldy + a.yoff + nb, v);
-                if (nb < a.ysplit) store4(Y2 + (size_t)m * a.ldy2 + a.y2off + nb, v);
-                if (AUX) {
-                    float ad[4];
-                    load4(ADD + (size_t)m * a.ld_add + a.add_off + nb, ad);
-                    float s4[4] = {v[0] + ad[0], v[1] + ad[1], v[2] + ad[2], v[3] + ad[3]};
-                    store4(AUX + (size_t)m * a.ld_aux + a.aux_off + nb, s4);
-                }
-            }
-            if (a.psum)
-                *reinterpret_cast<f32x4*>(cell) = ok ? f32x4{v[0] - sh4[0], v[1] - sh4[1], v[2] - sh4[2], v[3] - sh4[3]}
-                                                     : f32x4{0.f, 0.f, 0.f, 0.f};
-            m += 4; t += 4;
-            while (t >= a.T_out) { t -= a.T_out; ++b; }
-        }
-        }
-#ifdef VP_TIMING
-        if (h == 0) te1 = wall_clock64();
-#endif
-        if (a.psum) {
-            // lane = channel h*64 + lane of this wave's 128.  T_out >= 128 > 64 rows: at most one utterance
-            // boundary inside the wave's rows, at the wave-uniform row rb
-            const int col = wn * 128 + h * 64 + lane;
-            const int bb = (mw < a.M ? mw : a.M - 1) / a.T_out;
-            const int rb = min(64, (bb + 1) * a.T_out - mw);     // rows [0, rb) belong to utterance bb
-            const char* colp = slab + lane * 4;
-            float s1 = 0.f, s2 = 0.f;
-            int r = 0;
-#pragma unroll 4
-            for (; r < rb; ++r) {
-                const float d = *reinterpret_cast<const float*>(colp + r * OROW);
-                s1 += d; s2 += d * d;
-            }
-            if (bb - bfirst < 2) {
-                red[((0 * 4 + wm) * 2 + (bb - bfirst)) * T2 + col] = s1;
-                red[((1 * 4 + wm) * 2 + (bb - bfirst)) * T2 + col] = s2;
-            }
-            if (rb < 64) {
-                s1 = 0.f; s2 = 0.f;
-#pragma unroll 4
-                for (; r < 64; ++r) {
-                    const float d = *reinterpret_cast<const float*>(colp + r * OROW);
-                    s1 += d; s2 += d * d;
-                }
-                if (bb + 1 - bfirst < 2) {
-                    red[((0 * 4 + wm) * 2 + (bb + 1 - bfirst)) * T2 + col] = s1;
-                    red[((1 * 4 + wm) * 2 + (bb + 1 - bfirst)) * T2 + col] = s2;
-                }
-            }
-        }
-    }
-    if (a.psum) {
-        // per 128-row half (= one M-tile of the 128-wide kernel's psum layout): the two waves' partials.
-        // T_out >= 128 (host-checked, nseg == 2): a wave's 64 rows touch at most two utterances and
-        // flush each (wave, segment) slot at most once; slots never flushed must read as zero.
-        __syncthreads();
-        const int col = tid & 255, half = tid >> 8;
-        if (n0 + col < a.N && m0 + half * 128 < a.M) {
-            const int bf = (m0 + half * 128) / a.T_out;
-            for (int sgi = 0; sgi < 2; ++sgi) {
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int w = 0; w < 2; ++w) {
-                    const int wmx = half * 2 + w;
-                    const int mlo = m0 + wmx * 64, mhi = min(mlo + 63, a.M - 1);
-                    // did wave wmx own rows of utterance bf + sgi?
-                    if (mlo < a.M && mlo / a.T_out <= bf + sgi && bf + sgi <= mhi / a.T_out) {
-                        s1 += red[((0 * 4 + wmx) * 2 + sgi) * T2 + col];
-                        s2 += red[((1 * 4 + wmx) * 2 + sgi) * T2 + col];
-                    }
-                }
-                const size_t o = ((size_t)(tm * 2 + half) * a.nseg + sgi) * a.N + n0 + col;
-                a.psum[o] = s1;
-                if (a.psumsq) a.psumsq[o] = s2;
-            }
-        }
-    }
+    epilogue256(a, acc, smem, tid, tm, m0, n0);
 #ifdef VP_TIMING
     if (!a.aux && a.add_in) {          // debug build only: per-workgroup phase stamps (100 MHz counter)
         __syncthreads();
         if (tid == 0) {
             unsigned long long* o = (unsigned long long*)a.add_in + (size_t)blockIdx.x * 8;
-            o[0] = tk0; o[1] = tk1; o[2] = tk2; o[3] = wall_clock64(); o[4] = te0; o[5] = ck2 - ck1; o[6] = te1; o[7] = (twait << 32) | tbar;
+            o[0] = tk0; o[1] = tk1; o[2] = tk2; o[3] = wall_clock64(); o[4] = te0; o[5] = ck2 - ck1; o[6] = te0; o[7] = (twait << 32) | tbar;
         }
     }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// Half-tile ring schedule (schedules 4 / 5).
+// A K-step is 64 wide (one 128-byte line per tile row -- a ring of 64-byte rows was measured first and fetches every
+// line twice: TCP -> TCC read requests 43.6 M vs 22.0 M per MFA launch).  Per K-step t the operands are FOUR half-tiles of
+// 128 rows x 128 B = 16 KB: XA / XB = the first / second 32 of every wave row-group's 64 positions, WA / WB = the first /
+// second 64 of every wave column-group's 128 channels.  LDS holds two K-steps of them (8 buffers, 128 KB).  A K-step is
+// four phases of 16 MFMAs per wave (one quadrant of the wave's 64 x 128 tile, both k-halves):
+//   phase    computes    reads into the idle registers     DMA (2 pieces of 8 rows per wave)
+//   P1(t)    XA x WA     XB(t)                             XA(t+2) -> the buffer XA(t) left in P4(t-1)
+//   P2(t)    XB x WA     WB(t)                             XB(t+2)
+//   P3(t)    XB x WB     WA(t+1)                           WB(t+2)
+//   P4(t)    XA x WB     XA(t+1)                           WA(t+3)
+// Every fragment is read one phase before its first MFMA, every half-tile is staged seven phases before it is read: at
+// the end of a phase only the half-tile issued six phases earlier must have landed (own pieces: vmcnt(12); the barrier
+// publishes everyone's).  WAR: a buffer is re-staged in the phase after the one that read it; those reads retired
+// (lgkmcnt(0)) before the barrier in between.  Raw s_barrier: __syncthreads() would drain the DMAs in flight.
+// 96 fragment registers: WA and WB have a set each; XA / XB swap two sets every K-step (XA(t+1) is read while XA(t) is
+// still in use, into the set XB(t) just left), hence the loop body is two K-steps = eight phases.
+// Steps past K (odd step counts, the tail's prefetches) are out-of-range DMAs = zeros.
+constexpr int HT = 128 * ROWB;               // one half-tile: 128 rows x 128 B
+constexpr int K_XA = 0, K_XB = 1, K_WA = 2, K_WB = 3;
+
+// PERSIST: one workgroup per CU walks the tile list with stride gridDim.x (a multiple of 8, so a workgroup stays on the
+// XCD whose run of the tile order it serves) instead of one workgroup per tile.
+// VAR: 0 = every wave runs memory half, then MFMA half; 1 = the same with the younger half of the workgroup at priority 1;
+//      2 = MFMA half first.  (Giving the two waves of a SIMD opposite orders needs two copies of the loop: hipcc then spills
+//      fragment registers inside it -- scratch reloads wait vmcnt(0) and drain the DMA ring.)
+template <int MODE, bool PERSIST, int VAR>
+__global__ __launch_bounds__(512) void conv_gemm256_ring_kernel(const ConvArgs a) {
+    constexpr int MI = 4, NI = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const int li = lane & 15, g = lane >> 4;
+    const int ntiles = a.tiles_m * a.tiles_n;
+    for (int bid = blockIdx.x; bid < ntiles; bid += PERSIST ? (int)gridDim.x : ntiles) {
+#ifdef VP_TIMING
+    const unsigned long long tk0 = wall_clock64();
+#endif
+    const int nblk = ntiles;
+    const int qq = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
+    const int swz = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    const int gsz = a.group_m * a.tiles_n;
+    const int grp = swz / gsz, rem = swz - grp * gsz;
+    const int gm = min(a.group_m, a.tiles_m - grp * a.group_m);
+    const int tn = rem / gm;
+    const int tm = grp * a.group_m + (rem - tn * gm);
+    const int m0 = tm * T2, n0 = tn * T2;
+
+    constexpr unsigned OOB = 0xfffffff0u;
+    const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.w_bytes, 0x00020000);
+
+    // staging: wave wv fills rows [16 wv, 16 wv + 16) of every half-tile, 8 rows x 128 B per DMA; lane l lands at row
+    // l >> 3, position l & 7 and therefore fetches chunk position ^ row (the read applies the same XOR)
+    const int srow = lane >> 3;
+    const unsigned cb = (unsigned)((lane & 7) ^ srow) << 4;
+    const bool zero_pad = a.pad_mode == VP_PAD_ZERO;
+    const unsigned ldxb = (unsigned)a.ldx * 2u;
+    unsigned xo[2][2], wo[2][2];             // [half][piece]
+    int xp[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = wv * 16 + i * 8 + srow;                          // row of the half-tile
+            const int m = m0 + (r >> 5) * 64 + h * 32 + (r & 31);
+            const bool ok = m < a.M;
+            const int mm = ok ? m : 0;
+            const int b = mm / a.T_out;
+            const int t = mm - b * a.T_out;
+            xp[h][i] = t * a.stride - a.pad_left;
+            const unsigned ro = ok ? ((unsigned)(b * a.T_in) * (unsigned)a.ldx + (unsigned)a.xoff) * 2u : OOB;
+            if constexpr (MODE == MODE_1X1) {
+                const int traw = xp[h][i];
+                int ts = traw < 0 ? -traw : traw;
+                ts = ts >= a.T_in ? 2 * (a.T_in - 1) - ts : ts;
+                const bool inr = traw >= 0 && traw < a.T_in;
+                xo[h][i] = (ok && (inr || !zero_pad)) ? ro + (unsigned)ts * ldxb + cb : OOB;
+            } else {
+                xo[h][i] = ro;
+            }
+            const int n = n0 + (r >> 6) * 128 + h * 64 + (r & 63);
+            wo[h][i] = n < a.N ? (unsigned)n * (unsigned)a.K * 2u + cb : OOB;
+        }
+    const int KT = a.KT;
+    const int KTp = (KT + 1) & ~1;
+
+    // the wave's two pieces of half-tile `kind` of K-step t
+    auto issue_piece = [&](int t, int set, int kind, int i) {
+        char* dst = smem + (set * 4 + kind) * HT + (wv * 16 + i * 8) * ROWB;
+        const bool tv = t < KT;
+        const unsigned kb = (unsigned)t * (unsigned)ROWB;
+        const int h = kind & 1;
+        if (kind >= K_WA) {
+            const unsigned off = wo[h][i];
+            bool ok = tv && off != OOB;
+            if constexpr (MODE == MODE_TAPS_GEN) ok = ok && (t * 8 + (int)(cb >> 4)) < a.KC;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)dst, 16, ok ? off + kb : OOB, 0, 0, 0);
+        } else if constexpr (MODE == MODE_1X1) {
+            const unsigned off = xo[h][i];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_ptr_t)dst, 16, (tv && off != OOB) ? off + kb : OOB, 0, 0, 0);
+        } else {
+            int j;
+            unsigned cbyte;
+            bool kv = true;
+            if constexpr (MODE == MODE_TAPS_GEN) {           // this lane's 16-B chunk q of the K axis: tap q / (Cin / 8)
+                const int q = t * 8 + (int)(cb >> 4);
+                kv = q < a.KC;
+                j = q / a.cpt;
+                cbyte = (unsigned)(q - j * a.cpt) << 4;
+            } else {                                         // Cin % 64 == 0: one tap per K-step
+                const int k0 = t * 64;
+                j = k0 / a.Cin;
+                cbyte = (unsigned)(k0 - j * a.Cin) * 2u + cb;
+            }
+            const int traw = xp[h][i] + j * a.dilation;
+            int ts = traw < 0 ? -traw : traw;
+            ts = ts >= a.T_in ? 2 * (a.T_in - 1) - ts : ts;
+            const bool inr = traw >= 0 && traw < a.T_in;
+            const bool ok = tv && kv && xo[h][i] != OOB && (inr || !zero_pad);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_ptr_t)dst, 16, ok ? xo[h][i] + (unsigned)ts * ldxb + cbyte : OOB, 0, 0, 0);
+        }
+    };
+
+    // fragment reads: X half-tile rows wm * 32 + mi2 * 16 + li, W half-tile rows wn * 64 + ni4 * 16 + li
+    // (eight base registers: operand x k-half x K-step set -- a set is 64 KB, the reach of a ds_read immediate)
+    const int sw0 = (g ^ (li & 7)) << 4, sw1 = ((4 + g) ^ (li & 7)) << 4;
+    const char* const bx0 = smem + (wm * 32 + li) * ROWB + sw0;
+    const char* const bx1 = smem + (wm * 32 + li) * ROWB + sw1;
+    const char* const bw0 = smem + (wn * 64 + li) * ROWB + sw0;
+    const char* const bw1 = smem + (wn * 64 + li) * ROWB + sw1;
+    const char* const cx0 = bx0 + 4 * HT;
+    const char* const cx1 = bx1 + 4 * HT;
+    const char* const cw0 = bw0 + 4 * HT;
+    const char* const cw1 = bw1 + 4 * HT;
+    auto read_x = [&](int set, int kind, Frag<bf16_t> (&f)[4]) {
+        const char* S0 = (set ? cx0 : bx0) + kind * HT;
+        const char* S1 = (set ? cx1 : bx1) + kind * HT;
+#pragma unroll
+        for (int mi2 = 0; mi2 < 2; ++mi2) {
+            f[mi2 * 2 + 0].v = *reinterpret_cast<const bf16x8*>(S0 + mi2 * 16 * ROWB);
+            f[mi2 * 2 + 1].v = *reinterpret_cast<const bf16x8*>(S1 + mi2 * 16 * ROWB);
+        }
+    };
+    auto read_w = [&](int set, int kind, Frag<bf16_t> (&f)[8]) {
+        const char* S0 = (set ? cw0 : bw0) + kind * HT;
+        const char* S1 = (set ? cw1 : bw1) + kind * HT;
+#pragma unroll
+        for (int ni4 = 0; ni4 < 4; ++ni4) {
+            f[ni4 * 2 + 0].v = *reinterpret_cast<const bf16x8*>(S0 + ni4 * 16 * ROWB);
+            f[ni4 * 2 + 1].v = *reinterpret_cast<const bf16x8*>(S1 + ni4 * 16 * ROWB);
+        }
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // MFMAs e0 .. e1 of a quadrant's 16, the eight ks = 0 ones first: the two MFMAs of an accumulator are 8 apart
+    auto quad_mma = [&](const Frag<bf16_t> (&x)[4], const Frag<bf16_t> (&w)[8], int mi0, int ni0, int e0, int e1) {
+#pragma unroll
+        for (int e = e0; e < e1; ++e) {
+            const int ks = e >> 3, mi2 = (e >> 2) & 1, ni4 = e & 3;
+            mma(w[ni4 * 2 + ks], x[mi2 * 2 + ks], acc[mi0 + mi2][ni0 + ni4]);
+        }
+    };
+
+    // prologue: the eight half-tiles of K-steps 0 and 1 in the order they are read, then the first two reads
+    constexpr int first8[8][2] = {{0, K_WA}, {0, K_XA}, {0, K_XB}, {0, K_WB}, {1, K_WA}, {1, K_XA}, {1, K_XB}, {1, K_WB}};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        issue_piece(first8[q][0], first8[q][0], first8[q][1], 0);
+        issue_piece(first8[q][0], first8[q][0], first8[q][1], 1);
+    }
+    Frag<bf16_t> xpf[4], xqf[4], waf[8], wbf[8];
+    asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_w(0, K_WA, waf);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue_piece(2, 0, K_WA, 0);                               // phase "P4(-1)": WA(0)'s buffer is free, XA(0) has landed
+    issue_piece(2, 0, K_WA, 1);
+    read_x(0, K_XA, xpf);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef VP_TIMING
+    const unsigned long long tk1 = wall_clock64();
+    const unsigned long long ck1 = clock64();
+#endif
+
+    // One phase = a memory half (the reads, one or two per MFMA, then the two DMA pieces two MFMAs apart) and an MFMA-only
+    // half; the sched_barrier(0) fences pin the groups (left alone, hipcc sinks the reads and drags MFMAs across the s_barrier).
+    //   RX: 4 reads of an X half-tile into xr[]; !RX: 8 reads of a W half-tile into wr[]
+    //   rset / dset: the K-step set (0 / 1) read from / staged into -- literals at every call site
+    auto phase = [&](auto roleB, auto rx, int rset, int rkind, Frag<bf16_t> (&xr)[4], Frag<bf16_t> (&wr)[8],
+                     int td, int dset, int dkind, const Frag<bf16_t> (&xc)[4], const Frag<bf16_t> (&wc)[8], int mi0, int ni0) {
+        constexpr bool RB_ = decltype(roleB)::value;
+        constexpr bool RX = decltype(rx)::value;
+        constexpr int NR = RX ? 4 : 8;
+        auto mem_half = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (RX) read_x(rset, rkind, xr); else read_w(rset, rkind, wr);
+            quad_mma(xc, wc, mi0, ni0, 0, 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                                       // MFMA, then one (X) or two (W) reads, four times
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if constexpr (NR == 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            issue_piece(td, dset, dkind, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            quad_mma(xc, wc, mi0, ni0, 4, 6);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_piece(td, dset, dkind, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            quad_mma(xc, wc, mi0, ni0, 6, 8);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if constexpr (!RB_) {
+            mem_half();
+            quad_mma(xc, wc, mi0, ni0, 8, 16);
+        } else {
+            __builtin_amdgcn_sched_barrier(0);
+            quad_mma(xc, wc, mi0, ni0, 8, 16);
+            mem_half();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto steps = [&](auto roleB) {
+        constexpr std::true_type X{};
+        constexpr std::false_type W{};
+        for (int t = 0; t < KTp; t += 2) {
+            // even K-step t (set 0): XA in xpf, XB -> xqf
+            phase(roleB, X, 0, K_XB, xqf, wbf, t + 2, 0, K_XA, xpf, waf, 0, 0);
+            phase(roleB, W, 0, K_WB, xqf, wbf, t + 2, 0, K_XB, xqf, waf, 2, 0);
+            phase(roleB, W, 1, K_WA, xqf, waf, t + 2, 0, K_WB, xqf, wbf, 2, 4);
+            phase(roleB, X, 1, K_XA, xqf, wbf, t + 3, 1, K_WA, xpf, wbf, 0, 4);
+            // odd K-step t + 1 (set 1): XA in xqf, XB -> xpf
+            phase(roleB, X, 1, K_XB, xpf, wbf, t + 3, 1, K_XA, xqf, waf, 0, 0);
+            phase(roleB, W, 1, K_WB, xpf, wbf, t + 3, 1, K_XB, xpf, waf, 2, 0);
+            phase(roleB, W, 0, K_WA, xpf, waf, t + 3, 1, K_WB, xpf, wbf, 2, 4);
+            phase(roleB, X, 0, K_XA, xpf, wbf, t + 4, 0, K_WA, xqf, wbf, 0, 4);
+        }
+    };
+    if constexpr (VAR == 1) {
+        if (wv >= 4) __builtin_amdgcn_s_setprio(1);
+    }
+    steps(std::integral_constant<bool, VAR == 2>{});
+    if constexpr (VAR == 1) __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // zero-fill DMAs of the tail still target the buffers
+#ifdef VP_TIMING
+    const unsigned long long tk2 = wall_clock64();
+    const unsigned long long ck2 = clock64();
+    const unsigned long long te0 = tk2;
+#endif
+    epilogue256(a, acc, smem, tid, tm, m0, n0);
+#ifdef VP_TIMING
+    if (!a.aux && a.add_in) {
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long* o = (unsigned long long*)a.add_in + (size_t)bid * 8;
+            o[0] = tk0; o[1] = tk1; o[2] = tk2; o[3] = wall_clock64(); o[4] = te0; o[5] = ck2 - ck1; o[6] = te0; o[7] = 0;
+        }
+    }
+#endif
+    if constexpr (PERSIST) __syncthreads();        // the epilogue's LDS image is dead before the next tile's DMAs land on it
+    }
+}
+
+static int cu_count(vp_ctx* ctx) {
+    static int n = 0;
+    if (n == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || v <= 0) v = 256;
+        n = v - v % 8;                 // stride % 8 == 0 keeps a resident workgroup on its XCD's run of the tile order
+        if (n < 8) n = 8;
+    }
+    return n;
+}
+
+template <int MODE, int VAR>
+int launch256_ring_persist(vp_ctx* ctx, const ConvArgs& a, hipStream_t st) {
+    constexpr int smem = 8 * 64 * 272 + 2 * 4 * 2 * T2 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm256_ring_kernel<MODE, true, VAR>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    const int ntiles = a.tiles_m * a.tiles_n;
+    const int grid = ntiles < cu_count(ctx) ? ntiles : cu_count(ctx);
+    hipLaunchKernelGGL((conv_gemm256_ring_kernel<MODE, true, VAR>), dim3(grid), dim3(512), smem, st, a);
+    VP_LAUNCH_CHECK(ctx, "conv_gemm256_ring_persist");
+    return VP_OK;
+}
+
+template <int MODE, int VAR>
+int launch256_ring(vp_ctx* ctx, const ConvArgs& a, hipStream_t st) {
+    constexpr int smem = 8 * 64 * 272 + 2 * 4 * 2 * T2 * 4;      // output slabs + column-sum partials (> the 128 KB ring)
+    static bool attr_set = false;
+    if (!attr_set) {
+        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm256_ring_kernel<MODE, false, VAR>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_gemm256_ring_kernel<MODE, false, VAR>), dim3(a.tiles_m * a.tiles_n), dim3(512), smem, st, a);
+    VP_LAUNCH_CHECK(ctx, "conv_gemm256_ring");
+    return VP_OK;
 }
 
 template <int MODE, int SCHED>
@@ -601,6 +932,20 @@ int vp_conv_launch256_bf16(vp_ctx* ctx, const void* args, int mode, int sched, h
     } else if (sched == 1) {
         if (mode == MODE_1X1) return launch256<MODE_1X1, 1>(ctx, a, st);
         if (mode == MODE_TAPS) return launch256<MODE_TAPS, 1>(ctx, a, st);
+    } else if (sched >= 3 && sched <= 8) {
+        // 3 + 2 * VAR + resident: half-tile ring, one workgroup per tile (even offsets) or resident workgroups (odd)
+        const int var = (sched - 3) >> 1;
+        const bool res = (sched - 3) & 1;
+#define VP_RING(M)                                                                                                   \
+        (res ? (var == 0 ? launch256_ring_persist<M, 0>(ctx, a, st) : var == 1 ? launch256_ring_persist<M, 1>(ctx, a, st) \
+                                                                              : launch256_ring_persist<M, 2>(ctx, a, st))    \
+             : (var == 0 ? launch256_ring<M, 0>(ctx, a, st) : var == 1 ? launch256_ring<M, 1>(ctx, a, st)                 \
+                                                                      : launch256_ring<M, 2>(ctx, a, st)))
+        if (mode == MODE_1X1) return VP_RING(MODE_1X1);
+#undef VP_RING
+        // tapped convs stay on the two-stage schedule: their per-piece tap / reflect arithmetic pushes the ring loop past
+        // 256 VGPRs (scratch reloads inside the loop wait vmcnt(0) and drain the ring)
+        if (mode == MODE_TAPS) return a.Cin % 64 == 0 ? launch256<MODE_TAPS, 2>(ctx, a, st) : launch256<MODE_TAPS_GEN, 2>(ctx, a, st);
     } else {
         if (mode == MODE_1X1) return launch256<MODE_1X1, 2>(ctx, a, st);
         if (mode == MODE_TAPS) return a.Cin % 64 == 0 ? launch256<MODE_TAPS, 2>(ctx, a, st) : launch256<MODE_TAPS_GEN, 2>(ctx, a, st);

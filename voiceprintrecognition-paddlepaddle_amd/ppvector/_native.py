@@ -243,6 +243,7 @@ _PROTOS = {
     'vp_cosine_logits_bwd_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'vp_cosine_logits_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                      c_size_t, c_void_p]),
+    'vp_conv256_select': (c_int, [c_int]),
     'vp_cosine_scores_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'vp_cosine_scores_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                      c_size_t, c_void_p]),
@@ -308,6 +309,21 @@ def ctx(device=None):
 
 def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
+
+
+# Kernels that write parameters or buffers through raw pointers (the flat Adam step, the BatchNorm running statistics of a
+# train-mode forward) do not move torch's per-tensor version counters.  Every such writer bumps this epoch; caches of packed
+# weights (ppvector/models/engine.py) carry it in their key.
+_weights_epoch = 0
+
+
+def bump_weights_epoch():
+    global _weights_epoch
+    _weights_epoch += 1
+
+
+def weights_epoch():
+    return _weights_epoch
 
 
 def check(rc, c=None):

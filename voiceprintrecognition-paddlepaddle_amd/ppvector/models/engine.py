@@ -3,7 +3,7 @@
 A packed engine owns contiguous device copies of the weights in the layout the kernels want
 (conv weights [Cout][k*Cin] in the network dtype, BN folded to f32 scale/shift, the ASP context
 columns split off, asp_bn / bn5 / bn6 folded into the last dense layer).  Packing is redone only
-when a parameter's version counter moves.
+when a parameter's version counter or the package's raw-pointer weights epoch moves.
 """
 import ctypes as C
 
@@ -17,7 +17,9 @@ _TORCH_DT = {'float32': torch.float32, 'bfloat16': torch.bfloat16}
 
 
 def _versions(module):
-    return tuple(t._version for t in list(module.parameters()) + list(module.buffers()))
+    """Cache key of a packed engine: torch's version counters (in-place torch writes, load_state_dict) plus the epoch of
+    raw-pointer writers (Adam step, train-mode BatchNorm statistics), which the counters do not see."""
+    return (N.weights_epoch(),) + tuple(t._version for t in list(module.parameters()) + list(module.buffers()))
 
 
 class _Engine:
@@ -471,6 +473,7 @@ class EngineMixin:
                 raise NotImplementedError(f'training-mode forward/backward on the HIP engine is not built for {type(self).__name__} '
                                           '(TDNN, EcapaTdnn, CAMPPlus, ResNetSE, ERes2Net and ERes2NetV2 are: DESIGN.md section 7a); '
                                           'call .eval() for embedding extraction')
+            N.bump_weights_epoch()                 # the train-mode forward rewrites the BatchNorm running statistics in place
             return fwd(x)
         with torch.no_grad():
             eng = self.engine()

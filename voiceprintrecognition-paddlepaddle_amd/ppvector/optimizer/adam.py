@@ -49,6 +49,7 @@ class Adam:
         N.check(N.lib().vp_adam_step_f32(ctx, self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                          self.flat.numel(), float(self.get_lr()), self.beta1, self.beta2, self.eps, self.wd, self.t,
                                          float(grad_scale), N.stream_ptr()), ctx)
+        N.bump_weights_epoch()                     # parameters changed behind torch's version counters: packed engines are stale
 
     def _offset(self, p):
         return (p.data.data_ptr() - self.flat.data_ptr()) // 4
