@@ -150,8 +150,8 @@ int vp_conv1d_tiles_m(int B, int T_out);            /* rows of the psum arrays  
 int vp_conv1d_nseg(int T_out);                      /* utterance segments per M-tile               */
 int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream);
 /* Tuning knob (not part of the reference surface): K-loop schedule of the 256-wide bf16 kernel vp_conv1d_fwd dispatches the
- * wide layers to -- -1 = per launch (default), 0 = never (128-wide kernel), 1..3 = the two-stage schedules, 4..9 = half-tile
- * ring variants (csrc/conv_gemm.hip).  Process-wide; returns the previous value; out-of-range values only query.  Results
+ * wide layers to -- -1 = default, 0 = never (128-wide kernel), 1..3 = the two-stage schedules, 4 = half-tile
+ * ring, 5 = half-tile ring with resident workgroups (csrc/conv_gemm.hip).  Process-wide; returns the previous value; out-of-range values only query.  Results
  * are identical for every schedule. */
 int vp_conv256_select(int schedule);
 

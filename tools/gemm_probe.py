@@ -31,6 +31,10 @@ for cin, cout in shapes:
     d.pad_mode = N.VP_PAD_REFLECT
     d.x, d.ldx, d.w, d.y, d.ldy = x.data_ptr(), cin, w.data_ptr(), y.data_ptr(), cout
     d.bias, d.act, d.bn_scale, d.bn_shift = bias.data_ptr(), N.VP_ACT_RELU, sc.data_ptr(), sh.data_ptr()
+    if os.environ.get('PSUM'):                      # the fused time sums of tdnn2 / MFA inside the step
+        tiles, nseg = lib.vp_conv1d_tiles_m(B, T), lib.vp_conv1d_nseg(T)
+        ps = torch.empty((tiles, nseg, cout), device='cuda'); pq = torch.empty((tiles, nseg, cout), device='cuda')
+        d.psum, d.psumsq = ps.data_ptr(), pq.data_ptr()
     times = {s: [] for s in scheds}
     worst = {s: 0.0 for s in scheds}
     for r in range(rounds):

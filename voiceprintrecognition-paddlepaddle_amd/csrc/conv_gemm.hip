@@ -30,9 +30,8 @@ int vp_conv_launch_f32_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipS
 int vp_conv_launch256_bf16(vp_ctx* ctx, const void* args, int mode, int sched, hipStream_t st);
 
 // Schedule of the 256-wide kernel: 0 pins the 128-wide kernel; 1 = interleaved DMA, 2 = ping-pong phases, 3 = role-split
-// DMA (two 64 KB stages), 4 + 2 v + r = half-tile ring, variant v (0..2), r = 1: resident workgroups.  Default (-1): per
-// launch -- the ring (9) from 16 K-steps up, the two-stage schedule (3) for shorter contractions, whose tiles are mostly
-// prologue and epilogue (measured, MI355X: 1536 -> 1536 314 vs 346 us; 512 -> 512 66 vs 63 us).
+// DMA (two 64 KB stages; the tapped convs always take it), 4 = half-tile ring, 5 = half-tile ring with resident workgroups.
+// Default (-1) = 4: measured on MI355X, 1536 -> 1536 / 512 -> 512 with fused time sums: 3: 376 / 78 us, 4: 340 / 75, 5: 361 / 85.
 // VPMI_CONV256 presets it; vp_conv256_select() switches at run time (A/B in one process).
 static int g_conv256 = -2;
 static int use_conv256() {
@@ -44,7 +43,7 @@ extern "C" {
 
 int vp_conv256_select(int schedule) {
     const int prev = use_conv256();
-    if (schedule >= -1 && schedule <= 9) g_conv256 = schedule;
+    if (schedule >= -1 && schedule <= 5) g_conv256 = schedule;
     return prev;
 }
 
@@ -133,7 +132,7 @@ int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream) {
         a.group_m = 32 / a.tiles_n;
         if (a.group_m < 1) a.group_m = 1;
         if (a.group_m > 16) a.group_m = 16;
-        const int sched = use_conv256() < 0 ? (a.KT >= 16 ? 9 : 3) : use_conv256();
+        const int sched = use_conv256() < 0 ? 4 : use_conv256();
         return vp_conv_launch256_bf16(ctx, &a, mode, sched - 1, st);
     }
     if (d->dtype_in == VP_BF16 && d->dtype_out == VP_BF16) return vp_conv_launch_bf16_bf16(ctx, &a, bn, mode, st);

@@ -22,27 +22,30 @@ constexpr int STAGE2 = 2 * T2 * ROWB;        // X panel + W panel
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 // Epilogue of one 256 x 256 tile, shared by every K-loop schedule.  Entered by all 512 threads with the wave's 64 x 128
-// accumulators in registers; the K panels in LDS are dead (the function's first barrier orders that).
-__device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8], char* smem, int tid, int tm, int m0, int n0) {
-    constexpr int MI = 4;
+// accumulators in registers, after a barrier behind which the LDS range [ebase, ebase + 8 RS 272 + 16 KB) is dead.
+//   y = act2( bn( act( acc + bias + rowbias ) ) + res );  aux = y + add_in;  psum/psumsq over (y - shift)
+// (conv_gemm_impl.h semantics, no gate).  Written as ROLLED loops over an LDS image of the accumulators: the fully
+// unrolled per-register form of the 128-wide kernel is ~25k instructions for 128 accumulators per lane and ran 15 us per
+// tile on instruction fetch alone.  Per 64-channel half h and per pass of RS of the wave's 64 rows:
+//   A. dump RS x 64 f32 accumulators into the wave's own LDS slab (row stride 272 B: conflict-free both ways);
+//   B. rolled row loop -- fast form (whole block inside the problem, per-channel terms only): lane = (row 8j + lane/8,
+//      channels 8 (lane%8)..+7), one 16-B store per lane, 8 lanes = 128 contiguous bytes of a position; general form:
+//      lane = (row 4j + lane/16, 4 channels), masks / rowbias / residual / aux / tanh / SiLU; (y - shift) goes back to the slab;
+//   C. column sums: lane = one channel, the pass's rows split at the wave's utterance boundary, kept in registers.
+// RS = 64 uses 155,648 B from ebase (the whole LDS); RS = 32 uses 86,016 B: the resident-workgroup ring kernel runs it beside
+// the first four half-tiles of its NEXT tile, which `prefetch` (called once, after the first parameter loads went out, so
+// that their vmcnt wait does not cover the DMAs) stages into the other 64 KB.
+template <int RS, typename Prefetch>
+__device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8], char* ebase, int tid, int tm, int m0, int n0,
+                                            Prefetch&& prefetch) {
+    constexpr int OROW = 272;
+    constexpr int NP = 64 / RS;                                // row passes per 64-channel half
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 1, wn = wv & 1;
     const int li = lane & 15, g = lane >> 4;
-    // ------------------------------------------------------------------ epilogue
-    // y = act2( bn( act( acc + bias + rowbias ) ) + res );  aux = y + add_in;  psum/psumsq over (y - shift)
-    // (conv_gemm_impl.h semantics, no gate).  Written as ROLLED loops over an LDS image of the
-    // accumulators: the fully unrolled per-register form of the 128-wide kernel is ~25k instructions for
-    // 128 accumulators per lane and ran 15 us per tile on instruction fetch alone.  Per 64-channel half:
-    //   A. dump the wave's 64 x 64 f32 accumulators into its own LDS slab (row stride 272 B);
-    //   B. 16 iterations: lane = (row j*4 + lane/16, channels 4*(lane%16)..+3): math, 8-B store (16 lanes
-    //      cover 128 contiguous bytes of a position), (y - shift) written back to the slab;
-    //   C. column sums: lane = one channel, 64 rows, per utterance segment, into red[wm][seg][col].
-    constexpr int OROW = 272;
-    constexpr int SLABS = 8 * 64 * OROW;
-    __syncthreads();                                           // every wave is done reading the K panels
-    char* slab = smem + wv * (64 * OROW);
-    float* red = reinterpret_cast<float*>(smem + SLABS);       // [2 stats][4 wm][2 seg][256 col]
+    char* slab = ebase + wv * (RS * OROW);
+    float* red = reinterpret_cast<float*>(ebase + 8 * RS * OROW);     // [2 stats][4 wm][2 seg][256 col]
     bf16_t* __restrict__ Y = static_cast<bf16_t*>(a.y);
     bf16_t* __restrict__ Y2 = static_cast<bf16_t*>(a.y2);
     const bf16_t* __restrict__ ADD = static_cast<const bf16_t*>(a.add_in);
@@ -51,158 +54,214 @@ __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8
     const int mw = m0 + wm * 64;                               // first position of this wave
     const int bfirst = (m0 + (wm >> 1) * 128) / a.T_out;       // first utterance of the 128-row half
     const int q4 = lane >> 4, c4 = (lane & 15) * 4;
+    // T_out >= 128 > 64 rows (host-checked when psum is set): at most one utterance boundary inside the wave's rows, at
+    // the wave-uniform row rb -- rows [0, rb) belong to utterance bb
+    const int bb = (mw < a.M ? mw : a.M - 1) / a.T_out;
+    const int rb = min(64, (bb + 1) * a.T_out - mw);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-                *reinterpret_cast<f32x4*>(slab + (mi * 16 + li) * OROW + (ni * 16 + g * 4) * 4) = acc[mi][h * 4 + ni];
         const int nb = n0 + wn * 128 + h * 64 + c4;
         const bool nvalid = nb < a.N;
+        const int nh = n0 + wn * 128 + h * 64;
+        const int c8 = (lane & 7) * 8, q8 = lane >> 3;
+        const int nc = nh + c8;
+        // per-channel parameters of both lane layouts (general: 4 channels at nb; fast: 8 channels at nc)
         float bias4[4] = {0.f, 0.f, 0.f, 0.f}, sc4[4] = {1.f, 1.f, 1.f, 1.f}, sh4[4] = {0.f, 0.f, 0.f, 0.f};
         if (nvalid) {
             if (a.bias) load4(a.bias + nb, bias4);
             if (a.bn_scale) load4(a.bn_scale + nb, sc4);
             if (a.bn_shift) load4(a.bn_shift + nb, sh4);
         }
-        // FAST rows: the whole 64 x 64 block is inside the problem and only the per-channel terms are
-        // active (bias, ReLU, BN affine, ReLU) -- lane = (row 8j + lane/8, channels 8*(lane%8)..+7), one
-        // 16-B store per lane, 8 lanes = 128 contiguous bytes of a position.  ~40 VALU per 8 values; the
-        // general loop below spends ~25 per VALUE on masks and 64-bit addressing.
-        const int nh = n0 + wn * 128 + h * 64;
-        const bool fast = mw + 64 <= a.M && nh + 64 <= a.N && !a.rowbias && !RES && !AUX && a.act2 != VP_ACT_TANH && a.act2 != VP_ACT_SILU &&
-                          (a.ysplit <= nh || a.ysplit >= nh + 64) && ((a.ldy | a.yoff) & 7) == 0 &&
-                          (reinterpret_cast<uintptr_t>(a.y) & 15) == 0 &&
-                          (a.ysplit <= nh || (((a.ldy2 | a.y2off) & 7) == 0 && (reinterpret_cast<uintptr_t>(a.y2) & 15) == 0));
-        if (fast) {
-            const int c8 = (lane & 7) * 8, q8 = lane >> 3;
-            const int nc = nh + c8;
-            float bs[8], sc[8], sh[8];
+        const bool fast_cols = nh + 64 <= a.N && !a.rowbias && !RES && !AUX && a.act2 != VP_ACT_TANH && a.act2 != VP_ACT_SILU &&
+                               (a.ysplit <= nh || a.ysplit >= nh + 64) && ((a.ldy | a.yoff) & 7) == 0 &&
+                               (reinterpret_cast<uintptr_t>(a.y) & 15) == 0 &&
+                               (a.ysplit <= nh || (((a.ldy2 | a.y2off) & 7) == 0 && (reinterpret_cast<uintptr_t>(a.y2) & 15) == 0));
+        float bs[8], sc[8], sh[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { bs[e] = 0.f; sc[e] = 1.f; sh[e] = 0.f; }
+        for (int e = 0; e < 8; ++e) { bs[e] = 0.f; sc[e] = 1.f; sh[e] = 0.f; }
+        if (fast_cols) {
             if (a.bias) { load4(a.bias + nc, bs); load4(a.bias + nc + 4, bs + 4); }
             if (a.bn_scale) { load4(a.bn_scale + nc, sc); load4(a.bn_scale + nc + 4, sc + 4); }
             if (a.bn_shift) { load4(a.bn_shift + nc, sh); load4(a.bn_shift + nc + 4, sh + 4); }
-            const float lo1 = a.act == VP_ACT_RELU ? 0.f : -INFINITY;
-            const float lo2 = (a.act2 == VP_ACT_RELU || a.act2 == VP_ACT_HARDTANH20) ? 0.f : -INFINITY;
-            const float hi2 = a.act2 == VP_ACT_HARDTANH20 ? 20.f : INFINITY;
-            bf16_t* dst = Y + (size_t)(mw + q8) * a.ldy + a.yoff + nc;
-            const size_t dstep = (size_t)8 * a.ldy;
-            const bool split = a.ysplit > nh;
-            bf16_t* dst2 = split ? Y2 + (size_t)(mw + q8) * a.ldy2 + a.y2off + nc : nullptr;
-            const size_t dstep2 = (size_t)8 * a.ldy2;
-            const bool sums = a.psum != nullptr;
-            char* cell = slab + q8 * OROW + c8 * 4;
-            // two instances of the row loop: without a second activation (conv -> ReLU -> BN, the TDNN block) the clamp pair is
-            // dead work -- 16 of ~44 VALU instructions per 8 values in a loop that is VALU-bound
-            auto rows = [&](auto clamp2) {
-#pragma unroll 2
-                for (int j = 0; j < 8; ++j) {
-                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(cell);
-                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(cell + 16);
-                    float v[8];
+        }
+        if (h == 0) prefetch();
+        float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;      // general rows: column sums of this lane's channel, utterance bb / bb + 1
+        // fast rows: sums of this lane's 8 channels over its rows -- p = every row, q = the rows of utterance bb (only when the
+        // wave's rows straddle two utterances); reduced over the 8 lanes of a channel group after the passes
+        float p1[8], p2[8], q1[8], q2[8];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = fmaxf(a0[e] + bs[e], lo1) * sc[e] + sh[e];
-                        v[e + 4] = fmaxf(a1[e] + bs[e + 4], lo1) * sc[e + 4] + sh[e + 4];
-                        if constexpr (decltype(clamp2)::value) {
-                            v[e] = fminf(fmaxf(v[e], lo2), hi2);
-                            v[e + 4] = fminf(fmaxf(v[e + 4], lo2), hi2);
+        for (int e = 0; e < 8; ++e) { p1[e] = 0.f; p2[e] = 0.f; q1[e] = 0.f; q2[e] = 0.f; }
+        const bool fastw = fast_cols && mw + 64 <= a.M;        // wave-uniform: every pass of this half takes the fast rows
+#pragma unroll
+        for (int rp = 0; rp < NP; ++rp) {
+            const int mwp = mw + rp * RS;                      // first position of this pass
+#pragma unroll
+            for (int mi = 0; mi < RS / 16; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    *reinterpret_cast<f32x4*>(slab + (mi * 16 + li) * OROW + (ni * 16 + g * 4) * 4) = acc[rp * (RS / 16) + mi][h * 4 + ni];
+            if (fastw) {
+                const float lo1 = a.act == VP_ACT_RELU ? 0.f : -INFINITY;
+                const float lo2 = (a.act2 == VP_ACT_RELU || a.act2 == VP_ACT_HARDTANH20) ? 0.f : -INFINITY;
+                const float hi2 = a.act2 == VP_ACT_HARDTANH20 ? 20.f : INFINITY;
+                bf16_t* dst = Y + (size_t)(mwp + q8) * a.ldy + a.yoff + nc;
+                const size_t dstep = (size_t)8 * a.ldy;
+                const bool split = a.ysplit > nh;
+                bf16_t* dst2 = split ? Y2 + (size_t)(mwp + q8) * a.ldy2 + a.y2off + nc : nullptr;
+                const size_t dstep2 = (size_t)8 * a.ldy2;
+                const bool sums = a.psum != nullptr;
+                char* cell = slab + q8 * OROW + c8 * 4;
+                // two instances of the row loop: without a second activation (conv -> ReLU -> BN, the TDNN block) the clamp
+                // pair is dead work -- 16 of ~44 VALU instructions per 8 values in a loop that is VALU-bound
+                auto rows = [&](auto clamp2, auto straddle) {
+                    int row = rp * RS + q8;                    // of the wave's 64
+#pragma unroll 2
+                    for (int j = 0; j < RS / 8; ++j) {
+                        const f32x4 a0 = *reinterpret_cast<const f32x4*>(cell);
+                        const f32x4 a1 = *reinterpret_cast<const f32x4*>(cell + 16);
+                        float v[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = fmaxf(a0[e] + bs[e], lo1) * sc[e] + sh[e];
+                            v[e + 4] = fmaxf(a1[e] + bs[e + 4], lo1) * sc[e + 4] + sh[e + 4];
+                            if constexpr (decltype(clamp2)::value) {
+                                v[e] = fminf(fmaxf(v[e], lo2), hi2);
+                                v[e + 4] = fminf(fmaxf(v[e + 4], lo2), hi2);
+                            }
+                        }
+                        bf16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+                        *reinterpret_cast<bf16x8*>(dst) = o;
+                        dst += dstep;
+                        if (split) { *reinterpret_cast<bf16x8*>(dst2) = o; dst2 += dstep2; }
+                        if (sums) {
+                            const float mk = row < rb ? 1.f : 0.f;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float d = v[e] - sh[e];
+                                p1[e] += d; p2[e] += d * d;
+                                if constexpr (decltype(straddle)::value) {
+                                    const float dm = d * mk;
+                                    q1[e] += dm; q2[e] += dm * d;
+                                }
+                            }
+                        }
+                        row += 8;
+                        cell += 8 * OROW;
+                    }
+                };
+                if (rb >= 64 || !sums) {
+                    if (a.act2 == VP_ACT_NONE) rows(std::false_type{}, std::false_type{});
+                    else rows(std::true_type{}, std::false_type{});
+                } else {
+                    if (a.act2 == VP_ACT_NONE) rows(std::false_type{}, std::true_type{});
+                    else rows(std::true_type{}, std::true_type{});
+                }
+            } else {
+                int m = mwp + q4;
+                int b = (m < a.M ? m : a.M - 1) / a.T_out;
+                int t = m - b * a.T_out;                       // may run past T_out for rows >= M: never used then
+#pragma unroll 1
+                for (int j = 0; j < RS / 4; ++j) {
+                    char* cell = slab + (j * 4 + q4) * OROW + c4 * 4;
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(cell);
+                    const bool ok = nvalid && m < a.M;
+                    float v[4];
+                    float rbias[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (ok && a.rowbias) load4(a.rowbias + (size_t)b * a.N + nb, rbias);
+                    if (ok && RES) load4(RES + (size_t)m * a.ld_res + a.res_off + nb, rs);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float x = av[r] + bias4[r] + rbias[r];
+                        if (a.act == VP_ACT_RELU) x = fmaxf(x, 0.f);
+                        x = x * sc4[r] + sh4[r] + rs[r];
+                        if (a.act2 == VP_ACT_TANH) x = vp_tanh_for<bf16_t>(x);
+                        else if (a.act2 == VP_ACT_RELU) x = fmaxf(x, 0.f);
+                        else if (a.act2 == VP_ACT_HARDTANH20) x = fminf(fmaxf(x, 0.f), 20.f);
+                        else if (a.act2 == VP_ACT_SILU) x = vp_silu_for<bf16_t>(x);
+                        v[r] = x;
+                    }
+                    if (ok) {
+                        store4(Y + (size_t)m * a.ldy + a.yoff + nb, v);
+                        if (nb < a.ysplit) store4(Y2 + (size_t)m * a.ldy2 + a.y2off + nb, v);
+                        if (AUX) {
+                            float ad[4];
+                            load4(ADD + (size_t)m * a.ld_add + a.add_off + nb, ad);
+                            float s4[4] = {v[0] + ad[0], v[1] + ad[1], v[2] + ad[2], v[3] + ad[3]};
+                            store4(AUX + (size_t)m * a.ld_aux + a.aux_off + nb, s4);
                         }
                     }
-                    bf16x8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-                    *reinterpret_cast<bf16x8*>(dst) = o;
-                    dst += dstep;
-                    if (split) { *reinterpret_cast<bf16x8*>(dst2) = o; dst2 += dstep2; }
-                    if (sums) {
-                        *reinterpret_cast<f32x4*>(cell) = f32x4{v[0] - sh[0], v[1] - sh[1], v[2] - sh[2], v[3] - sh[3]};
-                        *reinterpret_cast<f32x4*>(cell + 16) = f32x4{v[4] - sh[4], v[5] - sh[5], v[6] - sh[6], v[7] - sh[7]};
-                    }
-                    cell += 8 * OROW;
-                }
-            };
-            if (a.act2 == VP_ACT_NONE) rows(std::false_type{});
-            else rows(std::true_type{});
-        } else {
-        int m = mw + q4;
-        int b = (m < a.M ? m : a.M - 1) / a.T_out;
-        int t = m - b * a.T_out;                               // may run past T_out for rows >= M: never used then
-#pragma unroll 1
-        for (int j = 0; j < 16; ++j) {
-            char* cell = slab + (j * 4 + q4) * OROW + c4 * 4;
-            const f32x4 av = *reinterpret_cast<const f32x4*>(cell);
-            const bool ok = nvalid && m < a.M;
-            float v[4];
-            float rbias[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f};
-            if (ok && a.rowbias) load4(a.rowbias + (size_t)b * a.N + nb, rbias);
-            if (ok && RES) load4(RES + (size_t)m * a.ld_res + a.res_off + nb, rs);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = av[r] + bias4[r] + rbias[r];
-                if (a.act == VP_ACT_RELU) x = fmaxf(x, 0.f);
-                x = x * sc4[r] + sh4[r] + rs[r];
-                if (a.act2 == VP_ACT_TANH) x = vp_tanh_for<bf16_t>(x);
-                else if (a.act2 == VP_ACT_RELU) x = fmaxf(x, 0.f);
-                else if (a.act2 == VP_ACT_HARDTANH20) x = fminf(fmaxf(x, 0.f), 20.f);
-                else if (a.act2 == VP_ACT_SILU) x = vp_silu_for<bf16_t>(x);
-                v[r] = x;
-            }
-            if (ok) {
-                store4(Y + (size_t)m * a.ldy + a.yoff + nb, v);
-                if (nb < a.ysplit) store4(Y2 + (size_t)m * a.ldy2 + a.y2off + nb, v);
-                if (AUX) {
-                    float ad[4];
-                    load4(ADD + (size_t)m * a.ld_add + a.add_off + nb, ad);
-                    float s4[4] = {v[0] + ad[0], v[1] + ad[1], v[2] + ad[2], v[3] + ad[3]};
-                    store4(AUX + (size_t)m * a.ld_aux + a.aux_off + nb, s4);
+                    if (a.psum)
+                        *reinterpret_cast<f32x4*>(cell) = ok ? f32x4{v[0] - sh4[0], v[1] - sh4[1], v[2] - sh4[2], v[3] - sh4[3]}
+                                                             : f32x4{0.f, 0.f, 0.f, 0.f};
+                    m += 4; t += 4;
+                    while (t >= a.T_out) { t -= a.T_out; ++b; }
                 }
             }
-            if (a.psum)
-                *reinterpret_cast<f32x4*>(cell) = ok ? f32x4{v[0] - sh4[0], v[1] - sh4[1], v[2] - sh4[2], v[3] - sh4[3]}
-                                                     : f32x4{0.f, 0.f, 0.f, 0.f};
-            m += 4; t += 4;
-            while (t >= a.T_out) { t -= a.T_out; ++b; }
-        }
-        }
-        if (a.psum) {
-            // lane = channel h*64 + lane of this wave's 128.  T_out >= 128 > 64 rows: at most one utterance
-            // boundary inside the wave's rows, at the wave-uniform row rb
-            const int col = wn * 128 + h * 64 + lane;
-            const int bb = (mw < a.M ? mw : a.M - 1) / a.T_out;
-            const int rb = min(64, (bb + 1) * a.T_out - mw);     // rows [0, rb) belong to utterance bb
-            const char* colp = slab + lane * 4;
-            float s1 = 0.f, s2 = 0.f;
-            int r = 0;
+            if (a.psum && !fastw) {
+                // lane = channel h*64 + lane of this wave's 128; rows of this pass before / after the utterance boundary
+                const int rbp = min(RS, max(0, rb - rp * RS));
+                const char* colp = slab + lane * 4;
+                int r = 0;
 #pragma unroll 4
-            for (; r < rb; ++r) {
-                const float d = *reinterpret_cast<const float*>(colp + r * OROW);
-                s1 += d; s2 += d * d;
-            }
-            if (bb - bfirst < 2) {
-                red[((0 * 4 + wm) * 2 + (bb - bfirst)) * T2 + col] = s1;
-                red[((1 * 4 + wm) * 2 + (bb - bfirst)) * T2 + col] = s2;
-            }
-            if (rb < 64) {
-                s1 = 0.f; s2 = 0.f;
-#pragma unroll 4
-                for (; r < 64; ++r) {
+                for (; r < rbp; ++r) {
                     const float d = *reinterpret_cast<const float*>(colp + r * OROW);
-                    s1 += d; s2 += d * d;
+                    s1a += d; s2a += d * d;
                 }
-                if (bb + 1 - bfirst < 2) {
-                    red[((0 * 4 + wm) * 2 + (bb + 1 - bfirst)) * T2 + col] = s1;
-                    red[((1 * 4 + wm) * 2 + (bb + 1 - bfirst)) * T2 + col] = s2;
+#pragma unroll 4
+                for (; r < RS; ++r) {
+                    const float d = *reinterpret_cast<const float*>(colp + r * OROW);
+                    s1b += d; s2b += d * d;
                 }
+            }
+        }
+        if (a.psum && fastw) {
+            // the 8 lanes of a channel group (equal lane & 7) hold partial sums over disjoint rows
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) {
+                    p1[e] += __shfl_xor(p1[e], o); p2[e] += __shfl_xor(p2[e], o);
+                    if (rb < 64) { q1[e] += __shfl_xor(q1[e], o); q2[e] += __shfl_xor(q2[e], o); }
+                }
+            }
+            if (lane < 8) {
+                const int col = wn * 128 + h * 64 + c8;
+                float* ra = &red[((0 * 4 + wm) * 2 + (bb - bfirst)) * T2 + col];
+                float* rq = &red[((1 * 4 + wm) * 2 + (bb - bfirst)) * T2 + col];
+                if (rb >= 64) {
+                    if (bb - bfirst < 2) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { ra[e] = p1[e]; rq[e] = p2[e]; }
+                    }
+                } else {
+                    if (bb - bfirst < 2) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { ra[e] = q1[e]; rq[e] = q2[e]; }
+                    }
+                    if (bb + 1 - bfirst < 2) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { ra[T2 + e] = p1[e] - q1[e]; rq[T2 + e] = p2[e] - q2[e]; }
+                    }
+                }
+            }
+        } else if (a.psum) {
+            const int col = wn * 128 + h * 64 + lane;
+            if (bb - bfirst < 2) {
+                red[((0 * 4 + wm) * 2 + (bb - bfirst)) * T2 + col] = s1a;
+                red[((1 * 4 + wm) * 2 + (bb - bfirst)) * T2 + col] = s2a;
+            }
+            if (rb < 64 && bb + 1 - bfirst < 2) {
+                red[((0 * 4 + wm) * 2 + (bb + 1 - bfirst)) * T2 + col] = s1b;
+                red[((1 * 4 + wm) * 2 + (bb + 1 - bfirst)) * T2 + col] = s2b;
             }
         }
     }
     if (a.psum) {
         // per 128-row half (= one M-tile of the 128-wide kernel's psum layout): the two waves' partials.
         // T_out >= 128 (host-checked, nseg == 2): a wave's 64 rows touch at most two utterances and
-        // flush each (wave, segment) slot at most once; slots never flushed must read as zero.
+        // flush each (wave, segment) slot at most once; slots never flushed are never read.
         __syncthreads();
         const int col = tid & 255, half = tid >> 8;
         if (n0 + col < a.N && m0 + half * 128 < a.M) {
@@ -568,7 +627,8 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(const ConvArgs a) {
 #ifdef VP_TIMING
     const unsigned long long te0 = wall_clock64();
 #endif
-    epilogue256(a, acc, smem, tid, tm, m0, n0);
+    __syncthreads();                                           // every wave is done reading the K panels
+    epilogue256<64>(a, acc, smem, tid, tm, m0, n0, [] {});
 #ifdef VP_TIMING
     if (!a.aux && a.add_in) {          // debug build only: per-workgroup phase stamps (100 MHz counter)
         __syncthreads();
@@ -604,10 +664,10 @@ constexpr int K_XA = 0, K_XB = 1, K_WA = 2, K_WB = 3;
 
 // PERSIST: one workgroup per CU walks the tile list with stride gridDim.x (a multiple of 8, so a workgroup stays on the
 // XCD whose run of the tile order it serves) instead of one workgroup per tile.
-// VAR: 0 = every wave runs memory half, then MFMA half; 1 = the same with the younger half of the workgroup at priority 1;
-//      2 = MFMA half first.  (Giving the two waves of a SIMD opposite orders needs two copies of the loop: hipcc then spills
-//      fragment registers inside it -- scratch reloads wait vmcnt(0) and drain the DMA ring.)
-template <int MODE, bool PERSIST, int VAR>
+// Every wave runs a phase's MFMA-only half first, then its memory half (measured against memory-half-first and against the
+// younger waves at priority 1: 314 / 326 / 322 us on the MFA GEMM).  Giving the two waves of a SIMD opposite orders needs two
+// copies of the loop: hipcc then spills fragment registers inside it -- scratch reloads wait vmcnt(0) and drain the DMA ring.
+template <int MODE, bool PERSIST>
 __global__ __launch_bounds__(512) void conv_gemm256_ring_kernel(const ConvArgs a) {
     constexpr int MI = 4, NI = 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -617,20 +677,6 @@ __global__ __launch_bounds__(512) void conv_gemm256_ring_kernel(const ConvArgs a
     const int wm = wv >> 1, wn = wv & 1;
     const int li = lane & 15, g = lane >> 4;
     const int ntiles = a.tiles_m * a.tiles_n;
-    for (int bid = blockIdx.x; bid < ntiles; bid += PERSIST ? (int)gridDim.x : ntiles) {
-#ifdef VP_TIMING
-    const unsigned long long tk0 = wall_clock64();
-#endif
-    const int nblk = ntiles;
-    const int qq = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
-    const int swz = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-    const int gsz = a.group_m * a.tiles_n;
-    const int grp = swz / gsz, rem = swz - grp * gsz;
-    const int gm = min(a.group_m, a.tiles_m - grp * a.group_m);
-    const int tn = rem / gm;
-    const int tm = grp * a.group_m + (rem - tn * gm);
-    const int m0 = tm * T2, n0 = tn * T2;
-
     constexpr unsigned OOB = 0xfffffff0u;
     const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.w_bytes, 0x00020000);
@@ -643,6 +689,18 @@ __global__ __launch_bounds__(512) void conv_gemm256_ring_kernel(const ConvArgs a
     const unsigned ldxb = (unsigned)a.ldx * 2u;
     unsigned xo[2][2], wo[2][2];             // [half][piece]
     int xp[2][2];
+    int tm, m0, n0;
+    // tile `bid` of the XCD-aware grouped order (conv_gemm_impl.h) and this wave's DMA source offsets in it
+    auto setup = [&](int bid) {
+    const int nblk = ntiles;
+    const int qq = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
+    const int swz = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    const int gsz = a.group_m * a.tiles_n;
+    const int grp = swz / gsz, rem = swz - grp * gsz;
+    const int gm = min(a.group_m, a.tiles_m - grp * a.group_m);
+    const int tn = rem / gm;
+    tm = grp * a.group_m + (rem - tn * gm);
+    m0 = tm * T2; n0 = tn * T2;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -667,6 +725,7 @@ __global__ __launch_bounds__(512) void conv_gemm256_ring_kernel(const ConvArgs a
             const int n = n0 + (r >> 6) * 128 + h * 64 + (r & 63);
             wo[h][i] = n < a.N ? (unsigned)n * (unsigned)a.K * 2u + cb : OOB;
         }
+    };
     const int KT = a.KT;
     const int KTp = (KT + 1) & ~1;
 
@@ -738,10 +797,6 @@ __global__ __launch_bounds__(512) void conv_gemm256_ring_kernel(const ConvArgs a
     };
 
     f32x4 acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // MFMAs e0 .. e1 of a quadrant's 16, the eight ks = 0 ones first: the two MFMAs of an accumulator are 8 apart
     auto quad_mma = [&](const Frag<bf16_t> (&x)[4], const Frag<bf16_t> (&w)[8], int mi0, int ni0, int e0, int e1) {
@@ -752,13 +807,30 @@ __global__ __launch_bounds__(512) void conv_gemm256_ring_kernel(const ConvArgs a
         }
     };
 
-    // prologue: the eight half-tiles of K-steps 0 and 1 in the order they are read, then the first two reads
-    constexpr int first8[8][2] = {{0, K_WA}, {0, K_XA}, {0, K_XB}, {0, K_WB}, {1, K_WA}, {1, K_XA}, {1, K_XB}, {1, K_WB}};
+    // prologue: the eight half-tiles of K-steps 0 and 1 in the order they are read (K-step 0 = set 0 may have been staged
+    // during the previous tile's epilogue), then the first two reads
+    constexpr int first4[4] = {K_WA, K_XA, K_XB, K_WB};
+    auto stage_set = [&](int s) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        issue_piece(first8[q][0], first8[q][0], first8[q][1], 0);
-        issue_piece(first8[q][0], first8[q][0], first8[q][1], 1);
+        for (int q = 0; q < 4; ++q) {
+            issue_piece(s, s, first4[q], 0);
+            issue_piece(s, s, first4[q], 1);
+        }
+    };
+    int bid = blockIdx.x;
+    if (bid < ntiles) {
+        setup(bid);
+        stage_set(0);
     }
+    while (bid < ntiles) {
+#ifdef VP_TIMING
+    const unsigned long long tk0 = wall_clock64();
+#endif
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    stage_set(1);
     Frag<bf16_t> xpf[4], xqf[4], waf[8], wbf[8];
     asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -841,18 +913,29 @@ __global__ __launch_bounds__(512) void conv_gemm256_ring_kernel(const ConvArgs a
             phase(roleB, X, 0, K_XA, xpf, wbf, t + 4, 0, K_WA, xqf, wbf, 0, 4);
         }
     };
-    if constexpr (VAR == 1) {
-        if (wv >= 4) __builtin_amdgcn_s_setprio(1);
-    }
-    steps(std::integral_constant<bool, VAR == 2>{});
-    if constexpr (VAR == 1) __builtin_amdgcn_s_setprio(0);
+    steps(std::true_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // zero-fill DMAs of the tail still target the buffers
 #ifdef VP_TIMING
     const unsigned long long tk2 = wall_clock64();
     const unsigned long long ck2 = clock64();
     const unsigned long long te0 = tk2;
 #endif
-    epilogue256(a, acc, smem, tid, tm, m0, n0);
+    const int ctm = tm, cm0 = m0, cn0 = n0;
+    const int nbid = PERSIST ? bid + (int)gridDim.x : ntiles;
+    __syncthreads();                                           // every wave is done reading the ring
+    if constexpr (PERSIST) {
+        // resident workgroup: the epilogue's LDS image lives in the set-1 buffers and the spare 32 KB while set 0 of the NEXT
+        // tile is staged behind it -- that tile's first MFMA then waits for no HBM round trip
+        epilogue256<32>(a, acc, smem + 4 * HT, tid, ctm, cm0, cn0, [&] {
+            if (nbid < ntiles) {
+                setup(nbid);
+                stage_set(0);
+            }
+        });
+        __syncthreads();                                       // the epilogue's LDS image is dead before set 1 is staged on it
+    } else {
+        epilogue256<64>(a, acc, smem, tid, ctm, cm0, cn0, [] {});
+    }
 #ifdef VP_TIMING
     if (!a.aux && a.add_in) {
         __syncthreads();
@@ -862,7 +945,7 @@ __global__ __launch_bounds__(512) void conv_gemm256_ring_kernel(const ConvArgs a
         }
     }
 #endif
-    if constexpr (PERSIST) __syncthreads();        // the epilogue's LDS image is dead before the next tile's DMAs land on it
+    bid = nbid;
     }
 }
 
@@ -877,32 +960,32 @@ static int cu_count(vp_ctx* ctx) {
     return n;
 }
 
-template <int MODE, int VAR>
+template <int MODE>
 int launch256_ring_persist(vp_ctx* ctx, const ConvArgs& a, hipStream_t st) {
     constexpr int smem = 8 * 64 * 272 + 2 * 4 * 2 * T2 * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm256_ring_kernel<MODE, true, VAR>),
+        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm256_ring_kernel<MODE, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
     const int ntiles = a.tiles_m * a.tiles_n;
     const int grid = ntiles < cu_count(ctx) ? ntiles : cu_count(ctx);
-    hipLaunchKernelGGL((conv_gemm256_ring_kernel<MODE, true, VAR>), dim3(grid), dim3(512), smem, st, a);
+    hipLaunchKernelGGL((conv_gemm256_ring_kernel<MODE, true>), dim3(grid), dim3(512), smem, st, a);
     VP_LAUNCH_CHECK(ctx, "conv_gemm256_ring_persist");
     return VP_OK;
 }
 
-template <int MODE, int VAR>
+template <int MODE>
 int launch256_ring(vp_ctx* ctx, const ConvArgs& a, hipStream_t st) {
     constexpr int smem = 8 * 64 * 272 + 2 * 4 * 2 * T2 * 4;      // output slabs + column-sum partials (> the 128 KB ring)
     static bool attr_set = false;
     if (!attr_set) {
-        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm256_ring_kernel<MODE, false, VAR>),
+        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm256_ring_kernel<MODE, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_gemm256_ring_kernel<MODE, false, VAR>), dim3(a.tiles_m * a.tiles_n), dim3(512), smem, st, a);
+    hipLaunchKernelGGL((conv_gemm256_ring_kernel<MODE, false>), dim3(a.tiles_m * a.tiles_n), dim3(512), smem, st, a);
     VP_LAUNCH_CHECK(ctx, "conv_gemm256_ring");
     return VP_OK;
 }
@@ -932,17 +1015,9 @@ int vp_conv_launch256_bf16(vp_ctx* ctx, const void* args, int mode, int sched, h
     } else if (sched == 1) {
         if (mode == MODE_1X1) return launch256<MODE_1X1, 1>(ctx, a, st);
         if (mode == MODE_TAPS) return launch256<MODE_TAPS, 1>(ctx, a, st);
-    } else if (sched >= 3 && sched <= 8) {
-        // 3 + 2 * VAR + resident: half-tile ring, one workgroup per tile (even offsets) or resident workgroups (odd)
-        const int var = (sched - 3) >> 1;
-        const bool res = (sched - 3) & 1;
-#define VP_RING(M)                                                                                                   \
-        (res ? (var == 0 ? launch256_ring_persist<M, 0>(ctx, a, st) : var == 1 ? launch256_ring_persist<M, 1>(ctx, a, st) \
-                                                                              : launch256_ring_persist<M, 2>(ctx, a, st))    \
-             : (var == 0 ? launch256_ring<M, 0>(ctx, a, st) : var == 1 ? launch256_ring<M, 1>(ctx, a, st)                 \
-                                                                      : launch256_ring<M, 2>(ctx, a, st)))
-        if (mode == MODE_1X1) return VP_RING(MODE_1X1);
-#undef VP_RING
+    } else if (sched == 3 || sched == 4) {
+        // half-tile ring: one workgroup per tile (3) or resident workgroups (4)
+        if (mode == MODE_1X1) return sched == 3 ? launch256_ring<MODE_1X1>(ctx, a, st) : launch256_ring_persist<MODE_1X1>(ctx, a, st);
         // tapped convs stay on the two-stage schedule: their per-piece tap / reflect arithmetic pushes the ring loop past
         // 256 VGPRs (scratch reloads inside the loop wait vmcnt(0) and drain the ring)
         if (mode == MODE_TAPS) return a.Cin % 64 == 0 ? launch256<MODE_TAPS, 2>(ctx, a, st) : launch256<MODE_TAPS_GEN, 2>(ctx, a, st);
