@@ -1,25 +1,39 @@
 #!/usr/bin/env python
 """Headline benchmark: utterances/s (3 s @ 16 kHz) through the hot path on N MI355X.
 
-One "step" = one pass of the hot path over one batch of synthetic input already resident in HBM:
-    waveforms (B, 48000) f32 -> HIP Fbank+CMN -> HIP ECAPA-TDNN forward (bf16 MFMA, f32 accumulate,
-    eval-mode BN) -> cosine head (2796 classes) + AAM-softmax loss.
-Workload = BASELINE.json configs[1] (ECAPA-TDNN + Fbank, 2796 classes, batch 256, bf16).  Utterances
-are independent, so N GPUs run N shards of the data with no data-path collective (weak scaling:
-batch 256 per GPU); the only cross-rank traffic is the timing barrier / max-reduce.
+--mode infer (default; BASELINE.json's metric).  One "step" = one pass of the hot path over one batch of synthetic input
+already resident in HBM:
+    waveforms (B, 48000) f32 -> HIP Fbank+CMN -> HIP ECAPA-TDNN forward (bf16 MFMA, f32 accumulate, eval-mode BN) ->
+    cosine head (2796 classes) + AAM-softmax loss.
+Workload = BASELINE.json configs[1] (ECAPA-TDNN + Fbank, 2796 classes, batch 256, bf16).  Utterances are independent, so N GPUs
+run N shards of the data with no data-path collective (weak scaling: batch 256 per GPU); the only cross-rank traffic is the
+timing barrier / max-reduce.  Inside a GPU the batch runs as --streams concurrent launch sequences (same kernels, same
+results; ppvector/models/engine.py: forward_streams).
+
+--mode train.  One step = the reference's optimisation step (ppvector/trainer.py:206-274): Fbank+CMN -> train-mode forward
+(batch-statistics BN) -> cosine head + AAM loss -> backward -> data-parallel gradient average (bucketed all-reduce over
+RCCL / xGMI, launched from autograd hooks while backward runs; ppvector/train/ddp.py) -> flat Adam.  Strong scaling by
+default (global batch 256 split over the ranks, as north_star states it); --weak keeps 256 per GPU.
+
+`python bench.py --gpus N` launches its own N ranks (one process per GPU, rendezvous on 127.0.0.1); under
+torch.distributed.run (RANK / WORLD_SIZE in the environment) it joins the existing job instead.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  "roofline"     : the dominant kernel (conv_gemm256_kernel: the 256x256 LDS-DMA conv GEMM, bf16 in / bf16 out --
-                   seven launches per step, 87 % of the forward's flops) timed launch-by-launch with HIP
-                   events on the launching stream, against the dense bf16 MFMA peak; "family" adds the two
-                   launches of the 128-wide kernel (block0, ASP attention TDNN) for the whole conv family;
-  "cpu_baseline" : the CPU oracle (reference algorithm restated on NumPy + PyTorch-CPU fp32 -- NOT
-                   the PaddlePaddle binary) timed on this host's cores on a bounded sample.
+  "roofline"     : the dominant kernel (the 256 x 256 LDS-DMA conv GEMM, bf16 in / bf16 out -- seven launches per step,
+                   87 % of the forward's flops) timed launch-by-launch with HIP events on the launching stream, against
+                   the dense bf16 MFMA peak; "family" adds the two other conv launches (block0, ASP attention TDNN);
+  "cpu_baseline" : the CPU oracle (reference algorithm restated on NumPy + PyTorch-CPU fp32 -- NOT the PaddlePaddle
+                   binary) timed on this host's cores on a bounded sample;
+  train mode     : "rccl_ranks" (world size seen by a real all-reduce), "allreduce_ms" (the gradient buffer's all-reduce
+                   alone), "comm_exposed_ms" (step time minus the same step with the collective switched off) and
+                   "overlap_frac" = 1 - exposed / alone.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,17 +48,28 @@ import torch  # noqa: E402
 
 BATCH, N_SAMPLES, N_MELS, N_CLASSES, EMBD = 256, 48000, 80, 2796, 192
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3            # f32 MFMA (the training engine's matrix cores today)
 ALG_GFLOP_PER_UTT = 2.857          # ECAPA forward, algorithmic
 
 
 def conv_family_shapes(T):
-    """(Cin, Cout, KW, dil, extras) of the launches of conv_gemm_kernel<bf16, bf16, 128> in one ECAPA step,
-    with the epilogue options each one carries inside the step."""
+    """(Cin, Cout, KW, dil, extras) of the conv GEMM launches in one ECAPA step, with the epilogue options each one
+    carries inside the step."""
     s = [(80, 512, 5, 1, ())]
     for d in (2, 3, 4):
         s += [(512, 512, 1, 1, ('ysplit',)), (512, 512, 1, 1, ('psum',))]        # tdnn1, tdnn2 of each SE-Res2 block
     s += [(1536, 1536, 1, 1, ('psum', 'psumsq')), (1536, 128, 1, 1, ('rowbias', 'tanh'))]   # MFA, ASP attention TDNN
     return s
+
+
+def kernel_git_hash():
+    """Hash of the kernel sources the PMC traffic numbers were taken on (profiles/pmc_traffic.json: "csrc_hash")."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ('conv_gemm256.hip', 'conv_gemm_impl.h', 'conv_gemm.hip'):
+        with open(os.path.join(PKG, 'csrc', f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
 
 
 def roofline_pass(reps):
@@ -98,25 +123,28 @@ def roofline_pass(reps):
         total_flop += flop
         per_shape.append({'cin': cin, 'cout': cout, 'kw': kw, 'ms': round(ms, 4), 'tflops': round(flop / ms / 1e9, 1)})
         del x, w, y, keep
-    # dominant kernel = the launches the host dispatches to conv_gemm256_kernel (Cin % 64 == 0, Cout >= 256)
-    dom = [p for p in per_shape if p['cin'] % 64 == 0 and p['cout'] >= 256]
+    # dominant kernel = the 1x1 launches the host dispatches to the half-tile ring kernel (Cin % 64 == 0, Cout >= 256)
+    dom = [p for p in per_shape if p['kw'] == 1 and p['cin'] % 64 == 0 and p['cout'] >= 256]
     fam_ms, fam_flop = total_ms, total_flop
     total_ms = sum(p['ms'] for p in dom)
     total_flop = sum(2.0 * M * p['cout'] * p['kw'] * p['cin'] for p in dom)
     n = len(dom)
     achieved = total_flop / (total_ms * 1e-3) / 1e12
+    # HBM bytes per launch from the PMC passes (tools/pmc_probe.sh): only while the file was taken on THESE kernel sources
     traffic = None
     tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if os.path.exists(tfile):
         try:
-            traffic = json.load(open(tfile)).get('conv_gemm256_bytes_per_launch')
+            tj = json.load(open(tfile))
+            if tj.get('csrc_hash') == kernel_git_hash():
+                traffic = tj.get('conv_gemm256_bytes_per_launch')
         except Exception:
             traffic = None
-    return {'bound': 'mfma', 'kernel': 'conv_gemm256_kernel<MODE_1X1> (7 launches/step: 6 x 512->512 + MFA 1536->1536, 87% of forward flops)',
+    return {'bound': 'mfma', 'kernel': 'conv_gemm256_ring_kernel<MODE_1X1> (7 launches/step: 6 x 512->512 + MFA 1536->1536, 87% of forward flops)',
             'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
             'flop_per_launch': total_flop / n, 'avg_launch_ms': round(total_ms / n, 4),
-            'family': {'kernels': 'conv_gemm256_kernel + conv_gemm_kernel<bf16,bf16,128> (9 launches/step, 90% of forward flops)',
+            'family': {'kernels': 'the 7 ring launches + conv_gemm256_kernel<TAPS_GEN> (block0) + conv_gemm_kernel<bf16,bf16,128> (ASP TDNN): 9 launches/step, 90% of forward flops',
                        'achieved': round(fam_flop / (fam_ms * 1e-3) / 1e12, 2), 'avg_launch_ms': round(fam_ms / len(per_shape), 4)},
             'launches': per_shape}
 
@@ -217,80 +245,261 @@ def run_timed(step, steps, warmup, dist, device):
     return dt, out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float32'])
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-roofline', action='store_true')
-    args = ap.parse_args()
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
 
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs: the engine has no CPU fallback'
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl')          # RCCL
-    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE {world}'
 
+def self_launch(n):
+    """`python bench.py --gpus N` outside a launcher: start N ranks of this same command (one process per GPU, rendezvous on
+    127.0.0.1), let rank 0 print the JSON line on the inherited stdout, return the worst exit code."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
+
+
+def init_dist(world, backend):
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29511')
+    dist.init_process_group(backend=backend)          # "nccl" IS RCCL on ROCm
+    return dist
+
+
+def measured_ranks(dist, device):
+    """World size as a real sum-all-reduce sees it (not just the environment variable)."""
+    one = torch.ones(1, device=device)
+    dist.all_reduce(one)
+    return int(one.item())
+
+
+# ------------------------------------------------------------------------------------------------------------ modes
+def run_dry(args, rank, world, dist):
+    """CPU / gloo rehearsal of the N-rank plumbing (launcher, rendezvous, timing, gradient all-reduce, JSON): no HIP code."""
+    from ppvector.train.ddp import allreduce_mean_
+    dev = torch.device('cpu')
+    grad = torch.full((1 << 18,), float(rank + 1))
+    a = torch.randn(128, 128)
+
+    def step():
+        b = a @ a
+        if dist is not None:
+            grad.fill_(float(rank + 1))
+            allreduce_mean_(grad, bucket_bytes=1 << 18)
+        return b.sum()
+
+    dt, _ = run_timed(step, args.steps, args.warmup, dist, dev)
+    ranks = measured_ranks(dist, dev) if dist is not None else 1
+    if rank == 0:
+        expect = (world + 1) / 2.0
+        assert abs(float(grad[0]) - expect) < 1e-6, (float(grad[0]), expect)
+        print(json.dumps({'metric': 'dry-run steps/sec (CPU, gloo): launcher / timing / all-reduce plumbing only', 'value': round(args.steps / dt, 2),
+                          'unit': 'steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                          'config': {'workload': 'dry run'}, 'rccl_ranks': ranks}), flush=True)
+
+
+def build_ecapa(dev, dtype_name):
     from ppvector.data_utils.featurizer import AudioFeaturizer
-    from ppvector.loss.aamloss import AAMLoss
     from ppvector.models.ecapa_tdnn import EcapaTdnn
     from ppvector.models.fc import SpeakerIdentification
-
-    dev = torch.device('cuda', local_rank)
-    # synthetic inputs, resident in HBM before the timed region (seed per rank: distinct shards)
-    wav = torch.from_numpy(synth_waves(BATCH, N_SAMPLES, seed=shard_seed(1000, rank))).to(dev)
-    labels = (torch.arange(BATCH, device=dev) * 7 + rank) % N_CLASSES
     fz = AudioFeaturizer('Fbank', dict(sr=16000, n_mels=N_MELS))
     model = EcapaTdnn(N_MELS, embd_dim=EMBD, pooling_type='ASP', channels=[512, 512, 512, 512, 1536])
     state = random_state(model, seed=1000)                          # random init, BN running stats randomised
     model.load_state_dict(state)
-    model = model.to(dev).eval()
+    model = model.to(dev)
     head = SpeakerIdentification(EMBD, N_CLASSES)
     head_w = random_state(head, seed=1001)['weight']
     head.load_state_dict({'weight': head_w})
-    head = head.to(dev).eval()            # eval-mode forward: logits without the autograd tape
+    head = head.to(dev)
+    return fz, model, head, state, head_w
+
+
+def run_infer(args, rank, local_rank, world, dist):
+    from ppvector.loss.aamloss import AAMLoss
+    dev = torch.device('cuda', local_rank)
+    # synthetic inputs, resident in HBM before the timed region (seed per rank: distinct shards)
+    wav = torch.from_numpy(synth_waves(BATCH, N_SAMPLES, seed=shard_seed(1000, rank))).to(dev)
+    labels = (torch.arange(BATCH, device=dev) * 7 + rank) % N_CLASSES
+    fz, model, head, state, head_w = build_ecapa(dev, args.dtype)
+    model.eval()
+    head.eval()                            # eval-mode forward: logits without the autograd tape
     crit = AAMLoss(margin=0.2, scale=32, easy_margin=False, label_smoothing=0.0)
     eng = model.engine(args.dtype)
     want16 = args.dtype == 'bfloat16'
 
     def step():
-        feats = fz(wav, want_bf16=want16)
-        emb = eng.forward(feats)
+        if args.streams > 1:               # featurizer + backbone of each shard on its own stream; head + loss over the whole batch
+            emb = eng.forward_streams(wav, args.streams, producer=lambda w: fz(w, want_bf16=want16))
+        else:
+            emb = eng.forward(fz(wav, want_bf16=want16))
         return crit(head(emb), labels)
+
+    run = step
+    if args.graph:
+        # the whole step (every shard's featurizer + backbone on its stream, head + loss behind the join) as ONE captured HIP
+        # graph: with several launch sequences per GPU the host would otherwise issue ~40 launches per shard per step
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_loss = step()
+
+        def run():
+            graph.replay()
+            return static_loss
+
+    dt, loss = run_timed(run, args.steps, args.warmup, dist, dev)
+    loss_v = float(loss)
+    assert np.isfinite(loss_v)
+    if rank != 0:
+        return
+    value = world * BATCH * args.steps / dt
+    out = {
+        'metric': 'utterances/sec (3 s, 16 kHz) ECAPA-TDNN fwd+AAM', 'value': round(value, 1),
+        'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'bf16' if want16 else 'f32', 'data': 'synthetic',
+        'config': {'workload': 'BASELINE configs[1]: ECAPA-TDNN (C=512, MFA 1536, ASP, embd 192) + Kaldi Fbank 80, '
+                               '3 s @ 16 kHz (T=298), 2796-class cosine head + AAMLoss, eval-mode forward, '
+                               f'batch {BATCH} per GPU, inputs resident in HBM, random-init weights',
+                   'batch_per_gpu': BATCH, 'global_batch': BATCH * world, 'parallelism': f'dp{world} (no collective)',
+                   'streams_per_gpu': args.streams, 'hip_graph': bool(args.graph)},
+        'loss': round(loss_v, 5),
+        'stage_roofline_frac': round(value / world * ALG_GFLOP_PER_UTT / 1e3 / PEAK_BF16_TFLOPS, 4),
+    }
+    if world == 1 and not args.no_roofline and want16:
+        out['roofline'] = roofline_pass(reps=10)
+    if world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(state, head_w)
+    print(json.dumps(out), flush=True)
+
+
+def run_train(args, rank, local_rank, world, dist):
+    """The reference's optimisation step over its own object graph (nn.Sequential(backbone, classifier), AAMLoss, flat Adam),
+    data-parallel over the ranks.  Communication is measured three ways: the flat gradient buffer's all-reduce alone, the step
+    with the collective (the reported time) and the same step with the collective switched off."""
+    from ppvector.loss.aamloss import AAMLoss
+    from ppvector.optimizer.adam import Adam
+    from ppvector.train.ddp import allreduce_mean_, shard_batch
+    from ppvector.train.step import TrainStep
+    dev = torch.device('cuda', local_rank)
+    gbatch = args.global_batch * (world if args.weak else 1)
+    idx = shard_batch(gbatch, rank, world)
+    B = len(idx)
+    assert B > 0, f'global batch {gbatch} leaves rank {rank} empty'
+    wav_all = synth_waves(gbatch if not args.weak else B, N_SAMPLES, seed=1000 if not args.weak else shard_seed(1000, rank))
+    wav = torch.from_numpy(wav_all[list(idx)] if not args.weak else wav_all).to(dev)
+    labels = ((torch.arange(gbatch) * 7) % N_CLASSES)[list(idx)].to(dev)
+    fz, backbone, head, _, _ = build_ecapa(dev, 'float32')
+    model = torch.nn.Sequential(backbone, head).to(dev)
+    crit = AAMLoss(margin=0.2, scale=32, easy_margin=False, label_smoothing=0.0)
+    opt = Adam(model.parameters(), learning_rate=1e-4, weight_decay=1e-6)
+    step_obj = TrainStep(model, crit, opt, featurizer=fz)
+    last = {}
+
+    def step():
+        last['loss'], last['acc'] = step_obj(wav, labels)
+        return last['loss']
 
     dt, loss = run_timed(step, args.steps, args.warmup, dist, dev)
     loss_v = float(loss)
     assert np.isfinite(loss_v)
+    ms_step = dt / args.steps * 1e3
+    comm = {}
+    if dist is not None:
+        ranks = measured_ranks(dist, dev)
+        g = opt.grad
+        for _ in range(3):
+            allreduce_mean_(g, bucket_bytes=16 << 20)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            allreduce_mean_(g, bucket_bytes=16 << 20)
+        torch.cuda.synchronize()
+        ar_ms = (time.perf_counter() - t0) / reps * 1e3
+        # the same step without the collective: hooks removed, nothing to finish
+        step_obj.reducer.remove()
+        step_obj.reducer.world = 1
+        dt0, _ = run_timed(step, max(5, args.steps // 4), 2, dist, dev)
+        ms_nocomm = dt0 / max(5, args.steps // 4) * 1e3
+        exposed = max(0.0, ms_step - ms_nocomm)
+        comm = {'rccl_ranks': ranks, 'allreduce_ms': round(ar_ms, 4), 'allreduce_bytes': int(g.numel() * 4),
+                'allreduce_algbw_GBps': round(g.numel() * 4 / ar_ms / 1e6, 2), 'step_ms_without_collective': round(ms_nocomm, 4),
+                'comm_exposed_ms': round(exposed, 4), 'overlap_frac': round(1.0 - min(1.0, exposed / ar_ms), 4) if ar_ms > 0 else None,
+                'grad_buckets': len(step_obj.reducer.buckets)}
+    if rank != 0:
+        return
+    value = gbatch * args.steps / dt
+    out = {
+        'metric': 'utterances/sec (3 s, 16 kHz) ECAPA-TDNN training step (Fbank + fwd + AAM + bwd + DP all-reduce + Adam)',
+        'value': round(value, 1), 'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(ms_step, 4), 'higher_is_better': True, 'scaling': 'weak' if args.weak else 'strong',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'ECAPA-TDNN (C=512, MFA 1536, ASP, embd 192) + Kaldi Fbank 80, 3 s @ 16 kHz (T=298), 2796-class cosine head + '
+                               'AAMLoss, train-mode forward (batch-statistics BN) + backward + flat Adam, f32 matrix cores, '
+                               f'global batch {gbatch}, inputs resident in HBM, random-init weights',
+                   'batch_per_gpu': B, 'global_batch': gbatch,
+                   'parallelism': f'dp{world} (bucketed gradient all-reduce over RCCL, overlapped with backward)' if world > 1 else 'dp1'},
+        'loss': round(loss_v, 5),
+        'stage_roofline_frac': round(value * 3 * ALG_GFLOP_PER_UTT / 1e3 / world / PEAK_F32_TFLOPS, 4),
+        'stage_roofline_peak': 'f32 MFMA 157.3 TFLOP/s per GPU, 3 x forward flops per utterance',
+    }
+    out.update(comm)
+    print(json.dumps(out), flush=True)
 
-    out = None
-    if rank == 0:
-        value = world * BATCH * args.steps / dt
-        out = {
-            'metric': 'utterances/sec (3 s, 16 kHz) ECAPA-TDNN fwd+AAM', 'value': round(value, 1),
-            'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'bf16' if want16 else 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: ECAPA-TDNN (C=512, MFA 1536, ASP, embd 192) + Kaldi Fbank 80, '
-                                   '3 s @ 16 kHz (T=298), 2796-class cosine head + AAMLoss, eval-mode forward, '
-                                   f'batch {BATCH} per GPU, inputs resident in HBM, random-init weights',
-                       'batch_per_gpu': BATCH, 'global_batch': BATCH * world, 'parallelism': f'dp{world} (no collective)'},
-            'loss': round(loss_v, 5),
-            'stage_roofline_frac': round(value / world * ALG_GFLOP_PER_UTT / 1e3 / PEAK_BF16_TFLOPS, 4),
-        }
-        if world == 1 and not args.no_roofline and want16:
-            out['roofline'] = roofline_pass(reps=10)
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(state, head_w)
-        print(json.dumps(out), flush=True)
-    if dist:
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--mode', default='infer', choices=['infer', 'train'])
+    ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float32'])
+    ap.add_argument('--streams', type=int, default=4, help='concurrent launch sequences per GPU (infer mode)')
+    ap.add_argument('--graph', type=int, default=1, help='infer mode: replay the step from one captured HIP graph (1) or launch eagerly (0)')
+    ap.add_argument('--global-batch', type=int, default=BATCH, help='train mode: global batch (strong scaling)')
+    ap.add_argument('--weak', action='store_true', help='train mode: keep --global-batch utterances PER GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--dry-run', action='store_true', help='CPU / gloo rehearsal of the multi-rank plumbing (tests)')
+    args = ap.parse_args()
+
+    world_env = os.environ.get('WORLD_SIZE')
+    if args.gpus > 1 and world_env is None:
+        sys.exit(self_launch(args.gpus))           # no launcher around us: become one
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(world_env or '1')
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE {world}'
+    dist = None
+    if args.dry_run:
+        if world > 1:
+            dist = init_dist(world, 'gloo')
+        run_dry(args, rank, world, dist)
+    else:
+        assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs: the engine has no CPU fallback'
+        torch.cuda.set_device(local_rank)
+        if world > 1:
+            dist = init_dist(world, 'nccl')
+        if args.mode == 'train':
+            run_train(args, rank, local_rank, world, dist)
+        else:
+            run_infer(args, rank, local_rank, world, dist)
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

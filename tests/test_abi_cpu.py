@@ -144,7 +144,25 @@ def test_margin_scheduler_matches_oracle():
         assert abs(ms.get_margin() - om.margin_schedule(step, spe, me)) < 1e-12
         assert abs(crit.margin - ms.get_margin()) < 1e-15
     lr = cosine_decay_with_warmup(0.001, spe, fix_epoch=me, warmup_epoch=5, min_lr=1e-5)
-    assert lr[0] == 0.0 and abs(lr[5 * spe] - 0.001) < 1e-12 and lr[-1] > 1e-5 and len(lr) == spe * me + 1
+    assert lr[0] == 0.0 and abs(lr[5 * spe] - 0.001) < 1e-12 and lr[-1] > 1e-5 and len(lr) == spe * me
+
+
+def test_lr_table_matches_the_reference_schedule(golden_dir):
+    """lr at every scheduler step == the reference's own cosine_decay_with_warmup run through PiecewiseDecay
+    (oracle/gen_lr_golden.py: the duplicated boundary at the end of warm-up, the hold past the table's end)."""
+    import numpy as np
+    from ppvector.optimizer import build_lr_scheduler
+    from ppvector.utils.utils import dict_to_object
+    g = np.load(os.path.join(golden_dir, 'lr_table_ref.npz'))
+    for name in ('ecapa_yaml', 'short_warm'):
+        lr0, spe, fix, warm, min_lr = g[name + '_args']
+        cfg = dict_to_object(dict(optimizer_conf=dict(scheduler='WarmupCosineSchedulerLR',
+                                                      scheduler_args=dict(learning_rate=float(lr0), min_lr=float(min_lr), warmup_epoch=int(warm))),
+                                  train_conf=dict(max_epoch=int(fix))))
+        sch = build_lr_scheduler(step_per_epoch=int(spe), configs=cfg)
+        for k, ref in enumerate(g[name]):
+            assert abs(sch.get_lr() - ref) < 1e-15, (name, k, sch.get_lr(), ref)
+            sch.step()
 
 
 def test_metrics_match_oracle():

@@ -151,3 +151,38 @@ def test_batch_loader_shards_like_distributed_batch_sampler():
     assert [[i for b in l for i in b] for l in again] == first                             # deterministic per (seed, epoch)
     tail = _BatchLoader(DS(10), batch_size=4, shuffle=False, drop_last=False)
     assert [b for b in tail] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9]] and len(tail) == 3
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must start two ranks itself, run a real all-reduce between them and
+    print ONE JSON line with n_gpus = 2 (the driver invokes it exactly like this).  --dry-run swaps the HIP step for a CPU one
+    and RCCL for gloo; launcher, rendezvous, timing, gradient all-reduce and reporting are the code the GPU run uses."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run', '--steps', '3', '--warmup', '1'],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['rccl_ranks'] == 2 and out['steps'] == 3 and out['value'] > 0
+
+
+def test_reducer_buckets_follow_backward_order():
+    """Buckets are cut from the LAST parameter backwards (backward fills them in that order) and cover the flat buffer exactly."""
+    sys.path.insert(0, os.path.join(ROOT, 'voiceprintrecognition-paddlepaddle_amd'))
+    from ppvector.train.ddp import OverlappedReducer
+
+    class Opt:
+        pass
+    o = Opt()
+    o.params = [torch.nn.Parameter(torch.zeros(n)) for n in (1000, 3000, 500, 4000, 200)]
+    o.grad = torch.zeros(sum(p.numel() for p in o.params))
+    r = OverlappedReducer(o, bucket_bytes=4 * 4000)
+    spans = sorted((b[0], b[1]) for b in r.buckets)
+    assert spans[0][0] == 0 and spans[-1][1] == o.grad.numel()
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))              # contiguous, no overlap
+    assert r.buckets[0][1] == o.grad.numel()                                # bucket 0 = the tail of the buffer
+    assert r.bucket_of[o.params[-1]] == 0 and r.bucket_of[o.params[0]] == len(r.buckets) - 1
+    assert len(r.buckets) >= 2

@@ -35,3 +35,17 @@ def set_graph_mode(on):
 
 def get_graph_mode():
     return _GRAPH_MODE
+
+
+_FORWARD_STREAMS = 1
+
+
+def set_forward_streams(n):
+    """Eval-mode backbones cut batches of >= 32 n utterances into n shards that run as concurrent launch sequences on n HIP
+    streams (bit-identical results; ppvector/models/engine.py: forward_streams)."""
+    global _FORWARD_STREAMS
+    _FORWARD_STREAMS = max(1, int(n))
+
+
+def get_forward_streams():
+    return _FORWARD_STREAMS

@@ -6,17 +6,16 @@ import math
 
 
 def cosine_decay_with_warmup(learning_rate, step_per_epoch, fix_epoch=1000, warmup_epoch=5, min_lr=0.0):
-    """Returns the list lr[step]: linear warm-up over warmup_epoch epochs, then cosine to min_lr
-    (the reference wraps the same table in paddle PiecewiseDecay with one boundary per step)."""
+    """Returns the list lr[step] the reference's schedule yields at scheduler step `step` (scheduler.py:6-40): it builds
+    paddle PiecewiseDecay(boundaries, values) with values = [lr i / warm for i = 0..warm] + [cos(i) for i = warm..total-1] and
+    boundaries = [1..warm] + [warm..total-1] -- the boundary `warm` appears TWICE, so PiecewiseDecay (first boundary > step picks
+    the value) skips the warm-up's last entry: lr[step] = lr step / warm below `warm` and cos(step) from `warm` on, where
+    cos(i) = min_lr + (lr - min_lr) (1 + cos((i - warm) pi / (total - warm))) / 2; past the table the last value holds."""
     warm = warmup_epoch * step_per_epoch
     total = fix_epoch * int(step_per_epoch)
-    table = []
-    for i in range(warm + 1):
-        if warm > 0:
-            table.append(learning_rate * i / warm)
-    n_warm = warm
+    table = [learning_rate * i / warm for i in range(min(warm, total))]
     for i in range(max(warm, 0), total):
-        table.append(min_lr + (learning_rate - min_lr) * 0.5 * (math.cos((i - n_warm) * math.pi / (total - n_warm)) + 1))
+        table.append(min_lr + (learning_rate - min_lr) * 0.5 * (math.cos((i - warm) * math.pi / (total - warm)) + 1))
     return table
 
 

@@ -80,6 +80,13 @@ class _BatchLoader:
             pending = nxt
 
 
+def outputs_classes(model, K=1):
+    """Number of classes the labels may name: logit columns of nn.Sequential(backbone, SpeakerIdentification) / K sub-centres."""
+    head = model[1]
+    w = head.weight if hasattr(head, 'weight') else head.output.weight          # Paddle layout: [in, out]
+    return int(w.shape[1]) // max(1, int(K))
+
+
 class PPVectorTrainer(object):
     def __init__(self, configs, use_gpu=True, data_augment_configs=None):
         if not use_gpu:
@@ -136,6 +143,7 @@ class PPVectorTrainer(object):
     def _features(self, items, dataset):
         """One decoded batch -> (features (B, T, F) f32 on the GPU, labels int64 on the GPU)."""
         labels = torch.tensor([int(it['label']) for it in items], dtype=torch.int64).to(self.device)
+        self._last_frames = None
         if 'feature' in items[0]:                                           # pre-extracted .npy features: the collate_fn path
             from ppvector.data_utils.collate_fn import collate_fn
             feats, _, _ = collate_fn([(torch.from_numpy(it['feature']).to(self.device), it['label']) for it in items])
@@ -151,7 +159,8 @@ class PPVectorTrainer(object):
             if int(n_valid.min()) == batch.shape[1]:
                 feats = self.audio_featurizer(batch)
             else:
-                feats, _ = self.audio_featurizer.forward_ragged(batch, n_valid)
+                feats, nf = self.audio_featurizer.forward_ragged(batch, n_valid)
+                self._last_frames = nf.tolist()                 # frames of each utterance before the zero padding
         return feats, labels
 
     def _upload(self, arrays):
@@ -226,8 +235,12 @@ class PPVectorTrainer(object):
             if self.stop_train:
                 break
             features, label = self._features(items, self.train_dataset)
-            if spec is not None:
-                features = spec.batch(features)
+            if spec is not None:                                # the reference masks each utterance's OWN feature before the
+                features = spec.batch(features, lengths=self._last_frames)      # collate (reader.py:105-107): T = its frames
+            if self.train_step < 3:                             # a wrong num_speakers / speed-perturb label offset reads outside
+                lo, hi = int(label.min()), int(label.max())     # the logits row in the loss kernels; paddle raises here too
+                if lo < 0 or hi >= outputs_classes(self.model, K):
+                    raise ValueError(f'label range [{lo}, {hi}] outside the classifier\'s {outputs_classes(self.model, K)} classes')
             outputs = self.model(features)
             los = self.loss(outputs, label)
             los.backward()
@@ -239,8 +252,8 @@ class PPVectorTrainer(object):
                 if K > 1:
                     logits = logits.reshape(logits.shape[0], -1, K).max(dim=2)[0]
                 acc = (logits.argmax(dim=1) == label).float().mean()
-            accuracies.append(float(acc))
-            loss_sum.append(float(los.detach()))
+            accuracies.append(acc)                              # device scalars: read back at the log interval only (the
+            loss_sum.append(los.detach())                       # reference syncs twice per step, trainer.py:237-238)
             train_times.append((time.time() - start) * 1000)
             self.train_step += 1
             if batch_id % self.configs.train_conf.log_interval == 0 and local_rank == 0:
@@ -248,7 +261,8 @@ class PPVectorTrainer(object):
                 world = dist.get_world_size() if dist.is_initialized() else 1
                 train_speed = len(items) * world / (per / 1000)          # GLOBAL utterances per second
                 self.train_eta_sec = per * (self.max_step - self.train_step) / 1000
-                self.train_loss, self.train_acc = sum(loss_sum) / len(loss_sum), sum(accuracies) / len(accuracies)
+                self.train_loss = float(torch.stack(loss_sum).mean())
+                self.train_acc = float(torch.stack(accuracies).mean())
                 margin_str = f'margin: {self.margin_scheduler.get_margin()}' if self.margin_scheduler else ''
                 _LOG.info('Train epoch: [%d/%d], batch: [%d/%d], loss: %.5f, accuracy: %.5f, learning rate: %.8f, %s speed: %.2f data/sec, '
                           'eta: %s', epoch_id, self.configs.train_conf.max_epoch, batch_id, len(self.train_loader), self.train_loss,
@@ -265,8 +279,11 @@ class PPVectorTrainer(object):
 
     def train(self, save_model_path='models/', log_dir='log/', resume_model=None, pretrained_model=None, do_eval=True):
         torch.manual_seed(1000)
-        random.seed(1000)
         world = int(os.environ.get('WORLD_SIZE', 1))
+        # weights: the same seed on every rank (replicas start identical); crop / speed / SpecAugment draws: a seed per rank,
+        # or every rank would augment its shard with the same sequence
+        random.seed(1000 + int(os.environ.get('RANK', 0)))
+        np.random.seed(1000 + int(os.environ.get('RANK', 0)))
         if world > 1 and not dist.is_initialized():                       # one process per GPU over RCCL (torchrun env)
             dist.init_process_group('nccl', device_id=self.device)
         local_rank = dist.get_rank() if dist.is_initialized() else 0
@@ -292,9 +309,8 @@ class PPVectorTrainer(object):
             epoch_id += 1
             start_epoch = time.time()
             self.__train_epoch(epoch_id=epoch_id, save_model_path=save_model_path, local_rank=local_rank)
-            if local_rank == 0 and do_eval:
-                if self.stop_eval:
-                    continue
+            if local_rank == 0 and do_eval and not self.stop_eval:
+                # (the reference `continue`s on stop_eval, trainer.py:343; here that would skip the barrier the other ranks wait in)
                 self.eval_eer, self.eval_min_dcf, self.eval_threshold = self.evaluate()
                 _LOG.info('Test epoch: %d, time/epoch: %s, threshold: %.2f, EER: %.5f, MinDCF: %.5f', epoch_id,
                           timedelta(seconds=(time.time() - start_epoch)), self.eval_threshold, self.eval_eer, self.eval_min_dcf)
