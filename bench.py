@@ -362,6 +362,11 @@ def run_infer(args, rank, local_rank, world, dist):
     dt, loss = run_timed(run, args.steps, args.warmup, dist, dev)
     loss_v = float(loss)
     assert np.isfinite(loss_v)
+    # the path that COMMUNICATES, measured in the same job: the data-parallel training step (global batch 256 split over the
+    # ranks, gradient all-reduce over RCCL overlapped with backward) -- reported beside the headline line as "dp_train"
+    dp_train = None
+    if not args.no_train_line:
+        dp_train = run_train(args, rank, local_rank, world, dist, steps=args.train_steps, warmup=3, emit=False)
     if rank != 0:
         return
     value = world * BATCH * args.steps / dt
@@ -378,6 +383,12 @@ def run_infer(args, rank, local_rank, world, dist):
         'loss': round(loss_v, 5),
         'stage_roofline_frac': round(value / world * ALG_GFLOP_PER_UTT / 1e3 / PEAK_BF16_TFLOPS, 4),
     }
+    if dp_train is not None:
+        keep = ('metric', 'value', 'unit', 'ms_per_step', 'scaling', 'dtype', 'loss', 'stage_roofline_frac', 'rccl_ranks', 'allreduce_ms',
+                'allreduce_bytes', 'allreduce_algbw_GBps', 'step_ms_without_collective', 'comm_exposed_ms', 'overlap_frac', 'grad_buckets')
+        out['dp_train'] = {k: dp_train[k] for k in keep if k in dp_train}
+        out['dp_train']['global_batch'] = dp_train['config']['global_batch']
+        out['dp_train']['steps'] = dp_train['steps']
     if world == 1 and not args.no_roofline and want16:
         out['roofline'] = roofline_pass(reps=10)
     if world == 1 and not args.no_cpu_baseline:
@@ -385,7 +396,7 @@ def run_infer(args, rank, local_rank, world, dist):
     print(json.dumps(out), flush=True)
 
 
-def run_train(args, rank, local_rank, world, dist):
+def run_train(args, rank, local_rank, world, dist, steps=None, warmup=None, emit=True):
     """The reference's optimisation step over its own object graph (nn.Sequential(backbone, classifier), AAMLoss, flat Adam),
     data-parallel over the ranks.  Communication is measured three ways: the flat gradient buffer's all-reduce alone, the step
     with the collective (the reported time) and the same step with the collective switched off."""
@@ -412,10 +423,12 @@ def run_train(args, rank, local_rank, world, dist):
         last['loss'], last['acc'] = step_obj(wav, labels)
         return last['loss']
 
-    dt, loss = run_timed(step, args.steps, args.warmup, dist, dev)
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    dt, loss = run_timed(step, steps, warmup, dist, dev)
     loss_v = float(loss)
     assert np.isfinite(loss_v)
-    ms_step = dt / args.steps * 1e3
+    ms_step = dt / steps * 1e3
     comm = {}
     if dist is not None:
         ranks = measured_ranks(dist, dev)
@@ -433,19 +446,19 @@ def run_train(args, rank, local_rank, world, dist):
         # the same step without the collective: hooks removed, nothing to finish
         step_obj.reducer.remove()
         step_obj.reducer.world = 1
-        dt0, _ = run_timed(step, max(5, args.steps // 4), 2, dist, dev)
-        ms_nocomm = dt0 / max(5, args.steps // 4) * 1e3
+        dt0, _ = run_timed(step, max(5, steps // 4), 2, dist, dev)
+        ms_nocomm = dt0 / max(5, steps // 4) * 1e3
         exposed = max(0.0, ms_step - ms_nocomm)
         comm = {'rccl_ranks': ranks, 'allreduce_ms': round(ar_ms, 4), 'allreduce_bytes': int(g.numel() * 4),
                 'allreduce_algbw_GBps': round(g.numel() * 4 / ar_ms / 1e6, 2), 'step_ms_without_collective': round(ms_nocomm, 4),
                 'comm_exposed_ms': round(exposed, 4), 'overlap_frac': round(1.0 - min(1.0, exposed / ar_ms), 4) if ar_ms > 0 else None,
                 'grad_buckets': len(step_obj.reducer.buckets)}
     if rank != 0:
-        return
-    value = gbatch * args.steps / dt
+        return None
+    value = gbatch * steps / dt
     out = {
         'metric': 'utterances/sec (3 s, 16 kHz) ECAPA-TDNN training step (Fbank + fwd + AAM + bwd + DP all-reduce + Adam)',
-        'value': round(value, 1), 'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'value': round(value, 1), 'unit': 'utterances/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
         'ms_per_step': round(ms_step, 4), 'higher_is_better': True, 'scaling': 'weak' if args.weak else 'strong',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'ECAPA-TDNN (C=512, MFA 1536, ASP, embd 192) + Kaldi Fbank 80, 3 s @ 16 kHz (T=298), 2796-class cosine head + '
@@ -458,7 +471,9 @@ def run_train(args, rank, local_rank, world, dist):
         'stage_roofline_peak': 'f32 MFMA 157.3 TFLOP/s per GPU, 3 x forward flops per utterance',
     }
     out.update(comm)
-    print(json.dumps(out), flush=True)
+    if emit:
+        print(json.dumps(out), flush=True)
+    return out
 
 
 def main():
@@ -468,10 +483,12 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'])
     ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float32'])
-    ap.add_argument('--streams', type=int, default=4, help='concurrent launch sequences per GPU (infer mode)')
+    ap.add_argument('--streams', type=int, default=2, help='concurrent launch sequences per GPU (infer mode)')
     ap.add_argument('--graph', type=int, default=1, help='infer mode: replay the step from one captured HIP graph (1) or launch eagerly (0)')
     ap.add_argument('--global-batch', type=int, default=BATCH, help='train mode: global batch (strong scaling)')
     ap.add_argument('--weak', action='store_true', help='train mode: keep --global-batch utterances PER GPU')
+    ap.add_argument('--no-train-line', action='store_true', help='infer mode: skip the "dp_train" measurement')
+    ap.add_argument('--train-steps', type=int, default=20, help='infer mode: timed steps of the "dp_train" measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--dry-run', action='store_true', help='CPU / gloo rehearsal of the multi-rank plumbing (tests)')

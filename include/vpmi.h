@@ -169,6 +169,7 @@ int vp_dense_f32(vp_ctx* ctx, const float* a, int lda, const float* w, int w_is_
 /* f32 -> bf16 (round to nearest even) of a contiguous tensor; x 16-B aligned, y 8-B aligned. */
 int vp_cast_f32_bf16(vp_ctx* ctx, const float* x, void* y, long long n, vp_stream stream);
 
+
 /* SE gate applied + residual: out = x * s[b, c] + res  (ecapa_tdnn.py:82 and :142). */
 int vp_se_scale_residual(vp_ctx* ctx, int dtype, const void* x, int ldx, int xoff, const float* s,
                          const void* res, int ldr, int roff, void* out, int ldo, int ooff,
@@ -223,6 +224,23 @@ typedef struct {
     const float* fc_w;        /* [embd][2*C_mfa] f32, asp_bn folded in */
     const float* fc_b;        /* [embd] */
 } vp_ecapa_weights;
+
+/* The three fused bf16 kernels of the ECAPA forward, one door each (vp_ecapa_fwd runs them in sequence).
+ * vp_res2_chain_fwd: Res2NetBlock.forward (ecapa_tdnn.py:36-47) for slices 1 .. nconv of t1 (B*T, C) bf16 -- y_1 = f_1(x_1),
+ *   y_j = f_j(x_j + y_{j-1}), f_j = BN(ReLU(conv k3, dilation, reflect pad)) -- written to columns [j*width, (j+1)*width) of r2;
+ *   slice 0 of r2 is left alone (the producing conv writes it).  One workgroup per utterance, activations ping-pong in LDS.
+ *   VP_EUNSUP unless width == 64, equal dilations, 2 <= T <= 384 (callers fall back to one vp_conv1d_fwd per conv).
+ * vp_asp_fused_fwd: AttentiveStatisticsPooling.forward (pooling.py:105-123) from the attention hidden layer on: logits =
+ *   w (C x att) h + bias, softmax over time, weighted mean and std of x; h (B*T, att) bf16, x (B*T, ldx) bf16, center (B, ldc)
+ *   f32 = per-utterance channel means (numerical centre of the variance), pooled (B, 2C) f32 = [mean | std].  att == 128.
+ * vp_se_gate_fwd: SEBlock.forward (ecapa_tdnn.py:69-82) without the final product: s = sigmoid(w2' relu(w1' mean + b1) + b2),
+ *   mean = shift + (sum of the producing conv's partial time sums) / T; psum as vp_conv1d_fwd writes it; w1 [C][H], w2 [H][C]. */
+int vp_res2_chain_fwd(vp_ctx* ctx, const vp_tdnn_layer* layers, int nconv, const void* t1, void* r2, int B, int T, int C,
+                      int width, vp_stream stream);
+int vp_asp_fused_fwd(vp_ctx* ctx, const void* h, const void* w, const float* bias, const void* x, int ldx, const float* center,
+                     int ldc, int B, int T, int C, int att, float eps, float* pooled, vp_stream stream);
+int vp_se_gate_fwd(vp_ctx* ctx, const float* psum, const float* shift, int B, int T, int C, int H, const float* w1, const float* b1,
+                   const float* w2, const float* b2, float* out, vp_stream stream);
 
 size_t vp_ecapa_workspace_bytes(const vp_ecapa_weights* w, int B, int T);
 /* feats: (B, T, feat_dim) in w->dtype; emb: (B, embd_dim) f32. */

@@ -778,3 +778,152 @@ def test_collate_fn_pads_like_reference(N):
     f, l, n = collate_fn([(dev(x), lab) for x, lab in batch])
     assert f.dtype == torch.float32 and l.dtype == torch.int64 and n.dtype == torch.int64
     assert np.array_equal(f.cpu().numpy(), rf) and np.array_equal(l.cpu().numpy(), rl) and np.array_equal(n.cpu().numpy(), rn)
+
+
+# ----------------------------------------------------------------- the three fused bf16 kernels of the ECAPA forward, one by one
+def _bf(t):
+    """Round a float64 tensor to bf16 (round-to-nearest-even, as the kernels store) and come back to float64."""
+    return t.float().to(torch.bfloat16).double()
+
+
+def _tdnn_layers(N, ws, bs, scs, shs, dil):
+    arr = (N.TdnnLayer * len(ws))()
+    keep = []
+    for j, (w, b, sc, sh) in enumerate(zip(ws, bs, scs, shs)):
+        wd = dev(w.permute(0, 2, 1).reshape(w.shape[0], -1), torch.bfloat16)       # [Cout][tap*Cin + c]
+        bd, sd, hd = dev(b, torch.float32), dev(sc, torch.float32), dev(sh, torch.float32)
+        keep += [wd, bd, sd, hd]
+        arr[j].w, arr[j].bias, arr[j].bn_scale, arr[j].bn_shift = wd.data_ptr(), bd.data_ptr(), sd.data_ptr(), hd.data_ptr()
+        arr[j].cin, arr[j].cout, arr[j].kw, arr[j].dil = w.shape[1], w.shape[0], w.shape[2], dil
+    return arr, keep
+
+
+@pytest.mark.parametrize('B,T,dil', [(3, 28, 2), (2, 298, 3), (5, 298, 4), (2, 384, 4), (4, 17, 2), (3, 33, 4)])
+def test_res2_chain_kernel_vs_float64(N, B, T, dil):
+    """vp_res2_chain_fwd against a float64 restatement of Res2NetBlock.forward (ecapa_tdnn.py:36-47) with the kernel's
+    rounding points (bf16 inputs / weights, y_j stored as bf16, next input = bf16(y_j + x_{j+1}) from the unrounded y_j):
+    every frame of every slice, so a wrong tap at one reflected boundary frame (t < dil, t >= T - dil) cannot hide."""
+    lib, ctx = N.lib(), N.ctx(0)
+    Cc, wdt, nconv = 512, 64, 7
+    g = torch.Generator().manual_seed(100 * T + dil)
+    t1 = _bf(torch.randn(B, T, Cc, generator=g, dtype=torch.float64))
+    ws = [_bf(torch.randn(wdt, wdt, 3, generator=g, dtype=torch.float64) / (3 * wdt) ** 0.5) for _ in range(nconv)]
+    bs = [0.1 * torch.randn(wdt, generator=g, dtype=torch.float64).float().double() for _ in range(nconv)]
+    scs = [(torch.rand(wdt, generator=g, dtype=torch.float64) + 0.5).float().double() for _ in range(nconv)]
+    shs = [0.2 * torch.randn(wdt, generator=g, dtype=torch.float64).float().double() for _ in range(nconv)]
+    ref = torch.zeros(B, T, Cc, dtype=torch.float64)
+    cur = t1[:, :, wdt:2 * wdt]
+    for j in range(nconv):
+        xt = F.pad(cur.transpose(1, 2), (dil, dil), mode='reflect')
+        v = (torch.relu(F.conv1d(xt, ws[j], bs[j], dilation=dil)) * scs[j][None, :, None] + shs[j][None, :, None]).transpose(1, 2)
+        ref[:, :, (j + 1) * wdt:(j + 2) * wdt] = _bf(v)
+        if j + 1 < nconv:
+            cur = _bf(v + t1[:, :, (j + 2) * wdt:(j + 3) * wdt])
+    layers, keep = _tdnn_layers(N, ws, bs, scs, shs, dil)
+    t1d = dev(t1, torch.bfloat16)
+    r2 = torch.full((B, T, Cc), 7.0, dtype=torch.bfloat16, device='cuda')
+    N.check(lib.vp_res2_chain_fwd(ctx, layers, nconv, t1d.data_ptr(), r2.data_ptr(), B, T, Cc, wdt, N.stream_ptr()), ctx)
+    torch.cuda.synchronize()
+    out = r2.double().cpu()
+    assert torch.all(out[:, :, :wdt] == 7.0)                                  # slice 0 belongs to the producing conv
+    err = (out[:, :, wdt:] - ref[:, :, wdt:]).abs()
+    scale = ref.abs().max().item()
+    # f32 vs float64 accumulation can flip a bf16 rounding (1 ulp = 2^-8 relative) and the flip feeds the next conv
+    print(f'[res2_chain B={B} T={T} d={dil}] max err {err.max().item():.3e} (max |ref| {scale:.2f}), mean {err.mean().item():.2e}')
+    assert err.max().item() < 2.0 ** -7 * scale, err.max().item()
+    assert err.mean().item() < 2e-4 * scale
+    edge = torch.cat([err[:, :2 * dil], err[:, -2 * dil:]], dim=1)            # the reflected frames, separately
+    assert edge.max().item() < 2.0 ** -7 * scale
+
+
+def test_res2_chain_refuses_shapes_it_does_not_cover(N):
+    lib, ctx = N.lib(), N.ctx(0)
+    g = torch.Generator().manual_seed(0)
+    ws = [torch.randn(64, 64, 3, generator=g, dtype=torch.float64) for _ in range(7)]
+    z = [torch.zeros(64, dtype=torch.float64) for _ in range(7)]
+    layers, keep = _tdnn_layers(N, ws, z, z, z, 2)
+    t1 = torch.zeros((1, 512, 512), dtype=torch.bfloat16, device='cuda')
+    r2 = torch.zeros_like(t1)
+    assert lib.vp_res2_chain_fwd(ctx, layers, 7, t1.data_ptr(), r2.data_ptr(), 1, 512, 512, 64, N.stream_ptr()) == N.VP_EUNSUP   # T > 384
+    assert lib.vp_res2_chain_fwd(ctx, layers, 7, t1.data_ptr(), r2.data_ptr(), 1, 100, 512, 32, N.stream_ptr()) == N.VP_EUNSUP   # width != 64
+
+
+@pytest.mark.parametrize('B,T,Cc', [(3, 28, 1536), (2, 298, 1536), (3, 512, 512), (2, 37, 200)])
+def test_asp_fused_kernel_vs_float64(N, B, T, Cc):
+    """vp_asp_fused_fwd against float64: logits GEMM (128 -> C) + softmax over time + weighted mean / std (pooling.py:105-123),
+    bf16 operands, every utterance and channel; T not a multiple of the kernel's 16-frame tile, C not a multiple of 128."""
+    lib, ctx = N.lib(), N.ctx(0)
+    att = 128
+    g = torch.Generator().manual_seed(T + Cc)
+    h = _bf(torch.tanh(torch.randn(B, T, att, generator=g, dtype=torch.float64)))
+    w = _bf(torch.randn(Cc, att, generator=g, dtype=torch.float64) * (3.0 / att ** 0.5))       # logits spread over several units
+    bias = torch.randn(Cc, generator=g, dtype=torch.float64).float().double()
+    x = _bf(torch.randn(B, T, Cc, generator=g, dtype=torch.float64) * 2 + 0.5 * torch.randn(1, 1, Cc, generator=g, dtype=torch.float64))
+    e = h @ w.t() + bias
+    al = torch.softmax(e, dim=1)
+    mu = (al * x).sum(1)
+    sd = torch.sqrt(((al * (x - mu[:, None]) ** 2).sum(1)).clamp(min=1e-12))
+    ref = torch.cat([mu, sd], 1)
+    center = torch.cat([x.mean(1), x.std(1, unbiased=False)], 1)                                # the global-context stats buffer
+    hd, wd, xd = dev(h, torch.bfloat16), dev(w, torch.bfloat16), dev(x, torch.bfloat16)
+    bd, cd = dev(bias, torch.float32), dev(center, torch.float32)
+    pooled = torch.full((B, 2 * Cc), float('nan'), dtype=torch.float32, device='cuda')
+    N.check(lib.vp_asp_fused_fwd(ctx, hd.data_ptr(), wd.data_ptr(), bd.data_ptr(), xd.data_ptr(), Cc, cd.data_ptr(), 2 * Cc, B, T, Cc, att,
+                                 1e-12, pooled.data_ptr(), N.stream_ptr()), ctx)
+    torch.cuda.synchronize()
+    err = (pooled.double().cpu() - ref).abs()
+    print(f'[asp_fused B={B} T={T} C={Cc}] max err {err.max().item():.3e} (max |ref| {ref.abs().max().item():.2f})')
+    assert not torch.isnan(pooled).any()
+    assert err.max().item() < 2e-4 * max(1.0, ref.abs().max().item()), err.max().item()
+
+
+def test_asp_fused_softmax_survives_a_spike(N):
+    """One frame whose logit dominates (the online softmax's new-maximum path): weights collapse on it, mean = its x, std = floor."""
+    lib, ctx = N.lib(), N.ctx(0)
+    B, T, Cc, att = 1, 100, 128, 128
+    h = torch.zeros(B, T, att, dtype=torch.float64)
+    h[0, 61] = 1.0                                                  # frame 61: logit 128 * 0.5 = 64 above the rest
+    w = torch.full((Cc, att), 0.5, dtype=torch.float64)
+    g = torch.Generator().manual_seed(5)
+    x = _bf(torch.randn(B, T, Cc, generator=g, dtype=torch.float64))
+    center = torch.cat([x.mean(1), x.std(1, unbiased=False)], 1)
+    hd, wd, xd = dev(h, torch.bfloat16), dev(w, torch.bfloat16), dev(x, torch.bfloat16)
+    bd, cd = torch.zeros(Cc, device='cuda'), dev(center, torch.float32)
+    pooled = torch.empty((B, 2 * Cc), dtype=torch.float32, device='cuda')
+    N.check(lib.vp_asp_fused_fwd(ctx, hd.data_ptr(), wd.data_ptr(), bd.data_ptr(), xd.data_ptr(), Cc, cd.data_ptr(), 2 * Cc, B, T, Cc, att,
+                                 1e-12, pooled.data_ptr(), N.stream_ptr()), ctx)
+    p = pooled.double().cpu()
+    assert (p[0, :Cc] - x[0, 61]).abs().max().item() < 1e-5
+    assert p[0, Cc:].max().item() < 1e-3
+
+
+@pytest.mark.parametrize('B,T', [(5, 28), (3, 298), (2, 512), (7, 130)])
+def test_se_gate_kernel_vs_float64(N, B, T):
+    """vp_se_gate_fwd from the producing conv's partial time sums (128-row tiles straddling utterances) against float64."""
+    lib, ctx = N.lib(), N.ctx(0)
+    Cc, H = 512, 128
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    y = torch.randn(B, T, Cc, generator=g, dtype=torch.float64)
+    shift = 0.3 * torch.randn(Cc, generator=g, dtype=torch.float64).float().double()
+    w1 = (torch.randn(Cc, H, generator=g, dtype=torch.float64) / Cc ** 0.5).float().double()
+    b1 = 0.1 * torch.randn(H, generator=g, dtype=torch.float64).float().double()
+    w2 = (torch.randn(H, Cc, generator=g, dtype=torch.float64) / H ** 0.5).float().double()
+    b2 = 0.1 * torch.randn(Cc, generator=g, dtype=torch.float64).float().double()
+    tiles, nseg = lib.vp_conv1d_tiles_m(B, T), lib.vp_conv1d_nseg(T)
+    ps = torch.full((tiles, nseg, Cc), float('nan'), dtype=torch.float64)
+    rows = (y - shift).reshape(B * T, Cc)
+    for tm in range(tiles):
+        b0 = (tm * 128) // T
+        for r0 in range(tm * 128, min((tm + 1) * 128, B * T)):
+            seg = r0 // T - b0
+            ps[tm, seg] = torch.where(torch.isnan(ps[tm, seg]), torch.zeros_like(ps[tm, seg]), ps[tm, seg]) + rows[r0]
+    mean = y.mean(1)
+    ref = torch.sigmoid(torch.relu(mean @ w1 + b1) @ w2 + b2)
+    out = torch.empty((B, Cc), dtype=torch.float32, device='cuda')
+    psd = dev(ps, torch.float32)                       # slots no tile row touched stay NaN: the kernel must not read them
+    keep = [dev(t, torch.float32) for t in (shift, w1, b1, w2, b2)]
+    N.check(lib.vp_se_gate_fwd(ctx, psd.data_ptr(), keep[0].data_ptr(), B, T, Cc, H, keep[1].data_ptr(), keep[2].data_ptr(),
+                               keep[3].data_ptr(), keep[4].data_ptr(), out.data_ptr(), N.stream_ptr()), ctx)
+    err = (out.double().cpu() - ref).abs().max().item()
+    print(f'[se_gate B={B} T={T}] max err {err:.3e}')
+    assert err < 2e-6, err

@@ -44,7 +44,7 @@ def test_ecapa_matches_reference_golden(ecapa, golden_dir, dtype, rel_tol, cos_t
     assert np.all(1 - c < cos_tol), 1 - c
 
 
-@pytest.mark.parametrize('dtype,score_tol', [('float32', 1e-4), ('bfloat16', 5e-3)])
+@pytest.mark.parametrize('dtype,score_tol', [('float32', 1e-4), ('bfloat16', 1e-4)])      # north_star's bound for both engines (bf16 measured: 7.3e-5)
 def test_end_to_end_real_speech_scores(ecapa, golden_dir, dtype, score_tol):
     """wav -> HIP Fbank+CMN -> HIP ECAPA -> cosine scores, against the reference graph's scores for
     the four reference WAVs (a_1/a_2 same speaker, b_1/b_2 same speaker)."""
@@ -354,3 +354,30 @@ def test_eres2netv2_matches_reference_golden(golden_dir):
         ref3 = oer.eres2netv2_forward(p, torch.from_numpy(feats)).numpy()
     e3 = m.engine('float32').forward(torch.from_numpy(feats).cuda()).cpu().numpy()
     assert np.linalg.norm(e3 - ref3) / np.linalg.norm(ref3) < 3e-4
+
+
+def test_bench_config_bf16_scores_vs_f32_oracle(ecapa):
+    """The benched configuration (BASELINE configs[1]: bf16 engine, B = 256, T = 298, randomised BN statistics): ALL-PAIRS cosine
+    scores of 256 utterances against the f32 CPU oracle (north_star: scores within 1e-4 -- stated for the fp32 reference).
+    The f32 engine is held to 1e-4 here too; the bf16 engine's measured bound is asserted and printed."""
+    import bench
+    from ppvector.data_utils.featurizer import AudioFeaturizer
+    B = 256
+    wav = torch.from_numpy(bench.synth_waves(B, 48000, seed=1234)).cuda()
+    fz = AudioFeaturizer('Fbank', dict(sr=16000, n_mels=80))
+    feats = fz(wav, want_bf16=True)
+    assert feats.shape == (B, 298, 80)
+    torch.set_num_threads(min(32, len(__import__('os').sched_getaffinity(0))))
+    with torch.no_grad():
+        ref = om.ecapa_forward({k: v.detach().cpu().float() for k, v in ecapa.state_dict().items()}, feats.cpu().float()).double()
+    rn = ref / ref.norm(dim=1, keepdim=True)
+    sref = rn @ rn.t()
+    res = {}
+    for dt in ('float32', 'bfloat16'):
+        e = ecapa.engine(dt).forward(feats).double().cpu()
+        en = e / e.norm(dim=1, keepdim=True)
+        res[dt] = ((en @ en.t()) - sref).abs().max().item()
+        one_minus_cos = (1 - (en * rn).sum(1)).max().item()
+        print(f'[bench config {dt}] all-pairs ({B} x {B}) max |score - oracle| {res[dt]:.3e}   worst 1 - cos(emb, oracle) {one_minus_cos:.3e}')
+    assert res['float32'] < 1e-4, res
+    assert res['bfloat16'] < 1e-4, res           # measured on MI355X: 9.4e-6 (f32 accumulation and f32 statistics everywhere)

@@ -453,13 +453,17 @@ def test_eres2netv2_training_step_vs_oracle_autograd(N):
     m.eval()
 
 
-def test_campplus_training_step_vs_oracle_autograd(N):
+@pytest.mark.parametrize('B,gtol', [(3, 3e-2), (16, 3e-3)])
+def test_campplus_training_step_vs_oracle_autograd(N, B, gtol):
     """CAM++ (configs/cam++.yml: embd 192): FCM with stride on the frequency axis, the stride-2 TDNN, 52 CAM dense layers with
-    two context segments (115 frames after the stride), transit layers, unbiased statistics pooling."""
+    two context segments (115 frames after the stride), transit layers, unbiased statistics pooling.
+    Batch of 3: the closing BatchNorm1D sees 3 rows per channel, (x - mean) / sqrt(var + eps) with var from 3 samples amplifies
+    f32 round-off of the 52-layer forward into its gradients (worst parameter 1.8e-2); at a batch of 16 the same code is an
+    order of magnitude closer -- conditioning of the problem, not an ordering bug in the backward kernels."""
     from oracle import campplus as oc
     from ppvector.models.campplus import CAMPPlus
     from ppvector.train.functions import HeadLoss
-    B, T, Cc = 3, 230, 8
+    T, Cc = 230, 8
     p = oc.campplus_params(80, 192, seed=17)
     g = torch.Generator().manual_seed(18)
     x = torch.randn(B, T, 80, generator=g) * 2
@@ -489,8 +493,8 @@ def test_campplus_training_step_vs_oracle_autograd(N):
         r = rel(v.grad, pr[k].grad)
         if r > worst:
             worst, wk = r, k
-        assert r < 3e-2, (k, r)
-    print(f'[cam++ train] loss {loss.item():.5f} (oracle {loss_ref.item():.5f}); worst parameter-gradient rel-L2 {worst:.2e} ({wk})')
+        assert r < gtol, (k, r)
+    print(f'[cam++ train B={B}] loss {loss.item():.5f} (oracle {loss_ref.item():.5f}); worst parameter-gradient rel-L2 {worst:.2e} ({wk})')
     m.eval()
 
 

@@ -126,6 +126,29 @@ int check_ecapa(vp_ctx* ctx, const vp_ecapa_weights* w) {
 
 extern "C" {
 
+// C-ABI doors of the three fused bf16 kernels of the ECAPA forward (tests call them one by one; vp_ecapa_fwd calls the
+// launchers directly)
+int vp_res2_chain_fwd(vp_ctx* ctx, const vp_tdnn_layer* layers, int nconv, const void* t1, void* r2, int B, int T, int C,
+                      int width, vp_stream stream) {
+    if (!ctx || !layers || !t1 || !r2 || B <= 0 || T <= 0 || C <= 0) VP_FAIL(ctx, VP_EINVAL, "res2_chain: bad arguments");
+    const int rc = vp_res2_chain_bf16(ctx, layers, nconv, t1, r2, B, T, C, width, (hipStream_t)stream);
+    if (rc == VP_EUNSUP) VP_FAIL(ctx, VP_EUNSUP, "res2_chain: shape not covered by the fused kernel (width 64, equal dilations, 2 <= T <= 384)");
+    return rc;
+}
+
+int vp_asp_fused_fwd(vp_ctx* ctx, const void* h, const void* w, const float* bias, const void* x, int ldx, const float* center,
+                     int ldc, int B, int T, int C, int att, float eps, float* pooled, vp_stream stream) {
+    if (!ctx || !h || !w || !x || !center || !pooled || B <= 0) VP_FAIL(ctx, VP_EINVAL, "asp_fused: bad arguments");
+    const int rc = vp_asp_fused_bf16(ctx, h, w, bias, x, ldx, center, ldc, B, T, C, att, eps, pooled, (hipStream_t)stream);
+    if (rc == VP_EUNSUP) VP_FAIL(ctx, VP_EUNSUP, "asp_fused: shape not covered (attention width 128, C and ldx multiples of 8, 16-byte aligned)");
+    return rc;
+}
+
+int vp_se_gate_fwd(vp_ctx* ctx, const float* psum, const float* shift, int B, int T, int C, int H, const float* w1, const float* b1,
+                   const float* w2, const float* b2, float* out, vp_stream stream) {
+    return vp_se_gate(ctx, psum, shift, B, T, C, H, w1, b1, w2, b2, out, (hipStream_t)stream);
+}
+
 size_t vp_ecapa_workspace_bytes(const vp_ecapa_weights* w, int B, int T) {
     if (!w || B <= 0 || T <= 0) return 0;
     EcapaPlan p;
