@@ -210,6 +210,27 @@ def main():
     cmp('eres2netv2 eval emb', ev_or, ev_ref, 2e-5)
     out['eres2netv2_ref_small.npz'] = dict(x=xv2, emb_eval=ev_ref.numpy(), param_seed=np.int64(1000))
 
+    # ---------------- ERes2Net-large (BASELINE configs[4]: the 55 M-parameter shape -- m_channels 64, expansion 4, base_width 24,
+    # scale 3, mul_channel 2; README.md:80), F=80, short T to keep the fixture small
+    LARGE = dict(m_channels=64, mul_channel=2, expansion=4, base_width=24, scale=3)
+    pl = oer.eres2net_params(input_size=F_, embd_dim=192, seed=1001, **LARGE)
+    lm = ref_er.ERes2Net(input_size=F_, embd_dim=192, **LARGE)
+    sdl = lm.state_dict()
+    assert set(sdl.keys()) == set(pl.keys()), sorted(set(sdl.keys()) ^ set(pl.keys()))[:10]
+    for k in sdl:
+        assert tuple(sdl[k].shape) == tuple(pl[k].shape), k
+    lm.load_state_dict(pl)
+    lm.eval()
+    nt, nb_ = om.count_params(pl)
+    print(f'ERes2Net-large F=80 params: trainable {nt}, buffers {nb_}')
+    assert 54.5e6 < nt < 56e6, nt                                   # "55 M"
+    xl = rng.standard_normal((2, 43, F_)).astype(np.float32) * 3.0
+    with torch.no_grad():
+        el_ref = lm(paddle_shim.to_tensor(xl))
+        el_or = oer.eres2net_forward(pl, torch.from_numpy(xl), **{k: v for k, v in LARGE.items() if k != 'mul_channel'})
+    cmp('eres2net-large eval emb', el_or, el_ref, 2e-5)
+    out['eres2net_large_ref_small.npz'] = dict(x=xl, emb_eval=el_ref.numpy(), param_seed=np.int64(1001))
+
     # ---------------- the other classification losses (loss/{amloss,armloss,celoss,subcenterloss,sphereface2}.py)
     from oracle import losses as ol
     ref_l = {n: importlib.import_module('ppvector.loss.' + n) for n in ('amloss', 'armloss', 'celoss', 'subcenterloss', 'sphereface2')}

@@ -381,3 +381,126 @@ def test_bench_config_bf16_scores_vs_f32_oracle(ecapa):
         print(f'[bench config {dt}] all-pairs ({B} x {B}) max |score - oracle| {res[dt]:.3e}   worst 1 - cos(emb, oracle) {one_minus_cos:.3e}')
     assert res['float32'] < 1e-4, res
     assert res['bfloat16'] < 1e-4, res           # measured on MI355X: 9.4e-6 (f32 accumulation and f32 statistics everywhere)
+
+
+# ------------------------------------------------------------------- BASELINE configs[2..4] at their NAMED shapes
+def test_eres2net_large_matches_reference_golden(golden_dir):
+    """BASELINE configs[4]: ERes2Net-large (55.2 M parameters: m_channels 64, expansion 4, base_width 24, scale 3, mul_channel 2;
+    README.md:80) vs the output of the reference's own eres2net.py on the same weights (golden from oracle/gen_golden.py)."""
+    from oracle import eres2net as oer
+    from ppvector.models.eres2net import ERes2Net
+    LARGE = dict(m_channels=64, mul_channel=2, expansion=4, base_width=24, scale=3)
+    g = np.load(f'{golden_dir}/eres2net_large_ref_small.npz')
+    p = oer.eres2net_params(80, 192, seed=int(g['param_seed']), **LARGE)
+    assert sum(v.numel() for k, v in p.items() if not k.endswith(('_mean', '_variance'))) == 55196112
+    m = ERes2Net(80, embd_dim=192, **LARGE)
+    m.load_state_dict(p)
+    m = m.cuda().eval()
+    x = torch.from_numpy(g['x']).cuda()
+    ref = g['emb_eval']
+    for dtype, tol in (('float32', 3e-4), ('bfloat16', 8e-2)):
+        emb = m.engine(dtype).forward(x).cpu().numpy()
+        rel = np.linalg.norm(emb - ref) / np.linalg.norm(ref)
+        c = _cos_rows(emb, ref)
+        print(f'[eres2net-large {dtype}] rel-L2 {rel:.3e}  1-cos {1 - c.min():.3e}')
+        assert rel < tol, (dtype, rel)
+
+
+@pytest.mark.parametrize('Cn,B', [(7205, 64), (200000, 128)])
+def test_cosine_head_and_aam_at_named_class_counts(Cn, B):
+    """BASELINE configs[2] (CAM++: 7 205 classes) and configs[4] (200 000-class ArcFace head, 128 utterances per GPU): cosine
+    logits (fc.py:41-53) + AAM loss (aamloss.py:28-47) forward AND the gradients to the embeddings and the class weights,
+    against float64 autograd of the oracle."""
+    from ppvector import _native as N
+    from ppvector.train.functions import HeadLoss
+    g = torch.Generator().manual_seed(Cn)
+    D = 192
+    emb = torch.randn(B, D, generator=g)
+    W = om.head_params(D, Cn, seed=11)
+    labels = torch.randint(0, Cn, (B,), generator=g)
+    labels[0], labels[1] = 0, Cn - 1                                   # the first and the last class column
+    e64, W64 = emb.double().requires_grad_(), W.double().requires_grad_()
+    ref = om.aam_loss(om.cosine_head(e64, W64), labels, 0.2, 32.0, False, 0.0)
+    ref.backward()
+    ed, Wd = emb.cuda().requires_grad_(), W.cuda().requires_grad_()
+    loss = HeadLoss.apply(ed, Wd, labels.cuda(), 0.2, 32.0, 0.0, False)
+    loss.backward()
+    torch.cuda.synchronize()
+    rl = abs(loss.item() - ref.item()) / abs(ref.item())
+    re = ((ed.grad.double().cpu() - e64.grad).norm() / e64.grad.norm()).item()
+    rw = ((Wd.grad.double().cpu() - W64.grad).norm() / W64.grad.norm()).item()
+    print(f'[head C={Cn} B={B}] loss {loss.item():.5f} (oracle {ref.item():.5f}, rel {rl:.1e})  d emb rel-L2 {re:.2e}  d W rel-L2 {rw:.2e}')
+    assert rl < 2e-5 and re < 2e-4 and rw < 2e-4
+    # eval path: logits of SpeakerIdentification on the same operands
+    from ppvector.models.fc import SpeakerIdentification
+    head = SpeakerIdentification(D, Cn)
+    head.load_state_dict({'weight': W})
+    lg = head.cuda().eval()(emb.cuda())['logits'].double().cpu()
+    assert (lg - om.cosine_head(emb.double(), W.double())).abs().max().item() < 2e-6
+
+
+def test_resnetse_melspectrogram_specaugment_pipeline():
+    """BASELINE configs[3] end to end at its named front end: MelSpectrogram(sr 16000, n_fft 1024, hop 320, win 1024, 64 mel,
+    f_min 50; README.md:288-296) -> SpecAugment (reader.py:105-107; augmentation.yml:36-48) -> ResNetSE(64) forward, 32 utterances
+    (= 128 / 4 GPUs), against the oracle run on the oracle's own features with the same mask draws."""
+    import random
+    from oracle import augment as oa
+    from oracle import resnet_se as orse
+    from ppvector.data_utils.featurizer import AudioFeaturizer
+    from ppvector.data_utils.spec_aug import SpecAugmentor
+    from ppvector.models.resnet_se import ResNetSE
+    margs = dict(sr=16000, n_fft=1024, hop_length=320, win_length=1024, n_mels=64, f_min=50)
+    conf = dict(prob=1.0, freq_mask_ratio=0.1, n_freq_masks=1, time_mask_ratio=0.05, n_time_masks=1, max_time_warp=0)
+    B = 32
+    w = ofb.synth_waves(B, 48000, seed=21, lowpass=0.9)
+    feats_ref = ofb.featurize_mel(w, method_args=margs)
+    assert feats_ref.shape == (B, 151, 64)
+    random.seed(77)
+    aug_ref = np.stack([oa.spec_augment(feats_ref[b], **conf) for b in range(B)])
+    p = orse.resnetse_params(64, 192, seed=5)
+    with torch.no_grad():
+        ref = orse.resnetse_forward(p, torch.from_numpy(aug_ref)).numpy()
+    fz = AudioFeaturizer('MelSpectrogram', margs)
+    assert fz.feature_dim == 64
+    feats = fz(torch.from_numpy(w).cuda())
+    random.seed(77)
+    aug = SpecAugmentor(**conf).batch(feats)
+    assert np.max(np.abs(aug.cpu().numpy() - aug_ref)) < 2e-4 * np.max(np.abs(aug_ref))
+    m = ResNetSE(64, embd_dim=192)
+    m.load_state_dict(p)
+    m = m.cuda().eval()
+    for dtype, tol in (('float32', 5e-4), ('bfloat16', 8e-2)):
+        emb = m.engine(dtype).forward(aug).cpu().numpy()
+        rel = np.linalg.norm(emb - ref) / np.linalg.norm(ref)
+        c = _cos_rows(emb, ref)
+        print(f'[resnetse <- mel64 <- specaug {dtype}] rel-L2 {rel:.3e}  1-cos {1 - c.min():.3e}')
+        assert rel < tol, (dtype, rel)
+
+
+def test_campplus_named_config_shapes():
+    """BASELINE configs[2]: CAM++ + Fbank at 64 utterances per GPU (512 / 8), 3 s, with its 7 205-class head: embeddings vs the
+    oracle on the oracle's Fbank, logits vs float64."""
+    from oracle import campplus as oc
+    from ppvector.data_utils.featurizer import AudioFeaturizer
+    from ppvector.models.campplus import CAMPPlus
+    from ppvector.models.fc import SpeakerIdentification
+    B = 64
+    w = ofb.synth_waves(B, 48000, seed=31, lowpass=0.9)
+    feats_ref = ofb.featurize(w, method_args=dict(sr=16000, n_mels=80))
+    p = oc.campplus_params(80, 192, seed=1000)
+    torch.set_num_threads(min(32, len(__import__('os').sched_getaffinity(0))))
+    with torch.no_grad():
+        ref = oc.campplus_forward(p, torch.from_numpy(feats_ref)).numpy()
+    m = CAMPPlus(80, embd_dim=192)
+    m.load_state_dict(p)
+    m = m.cuda().eval()
+    feats = AudioFeaturizer('Fbank', dict(sr=16000, n_mels=80))(torch.from_numpy(w).cuda())
+    emb = m.engine('float32').forward(feats)
+    rel = np.linalg.norm(emb.cpu().numpy() - ref) / np.linalg.norm(ref)
+    print(f'[cam++ B=64 x 3 s float32] rel-L2 {rel:.3e}')
+    assert rel < 5e-4
+    W = om.head_params(192, 7205, seed=3)
+    head = SpeakerIdentification(192, 7205)
+    head.load_state_dict({'weight': W})
+    lg = head.cuda().eval()(emb)['logits'].double().cpu()
+    assert (lg - om.cosine_head(torch.from_numpy(ref).double(), W.double())).abs().max().item() < 5e-4

@@ -453,13 +453,14 @@ def test_eres2netv2_training_step_vs_oracle_autograd(N):
     m.eval()
 
 
-@pytest.mark.parametrize('B,gtol', [(3, 3e-2), (16, 3e-3)])
+@pytest.mark.parametrize('B,gtol', [(3, 3e-2), (16, 2e-2)])
 def test_campplus_training_step_vs_oracle_autograd(N, B, gtol):
     """CAM++ (configs/cam++.yml: embd 192): FCM with stride on the frequency axis, the stride-2 TDNN, 52 CAM dense layers with
     two context segments (115 frames after the stride), transit layers, unbiased statistics pooling.
-    Batch of 3: the closing BatchNorm1D sees 3 rows per channel, (x - mean) / sqrt(var + eps) with var from 3 samples amplifies
-    f32 round-off of the 52-layer forward into its gradients (worst parameter 1.8e-2); at a batch of 16 the same code is an
-    order of magnitude closer -- conditioning of the problem, not an ordering bug in the backward kernels."""
+    Every other backbone matches float64 to <= 7e-4; CAM++ sits at 1.8e-2 (B = 3) / 8e-3 (B = 16).  That is the f32 conditioning
+    of this 60-layer train-mode graph, not the backward kernels: PyTorch-CPU f32 autograd over the ORACLE graph deviates from
+    its own float64 run by 1.5e-2 (B = 3) / 1.3e-2 (B = 16) worst parameter (head.conv1.weight: 7.2e-3 / 6.7e-3).  The test
+    therefore also runs that f32 CPU autograd and requires the HIP engine to be no further from float64 than 2.5 x it."""
     from oracle import campplus as oc
     from ppvector.models.campplus import CAMPPlus
     from ppvector.train.functions import HeadLoss
@@ -494,6 +495,12 @@ def test_campplus_training_step_vs_oracle_autograd(N, B, gtol):
         if r > worst:
             worst, wk = r, k
         assert r < gtol, (k, r)
+    p32 = {k: v.clone().float().requires_grad_(not k.endswith(('_mean', '_variance'))) for k, v in p.items()}
+    W32 = Wh.clone().float().requires_grad_()
+    om.aam_loss(om.cosine_head(oc.campplus_forward(p32, x.float(), training=True), W32), labels, 0.2, 32.0, False, 0.0).backward()
+    w32 = max(rel(p32[k].grad, pr[k].grad) for k in p32 if pr[k].grad is not None and pr[k].grad.norm().item() >= 1e-9)
+    print(f'[cam++ train B={B}] PyTorch-CPU f32 autograd of the oracle graph vs float64: worst rel-L2 {w32:.2e}')
+    assert worst < max(2.5 * w32, 1e-3), (worst, w32)
     print(f'[cam++ train B={B}] loss {loss.item():.5f} (oracle {loss_ref.item():.5f}); worst parameter-gradient rel-L2 {worst:.2e} ({wk})')
     m.eval()
 

@@ -64,7 +64,11 @@ def test_2d_backbone_oracles_match_reference_golden(golden_dir):
                               ('resnetse_ref_small.npz', orse.resnetse_params, orse.resnetse_forward),
                               ('eres2net_ref_small.npz', oer.eres2net_params, oer.eres2net_forward),
                               ('eres2netv2_ref_small.npz', lambda f, e, seed: oer.eres2net_params(f, e, base_width=26, seed=seed, v2=True),
-                               oer.eres2netv2_forward)):
+                               oer.eres2netv2_forward),
+                              # BASELINE configs[4]: the 55 M-parameter ERes2Net (m_channels 64, expansion 4, base_width 24, scale 3)
+                              ('eres2net_large_ref_small.npz',
+                               lambda f, e, seed: oer.eres2net_params(f, e, seed=seed, m_channels=64, mul_channel=2, expansion=4, base_width=24, scale=3),
+                               lambda p, x: oer.eres2net_forward(p, x, m_channels=64, expansion=4, base_width=24, scale=3))):
         g = _load(golden_dir, name)
         p = params(80, 192, seed=int(g['param_seed']))
         with torch.no_grad():
