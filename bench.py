@@ -412,6 +412,8 @@ def run_train(args, rank, local_rank, world, dist, steps=None, warmup=None, emit
     wav_all = synth_waves(gbatch if not args.weak else B, N_SAMPLES, seed=1000 if not args.weak else shard_seed(1000, rank))
     wav = torch.from_numpy(wav_all[list(idx)] if not args.weak else wav_all).to(dev)
     labels = ((torch.arange(gbatch) * 7) % N_CLASSES)[list(idx)].to(dev)
+    import ppvector
+    ppvector.set_train_amp(bool(args.amp))      # enable_amp: bf16 matrix cores over f32 tensors in the three conv GEMMs
     fz, backbone, head, _, _ = build_ecapa(dev, 'float32')
     model = torch.nn.Sequential(backbone, head).to(dev)
     crit = AAMLoss(margin=0.2, scale=32, easy_margin=False, label_smoothing=0.0)
@@ -460,15 +462,17 @@ def run_train(args, rank, local_rank, world, dist, steps=None, warmup=None, emit
         'metric': 'utterances/sec (3 s, 16 kHz) ECAPA-TDNN training step (Fbank + fwd + AAM + bwd + DP all-reduce + Adam)',
         'value': round(value, 1), 'unit': 'utterances/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
         'ms_per_step': round(ms_step, 4), 'higher_is_better': True, 'scaling': 'weak' if args.weak else 'strong',
-        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': 'bf16 matrix cores over f32 tensors (enable_amp), f32 master weights' if args.amp else 'f32', 'data': 'synthetic',
         'config': {'workload': 'ECAPA-TDNN (C=512, MFA 1536, ASP, embd 192) + Kaldi Fbank 80, 3 s @ 16 kHz (T=298), 2796-class cosine head + '
-                               'AAMLoss, train-mode forward (batch-statistics BN) + backward + flat Adam, f32 matrix cores, '
+                               'AAMLoss, train-mode forward (batch-statistics BN) + backward + flat Adam, '
+                               + ('conv GEMMs (forward, data and weight gradient) on the bf16 matrix cores, ' if args.amp else 'f32 matrix cores, ') +
+                               
                                f'global batch {gbatch}, inputs resident in HBM, random-init weights',
                    'batch_per_gpu': B, 'global_batch': gbatch,
                    'parallelism': f'dp{world} (bucketed gradient all-reduce over RCCL, overlapped with backward)' if world > 1 else 'dp1'},
         'loss': round(loss_v, 5),
-        'stage_roofline_frac': round(value * 3 * ALG_GFLOP_PER_UTT / 1e3 / world / PEAK_F32_TFLOPS, 4),
-        'stage_roofline_peak': 'f32 MFMA 157.3 TFLOP/s per GPU, 3 x forward flops per utterance',
+        'stage_roofline_frac': round(value * 3 * ALG_GFLOP_PER_UTT / 1e3 / world / (PEAK_BF16_TFLOPS if args.amp else PEAK_F32_TFLOPS), 4),
+        'stage_roofline_peak': ('bf16 MFMA 2500' if args.amp else 'f32 MFMA 157.3') + ' TFLOP/s per GPU, 3 x forward flops per utterance',
     }
     out.update(comm)
     if emit:
@@ -485,6 +489,7 @@ def main():
     ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float32'])
     ap.add_argument('--streams', type=int, default=2, help='concurrent launch sequences per GPU (infer mode)')
     ap.add_argument('--graph', type=int, default=1, help='infer mode: replay the step from one captured HIP graph (1) or launch eagerly (0)')
+    ap.add_argument('--amp', type=int, default=1, help='training: conv GEMMs on the bf16 matrix cores over f32 tensors (enable_amp); 0 = exact f32')
     ap.add_argument('--global-batch', type=int, default=BATCH, help='train mode: global batch (strong scaling)')
     ap.add_argument('--weak', action='store_true', help='train mode: keep --global-batch utterances PER GPU')
     ap.add_argument('--no-train-line', action='store_true', help='infer mode: skip the "dp_train" measurement')

@@ -144,6 +144,9 @@ typedef struct {
     const float* pro_shift;
     const void* res; int ld_res, res_off;        /* residual added after BN, before act2 (dtype_out)     */
     const float* gate; int gate_len, gate_nseg;  /* [B*gate_nseg][Cout]: y *= gate[b, t / gate_len, :]   */
+    /* --- mixed-precision training (trainer.py:209-229, auto_cast O1) --------------------------------------------------- */
+    int mfma_bf16;                       /* f32 tensors only: 1 = round x and w to bf16 while staging and run the bf16
+                                            matrix cores (f32 accumulate, f32 out); 0 = exact f32 matrix cores            */
 } vp_conv1d_desc;
 
 int vp_conv1d_tiles_m(int B, int T_out);            /* rows of the psum arrays                     */

@@ -29,6 +29,41 @@ import torch.nn.functional as F
 
 BN_EPS = 1e-5
 
+# Mixed-precision emulation for the tests of the HIP training engine under enable_amp: when AMP is True every convolution
+# GEMM sees its operands rounded to bf16 -- x and w in the forward and in the weight / data gradient, the incoming gradient
+# dz in both backward GEMMs -- while biases, BatchNorm, activations and accumulation keep the tensor dtype (float64 in the
+# tests): the arithmetic libvpmi performs with vp_conv1d_desc.mfma_bf16, minus its f32 accumulation order.
+AMP = False
+
+
+class _RoundBf16(torch.autograd.Function):
+    """bf16 rounding forward, straight-through backward (the GEMM reads a rounded copy; the tensor itself is untouched)."""
+    @staticmethod
+    def forward(ctx, x):
+        return x.float().to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundGradBf16(torch.autograd.Function):
+    """identity forward, bf16-rounded gradient backward (both backward GEMMs read dz rounded)."""
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.float().to(torch.bfloat16).to(g.dtype)
+
+
+def _conv1d(x, w, b=None, **kw):
+    if not AMP:
+        return F.conv1d(x, w, b, **kw)
+    y = _RoundGradBf16.apply(F.conv1d(_RoundBf16.apply(x), _RoundBf16.apply(w), None, **kw))
+    return y if b is None else y + b.view(1, -1, 1)
+
 
 # ----------------------------------------------------------------------------- layers
 def conv1d_same(x, w, b, dilation=1):
@@ -37,7 +72,7 @@ def conv1d_same(x, w, b, dilation=1):
     pad = dilation * (k - 1) // 2
     if pad > 0:
         x = F.pad(x, (pad, pad), mode='reflect')
-    return F.conv1d(x, w, b, dilation=dilation)
+    return _conv1d(x, w, b, dilation=dilation)
 
 
 def batchnorm(x, p, prefix, training=False, stats_out=None):
@@ -76,15 +111,15 @@ def res2net_block(x, p, prefix, scale=8, dilation=1, training=False, stats_out=N
 
 def se_block(x, p, prefix):
     s = x.mean(dim=2, keepdim=True)
-    s = F.relu(F.conv1d(s, p[prefix + 'conv1.conv.weight'], p[prefix + 'conv1.conv.bias']))
-    s = torch.sigmoid(F.conv1d(s, p[prefix + 'conv2.conv.weight'], p[prefix + 'conv2.conv.bias']))
+    s = F.relu(_conv1d(s, p[prefix + 'conv1.conv.weight'], p[prefix + 'conv1.conv.bias']))
+    s = torch.sigmoid(_conv1d(s, p[prefix + 'conv2.conv.weight'], p[prefix + 'conv2.conv.bias']))
     return s * x
 
 
 def seres2net_block(x, p, prefix, scale=8, dilation=1, training=False, stats_out=None):
     residual = x
     if (prefix + 'shortcut.conv.weight') in p:
-        residual = F.conv1d(x, p[prefix + 'shortcut.conv.weight'], p[prefix + 'shortcut.conv.bias'])
+        residual = _conv1d(x, p[prefix + 'shortcut.conv.weight'], p[prefix + 'shortcut.conv.bias'])
     x = tdnn_block(x, p, prefix + 'tdnn1.', 1, training, stats_out)
     x = res2net_block(x, p, prefix + 'res2net_block.', scale, dilation, training, stats_out)
     x = tdnn_block(x, p, prefix + 'tdnn2.', 1, training, stats_out)
@@ -108,7 +143,7 @@ def asp(x, p, prefix, global_context=True, training=False, stats_out=None, eps=1
     else:
         attn = x
     attn = tdnn_block(attn, p, prefix + 'tdnn.', 1, training, stats_out)
-    attn = F.conv1d(torch.tanh(attn), p[prefix + 'conv.conv.weight'], p[prefix + 'conv.conv.bias'])
+    attn = _conv1d(torch.tanh(attn), p[prefix + 'conv.conv.weight'], p[prefix + 'conv.conv.bias'])
     attn = F.softmax(attn, dim=2)
     mean, std = stats(x, attn)
     return torch.cat([mean, std], dim=1)
@@ -141,7 +176,7 @@ def ecapa_forward(p, x, prefix='', training=False, stats_out=None, taps=None, **
     if taps is not None:
         taps['asp'] = x
     x = batchnorm(x, p, prefix + 'asp_bn.norm.', training, stats_out)
-    x = F.conv1d(x.unsqueeze(2), p[prefix + 'fc.conv.weight'], p[prefix + 'fc.conv.bias']).squeeze(-1)
+    x = _conv1d(x.unsqueeze(2), p[prefix + 'fc.conv.weight'], p[prefix + 'fc.conv.bias']).squeeze(-1)
     return x
 
 
@@ -149,9 +184,9 @@ def tdnn_forward(p, x, prefix='', training=False, stats_out=None):
     """TDNN.forward (tdnn.py:46-68), pooling_type ASP: five un-padded Conv1D + ReLU + BN."""
     x = x.transpose(1, 2)
     for i, d in zip(range(1, 5), (1, 2, 3, 1)):
-        x = F.relu(F.conv1d(x, p[f'{prefix}td_layer{i}.weight'], p[f'{prefix}td_layer{i}.bias'], dilation=d))
+        x = F.relu(_conv1d(x, p[f'{prefix}td_layer{i}.weight'], p[f'{prefix}td_layer{i}.bias'], dilation=d))
         x = batchnorm(x, p, f'{prefix}bn{i}.', training, stats_out)
-    x = F.relu(F.conv1d(x, p[prefix + 'td_layer5.weight'], p[prefix + 'td_layer5.bias']))
+    x = F.relu(_conv1d(x, p[prefix + 'td_layer5.weight'], p[prefix + 'td_layer5.bias']))
     x = asp(x, p, prefix + 'pooling.', True, training, stats_out)
     x = batchnorm(x, p, prefix + 'bn5.norm.', training, stats_out)
     x = x @ p[prefix + 'linear.weight'] + p[prefix + 'linear.bias']        # Paddle Linear: [in, out]

@@ -158,7 +158,7 @@ def conv_ref(x, w, bias, kw, dil, pad_mode, stride=1):
 
 
 def run_conv(N, x, w, bias, kw, dil, pad_mode, dtype, out_dtype=None, relu=False, bn=None, act2=0, rowbias=None,
-             add_in=None, want_sums=False, ysplit=0, T_out=None):
+             add_in=None, want_sums=False, ysplit=0, T_out=None, amp=False):
     lib, ctx = N.lib(), N.ctx(0)
     B, T, Cin = x.shape
     Cout = w.shape[0]
@@ -175,6 +175,7 @@ def run_conv(N, x, w, bias, kw, dil, pad_mode, dtype, out_dtype=None, relu=False
     d.B, d.T_in, d.T_out, d.Cin, d.Cout, d.KW, d.dilation, d.stride = B, T, T_out, Cin, Cout, kw, dil, 1
     d.pad_mode, d.pad_left = pm, (0 if pad_mode == 'none' else dil * (kw - 1) // 2)
     d.x, d.ldx, d.xoff = xd.data_ptr(), Cin, 0
+    d.mfma_bf16 = int(amp)
     keep = [xd, wd, y]
     y2 = None
     if ysplit:
@@ -245,6 +246,24 @@ def test_conv1d_plain(N, case, dtype):
     # same quantised inputs on both sides: only accumulation order / f32 accumulate differs
     assert err < 2e-4, err
     assert y.shape == ref.shape
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv1d_mixed_precision(N, case):
+    """vp_conv1d_desc.mfma_bf16: f32 tensors, operands rounded to bf16 while staging, bf16 matrix cores, f32 accumulate and f32
+    out (the training engine under enable_amp) == float64 conv of the bf16-rounded operands; and it is NOT the exact-f32 result."""
+    B, T, Cin, Cout, kw, dil, pad = case
+    g = torch.Generator().manual_seed(7 * kw + dil)
+    x = torch.randn(B, T, Cin, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, kw, generator=g, dtype=torch.float64) / (Cin * kw) ** 0.5
+    bias = torch.randn(Cout, generator=g, dtype=torch.float64)
+    ref = conv_ref(q(x, 'bf16'), q(w, 'bf16'), bias, kw, dil, pad)
+    y, _, ps, pq = run_conv(N, x, w, bias, kw, dil, pad, 'f32', amp=True, want_sums=True)
+    assert y.dtype == torch.float32
+    assert (y.double().cpu() - ref).abs().max().item() < 2e-4
+    exact = conv_ref(q(x, 'f32'), q(w, 'f32'), bias, kw, dil, pad)
+    assert (y.double().cpu() - exact).abs().max().item() > 1e-3          # bf16 rounding of the operands is really there
+    assert not torch.isnan(ps).any()
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])

@@ -550,3 +550,112 @@ def test_eval_engine_follows_training_updates(N):
     assert rel(e1['float32'], ref1) < 1e-5, rel(e1['float32'], ref1)
     assert rel(eg1, ref1) < 1e-5 and rel(eg1, eg0) > 1e-3
     assert rel(e1['bfloat16'], ref1) < 2e-2 and rel(e1['bfloat16'], e0['bfloat16']) > 1e-3
+
+
+# ------------------------------------------------------------------------------- mixed precision (train_conf.enable_amp)
+@pytest.fixture
+def amp():
+    import ppvector
+    ppvector.set_train_amp(True)
+    yield
+    ppvector.set_train_amp(False)
+
+
+@pytest.mark.parametrize('case', [
+    # B, T, Cin, Cout, kw, dil, pad
+    (70, 131, 512, 512, 1, 1, 'none'),    # the wide 1x1 layers: the 128 x 128 weight-gradient tiles' fast path (source row = output row)
+    (9, 77, 192, 320, 1, 1, 'none'),      # ragged tiles (N, K not multiples of 128), rows not a multiple of the 64-row chunk
+    (3, 50, 80, 64, 5, 1, 'none'),        # taps, Cin % 64 != 0
+    (3, 40, 64, 64, 3, 4, 'reflect'),     # ECAPA Res2 conv
+    (2, 33, 80, 128, 5, 1, 'reflect'),    # ECAPA block0
+])
+def test_conv_block_grads_mixed_precision(N, amp, case):
+    """enable_amp: forward, data gradient and weight gradient on the bf16 matrix cores over f32 tensors.  Forward == float64 conv
+    of the bf16-rounded operands (tight); gradients vs float64 autograd of the UN-rounded graph at bf16 tolerances (each GEMM
+    operand carries 2^-9 relative rounding: rel-L2 of a few 1e-3 per gradient)."""
+    from ppvector.train.functions import ConvBlock
+    B, T, Cin, Cout, kw, dil, pad = case
+    g = torch.Generator().manual_seed(11 + kw + dil + Cin)
+    x = torch.randn(B, T, Cin, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Cout, Cin, kw, generator=g, dtype=torch.float64) / (Cin * kw) ** 0.5).requires_grad_()
+    b = torch.randn(Cout, generator=g, dtype=torch.float64, requires_grad=True)
+    xt = x.transpose(1, 2)
+    if pad == 'reflect':
+        xt = F.pad(xt, (dil * (kw - 1) // 2,) * 2, mode='reflect')
+    y = F.conv1d(xt, w, b, dilation=dil).transpose(1, 2)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    xq, wq = x.detach().float().bfloat16().double(), w.detach().float().bfloat16().double()
+    xtq = xq.transpose(1, 2)
+    if pad == 'reflect':
+        xtq = F.pad(xtq, (dil * (kw - 1) // 2,) * 2, mode='reflect')
+    yq = F.conv1d(xtq, wq, b.detach(), dilation=dil).transpose(1, 2)
+    xd = x.detach().float().reshape(B * T, Cin).cuda().requires_grad_()
+    wd, bd = w.detach().float().cuda().requires_grad_(), b.detach().float().cuda().requires_grad_()
+    out = ConvBlock.apply(xd, wd, bd, None, None, None, None, None, dict(B=B, T=T, dilation=dil, pad=pad, relu=False))
+    out.backward(dy.float().reshape(-1, Cout).cuda())
+    To = y.shape[1]
+    assert rel(out.reshape(B, To, Cout), yq) < 2e-6                      # exactly the bf16-operand product, f32 accumulated
+    assert rel(out.reshape(B, To, Cout), y.detach()) > 1e-4              # ... and not the f32 one
+    for name, got, ref in (('dx', xd.grad.reshape(B, T, Cin), x.grad), ('dW', wd.grad, w.grad), ('dbias', bd.grad, b.grad)):
+        r = rel(got, ref)
+        print(f'[amp conv {case}] {name} rel-L2 {r:.2e}')
+        assert r < (2e-5 if name == 'dbias' else 8e-3), (name, r)
+
+
+def test_ecapa_training_step_mixed_precision(N, amp):
+    """ECAPA-TDNN training step under enable_amp.  Two references over the oracle graph, both float64 autograd:
+      exact -- the plain graph;  emulated -- the same graph with every conv GEMM's operands (x, w, and dz in both backward GEMMs)
+      rounded to bf16 (oracle.models.AMP), i.e. the arithmetic the engine performs minus its f32 accumulation order.
+    Measured on MI355X (B = 6, T = 60): loss 12.1558 (emulated 12.1512, exact 12.1613); whole-gradient rel-L2 engine vs exact
+    2.25e-1, emulated vs exact 2.24e-1, engine vs emulated 9.3e-2.  bf16 GEMM operands move this tiny train-mode-BatchNorm graph
+    by 22 % in its gradient whoever does the arithmetic (BatchNorm backward subtracts the dominant common mode of dy and so
+    amplifies the 2^-9 operand rounding; an f32-vs-f64 accumulation difference flips individual roundings, hence engine and
+    emulation differ too) -- a property of mixed precision on this problem, not of the kernels, which are held to 2.4e-3 per
+    GEMM in test_conv_block_grads_mixed_precision.  Asserted: the engine is closer to the emulation than the emulation is to
+    the exact graph, and no further from the exact graph than 1.5 x the emulation."""
+    from ppvector.models.ecapa_tdnn import EcapaTdnn
+    from ppvector.train.functions import HeadLoss
+    B, T, Cc = 6, 60, 30
+    p = om.ecapa_params(80, seed=21)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(B, T, 80, generator=g) * 2
+    labels = torch.randint(0, Cc, (B,), generator=g)
+    Wh = om.head_params(192, Cc, seed=5)
+
+    def oracle(amp_on):
+        pr = {k: v.clone().double().requires_grad_(not k.endswith(('_mean', '_variance'))) for k, v in p.items()}
+        Wr = Wh.clone().double().requires_grad_()
+        om.AMP = amp_on
+        try:
+            emb = om.ecapa_forward(pr, x.double(), training=True)
+            loss = om.aam_loss(om.cosine_head(emb, Wr), labels, 0.2, 32.0, False, 0.0)
+            loss.backward()
+        finally:
+            om.AMP = False
+        return emb.detach(), loss.item(), {k: v.grad for k, v in pr.items() if v.grad is not None and v.grad.norm().item() >= 1e-9}
+
+    emb_x, loss_x, g_x = oracle(False)
+    emb_e, loss_e, g_e = oracle(True)
+    m = EcapaTdnn(80)
+    m.load_state_dict(p)
+    m = m.cuda().train()
+    Wd = Wh.cuda().requires_grad_()
+    emb = m(x.cuda())
+    loss = HeadLoss.apply(emb, Wd, labels.cuda(), 0.2, 32.0, 0.0, False)
+    loss.backward()
+    got = {k: v.grad.double().cpu() for k, v in m.named_parameters()}
+
+    def whole(a, b):
+        num = sum((a[k] - b[k]).pow(2).sum().item() for k in b)
+        return (num / sum(b[k].pow(2).sum().item() for k in b)) ** 0.5
+
+    w_emu, w_exact, w_inh = whole(got, g_e), whole(got, g_x), whole(g_e, g_x)
+    print(f'[ecapa train amp] loss {loss.item():.5f} (emulated {loss_e:.5f}, exact {loss_x:.5f});  emb rel-L2 vs emulated {rel(emb, emb_e):.2e}, '
+          f'vs exact {rel(emb, emb_x):.2e};  whole-gradient rel-L2 vs emulated {w_emu:.2e}, vs exact {w_exact:.2e} '
+          f'(emulated vs exact: {w_inh:.2e})')
+    assert abs(loss.item() - loss_e) < 1e-3 * abs(loss_e) and rel(emb, emb_e) < 2e-2
+    assert w_emu < w_inh, (w_emu, w_inh)
+    assert abs(loss.item() - loss_x) < 2e-3 * abs(loss_x) and rel(emb, emb_x) < 3e-2
+    assert w_exact < 1.5 * w_inh + 2e-2, (w_exact, w_inh)
+    m.eval()

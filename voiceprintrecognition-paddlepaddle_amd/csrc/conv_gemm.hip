@@ -27,6 +27,7 @@
 int vp_conv_launch_bf16_bf16(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
 int vp_conv_launch_bf16_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
 int vp_conv_launch_f32_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
+int vp_conv_launch_amp_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
 int vp_conv_launch256_bf16(vp_ctx* ctx, const void* args, int mode, int sched, hipStream_t st);
 
 // Schedule of the 256-wide kernel: 0 pins the 128-wide kernel; 1 = interleaved DMA, 2 = ping-pong phases, 3 = role-split
@@ -137,6 +138,7 @@ int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream) {
     }
     if (d->dtype_in == VP_BF16 && d->dtype_out == VP_BF16) return vp_conv_launch_bf16_bf16(ctx, &a, bn, mode, st);
     if (d->dtype_in == VP_BF16 && d->dtype_out == VP_F32) return vp_conv_launch_bf16_f32(ctx, &a, bn, mode, st);
+    if (d->mfma_bf16) return vp_conv_launch_amp_f32(ctx, &a, bn, mode, st);
     return vp_conv_launch_f32_f32(ctx, &a, bn, mode, st);
 }
 

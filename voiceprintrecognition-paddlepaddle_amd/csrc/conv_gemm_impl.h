@@ -3,6 +3,8 @@
 #pragma once
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int BM = VP_CONV_BM;
@@ -31,9 +33,18 @@ struct ConvArgs {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
+// amp_t: f32 tensors in memory, ROUNDED TO bf16 on their way into LDS -- bf16 MFMA with f32 accumulation and f32 outputs
+// (the mixed-precision training engine: paddle.amp.auto_cast O1 runs conv / matmul in low precision and keeps the rest f32,
+// trainer.py:209-229).  A stage is 32 k (one v_mfma_f32_16x16x32_bf16 step) = 64-byte LDS rows.
+struct amp_t { float v; };
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { bf16x8 v; };
 template <> struct Frag<float> { float4 lo, hi; };
+template <> struct Frag<amp_t> { bf16x8 v; };
+constexpr int ROWB_AMP = 64;
+// 64-byte rows: the ds_read_b128 lane groups ({0-3,12-15,20-27}, ...) are conflict-free with the 16-B chunk g stored at
+// position g ^ ((-(row >> 2)) & 3)
+__device__ __forceinline__ int amp_pos(int row, int g) { return (g ^ ((0 - (row >> 2)) & 3)) << 4; }
 
 __device__ __forceinline__ void load_frag(const char* tile, int row, int ks, int g, Frag<bf16_t>& f) {
     const int c = ks * 4 + g;
@@ -44,9 +55,15 @@ __device__ __forceinline__ void load_frag(const char* tile, int row, int /*ks*/,
     f.lo = *reinterpret_cast<const float4*>(tile + row * ROWB + ((c ^ (row & 7)) << 4));
     f.hi = *reinterpret_cast<const float4*>(tile + row * ROWB + (((c + 1) ^ (row & 7)) << 4));
 }
+__device__ __forceinline__ void load_frag(const char* tile, int row, int /*ks*/, int g, Frag<amp_t>& f) {
+    f.v = *reinterpret_cast<const bf16x8*>(tile + row * ROWB_AMP + amp_pos(row, g));
+}
 // D[n][m] += sum_k W[n][k] * X[m][k]: weights are the A operand (row = lane & 15 -> n), activations
 // the B operand (col = lane & 15 -> m); result register r of lane l = (n = (l >> 4) * 4 + r, m = l & 15).
 __device__ __forceinline__ void mma(const Frag<bf16_t>& w, const Frag<bf16_t>& x, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, x.v, c, 0, 0, 0);
+}
+__device__ __forceinline__ void mma(const Frag<amp_t>& w, const Frag<amp_t>& x, f32x4& c) {
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, x.v, c, 0, 0, 0);
 }
 __device__ __forceinline__ void mma(const Frag<float>& w, const Frag<float>& x, f32x4& c) {
@@ -92,6 +109,20 @@ __device__ __forceinline__ u32x4 prologue_chunk(u32x4 v, const float (&s)[8], co
     }
     return o;
 }
+__device__ __forceinline__ u32x4 prologue_chunk(u32x4 v, const float (&s)[8], const float (&h)[8], float);
+__device__ __forceinline__ u32x4 prologue_chunk(u32x4 v, const float (&s)[8], const float (&h)[8], amp_t) {
+    return prologue_chunk(v, s, h, float{});
+}
+// four f32 -> four bf16 (round to nearest even), packed into 8 bytes
+__device__ __forceinline__ uint2 amp_pack(u32x4 v) {
+    const unsigned a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+    const bf16_t b0 = (bf16_t)__builtin_bit_cast(float, a0), b1 = (bf16_t)__builtin_bit_cast(float, a1);
+    const bf16_t b2 = (bf16_t)__builtin_bit_cast(float, a2), b3 = (bf16_t)__builtin_bit_cast(float, a3);
+    uint2 o;
+    o.x = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
+    o.y = (unsigned)__builtin_bit_cast(unsigned short, b2) | ((unsigned)__builtin_bit_cast(unsigned short, b3) << 16);
+    return o;
+}
 __device__ __forceinline__ u32x4 prologue_chunk(u32x4 v, const float (&s)[8], const float (&h)[8], float) {
     u32x4 o;
 #pragma unroll
@@ -112,7 +143,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
     constexpr int MI = BM / (WM * 16);
     constexpr int WCOLS = NI * 16;
     constexpr int BROWS = BN / 32;
-    constexpr int STAGE = (BM + BN) * ROWB;
+    constexpr bool AMP = std::is_same<TI, amp_t>::value;
+    constexpr int RB = AMP ? ROWB_AMP : ROWB;            // bytes per tile row per stage in LDS
+    constexpr int STAGE = (BM + BN) * RB;
     constexpr bool PRO = MODE == MODE_1X1_PRO;
     constexpr bool ONE = MODE == MODE_1X1 || MODE == MODE_1X1_PRO;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -150,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
 
     // global -> LDS staging assignment: 16-B chunk cc of rows r0 + 32 i
     const int cc = tid & 7, r0 = tid >> 3;
-    const int pw = (cc ^ (r0 & 7)) << 4;
+    const int pw = AMP ? ((((cc >> 1) ^ ((0 - (r0 >> 2)) & 3)) << 4) + (cc & 1) * 8) : ((cc ^ (r0 & 7)) << 4);
     const bool zero_pad = a.pad_mode == VP_PAD_ZERO;
     const unsigned ldxb = (unsigned)a.ldx * ES;
     // per staged row: rowoff = byte offset of (utterance b, frame 0 [, freq 0]); tpos / fpos = the
@@ -251,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
     auto swrite = [&](int s, const u32x4 (&ra)[4], const u32x4 (&rb)[BROWS], const float (&ps)[NPRO],
                       const float (&ph)[NPRO]) {
         char* As = smem + s * STAGE;
-        char* Bs = As + BM * ROWB;
+        char* Bs = As + BM * RB;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             u32x4 v = ra[i];
@@ -261,10 +294,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
                 for (int e = 0; e < 8; ++e) { s8[e] = ps[e % NPRO]; h8[e] = ph[e % NPRO]; }
                 v = prologue_chunk(v, s8, h8, TI{});
             }
-            *reinterpret_cast<u32x4*>(As + (r0 + 32 * i) * ROWB + pw) = v;
+            if constexpr (AMP) *reinterpret_cast<uint2*>(As + (r0 + 32 * i) * RB + pw) = amp_pack(v);
+            else *reinterpret_cast<u32x4*>(As + (r0 + 32 * i) * RB + pw) = v;
         }
 #pragma unroll
-        for (int i = 0; i < BROWS; ++i) *reinterpret_cast<u32x4*>(Bs + (r0 + 32 * i) * ROWB + pw) = rb[i];
+        for (int i = 0; i < BROWS; ++i) {
+            if constexpr (AMP) *reinterpret_cast<uint2*>(Bs + (r0 + 32 * i) * RB + pw) = amp_pack(rb[i]);
+            else *reinterpret_cast<u32x4*>(Bs + (r0 + 32 * i) * RB + pw) = rb[i];
+        }
     };
 
     f32x4 acc[MI][NI];
@@ -275,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
 
     auto compute = [&](int s) {
         const char* As = smem + s * STAGE;
-        const char* Bs = As + BM * ROWB;
+        const char* Bs = As + BM * RB;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             Frag<TI> xf[MI], wf[NI];

@@ -49,3 +49,19 @@ def set_forward_streams(n):
 
 def get_forward_streams():
     return _FORWARD_STREAMS
+
+
+_TRAIN_AMP = False
+
+
+def set_train_amp(on):
+    """Mixed-precision training (the reference's train_conf.enable_amp -> paddle.amp.auto_cast level O1, trainer.py:209-229): the
+    convolution GEMMs of the training step -- forward, data gradient, weight gradient -- round their f32 operands to bf16 on the way
+    into LDS and run the bf16 matrix cores with f32 accumulation; tensors, BatchNorm statistics, the head / loss, gradients in
+    memory and the Adam master weights stay f32.  bf16 has f32's exponent range: no loss scaling (GradScaler) is needed."""
+    global _TRAIN_AMP
+    _TRAIN_AMP = bool(on)
+
+
+def get_train_amp():
+    return _TRAIN_AMP

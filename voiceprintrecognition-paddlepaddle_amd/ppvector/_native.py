@@ -51,7 +51,7 @@ class Conv1dDesc(C.Structure):
                 ('F_in', c_int), ('F_out', c_int), ('KF', c_int), ('stride_f', c_int), ('pad_f', c_int),
                 ('pro_scale', c_void_p), ('pro_shift', c_void_p),
                 ('res', c_void_p), ('ld_res', c_int), ('res_off', c_int),
-                ('gate', c_void_p), ('gate_len', c_int), ('gate_nseg', c_int)]
+                ('gate', c_void_p), ('gate_len', c_int), ('gate_nseg', c_int), ('mfma_bf16', c_int)]
 
 
 class TdnnLayer(C.Structure):

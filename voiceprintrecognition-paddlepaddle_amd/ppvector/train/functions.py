@@ -13,6 +13,8 @@ import ctypes as C
 
 import torch
 
+import ppvector
+
 from ppvector import _native as N
 
 _PAD = {'none': N.VP_PAD_NONE, 'zero': N.VP_PAD_ZERO, 'reflect': N.VP_PAD_REFLECT}
@@ -45,6 +47,7 @@ def _conv_desc(x, B, T_in, T_out, Cin, Cout, KW, dil, pad_mode, pad_left, w, bia
         d.rowbias = rowbias.data_ptr()
     d.act = N.VP_ACT_RELU if relu else N.VP_ACT_NONE
     d.ldy = Cout
+    d.mfma_bf16 = int(ppvector.get_train_amp())          # enable_amp: bf16 matrix cores over f32 tensors (forward, dgrad and wgrad)
     return d
 
 

@@ -25,6 +25,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 import yaml
+
+import ppvector
 from torch import nn
 
 from ppvector.data_utils.featurizer import AudioFeaturizer
@@ -204,8 +206,9 @@ class PPVectorTrainer(object):
     def __setup_model(self, input_size, is_train=False):
         self.backbone = build_model(input_size=input_size, configs=self.configs)
         if is_train:
-            if self.configs.train_conf.get('enable_amp', False):
-                raise NotImplementedError('enable_amp: the MI355X training engine is f32 (every shipped config sets enable_amp: False)')
+            # enable_amp (trainer.py:209-229: auto_cast O1 + GradScaler): conv GEMMs on the bf16 matrix cores over f32 tensors;
+            # bf16 keeps f32's exponent range, so there is no loss scale to maintain (amp_scaler stays None)
+            ppvector.set_train_amp(bool(self.configs.train_conf.get('enable_amp', False)))
             num_class = self.configs.model_conf.classifier.num_speakers
             spd = self.data_augment_configs.get('speed') if self.data_augment_configs is not None else None
             if spd is not None and spd.get('prob', 0.0) > 0 and spd.get('speed_perturb_3_class', False):
