@@ -113,17 +113,24 @@ __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8
                 char* cell = slab + q8 * OROW + c8 * 4;
                 // two instances of the row loop: without a second activation (conv -> ReLU -> BN, the TDNN block) the clamp
                 // pair is dead work -- 16 of ~44 VALU instructions per 8 values in a loop that is VALU-bound
-                auto rows = [&](auto clamp2, auto straddle) {
+                // The column sums are taken over r = act(acc + bias), BEFORE the BN affine, when no second activation follows: sum(y - shift)
+                // = scale * sum(r), sum((y - shift)^2) = scale^2 * sum(r^2) -- one add (and one fma for the squares, only when
+                // asked for) per value instead of sub / add / fma; the scale is applied once per lane after the passes.
+                auto rows = [&](auto clamp2, auto straddle, auto wantsq) {
+                    constexpr bool PRE = !decltype(clamp2)::value;
+                    constexpr bool SQ = decltype(wantsq)::value;
                     int row = rp * RS + q8;                    // of the wave's 64
 #pragma unroll 2
                     for (int j = 0; j < RS / 8; ++j) {
                         const f32x4 a0 = *reinterpret_cast<const f32x4*>(cell);
                         const f32x4 a1 = *reinterpret_cast<const f32x4*>(cell + 16);
-                        float v[8];
+                        float v[8], r8[8];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            v[e] = fmaxf(a0[e] + bs[e], lo1) * sc[e] + sh[e];
-                            v[e + 4] = fmaxf(a1[e] + bs[e + 4], lo1) * sc[e + 4] + sh[e + 4];
+                            r8[e] = fmaxf(a0[e] + bs[e], lo1);
+                            r8[e + 4] = fmaxf(a1[e] + bs[e + 4], lo1);
+                            v[e] = r8[e] * sc[e] + sh[e];
+                            v[e + 4] = r8[e + 4] * sc[e + 4] + sh[e + 4];
                             if constexpr (decltype(clamp2)::value) {
                                 v[e] = fminf(fmaxf(v[e], lo2), hi2);
                                 v[e + 4] = fminf(fmaxf(v[e + 4], lo2), hi2);
@@ -139,11 +146,13 @@ __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8
                             const float mk = row < rb ? 1.f : 0.f;
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
-                                const float d = v[e] - sh[e];
-                                p1[e] += d; p2[e] += d * d;
+                                const float d = PRE ? r8[e] : v[e] - sh[e];
+                                p1[e] += d;
+                                if constexpr (SQ) p2[e] += d * d;
                                 if constexpr (decltype(straddle)::value) {
                                     const float dm = d * mk;
-                                    q1[e] += dm; q2[e] += dm * d;
+                                    q1[e] += dm;
+                                    if constexpr (SQ) q2[e] += dm * d;
                                 }
                             }
                         }
@@ -151,12 +160,18 @@ __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8
                         cell += 8 * OROW;
                     }
                 };
-                if (rb >= 64 || !sums) {
-                    if (a.act2 == VP_ACT_NONE) rows(std::false_type{}, std::false_type{});
-                    else rows(std::true_type{}, std::false_type{});
+                const bool strad = sums && rb < 64;
+                if (a.act2 == VP_ACT_NONE) {
+                    if (a.psumsq) {
+                        if (strad) rows(std::false_type{}, std::true_type{}, std::true_type{});
+                        else rows(std::false_type{}, std::false_type{}, std::true_type{});
+                    } else {
+                        if (strad) rows(std::false_type{}, std::true_type{}, std::false_type{});
+                        else rows(std::false_type{}, std::false_type{}, std::false_type{});
+                    }
                 } else {
-                    if (a.act2 == VP_ACT_NONE) rows(std::false_type{}, std::true_type{});
-                    else rows(std::true_type{}, std::true_type{});
+                    if (strad) rows(std::true_type{}, std::true_type{}, std::true_type{});
+                    else rows(std::true_type{}, std::false_type{}, std::true_type{});
                 }
             } else {
                 int m = mwp + q4;
@@ -217,6 +232,13 @@ __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8
             }
         }
         if (a.psum && fastw) {
+            if (a.act2 == VP_ACT_NONE) {             // sums were taken before the BN affine (see the row loop)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float s2 = sc[e] * sc[e];
+                    p1[e] *= sc[e]; q1[e] *= sc[e]; p2[e] *= s2; q2[e] *= s2;
+                }
+            }
             // the 8 lanes of a channel group (equal lane & 7) hold partial sums over disjoint rows
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
