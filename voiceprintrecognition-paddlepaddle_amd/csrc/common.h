@@ -19,6 +19,8 @@ struct vp_ctx {
     int* fb_mel_start;    // [nmel + 1] CSR offsets into fb_mel_w
     int* fb_mel_bin0;     // [nmel] first FFT bin of each filter
     float* fb_mel_w;      // [nnz]
+    float* fb_wpad;       // padded [round][tap][16] mel weights of the four-frames-per-wave kernel (x 0.25)
+    int fb_f16, fb_rounds, fb_wpad_len, fb_round_off[8], fb_round_max[8];
     // MelSpectrogram tables
     vp_mel_opts ms_opts;
     int ms_valid, ms_nnz;

@@ -19,6 +19,7 @@
 #include "common.h"
 
 #include <math.h>
+#include <algorithm>
 #include <vector>
 
 namespace {
@@ -235,6 +236,225 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_frames_kernel(FbankArgs a
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// fbank_frames16_kernel: four frames per wave, the 256-point complex FFT as 16 x 16 (two register-resident radix-16
+// passes, ONE exchange through LDS) instead of one frame per wave and four radix-4 passes through LDS.
+//   lane = (frame f = lane >> 4 of the wave's four, j = lane & 15).  With packed point n = 16 n1 + n2 and bin k = k1 + 16 k2:
+//     X[k1 + 16 k2] = sum_n2 W16^(n2 k2) * [ W256^(n2 k1) * sum_n1 z[16 n1 + n2] W16^(n1 k1) ]
+//   pass 1: lane j = n2 holds z[16 n1 + j], n1 = 0..15, straight from global memory (16 lanes read 128 contiguous bytes per
+//           n1; points past the window are literal zeros the compiler prunes from the butterflies), DFT-16 over n1, twiddle;
+//   exchange: element (k1, n2) of the frame goes to LDS slot k1 * 17 + n2 (rows padded by one slot: conflict-free both ways, and
+//           every address is a lane base plus an immediate);
+//   pass 2: lane j = k1 reads its 16 n2, DFT-16 over n2 -> X[j + 16 k2]; Z goes back to LDS in bin order;
+//   unpack: lane j takes the bin pairs (k, 256 - k), k = j + 16 r, r = 0..7 (they share e and w o); no other lane reads those two
+//           slots, so the (4x-scaled: the mel weights carry the 0.25) powers overwrite them in place;
+//   mel: rounds of 16 filters, lane j = filter 16 r + j of frame f, taps padded to the round's longest filter (filters of a
+//        round have similar widths), weights from LDS in [tap][16] order; log; 64 contiguous bytes per frame and round.
+// The old kernel ran ~600 VALU + LDS instructions per frame-wave; this one ~190.
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+constexpr int F16_MAX_TAPS = 32;             // longest filter (taps) a round may have: the zeroed tail behind bin 255
+constexpr int F16_ZSTRIDE = 2048 + F16_MAX_TAPS * 8 + 128;   // bytes per frame in the per-wave exchange buffer: 256 slots of 8 B, the
+                                             // zero tail, and 128 B that put odd frames on the other 32 banks (stride = 128 mod 256)
+constexpr int F16_MAX_WPAD = 1536;           // padded mel taps (floats) the kernel keeps in LDS
+constexpr int F16_MAX_ROUNDS = FB_MAX_MEL / 16;
+
+struct Fbank16Args {
+    const float* wav; float* out; float* psum; const float* window; const float2* tw;
+    const float* wpad; const int* mel_bin0;
+    int B, L, T, tiles, win, shift, n_mels, n_rounds, wpad_len;
+    int round_off[F16_MAX_ROUNDS], round_max[F16_MAX_ROUNDS];
+    float preemph, log_floor;
+    int remove_dc;
+};
+
+__device__ __forceinline__ v2f c_mul(v2f a, v2f b) { return v2f{a.x, a.x} * b + v2f{a.y, a.y} * v2f{-b.y, b.x}; }
+
+__device__ __forceinline__ void dft4(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {          // forward, W4 = -i
+    const v2f s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
+    const v2f r13 = v2f{d13.y, -d13.x};                                             // -i * d13
+    a0 = s02 + s13; a1 = d02 + r13; a2 = s02 - s13; a3 = d02 - r13;
+}
+
+// in-place 16-point forward DFT as 4 x 4; output k lives in v[4 (k & 3) + (k >> 2)]
+__device__ __forceinline__ void dft16(v2f (&v)[16]) {
+    constexpr float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) dft4(v[b], v[4 + b], v[8 + b], v[12 + b]);          // v[4 c + b] = t[b][c]
+    // t[b][c] *= W16^(b c)
+    v[4 * 1 + 1] = c_mul(v[4 * 1 + 1], v2f{c1, -s1});
+    v[4 * 1 + 2] = c_mul(v[4 * 1 + 2], v2f{h, -h});
+    v[4 * 1 + 3] = c_mul(v[4 * 1 + 3], v2f{s1, -c1});
+    v[4 * 2 + 1] = c_mul(v[4 * 2 + 1], v2f{h, -h});
+    v[4 * 2 + 2] = v2f{v[4 * 2 + 2].y, -v[4 * 2 + 2].x};
+    v[4 * 2 + 3] = c_mul(v[4 * 2 + 3], v2f{-h, -h});
+    v[4 * 3 + 1] = c_mul(v[4 * 3 + 1], v2f{s1, -c1});
+    v[4 * 3 + 2] = c_mul(v[4 * 3 + 2], v2f{-h, -h});
+    v[4 * 3 + 3] = c_mul(v[4 * 3 + 3], v2f{-c1, s1});
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dft4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);   // v[4 c + d] = Y[c + 4 d]
+}
+#define DFT16_OUT(v, k) v[4 * ((k) & 3) + ((k) >> 2)]
+
+// NP1 = packed-point rows (of 16) that can be non-zero: ceil(win / 32); 13 for the 25 ms window at 16 kHz
+template <int NP1>
+__global__ __launch_bounds__(FB_WAVES * 64, 3) void fbank_frames16_kernel(Fbank16Args a) {
+    __shared__ __attribute__((aligned(16))) float s_win[FB_NFFT];
+    __shared__ __attribute__((aligned(16))) float2 s_tw1[256];                   // W256^(n2 k1) at [n2 * 16 + k1]
+    __shared__ __attribute__((aligned(16))) float s_wpad[F16_MAX_WPAD];
+    __shared__ int s_mbin0[FB_MAX_MEL];
+    __shared__ __attribute__((aligned(16))) char s_x[FB_WAVES][4 * F16_ZSTRIDE];
+    __shared__ float s_red[2][FB_WAVES][FB_MAX_MEL];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int f = lane >> 4, j = lane & 15;
+
+    for (int i = tid; i < FB_NFFT; i += FB_WAVES * 64) s_win[i] = i < a.win ? a.window[i] : 0.f;
+    { const int n2 = tid >> 4, k1 = tid & 15; s_tw1[tid] = a.tw[(2 * n2 * k1) & (FB_NFFT - 1)]; }
+    for (int i = tid; i < a.wpad_len; i += FB_WAVES * 64) s_wpad[i] = a.wpad[i];
+    for (int i = tid; i < FB_MAX_MEL; i += FB_WAVES * 64) s_mbin0[i] = i < a.n_mels ? a.mel_bin0[i] : 0;
+    v2f twu[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { const float2 w = a.tw[j + 16 * r]; twu[r] = v2f{w.x, w.y}; }
+
+    // Resident workgroups walk the (utterance, tile) list: the tables above are staged once, and the samples of the NEXT tile are
+    // fetched while this one is transformed.  samples 2n, 2n+1 of packed point n = 16 n1 + j; the wave's frame is clamped into
+    // the utterance (frames past T are computed on frame T-1 and never stored); reads past the utterance return zero.
+    const int total = a.tiles * a.B;
+    v2u raw[NP1];
+    auto fetch = [&](int id) {
+        const int bb = id / a.tiles, tt = id - bb * a.tiles;
+        const int tf = min(tt * FRAMES_PER_WG + wv * 4 + f, a.T - 1);
+        const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wav + (size_t)bb * a.L), 0,
+                                                                             (unsigned)a.L * 4u, 0x00020000);
+        const unsigned base = (unsigned)(tf * a.shift + 2 * j) * 4u;
+#pragma unroll
+        for (int n1 = 0; n1 < NP1; ++n1) raw[n1] = __builtin_amdgcn_raw_buffer_load_b64(wsrd, base + (unsigned)n1 * 128u, 0, 0);
+    };
+    if ((int)blockIdx.x < total) fetch(blockIdx.x);
+    __syncthreads();
+    int par = 0;
+    for (int id = blockIdx.x; id < total; id += gridDim.x, par ^= 1) {
+    const int b = id / a.tiles, tile = id - b * a.tiles;
+    const int t = tile * FRAMES_PER_WG + wv * 4 + f;
+    const int tl = min(t, a.T - 1);
+
+    // ---- DC removal, pre-emphasis, window, even/odd pack
+    v2f x[NP1];
+    float part = 0.f;
+#pragma unroll
+    for (int n1 = 0; n1 < NP1; ++n1) {
+        x[n1] = __builtin_bit_cast(v2f, raw[n1]);       // whole-vector cast (an element-wise bit_cast of an ext-vector lvalue reads element 0)
+        const int i0 = 32 * n1 + 2 * j;
+        if (n1 < NP1 - 1 && NP1 < 16) part += x[n1].x + x[n1].y;                 // NP1 = ceil(win / 32): only the last row can cross the window end
+        else part += (i0 < a.win ? x[n1].x : 0.f) + (i0 + 1 < a.win ? x[n1].y : 0.f);
+    }
+    if (id + (int)gridDim.x < total) fetch(id + gridDim.x);
+    if (a.remove_dc) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) part += __shfl_xor(part, o);
+        const float mean = part / (float)a.win;
+#pragma unroll
+        for (int n1 = 0; n1 < NP1; ++n1) x[n1] -= v2f{mean, mean};
+    }
+    v2f v[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) v[n1] = v2f{0.f, 0.f};
+#pragma unroll
+    for (int n1 = 0; n1 < NP1; ++n1) {
+        // x[2n - 1]: the odd sample of lane j - 1 (DPP row_shr:1), or for lane 0 of lane 15 one row up (DPP row_ror:1 of the
+        // previous register, kept where row_shr has no source lane); the very first sample replicates itself
+        const float odd = x[n1].y, odd_up = x[n1 > 0 ? n1 - 1 : 0].y, first = x[0].x;      // scalars: see the bit_cast note above
+        const int wrap = n1 > 0 ? __builtin_amdgcn_update_dpp(0, __float_as_int(odd_up), 0x121, 0xf, 0xf, false) : __float_as_int(first);
+        const float prev = __int_as_float(__builtin_amdgcn_update_dpp(wrap, __float_as_int(odd), 0x111, 0xf, 0xf, false));
+        const float2 w = *reinterpret_cast<const float2*>(&s_win[32 * n1 + 2 * j]);
+        v[n1] = v2f{(x[n1].x - a.preemph * prev) * w.x, (x[n1].y - a.preemph * x[n1].x) * w.y};
+    }
+    // ---- pass 1: DFT-16 over n1, twiddle by W256^(j k1), exchange
+    dft16(v);
+    char* xb = s_x[wv] + f * F16_ZSTRIDE;
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) {
+        v2f o = DFT16_OUT(v, k1);
+        if (k1 > 0) { const float2 w = s_tw1[j * 16 + k1]; o = c_mul(o, v2f{w.x, w.y}); }
+        *reinterpret_cast<v2f*>(xb + (k1 * 17 + j) * 8) = o;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) v[n2] = *reinterpret_cast<const v2f*>(xb + (j * 17 + n2) * 8);
+    __builtin_amdgcn_wave_barrier();
+    // ---- pass 2: DFT-16 over n2 -> Z[j + 16 k2], back to LDS in bin order
+    dft16(v);
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) *reinterpret_cast<v2f*>(xb + (j + 16 * k2) * 8) = DFT16_OUT(v, k2);
+    __builtin_amdgcn_wave_barrier();
+    // ---- real-FFT unpack of the pairs (k, 256 - k): 2 X[k] = e + w o, 2 X[256 - k] = conj(e - w o),
+    //      e = Z[k] + conj(Z[256 - k]), o = (Z[k] - conj(Z[256 - k])) / i, w = W512^k.  The mel weights carry the 0.25.
+#pragma unroll
+    for (int r = 0; r < F16_MAX_TAPS / 16; ++r) *reinterpret_cast<float*>(xb + (256 + j + 16 * r) * 8) = 0.f;   // taps past bin 255 (zero weight) must read finite
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int k = j + 16 * r;
+        const v2f zk = *reinterpret_cast<const v2f*>(xb + k * 8);
+        const v2f zn = *reinterpret_cast<const v2f*>(xb + ((256 - k) & 255) * 8);
+        const v2f e = v2f{zk.x + zn.x, zk.y - zn.y};
+        const v2f o = v2f{zk.y + zn.y, zn.x - zk.x};
+        const v2f wo = c_mul(o, twu[r]);
+        const v2f p = e + wo, q = e - wo;
+        *reinterpret_cast<float*>(xb + k * 8) = p.x * p.x + p.y * p.y;
+        if (k > 0) *reinterpret_cast<float*>(xb + (256 - k) * 8) = q.x * q.x + q.y * q.y;
+    }
+    if (j == 0) {                                       // bin 128 pairs with itself: |X[128]|^2 = |Z[128]|^2 (scaled like the rest)
+        const v2f z = *reinterpret_cast<const v2f*>(xb + 128 * 8);
+        *reinterpret_cast<float*>(xb + 128 * 8) = 4.f * (z.x * z.x + z.y * z.y);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- mel rounds: lane j = filter 16 r + j
+    float* orow = a.out + ((size_t)b * a.T + tl) * a.n_mels;
+    const bool tvalid = t < a.T;
+    float csum[F16_MAX_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < F16_MAX_ROUNDS; ++r) {
+        csum[r] = 0.f;
+        if (r < a.n_rounds) {                           // uniform
+            const int m = 16 * r + j;
+            const float* wp = s_wpad + a.round_off[r] + j;
+            const char* pp = xb + s_mbin0[min(m, FB_MAX_MEL - 1)] * 8;
+            const int nq = a.round_max[r];              // multiple of 4 (host-padded)
+            float e0 = 0.f, e1 = 0.f;
+            for (int q = 0; q < nq; q += 4) {
+                const float w0 = wp[(q + 0) * 16], w1 = wp[(q + 1) * 16], w2 = wp[(q + 2) * 16], w3 = wp[(q + 3) * 16];
+                const float p0 = *reinterpret_cast<const float*>(pp + q * 8), p1 = *reinterpret_cast<const float*>(pp + q * 8 + 8);
+                const float p2 = *reinterpret_cast<const float*>(pp + q * 8 + 16), p3 = *reinterpret_cast<const float*>(pp + q * 8 + 24);
+                e0 += w0 * p0; e1 += w1 * p1; e0 += w2 * p2; e1 += w3 * p3;
+            }
+            const float val = __logf(fmaxf(e0 + e1, a.log_floor));
+            if (m < a.n_mels && tvalid) { orow[m] = val; csum[r] = val; }
+        }
+    }
+    // ---- per-tile column sums (fixed order: frames of a wave by shuffles, then the four waves); two buffers, one barrier per tile
+#pragma unroll
+    for (int r = 0; r < F16_MAX_ROUNDS; ++r) {
+        if (r < a.n_rounds) {
+            float s = csum[r];
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (f == 0) s_red[par][wv][16 * r + j] = s;
+        }
+    }
+    __syncthreads();
+    if (tid < a.n_mels) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < FB_WAVES; ++w) s += s_red[par][w][tid];
+        a.psum[((size_t)b * a.tiles + tile) * a.n_mels + tid] = s;
+    }
+    }
+}
+
 struct CmnArgs {
     float* out;
     bf16_t* out_bf16;
@@ -376,6 +596,33 @@ int build_tables(vp_ctx* ctx, const vp_fbank_opts* o) {
     start[o->n_mels] = (int)wts.size();
     if (wts.size() > FB_MAX_NNZ) VP_FAIL(ctx, VP_EUNSUP, "fbank: mel bank too dense (%zu taps)", wts.size());
     if (wts.empty()) wts.push_back(0.f);
+    // padded round layout of the four-frames-per-wave kernel: round r = filters 16 r .. 16 r + 15, taps padded to the round's longest
+    // filter (rounded up to 4) in [tap][16] order, scaled by 0.25 (its power spectrum is 4 |X|^2)
+    {
+        const int nr = (o->n_mels + 15) / 16;
+        std::vector<float> wpad;
+        bool ok = nr <= F16_MAX_ROUNDS;
+        for (int r = 0; r < nr && ok; ++r) {
+            int mx = 0;
+            for (int m = 16 * r; m < std::min(16 * r + 16, o->n_mels); ++m) mx = std::max(mx, start[m + 1] - start[m]);
+            mx = std::max(4, (mx + 3) / 4 * 4);
+            if (mx > F16_MAX_TAPS) ok = false;
+            ctx->fb_round_off[r] = (int)wpad.size();
+            ctx->fb_round_max[r] = mx;
+            for (int q = 0; q < mx; ++q)
+                for (int jj = 0; jj < 16; ++jj) {
+                    const int m = 16 * r + jj;
+                    const bool in = m < o->n_mels && q < start[m + 1] - start[m];
+                    wpad.push_back(in ? 0.25f * wts[start[m] + q] : 0.f);
+                }
+        }
+        ctx->fb_f16 = ok && (int)wpad.size() <= F16_MAX_WPAD;
+        ctx->fb_rounds = nr;
+        ctx->fb_wpad_len = (int)wpad.size();
+        if (wpad.empty()) wpad.push_back(0.f);
+        VP_HIP(ctx, hipMalloc(&ctx->fb_wpad, wpad.size() * sizeof(float)));
+        VP_HIP(ctx, hipMemcpy(ctx->fb_wpad, wpad.data(), wpad.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     VP_HIP(ctx, hipMalloc(&ctx->fb_window, win * sizeof(float)));
     VP_HIP(ctx, hipMalloc(&ctx->fb_twiddle, nfft * sizeof(float2)));
     VP_HIP(ctx, hipMalloc(&ctx->fb_mel_start, (o->n_mels + 1) * sizeof(int)));
@@ -416,8 +663,50 @@ int vp_fbank_release_tables(vp_ctx* ctx) {
     if (ctx->fb_mel_start) (void)hipFree(ctx->fb_mel_start);
     if (ctx->fb_mel_bin0) (void)hipFree(ctx->fb_mel_bin0);
     if (ctx->fb_mel_w) (void)hipFree(ctx->fb_mel_w);
+    if (ctx->fb_wpad) (void)hipFree(ctx->fb_wpad);
+    ctx->fb_wpad = nullptr;
     ctx->fb_window = nullptr; ctx->fb_twiddle = nullptr; ctx->fb_mel_start = nullptr;
     ctx->fb_mel_bin0 = nullptr; ctx->fb_mel_w = nullptr; ctx->fb_valid = 0;
+    return VP_OK;
+}
+
+// Frame kernel launch shared by the rectangular and the ragged entry points.
+static int launch_frames(vp_ctx* ctx, const float* wav, float* out, float* psum, int B, int L, int T, int tiles, const vp_fbank_opts* o,
+                         hipStream_t st) {
+    static int force_old = -1;
+    if (force_old < 0) { const char* e = getenv("VPMI_FBANK_OLD"); force_old = e && atoi(e) ? 1 : 0; }
+    if (ctx->fb_f16 && !force_old) {
+        Fbank16Args a;
+        memset(&a, 0, sizeof(a));
+        a.wav = wav; a.out = out; a.psum = psum; a.window = ctx->fb_window; a.tw = ctx->fb_twiddle;
+        a.wpad = ctx->fb_wpad; a.mel_bin0 = ctx->fb_mel_bin0;
+        a.B = B; a.L = L; a.T = T; a.tiles = tiles; a.win = ctx->fb_win; a.shift = ctx->fb_shift;
+        a.n_mels = o->n_mels; a.n_rounds = ctx->fb_rounds; a.wpad_len = ctx->fb_wpad_len;
+        for (int r = 0; r < F16_MAX_ROUNDS; ++r) { a.round_off[r] = ctx->fb_round_off[r]; a.round_max[r] = ctx->fb_round_max[r]; }
+        a.preemph = o->preemph; a.log_floor = o->log_floor; a.remove_dc = o->remove_dc;
+        static int slots = 0;                      // three resident workgroups per CU (LDS 52 KB each)
+        if (slots == 0) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || v <= 0) v = 256;
+            slots = 3 * v;
+        }
+        const long long total = (long long)tiles * B;
+        const int grid = (int)(total < slots ? total : slots);
+        if ((ctx->fb_win + 31) / 32 == 13)
+            hipLaunchKernelGGL(fbank_frames16_kernel<13>, dim3(grid), dim3(FB_WAVES * 64), 0, st, a);
+        else
+            hipLaunchKernelGGL(fbank_frames16_kernel<16>, dim3(grid), dim3(FB_WAVES * 64), 0, st, a);
+        VP_LAUNCH_CHECK(ctx, "fbank_frames16");
+        return VP_OK;
+    }
+    FbankArgs a;
+    a.wav = wav; a.out = out; a.psum = psum; a.window = ctx->fb_window; a.tw = ctx->fb_twiddle;
+    a.mel_start = ctx->fb_mel_start; a.mel_bin0 = ctx->fb_mel_bin0; a.mel_w = ctx->fb_mel_w;
+    a.B = B; a.L = L; a.T = T; a.tiles = tiles; a.win = ctx->fb_win; a.shift = ctx->fb_shift;
+    a.n_mels = o->n_mels; a.nnz = ctx->fb_nnz; a.preemph = o->preemph; a.log_floor = o->log_floor;
+    a.remove_dc = o->remove_dc;
+    hipLaunchKernelGGL(fbank_frames_kernel, dim3(tiles, B), dim3(FB_WAVES * 64), 0, st, a);
+    VP_LAUNCH_CHECK(ctx, "fbank_frames");
     return VP_OK;
 }
 
@@ -453,14 +742,7 @@ int vp_fbank_cmn_f32(vp_ctx* ctx, const float* wav, const float* lens_ratio, int
     if (!ws || ws_bytes < vp_fbank_workspace_bytes(o, B, L)) VP_FAIL(ctx, VP_EWORKSPACE, "fbank: workspace too small");
     const int tiles = (T + FRAMES_PER_WG - 1) / FRAMES_PER_WG;
     hipStream_t st = (hipStream_t)stream;
-    FbankArgs a;
-    a.wav = wav; a.out = out; a.psum = (float*)ws; a.window = ctx->fb_window; a.tw = ctx->fb_twiddle;
-    a.mel_start = ctx->fb_mel_start; a.mel_bin0 = ctx->fb_mel_bin0; a.mel_w = ctx->fb_mel_w;
-    a.B = B; a.L = L; a.T = T; a.tiles = tiles; a.win = ctx->fb_win; a.shift = ctx->fb_shift;
-    a.n_mels = o->n_mels; a.nnz = ctx->fb_nnz; a.preemph = o->preemph; a.log_floor = o->log_floor;
-    a.remove_dc = o->remove_dc;
-    hipLaunchKernelGGL(fbank_frames_kernel, dim3(tiles, B), dim3(FB_WAVES * 64), 0, st, a);
-    VP_LAUNCH_CHECK(ctx, "fbank_frames");
+    if ((rc = launch_frames(ctx, wav, out, (float*)ws, B, L, T, tiles, o, st))) return rc;
     return vp_feat_cmn(ctx, out, out_bf16, (const float*)ws, lens_ratio, B, T, tiles, o->n_mels, st);
 }
 
@@ -475,14 +757,7 @@ int vp_fbank_cmn_ragged_f32(vp_ctx* ctx, const float* wav, const int32_t* n_samp
     if (!ws || ws_bytes < vp_fbank_workspace_bytes(o, B, L)) VP_FAIL(ctx, VP_EWORKSPACE, "fbank: workspace too small");
     const int tiles = (T + FRAMES_PER_WG - 1) / FRAMES_PER_WG;
     hipStream_t st = (hipStream_t)stream;
-    FbankArgs a;
-    a.wav = wav; a.out = out; a.psum = (float*)ws; a.window = ctx->fb_window; a.tw = ctx->fb_twiddle;
-    a.mel_start = ctx->fb_mel_start; a.mel_bin0 = ctx->fb_mel_bin0; a.mel_w = ctx->fb_mel_w;
-    a.B = B; a.L = L; a.T = T; a.tiles = tiles; a.win = ctx->fb_win; a.shift = ctx->fb_shift;
-    a.n_mels = o->n_mels; a.nnz = ctx->fb_nnz; a.preemph = o->preemph; a.log_floor = o->log_floor;
-    a.remove_dc = o->remove_dc;
-    hipLaunchKernelGGL(fbank_frames_kernel, dim3(tiles, B), dim3(FB_WAVES * 64), 0, st, a);
-    VP_LAUNCH_CHECK(ctx, "fbank_frames");
+    if ((rc = launch_frames(ctx, wav, out, (float*)ws, B, L, T, tiles, o, st))) return rc;
     hipLaunchKernelGGL(frames_of_samples_kernel, dim3((B + 255) / 256), dim3(256), 0, st, n_samples, B, ctx->fb_win, ctx->fb_shift, T, n_frames);
     VP_LAUNCH_CHECK(ctx, "frames_of_samples");
     CmnRaggedArgs c{out, (bf16_t*)out_bf16, n_frames, T, o->n_mels};
