@@ -19,13 +19,17 @@ x = (torch.randn(B, 298, 80, device='cuda') * 3).to(torch.bfloat16)
 eng = m.engine('bfloat16')
 for _ in range(2):
     eng.forward(x)
-dbg = torch.zeros((B, 12), dtype=torch.int64, device='cuda')
+dbg = torch.zeros((B, 32), dtype=torch.int64, device='cuda')
 raw = C.CDLL(os.environ['VPMI_LIB'])
 raw.vp_dbg_res2_buffer.argtypes = [C.c_void_p]
 raw.vp_dbg_res2_buffer(dbg.data_ptr())
 eng.forward(x)
 torch.cuda.synchronize()
 s = dbg.cpu().double() / 100.0
-d = s[:, 1:9] - s[:, 0:8]
-print('res2 chain (last block), us per phase, mean over workgroups: stage-in', f'{d[:, 0].mean():.2f}', ' convs', ' '.join(f'{d[:, i].mean():.2f}' for i in range(1, 8)),
-      ' total', f'{(s[:, 8] - s[:, 0]).mean():.2f}', ' span', f'{s[:, 8].max() - s[:, 0].min():.2f}')
+# stamps: 0 start, 1 staged; per conv: MFMAs done, DMAs landed + barrier, epilogue + barrier, copy-out + barrier
+print('res2 chain (last block), us, mean over workgroups: stage-in', f'{(s[:, 1] - s[:, 0]).mean():.2f}')
+for j in range(7):
+    q = s[:, 1 + 4 * j: 6 + 4 * j]
+    d = (q[:, 1:] - q[:, :-1]).mean(0)
+    print(f'  conv {j}: mfma {d[0]:.2f}  dma-wait+barrier {d[1]:.2f}  epilogue+barrier {d[2]:.2f}  copy-out+barrier {d[3]:.2f}   total {d.sum():.2f}')
+print('  total', f'{(s[:, 29] - s[:, 0]).mean():.2f}', ' span', f'{s[:, 29].max() - s[:, 0].min():.2f}')

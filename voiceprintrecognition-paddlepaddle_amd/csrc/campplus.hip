@@ -371,7 +371,13 @@ int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats
     const int bnc = w->bn_channels, gr = w->growth, nseg = p.nseg;
     for (int b = 0; b < w->n_blocks; ++b) {
         void* cat = p.cat[cb];
-        for (int l = 0; l < w->block_layers[b]; ++l, ++li) {
+        // the whole block as one kernel, a resident workgroup per utterance (cam_block.hip), when the shape is covered
+        int fused = VP_EUNSUP;
+        if (dt == VP_BF16)
+            fused = vp_cam_block_bf16(ctx, &w->layers[li], w->block_layers[b], cat, ld, ch, B, Tn, w->seg_len, bnc, gr, st);
+        if (fused != VP_OK && fused != VP_EUNSUP) return fused;
+        if (fused == VP_OK) { li += w->block_layers[b]; ch += w->block_layers[b] * gr; }
+        for (int l = 0; l < w->block_layers[b] && fused != VP_OK; ++l, ++li) {
             const vp_cam_layer& L = w->layers[li];
             // h2 = relu(bn2(linear1(relu(bn1(x[:, :ch])))))  -- bn1+relu is the conv's input prologue
             memset(&d, 0, sizeof(d));

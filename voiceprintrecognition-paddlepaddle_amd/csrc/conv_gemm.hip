@@ -133,6 +133,7 @@ int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream) {
         a.group_m = 32 / a.tiles_n;
         if (a.group_m < 1) a.group_m = 1;
         if (a.group_m > 16) a.group_m = 16;
+        { static int gm = -1; if (gm < 0) { const char* e = getenv("VPMI_GROUP_M"); gm = e ? atoi(e) : 0; } if (gm > 0) a.group_m = gm; }
         const int sched = use_conv256() < 0 ? 4 : use_conv256();
         return vp_conv_launch256_bf16(ctx, &a, mode, sched - 1, st);
     }

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(R2_THREADS, 1) void res2_chain_kernel(Res2Args a) {
     char* wt0 = smem + 2 * act_bytes;
     constexpr int WT_BYTES = R2_W * R2_K * 2;     // 24576
 #ifdef VP_TIMING
-    unsigned long long stamps[12];
+    unsigned long long stamps[32];
     int nst = 0;
     stamps[nst++] = wall_clock64();
 #endif
@@ -147,8 +147,14 @@ __global__ __launch_bounds__(R2_THREADS, 1) void res2_chain_kernel(Res2Args a) {
             }
         }
         // own DMAs landed; after the barrier everyone's have, and every wave is done reading `ain`
+#ifdef VP_TIMING
+        if (nst < 32) stamps[nst++] = wall_clock64();
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#ifdef VP_TIMING
+        if (nst < 32) stamps[nst++] = wall_clock64();
+#endif
         const float* pj = prm + j * 192;
 #pragma unroll
         for (int r = 0; r < R2_ROUNDS; ++r) {
@@ -182,6 +188,9 @@ __global__ __launch_bounds__(R2_THREADS, 1) void res2_chain_kernel(Res2Args a) {
             }
         }
         __syncthreads();
+#ifdef VP_TIMING
+        if (nst < 32) stamps[nst++] = wall_clock64();
+#endif
         // y_{j+1} out: 8 lanes per frame, 128 contiguous bytes
         {
             bf16_t* ybase = a.r2 + row0 * a.C + (j + 1) * R2_W;
@@ -193,12 +202,12 @@ __global__ __launch_bounds__(R2_THREADS, 1) void res2_chain_kernel(Res2Args a) {
         }
         __syncthreads();                                              // `ain` is the next conv's DMA target
 #ifdef VP_TIMING
-        if (nst < 12) stamps[nst++] = wall_clock64();
+        if (nst < 32) stamps[nst++] = wall_clock64();
 #endif
     }
 #ifdef VP_TIMING
     if (a.dbg && tid == 0)
-        for (int i = 0; i < 12; ++i) a.dbg[(size_t)b * 12 + i] = i < nst ? stamps[i] : 0;
+        for (int i = 0; i < 32; ++i) a.dbg[(size_t)b * 32 + i] = i < nst ? stamps[i] : 0;
 #endif
 }
 
