@@ -5,4 +5,5 @@ for B in 256 64; do
 VP_BF16_ONLY=1 timeout 120 python tools/model_probe.py $B CAMPPlus 2>&1 | grep CAMP
 VPMI_CAM_UNFUSED=1 VP_BF16_ONLY=1 timeout 120 python tools/model_probe.py $B CAMPPlus 2>&1 | grep CAMP
 done
-VPMI_LIB=voiceprintrecognition-paddlepaddle_amd/lib/libvpmi_timing.so python tools/cam_timing.py 256 2>&1 | tail -n 1
+
+VPMI_FCM_GENERAL=1 VP_BF16_ONLY=1 timeout 120 python tools/model_probe.py 256 CAMPPlus 2>&1 | grep CAMP

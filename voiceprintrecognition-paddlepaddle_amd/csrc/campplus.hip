@@ -328,30 +328,48 @@ int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats
     for (int i = 0; i < 4; ++i) {
         const vp_resblock& R = w->res[i];
         const int Fo = R.stride == 2 ? (F - 1) / 2 + 1 : F;
-        // h = relu(bn1(conv1(x)))
-        conv2d_desc(d, R.conv1, dt, B, T, F, Fo, R.stride);
-        d.x = cur; d.y = t1; d.act2 = VP_ACT_RELU;
-        if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+        // h = relu(bn1(conv1(x))) [+ the stride-2 block's shortcut bn(conv1x1(x)) from the same input slab]
         const void* sc = cur;
-        if (R.has_shortcut) {      // bn(conv1x1 stride (s,1))
-            conv2d_desc(d, R.shortcut, dt, B, T, F, Fo, R.stride);
-            d.x = cur; d.y = t2;
+        int fast = VP_EUNSUP;
+        if (dt == VP_BF16)
+            fast = vp_conv3x3_c32_bf16(ctx, cur, t1, &R.conv1, nullptr, 1, R.has_shortcut ? &R.shortcut : nullptr, t2, B, T, F, R.stride, st);
+        if (fast != VP_OK && fast != VP_EUNSUP) return fast;
+        if (fast == VP_OK) {
+            if (R.has_shortcut) sc = t2;
+        } else {
+            conv2d_desc(d, R.conv1, dt, B, T, F, Fo, R.stride);
+            d.x = cur; d.y = t1; d.act2 = VP_ACT_RELU;
             if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
-            sc = t2;
+            if (R.has_shortcut) {      // bn(conv1x1 stride (s,1))
+                conv2d_desc(d, R.shortcut, dt, B, T, F, Fo, R.stride);
+                d.x = cur; d.y = t2;
+                if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+                sc = t2;
+            }
         }
         // out = relu(bn2(conv2(h)) + shortcut)
         void* outb = R.has_shortcut ? cur : t2;          // never the buffer that holds the shortcut
-        conv2d_desc(d, R.conv2, dt, B, T, Fo, Fo, 1);
-        d.x = t1; d.y = outb; d.res = sc; d.ld_res = R.conv2.cout; d.act2 = VP_ACT_RELU;
-        if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+        fast = VP_EUNSUP;
+        if (dt == VP_BF16) fast = vp_conv3x3_c32_bf16(ctx, t1, outb, &R.conv2, sc, 1, nullptr, nullptr, B, T, Fo, 1, st);
+        if (fast != VP_OK && fast != VP_EUNSUP) return fast;
+        if (fast != VP_OK) {
+            conv2d_desc(d, R.conv2, dt, B, T, Fo, Fo, 1);
+            d.x = t1; d.y = outb; d.res = sc; d.ld_res = R.conv2.cout; d.act2 = VP_ACT_RELU;
+            if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+        }
         if (!R.has_shortcut) { void* tmp = cur; cur = t2; t2 = tmp; }
         F = Fo;
     }
     {
         const int Fo = (F - 1) / 2 + 1;
-        conv2d_desc(d, w->fcm_conv2, dt, B, T, F, Fo, 2);
-        d.x = cur; d.y = t1; d.act2 = VP_ACT_RELU;
-        if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+        int fast = VP_EUNSUP;
+        if (dt == VP_BF16) fast = vp_conv3x3_c32_bf16(ctx, cur, t1, &w->fcm_conv2, nullptr, 1, nullptr, nullptr, B, T, F, 2, st);
+        if (fast != VP_OK && fast != VP_EUNSUP) return fast;
+        if (fast != VP_OK) {
+            conv2d_desc(d, w->fcm_conv2, dt, B, T, F, Fo, 2);
+            d.x = cur; d.y = t1; d.act2 = VP_ACT_RELU;
+            if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+        }
         F = Fo;
     }
     const int Cf = F * w->m_channels;                    // = tdnn.cin: (B, T, F', 32) read as (B, T, F'*32)

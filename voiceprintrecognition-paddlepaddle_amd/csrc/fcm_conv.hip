@@ -1,0 +1,222 @@
+// 3x3 convolution over a (B, T, F, 32) bf16 map with 32 output channels: the FCM head of CAM++ (campplus.py:211-281: BasicResBlock
+// conv1 / conv2 / shortcut, FCM.conv2), stride 1 or 2 on the frequency axis, zero 'same' padding.
+//
+// These layers are N = 32 GEMMs over 10^6 positions: on the general conv GEMM (tile 128 positions x 32 channels, the 2-D loader
+// recomputing (t, f) bounds per tap and per 16-byte piece) they ran 2.5x off their HBM roofline (173 us average at B = 256 where
+// reading the input and writing the output once takes 70).  Here a workgroup owns TT time rows x all F of one utterance:
+//   - the input slab (TT + 2 rows, F + 2 columns: the zero padding is materialised once, so a tap is a constant LDS offset) is
+//     loaded with 16-byte coalesced accesses -- a time row of the map is contiguous in HBM;
+//   - the 9 x 2 weight fragments (32 x 288 bf16) live in registers for the whole workgroup;
+//   - per 16 output positions: 9 ds_read_b128 + 18 v_mfma_f32_16x16x32_bf16 (weights = A, positions = B: a lane ends with 4
+//     consecutive channels of one position);
+//   - epilogue: bias, BN, residual, ReLU in f32, transposed through a 1.25 KB LDS tile so that a wave stores 1 KB contiguous;
+//   - the stride-2 blocks' 1x1 shortcut conv (BN folded) reads the centre-tap fragment that is already in registers: 2 more MFMAs
+//     and a second output instead of another pass over the input.
+#include "common.h"
+
+namespace {
+
+constexpr int C32 = 32;
+constexpr int C32_THREADS = 256;
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+constexpr int C32_SROW = 80;                 // bytes per position of the output staging tile (64 + pad: 16-byte aligned, conflict-light)
+
+struct C32Args {
+    const bf16_t* x; bf16_t* y; const bf16_t* res; bf16_t* y2;
+    const bf16_t* w; const float* bias; const float* scale; const float* shift;        // [32][9 * 32], k = (kt * 3 + kf) * 32 + c
+    const bf16_t* w2; const float* bias2; const float* scale2; const float* shift2;    // shortcut 1x1 [32][32] (y2 != NULL)
+    int B, T, F_in, F_out, TT, relu;
+};
+
+template <int SF>
+__global__ __launch_bounds__(C32_THREADS) void conv3x3_c32_kernel(const C32Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y, t0 = blockIdx.x * a.TT;
+    const int Fp = a.F_in + 2;                              // padded row: column 0 and F_in + 1 are zeros
+    const int rows = a.TT + 2;
+    char* slab = smem;
+    char* stage = smem + (size_t)rows * Fp * 64 + wv * (2 * 16 * C32_SROW);      // per wave: main tile | shortcut tile
+
+    // ---- weight fragments (registers, whole workgroup lifetime)
+    bf16x8 wf[2][9];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+            wf[nt][tap] = *reinterpret_cast<const bf16x8*>(a.w + (size_t)(nt * 16 + li) * 288 + tap * 32 + g * 8);
+    bf16x8 w2f[2];
+    if (SF == 2 && a.y2) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) w2f[nt] = *reinterpret_cast<const bf16x8*>(a.w2 + (size_t)(nt * 16 + li) * 32 + g * 8);
+    } else {
+        w2f[0] = w2f[1] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+
+    // ---- input slab: rows t0 - 1 .. t0 + TT, 16 B per access.  The rows are one contiguous range of the utterance's map: buffer
+    //      loads at src0 + 16 i, where a row before the utterance wraps to a huge unsigned offset and a row past it runs off the
+    //      descriptor -- both return zeros, with no branch (a conditional load makes hipcc wait for the load right behind it);
+    //      eight loads in flight per thread.  The two pad columns of every row are zeros.
+    {
+        const int per_row = a.F_in * 4;                     // 16-byte chunks of a time row
+        const int total = rows * per_row;
+        const float inv_row = 1.f / (float)per_row;
+        const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x + (size_t)b * a.T * a.F_in * C32), 0,
+                                                                             (unsigned)(a.T * a.F_in * 64), 0x00020000);
+        const int src0 = (t0 - 1) * a.F_in * 64;
+        for (int i0 = tid; i0 < total; i0 += 8 * C32_THREADS) {
+            u32x4_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + k * C32_THREADS;
+                v[k] = __builtin_amdgcn_raw_buffer_load_b128(xsrd, i < total ? (unsigned)(src0 + i * 16) : 0xfffffff0u, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + k * C32_THREADS;
+                const int r = (int)(((float)i + 0.5f) * inv_row);       // i / per_row (exact: i < 2^16, per_row >= 8)
+                if (i < total) *reinterpret_cast<u32x4_t*>(slab + (size_t)i * 16 + 64 + 128 * r) = v[k];
+            }
+        }
+        for (int i = tid; i < rows * 8; i += C32_THREADS) {  // pad columns: 2 x 64 B per row
+            const int r = i >> 3, q = i & 7;
+            const int col = (q >> 2) ? Fp - 1 : 0;
+            *reinterpret_cast<uint4*>(slab + ((size_t)r * Fp + col) * 64 + (q & 3) * 16) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    __syncthreads();
+
+    // ---- per-channel epilogue terms of this lane's 2 x 4 channels
+    float bs[2][4], sc[2][4], sh[2][4], bs2[2][4], sc2[2][4], sh2[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = nt * 16 + g * 4 + r;
+            bs[nt][r] = a.bias ? a.bias[c] : 0.f;
+            sc[nt][r] = a.scale ? a.scale[c] : 1.f;
+            sh[nt][r] = a.shift ? a.shift[c] : 0.f;
+            bs2[nt][r] = (a.y2 && a.bias2) ? a.bias2[c] : 0.f;
+            sc2[nt][r] = (a.y2 && a.scale2) ? a.scale2[c] : 1.f;
+            sh2[nt][r] = (a.y2 && a.shift2) ? a.shift2[c] : 0.f;
+        }
+
+    const int npos = a.TT * a.F_out;
+    const int ntile = (npos + 15) >> 4;
+    const size_t out0 = ((size_t)b * a.T + t0) * a.F_out;  // first output position of the workgroup
+    const int tvalid = min(a.TT, a.T - t0) * a.F_out;      // positions of rows inside the utterance
+    // residual: the workgroup's output range of `res` (a descriptor of zero records when there is none: every load returns zero)
+    const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.res ? a.res + out0 * C32 : a.x), 0,
+                                                                         a.res ? (unsigned)(tvalid * 64) : 0u, 0x00020000);
+    for (int tile = wv; tile < ntile; tile += C32_THREADS / 64) {
+        const int p = tile * 16 + li;
+        const int pc = min(p, npos - 1);
+        const int tt = pc / a.F_out, fo = pc - tt * a.F_out;
+        const char* base = slab + ((size_t)tt * Fp + fo * SF) * 64 + g * 16;     // tap (kt, kf): + (kt * Fp + kf) * 64
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0, s0 = acc0, s1 = acc0;
+        // the residual in the accumulator layout (4 channels of position p), fetched before the MFMAs; no residual or a position
+        // past the utterance: an out-of-range offset, zeros
+        u32x2_t rraw[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            rraw[nt] = __builtin_amdgcn_raw_buffer_load_b64(rsrd, p < tvalid ? (unsigned)(p * 64 + (nt * 16 + g * 4) * 2) : 0xfffffff0u, 0, 0);
+        bf16x8 xf[9];
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int kf = 0; kf < 3; ++kf) xf[kt * 3 + kf] = *reinterpret_cast<const bf16x8*>(base + (kt * Fp + kf) * 64);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][tap], xf[tap], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][tap], xf[tap], acc1, 0, 0, 0);
+        }
+        if (SF == 2 && a.y2) {
+            s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[0], xf[4], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[1], xf[4], s1, 0, 0, 0);
+        }
+        // epilogue in the accumulator layout (4 channels of position p), then the transpose
+        float v[2][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[0][r] = (acc0[r] + bs[0][r]) * sc[0][r] + sh[0][r];
+            v[1][r] = (acc1[r] + bs[1][r]) * sc[1][r] + sh[1][r];
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const bf16x4 rv = __builtin_bit_cast(bf16x4, rraw[nt]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[nt][r] += (float)rv[r];
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(a.relu ? fmaxf(v[nt][r], 0.f) : v[nt][r]);
+            *reinterpret_cast<bf16x4*>(stage + li * C32_SROW + (nt * 16 + g * 4) * 2) = o;
+        }
+        if (SF == 2 && a.y2) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const f32x4& s = nt ? s1 : s0;
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (bf16_t)((s[r] + bs2[nt][r]) * sc2[nt][r] + sh2[nt][r]);
+                *reinterpret_cast<bf16x4*>(stage + 16 * C32_SROW + li * C32_SROW + (nt * 16 + g * 4) * 2) = o;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int pos = lane >> 2, q = lane & 3;       // 16 positions x 4 chunks of 16 B = 1 KB contiguous
+            const int pp = tile * 16 + pos;
+            if (pp < tvalid) {
+                *reinterpret_cast<uint4*>(a.y + (out0 + pp) * C32 + q * 8) = *reinterpret_cast<const uint4*>(stage + pos * C32_SROW + q * 16);
+                if (SF == 2 && a.y2)
+                    *reinterpret_cast<uint4*>(a.y2 + (out0 + pp) * C32 + q * 8) =
+                        *reinterpret_cast<const uint4*>(stage + 16 * C32_SROW + pos * C32_SROW + q * 16);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace
+
+// y = [relu]( bn(conv3x3(x) + bias) [+ res] ), optionally y2 = bn2(conv1x1_stride(x) + bias2) (stride_f == 2 only).
+// Returns VP_EUNSUP when the shape is not covered (the caller falls back to the general conv GEMM).
+int vp_conv3x3_c32_bf16(vp_ctx* ctx, const void* x, void* y, const vp_tdnn_layer* conv, const void* res, int relu,
+                        const vp_tdnn_layer* shortcut, void* y2, int B, int T, int F_in, int stride_f, hipStream_t st) {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("VPMI_FCM_GENERAL"); off = e && atoi(e) ? 1 : 0; }
+    if (off) return VP_EUNSUP;
+    if (!conv || conv->cin != C32 || conv->cout != C32 || conv->kw != 9 || (stride_f != 1 && stride_f != 2) || F_in < 2 || B > 65535)
+        return VP_EUNSUP;
+    if (shortcut && (stride_f != 2 || !y2 || shortcut->cin != C32 || shortcut->cout != C32 || shortcut->kw != 1)) return VP_EUNSUP;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(y2)) & 15)
+        return VP_EUNSUP;
+    const int F_out = (F_in - 1) / stride_f + 1;
+    const int Fp = F_in + 2;
+    int TT = (60 * 1024) / (Fp * 64) - 2;                  // slab of <= 60 KB: two workgroups per CU
+    if (TT > T) TT = T;
+    if (TT < 1) return VP_EUNSUP;
+    const size_t smem = (size_t)(TT + 2) * Fp * 64 + (size_t)(C32_THREADS / 64) * 2 * 16 * C32_SROW;
+    C32Args a;
+    memset(&a, 0, sizeof(a));
+    a.x = (const bf16_t*)x; a.y = (bf16_t*)y; a.res = (const bf16_t*)res; a.y2 = shortcut ? (bf16_t*)y2 : nullptr;
+    a.w = (const bf16_t*)conv->w; a.bias = conv->bias; a.scale = conv->bn_scale; a.shift = conv->bn_shift;
+    if (shortcut) { a.w2 = (const bf16_t*)shortcut->w; a.bias2 = shortcut->bias; a.scale2 = shortcut->bn_scale; a.shift2 = shortcut->bn_shift; }
+    a.B = B; a.T = T; a.F_in = F_in; a.F_out = F_out; a.TT = TT; a.relu = relu;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+        attr_set = true;
+    }
+    const dim3 grid((T + TT - 1) / TT, B);
+    if (stride_f == 1) hipLaunchKernelGGL(conv3x3_c32_kernel<1>, grid, dim3(C32_THREADS), smem, st, a);
+    else hipLaunchKernelGGL(conv3x3_c32_kernel<2>, grid, dim3(C32_THREADS), smem, st, a);
+    VP_LAUNCH_CHECK(ctx, "conv3x3_c32");
+    return VP_OK;
+}
