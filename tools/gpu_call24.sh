@@ -8,7 +8,7 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # last forward: find last fcm_conv1 launch
-idx = max(i for i, r in enumerate(rows) if 'fcm_conv1' in r['Kernel_Name'])
+idx = max(i for i, r in enumerate(rows) if 'fcm_conv1' in r['Kernel_Name'] or 'Lb1EEE' in r['Kernel_Name'] or '<2, true>' in r['Kernel_Name'])
 tot = 0
 for r in rows[idx:]:
     d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3

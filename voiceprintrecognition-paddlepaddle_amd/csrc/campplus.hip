@@ -319,7 +319,16 @@ int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats
     vp_conv1d_desc d;
 
     // ---- FCM head: conv1 (1 -> 32), 2 x [ResBlock s2, ResBlock s1], conv2 s2
-    if ((rc = vp_conv3x3_c1(ctx, dt, feats, p.fa, w->fcm1_w, w->fcm1_b, w->fcm1_scale, w->fcm1_shift, B, T, w->feat_dim, 32, st)))
+    // conv1 (1 -> 32) is produced inside the first ResBlock's kernels' input slab when that path is taken (bf16 engine); its
+    // output tensor (B, T, F, 32) then never exists
+    bool c1_fused = false;
+    if (dt == VP_BF16 && w->res[0].stride == 2 && w->res[0].has_shortcut) {
+        const int fr = vp_conv3x3_c32_bf16(ctx, nullptr, p.fb, &w->res[0].conv1, nullptr, 1, &w->res[0].shortcut, p.fc, B, T, w->feat_dim, 2,
+                                           feats, w->fcm1_w, w->fcm1_b, w->fcm1_scale, w->fcm1_shift, st);
+        if (fr != VP_OK && fr != VP_EUNSUP) return fr;
+        c1_fused = fr == VP_OK;
+    }
+    if (!c1_fused && (rc = vp_conv3x3_c1(ctx, dt, feats, p.fa, w->fcm1_w, w->fcm1_b, w->fcm1_scale, w->fcm1_shift, B, T, w->feat_dim, 32, st)))
         return rc;
     int F = w->feat_dim;
     void* cur = p.fa;
@@ -331,8 +340,10 @@ int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats
         // h = relu(bn1(conv1(x))) [+ the stride-2 block's shortcut bn(conv1x1(x)) from the same input slab]
         const void* sc = cur;
         int fast = VP_EUNSUP;
-        if (dt == VP_BF16)
-            fast = vp_conv3x3_c32_bf16(ctx, cur, t1, &R.conv1, nullptr, 1, R.has_shortcut ? &R.shortcut : nullptr, t2, B, T, F, R.stride, st);
+        if (i == 0 && c1_fused) fast = VP_OK;            // launched above: t1 = h, t2 = shortcut
+        else if (dt == VP_BF16)
+            fast = vp_conv3x3_c32_bf16(ctx, cur, t1, &R.conv1, nullptr, 1, R.has_shortcut ? &R.shortcut : nullptr, t2, B, T, F, R.stride,
+                                       nullptr, nullptr, nullptr, nullptr, nullptr, st);
         if (fast != VP_OK && fast != VP_EUNSUP) return fast;
         if (fast == VP_OK) {
             if (R.has_shortcut) sc = t2;
@@ -350,7 +361,7 @@ int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats
         // out = relu(bn2(conv2(h)) + shortcut)
         void* outb = R.has_shortcut ? cur : t2;          // never the buffer that holds the shortcut
         fast = VP_EUNSUP;
-        if (dt == VP_BF16) fast = vp_conv3x3_c32_bf16(ctx, t1, outb, &R.conv2, sc, 1, nullptr, nullptr, B, T, Fo, 1, st);
+        if (dt == VP_BF16) fast = vp_conv3x3_c32_bf16(ctx, t1, outb, &R.conv2, sc, 1, nullptr, nullptr, B, T, Fo, 1, nullptr, nullptr, nullptr, nullptr, nullptr, st);
         if (fast != VP_OK && fast != VP_EUNSUP) return fast;
         if (fast != VP_OK) {
             conv2d_desc(d, R.conv2, dt, B, T, Fo, Fo, 1);
@@ -363,7 +374,7 @@ int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats
     {
         const int Fo = (F - 1) / 2 + 1;
         int fast = VP_EUNSUP;
-        if (dt == VP_BF16) fast = vp_conv3x3_c32_bf16(ctx, cur, t1, &w->fcm_conv2, nullptr, 1, nullptr, nullptr, B, T, F, 2, st);
+        if (dt == VP_BF16) fast = vp_conv3x3_c32_bf16(ctx, cur, t1, &w->fcm_conv2, nullptr, 1, nullptr, nullptr, B, T, F, 2, nullptr, nullptr, nullptr, nullptr, nullptr, st);
         if (fast != VP_OK && fast != VP_EUNSUP) return fast;
         if (fast != VP_OK) {
             conv2d_desc(d, w->fcm_conv2, dt, B, T, F, Fo, 2);

@@ -27,9 +27,11 @@ struct C32Args {
     const bf16_t* w; const float* bias; const float* scale; const float* shift;        // [32][9 * 32], k = (kt * 3 + kf) * 32 + c
     const bf16_t* w2; const float* bias2; const float* scale2; const float* shift2;    // shortcut 1x1 [32][32] (y2 != NULL)
     int B, T, F_in, F_out, TT, relu;
+    // FUSE: x is not read; the slab is FCM.conv1 (1 -> 32 channels, 3x3, BN, ReLU; campplus.py:254-255,274) of feats (B, T, F_in)
+    const bf16_t* feats; const float* c1_w; const float* c1_b; const float* c1_scale; const float* c1_shift;   // c1_w [32][9], tap = kt * 3 + kf
 };
 
-template <int SF>
+template <int SF, bool FUSE>
 __global__ __launch_bounds__(C32_THREADS) void conv3x3_c32_kernel(const C32Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -41,21 +43,65 @@ __global__ __launch_bounds__(C32_THREADS) void conv3x3_c32_kernel(const C32Args 
     char* slab = smem;
     char* stage = smem + (size_t)rows * Fp * 64 + wv * (2 * 16 * C32_SROW);      // per wave: main tile | shortcut tile
 
-    // ---- weight fragments (registers, whole workgroup lifetime)
-    bf16x8 wf[2][9];
+    if constexpr (FUSE) {
+        // ---- the slab IS conv1's output: feats rows t0 - 2 .. t0 + TT + 1 (zero outside the utterance, one zero column each side)
+        //      go to LDS as f32; a thread then owns 8 channels (weights in registers) of every fourth-of-a-position it visits
+        float* fs = reinterpret_cast<float*>(smem + (size_t)rows * Fp * 64 + (C32_THREADS / 64) * (2 * 16 * C32_SROW));
+        const int frows = a.TT + 4;
+        const __amdgpu_buffer_rsrc_t fsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.feats + (size_t)b * a.T * a.F_in), 0,
+                                                                             (unsigned)(a.T * a.F_in * 2), 0x00020000);
+        for (int i0 = tid; i0 < frows * Fp; i0 += 4 * C32_THREADS) {       // branch-free: out-of-range offsets read zero
+            unsigned short raw[4];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * C32_THREADS;
+                const int r = i / Fp, c = i - r * Fp;
+                const int t = t0 - 2 + r, f = c - 1;
+                const bool ok = i < frows * Fp && t >= 0 && t < a.T && f >= 0 && f < a.F_in;
+                raw[k] = __builtin_amdgcn_raw_buffer_load_b16(fsrd, ok ? (unsigned)((t * a.F_in + f) * 2) : 0xfffffff0u, 0, 0);
+            }
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-            wf[nt][tap] = *reinterpret_cast<const bf16x8*>(a.w + (size_t)(nt * 16 + li) * 288 + tap * 32 + g * 8);
-    bf16x8 w2f[2];
-    if (SF == 2 && a.y2) {
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * C32_THREADS;
+                if (i < frows * Fp) fs[i] = __uint_as_float((unsigned)raw[k] << 16);
+            }
+        }
+        const int cg = (tid & 3) * 8;
+        float w1[8][9], b1[8], s1[8], h1[8];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) w2f[nt] = *reinterpret_cast<const bf16x8*>(a.w2 + (size_t)(nt * 16 + li) * 32 + g * 8);
+        for (int c = 0; c < 8; ++c) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) w1[c][k] = a.c1_w[(cg + c) * 9 + k];
+            b1[c] = a.c1_b[cg + c]; s1[c] = a.c1_scale[cg + c]; h1[c] = a.c1_shift[cg + c];
+        }
+        __syncthreads();
+        const float inv_f = 1.f / (float)a.F_in;
+        for (int i = tid; i < rows * a.F_in * 4; i += C32_THREADS) {
+            const int pos = i >> 2;
+            const int r = (int)(((float)pos + 0.5f) * inv_f);
+            const int f = pos - r * a.F_in;
+            const int t = t0 - 1 + r;
+            float in[9];
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+                for (int kf = 0; kf < 3; ++kf) in[kt * 3 + kf] = fs[(r + kt) * Fp + f + kf];
+            bf16x8 o;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float acc = b1[c];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc += w1[c][k] * in[k];
+                o[c] = (bf16_t)((t >= 0 && t < a.T) ? fmaxf(acc * s1[c] + h1[c], 0.f) : 0.f);
+            }
+            *reinterpret_cast<bf16x8*>(slab + ((size_t)r * Fp + f + 1) * 64 + cg * 2) = o;
+        }
+        for (int i = tid; i < rows * 8; i += C32_THREADS) {  // pad columns: 2 x 64 B per row
+            const int r = i >> 3, q = i & 7;
+            const int col = (q >> 2) ? Fp - 1 : 0;
+            *reinterpret_cast<uint4*>(slab + ((size_t)r * Fp + col) * 64 + (q & 3) * 16) = make_uint4(0u, 0u, 0u, 0u);
+        }
     } else {
-        w2f[0] = w2f[1] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    }
-
     // ---- input slab: rows t0 - 1 .. t0 + TT, 16 B per access.  The rows are one contiguous range of the utterance's map: buffer
     //      loads at src0 + 16 i, where a row before the utterance wraps to a huge unsigned offset and a row past it runs off the
     //      descriptor -- both return zeros, with no branch (a conditional load makes hipcc wait for the load right behind it);
@@ -87,6 +133,22 @@ __global__ __launch_bounds__(C32_THREADS) void conv3x3_c32_kernel(const C32Args 
             *reinterpret_cast<uint4*>(slab + ((size_t)r * Fp + col) * 64 + (q & 3) * 16) = make_uint4(0u, 0u, 0u, 0u);
         }
     }
+    }
+    // ---- weight fragments (registers, whole workgroup lifetime)
+    bf16x8 wf[2][9];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+            wf[nt][tap] = *reinterpret_cast<const bf16x8*>(a.w + (size_t)(nt * 16 + li) * 288 + tap * 32 + g * 8);
+    bf16x8 w2f[2];
+    if (SF == 2 && a.y2) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) w2f[nt] = *reinterpret_cast<const bf16x8*>(a.w2 + (size_t)(nt * 16 + li) * 32 + g * 8);
+    } else {
+        w2f[0] = w2f[1] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+
     __syncthreads();
 
     // ---- per-channel epilogue terms of this lane's 2 x 4 channels
@@ -187,13 +249,17 @@ __global__ __launch_bounds__(C32_THREADS) void conv3x3_c32_kernel(const C32Args 
 // y = [relu]( bn(conv3x3(x) + bias) [+ res] ), optionally y2 = bn2(conv1x1_stride(x) + bias2) (stride_f == 2 only).
 // Returns VP_EUNSUP when the shape is not covered (the caller falls back to the general conv GEMM).
 int vp_conv3x3_c32_bf16(vp_ctx* ctx, const void* x, void* y, const vp_tdnn_layer* conv, const void* res, int relu,
-                        const vp_tdnn_layer* shortcut, void* y2, int B, int T, int F_in, int stride_f, hipStream_t st) {
+                        const vp_tdnn_layer* shortcut, void* y2, int B, int T, int F_in, int stride_f, const void* c1_feats,
+                        const float* c1_w, const float* c1_b, const float* c1_scale, const float* c1_shift, hipStream_t st) {
     static int off = -1;
     if (off < 0) { const char* e = getenv("VPMI_FCM_GENERAL"); off = e && atoi(e) ? 1 : 0; }
     if (off) return VP_EUNSUP;
     if (!conv || conv->cin != C32 || conv->cout != C32 || conv->kw != 9 || (stride_f != 1 && stride_f != 2) || F_in < 2 || B > 65535)
         return VP_EUNSUP;
+    const bool fuse = c1_feats != nullptr;
+    if (fuse && (stride_f != 2 || !c1_w || !c1_b || !c1_scale || !c1_shift)) return VP_EUNSUP;
     if (shortcut && (stride_f != 2 || !y2 || shortcut->cin != C32 || shortcut->cout != C32 || shortcut->kw != 1)) return VP_EUNSUP;
+    if (!fuse && !x) return VP_EUNSUP;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(y2)) & 15)
         return VP_EUNSUP;
     const int F_out = (F_in - 1) / stride_f + 1;
@@ -201,22 +267,27 @@ int vp_conv3x3_c32_bf16(vp_ctx* ctx, const void* x, void* y, const vp_tdnn_layer
     int TT = (60 * 1024) / (Fp * 64) - 2;                  // slab of <= 60 KB: two workgroups per CU
     if (TT > T) TT = T;
     if (TT < 1) return VP_EUNSUP;
-    const size_t smem = (size_t)(TT + 2) * Fp * 64 + (size_t)(C32_THREADS / 64) * 2 * 16 * C32_SROW;
+    if (fuse && TT > 2) TT -= 1;                           // room for the f32 feature rows behind the slab
+    const size_t smem = (size_t)(TT + 2) * Fp * 64 + (size_t)(C32_THREADS / 64) * 2 * 16 * C32_SROW + (fuse ? (size_t)(TT + 4) * Fp * 4 : 0);
     C32Args a;
     memset(&a, 0, sizeof(a));
     a.x = (const bf16_t*)x; a.y = (bf16_t*)y; a.res = (const bf16_t*)res; a.y2 = shortcut ? (bf16_t*)y2 : nullptr;
     a.w = (const bf16_t*)conv->w; a.bias = conv->bias; a.scale = conv->bn_scale; a.shift = conv->bn_shift;
     if (shortcut) { a.w2 = (const bf16_t*)shortcut->w; a.bias2 = shortcut->bias; a.scale2 = shortcut->bn_scale; a.shift2 = shortcut->bn_shift; }
     a.B = B; a.T = T; a.F_in = F_in; a.F_out = F_out; a.TT = TT; a.relu = relu;
+    a.feats = (const bf16_t*)c1_feats; a.c1_w = c1_w; a.c1_b = c1_b; a.c1_scale = c1_scale; a.c1_shift = c1_shift;
     static bool attr_set = false;
     if (!attr_set) {
-        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
-        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
         attr_set = true;
     }
     const dim3 grid((T + TT - 1) / TT, B);
-    if (stride_f == 1) hipLaunchKernelGGL(conv3x3_c32_kernel<1>, grid, dim3(C32_THREADS), smem, st, a);
-    else hipLaunchKernelGGL(conv3x3_c32_kernel<2>, grid, dim3(C32_THREADS), smem, st, a);
+    if (smem > 72 * 1024) return VP_EUNSUP;
+    if (fuse) hipLaunchKernelGGL((conv3x3_c32_kernel<2, true>), grid, dim3(C32_THREADS), smem, st, a);
+    else if (stride_f == 1) hipLaunchKernelGGL((conv3x3_c32_kernel<1, false>), grid, dim3(C32_THREADS), smem, st, a);
+    else hipLaunchKernelGGL((conv3x3_c32_kernel<2, false>), grid, dim3(C32_THREADS), smem, st, a);
     VP_LAUNCH_CHECK(ctx, "conv3x3_c32");
     return VP_OK;
 }
