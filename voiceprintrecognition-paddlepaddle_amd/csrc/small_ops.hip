@@ -443,17 +443,39 @@ __global__ __launch_bounds__(1024) void se_gate_kernel(SeGateArgs a) {
     float* sg = h + SE_UPW * a.H;
     float* part = sg + SE_UPW * a.C;
     const int b0 = blockIdx.x * SE_UPW;
-    for (int i = threadIdx.x; i < SE_UPW * a.C; i += blockDim.x) {
+    // time mean from the conv's partial sums: (B*T positions) / 128 tiles per utterance -- 3 for a 3 s ECAPA utterance, 186 for a
+    // ResNetSE stage-1 map.  The tiles of a channel are split over blockDim / C threads (a lone thread walking 186 dependent
+    // loads made this kernel 32 us per call there), partials through LDS, fixed order.
+    {
+        const int groups = max(1, (int)blockDim.x / (SE_UPW * a.C));
+        const int i = threadIdx.x % (SE_UPW * a.C), gq = threadIdx.x / (SE_UPW * a.C);
         const int u = i / a.C, c = i - u * a.C;
         const int b = min(b0 + u, a.B - 1);
         const int t0 = (int)(((long long)b * a.T) / VP_CONV_BM);
         const int t1 = (int)(((long long)(b + 1) * a.T - 1) / VP_CONV_BM);
-        float s1 = 0.f;
-        for (int tm = t0; tm <= t1; ++tm) {
-            const int seg = b - (int)(((long long)tm * VP_CONV_BM) / a.T);
-            s1 += a.psum[((size_t)tm * a.nseg + seg) * a.C + c];
+        for (int i2 = i; i2 < SE_UPW * a.C; i2 += blockDim.x) {      // C > blockDim: several channels per thread (groups == 1)
+            const int u2 = i2 / a.C, c2 = i2 - u2 * a.C;
+            float s1 = 0.f;
+            if (gq < groups) {
+#pragma unroll 4
+                for (int tm = t0 + gq; tm <= t1; tm += groups) {
+                    const int seg = b - (int)(((long long)tm * VP_CONV_BM) / a.T);
+                    s1 += a.psum[((size_t)tm * a.nseg + seg) * a.C + c2];
+                }
+            }
+            if (groups == 1) mean[i2] = (a.shift ? a.shift[c2] : 0.f) + s1 / (float)a.T;
+            else if (gq < groups) part[gq * (SE_UPW * a.C) + i2] = s1;
+            (void)u2;
         }
-        mean[i] = (a.shift ? a.shift[c] : 0.f) + s1 / (float)a.T;
+        if (groups > 1) {
+            __syncthreads();
+            if (gq == 0) {
+                float s1 = 0.f;
+                for (int q = 0; q < groups; ++q) s1 += part[q * (SE_UPW * a.C) + i];
+                mean[i] = (a.shift ? a.shift[c] : 0.f) + s1 / (float)a.T;
+            }
+        }
+        (void)u;
     }
     __syncthreads();
     se_matvec(mean, a.C, a.C, a.w1, a.H, a.b1, 0, h, a.H, part);
