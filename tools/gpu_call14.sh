@@ -1,7 +1,7 @@
 #!/bin/bash
 # Session baseline of HEAD: whole GPU suite, smoke, bench (+ rocprof of the same command), train rocprof, model probe.
 mkdir -p gpurun_out; export TMPDIR=/tmp
-T=r02a
+T=${1:-r02b}
 timeout 800 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --timeout 200 --timeout-method thread > gpurun_out/pytest_$T.log 2>&1
 echo "pytest rc=$?"; grep -E "passed|failed|error|Timeout" gpurun_out/pytest_$T.log | tail -n 5; grep -E "^(FAILED|ERROR)" gpurun_out/pytest_$T.log | head -20
 timeout 240 python __graft_entry__.py smoke > gpurun_out/smoke_$T.log 2>&1; echo "smoke rc=$?"; tail -n 3 gpurun_out/smoke_$T.log
@@ -16,4 +16,4 @@ find gpurun_out/proft_$T -name "*kernel_stats.csv" | head -n 1 | xargs -I{} cp {
 find gpurun_out/proft_$T -name "*kernel_trace.csv" -delete
 head -n 30 gpurun_out/kernel_stats_train_$T.csv | cut -c 1-170
 tail -n 1 gpurun_out/proft_$T.log | cut -c 1-1500
-VP_BF16_ONLY=1 timeout 200 python tools/model_probe.py 256 > gpurun_out/model_probe_$T.log 2>&1; cat gpurun_out/model_probe_$T.log
+VP_BF16_ONLY=1 timeout 300 python tools/model_probe.py 256 > gpurun_out/model_probe_$T.log 2>&1; cat gpurun_out/model_probe_$T.log
