@@ -1,0 +1,81 @@
+"""Forward + head + loss time of BASELINE.json configs[2..4] at their named shapes and per-GPU batches (bf16 engine, 3 s utterances):
+  configs[2]  CAM++ + Fbank(80) + AAMLoss, 7 205 classes, batch 512 over 8 GPUs  -> 64 per GPU
+  configs[3]  ResNetSE + MelSpectrogram(n_fft 1024, hop 320, 64 mel) + 2 796 classes, batch 128 over 4 GPUs -> 32 per GPU
+  configs[4]  ERes2Net-large (m_channels 64, expansion 4, base_width 24, scale 3, mul_channel 2) + Fbank(80) + 200 000-class
+              ArcFace head, batch 1024 over 8 GPUs -> 128 per GPU
+One "step" = featurizer -> backbone forward -> cosine head -> AAM loss on synthetic waveforms resident in HBM (random-init weights
+from the oracle's parameter generators).  Usage: python tools/config_probe.py [2 3 4]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'voiceprintrecognition-paddlepaddle_amd'))
+import torch  # noqa: E402
+import ppvector  # noqa: E402
+from oracle import campplus as oc  # noqa: E402
+from oracle import eres2net as oer  # noqa: E402
+from oracle import models as om  # noqa: E402
+from oracle import resnet_se as orse  # noqa: E402
+from ppvector.data_utils.featurizer import AudioFeaturizer  # noqa: E402
+from ppvector.loss import AAMLoss  # noqa: E402
+from ppvector.models.campplus import CAMPPlus  # noqa: E402
+from ppvector.models.eres2net import ERes2Net  # noqa: E402
+from ppvector.models.fc import SpeakerIdentification  # noqa: E402
+from ppvector.models.resnet_se import ResNetSE  # noqa: E402
+
+LARGE = dict(m_channels=64, mul_channel=2, expansion=4, base_width=24, scale=3)
+CONFIGS = {
+    2: ('CAM++ + Fbank80 + AAM, 7205 classes', 64, ('Fbank', dict(sr=16000, n_mels=80)), 80,
+        lambda f: CAMPPlus(f, embd_dim=192), lambda f: oc.campplus_params(f, 192), 7205),
+    3: ('ResNetSE + MelSpectrogram(1024/320/64) + AAM, 2796 classes', 32,
+        ('MelSpectrogram', dict(sr=16000, n_fft=1024, hop_length=320, win_length=1024, n_mels=64)), 64,
+        lambda f: ResNetSE(f), lambda f: orse.resnetse_params(f, 192), 2796),
+    4: ('ERes2Net-large + Fbank80 + AAM, 200000 classes', 128, ('Fbank', dict(sr=16000, n_mels=80)), 80,
+        lambda f: ERes2Net(f, **LARGE), lambda f: oer.eres2net_params(f, 192, **LARGE), 200000),
+}
+
+which = [int(v) for v in sys.argv[1:]] or [2, 3, 4]
+ppvector.set_compute_dtype('bfloat16')
+for k in which:
+    name, B, (fm, fargs), fdim, mk, pk, ncls = CONFIGS[k]
+    wav = torch.randn(B, 48000, device='cuda') * 0.1
+    fz = AudioFeaturizer(fm, fargs)
+    m = mk(fdim)
+    m.load_state_dict(pk(fdim))
+    m = m.cuda().eval()
+    head = SpeakerIdentification(192, ncls)
+    head.load_state_dict({'weight': om.head_params(192, ncls, seed=3)})
+    head = head.cuda().eval()
+    crit = AAMLoss(margin=0.2, scale=32)
+    labels = torch.randint(0, ncls, (B,), device='cuda')
+
+    def step():
+        with torch.no_grad():
+            feats = fz(wav, want_bf16=True)
+            emb = m(feats)
+            logits = head(emb)
+            return crit(logits, labels)
+
+    def timed(fn, n=5):
+        for _ in range(2):
+            fn()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for a, b in evs:
+            a.record(); fn(); b.record()
+        torch.cuda.synchronize()
+        return sorted(a.elapsed_time(b) for a, b in evs)[n // 2]
+
+    ms = timed(step)
+    with torch.no_grad():
+        feats = fz(wav, want_bf16=True)
+        emb = m(feats)
+    ms_f = timed(lambda: fz(wav, want_bf16=True))
+    ms_m = timed(lambda: m(feats))
+    ms_h = timed(lambda: crit(head(emb), labels))
+    loss = float(step())
+    print(f'configs[{k}] {name}: B/GPU {B}: step {ms:8.3f} ms = {B / ms * 1e3:9.0f} utt/s per GPU  '
+          f'(featurizer {ms_f:.3f}, backbone {ms_m:.3f}, head + loss {ms_h:.3f} ms)  loss {loss:.4f}', flush=True)
+    del m, head, wav
+    torch.cuda.empty_cache()
+ppvector.set_compute_dtype('float32')
