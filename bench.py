@@ -362,13 +362,6 @@ def run_infer(args, rank, local_rank, world, dist):
     dt, loss = run_timed(run, args.steps, args.warmup, dist, dev)
     loss_v = float(loss)
     assert np.isfinite(loss_v)
-    # the path that COMMUNICATES, measured in the same job: the data-parallel training step (global batch 256 split over the
-    # ranks, gradient all-reduce over RCCL overlapped with backward) -- reported beside the headline line as "dp_train"
-    dp_train = None
-    if not args.no_train_line:
-        dp_train = run_train(args, rank, local_rank, world, dist, steps=args.train_steps, warmup=3, emit=False)
-    if rank != 0:
-        return
     value = world * BATCH * args.steps / dt
     out = {
         'metric': 'utterances/sec (3 s, 16 kHz) ECAPA-TDNN fwd+AAM', 'value': round(value, 1),
@@ -383,6 +376,38 @@ def run_infer(args, rank, local_rank, world, dist):
         'loss': round(loss_v, 5),
         'stage_roofline_frac': round(value / world * ALG_GFLOP_PER_UTT / 1e3 / PEAK_BF16_TFLOPS, 4),
     }
+    # the path that COMMUNICATES, measured in the same job: the data-parallel training step (global batch 256 split over the
+    # ranks, gradient all-reduce over RCCL overlapped with backward) -- reported beside the headline line as "dp_train".
+    # The headline line above is already complete: if the collective part fails or hangs on this node (a watchdog thread for
+    # world > 1: a hung collective cannot be interrupted from Python), rank 0 still prints it, with the failure in "dp_train".
+    dp_train, dp_err = None, None
+    if not args.no_train_line:
+        import threading
+
+        def bail(reason):
+            if rank == 0:
+                out['dp_train'] = {'error': reason}
+                print(json.dumps(out), flush=True)
+            sys.stdout.flush()
+            os._exit(0)                    # no collective teardown: it would hang with the step
+
+        dog = None
+        if world > 1:
+            dog = threading.Timer(float(os.environ.get('VP_BENCH_TRAIN_TIMEOUT', '300')), bail, args=('dp_train did not finish in time',))
+            dog.daemon = True
+            dog.start()
+        try:
+            dp_train = run_train(args, rank, local_rank, world, dist, steps=args.train_steps, warmup=3, emit=False)
+        except Exception as e:             # noqa: BLE001 -- anything here must not cost the headline line
+            dp_err = f'{type(e).__name__}: {e}'[:300]
+        if dog is not None:
+            dog.cancel()
+        if dp_err is not None and world > 1:
+            bail(dp_err)                   # the other ranks may be inside a collective: leave without the barrier
+    if rank != 0:
+        return
+    if dp_err is not None:
+        out['dp_train'] = {'error': dp_err}
     if dp_train is not None:
         keep = ('metric', 'value', 'unit', 'ms_per_step', 'scaling', 'dtype', 'loss', 'stage_roofline_frac', 'rccl_ranks', 'allreduce_ms',
                 'allreduce_bytes', 'allreduce_algbw_GBps', 'step_ms_without_collective', 'comm_exposed_ms', 'overlap_frac', 'grad_buckets')
