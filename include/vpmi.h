@@ -315,6 +315,20 @@ typedef struct {
     const float* dense_b;
 } vp_campplus_weights;
 
+/* Kernel doors of the CAM++ forward's two fused bf16 kernels (kernel-level parity tests; vp_campplus_fwd uses them internally):
+ * vp_cam_block_fwd: CAMDenseTDNNBlock.forward (models/campplus.py:145-173) over n_layers CAMDenseTDNNLayers (:109-142, CAMLayer
+ *   :67-106): cat (B*Tn, ld) bf16 holds the block input in columns [0, ch0); layer l reads columns [0, ch0 + 32 l) and appends
+ *   its 32 output channels in place.  VP_EUNSUP outside bottleneck 128 / growth 32 / k3 / T' <= 160 / <= 24 layers.
+ * vp_conv3x3_c32_fwd: one 3x3 conv of the FCM head over a (B, T, F_in, 32) bf16 map (BasicResBlock conv1 / conv2, FCM.conv2:
+ *   models/campplus.py:211-281), frequency stride 1 or 2, zero padding: y = [relu](bn(conv(x) + bias) [+ res]); with `shortcut`
+ *   (stride 2) also y2 = bn_s(conv1x1_s2(x) + bias_s) (:232-239); with c1_feats the input map is FCM.conv1 (:254-255, 274) of the
+ *   (B, T, F_in) bf16 features, produced inside the kernel (x is not read). */
+int vp_cam_block_fwd(vp_ctx* ctx, const vp_cam_layer* layers, int n_layers, void* cat, int ld, int ch0, int B, int Tn, int seg_len,
+                     int bn_channels, int growth, vp_stream stream);
+int vp_conv3x3_c32_fwd(vp_ctx* ctx, const void* x, void* y, const vp_tdnn_layer* conv, const void* res, int relu,
+                       const vp_tdnn_layer* shortcut, void* y2, int B, int T, int F_in, int stride_f, const void* c1_feats,
+                       const float* c1_w, const float* c1_b, const float* c1_scale, const float* c1_shift, vp_stream stream);
+
 size_t vp_campplus_workspace_bytes(const vp_campplus_weights* w, int B, int T);
 int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats, int B, int T, float* emb,
                     void* ws, size_t ws_bytes, vp_stream stream);

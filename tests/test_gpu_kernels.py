@@ -946,3 +946,166 @@ def test_se_gate_kernel_vs_float64(N, B, T):
     err = (out.double().cpu() - ref).abs().max().item()
     print(f'[se_gate B={B} T={T}] max err {err:.3e}')
     assert err < 2e-6, err
+
+
+# --------------------------------------------------------------------------------------- CAM++ fused kernels (round 2)
+def _layer(N, w, b, sc, sh, dil=1, keep=None):
+    """vp_tdnn_layer over a (Cout, Cin, K) float64 weight: [Cout][tap * Cin + c] bf16, f32 epilogue terms (None = absent)."""
+    L = N.TdnnLayer()
+    wd = dev(w.permute(0, 2, 1).reshape(w.shape[0], -1), torch.bfloat16)
+    keep.append(wd)
+    L.w = wd.data_ptr()
+    for name, v in (('bias', b), ('bn_scale', sc), ('bn_shift', sh)):
+        if v is not None:
+            d_ = dev(v, torch.float32)
+            keep.append(d_)
+            setattr(L, name, d_.data_ptr())
+    L.cin, L.cout, L.kw, L.dil = w.shape[1], w.shape[0], w.shape[2], dil
+    return L
+
+
+@pytest.mark.parametrize('B,Tn,ch0,nl,seg', [(3, 149, 128, 3, 100), (2, 37, 256, 2, 100), (2, 160, 192, 2, 50), (1, 16, 128, 1, 100)])
+def test_cam_block_kernel_vs_float64(N, B, Tn, ch0, nl, seg):
+    """vp_cam_block_fwd against a float64 restatement of CAMDenseTDNNBlock.forward (campplus.py:145-173; CAMDenseTDNNLayer :109-142,
+    CAMLayer :67-106) with the kernel's rounding points: bf16 concat buffer and weights, the BN1 + ReLU input staged as bf16, h stored
+    as bf16 (the context is taken over that bf16 h), outputs stored as bf16.  Every frame and channel of every layer: two context
+    segments (T' = 149, seg 100), four (T' = 160, seg 50), an utterance shorter than a segment, a single 16-frame tile."""
+    lib, ctx = N.lib(), N.ctx(0)
+    bnc, gr, H = 128, 32, 64
+    g = torch.Generator().manual_seed(Tn * 7 + ch0)
+    ld = ch0 + nl * gr + 32                                              # a concat buffer wider than the block needs
+    cat = torch.zeros(B, Tn, ld, dtype=torch.float64)
+    cat[:, :, :ch0] = _bf(torch.randn(B, Tn, ch0, generator=g, dtype=torch.float64))
+    ref = cat.clone()
+    layers = (N.CamLayer * nl)()
+    keep = []
+    f32 = lambda t: t.float().double()                                  # noqa: E731 -- parameters the kernel holds in f32
+    ch = ch0
+    for l in range(nl):
+        dil = 1 + l                                                      # the reference's blocks use dilation 1 / 2: cover both and 3
+        s1, h1 = f32(torch.rand(ch, generator=g, dtype=torch.float64) + 0.5), f32(0.3 * torch.randn(ch, generator=g, dtype=torch.float64))
+        w1 = _bf(torch.randn(bnc, ch, 1, generator=g, dtype=torch.float64) / ch ** 0.5)
+        b1 = f32(0.1 * torch.randn(bnc, generator=g, dtype=torch.float64))
+        s2, h2 = f32(torch.rand(bnc, generator=g, dtype=torch.float64) + 0.5), f32(0.2 * torch.randn(bnc, generator=g, dtype=torch.float64))
+        wl = _bf(torch.randn(gr, bnc, 3, generator=g, dtype=torch.float64) / (3 * bnc) ** 0.5)
+        bl = f32(0.1 * torch.randn(gr, generator=g, dtype=torch.float64))
+        cw1, cb1 = f32(torch.randn(bnc, H, generator=g, dtype=torch.float64) / bnc ** 0.5), f32(0.1 * torch.randn(H, generator=g, dtype=torch.float64))
+        cw2, cb2 = f32(torch.randn(H, gr, generator=g, dtype=torch.float64) / H ** 0.5), f32(0.1 * torch.randn(gr, generator=g, dtype=torch.float64))
+        # float64 reference with the kernel's rounding points
+        xin = _bf(torch.relu(ref[:, :, :ch] * s1 + h1))
+        hmid = _bf(torch.relu((xin @ w1[:, :, 0].t() + b1) * s2 + h2))                          # (B, Tn, 128)
+        nseg = (Tn + seg - 1) // seg
+        segmean = torch.stack([hmid[:, s * seg:min((s + 1) * seg, Tn)].mean(1) for s in range(nseg)], 1)      # (B, nseg, 128)
+        ctxv = hmid.mean(1, keepdim=True) + segmean
+        gate = torch.sigmoid(torch.relu(ctxv @ cw1 + cb1) @ cw2 + cb2)                           # (B, nseg, 32)
+        loc = F.conv1d(hmid.transpose(1, 2), wl, bl, padding=dil, dilation=dil).transpose(1, 2)  # zero 'same' padding
+        segidx = torch.arange(Tn) // seg
+        ref[:, :, ch:ch + gr] = _bf(loc * gate[:, segidx])
+        # device-side layer
+        L = layers[l]
+        for name, v in (('bn1_scale', s1), ('bn1_shift', h1), ('ctx_w1', cw1), ('ctx_b1', cb1), ('ctx_w2', cw2), ('ctx_b2', cb2)):
+            d_ = dev(v, torch.float32)
+            keep.append(d_)
+            setattr(L, name, d_.data_ptr())
+        L.linear1 = _layer(N, w1, b1, s2, h2, 1, keep)
+        L.local = _layer(N, wl, bl, None, None, dil, keep)
+        ch += gr
+    catd = dev(cat, torch.bfloat16)
+    N.check(lib.vp_cam_block_fwd(ctx, layers, nl, catd.data_ptr(), ld, ch0, B, Tn, seg, bnc, gr, N.stream_ptr()), ctx)
+    torch.cuda.synchronize()
+    out = catd.double().cpu()
+    assert torch.equal(out[:, :, :ch0], cat[:, :, :ch0])                 # the block input is read-only
+    assert torch.all(out[:, :, ch:] == 0)                                # columns past the block are untouched
+    err = (out[:, :, ch0:ch] - ref[:, :, ch0:ch]).abs()
+    scale = ref[:, :, ch0:ch].abs().max().item()
+    print(f'[cam_block B={B} Tn={Tn} ch0={ch0} layers={nl} seg={seg}] max err {err.max().item():.3e} (max |ref| {scale:.2f}), mean {err.mean().item():.2e}')
+    # f32 vs float64 accumulation can flip a bf16 rounding of h (1 ulp = 2^-8 relative), which the next layers read
+    assert err.max().item() < 2.0 ** -6 * scale, err.max().item()
+    assert err.mean().item() < 4e-4 * scale
+
+
+def test_cam_block_refuses_shapes_it_does_not_cover(N):
+    lib, ctx = N.lib(), N.ctx(0)
+    keep = []
+    layers = (N.CamLayer * 1)()
+    z = torch.zeros(128, dtype=torch.float64)
+    layers[0].linear1 = _layer(N, torch.zeros(128, 128, 1, dtype=torch.float64), z, z, z, 1, keep)
+    layers[0].local = _layer(N, torch.zeros(32, 128, 3, dtype=torch.float64), z[:32], None, None, 1, keep)
+    cat = torch.zeros((1, 200, 256), dtype=torch.bfloat16, device='cuda')
+    assert lib.vp_cam_block_fwd(ctx, layers, 1, cat.data_ptr(), 256, 128, 1, 200, 100, 128, 32, N.stream_ptr()) == N.VP_EUNSUP   # T' > 160
+    assert lib.vp_cam_block_fwd(ctx, layers, 1, cat.data_ptr(), 256, 128, 1, 100, 100, 64, 32, N.stream_ptr()) == N.VP_EUNSUP    # bottleneck != 128
+
+
+@pytest.mark.parametrize('B,T,F_in,stride,mode', [(2, 37, 40, 1, 'res'), (3, 20, 80, 2, 'shortcut'), (2, 9, 20, 2, 'plain'),
+                                                  (1, 298, 10, 1, 'res'), (2, 23, 80, 2, 'fused_c1'), (1, 5, 11, 2, 'shortcut')])
+def test_conv3x3_c32_kernel_vs_float64(N, B, T, F_in, stride, mode):
+    """vp_conv3x3_c32_fwd against float64 conv2d over the same bf16 operands (BasicResBlock / FCM, campplus.py:211-281): stride 1 with
+    the residual, stride 2 with the fused 1x1 shortcut, the plain stride-2 FCM.conv2, and the variant whose input map is FCM.conv1
+    (1 -> 32, BN, ReLU, rounded to bf16 as the unfused path stores it) produced inside the kernel.  Every position, incl. the map's
+    border rows / columns (zero padding), an odd F and more time rows than one workgroup's slab."""
+    lib, ctx = N.lib(), N.ctx(0)
+    Cc = 32
+    g = torch.Generator().manual_seed(T * 100 + F_in + stride)
+    keep = []
+    f32 = lambda t: t.float().double()                                  # noqa: E731
+    w = _bf(torch.randn(Cc, Cc, 3, 3, generator=g, dtype=torch.float64) / (9 * Cc) ** 0.5)     # (out, in, kt, kf)
+    bias = f32(0.1 * torch.randn(Cc, generator=g, dtype=torch.float64))
+    sc, sh = f32(torch.rand(Cc, generator=g, dtype=torch.float64) + 0.5), f32(0.2 * torch.randn(Cc, generator=g, dtype=torch.float64))
+    F_out = (F_in - 1) // stride + 1
+    feats = c1 = None
+    if mode == 'fused_c1':
+        feats = _bf(torch.randn(B, T, F_in, generator=g, dtype=torch.float64) * 3)
+        c1w = f32(torch.randn(Cc, 1, 3, 3, generator=g, dtype=torch.float64) / 3)
+        c1b, c1s, c1h = (f32(0.1 * torch.randn(Cc, generator=g, dtype=torch.float64)), f32(torch.rand(Cc, generator=g, dtype=torch.float64) + 0.5),
+                         f32(0.2 * torch.randn(Cc, generator=g, dtype=torch.float64)))
+        y1 = F.conv2d(feats[:, None], c1w, c1b, padding=1)               # (B, 32, T, F)
+        x = _bf(torch.relu(y1 * c1s[None, :, None, None] + c1h[None, :, None, None])).permute(0, 2, 3, 1)     # (B, T, F, 32)
+        c1 = [dev(c1w.reshape(Cc, 9), torch.float32), dev(c1b, torch.float32), dev(c1s, torch.float32), dev(c1h, torch.float32)]
+    else:
+        x = _bf(torch.randn(B, T, F_in, Cc, generator=g, dtype=torch.float64))
+    conv = F.conv2d(x.permute(0, 3, 1, 2), w, bias, stride=(1, stride), padding=1)              # (B, 32, T, F_out)
+    y = conv * sc[None, :, None, None] + sh[None, :, None, None]
+    res = None
+    if mode == 'res':
+        res = _bf(torch.randn(B, T, F_out, Cc, generator=g, dtype=torch.float64))
+        y = y + res.permute(0, 3, 1, 2)
+    ref = _bf(torch.relu(y)).permute(0, 2, 3, 1)
+    # time-major taps: k = (kt * 3 + kf) * 32 + c
+    L = N.TdnnLayer()
+    wd = dev(w.permute(0, 2, 3, 1).reshape(Cc, 9 * Cc), torch.bfloat16)
+    bd, sd, hd = dev(bias, torch.float32), dev(sc, torch.float32), dev(sh, torch.float32)
+    keep += [wd, bd, sd, hd]
+    L.w, L.bias, L.bn_scale, L.bn_shift, L.cin, L.cout, L.kw, L.dil = wd.data_ptr(), bd.data_ptr(), sd.data_ptr(), hd.data_ptr(), Cc, Cc, 9, 1
+    S = None
+    ref2 = None
+    if mode in ('shortcut', 'fused_c1'):
+        w2 = _bf(torch.randn(Cc, Cc, 1, 1, generator=g, dtype=torch.float64) / Cc ** 0.5)
+        b2 = f32(0.1 * torch.randn(Cc, generator=g, dtype=torch.float64))
+        s2, h2 = f32(torch.rand(Cc, generator=g, dtype=torch.float64) + 0.5), f32(0.2 * torch.randn(Cc, generator=g, dtype=torch.float64))
+        y2 = F.conv2d(x.permute(0, 3, 1, 2), w2, b2, stride=(1, stride))
+        ref2 = _bf(y2 * s2[None, :, None, None] + h2[None, :, None, None]).permute(0, 2, 3, 1)
+        S = N.TdnnLayer()
+        w2d, b2d, s2d, h2d = dev(w2.reshape(Cc, Cc), torch.bfloat16), dev(b2, torch.float32), dev(s2, torch.float32), dev(h2, torch.float32)
+        keep += [w2d, b2d, s2d, h2d]
+        S.w, S.bias, S.bn_scale, S.bn_shift, S.cin, S.cout, S.kw, S.dil = w2d.data_ptr(), b2d.data_ptr(), s2d.data_ptr(), h2d.data_ptr(), Cc, Cc, 1, 1
+    xd = dev(x, torch.bfloat16)
+    yd = torch.full((B, T, F_out, Cc), 7.0, dtype=torch.bfloat16, device='cuda')
+    y2d = torch.full((B, T, F_out, Cc), 7.0, dtype=torch.bfloat16, device='cuda')
+    resd = dev(res, torch.bfloat16) if res is not None else None
+    fd = dev(feats, torch.bfloat16) if feats is not None else None
+    N.check(lib.vp_conv3x3_c32_fwd(ctx, None if fd is not None else xd.data_ptr(), yd.data_ptr(), C.byref(L), resd.data_ptr() if resd is not None else None, 1,
+                                   C.byref(S) if S is not None else None, y2d.data_ptr() if S is not None else None, B, T, F_in, stride,
+                                   fd.data_ptr() if fd is not None else None, *( [t.data_ptr() for t in c1] if c1 else [None] * 4), N.stream_ptr()), ctx)
+    torch.cuda.synchronize()
+    out = yd.double().cpu()
+    scale = ref.abs().max().item()
+    err = (out - ref).abs()
+    print(f'[conv3x3_c32 B={B} T={T} F={F_in} s={stride} {mode}] max err {err.max().item():.3e} (max |ref| {scale:.2f})')
+    # f32 accumulation of bf16 products vs float64: below half a bf16 ulp of the output plus accumulation noise
+    assert err.max().item() < 2e-4 * scale + 2.0 ** -8 * scale, err.max().item()
+    assert err.mean().item() < 2e-4 * scale
+    if ref2 is not None:
+        e2 = (y2d.double().cpu() - ref2).abs()
+        assert e2.max().item() < 2e-4 * ref2.abs().max().item() + 2.0 ** -8 * ref2.abs().max().item(), e2.max().item()
+    else:
+        assert torch.all(y2d == 7.0)

@@ -294,6 +294,27 @@ int vp_conv3x3_c1(vp_ctx* ctx, int dtype, const void* feats, void* out, const fl
 
 extern "C" {
 
+// C-ABI doors of the two fused bf16 kernels of the CAM++ forward (tests call them one by one; vp_campplus_fwd calls the launchers)
+int vp_cam_block_fwd(vp_ctx* ctx, const vp_cam_layer* layers, int n_layers, void* cat, int ld, int ch0, int B, int Tn, int seg_len,
+                     int bn_channels, int growth, vp_stream stream) {
+    if (!ctx || !layers || !cat || B <= 0 || Tn <= 0 || seg_len <= 0) VP_FAIL(ctx, VP_EINVAL, "cam_block: bad arguments");
+    const int rc = vp_cam_block_bf16(ctx, layers, n_layers, cat, ld, ch0, B, Tn, seg_len, bn_channels, growth, (hipStream_t)stream);
+    if (rc == VP_EUNSUP)
+        VP_FAIL(ctx, VP_EUNSUP, "cam_block: shape not covered by the fused kernel (bottleneck 128, growth 32, k3 local convs, T' <= 160, "
+                                "<= 4 context segments, <= 24 layers, <= 1024 channels)");
+    return rc;
+}
+
+int vp_conv3x3_c32_fwd(vp_ctx* ctx, const void* x, void* y, const vp_tdnn_layer* conv, const void* res, int relu,
+                       const vp_tdnn_layer* shortcut, void* y2, int B, int T, int F_in, int stride_f, const void* c1_feats,
+                       const float* c1_w, const float* c1_b, const float* c1_scale, const float* c1_shift, vp_stream stream) {
+    if (!ctx || !y || !conv || B <= 0 || T <= 0 || F_in <= 0) VP_FAIL(ctx, VP_EINVAL, "conv3x3_c32: bad arguments");
+    const int rc = vp_conv3x3_c32_bf16(ctx, x, y, conv, res, relu, shortcut, y2, B, T, F_in, stride_f, c1_feats, c1_w, c1_b, c1_scale,
+                                       c1_shift, (hipStream_t)stream);
+    if (rc == VP_EUNSUP) VP_FAIL(ctx, VP_EUNSUP, "conv3x3_c32: shape not covered (32 -> 32 channels, 3x3, frequency stride 1 or 2, 16-byte aligned)");
+    return rc;
+}
+
 size_t vp_campplus_workspace_bytes(const vp_campplus_weights* w, int B, int T) {
     if (!w || B <= 0 || T <= 0) return 0;
     CamPlan p;

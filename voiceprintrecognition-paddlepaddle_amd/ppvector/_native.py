@@ -244,6 +244,9 @@ _PROTOS = {
     'vp_cosine_logits_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                      c_size_t, c_void_p]),
     'vp_conv256_select': (c_int, [c_int]),
+    'vp_cam_block_fwd': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'vp_conv3x3_c32_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'vp_res2_chain_fwd': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'vp_asp_fused_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                  c_float, c_void_p, c_void_p]),
