@@ -129,7 +129,7 @@ class ConvBlock(torch.autograd.Function):
         if bn or relu:
             if bn:
                 sums = col_sums(dy, z, mean, invstd)
-                dgamma, dbeta = sums[1].clone(), sums[0].clone()
+                dgamma, dbeta = sums[1], sums[0]             # views of a buffer this call owns: no copies
                 mu, istd, g = mean, invstd, gamma
             else:                                   # ReLU alone: the BN backward formula with identity statistics
                 sums = torch.zeros((2, Cout), dtype=torch.float32, device=dev)
@@ -142,7 +142,7 @@ class ConvBlock(torch.autograd.Function):
                                         dz.data_ptr(), Cout, N.stream_ptr()), hctx)
         else:
             dz = dy
-        dbias = col_sums(dz)[0].clone() if has_bias else None
+        dbias = col_sums(dz)[0] if has_bias else None
         drb = None
         if has_rb:
             drb = torch.empty((B, Cout), dtype=torch.float32, device=dev)
@@ -291,7 +291,7 @@ class BNRows(torch.autograd.Function):
         dx = torch.empty_like(x)
         _chk(lib.vp_bn_relu_bwd_f32(hctx, dy.data_ptr(), Cc, x.data_ptr(), Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
                                     sums.data_ptr(), M, Cc, 0, dx.data_ptr(), Cc, N.stream_ptr()), hctx)
-        return dx, sums[1].clone(), sums[0].clone(), None, None, None, None, None
+        return dx, sums[1], sums[0], None, None, None, None, None
 
 
 class HeadLoss(torch.autograd.Function):
@@ -405,7 +405,7 @@ class Dense(torch.autograd.Function):
             dw = torch.empty_like(w_kn)
             _chk(lib.vp_dense_f32(hctx, xt.data_ptr(), M, dy.data_ptr(), 1, None, K, Nn, M, N.VP_ACT_NONE, dw.data_ptr(), Nn,
                                   N.stream_ptr()), hctx)
-        db = col_sums(dy)[0].clone() if ctx.has_bias and ctx.needs_input_grad[2] else None
+        db = col_sums(dy)[0] if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db
 
 
@@ -522,11 +522,11 @@ class Conv2dBlock(torch.autograd.Function):
         dz = dy
         if bn:
             sums = col_sums(dy, z, mean, invstd)
-            dgamma, dbeta = sums[1].clone(), sums[0].clone()
+            dgamma, dbeta = sums[1], sums[0]
             dz = torch.empty_like(dy)
             _chk(lib.vp_bn_relu_bwd_f32(hctx, dy.data_ptr(), Cout, z.data_ptr(), Cout, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
                                         sums.data_ptr(), M, Cout, 0, dz.data_ptr(), Cout, N.stream_ptr()), hctx)
-        dbias = col_sums(dz)[0].clone() if has_bias else None
+        dbias = col_sums(dz)[0] if has_bias else None
         st, sf, dil, padf = s
         d = _conv_desc(x, B, T, To, Cin, Cout, KT * KF, dil, N.VP_PAD_ZERO, pad, weight)
         d.F_in, d.F_out, d.KF, d.stride, d.stride_f, d.pad_f = Fq, Fo, KF, st, sf, padf
