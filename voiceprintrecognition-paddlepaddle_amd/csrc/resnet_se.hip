@@ -108,11 +108,18 @@ int vp_resnetse_fwd(vp_ctx* ctx, const vp_resnetse_weights* w, const void* feats
         base_desc(d, b.conv1, dt);
         d.B = B; d.T_in = t * f; d.T_out = t * f; d.x = x; d.y = p.o1; d.act2 = VP_ACT_RELU;
         if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
-        // o2 = relu(bn2(conv3x3 stride s (o1)))
-        base_desc(d, b.conv2, dt);
-        d.B = B; d.T_in = t; d.T_out = to; d.F_in = f; d.F_out = fo; d.KF = 3; d.stride = b.stride; d.stride_f = b.stride;
-        d.pad_left = 1; d.pad_f = 1; d.x = p.o1; d.y = p.o2; d.act2 = VP_ACT_RELU;
-        if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+        // o2 = relu(bn2(conv3x3 stride s (o1))): the stage-1 blocks (32 -> 32 channels, stride 1, full-resolution maps) run on the
+        // slab kernel of the CAM++ FCM head (fcm_conv.hip), the rest on the conv GEMM's 2-D loader
+        int fast = VP_EUNSUP;
+        if (dt == VP_BF16 && b.stride == 1 && b.conv2.cin == 32 && b.conv2.cout == 32)
+            fast = vp_conv3x3_c32_bf16(ctx, p.o1, p.o2, &b.conv2, nullptr, 1, nullptr, nullptr, B, t, f, 1, nullptr, nullptr, nullptr, nullptr, nullptr, st);
+        if (fast != VP_OK && fast != VP_EUNSUP) return fast;
+        if (fast != VP_OK) {
+            base_desc(d, b.conv2, dt);
+            d.B = B; d.T_in = t; d.T_out = to; d.F_in = f; d.F_out = fo; d.KF = 3; d.stride = b.stride; d.stride_f = b.stride;
+            d.pad_left = 1; d.pad_f = 1; d.x = p.o1; d.y = p.o2; d.act2 = VP_ACT_RELU;
+            if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+        }
         // o3 = bn3(conv1x1(o2)) with the per-utterance sums of the SE squeeze fused in
         base_desc(d, b.conv3, dt);
         d.B = B; d.T_in = to * fo; d.T_out = to * fo; d.x = p.o2; d.y = p.o3; d.psum = p.psum;
