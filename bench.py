@@ -428,7 +428,7 @@ def run_train(args, rank, local_rank, world, dist, steps=None, warmup=None, emit
     from ppvector.loss.aamloss import AAMLoss
     from ppvector.optimizer.adam import Adam
     from ppvector.train.ddp import allreduce_mean_, shard_batch
-    from ppvector.train.step import TrainStep
+    from ppvector.train.step import GraphedTrainStep, TrainStep
     dev = torch.device('cuda', local_rank)
     gbatch = args.global_batch * (world if args.weak else 1)
     idx = shard_batch(gbatch, rank, world)
@@ -443,7 +443,10 @@ def run_train(args, rank, local_rank, world, dist, steps=None, warmup=None, emit
     model = torch.nn.Sequential(backbone, head).to(dev)
     crit = AAMLoss(margin=0.2, scale=32, easy_margin=False, label_smoothing=0.0)
     opt = Adam(model.parameters(), learning_rate=1e-4, weight_decay=1e-6)
-    step_obj = TrainStep(model, crit, opt, featurizer=fz)
+    # forward + backward from one captured HIP graph (ppvector/train/step.py: GraphedTrainStep) unless --train-graph 0: the step is
+    # ~1000 launches, and at the 32 utterances per GPU of the strong-scaled 8-GPU point the eager step is host-bound
+    graphed = bool(args.train_graph)
+    step_obj = GraphedTrainStep(model, crit, opt, featurizer=fz) if graphed else TrainStep(model, crit, opt, featurizer=fz)
     last = {}
 
     def step():
@@ -470,16 +473,19 @@ def run_train(args, rank, local_rank, world, dist, steps=None, warmup=None, emit
             allreduce_mean_(g, bucket_bytes=16 << 20)
         torch.cuda.synchronize()
         ar_ms = (time.perf_counter() - t0) / reps * 1e3
-        # the same step without the collective: hooks removed, nothing to finish
-        step_obj.reducer.remove()
-        step_obj.reducer.world = 1
+        # the same step without the collective: hooks removed, nothing to finish (graph mode: the all-reduce call is skipped)
+        if step_obj.reducer is not None:
+            step_obj.reducer.remove()
+            step_obj.reducer.world = 1
+        else:
+            step_obj.skip_allreduce = True
         dt0, _ = run_timed(step, max(5, steps // 4), 2, dist, dev)
         ms_nocomm = dt0 / max(5, steps // 4) * 1e3
         exposed = max(0.0, ms_step - ms_nocomm)
         comm = {'rccl_ranks': ranks, 'allreduce_ms': round(ar_ms, 4), 'allreduce_bytes': int(g.numel() * 4),
                 'allreduce_algbw_GBps': round(g.numel() * 4 / ar_ms / 1e6, 2), 'step_ms_without_collective': round(ms_nocomm, 4),
                 'comm_exposed_ms': round(exposed, 4), 'overlap_frac': round(1.0 - min(1.0, exposed / ar_ms), 4) if ar_ms > 0 else None,
-                'grad_buckets': len(step_obj.reducer.buckets)}
+                'grad_buckets': len(step_obj.reducer.buckets) if step_obj.reducer is not None else -(-int(g.numel() * 4) // (16 << 20))}
     if rank != 0:
         return None
     value = gbatch * steps / dt
@@ -494,11 +500,16 @@ def run_train(args, rank, local_rank, world, dist, steps=None, warmup=None, emit
                                
                                f'global batch {gbatch}, inputs resident in HBM, random-init weights',
                    'batch_per_gpu': B, 'global_batch': gbatch,
-                   'parallelism': f'dp{world} (bucketed gradient all-reduce over RCCL, overlapped with backward)' if world > 1 else 'dp1'},
+                   'parallelism': (f'dp{world} (bucketed gradient all-reduce over RCCL, ' +
+                                   ('after the replayed backward)' if graphed and getattr(step_obj, 'capture_error', None) is None
+                                    else 'overlapped with backward)')) if world > 1 else 'dp1',
+                   'hip_graph': bool(graphed and getattr(step_obj, 'capture_error', None) is None)},
         'loss': round(loss_v, 5),
         'stage_roofline_frac': round(value * 3 * ALG_GFLOP_PER_UTT / 1e3 / world / (PEAK_BF16_TFLOPS if args.amp else PEAK_F32_TFLOPS), 4),
         'stage_roofline_peak': ('bf16 MFMA 2500' if args.amp else 'f32 MFMA 157.3') + ' TFLOP/s per GPU, 3 x forward flops per utterance',
     }
+    if graphed and getattr(step_obj, 'capture_error', None):
+        out['hip_graph_error'] = step_obj.capture_error
     out.update(comm)
     if emit:
         print(json.dumps(out), flush=True)
@@ -517,6 +528,7 @@ def main():
     ap.add_argument('--amp', type=int, default=1, help='training: conv GEMMs on the bf16 matrix cores over f32 tensors (enable_amp); 0 = exact f32')
     ap.add_argument('--global-batch', type=int, default=BATCH, help='train mode: global batch (strong scaling)')
     ap.add_argument('--weak', action='store_true', help='train mode: keep --global-batch utterances PER GPU')
+    ap.add_argument('--train-graph', type=int, default=1, help='training: replay forward + backward from a captured HIP graph (1) or launch eagerly (0)')
     ap.add_argument('--no-train-line', action='store_true', help='infer mode: skip the "dp_train" measurement')
     ap.add_argument('--train-steps', type=int, default=20, help='infer mode: timed steps of the "dp_train" measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')

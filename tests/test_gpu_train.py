@@ -659,3 +659,48 @@ def test_ecapa_training_step_mixed_precision(N, amp):
     assert abs(loss.item() - loss_x) < 2e-3 * abs(loss_x) and rel(emb, emb_x) < 3e-2
     assert w_exact < 1.5 * w_inh + 2e-2, (w_exact, w_inh)
     m.eval()
+
+
+def test_graphed_train_step_equals_the_eager_step(N):
+    """GraphedTrainStep (forward + backward replayed from one captured HIP graph; all-reduce, Adam and the schedulers eager) against
+    TrainStep from the same initial state on the same batches: losses of every step, the trained parameters and the BatchNorm
+    running statistics.  Six steps: three eager warm-up steps inside GraphedTrainStep, the capture, two replays with NEW inputs
+    (the static buffers must be refreshed), and a changed loss margin (a launch scalar: must re-capture)."""
+    from ppvector.loss.aamloss import AAMLoss
+    from ppvector.models.fc import SpeakerIdentification
+    from ppvector.models.tdnn import TDNN
+    from ppvector.optimizer.adam import Adam
+    from ppvector.train.step import GraphedTrainStep, TrainStep
+    g = torch.Generator().manual_seed(11)
+    xs = [(torch.randn(6, 90, 80, generator=g) * 2).cuda() for _ in range(7)]
+    ys = [torch.randint(0, 12, (6,), generator=g).cuda() for _ in range(7)]
+
+    def run(cls):
+        torch.manual_seed(0)
+        m = TDNN(80)
+        m.load_state_dict(om.tdnn_params(80, seed=5))
+        head = SpeakerIdentification(192, 12)
+        head.load_state_dict({'weight': om.head_params(192, 12, seed=6)})
+        model = torch.nn.Sequential(m, head).cuda()
+        crit = AAMLoss(margin=0.2, scale=32)
+        opt = Adam(model.parameters(), learning_rate=2e-3, weight_decay=1e-6)
+        step = cls(model, crit, opt)
+        losses = []
+        for i, (x, y) in enumerate(zip(xs, ys)):
+            if i == 6:
+                crit.update(0.3)
+            loss, acc = step(x, y)
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        return losses, {k: v.detach().clone() for k, v in model.state_dict().items()}, step
+
+    le, se, _ = run(TrainStep)
+    lg, sg, st = run(GraphedTrainStep)
+    assert st.capture_error is None, st.capture_error
+    assert st._graph is not None
+    print('[graphed step] losses eager', [f'{v:.5f}' for v in le], 'graphed', [f'{v:.5f}' for v in lg])
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (le, lg)
+    for k in se:
+        d = (se[k].double() - sg[k].double()).abs().max().item()
+        assert d <= 1e-5 * max(1.0, se[k].abs().max().item()), (k, d)
