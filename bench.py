@@ -351,13 +351,20 @@ def run_infer(args, rank, local_rank, world, dist):
         for _ in range(3):
             step()
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_loss = step()
+        try:
+            graph = torch.cuda.CUDAGraph()
+            # thread-local error mode: with world > 1 the collective library's watchdog thread polls its events while we capture
+            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                static_loss = step()
 
-        def run():
-            graph.replay()
-            return static_loss
+            def run():
+                graph.replay()
+                return static_loss
+        except Exception as e:             # noqa: BLE001 -- a failed capture must not cost the measurement: launch eagerly
+            print(f'bench: HIP graph capture failed ({type(e).__name__}: {e}); launching eagerly', file=sys.stderr, flush=True)
+            args.graph = 0
+            torch.cuda.synchronize()
+            run = step
 
     dt, loss = run_timed(run, args.steps, args.warmup, dist, dev)
     loss_v = float(loss)
@@ -455,6 +462,8 @@ def run_train(args, rank, local_rank, world, dist, steps=None, warmup=None, emit
 
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
+    if graphed:
+        warmup = max(warmup, 5)             # three eager steps + the capture + one replay stay outside the timed region
     dt, loss = run_timed(step, steps, warmup, dist, dev)
     loss_v = float(loss)
     assert np.isfinite(loss_v)

@@ -469,7 +469,7 @@ def _graph_forward(eng, x):
             eng.forward(static_in)
         torch.cuda.current_stream().wait_stream(side)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):
             static_out = eng.forward(static_in)
         ent = graphs[key] = (g, static_in, static_out)
     g, static_in, static_out = ent

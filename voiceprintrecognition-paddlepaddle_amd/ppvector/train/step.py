@@ -84,7 +84,9 @@ class GraphedTrainStep(TrainStep):
         st['feats'], st['labels'] = feats.clone(), labels.clone()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread-local error mode: another thread of the process (the collective library's watchdog polling its events) must not
+        # invalidate the capture
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):
             outputs = self.model(st['feats'])
             loss = self.criterion(outputs, st['labels'])
             loss.backward()
