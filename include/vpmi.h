@@ -68,6 +68,13 @@ size_t vp_fbank_workspace_bytes(const vp_fbank_opts* o, int B, int L);
 int vp_fbank_cmn_f32(vp_ctx* ctx, const float* wav, const float* lens_ratio, int B, int L,
                      const vp_fbank_opts* o, float* out, void* out_bf16, void* ws, size_t ws_bytes,
                      vp_stream stream);
+/* vp_fbank_cmn_pcm16 -- the same featurizer over 16-bit PCM as the decoder delivers it (the reference's readers convert to float32 on
+ * the host: yeaudio AudioSegment, x / 32768): samples are widened as the frame kernel loads them (x pcm_scale), so the host -> device
+ * copy in front of featurizer.py:33-60 carries half the bytes.  L and the frame shift must be even.  Same outputs, bit for bit, as
+ * vp_fbank_cmn_f32 over the widened samples. */
+int vp_fbank_cmn_pcm16(vp_ctx* ctx, const int16_t* wav, float pcm_scale, const float* lens_ratio, int B, int L,
+                       const vp_fbank_opts* o, float* out, void* out_bf16, void* ws, size_t ws_bytes, vp_stream stream);
+
 /* Ragged batch, the training loader's semantics: the reference featurises every utterance on its own (AudioFeaturizer on
  * one waveform, time mean over ITS frames, data_utils/reader.py:102-103) and collate_fn zero-pads the features
  * (collate_fn.py:5-23).  wav (B, L) holds utterance b in its first n_samples[b] samples; frames [0, n_frames[b]),

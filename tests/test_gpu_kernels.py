@@ -48,6 +48,27 @@ def test_fbank_matches_oracle(N, B, L):
     assert np.max(np.abs(twin - got)) <= np.max(np.abs(got)) * 2 ** -8 + 1e-6
 
 
+def test_fbank_pcm16_equals_float_path(N):
+    """16-bit PCM input (vp_fbank_cmn_pcm16: samples widened x 1/32768 inside the frame kernel, what the reference's readers do on the
+    host) against the float32 entry over the widened samples: bit for bit, incl. the length mask and the bf16 twin; and against the
+    oracle on the widened samples.  An odd number of samples per row takes the widen-first route."""
+    from ppvector.data_utils.featurizer import AudioFeaturizer
+    w = ofb.synth_waves(3, 16000, seed=77)
+    pcm = np.clip(np.round(w / np.abs(w).max() * 20000.0), -32768, 32767).astype(np.int16)
+    wf = pcm.astype(np.float32) * np.float32(1.0 / 32768.0)
+    ratio = np.asarray([1.0, 0.6, 0.31], np.float32)
+    fz = AudioFeaturizer('Fbank', dict(sr=16000, n_mels=80))
+    a = fz(dev(torch.from_numpy(pcm)), dev(ratio), want_bf16=True)
+    b = fz(dev(wf), dev(ratio), want_bf16=True)
+    torch.cuda.synchronize()
+    assert a.dtype == torch.float32 and torch.equal(a, b)
+    assert torch.equal(a._vp_bf16, b._vp_bf16)
+    ref = ofb.featurize(wf, ratio, method_args=dict(sr=16000, n_mels=80))
+    assert np.max(np.abs(a.cpu().numpy() - ref)) < 2e-3
+    odd = fz(dev(torch.from_numpy(pcm[:, :15999])))
+    assert torch.equal(odd, fz(dev(wf[:, :15999])))
+
+
 def test_fbank_mask_and_1d(N):
     from ppvector.data_utils.featurizer import AudioFeaturizer
     w = ofb.synth_waves(4, 12000, seed=5)

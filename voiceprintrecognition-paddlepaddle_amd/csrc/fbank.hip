@@ -263,6 +263,7 @@ constexpr int F16_MAX_ROUNDS = FB_MAX_MEL / 16;
 struct Fbank16Args {
     const float* wav; float* out; float* psum; const float* window; const float2* tw;
     const float* wpad; const int* mel_bin0;
+    const short* wav16; float pcm_scale;       // PCM16 variant: 16-bit samples widened (x pcm_scale) as they are loaded; wav unused
     int B, L, T, tiles, win, shift, n_mels, n_rounds, wpad_len;
     int round_off[F16_MAX_ROUNDS], round_max[F16_MAX_ROUNDS];
     float preemph, log_floor;
@@ -298,7 +299,7 @@ __device__ __forceinline__ void dft16(v2f (&v)[16]) {
 #define DFT16_OUT(v, k) v[4 * ((k) & 3) + ((k) >> 2)]
 
 // NP1 = packed-point rows (of 16) that can be non-zero: ceil(win / 32); 13 for the 25 ms window at 16 kHz
-template <int NP1>
+template <int NP1, bool PCM16>
 __global__ __launch_bounds__(FB_WAVES * 64, 3) void fbank_frames16_kernel(Fbank16Args a) {
     __shared__ __attribute__((aligned(16))) float s_win[FB_NFFT];
     __shared__ __attribute__((aligned(16))) float2 s_tw1[256];                   // W256^(n2 k1) at [n2 * 16 + k1]
@@ -328,11 +329,19 @@ __global__ __launch_bounds__(FB_WAVES * 64, 3) void fbank_frames16_kernel(Fbank1
     auto fetch = [&](int id) {
         const int bb = id / a.tiles, tt = id - bb * a.tiles;
         const int tf = min(tt * FRAMES_PER_WG + wv * 4 + f, a.T - 1);
-        const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wav + (size_t)bb * a.L), 0,
-                                                                             (unsigned)a.L * 4u, 0x00020000);
-        const unsigned base = (unsigned)(tf * a.shift + 2 * j) * 4u;
+        if constexpr (PCM16) {                             // two 16-bit samples per lane and row: 64 contiguous bytes per 16 lanes
+            const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<short*>(a.wav16 + (size_t)bb * a.L), 0,
+                                                                                 (unsigned)a.L * 2u, 0x00020000);
+            const unsigned base = (unsigned)(tf * a.shift + 2 * j) * 2u;
 #pragma unroll
-        for (int n1 = 0; n1 < NP1; ++n1) raw[n1] = __builtin_amdgcn_raw_buffer_load_b64(wsrd, base + (unsigned)n1 * 128u, 0, 0);
+            for (int n1 = 0; n1 < NP1; ++n1) raw[n1].x = __builtin_amdgcn_raw_buffer_load_b32(wsrd, base + (unsigned)n1 * 64u, 0, 0);
+        } else {
+            const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wav + (size_t)bb * a.L), 0,
+                                                                                 (unsigned)a.L * 4u, 0x00020000);
+            const unsigned base = (unsigned)(tf * a.shift + 2 * j) * 4u;
+#pragma unroll
+            for (int n1 = 0; n1 < NP1; ++n1) raw[n1] = __builtin_amdgcn_raw_buffer_load_b64(wsrd, base + (unsigned)n1 * 128u, 0, 0);
+        }
     };
     if ((int)blockIdx.x < total) fetch(blockIdx.x);
     __syncthreads();
@@ -347,7 +356,12 @@ __global__ __launch_bounds__(FB_WAVES * 64, 3) void fbank_frames16_kernel(Fbank1
     float part = 0.f;
 #pragma unroll
     for (int n1 = 0; n1 < NP1; ++n1) {
-        x[n1] = __builtin_bit_cast(v2f, raw[n1]);       // whole-vector cast (an element-wise bit_cast of an ext-vector lvalue reads element 0)
+        if constexpr (PCM16) {
+            const unsigned pr = raw[n1].x;                  // low half = sample 2n, high half = sample 2n + 1 (sign-extended)
+            x[n1] = v2f{(float)(short)(pr & 0xffffu) * a.pcm_scale, (float)((int)pr >> 16) * a.pcm_scale};
+        } else {
+            x[n1] = __builtin_bit_cast(v2f, raw[n1]);       // whole-vector cast (an element-wise bit_cast of an ext-vector lvalue reads element 0)
+        }
         const int i0 = 32 * n1 + 2 * j;
         if (n1 < NP1 - 1 && NP1 < 16) part += x[n1].x + x[n1].y;                 // NP1 = ceil(win / 32): only the last row can cross the window end
         else part += (i0 < a.win ? x[n1].x : 0.f) + (i0 + 1 < a.win ? x[n1].y : 0.f);
@@ -671,14 +685,14 @@ int vp_fbank_release_tables(vp_ctx* ctx) {
 }
 
 // Frame kernel launch shared by the rectangular and the ragged entry points.
-static int launch_frames(vp_ctx* ctx, const float* wav, float* out, float* psum, int B, int L, int T, int tiles, const vp_fbank_opts* o,
-                         hipStream_t st) {
+static int launch_frames(vp_ctx* ctx, const float* wav, const short* wav16, float pcm_scale, float* out, float* psum, int B, int L, int T,
+                         int tiles, const vp_fbank_opts* o, hipStream_t st) {
     static int force_old = -1;
     if (force_old < 0) { const char* e = getenv("VPMI_FBANK_OLD"); force_old = e && atoi(e) ? 1 : 0; }
-    if (ctx->fb_f16 && !force_old) {
+    if (ctx->fb_f16 && (!force_old || wav16)) {
         Fbank16Args a;
         memset(&a, 0, sizeof(a));
-        a.wav = wav; a.out = out; a.psum = psum; a.window = ctx->fb_window; a.tw = ctx->fb_twiddle;
+        a.wav = wav; a.wav16 = wav16; a.pcm_scale = pcm_scale; a.out = out; a.psum = psum; a.window = ctx->fb_window; a.tw = ctx->fb_twiddle;
         a.wpad = ctx->fb_wpad; a.mel_bin0 = ctx->fb_mel_bin0;
         a.B = B; a.L = L; a.T = T; a.tiles = tiles; a.win = ctx->fb_win; a.shift = ctx->fb_shift;
         a.n_mels = o->n_mels; a.n_rounds = ctx->fb_rounds; a.wpad_len = ctx->fb_wpad_len;
@@ -692,13 +706,18 @@ static int launch_frames(vp_ctx* ctx, const float* wav, float* out, float* psum,
         }
         const long long total = (long long)tiles * B;
         const int grid = (int)(total < slots ? total : slots);
-        if ((ctx->fb_win + 31) / 32 == 13)
-            hipLaunchKernelGGL(fbank_frames16_kernel<13>, dim3(grid), dim3(FB_WAVES * 64), 0, st, a);
-        else
-            hipLaunchKernelGGL(fbank_frames16_kernel<16>, dim3(grid), dim3(FB_WAVES * 64), 0, st, a);
+        const bool np13 = (ctx->fb_win + 31) / 32 == 13;
+        if (wav16) {
+            if (np13) hipLaunchKernelGGL((fbank_frames16_kernel<13, true>), dim3(grid), dim3(FB_WAVES * 64), 0, st, a);
+            else hipLaunchKernelGGL((fbank_frames16_kernel<16, true>), dim3(grid), dim3(FB_WAVES * 64), 0, st, a);
+        } else {
+            if (np13) hipLaunchKernelGGL((fbank_frames16_kernel<13, false>), dim3(grid), dim3(FB_WAVES * 64), 0, st, a);
+            else hipLaunchKernelGGL((fbank_frames16_kernel<16, false>), dim3(grid), dim3(FB_WAVES * 64), 0, st, a);
+        }
         VP_LAUNCH_CHECK(ctx, "fbank_frames16");
         return VP_OK;
     }
+    if (wav16) VP_FAIL(ctx, VP_EUNSUP, "fbank: 16-bit PCM input needs the four-frames-per-wave kernel (mel bank not covered)");
     FbankArgs a;
     a.wav = wav; a.out = out; a.psum = psum; a.window = ctx->fb_window; a.tw = ctx->fb_twiddle;
     a.mel_start = ctx->fb_mel_start; a.mel_bin0 = ctx->fb_mel_bin0; a.mel_w = ctx->fb_mel_w;
@@ -742,7 +761,24 @@ int vp_fbank_cmn_f32(vp_ctx* ctx, const float* wav, const float* lens_ratio, int
     if (!ws || ws_bytes < vp_fbank_workspace_bytes(o, B, L)) VP_FAIL(ctx, VP_EWORKSPACE, "fbank: workspace too small");
     const int tiles = (T + FRAMES_PER_WG - 1) / FRAMES_PER_WG;
     hipStream_t st = (hipStream_t)stream;
-    if ((rc = launch_frames(ctx, wav, out, (float*)ws, B, L, T, tiles, o, st))) return rc;
+    if ((rc = launch_frames(ctx, wav, nullptr, 0.f, out, (float*)ws, B, L, T, tiles, o, st))) return rc;
+    return vp_feat_cmn(ctx, out, out_bf16, (const float*)ws, lens_ratio, B, T, tiles, o->n_mels, st);
+}
+
+int vp_fbank_cmn_pcm16(vp_ctx* ctx, const int16_t* wav, float pcm_scale, const float* lens_ratio, int B, int L,
+                       const vp_fbank_opts* o, float* out, void* out_bf16, void* ws, size_t ws_bytes, vp_stream stream) {
+    if (!ctx || !wav || !o || !out || B <= 0) VP_FAIL(ctx, VP_EINVAL, "fbank: bad arguments");
+    const int T = vp_fbank_num_frames(o, L);
+    if (T <= 0) VP_FAIL(ctx, VP_EINVAL, "fbank: %d samples give no frame", L);
+    if (B > 65535) VP_FAIL(ctx, VP_EINVAL, "fbank: batch %d > 65535", B);
+    if (L & 1) VP_FAIL(ctx, VP_EUNSUP, "fbank: 16-bit PCM rows must hold an even number of samples (4-byte aligned pairs)");
+    int rc = build_tables(ctx, o);
+    if (rc != VP_OK) return rc;
+    if (ctx->fb_shift & 1) VP_FAIL(ctx, VP_EUNSUP, "fbank: 16-bit PCM input needs an even frame shift (4-byte aligned sample pairs)");
+    if (!ws || ws_bytes < vp_fbank_workspace_bytes(o, B, L)) VP_FAIL(ctx, VP_EWORKSPACE, "fbank: workspace too small");
+    const int tiles = (T + FRAMES_PER_WG - 1) / FRAMES_PER_WG;
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = launch_frames(ctx, nullptr, wav, pcm_scale, out, (float*)ws, B, L, T, tiles, o, st))) return rc;
     return vp_feat_cmn(ctx, out, out_bf16, (const float*)ws, lens_ratio, B, T, tiles, o->n_mels, st);
 }
 
@@ -757,7 +793,7 @@ int vp_fbank_cmn_ragged_f32(vp_ctx* ctx, const float* wav, const int32_t* n_samp
     if (!ws || ws_bytes < vp_fbank_workspace_bytes(o, B, L)) VP_FAIL(ctx, VP_EWORKSPACE, "fbank: workspace too small");
     const int tiles = (T + FRAMES_PER_WG - 1) / FRAMES_PER_WG;
     hipStream_t st = (hipStream_t)stream;
-    if ((rc = launch_frames(ctx, wav, out, (float*)ws, B, L, T, tiles, o, st))) return rc;
+    if ((rc = launch_frames(ctx, wav, nullptr, 0.f, out, (float*)ws, B, L, T, tiles, o, st))) return rc;
     hipLaunchKernelGGL(frames_of_samples_kernel, dim3((B + 255) / 256), dim3(256), 0, st, n_samples, B, ctx->fb_win, ctx->fb_shift, T, n_frames);
     VP_LAUNCH_CHECK(ctx, "frames_of_samples");
     CmnRaggedArgs c{out, (bf16_t*)out_bf16, n_frames, T, o->n_mels};

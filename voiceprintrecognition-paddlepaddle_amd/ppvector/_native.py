@@ -153,6 +153,8 @@ _PROTOS = {
     'vp_fbank_workspace_bytes': (c_size_t, [C.POINTER(FbankOpts), c_int, c_int]),
     'vp_fbank_cmn_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, C.POINTER(FbankOpts), c_void_p,
                                  c_void_p, c_void_p, c_size_t, c_void_p]),
+    'vp_fbank_cmn_pcm16': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, C.POINTER(FbankOpts), c_void_p, c_void_p, c_void_p,
+                                   c_size_t, c_void_p]),
     'vp_fbank_cmn_ragged_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, C.POINTER(FbankOpts), c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_size_t, c_void_p]),
     'vp_mel_default_opts': (None, [C.POINTER(MelOpts)]),

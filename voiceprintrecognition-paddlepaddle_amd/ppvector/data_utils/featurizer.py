@@ -118,7 +118,12 @@ class AudioFeaturizer(nn.Module):
             waveforms = waveforms.unsqueeze(0)
         if not waveforms.is_cuda:
             raise N.VpmiError('AudioFeaturizer needs GPU tensors: the engine has no CPU fallback')
-        wav = waveforms.contiguous().float()
+        # 16-bit PCM as decoded (torch.int16): widened inside the Fbank frame kernel (x 1 / 32768, what the reference's readers do on
+        # the host), so an upload in front of this call carries half the bytes; other methods widen first
+        pcm16 = waveforms.dtype == torch.int16 and self._feature_method == 'Fbank' and waveforms.shape[-1] % 2 == 0
+        if waveforms.dtype == torch.int16 and not pcm16:
+            waveforms = waveforms.float() * (1.0 / 32768.0)
+        wav = waveforms.contiguous() if pcm16 else waveforms.contiguous().float()
         B, L = wav.shape
         lib, ctx = N.lib(), N.ctx(wav.device)
         mel = self._feature_method in ('MelSpectrogram', 'LogMelSpectrogram', 'MFCC')
@@ -133,9 +138,13 @@ class AudioFeaturizer(nn.Module):
             ratio = input_lens_ratio.to(device=wav.device, dtype=torch.float32).contiguous()
         nws = (lib.vp_mel_workspace_bytes if mel else lib.vp_fbank_workspace_bytes)(C.byref(self._opts), B, L)
         ws = self._ws.get(nws, wav.device)
-        fn = lib.vp_melspec_cmn_f32 if mel else lib.vp_fbank_cmn_f32
-        N.check(fn(ctx, N.ptr(wav), N.ptr(ratio), B, L, C.byref(self._opts), N.ptr(out), N.ptr(out16), N.ptr(ws),
-                   ws.numel(), N.stream_ptr()), ctx)
+        if pcm16:
+            N.check(lib.vp_fbank_cmn_pcm16(ctx, N.ptr(wav), 1.0 / 32768.0, N.ptr(ratio), B, L, C.byref(self._opts), N.ptr(out), N.ptr(out16),
+                                           N.ptr(ws), ws.numel(), N.stream_ptr()), ctx)
+        else:
+            fn = lib.vp_melspec_cmn_f32 if mel else lib.vp_fbank_cmn_f32
+            N.check(fn(ctx, N.ptr(wav), N.ptr(ratio), B, L, C.byref(self._opts), N.ptr(out), N.ptr(out16), N.ptr(ws),
+                       ws.numel(), N.stream_ptr()), ctx)
         if self._feature_method == 'MFCC':
             # paddle.audio.features.MFCC (featurizer.py:26-27): log-mel @ create_dct(n_mfcc, n_mels, norm='ortho').  The DCT is
             # linear, so it commutes with the mean subtraction and the zeroed rows already applied to the log-mel features.
