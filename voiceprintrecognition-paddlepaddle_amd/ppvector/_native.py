@@ -359,9 +359,14 @@ class Workspace:
     allocates nothing (hipGraph-friendly)."""
 
     def __init__(self):
-        self.buf = None
+        self.bufs = {}
 
     def get(self, nbytes, device):
-        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
-            self.buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
-        return self.buf
+        # one buffer per (device, stream): the same consumer may run on several streams at once (engine.forward_streams' shard
+        # tails), and a kernel's scratch must not be shared between launch sequences that overlap
+        key = (device, torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0)
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+            self.bufs[key] = buf
+        return buf
