@@ -534,6 +534,11 @@ int vp_affine_rows_f32(vp_ctx* ctx, const float* z, int ldz, const float* scale,
 int vp_bn_relu_bwd_f32(vp_ctx* ctx, const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* invstd,
                        const float* gamma, const float* sums, long long M, int C, int relu_mask, float* dz, int lddz,
                        vp_stream stream);
+/* vp_pack_segments_f32: dst[offs[i] .. offs[i] + sizes[i]) = srcs[i] (zeros where srcs[i] is NULL), HOST arrays of n entries -- the
+ * parameters' gradient tensors into the optimiser's flat buffer in one or two launches (what fleet's fused gradient buffers do for
+ * the reference's DataParallel; trainer.py:213-229 only sees loss.backward() / optimizer.step()). */
+int vp_pack_segments_f32(vp_ctx* ctx, const void* const* srcs, const long long* offs, const long long* sizes, int n, float* dst,
+                         vp_stream stream);
 int vp_adam_step_f32(vp_ctx* ctx, float* param, const float* grad, float* m, float* v, long long n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, int step, float grad_scale, vp_stream stream);
 

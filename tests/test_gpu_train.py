@@ -140,7 +140,7 @@ def test_adam_matches_formula(N):
         opt.clear_grad()
         grads = [torch.randn(p.shape, generator=g) for p in ps]
         for p, gr in zip(ps, grads):
-            p.grad.copy_(gr.cuda())
+            p.grad = gr.cuda()                      # as autograd leaves it after clear_grad(): the optimiser packs the tensors itself
         opt.step()
         for i, gr in enumerate(grads):
             gg = gr.double() + 1e-3 * ref[i]

@@ -405,6 +405,21 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
     }
 }
 
+// ---------------------------------------------------------------------------------------------- gradient packing
+// dst[off_i .. off_i + n_i) = src_i (or zeros when src_i is NULL) for up to 128 segments per launch: the parameters' gradient
+// tensors, as autograd left them, into the optimiser's flat gradient buffer.  (With .grad bound to views of the flat buffer
+// autograd accumulates in place: one add_ launch per parameter, 148 per ECAPA step -- a seventh of all launches.)
+constexpr int PACK_MAX = 128;
+struct PackArgs { const float* src[PACK_MAX]; long long off[PACK_MAX]; long long n[PACK_MAX]; float* dst; };
+
+__global__ __launch_bounds__(256) void pack_segments_kernel(const PackArgs a) {
+    const int sgm = blockIdx.y;
+    const float* __restrict__ src = a.src[sgm];
+    float* __restrict__ dst = a.dst + a.off[sgm];
+    const long long n = a.n[sgm];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = src ? src[i] : 0.f;
+}
+
 // ---------------------------------------------------------------------------------------------- per-utterance pieces (ASP)
 // out[b][c] = sum_t a[b, t, c]   (gradient of a per-utterance bias; one workgroup = 64 channels of one utterance)
 __global__ __launch_bounds__(256) void utt_sums_kernel(const float* a, int lda, int T, int C, float* out) {
@@ -827,6 +842,28 @@ int vp_adam_step_f32(vp_ctx* ctx, float* param, const float* grad, float* m, flo
     hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, lr, beta1, beta2, eps,
                        weight_decay, c1, c2, grad_scale);
     VP_LAUNCH_CHECK(ctx, "adam");
+    return VP_OK;
+}
+
+int vp_pack_segments_f32(vp_ctx* ctx, const void* const* srcs, const long long* offs, const long long* sizes, int n, float* dst,
+                         vp_stream stream) {
+    if (!ctx || !srcs || !offs || !sizes || !dst || n <= 0) VP_FAIL(ctx, VP_EINVAL, "pack_segments: bad arguments");
+    for (int i0 = 0; i0 < n; i0 += PACK_MAX) {
+        PackArgs a;
+        const int cnt = n - i0 < PACK_MAX ? n - i0 : PACK_MAX;
+        long long big = 0;
+        for (int i = 0; i < cnt; ++i) {
+            if (offs[i0 + i] < 0 || sizes[i0 + i] < 0) VP_FAIL(ctx, VP_EINVAL, "pack_segments: negative offset / size");
+            a.src[i] = (const float*)srcs[i0 + i]; a.off[i] = offs[i0 + i]; a.n[i] = sizes[i0 + i];
+            if (sizes[i0 + i] > big) big = sizes[i0 + i];
+        }
+        a.dst = dst;
+        long long bx = (big + 4 * 256 - 1) / (4 * 256);
+        if (bx < 1) bx = 1;
+        if (bx > 64) bx = 64;
+        hipLaunchKernelGGL(pack_segments_kernel, dim3((unsigned)bx, cnt), dim3(256), 0, (hipStream_t)stream, a);
+        VP_LAUNCH_CHECK(ctx, "pack_segments");
+    }
     return VP_OK;
 }
 

@@ -41,7 +41,7 @@ class OverlappedReducer:
         self.opt = optimizer
         self.flat = optimizer.grad
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        self.buckets, self.bucket_of = [], {}
+        self.buckets, self.bucket_of, self.members = [], {}, []
         ends = []
         off = 0
         for p in optimizer.params:
@@ -53,32 +53,46 @@ class OverlappedReducer:
             size += p.numel()
             if size * 4 >= bucket_bytes:
                 self.buckets.append([e - p.numel(), end, len(members), 0, None])      # [begin, end, n_params, n_ready, handle]
+                self.members.append(list(members))
                 for q in members:
                     self.bucket_of[q] = len(self.buckets) - 1
                 end, size, members = e - p.numel(), 0, []
         if members:
             self.buckets.append([0, end, len(members), 0, None])
+            self.members.append(list(members))
             for q in members:
                 self.bucket_of[q] = len(self.buckets) - 1
         self.hooks = [p.register_post_accumulate_grad_hook(self._ready) for p in optimizer.params] if self.world > 1 else []
 
     def _ready(self, p):
-        b = self.buckets[self.bucket_of[p]]
+        bi = self.bucket_of[p]
+        b = self.buckets[bi]
         b[3] += 1
         if b[3] == b[2]:
+            self._pack(bi)
             b[4] = dist.all_reduce(self.flat[b[0]:b[1]], op=dist.ReduceOp.SUM, async_op=True)
 
     def finish(self):
         """Call after backward, before optimizer.step(): waits for every bucket and turns the sums into means."""
         if self.world == 1:
             return
-        for b in self.buckets:
+        for bi, b in enumerate(self.buckets):
             if b[4] is None:                      # a bucket with a parameter that received no gradient this step
+                self._pack(bi)
                 b[4] = dist.all_reduce(self.flat[b[0]:b[1]], op=dist.ReduceOp.SUM, async_op=True)
         for b in self.buckets:
             b[4].wait()
             b[3], b[4] = 0, None
         self.flat.div_(self.world)
+        if hasattr(self.opt, '_packed'):
+            self.opt._packed = True               # every bucket was gathered before its all-reduce: step() must not re-pack
+
+    def _pack(self, bi):
+        """The bucket's gradients into the flat buffer (the optimiser gathers them by kernel: optimizer/adam.py) just before its
+        all-reduce; an optimiser without pack_range keeps .grad views of the flat buffer and needs nothing."""
+        pack = getattr(self.opt, 'pack_range', None)
+        if pack is not None:
+            pack(self.members[bi])
 
     def remove(self):
         for h in self.hooks:

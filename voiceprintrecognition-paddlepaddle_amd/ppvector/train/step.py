@@ -35,6 +35,7 @@ class TrainStep:
         if self.reducer is not None:
             self.reducer.finish()
         else:
+            self.optimizer.pack_grads()
             allreduce_mean_(self.optimizer.grad)
         self.optimizer.step()
         self.optimizer.clear_grad()
@@ -90,6 +91,7 @@ class GraphedTrainStep(TrainStep):
             outputs = self.model(st['feats'])
             loss = self.criterion(outputs, st['labels'])
             loss.backward()
+            self.optimizer.pack_grads()                     # gradients -> flat buffer: part of the replayed sequence
             st['loss'] = loss.detach()
             st['acc'] = (outputs['logits'].detach().argmax(dim=1) == st['labels']).float().mean()
         self._graph = g
@@ -116,6 +118,7 @@ class GraphedTrainStep(TrainStep):
             self._static['feats'].copy_(feats)
             self._static['labels'].copy_(labels)
         self._graph.replay()
+        self.optimizer._packed = True                           # the replay gathered the gradients
         N.bump_weights_epoch()                                  # the replayed forward rewrote the BatchNorm running statistics
         if not self.skip_allreduce:
             allreduce_mean_(self.optimizer.grad, bucket_bytes=self.bucket_bytes)
