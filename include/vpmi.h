@@ -400,6 +400,10 @@ typedef struct {
     const float* lin_b;
 } vp_resnetse_weights;
 
+/* vp_pointwise_fwd -- kernel door (tests): the streaming 1x1 conv of the few-channel full-resolution stages (SEBottleneck conv1 /
+ * conv3 / downsample, models/resnet_se.py:8-45): same vp_conv1d_desc semantics as vp_conv1d_fwd for KW = 1, stride 1, bf16, bias /
+ * ReLU / BN / ReLU epilogue and the fused per-utterance column sums (psum, T_out = positions per utterance). */
+int vp_pointwise_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream);
 size_t vp_resnetse_workspace_bytes(const vp_resnetse_weights* w, int B, int T);
 int vp_resnetse_fwd(vp_ctx* ctx, const vp_resnetse_weights* w, const void* feats, int B, int T, float* emb,
                     void* ws, size_t ws_bytes, vp_stream stream);

@@ -1130,3 +1130,62 @@ def test_conv3x3_c32_kernel_vs_float64(N, B, T, F_in, stride, mode):
         assert e2.max().item() < 2e-4 * ref2.abs().max().item() + 2.0 ** -8 * ref2.abs().max().item(), e2.max().item()
     else:
         assert torch.all(y2d == 7.0)
+
+
+@pytest.mark.parametrize('K,Nn,T,relu2,psum', [(32, 128, 23840, False, True), (128, 32, 5000, True, False), (64, 64, 300, True, True),
+                                               (32, 32, 40000, False, True), (64, 128, 777, False, True)])
+def test_pointwise_kernel_vs_float64(N, K, Nn, T, relu2, psum):
+    """vp_pointwise_fwd (the streaming 1x1 conv of the 2-D backbones' full-resolution stages, resnet_se.py:8-45) against float64 over the
+    same bf16 operands: every output, and the fused per-utterance column sums in the conv GEMM's psum layout ((tile, segment, channel)
+    of 128-row tiles, values = y - bn_shift) from which the SE gate takes its mean -- utterance lengths that are not multiples of 128
+    (every tile position of the boundary), a ragged last tile, a column-offset input view."""
+    lib, ctx = N.lib(), N.ctx(0)
+    B = max(2, -(-40000 // T))
+    M = B * T
+    g = torch.Generator().manual_seed(K * 1000 + Nn + T)
+    ldx, xoff = K + 32, 16
+    xfull = _bf(torch.randn(M, ldx, generator=g, dtype=torch.float64))
+    x = xfull[:, xoff:xoff + K]
+    w = _bf(torch.randn(Nn, K, generator=g, dtype=torch.float64) / K ** 0.5)
+    f32 = lambda t: t.float().double()                                  # noqa: E731
+    bias = f32(0.1 * torch.randn(Nn, generator=g, dtype=torch.float64))
+    sc, sh = f32(torch.rand(Nn, generator=g, dtype=torch.float64) + 0.5), f32(0.3 * torch.randn(Nn, generator=g, dtype=torch.float64))
+    pre = (x @ w.t() + bias) * sc
+    y = pre + sh
+    if relu2:
+        y = torch.relu(y)
+    ref = _bf(y)
+    xd, wd = dev(xfull, torch.bfloat16), dev(w, torch.bfloat16)
+    bd, sd, hd = dev(bias, torch.float32), dev(sc, torch.float32), dev(sh, torch.float32)
+    yd = torch.full((M, Nn), 7.0, dtype=torch.bfloat16, device='cuda')
+    d = N.Conv1dDesc()
+    d.dtype_in = d.dtype_out = N.VP_BF16
+    d.B, d.T_in, d.T_out, d.Cin, d.Cout, d.KW, d.dilation, d.stride = B, T, T, K, Nn, 1, 1, 1
+    d.pad_mode = N.VP_PAD_ZERO
+    d.x, d.ldx, d.xoff, d.w, d.bias = xd.data_ptr(), ldx, xoff, wd.data_ptr(), bd.data_ptr()
+    d.bn_scale, d.bn_shift, d.act2 = sd.data_ptr(), hd.data_ptr(), N.VP_ACT_RELU if relu2 else N.VP_ACT_NONE
+    d.y, d.ldy = yd.data_ptr(), Nn
+    tiles, nseg = lib.vp_conv1d_tiles_m(B, T), lib.vp_conv1d_nseg(T)
+    ps = torch.full((tiles, nseg, Nn), float('nan'), dtype=torch.float32, device='cuda')
+    if psum:
+        d.psum = ps.data_ptr()
+    N.check(lib.vp_pointwise_fwd(ctx, C.byref(d), N.stream_ptr()), ctx)
+    torch.cuda.synchronize()
+    err = (yd.double().cpu() - ref).abs()
+    scale = ref.abs().max().item()
+    print(f'[pointwise K={K} N={Nn} T={T}] max err {err.max().item():.3e} (max |ref| {scale:.2f})')
+    assert err.max().item() < 2e-4 * scale + 2.0 ** -8 * scale
+    assert err.mean().item() < 1e-4 * scale
+    if psum:
+        # per-utterance sums of (y - shift) recovered from the tiles the way se_gate_kernel walks them
+        p = ps.double().cpu()
+        dvals = (y - sh)
+        for b in range(B):
+            t0, t1 = (b * T) // 128, ((b + 1) * T - 1) // 128
+            tot = torch.zeros(Nn, dtype=torch.float64)
+            for tm in range(t0, t1 + 1):
+                seg = b - (tm * 128) // T
+                tot += p[tm, seg]
+            want = dvals[b * T:(b + 1) * T].sum(0)
+            assert not torch.isnan(tot).any()
+            assert (tot - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item()) * T ** 0.5, (b, (tot - want).abs().max().item())

@@ -71,9 +71,24 @@ void base_desc(vp_conv1d_desc& d, const vp_tdnn_layer& L, int dt) {
     d.w = L.w; d.bias = L.bias; d.bn_scale = L.bn_scale; d.bn_shift = L.bn_shift;
 }
 
+// 1x1 convs over positions: the streaming kernel for the few-channel full-resolution stages (pointwise.hip), else the conv GEMM
+int conv1x1(vp_ctx* ctx, const vp_conv1d_desc& d, hipStream_t st) {
+    const int rc = vp_pointwise_bf16(ctx, &d, st);
+    return rc == VP_EUNSUP ? vp_conv1d_fwd(ctx, &d, st) : rc;
+}
+
 }  // namespace
 
 extern "C" {
+
+// C-ABI door of the streaming 1x1 kernel (tests; vp_resnetse_fwd calls the launcher)
+int vp_pointwise_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream) {
+    if (!ctx || !d || !d->x || !d->w || !d->y) VP_FAIL(ctx, VP_EINVAL, "pointwise: null argument");
+    const int rc = vp_pointwise_bf16(ctx, d, (hipStream_t)stream);
+    if (rc == VP_EUNSUP)
+        VP_FAIL(ctx, VP_EUNSUP, "pointwise: shape not covered (bf16 1x1 stride 1, Cin / Cout in {32, 64, 128} with Cin * Cout <= 8192, >= 32768 positions)");
+    return rc;
+}
 
 size_t vp_resnetse_workspace_bytes(const vp_resnetse_weights* w, int B, int T) {
     if (!w || B <= 0 || T <= 0 || w->n_blocks < 1 || w->n_blocks > VP_MAX_RSE_BLOCKS) return 0;
@@ -107,7 +122,7 @@ int vp_resnetse_fwd(vp_ctx* ctx, const vp_resnetse_weights* w, const void* feats
         // o1 = relu(bn1(conv1x1(x))): a GEMM over the B*t*f positions
         base_desc(d, b.conv1, dt);
         d.B = B; d.T_in = t * f; d.T_out = t * f; d.x = x; d.y = p.o1; d.act2 = VP_ACT_RELU;
-        if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+        if ((rc = conv1x1(ctx, d, st))) return rc;
         // o2 = relu(bn2(conv3x3 stride s (o1))): the stage-1 blocks (32 -> 32 channels, stride 1, full-resolution maps) run on the
         // slab kernel of the CAM++ FCM head (fcm_conv.hip), the rest on the conv GEMM's 2-D loader
         int fast = VP_EUNSUP;
@@ -123,7 +138,7 @@ int vp_resnetse_fwd(vp_ctx* ctx, const vp_resnetse_weights* w, const void* feats
         // o3 = bn3(conv1x1(o2)) with the per-utterance sums of the SE squeeze fused in
         base_desc(d, b.conv3, dt);
         d.B = B; d.T_in = to * fo; d.T_out = to * fo; d.x = p.o2; d.y = p.o3; d.psum = p.psum;
-        if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+        if ((rc = conv1x1(ctx, d, st))) return rc;
         if ((rc = vp_se_gate(ctx, p.psum, b.conv3.bn_shift, B, to * fo, C, C / 8, b.se_w1, b.se_b1, b.se_w2, b.se_b2, p.se_s, st)))
             return rc;
         const void* res = x;
@@ -131,7 +146,10 @@ int vp_resnetse_fwd(vp_ctx* ctx, const vp_resnetse_weights* w, const void* feats
             base_desc(d, b.down, dt);
             d.B = B; d.T_in = t; d.T_out = to; d.F_in = f; d.F_out = fo; d.KF = 1; d.stride = b.stride; d.stride_f = b.stride;
             d.x = x; d.y = p.res;
-            if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+            if (b.stride == 1) {           // a plain pointwise conv over the B * t * f positions
+                d.T_in = t * f; d.T_out = t * f; d.F_in = 0; d.F_out = 0; d.KF = 0; d.stride = 1; d.stride_f = 0;
+                if ((rc = conv1x1(ctx, d, st))) return rc;
+            } else if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
             res = p.res;
         }
         // x <- relu(o3 * s + residual)
