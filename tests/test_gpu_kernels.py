@@ -1133,7 +1133,7 @@ def test_conv3x3_c32_kernel_vs_float64(N, B, T, F_in, stride, mode):
 
 
 @pytest.mark.parametrize('K,Nn,T,relu2,psum', [(32, 128, 23840, False, True), (128, 32, 5000, True, False), (64, 64, 300, True, True),
-                                               (32, 32, 40000, False, True), (64, 128, 777, False, True)])
+                                               (32, 32, 40000, False, True), (64, 128, 777, False, True), (32, 64, 5960, 'res_hardtanh', False)])
 def test_pointwise_kernel_vs_float64(N, K, Nn, T, relu2, psum):
     """vp_pointwise_fwd (the streaming 1x1 conv of the 2-D backbones' full-resolution stages, resnet_se.py:8-45) against float64 over the
     same bf16 operands: every output, and the fused per-utterance column sums in the conv GEMM's psum layout ((tile, segment, channel)
@@ -1152,7 +1152,11 @@ def test_pointwise_kernel_vs_float64(N, K, Nn, T, relu2, psum):
     sc, sh = f32(torch.rand(Nn, generator=g, dtype=torch.float64) + 0.5), f32(0.3 * torch.randn(Nn, generator=g, dtype=torch.float64))
     pre = (x @ w.t() + bias) * sc
     y = pre + sh
-    if relu2:
+    res = None
+    if relu2 == 'res_hardtanh':                                         # ERes2Net's conv3: hardtanh(bn(conv) + residual, 0, 20)
+        res = _bf(torch.randn(M, Nn, generator=g, dtype=torch.float64) * 8)
+        y = torch.clamp(y + res, 0.0, 20.0)
+    elif relu2:
         y = torch.relu(y)
     ref = _bf(y)
     xd, wd = dev(xfull, torch.bfloat16), dev(w, torch.bfloat16)
@@ -1163,7 +1167,11 @@ def test_pointwise_kernel_vs_float64(N, K, Nn, T, relu2, psum):
     d.B, d.T_in, d.T_out, d.Cin, d.Cout, d.KW, d.dilation, d.stride = B, T, T, K, Nn, 1, 1, 1
     d.pad_mode = N.VP_PAD_ZERO
     d.x, d.ldx, d.xoff, d.w, d.bias = xd.data_ptr(), ldx, xoff, wd.data_ptr(), bd.data_ptr()
-    d.bn_scale, d.bn_shift, d.act2 = sd.data_ptr(), hd.data_ptr(), N.VP_ACT_RELU if relu2 else N.VP_ACT_NONE
+    d.bn_scale, d.bn_shift = sd.data_ptr(), hd.data_ptr()
+    d.act2 = N.VP_ACT_HARDTANH20 if relu2 == 'res_hardtanh' else (N.VP_ACT_RELU if relu2 else N.VP_ACT_NONE)
+    resd = dev(res, torch.bfloat16) if res is not None else None
+    if resd is not None:
+        d.res, d.ld_res = resd.data_ptr(), Nn
     d.y, d.ldy = yd.data_ptr(), Nn
     tiles, nseg = lib.vp_conv1d_tiles_m(B, T), lib.vp_conv1d_nseg(T)
     ps = torch.full((tiles, nseg, Nn), float('nan'), dtype=torch.float32, device='cuda')

@@ -94,6 +94,12 @@ void geom2d(vp_conv1d_desc& d, int B, int t, int f, int s, bool k3) {
     d.KF = k3 ? 3 : 1; d.stride = s; d.stride_f = s; d.pad_left = k3 ? 1 : 0; d.pad_f = k3 ? 1 : 0;
 }
 
+// 1x1 convs over positions: the streaming kernel for the few-channel full-resolution stages (pointwise.hip), else the conv GEMM
+int conv1x1(vp_ctx* ctx, const vp_conv1d_desc& d, hipStream_t st) {
+    const int rc = vp_pointwise_bf16(ctx, &d, st);
+    return rc == VP_EUNSUP ? vp_conv1d_fwd(ctx, &d, st) : rc;
+}
+
 // AFF (eres2net.py:33-53): out = x (1 + tanh(att)) + y (1 - tanh(att)), att = BN(conv(SiLU(BN(conv(cat(x, y))))))
 int run_aff(vp_ctx* ctx, const vp_aff_weights& A, int dt, const void* x, int ldx, int xoff, const void* y, int ldy, int yoff,
             void* out, int ldo, int ooff, long long P, int C, void* cat, void* a1, void* att, hipStream_t st) {
@@ -155,7 +161,7 @@ int vp_eres2net_fwd(vp_ctx* ctx, const vp_eres2net_weights* w, const void* feats
             if (b.stride == 1) { d.B = 1; d.T_in = (int)P; d.T_out = (int)P; }
             else geom2d(d, B, tin, fin, b.stride, false);
             d.x = x; d.y = p.o1; d.act2 = VP_ACT_HARDTANH20;
-            if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+            if ((rc = b.stride == 1 ? conv1x1(ctx, d, st) : vp_conv1d_fwd(ctx, &d, st))) return rc;
             // chunk chain: sp_i = hardtanh(bn_i(conv3x3(in_i))) into o2[:, i*wd : (i+1)*wd]
             for (int i = 0; i < b.scale; ++i) {
                 conv_desc(d, b.convs[i], dt);
@@ -182,7 +188,7 @@ int vp_eres2net_fwd(vp_ctx* ctx, const vp_eres2net_weights* w, const void* feats
                 if (b.stride == 1) { d.B = 1; d.T_in = (int)P; d.T_out = (int)P; }
                 else geom2d(d, B, tin, fin, b.stride, false);
                 d.x = x; d.y = p.res;
-                if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+                if ((rc = b.stride == 1 ? conv1x1(ctx, d, st) : vp_conv1d_fwd(ctx, &d, st))) return rc;
                 res = p.res; ld_res = Co;
             }
             // out = hardtanh(bn3(conv1x1(o2)) + residual); the last block of a stage lands in the stage buffer
@@ -190,7 +196,7 @@ int vp_eres2net_fwd(vp_ctx* ctx, const vp_eres2net_weights* w, const void* feats
             conv_desc(d, b.conv3, dt);
             d.B = 1; d.T_in = (int)P; d.T_out = (int)P; d.x = p.o2; d.y = dst;
             d.res = res; d.ld_res = ld_res; d.act2 = VP_ACT_HARDTANH20;
-            if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+            if ((rc = conv1x1(ctx, d, st))) return rc;
             x = dst;
         }
     }

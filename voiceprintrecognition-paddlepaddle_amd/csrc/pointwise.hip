@@ -18,7 +18,8 @@ constexpr int PW_ROWS = 128;               // rows per workgroup = VP_CONV_BM
 
 struct PwArgs {
     const bf16_t* x; const bf16_t* w; bf16_t* y; const float* bias; const float* scale; const float* shift; float* psum;
-    int ldx, xoff, ldy, yoff, M, T, nseg, act, act2;
+    const bf16_t* res;                         // optional residual, added before act2 (rows as y)
+    int ldx, xoff, ldy, yoff, ld_res, res_off, M, T, nseg, act, act2;
     unsigned x_bytes;
 };
 
@@ -86,17 +87,23 @@ __global__ __launch_bounds__(PW_THREADS) void pointwise_kernel(const PwArgs a) {
             const float4 ss = *reinterpret_cast<const float4*>(&par[1][c0]);
             const float4 hh = *reinterpret_cast<const float4*>(&par[2][c0]);
             const float bv[4] = {bb.x, bb.y, bb.z, bb.w}, sv[4] = {ss.x, ss.y, ss.z, ss.w}, hv[4] = {hh.x, hh.y, hh.z, hh.w};
+            float rv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.res && live) {
+                const bf16x4 rr = *reinterpret_cast<const bf16x4*>(a.res + (size_t)(m0 + row) * a.ld_res + a.res_off + c0);
+                rv[0] = (float)rr[0]; rv[1] = (float)rr[1]; rv[2] = (float)rr[2]; rv[3] = (float)rr[3];
+            }
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float t = acc[nt][r] + bv[r];
                 if (a.act == VP_ACT_RELU) t = fmaxf(t, 0.f);
                 const float pre = t * sv[r];                                       // y - shift: what the column sums carry
-                t = pre + hv[r];
+                t = pre + hv[r] + rv[r];
                 if (a.act2 == VP_ACT_RELU) t = fmaxf(t, 0.f);
+                else if (a.act2 == VP_ACT_HARDTANH20) t = fminf(fmaxf(t, 0.f), 20.f);
                 v[r] = t;
                 if (a.psum) {
-                    const float d = live ? (a.act2 == VP_ACT_RELU ? t - hv[r] : pre) : 0.f;
+                    const float d = live ? t - hv[r] : 0.f;
                     if (row < rb) s_lo[nt][r] += d; else s_hi[nt][r] += d;
                 }
             }
@@ -152,8 +159,10 @@ int vp_pointwise_bf16(vp_ctx* ctx, const vp_conv1d_desc* d, hipStream_t st) {
     if (off) return VP_EUNSUP;
     if (d->dtype_in != VP_BF16 || d->dtype_out != VP_BF16 || d->KW != 1 || d->stride != 1 || d->KF > 1 || d->F_in > 1 || d->F_out > 1)
         return VP_EUNSUP;
-    if (d->rowbias || d->res || d->aux || d->add_in || d->gate || d->pro_scale || d->ysplit || d->psumsq) return VP_EUNSUP;
-    if ((d->act != VP_ACT_NONE && d->act != VP_ACT_RELU) || (d->act2 != VP_ACT_NONE && d->act2 != VP_ACT_RELU)) return VP_EUNSUP;
+    if (d->rowbias || d->aux || d->add_in || d->gate || d->pro_scale || d->ysplit || d->psumsq) return VP_EUNSUP;
+    if ((d->act != VP_ACT_NONE && d->act != VP_ACT_RELU) ||
+        (d->act2 != VP_ACT_NONE && d->act2 != VP_ACT_RELU && d->act2 != VP_ACT_HARDTANH20)) return VP_EUNSUP;
+    if (d->res && (d->ld_res % 4 || d->res_off % 4 || (reinterpret_cast<uintptr_t>(d->res) & 7))) return VP_EUNSUP;
     const int K = d->Cin, Nn = d->Cout;
     if ((K != 32 && K != 64 && K != 128) || (Nn != 32 && Nn != 64 && Nn != 128) || K * Nn > 128 * 64) return VP_EUNSUP;   // <= 128 weight registers
     if (d->ldx % 8 || d->xoff % 8 || d->ldy % 8 || d->yoff % 8) return VP_EUNSUP;
@@ -165,6 +174,7 @@ int vp_pointwise_bf16(vp_ctx* ctx, const vp_conv1d_desc* d, hipStream_t st) {
     if (xb >= 0xffffff00ull || M > 0x7fffffffLL) return VP_EUNSUP;
     PwArgs a;
     a.x = (const bf16_t*)d->x; a.w = (const bf16_t*)d->w; a.y = (bf16_t*)d->y; a.bias = d->bias; a.scale = d->bn_scale; a.shift = d->bn_shift;
+    a.res = (const bf16_t*)d->res; a.ld_res = d->ld_res; a.res_off = d->res_off;
     a.psum = d->psum; a.ldx = d->ldx; a.xoff = d->xoff; a.ldy = d->ldy; a.yoff = d->yoff; a.M = (int)M; a.T = d->T_out;
     a.nseg = vp_conv1d_nseg(d->T_out); a.act = d->act; a.act2 = d->act2; a.x_bytes = (unsigned)xb;
     const int ks = K / 32, nt = Nn / 16;
