@@ -1133,7 +1133,8 @@ def test_conv3x3_c32_kernel_vs_float64(N, B, T, F_in, stride, mode):
 
 
 @pytest.mark.parametrize('K,Nn,T,relu2,psum', [(32, 128, 23840, False, True), (128, 32, 5000, True, False), (64, 64, 300, True, True),
-                                               (32, 32, 40000, False, True), (64, 128, 777, False, True), (32, 64, 5960, 'res_hardtanh', False)])
+                                               (32, 32, 40000, False, True), (64, 128, 777, False, True), (32, 64, 5960, 'res_hardtanh', False),
+                                               (64, 256, 5960, False, True), (256, 64, 5960, True, False), (128, 512, 1490, False, True)])
 def test_pointwise_kernel_vs_float64(N, K, Nn, T, relu2, psum):
     """vp_pointwise_fwd (the streaming 1x1 conv of the 2-D backbones' full-resolution stages, resnet_se.py:8-45) against float64 over the
     same bf16 operands: every output, and the fused per-utterance column sums in the conv GEMM's psum layout ((tile, segment, channel)

@@ -96,7 +96,7 @@ void geom2d(vp_conv1d_desc& d, int B, int t, int f, int s, bool k3) {
 
 // 1x1 convs over positions: the streaming kernel for the few-channel full-resolution stages (pointwise.hip), else the conv GEMM
 int conv1x1(vp_ctx* ctx, const vp_conv1d_desc& d, hipStream_t st) {
-    const int rc = vp_pointwise_bf16(ctx, &d, st);
+    const int rc = vp_pointwise_bf16(ctx, &d, 1, st);
     return rc == VP_EUNSUP ? vp_conv1d_fwd(ctx, &d, st) : rc;
 }
 

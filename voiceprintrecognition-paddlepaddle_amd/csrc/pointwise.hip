@@ -19,7 +19,7 @@ constexpr int PW_ROWS = 128;               // rows per workgroup = VP_CONV_BM
 struct PwArgs {
     const bf16_t* x; const bf16_t* w; bf16_t* y; const float* bias; const float* scale; const float* shift; float* psum;
     const bf16_t* res;                         // optional residual, added before act2 (rows as y)
-    int ldx, xoff, ldy, yoff, ld_res, res_off, M, T, nseg, act, act2;
+    int ldx, xoff, ldy, yoff, ld_res, res_off, M, T, nseg, act, act2, Ntot;   // Ntot: all output channels (blockIdx.y picks a chunk of N)
     unsigned x_bytes;
 };
 
@@ -34,6 +34,7 @@ __global__ __launch_bounds__(PW_THREADS) void pointwise_kernel(const PwArgs a) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.x * PW_ROWS;
+    const int n_off = blockIdx.y * N;                        // this workgroup's output-channel chunk (the input is read once per chunk)
     const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x), 0, a.x_bytes, 0x00020000);
     constexpr unsigned OOB = 0xfffffff0u;
 
@@ -48,13 +49,13 @@ __global__ __launch_bounds__(PW_THREADS) void pointwise_kernel(const PwArgs a) {
         for (int ks = 0; ks < KS; ++ks) xr[tl][ks] = __builtin_amdgcn_raw_buffer_load_b128(xsrd, base != OOB ? base + ks * 64u : OOB, 0, 0);
     }
     for (int i = tid; i < N; i += PW_THREADS) {
-        par[0][i] = a.bias ? a.bias[i] : 0.f; par[1][i] = a.scale ? a.scale[i] : 1.f; par[2][i] = a.shift ? a.shift[i] : 0.f;
+        par[0][i] = a.bias ? a.bias[n_off + i] : 0.f; par[1][i] = a.scale ? a.scale[n_off + i] : 1.f; par[2][i] = a.shift ? a.shift[n_off + i] : 0.f;
     }
     bf16x8 wf[NT][KS];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) wf[nt][ks] = *reinterpret_cast<const bf16x8*>(a.w + (size_t)(nt * 16 + li) * K + ks * 32 + g * 8);
+        for (int ks = 0; ks < KS; ++ks) wf[nt][ks] = *reinterpret_cast<const bf16x8*>(a.w + (size_t)(n_off + nt * 16 + li) * K + ks * 32 + g * 8);
 
     __syncthreads();
     // utterance boundary inside the workgroup's 128 rows (T >= 128, host-checked: at most one)
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(PW_THREADS) void pointwise_kernel(const PwArgs a) {
             const float bv[4] = {bb.x, bb.y, bb.z, bb.w}, sv[4] = {ss.x, ss.y, ss.z, ss.w}, hv[4] = {hh.x, hh.y, hh.z, hh.w};
             float rv[4] = {0.f, 0.f, 0.f, 0.f};
             if (a.res && live) {
-                const bf16x4 rr = *reinterpret_cast<const bf16x4*>(a.res + (size_t)(m0 + row) * a.ld_res + a.res_off + c0);
+                const bf16x4 rr = *reinterpret_cast<const bf16x4*>(a.res + (size_t)(m0 + row) * a.ld_res + a.res_off + n_off + c0);
                 rv[0] = (float)rr[0]; rv[1] = (float)rr[1]; rv[2] = (float)rr[2]; rv[3] = (float)rr[3];
             }
             float v[4];
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(PW_THREADS) void pointwise_kernel(const PwArgs a) {
             const int pos = i / CPP, q = i - pos * CPP;
             const int m = m0 + wv * 32 + tl * 16 + pos;
             if (m < a.M)
-                *reinterpret_cast<uint4*>(a.y + (size_t)m * a.ldy + a.yoff + q * 8) = *reinterpret_cast<const uint4*>(st + pos * SROW + q * 16);
+                *reinterpret_cast<uint4*>(a.y + (size_t)m * a.ldy + a.yoff + n_off + q * 8) = *reinterpret_cast<const uint4*>(st + pos * SROW + q * 16);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -139,21 +140,22 @@ __global__ __launch_bounds__(PW_THREADS) void pointwise_kernel(const PwArgs a) {
             const int sgi = i / N, c = i - sgi * N;
             // segment sgi exists iff some row of the tile belongs to utterance bfirst + sgi
             const bool has = sgi == 0 ? true : (rb < PW_ROWS && m0 + rb < a.M);
-            if (has) a.psum[((size_t)blockIdx.x * a.nseg + sgi) * N + c] = red[0][sgi][c] + red[1][sgi][c] + red[2][sgi][c] + red[3][sgi][c];
+            if (has) a.psum[((size_t)blockIdx.x * a.nseg + sgi) * a.Ntot + n_off + c] = red[0][sgi][c] + red[1][sgi][c] + red[2][sgi][c] + red[3][sgi][c];
         }
     }
 }
 
 template <int KS, int NT>
 void launch_pw(const PwArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL((pointwise_kernel<KS, NT>), dim3((a.M + PW_ROWS - 1) / PW_ROWS), dim3(PW_THREADS), 0, st, a);
+    hipLaunchKernelGGL((pointwise_kernel<KS, NT>), dim3((a.M + PW_ROWS - 1) / PW_ROWS, a.Ntot / (16 * NT)), dim3(PW_THREADS), 0, st, a);
 }
 
 }  // namespace
 
 // Returns VP_EUNSUP when the shape is not covered (the caller falls back to vp_conv1d_fwd).  d: a 1x1, stride-1 conv descriptor
-// (bf16 in / out); T_out = positions per utterance (psum segmentation).
-int vp_pointwise_bf16(vp_ctx* ctx, const vp_conv1d_desc* d, hipStream_t st) {
+// (bf16 in / out); T_out = positions per utterance (psum segmentation).  only_where_it_wins: the backbones' dispatch rule;
+// the test door passes 0 and reaches every shape the kernel covers.
+int vp_pointwise_bf16(vp_ctx* ctx, const vp_conv1d_desc* d, int only_where_it_wins, hipStream_t st) {
     static int off = -1;
     if (off < 0) { const char* e = getenv("VPMI_PW_GENERAL"); off = e && atoi(e) ? 1 : 0; }
     if (off) return VP_EUNSUP;
@@ -164,7 +166,16 @@ int vp_pointwise_bf16(vp_ctx* ctx, const vp_conv1d_desc* d, hipStream_t st) {
         (d->act2 != VP_ACT_NONE && d->act2 != VP_ACT_RELU && d->act2 != VP_ACT_HARDTANH20)) return VP_EUNSUP;
     if (d->res && (d->ld_res % 4 || d->res_off % 4 || (reinterpret_cast<uintptr_t>(d->res) & 7))) return VP_EUNSUP;
     const int K = d->Cin, Nn = d->Cout;
-    if ((K != 32 && K != 64 && K != 128) || (Nn != 32 && Nn != 64 && Nn != 128) || K * Nn > 128 * 64) return VP_EUNSUP;   // <= 128 weight registers
+    if (K != 32 && K != 64 && K != 128 && K != 256) return VP_EUNSUP;
+    // measured (ResNetSE / ERes2Net, B = 64): the streaming kernel beats the tiled conv GEMM for K, N <= 128 with K N <= 8192 (the
+    // full-resolution stages); with more channels the GEMM's operand reuse wins (4.23 -> 4.53 ms when everything was routed here)
+    if (only_where_it_wins && (K > 128 || Nn > 128 || K * Nn > 8192)) return VP_EUNSUP;
+    // output channels in chunks (grid.y) such that a chunk's weight fragments stay within 128 registers (64 beside the column sums)
+    int cap = (d->psum ? 8192 : 16384) / K;
+    if (cap > 128) cap = 128;
+    int Nc = cap < Nn ? cap : Nn;
+    Nc = Nc >= 128 ? 128 : (Nc >= 64 ? 64 : (Nc >= 32 ? 32 : 0));
+    if (Nc == 0 || Nn % Nc || Nn > 2048) return VP_EUNSUP;
     if (d->ldx % 8 || d->xoff % 8 || d->ldy % 8 || d->yoff % 8) return VP_EUNSUP;
     if ((reinterpret_cast<uintptr_t>(d->x) | reinterpret_cast<uintptr_t>(d->y) | reinterpret_cast<uintptr_t>(d->w)) & 15) return VP_EUNSUP;
     const long long M = (long long)d->B * d->T_out;
@@ -176,8 +187,8 @@ int vp_pointwise_bf16(vp_ctx* ctx, const vp_conv1d_desc* d, hipStream_t st) {
     a.x = (const bf16_t*)d->x; a.w = (const bf16_t*)d->w; a.y = (bf16_t*)d->y; a.bias = d->bias; a.scale = d->bn_scale; a.shift = d->bn_shift;
     a.res = (const bf16_t*)d->res; a.ld_res = d->ld_res; a.res_off = d->res_off;
     a.psum = d->psum; a.ldx = d->ldx; a.xoff = d->xoff; a.ldy = d->ldy; a.yoff = d->yoff; a.M = (int)M; a.T = d->T_out;
-    a.nseg = vp_conv1d_nseg(d->T_out); a.act = d->act; a.act2 = d->act2; a.x_bytes = (unsigned)xb;
-    const int ks = K / 32, nt = Nn / 16;
+    a.nseg = vp_conv1d_nseg(d->T_out); a.act = d->act; a.act2 = d->act2; a.x_bytes = (unsigned)xb; a.Ntot = Nn;
+    const int ks = K / 32, nt = Nc / 16;
     if (ks == 1 && nt == 2) launch_pw<1, 2>(a, st);
     else if (ks == 1 && nt == 4) launch_pw<1, 4>(a, st);
     else if (ks == 1 && nt == 8) launch_pw<1, 8>(a, st);
@@ -186,6 +197,9 @@ int vp_pointwise_bf16(vp_ctx* ctx, const vp_conv1d_desc* d, hipStream_t st) {
     else if (ks == 2 && nt == 8) launch_pw<2, 8>(a, st);
     else if (ks == 4 && nt == 2) launch_pw<4, 2>(a, st);
     else if (ks == 4 && nt == 4) launch_pw<4, 4>(a, st);
+    else if (ks == 4 && nt == 8) launch_pw<4, 8>(a, st);
+    else if (ks == 8 && nt == 2) launch_pw<8, 2>(a, st);
+    else if (ks == 8 && nt == 4) launch_pw<8, 4>(a, st);
     else return VP_EUNSUP;
     VP_LAUNCH_CHECK(ctx, "pointwise");
     return VP_OK;

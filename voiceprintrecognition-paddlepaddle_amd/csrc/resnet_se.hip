@@ -73,7 +73,7 @@ void base_desc(vp_conv1d_desc& d, const vp_tdnn_layer& L, int dt) {
 
 // 1x1 convs over positions: the streaming kernel for the few-channel full-resolution stages (pointwise.hip), else the conv GEMM
 int conv1x1(vp_ctx* ctx, const vp_conv1d_desc& d, hipStream_t st) {
-    const int rc = vp_pointwise_bf16(ctx, &d, st);
+    const int rc = vp_pointwise_bf16(ctx, &d, 1, st);
     return rc == VP_EUNSUP ? vp_conv1d_fwd(ctx, &d, st) : rc;
 }
 
@@ -84,7 +84,7 @@ extern "C" {
 // C-ABI door of the streaming 1x1 kernel (tests; vp_resnetse_fwd calls the launcher)
 int vp_pointwise_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream) {
     if (!ctx || !d || !d->x || !d->w || !d->y) VP_FAIL(ctx, VP_EINVAL, "pointwise: null argument");
-    const int rc = vp_pointwise_bf16(ctx, d, (hipStream_t)stream);
+    const int rc = vp_pointwise_bf16(ctx, d, 0, (hipStream_t)stream);
     if (rc == VP_EUNSUP)
         VP_FAIL(ctx, VP_EUNSUP, "pointwise: shape not covered (bf16 1x1 stride 1, Cin / Cout in {32, 64, 128} with Cin * Cout <= 8192, >= 32768 positions)");
     return rc;
