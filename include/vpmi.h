@@ -332,6 +332,10 @@ typedef struct {
  *   (B, T, F_in) bf16 features, produced inside the kernel (x is not read). */
 int vp_cam_block_fwd(vp_ctx* ctx, const vp_cam_layer* layers, int n_layers, void* cat, int ld, int ch0, int B, int Tn, int seg_len,
                      int bn_channels, int growth, vp_stream stream);
+/* vp_resblock_c32_fwd: a whole stride-1 BasicResBlock with the identity shortcut (models/campplus.py:211-243) over a (B, T, F, 32) bf16
+ * map in one launch: y = relu(bn2(conv2(relu(bn1(conv1(x))))) + x); h never leaves the chip.  x and y must not alias. */
+int vp_resblock_c32_fwd(vp_ctx* ctx, const void* x, void* y, const vp_tdnn_layer* conv1, const vp_tdnn_layer* conv2, int B, int T, int F,
+                        vp_stream stream);
 int vp_conv3x3_c32_fwd(vp_ctx* ctx, const void* x, void* y, const vp_tdnn_layer* conv, const void* res, int relu,
                        const vp_tdnn_layer* shortcut, void* y2, int B, int T, int F_in, int stride_f, const void* c1_feats,
                        const float* c1_w, const float* c1_b, const float* c1_scale, const float* c1_shift, vp_stream stream);

@@ -1198,3 +1198,41 @@ def test_pointwise_kernel_vs_float64(N, K, Nn, T, relu2, psum):
             want = dvals[b * T:(b + 1) * T].sum(0)
             assert not torch.isnan(tot).any()
             assert (tot - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item()) * T ** 0.5, (b, (tot - want).abs().max().item())
+
+
+@pytest.mark.parametrize('B,T,F_in', [(2, 37, 40), (3, 50, 20), (1, 298, 10), (2, 5, 11)])
+def test_resblock_c32_kernel_vs_float64(N, B, T, F_in):
+    """vp_resblock_c32_fwd (a stride-1 BasicResBlock of the FCM head in one launch, campplus.py:211-243) against float64 over the same
+    bf16 operands, h rounded to bf16 as the two-launch path stores it: every position incl. the map's border rows / columns, more
+    time rows than one workgroup's slab (the two-row halo across slabs), an odd F."""
+    lib, ctx = N.lib(), N.ctx(0)
+    Cc = 32
+    g = torch.Generator().manual_seed(T * 10 + F_in)
+    f32 = lambda t: t.float().double()                                  # noqa: E731
+    x = _bf(torch.randn(B, T, F_in, Cc, generator=g, dtype=torch.float64))
+    keep, Ls, ws = [], [], []
+    for _ in range(2):
+        w = _bf(torch.randn(Cc, Cc, 3, 3, generator=g, dtype=torch.float64) / (9 * Cc) ** 0.5)
+        bias = f32(0.1 * torch.randn(Cc, generator=g, dtype=torch.float64))
+        sc, sh = f32(torch.rand(Cc, generator=g, dtype=torch.float64) + 0.5), f32(0.2 * torch.randn(Cc, generator=g, dtype=torch.float64))
+        ws.append((w, bias, sc, sh))
+        L = N.TdnnLayer()
+        wd = dev(w.permute(0, 2, 3, 1).reshape(Cc, 9 * Cc), torch.bfloat16)
+        bd, sd, hd = dev(bias, torch.float32), dev(sc, torch.float32), dev(sh, torch.float32)
+        keep += [wd, bd, sd, hd]
+        L.w, L.bias, L.bn_scale, L.bn_shift, L.cin, L.cout, L.kw, L.dil = wd.data_ptr(), bd.data_ptr(), sd.data_ptr(), hd.data_ptr(), Cc, Cc, 9, 1
+        Ls.append(L)
+    xc = x.permute(0, 3, 1, 2)
+    (w1, b1, s1, h1), (w2, b2, s2, h2) = ws
+    h = _bf(torch.relu(F.conv2d(xc, w1, b1, padding=1) * s1[None, :, None, None] + h1[None, :, None, None]))
+    ref = _bf(torch.relu(F.conv2d(h, w2, b2, padding=1) * s2[None, :, None, None] + h2[None, :, None, None] + xc)).permute(0, 2, 3, 1)
+    xd = dev(x, torch.bfloat16)
+    yd = torch.full((B, T, F_in, Cc), 7.0, dtype=torch.bfloat16, device='cuda')
+    N.check(lib.vp_resblock_c32_fwd(ctx, xd.data_ptr(), yd.data_ptr(), C.byref(Ls[0]), C.byref(Ls[1]), B, T, F_in, N.stream_ptr()), ctx)
+    torch.cuda.synchronize()
+    err = (yd.double().cpu() - ref).abs()
+    scale = ref.abs().max().item()
+    print(f'[resblock_c32 B={B} T={T} F={F_in}] max err {err.max().item():.3e} (max |ref| {scale:.2f}), mean {err.mean().item():.2e}')
+    # a bf16 rounding of h can flip (f32 vs float64 accumulation) and feeds nine taps of conv2
+    assert err.max().item() < 2.0 ** -6 * scale, err.max().item()
+    assert err.mean().item() < 3e-4 * scale

@@ -305,6 +305,14 @@ int vp_cam_block_fwd(vp_ctx* ctx, const vp_cam_layer* layers, int n_layers, void
     return rc;
 }
 
+int vp_resblock_c32_fwd(vp_ctx* ctx, const void* x, void* y, const vp_tdnn_layer* conv1, const vp_tdnn_layer* conv2, int B, int T, int F,
+                        vp_stream stream) {
+    if (!ctx || !x || !y || !conv1 || !conv2 || B <= 0 || T <= 0 || F <= 0) VP_FAIL(ctx, VP_EINVAL, "resblock_c32: bad arguments");
+    const int rc = vp_resblock_c32_bf16(ctx, x, y, conv1, conv2, B, T, F, (hipStream_t)stream);
+    if (rc == VP_EUNSUP) VP_FAIL(ctx, VP_EUNSUP, "resblock_c32: shape not covered (32 channels, 3x3, stride 1, distinct 16-byte aligned buffers)");
+    return rc;
+}
+
 int vp_conv3x3_c32_fwd(vp_ctx* ctx, const void* x, void* y, const vp_tdnn_layer* conv, const void* res, int relu,
                        const vp_tdnn_layer* shortcut, void* y2, int B, int T, int F_in, int stride_f, const void* c1_feats,
                        const float* c1_w, const float* c1_b, const float* c1_scale, const float* c1_shift, vp_stream stream) {
@@ -358,6 +366,15 @@ int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats
     for (int i = 0; i < 4; ++i) {
         const vp_resblock& R = w->res[i];
         const int Fo = R.stride == 2 ? (F - 1) / 2 + 1 : F;
+        // a stride-1 block with the identity shortcut: both convs and the residual in one launch (h stays in LDS)
+        if (dt == VP_BF16 && !R.has_shortcut && R.stride == 1) {
+            const int fr = vp_resblock_c32_bf16(ctx, cur, t2, &R.conv1, &R.conv2, B, T, F, st);
+            if (fr != VP_OK && fr != VP_EUNSUP) return fr;
+            if (fr == VP_OK) {
+                void* tmp = cur; cur = t2; t2 = tmp;
+                continue;
+            }
+        }
         // h = relu(bn1(conv1(x))) [+ the stride-2 block's shortcut bn(conv1x1(x)) from the same input slab]
         const void* sc = cur;
         int fast = VP_EUNSUP;

@@ -130,6 +130,8 @@ int vp_row_inv_norm(vp_ctx* ctx, const float* x, int rows, int D, int ld, float 
 int vp_conv3x3_c32_bf16(vp_ctx* ctx, const void* x, void* y, const vp_tdnn_layer* conv, const void* res, int relu,
                         const vp_tdnn_layer* shortcut, void* y2, int B, int T, int F_in, int stride_f, const void* c1_feats,
                         const float* c1_w, const float* c1_b, const float* c1_scale, const float* c1_shift, hipStream_t st);
+int vp_resblock_c32_bf16(vp_ctx* ctx, const void* x, void* y, const vp_tdnn_layer* conv1, const vp_tdnn_layer* conv2, int B, int T, int F,
+                         hipStream_t st);
 int vp_pointwise_bf16(vp_ctx* ctx, const vp_conv1d_desc* d, int only_where_it_wins, hipStream_t st);
 int vp_cam_block_bf16(vp_ctx* ctx, const vp_cam_layer* layers, int n_layers, void* cat, int ld, int ch0, int B, int Tn, int seg_len,
                       int bn_channels, int growth, hipStream_t st);

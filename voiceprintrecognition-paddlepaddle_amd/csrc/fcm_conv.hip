@@ -244,6 +244,160 @@ __global__ __launch_bounds__(C32_THREADS) void conv3x3_c32_kernel(const C32Args 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// A whole stride-1 BasicResBlock (campplus.py:211-243 with the identity shortcut): out = relu(bn2(conv2(relu(bn1(conv1(x))))) + x).
+// As two launches the block moves x in, h out, h in, x in again, out: 975 MB at B = 256 on the F = 40 maps.  Here the
+// workgroup's x slab carries a two-row halo, h = relu(bn1(conv1(x))) for TT + 2 rows goes into a second LDS slab (bf16, as the
+// two-launch path stores it; rows outside the utterance are ZERO -- conv2 pads h, not x) and conv2 reads it from there; the
+// residual is the centre of the x slab.  390 MB instead of 975.
+struct RB32Args {
+    const bf16_t* x; bf16_t* y;
+    const bf16_t* w1; const float* b1; const float* s1; const float* h1;
+    const bf16_t* w2; const float* b2; const float* s2; const float* h2;
+    int B, T, F, TT;
+};
+
+__global__ __launch_bounds__(C32_THREADS) void resblock_c32_kernel(const RB32Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y, t0 = blockIdx.x * a.TT;
+    const int Fp = a.F + 2;
+    const int xrows = a.TT + 4, mrows = a.TT + 2;
+    char* xslab = smem;                                           // rows t0 - 2 .. t0 + TT + 1
+    char* mslab = smem + (size_t)xrows * Fp * 64;                 // rows t0 - 1 .. t0 + TT
+    char* stage = mslab + (size_t)mrows * Fp * 64 + wv * (16 * C32_SROW);
+
+    // ---- x slab (branch-free: out-of-range offsets read zeros), pad columns of both slabs
+    {
+        const int per_row = a.F * 4;
+        const int total = xrows * per_row;
+        const float inv_row = 1.f / (float)per_row;
+        const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x + (size_t)b * a.T * a.F * C32), 0,
+                                                                             (unsigned)(a.T * a.F * 64), 0x00020000);
+        const int src0 = (t0 - 2) * a.F * 64;
+        for (int i0 = tid; i0 < total; i0 += 8 * C32_THREADS) {
+            u32x4_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + k * C32_THREADS;
+                v[k] = __builtin_amdgcn_raw_buffer_load_b128(xsrd, i < total ? (unsigned)(src0 + i * 16) : 0xfffffff0u, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + k * C32_THREADS;
+                const int r = (int)(((float)i + 0.5f) * inv_row);
+                if (i < total) *reinterpret_cast<u32x4_t*>(xslab + (size_t)i * 16 + 64 + 128 * r) = v[k];
+            }
+        }
+        for (int i = tid; i < (xrows + mrows) * 8; i += C32_THREADS) {
+            const int r = i >> 3, q = i & 7;
+            const int col = (q >> 2) ? Fp - 1 : 0;
+            char* base = r < xrows ? xslab + (size_t)r * Fp * 64 : mslab + (size_t)(r - xrows) * Fp * 64;
+            *reinterpret_cast<uint4*>(base + col * 64 + (q & 3) * 16) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    bf16x8 wf[2][9];
+    auto load_w = [&](const bf16_t* w) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) wf[nt][tap] = *reinterpret_cast<const bf16x8*>(w + (size_t)(nt * 16 + li) * 288 + tap * 32 + g * 8);
+    };
+    auto params = [&](const float* bb, const float* ss, const float* hh, float (&bs)[2][4], float (&sc)[2][4], float (&sh)[2][4]) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = nt * 16 + g * 4 + r;
+                bs[nt][r] = bb ? bb[c] : 0.f; sc[nt][r] = ss ? ss[c] : 1.f; sh[nt][r] = hh ? hh[c] : 0.f;
+            }
+    };
+    float bs[2][4], sc[2][4], sh[2][4];
+    load_w(a.w1);
+    params(a.b1, a.s1, a.h1, bs, sc, sh);
+    __syncthreads();
+
+    // ---- phase 1: h over rows t0 - 1 .. t0 + TT into the mid slab
+    {
+        const int npos = mrows * a.F;
+        const int ntile = (npos + 15) >> 4;
+        for (int tile = wv; tile < ntile; tile += C32_THREADS / 64) {
+            const int p = tile * 16 + li;
+            const int pc = min(p, npos - 1);
+            const int r1 = pc / a.F, f = pc - r1 * a.F;
+            const char* base = xslab + ((size_t)r1 * Fp + f) * 64 + g * 16;
+            f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+            bf16x8 xf[9];
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+                for (int kf = 0; kf < 3; ++kf) xf[kt * 3 + kf] = *reinterpret_cast<const bf16x8*>(base + (kt * Fp + kf) * 64);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][tap], xf[tap], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][tap], xf[tap], acc1, 0, 0, 0);
+            }
+            const int t = t0 - 1 + r1;
+            const bool live = p < npos && t >= 0 && t < a.T;
+            if (p < npos) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const f32x4& ac = nt ? acc1 : acc0;
+                    bf16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(live ? fmaxf((ac[r] + bs[nt][r]) * sc[nt][r] + sh[nt][r], 0.f) : 0.f);
+                    *reinterpret_cast<bf16x4*>(mslab + ((size_t)r1 * Fp + f + 1) * 64 + (nt * 16 + g * 4) * 2) = o;
+                }
+            }
+        }
+    }
+    load_w(a.w2);
+    params(a.b2, a.s2, a.h2, bs, sc, sh);
+    __syncthreads();
+
+    // ---- phase 2: out = relu(bn2(conv2(h)) + x)
+    const int npos = a.TT * a.F;
+    const int ntile = (npos + 15) >> 4;
+    const size_t out0 = ((size_t)b * a.T + t0) * a.F;
+    const int tvalid = min(a.TT, a.T - t0) * a.F;
+    for (int tile = wv; tile < ntile; tile += C32_THREADS / 64) {
+        const int p = tile * 16 + li;
+        const int pc = min(p, npos - 1);
+        const int tt = pc / a.F, fo = pc - tt * a.F;
+        const char* base = mslab + ((size_t)tt * Fp + fo) * 64 + g * 16;
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        bf16x8 xf[9];
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int kf = 0; kf < 3; ++kf) xf[kt * 3 + kf] = *reinterpret_cast<const bf16x8*>(base + (kt * Fp + kf) * 64);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][tap], xf[tap], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][tap], xf[tap], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const f32x4& ac = nt ? acc1 : acc0;
+            const bf16x4 rv = *reinterpret_cast<const bf16x4*>(xslab + ((size_t)(tt + 2) * Fp + fo + 1) * 64 + (nt * 16 + g * 4) * 2);
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)fmaxf((ac[r] + bs[nt][r]) * sc[nt][r] + sh[nt][r] + (float)rv[r], 0.f);
+            *reinterpret_cast<bf16x4*>(stage + li * C32_SROW + (nt * 16 + g * 4) * 2) = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int pos = lane >> 2, q = lane & 3;
+            const int pp = tile * 16 + pos;
+            if (pp < tvalid) *reinterpret_cast<uint4*>(a.y + (out0 + pp) * C32 + q * 8) = *reinterpret_cast<const uint4*>(stage + pos * C32_SROW + q * 16);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace
 
 // y = [relu]( bn(conv3x3(x) + bias) [+ res] ), optionally y2 = bn2(conv1x1_stride(x) + bias2) (stride_f == 2 only).
@@ -289,5 +443,37 @@ int vp_conv3x3_c32_bf16(vp_ctx* ctx, const void* x, void* y, const vp_tdnn_layer
     else if (stride_f == 1) hipLaunchKernelGGL((conv3x3_c32_kernel<1, false>), grid, dim3(C32_THREADS), smem, st, a);
     else hipLaunchKernelGGL((conv3x3_c32_kernel<2, false>), grid, dim3(C32_THREADS), smem, st, a);
     VP_LAUNCH_CHECK(ctx, "conv3x3_c32");
+    return VP_OK;
+}
+
+// out = relu(bn2(conv2(relu(bn1(conv1(x))))) + x): a stride-1 BasicResBlock with the identity shortcut in one launch.
+// VP_EUNSUP when the shape is not covered (the caller runs the two convs).
+int vp_resblock_c32_bf16(vp_ctx* ctx, const void* x, void* y, const vp_tdnn_layer* conv1, const vp_tdnn_layer* conv2, int B, int T, int F,
+                         hipStream_t st) {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("VPMI_FCM_UNFUSED"); off = e && atoi(e) ? 1 : 0; }
+    if (off) return VP_EUNSUP;
+    if (!x || !y || !conv1 || !conv2 || conv1->cin != C32 || conv1->cout != C32 || conv1->kw != 9 || conv2->cin != C32 || conv2->cout != C32 ||
+        conv2->kw != 9 || F < 2 || B > 65535 || x == y)
+        return VP_EUNSUP;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return VP_EUNSUP;
+    const int Fp = F + 2;
+    int TT = ((64 * 1024) / (Fp * 64) - 6) / 2;            // x slab (TT + 4 rows) + h slab (TT + 2 rows) <= 64 KB: two workgroups per CU
+    if (TT > T) TT = T;
+    if (TT < 2) return VP_EUNSUP;
+    const size_t smem = (size_t)(2 * TT + 6) * Fp * 64 + (size_t)(C32_THREADS / 64) * 16 * C32_SROW;
+    if (smem > 72 * 1024) return VP_EUNSUP;
+    RB32Args a;
+    a.x = (const bf16_t*)x; a.y = (bf16_t*)y;
+    a.w1 = (const bf16_t*)conv1->w; a.b1 = conv1->bias; a.s1 = conv1->bn_scale; a.h1 = conv1->bn_shift;
+    a.w2 = (const bf16_t*)conv2->w; a.b2 = conv2->bias; a.s2 = conv2->bn_scale; a.h2 = conv2->bn_shift;
+    a.B = B; a.T = T; a.F = F; a.TT = TT;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_c32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(resblock_c32_kernel, dim3((T + TT - 1) / TT, B), dim3(C32_THREADS), smem, st, a);
+    VP_LAUNCH_CHECK(ctx, "resblock_c32");
     return VP_OK;
 }

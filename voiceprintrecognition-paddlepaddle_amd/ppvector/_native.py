@@ -248,6 +248,7 @@ _PROTOS = {
                                      c_size_t, c_void_p]),
     'vp_conv256_select': (c_int, [c_int]),
     'vp_cam_block_fwd': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'vp_resblock_c32_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'vp_conv3x3_c32_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'vp_pointwise_fwd': (c_int, [c_void_p, C.POINTER(Conv1dDesc), c_void_p]),
