@@ -98,6 +98,17 @@ def _overlap_worker(rank, world, port, q):
     ((net(x[idx]) - y[idx]) ** 2).sum().div(len(idx)).backward()       # rank-local mean; equal shards -> mean of means = global mean
     red.finish()
     err = max((p.grad - r.grad).abs().max().item() for p, r in zip(net.parameters(), full.parameters()))
+    # second step as the trainer runs it: clear_grad() drops the .grad tensors, autograd hands over fresh ones, every bucket is
+    # PACKED into the flat buffer just before its all-reduce, and the averaged gradients sit in the flat buffer only
+    opt.clear_grad()
+    assert all(p.grad is None for p in net.parameters())
+    ((net(x[idx]) - y[idx]) ** 2).sum().div(len(idx)).backward()
+    assert all(p.grad.data_ptr() != opt.grad.data_ptr() + 4 * opt._offset(p) for p in net.parameters())
+    red.finish()
+    assert opt._packed
+    for p, r in zip(net.parameters(), full.parameters()):
+        o = opt._offset(p)
+        err = max(err, (opt.grad[o:o + p.numel()].view_as(r.grad) - r.grad).abs().max().item())
     q.put((rank, len(red.buckets), err))
     dist.barrier()
     dist.destroy_process_group()

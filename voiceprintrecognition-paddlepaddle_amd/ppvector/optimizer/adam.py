@@ -53,6 +53,11 @@ class Adam:
         if not todo:
             return
         keep = [None if p.grad is None else p.grad.contiguous().float() for p in todo]
+        if not self.grad.is_cuda:                  # host tensors (the CPU tests of the data-parallel plumbing): plain copies
+            for p, g in zip(todo, keep):
+                o = self._offset(p)
+                self.grad[o:o + p.numel()] = 0.0 if g is None else g.reshape(-1)
+            return
         n = len(todo)
         srcs = (C.c_void_p * n)(*[None if g is None else g.data_ptr() for g in keep])
         offs = (C.c_longlong * n)(*[self._offset(p) for p in todo])
