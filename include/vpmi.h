@@ -542,6 +542,12 @@ int vp_affine_rows_f32(vp_ctx* ctx, const float* z, int ldz, const float* scale,
 int vp_bn_relu_bwd_f32(vp_ctx* ctx, const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* invstd,
                        const float* gamma, const float* sums, long long M, int C, int relu_mask, float* dz, int lddz,
                        vp_stream stream);
+/* vp_bn_relu_bwd_dbias_f32: the same dz plus dbias[c] = sum_m dz[m][c] from the pass that writes dz -- the bias gradient of the
+ * conv in front of the ReLU (utils.py:122-148: conv(+bias) -> ReLU -> BN) without a second read of dz. */
+size_t vp_bn_relu_bwd_dbias_workspace_bytes(long long M, int C);
+int vp_bn_relu_bwd_dbias_f32(vp_ctx* ctx, const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* invstd,
+                             const float* gamma, const float* sums, long long M, int C, int relu_mask, float* dz, int lddz,
+                             float* dbias, void* ws, size_t ws_bytes, vp_stream stream);
 /* vp_pack_segments_f32: dst[offs[i] .. offs[i] + sizes[i]) = srcs[i] (zeros where srcs[i] is NULL), HOST arrays of n entries -- the
  * parameters' gradient tensors into the optimiser's flat buffer in one or two launches (what fleet's fused gradient buffers do for
  * the reference's DataParallel; trainer.py:213-229 only sees loss.backward() / optimizer.step()). */

@@ -704,3 +704,57 @@ def test_graphed_train_step_equals_the_eager_step(N):
     for k in se:
         d = (se[k].double() - sg[k].double()).abs().max().item()
         assert d <= 1e-5 * max(1.0, se[k].abs().max().item()), (k, d)
+
+
+@pytest.mark.parametrize('M,C,two', [(76288, 512, True), (5000, 64, True), (777, 128, False), (1234, 1536, True), (256, 192, True),
+                                      (999, 6, True), (19, 64, True)])
+def test_col_sums_kernel_vs_float64(N, M, C, two):
+    """vp_col_sums_f32 (four-channels-per-lane kernel; C = 6 takes the scalar one): both BatchNorm-backward reductions."""
+    from ppvector.train.functions import col_sums
+    g = torch.Generator().manual_seed(M + C)
+    a = torch.randn(M, C, generator=g)
+    b = torch.randn(M, C, generator=g) * 2 + 0.5
+    mu, sc = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    if two:
+        got = col_sums(a.cuda(), b.cuda(), mu.cuda(), sc.cuda())
+        want1 = (a.double() * (b.double() - mu.double()) * sc.double()).sum(0)
+        assert (got[1].double().cpu() - want1).abs().max().item() <= 2e-6 * (a.abs() * (b - mu).abs() * sc).double().sum(0).max().item()
+    else:
+        got = col_sums(a.cuda())
+    want0 = a.double().sum(0)
+    assert (got[0].double().cpu() - want0).abs().max().item() <= 2e-6 * a.abs().double().sum(0).max().item()
+
+
+@pytest.mark.parametrize('M,C,relu,gamma', [(76288, 512, 1, True), (4097, 64, 1, True), (300, 128, 0, True), (1000, 1536, 1, False),
+                                            (23, 192, 1, True)])
+def test_bn_relu_bwd_dbias_kernel_vs_float64(N, M, C, relu, gamma):
+    """vp_bn_relu_bwd_dbias_f32: dz through BatchNorm (batch statistics) and the ReLU mask, and its column sums, against the
+    float64 formula, and against the unfused kernel."""
+    lib, ctx = N.lib(), N.ctx(0)
+    g = torch.Generator().manual_seed(M * 7 + C)
+    dy, z = torch.randn(M, C, generator=g), torch.randn(M, C, generator=g)
+    mean, invstd = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    gam = torch.randn(C, generator=g) if gamma else None
+    zh = (z.double() - mean.double()) * invstd.double()
+    sums = torch.stack([dy.double().sum(0), (dy.double() * zh).sum(0)]).float()
+    want = (gam.double() if gamma else 1.0) * invstd.double() * (dy.double() - sums[0].double() / M - zh * sums[1].double() / M)
+    if relu:
+        want = want * (z > 0)
+    dyc, zc, mc, ic, sc = dy.cuda(), z.cuda(), mean.cuda(), invstd.cuda(), sums.cuda()
+    gc = gam.cuda() if gamma else None
+    dz, dz0 = torch.empty_like(dyc), torch.empty_like(dyc)
+    db = torch.empty(C, device='cuda')
+    ws = torch.empty(lib.vp_bn_relu_bwd_dbias_workspace_bytes(M, C), dtype=torch.uint8, device='cuda')
+    rc = lib.vp_bn_relu_bwd_dbias_f32(ctx, dyc.data_ptr(), C, zc.data_ptr(), C, mc.data_ptr(), ic.data_ptr(),
+                                      gc.data_ptr() if gamma else None, sc.data_ptr(), M, C, relu, dz.data_ptr(), C, db.data_ptr(),
+                                      ws.data_ptr(), ws.numel(), N.stream_ptr())
+    N.check(rc, ctx)
+    rc = lib.vp_bn_relu_bwd_f32(ctx, dyc.data_ptr(), C, zc.data_ptr(), C, mc.data_ptr(), ic.data_ptr(), gc.data_ptr() if gamma else None,
+                                sc.data_ptr(), M, C, relu, dz0.data_ptr(), C, N.stream_ptr())
+    N.check(rc, ctx)
+    torch.cuda.synchronize()
+    assert rel(dz, want) < 2e-6
+    assert rel(dz, dz0) < 1e-6                 # the two kernels contract their multiply-adds differently: not bit-equal
+    assert torch.equal(dz == 0, dz0 == 0)      # ... but the ReLU mask is the same
+    wdb = want.sum(0)
+    assert (db.double().cpu() - wdb).abs().max().item() <= 2e-6 * want.abs().sum(0).max().item()

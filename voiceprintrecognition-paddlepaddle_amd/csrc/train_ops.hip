@@ -303,6 +303,62 @@ __global__ __launch_bounds__(256) void col_sums_kernel(ColSumArgs p) {
     }
 }
 
+// Four channels per lane (C and the row pitches multiples of 4, 16-byte aligned bases): a wave-instruction moves 1 KB of a row
+// instead of 256 B, and four rows' loads are issued before the first add.  Workgroup = CL column lanes x (256 / CL) row groups
+// over rows_per_chunk rows; CL = 64 / 32 / 16 by width so that 64-channel tensors (the Res2 convs) still fill the lanes.
+struct ColSum4Args { const float* a; const float* b; const float* bmean; const float* bscale; float* part; int lda, ldb, M, C4, rows_per_chunk, cl_shift; };
+
+template <bool HASB>
+__global__ __launch_bounds__(256) void col_sums4_kernel(ColSum4Args p) {
+    __shared__ float sm[2][256][4];
+    const int CL = 1 << p.cl_shift, RG = 256 >> p.cl_shift;
+    const int lc = threadIdx.x & (CL - 1), rg = threadIdx.x >> p.cl_shift;
+    const int c4 = blockIdx.x * CL + lc, c = c4 * 4;
+    const int m0 = blockIdx.y * p.rows_per_chunk, m1 = min(p.M, m0 + p.rows_per_chunk);
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c4 < p.C4) {
+        float mu[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (HASB) { vp_load4(p.bmean + c, mu); vp_load4(p.bscale + c, sc); }
+        int m = m0 + rg;
+        for (; m + 3 * RG < m1; m += 4 * RG) {
+            float av[4][4], bv[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                vp_load4(p.a + (size_t)(m + u * RG) * p.lda + c, av[u]);
+                if (HASB) vp_load4(p.b + (size_t)(m + u * RG) * p.ldb + c, bv[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s1[e] += av[u][e];
+                    if (HASB) s2[e] += av[u][e] * (bv[u][e] - mu[e]) * sc[e];
+                }
+        }
+        for (; m < m1; m += RG) {
+            float av[4], bv[4];
+            vp_load4(p.a + (size_t)m * p.lda + c, av);
+            if (HASB) vp_load4(p.b + (size_t)m * p.ldb + c, bv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s1[e] += av[e];
+                if (HASB) s2[e] += av[e] * (bv[e] - mu[e]) * sc[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sm[0][threadIdx.x][e] = s1[e]; sm[1][threadIdx.x][e] = s2[e]; }
+    __syncthreads();
+    if (rg == 0 && c4 < p.C4) {
+        float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < RG; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { t1[e] += sm[0][r * CL + lc][e]; t2[e] += sm[1][r * CL + lc][e]; }
+        float* o = p.part + (size_t)blockIdx.y * 8 * p.C4;
+        vp_store4(o + c, t1); vp_store4(o + 4 * p.C4 + c, t2);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- BatchNorm, batch statistics
 // from the producing conv's fused sums: mean / biased variance over all M rows, the folded affine for the apply pass,
 // the saved mean / inverse std for backward, and the running statistics (Paddle: running = mom * running + (1 - mom) * batch).
@@ -387,6 +443,62 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdArgs a) {
             o[e] = (a.relu_mask && !(z[e] > 0.f)) ? 0.f : v;
         }
         vp_store4(a.dz + m * a.lddz + c, o);
+    }
+}
+
+// The same dz, laid out like col_sums4_kernel so that a lane keeps its four channels: the column sums of dz (the bias gradient of
+// the conv in front of the ReLU) come out of the pass that writes dz instead of a second read of it.  part[chunk][C].
+struct BnBwdSumArgs { BnBwdArgs b; float* part; int M, rows_per_chunk, cl_shift; };
+
+__global__ __launch_bounds__(256) void bn_relu_bwd_dbias_kernel(BnBwdSumArgs p) {
+    __shared__ float sm[256][4];
+    const BnBwdArgs& a = p.b;
+    const int CL = 1 << p.cl_shift, RG = 256 >> p.cl_shift;
+    const int lc = threadIdx.x & (CL - 1), rg = threadIdx.x >> p.cl_shift;
+    const int c4 = blockIdx.x * CL + lc, c = c4 * 4, C = a.C4 * 4;
+    const int m0 = blockIdx.y * p.rows_per_chunk, m1 = min(p.M, m0 + p.rows_per_chunk);
+    const float invM = 1.f / (float)a.M;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c4 < a.C4) {
+        float mu[4], is[4], g[4], s1[4], s2[4];
+        vp_load4(a.mean + c, mu); vp_load4(a.invstd + c, is); vp_load4(a.sums + c, s1); vp_load4(a.sums + C + c, s2);
+        if (a.gamma) vp_load4(a.gamma + c, g); else { g[0] = g[1] = g[2] = g[3] = 1.f; }
+        auto one = [&](const float* dy, const float* z, float* o) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float zh = (z[e] - mu[e]) * is[e];
+                const float v = g[e] * is[e] * (dy[e] - s1[e] * invM - zh * s2[e] * invM);
+                o[e] = (a.relu_mask && !(z[e] > 0.f)) ? 0.f : v;
+                acc[e] += o[e];
+            }
+        };
+        int m = m0 + rg;
+        for (; m + 3 * RG < m1; m += 4 * RG) {
+            float dy[4][4], z[4][4], o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                vp_load4(a.dy + (size_t)(m + u * RG) * a.lddy + c, dy[u]);
+                vp_load4(a.z + (size_t)(m + u * RG) * a.ldz + c, z[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { one(dy[u], z[u], o); vp_store4(a.dz + (size_t)(m + u * RG) * a.lddz + c, o); }
+        }
+        for (; m < m1; m += RG) {
+            float dy[4], z[4], o[4];
+            vp_load4(a.dy + (size_t)m * a.lddy + c, dy); vp_load4(a.z + (size_t)m * a.ldz + c, z);
+            one(dy, z, o);
+            vp_store4(a.dz + (size_t)m * a.lddz + c, o);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sm[threadIdx.x][e] = acc[e];
+    __syncthreads();
+    if (rg == 0 && c4 < a.C4) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < RG; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] += sm[r * CL + lc][e];
+        vp_store4(p.part + (size_t)blockIdx.y * C + c, t);
     }
 }
 
@@ -781,10 +893,23 @@ int vp_conv1d_wgrad_f32(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, i
     return VP_OK;
 }
 
+// rows per chunk / chunks / lane split of the four-channels-per-lane kernels: ~2048 workgroups, at most 1024 chunks
+static void colsum4_geometry(long long M, int C4, int& cl_shift, int& colblocks, int& rpc, int& chunks) {
+    cl_shift = C4 >= 64 ? 6 : (C4 >= 32 ? 5 : 4);
+    const int CL = 1 << cl_shift, RG = 256 >> cl_shift;
+    colblocks = (C4 + CL - 1) / CL;
+    long long ch = 2048 / colblocks;
+    if (ch < 1) ch = 1;
+    if (ch > 1024) ch = 1024;
+    long long r = (M + ch - 1) / ch;
+    if (r < 4 * RG) r = 4 * RG;
+    rpc = (int)r;
+    chunks = (int)((M + r - 1) / r);
+}
+
 size_t vp_col_sums_workspace_bytes(long long M, int C) {
-    long long chunks = (M + 511) / 512;
-    if (chunks > 1024) chunks = 1024;
-    return (size_t)chunks * 2 * C * sizeof(float) + 256;
+    (void)M;
+    return (size_t)1024 * 2 * C * sizeof(float) + 256;
 }
 
 // sums [2][C]: sum_m a[m][c] and (when b) sum_m a[m][c] * (b[m][c] - bmean[c]) * bscale[c]
@@ -792,13 +917,24 @@ int vp_col_sums_f32(vp_ctx* ctx, const float* a, int lda, const float* b, int ld
                     long long M, int C, float* sums, void* ws, size_t ws_bytes, vp_stream stream) {
     if (!ctx || !a || !sums || M <= 0 || C <= 0 || (b && (!bmean || !bscale))) VP_FAIL(ctx, VP_EINVAL, "col_sums: bad arguments");
     if (!ws || ws_bytes < vp_col_sums_workspace_bytes(M, C)) VP_FAIL(ctx, VP_EWORKSPACE, "col_sums: workspace too small");
-    long long chunks = (M + 511) / 512;
-    if (chunks > 1024) chunks = 1024;
-    const int rpc = (int)((M + chunks - 1) / chunks);
-    chunks = (M + rpc - 1) / rpc;
-    ColSumArgs p{a, b, bmean, bscale, (float*)ws, lda, ldb, (int)M, C, rpc};
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(col_sums_kernel, dim3((C + 63) / 64, (unsigned)chunks), dim3(256), 0, st, p);
+    long long chunks;
+    if (M > 0x7fffffffLL) VP_FAIL(ctx, VP_EINVAL, "col_sums: more than 2^31 rows");
+    if (((C | lda | (b ? ldb : 0)) & 3) == 0 && (((uintptr_t)a | (uintptr_t)(b ? b : a)) & 15) == 0) {
+        int cl_shift, colblocks, rpc, ch;
+        colsum4_geometry(M, C / 4, cl_shift, colblocks, rpc, ch);
+        chunks = ch;
+        ColSum4Args p{a, b, bmean, bscale, (float*)ws, lda, ldb, (int)M, C / 4, rpc, cl_shift};
+        if (b) hipLaunchKernelGGL(col_sums4_kernel<true>, dim3(colblocks, (unsigned)chunks), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(col_sums4_kernel<false>, dim3(colblocks, (unsigned)chunks), dim3(256), 0, st, p);
+    } else {
+        chunks = (M + 511) / 512;
+        if (chunks > 1024) chunks = 1024;
+        const int rpc = (int)((M + chunks - 1) / chunks);
+        chunks = (M + rpc - 1) / rpc;
+        ColSumArgs p{a, b, bmean, bscale, (float*)ws, lda, ldb, (int)M, C, rpc};
+        hipLaunchKernelGGL(col_sums_kernel, dim3((C + 63) / 64, (unsigned)chunks), dim3(256), 0, st, p);
+    }
     VP_LAUNCH_CHECK(ctx, "col_sums");
     launch_sum_partials((const float*)ws, (int)chunks, (long long)2 * C, sums, st);
     VP_LAUNCH_CHECK(ctx, "col_sums_reduce");
@@ -832,6 +968,29 @@ int vp_bn_relu_bwd_f32(vp_ctx* ctx, const float* dy, int lddy, const float* z, i
     BnBwdArgs a{dy, z, mean, invstd, gamma, sums, dz, lddy, ldz, lddz, C / 4, relu_mask, M};
     hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(grid1d(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
     VP_LAUNCH_CHECK(ctx, "bn_relu_bwd");
+    return VP_OK;
+}
+
+size_t vp_bn_relu_bwd_dbias_workspace_bytes(long long M, int C) {
+    (void)M;
+    return (size_t)1024 * C * sizeof(float) + 256;
+}
+
+int vp_bn_relu_bwd_dbias_f32(vp_ctx* ctx, const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* invstd,
+                             const float* gamma, const float* sums, long long M, int C, int relu_mask, float* dz, int lddz,
+                             float* dbias, void* ws, size_t ws_bytes, vp_stream stream) {
+    if (!ctx || !dy || !z || !mean || !invstd || !sums || !dz || !dbias || M <= 0 || M > 0x7fffffffLL || C <= 0 ||
+        (C | lddy | ldz | lddz) & 3 || (((uintptr_t)dy | (uintptr_t)z | (uintptr_t)dz) & 15))
+        VP_FAIL(ctx, VP_EINVAL, "bn_relu_bwd_dbias: bad arguments");
+    if (!ws || ws_bytes < vp_bn_relu_bwd_dbias_workspace_bytes(M, C)) VP_FAIL(ctx, VP_EWORKSPACE, "bn_relu_bwd_dbias: workspace too small");
+    int cl_shift, colblocks, rpc, chunks;
+    colsum4_geometry(M, C / 4, cl_shift, colblocks, rpc, chunks);
+    BnBwdSumArgs p{{dy, z, mean, invstd, gamma, sums, dz, lddy, ldz, lddz, C / 4, relu_mask, M}, (float*)ws, (int)M, rpc, cl_shift};
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_relu_bwd_dbias_kernel, dim3(colblocks, (unsigned)chunks), dim3(256), 0, st, p);
+    VP_LAUNCH_CHECK(ctx, "bn_relu_bwd_dbias");
+    launch_sum_partials((const float*)ws, chunks, (long long)C, dbias, st);
+    VP_LAUNCH_CHECK(ctx, "bn_relu_bwd_dbias_reduce");
     return VP_OK;
 }
 

@@ -137,12 +137,21 @@ class ConvBlock(torch.autograd.Function):
                 istd = torch.ones(Cout, dtype=torch.float32, device=dev)
                 g = None
             dz = torch.empty_like(dy)
-            _chk(lib.vp_bn_relu_bwd_f32(hctx, dy.data_ptr(), Cout, z.data_ptr(), Cout, mu.data_ptr(), istd.data_ptr(),
-                                        g.data_ptr() if g is not None else None, sums.data_ptr(), M, Cout, int(relu),
-                                        dz.data_ptr(), Cout, N.stream_ptr()), hctx)
+            if has_bias and Cout % 4 == 0:          # the bias gradient (column sums of dz) from the pass that writes dz
+                dbias = torch.empty(Cout, dtype=torch.float32, device=dev)
+                ws = _bytes(lib.vp_bn_relu_bwd_dbias_workspace_bytes(M, Cout), dev)
+                _chk(lib.vp_bn_relu_bwd_dbias_f32(hctx, dy.data_ptr(), Cout, z.data_ptr(), Cout, mu.data_ptr(), istd.data_ptr(),
+                                                  g.data_ptr() if g is not None else None, sums.data_ptr(), M, Cout, int(relu),
+                                                  dz.data_ptr(), Cout, dbias.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                  N.stream_ptr()), hctx)
+            else:
+                _chk(lib.vp_bn_relu_bwd_f32(hctx, dy.data_ptr(), Cout, z.data_ptr(), Cout, mu.data_ptr(), istd.data_ptr(),
+                                            g.data_ptr() if g is not None else None, sums.data_ptr(), M, Cout, int(relu),
+                                            dz.data_ptr(), Cout, N.stream_ptr()), hctx)
+                dbias = col_sums(dz)[0] if has_bias else None
         else:
             dz = dy
-        dbias = col_sums(dz)[0] if has_bias else None
+            dbias = col_sums(dz)[0] if has_bias else None
         drb = None
         if has_rb:
             drb = torch.empty((B, Cout), dtype=torch.float32, device=dev)
