@@ -531,6 +531,12 @@ int vp_sphereface2(vp_ctx* ctx, const float* logits, const int64_t* labels, cons
 size_t vp_conv1d_wgrad_workspace_bytes(const vp_conv1d_desc* d);
 int vp_conv1d_wgrad_f32(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int lddz, float* dW, void* ws, size_t ws_bytes,
                         vp_stream stream);
+/* vp_conv1d_wgrad_oik_f32: the same gradient reduced straight into the model's (Cout, Cin, KW) layout (utils.py:22-93 stores
+ * nn.Conv1D weights that way).  vp_conv_weight_layouts_f32: from that tensor, the forward weight panel wp (Cout, KW * Cin) and the
+ * data-gradient panel w2 (Cin, KW * Cout; taps reversed, channel roles swapped) in one launch; either output may be NULL. */
+int vp_conv1d_wgrad_oik_f32(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int lddz, float* dW, void* ws, size_t ws_bytes,
+                            vp_stream stream);
+int vp_conv_weight_layouts_f32(vp_ctx* ctx, const float* w, int Cout, int Cin, int KW, float* wp, float* w2, vp_stream stream);
 size_t vp_col_sums_workspace_bytes(long long M, int C);
 int vp_col_sums_f32(vp_ctx* ctx, const float* a, int lda, const float* b, int ldb, const float* bmean, const float* bscale,
                     long long M, int C, float* sums, void* ws, size_t ws_bytes, vp_stream stream);
@@ -562,6 +568,9 @@ int vp_adam_step_f32(vp_ctx* ctx, float* param, const float* grad, float* m, flo
 int vp_utt_sums_f32(vp_ctx* ctx, const float* a, int lda, int B, int T, int C, float* out, vp_stream stream);
 int vp_time_stats_f32(vp_ctx* ctx, const float* x, int ldx, int B, int T, int C, float eps, int unbiased /* 1: TSTP, sqrt(var_unbiased + eps) */,
                       float* stats, vp_stream stream);
+/* vp_time_stats_bwd_add_f32: the same gradient plus `add` (the other consumers' gradients of x; may alias dx), one pass. */
+int vp_time_stats_bwd_add_f32(vp_ctx* ctx, const float* x, int ldx, const float* stats, const float* dstats, int B, int T, int C, float eps,
+                              int unbiased, const float* add, int ldadd, float* dx, int lddx, vp_stream stream);
 int vp_time_stats_bwd_f32(vp_ctx* ctx, const float* x, int ldx, const float* stats, const float* dstats, int B, int T, int C, float eps,
                           int unbiased, float* dx, int lddx, vp_stream stream);
 int vp_attn_stats_bwd_f32(vp_ctx* ctx, const float* e, const float* x, int ldx, const float* pooled, const float* dpooled, int B, int T,
@@ -587,6 +596,11 @@ int vp_aff_combine_f32(vp_ctx* ctx, const float* t, const float* x, const float*
 int vp_aff_combine_bwd_f32(vp_ctx* ctx, const float* g, const float* t, const float* x, const float* y, long long n, float* dx, float* dy,
                            float* dt, vp_stream stream);
 int vp_reflect_fold_f32(vp_ctx* ctx, const float* dxp, int B, int T, int pad, int C, float* dx, vp_stream stream);
+/* The SE block's backward as two passes (SEBlock + residual, ecapa_tdnn.py:50-82, 139-141):
+ * vp_utt_dot_f32: ds[b][c] = sum_t dy[b,t,c] * x[b,t,c];  vp_scale_shift_rows_f32: dx[b,t,c] = dy[b,t,c] * s[b][c] + dm[b][c] / T
+ * (dm = the gradient that reached the squeeze mean through the two dense layers).  C % 4 == 0, contiguous (B*T, C) tensors. */
+int vp_utt_dot_f32(vp_ctx* ctx, const float* dy, const float* x, int B, int T, int C, float* ds, vp_stream stream);
+int vp_scale_shift_rows_f32(vp_ctx* ctx, const float* dy, const float* s, const float* dm, int B, int T, int C, float* dx, vp_stream stream);
 int vp_scale_rows_bwd_f32(vp_ctx* ctx, const float* dy, const float* x, const float* s, int B, int T, int C, float* dx, float* ds,
                           vp_stream stream);
 

@@ -300,13 +300,61 @@ __global__ __launch_bounds__(256) void time_moments_kernel(TmArgs<T> a) {
                                                             : sqrtf(fmaxf(ss / (float)a.Tn, a.eps));
     }
 }
+
+// f32 activations (the training path), four channels per lane: 32 lanes x 8 frame groups, four frames' loads in flight
+__global__ __launch_bounds__(256) void time_moments4_kernel(TmArgs<float> a) {
+    __shared__ float sm[2][256][4];
+    const int lc = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int b = blockIdx.y, c4 = blockIdx.x * 32 + lc;
+    const int C4 = a.C >> 2;
+    const bool ok = c4 < C4;
+    const int c = ok ? c4 * 4 : 0;
+    const float* xb = a.x + (size_t)b * a.Tn * a.ldx + c;
+    float c0[4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    vp_load4(xb, c0);
+    int t = rg;
+    for (; t + 24 < a.Tn; t += 32) {
+        float v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vp_load4(xb + (size_t)(t + 8 * u) * a.ldx, v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[u][e] - c0[e]; s1[e] += d; s2[e] += d * d; }
+    }
+    for (; t < a.Tn; t += 8) {
+        float v[4];
+        vp_load4(xb + (size_t)t * a.ldx, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[e] - c0[e]; s1[e] += d; s2[e] += d * d; }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sm[0][threadIdx.x][e] = s1[e]; sm[1][threadIdx.x][e] = s2[e]; }
+    __syncthreads();
+    if (rg != 0 || !ok) return;
+    float m[4], sd[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int r = 0; r < 8; ++r) { t1 += sm[0][r * 32 + lc][e]; t2 += sm[1][r * 32 + lc][e]; }
+        const float md = t1 / (float)a.Tn;
+        m[e] = c0[e] + md;
+        const float ss = fmaxf(t2 - (float)a.Tn * md * md, 0.f);
+        sd[e] = a.unbiased ? sqrtf(ss / (float)(a.Tn > 1 ? a.Tn - 1 : 1) + a.eps) : sqrtf(fmaxf(ss / (float)a.Tn, a.eps));
+    }
+    vp_store4(a.stats + (size_t)b * 2 * a.C + c, m);
+    vp_store4(a.stats + (size_t)b * 2 * a.C + a.C + c, sd);
+}
 }  // namespace
 
 int vp_time_moments(vp_ctx* ctx, int dtype, const void* x, int ldx, int B, int T, int C, float eps, int unbiased,
                     float* stats, hipStream_t st) {
     if (B > 65535) VP_FAIL(ctx, VP_EINVAL, "time_moments: batch too large");
     dim3 grid((C + 63) / 64, B);
-    if (dtype == VP_BF16) {
+    if (dtype != VP_BF16 && ((C | ldx) & 3) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)stats & 15) == 0) {
+        TmArgs<float> a{(const float*)x, stats, ldx, T, C, eps, unbiased};
+        hipLaunchKernelGGL(time_moments4_kernel, dim3((C / 4 + 31) / 32, B), dim3(256), 0, st, a);
+    } else if (dtype == VP_BF16) {
         TmArgs<bf16_t> a{(const bf16_t*)x, stats, ldx, T, C, eps, unbiased};
         hipLaunchKernelGGL(time_moments_kernel<bf16_t>, grid, dim3(256), 0, st, a);
     } else {

@@ -251,29 +251,61 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_amp_kernel(WgradArgs a) {
 
 // out[i] = sum_k part[k][i]: 16 outputs x 16 partial-lanes per workgroup, fixed order (one thread walking all S partials
 // serially took 33 us per call -- 3.6 ms of a 39 ms training step over ~110 calls)
-__global__ __launch_bounds__(256) void sum_partials_kernel(const float* part, int S, long long n, float* out) {
+// (KW > 1: the weight gradient leaves in the model's (Cout, Cin, KW) layout: partial index (o, tap, c) -> (o, c, tap))
+__device__ __forceinline__ long long oik_index(long long idx, int Cin, int KW) {
+    if (KW <= 1) return idx;
+    const long long o = idx / ((long long)KW * Cin);
+    const int r = (int)(idx - o * KW * Cin);
+    const int j = r / Cin, c = r - j * Cin;
+    return (o * Cin + c) * KW + j;
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* part, int S, long long n, float* out, int Cin, int KW) {
     __shared__ float sm[16][17];
     const int ol = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const long long idx = (long long)blockIdx.x * 16 + ol;
     float s = 0.f;
-    if (idx < n)
-        for (int k = pl; k < S; k += 16) s += part[(size_t)k * n + idx];
+    if (idx < n) {
+        int k = pl;
+        for (; k + 48 < S; k += 64) {             // four partial rows per trip, their loads issued together, summed in row order
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = part[(size_t)(k + 16 * u) * n + idx];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += v[u];
+        }
+        for (; k < S; k += 16) s += part[(size_t)k * n + idx];
+    }
     sm[pl][ol] = s;
     __syncthreads();
     if (pl == 0 && idx < n) {
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += sm[k][ol];
-        out[idx] = t;
+        out[oik_index(idx, Cin, KW)] = t;
     }
 }
 
-__global__ __launch_bounds__(256) void sum_partials_wide_kernel(const float* part, int S, long long n, float* out) {
+__global__ __launch_bounds__(256) void sum_partials_wide_kernel(const float* part, int S, long long n, float* out, int Cin, int KW) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float s = 0.f;
     for (int k = 0; k < S; ++k) s += part[(size_t)k * n + i];
-    out[i] = s;
+    out[oik_index(i, Cin, KW)] = s;
+}
+
+// wp[o][tap * Cin + c] = w[o][c][tap] (the forward kernel's weight panel) and w2[c][(KW - 1 - tap) * Cout + o] = w[o][c][tap]
+// (the data-gradient conv's: taps reversed, channel roles swapped) from the model's (Cout, Cin, KW) tensor in one launch
+__global__ __launch_bounds__(256) void weight_layouts_kernel(const float* w, int Cout, int Cin, int KW, float* wp, float* w2) {
+    const long long n = (long long)Cout * Cin * KW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int o = (int)(i / ((long long)Cin * KW));
+        const int r = (int)(i - (long long)o * Cin * KW);
+        const int c = r / KW, j = r - c * KW;
+        const float v = w[i];
+        if (wp) wp[((size_t)o * KW + j) * Cin + c] = v;
+        if (w2) w2[((size_t)c * KW + (KW - 1 - j)) * Cout + o] = v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- column sums over rows
@@ -548,7 +580,8 @@ __global__ __launch_bounds__(256) void utt_sums_kernel(const float* a, int lda, 
 
 // Backward of stats[b] = [mean_t x | sqrt(max(var_biased_t x, eps))] (pooling.py:97-104 with a mask of ones):
 // dx[b,t,c] = dmean / T + [var > eps] * dstd / std * (x - mean) / T
-struct TsBwdArgs { const float* x; const float* stats; const float* dstats; float* dx; int ldx, lddx, T, C4; float eps; long long total; int unbiased; };
+struct TsBwdArgs { const float* x; const float* stats; const float* dstats; float* dx; int ldx, lddx, T, C4; float eps; long long total; int unbiased;
+                   const float* add; int ldadd; };     // add: other gradients of x summed in the same pass (may alias dx)
 __global__ __launch_bounds__(256) void time_stats_bwd_kernel(TsBwdArgs a) {
     const int C = a.C4 * 4;
     const float invT = 1.f / (float)a.T;
@@ -564,6 +597,12 @@ __global__ __launch_bounds__(256) void time_stats_bwd_kernel(TsBwdArgs a) {
         for (int e = 0; e < 4; ++e)
             o[e] = a.unbiased ? dm[e] * invT + ds[e] / sd[e] * (x[e] - mu[e]) / (float)(a.T > 1 ? a.T - 1 : 1)      // sd = sqrt(var_unbiased + eps)
                               : dm[e] * invT + ((sd[e] * sd[e] > a.eps) ? ds[e] / sd[e] * (x[e] - mu[e]) * invT : 0.f);
+        if (a.add) {
+            float ad[4];
+            vp_load4(a.add + m * a.ldadd + c, ad);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += ad[e];
+        }
         vp_store4(a.dx + m * a.lddx + c, o);
     }
 }
@@ -657,6 +696,60 @@ __global__ __launch_bounds__(256) void scale_rows_bwd_kernel(const float* dy, co
     sm[rg][lc] = acc;
     __syncthreads();
     if (rg == 0 && c < C) ds[(size_t)b * C + c] = sm[0][lc] + sm[1][lc] + sm[2][lc] + sm[3][lc];
+}
+
+// The SE gate's backward in two passes (see SEBlockFn in train/functions.py): ds[b,c] = sum_t dy * x first -- the squeeze path's
+// gradient dm[b,c] (through the two dense layers) depends on it -- then dx = dy * s[b,c] + dm[b,c] / T in one write of dx, instead
+// of dx = dy * s, a separate mean-backward tensor and their sum.  Four channels per lane; 32 lanes x 8 frame groups per utterance.
+__global__ __launch_bounds__(256) void utt_dot4_kernel(const float* dy, const float* x, int T, int C, float* ds) {
+    __shared__ float sm[256][4];
+    const int lc = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int b = blockIdx.y, c4 = blockIdx.x * 32 + lc;
+    const bool ok = c4 < (C >> 2);
+    const int c = ok ? c4 * 4 : 0;
+    const float* gb = dy + (size_t)b * T * C + c;
+    const float* xb = x + (size_t)b * T * C + c;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int t = rg;
+    for (; t + 24 < T; t += 32) {
+        float g[4][4], v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { vp_load4(gb + (size_t)(t + 8 * u) * C, g[u]); vp_load4(xb + (size_t)(t + 8 * u) * C, v[u]); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += g[u][e] * v[u][e];
+    }
+    for (; t < T; t += 8) {
+        float g[4], v[4];
+        vp_load4(gb + (size_t)t * C, g); vp_load4(xb + (size_t)t * C, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += g[e] * v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sm[threadIdx.x][e] = acc[e];
+    __syncthreads();
+    if (rg != 0 || !ok) return;
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += sm[r * 32 + lc][e];
+    vp_store4(ds + (size_t)b * C + c, o);
+}
+
+__global__ __launch_bounds__(256) void scale_shift_rows4_kernel(const float* dy, const float* s, const float* dm, int T, int C4, float inv_t,
+                                                                long long total, float* dx) {
+    const int C = C4 * 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long m = i / C4;
+        const int c = (int)(i - m * C4) * 4;
+        const long long b = m / T;
+        float g[4], sv[4], d[4], o[4];
+        vp_load4(dy + m * C + c, g); vp_load4(s + b * C + c, sv); vp_load4(dm + b * C + c, d);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = g[e] * sv[e] + d[e] * inv_t;
+        vp_store4(dx + m * C + c, o);
+    }
 }
 
 // up[b, t, f, :] = dz[b, t / s, f / s, :] when t and f are multiples of s (and in range), else 0: the zero-insertion that turns
@@ -823,9 +916,9 @@ unsigned grid1d(long long total) {
 }  // namespace
 
 // many outputs: one thread per output (coalesced over the outputs); few outputs, many partials: 16 x 16 per workgroup
-static void launch_sum_partials(const float* part, int S, long long n, float* out, hipStream_t st) {
-    if (n >= 32768) hipLaunchKernelGGL(sum_partials_wide_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, S, n, out);
-    else hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, part, S, n, out);
+static void launch_sum_partials(const float* part, int S, long long n, float* out, hipStream_t st, int Cin = 1, int KW = 1) {
+    if (n >= 32768) hipLaunchKernelGGL(sum_partials_wide_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, S, n, out, Cin, KW);
+    else hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, part, S, n, out, Cin, KW);
 }
 
 extern "C" {
@@ -843,8 +936,8 @@ size_t vp_conv1d_wgrad_workspace_bytes(const vp_conv1d_desc* d) {
 }
 
 // d: the FORWARD conv's descriptor (x / ldx / xoff and the geometry; w, y, epilogue fields ignored).  dz (B*T_out, lddz) f32.
-int vp_conv1d_wgrad_f32(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int lddz, float* dW, void* ws, size_t ws_bytes,
-                        vp_stream stream) {
+static int wgrad_impl(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int lddz, float* dW, void* ws, size_t ws_bytes,
+                      vp_stream stream, bool oik) {
     if (!ctx || !d || !d->x || !dz || !dW) VP_FAIL(ctx, VP_EINVAL, "wgrad: null argument");
     if (d->dtype_in != VP_F32) VP_FAIL(ctx, VP_EUNSUP, "wgrad: f32 tensors only (mfma_bf16 selects the bf16 matrix cores)");
     const bool two_d = d->KF > 1 || d->F_in > 1 || d->F_out > 1;
@@ -888,19 +981,38 @@ int vp_conv1d_wgrad_f32(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, i
     }
     VP_LAUNCH_CHECK(ctx, "conv_wgrad");
     const long long n = (long long)d->Cout * K;
-    launch_sum_partials((const float*)ws, S, n, dW, st);
+    launch_sum_partials((const float*)ws, S, n, dW, st, d->Cin, oik ? d->KW : 1);
     VP_LAUNCH_CHECK(ctx, "wgrad_reduce");
     return VP_OK;
 }
 
-// rows per chunk / chunks / lane split of the four-channels-per-lane kernels: ~2048 workgroups, at most 1024 chunks
+int vp_conv1d_wgrad_f32(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int lddz, float* dW, void* ws, size_t ws_bytes,
+                        vp_stream stream) {
+    return wgrad_impl(ctx, d, dz, lddz, dW, ws, ws_bytes, stream, false);
+}
+
+// the same gradient in the model's own (Cout, Cin, KW) layout (KW = KT * KF taps for the 2-D convs): no permute copy afterwards
+int vp_conv1d_wgrad_oik_f32(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int lddz, float* dW, void* ws, size_t ws_bytes,
+                            vp_stream stream) {
+    return wgrad_impl(ctx, d, dz, lddz, dW, ws, ws_bytes, stream, true);
+}
+
+int vp_conv_weight_layouts_f32(vp_ctx* ctx, const float* w, int Cout, int Cin, int KW, float* wp, float* w2, vp_stream stream) {
+    if (!ctx || !w || (!wp && !w2) || Cout <= 0 || Cin <= 0 || KW <= 0) VP_FAIL(ctx, VP_EINVAL, "weight_layouts: bad arguments");
+    hipLaunchKernelGGL(weight_layouts_kernel, dim3(grid1d((long long)Cout * Cin * KW)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, KW,
+                       wp, w2);
+    VP_LAUNCH_CHECK(ctx, "weight_layouts");
+    return VP_OK;
+}
+
+// rows per chunk / chunks / lane split of the four-channels-per-lane kernels: ~1024 workgroups, at most 512 chunks
 static void colsum4_geometry(long long M, int C4, int& cl_shift, int& colblocks, int& rpc, int& chunks) {
     cl_shift = C4 >= 64 ? 6 : (C4 >= 32 ? 5 : 4);
     const int CL = 1 << cl_shift, RG = 256 >> cl_shift;
     colblocks = (C4 + CL - 1) / CL;
-    long long ch = 2048 / colblocks;
+    long long ch = 1024 / colblocks;              // (more chunks cost more in the partial-sum reduce than they gain here)
     if (ch < 1) ch = 1;
-    if (ch > 1024) ch = 1024;
+    if (ch > 512) ch = 512;
     long long r = (M + ch - 1) / ch;
     if (r < 4 * RG) r = 4 * RG;
     rpc = (int)r;
@@ -1041,9 +1153,20 @@ int vp_time_stats_f32(vp_ctx* ctx, const float* x, int ldx, int B, int T, int C,
 int vp_time_stats_bwd_f32(vp_ctx* ctx, const float* x, int ldx, const float* stats, const float* dstats, int B, int T, int C, float eps,
                           int unbiased, float* dx, int lddx, vp_stream stream) {
     if (!ctx || !x || !stats || !dstats || !dx || B <= 0 || T <= 0 || C <= 0 || (C | ldx | lddx) & 3) VP_FAIL(ctx, VP_EINVAL, "time_stats_bwd: bad arguments");
-    TsBwdArgs a{x, stats, dstats, dx, ldx, lddx, T, C / 4, eps, (long long)B * T * (C / 4), unbiased};
+    TsBwdArgs a{x, stats, dstats, dx, ldx, lddx, T, C / 4, eps, (long long)B * T * (C / 4), unbiased, nullptr, 0};
     hipLaunchKernelGGL(time_stats_bwd_kernel, dim3(grid1d(a.total)), dim3(256), 0, (hipStream_t)stream, a);
     VP_LAUNCH_CHECK(ctx, "time_stats_bwd");
+    return VP_OK;
+}
+
+// dx = add + (the gradient through the statistics): the other consumers' gradients of x folded into this pass (add may be dx)
+int vp_time_stats_bwd_add_f32(vp_ctx* ctx, const float* x, int ldx, const float* stats, const float* dstats, int B, int T, int C, float eps,
+                              int unbiased, const float* add, int ldadd, float* dx, int lddx, vp_stream stream) {
+    if (!ctx || !x || !stats || !dstats || !dx || !add || B <= 0 || T <= 0 || C <= 0 || (C | ldx | lddx | ldadd) & 3)
+        VP_FAIL(ctx, VP_EINVAL, "time_stats_bwd_add: bad arguments");
+    TsBwdArgs a{x, stats, dstats, dx, ldx, lddx, T, C / 4, eps, (long long)B * T * (C / 4), unbiased, add, ldadd};
+    hipLaunchKernelGGL(time_stats_bwd_kernel, dim3(grid1d(a.total)), dim3(256), 0, (hipStream_t)stream, a);
+    VP_LAUNCH_CHECK(ctx, "time_stats_bwd_add");
     return VP_OK;
 }
 
@@ -1083,6 +1206,25 @@ int vp_scale_rows_bwd_f32(vp_ctx* ctx, const float* dy, const float* x, const fl
     if (!ctx || !dy || !x || !s || !dx || !ds || B <= 0 || T <= 0 || C <= 0 || B > 65535) VP_FAIL(ctx, VP_EINVAL, "scale_rows_bwd: bad arguments");
     hipLaunchKernelGGL(scale_rows_bwd_kernel, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, dy, x, s, T, C, dx, ds);
     VP_LAUNCH_CHECK(ctx, "scale_rows_bwd");
+    return VP_OK;
+}
+
+int vp_utt_dot_f32(vp_ctx* ctx, const float* dy, const float* x, int B, int T, int C, float* ds, vp_stream stream) {
+    if (!ctx || !dy || !x || !ds || B <= 0 || T <= 0 || C <= 0 || (C & 3) || B > 65535 || (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)ds) & 15))
+        VP_FAIL(ctx, VP_EINVAL, "utt_dot: bad arguments");
+    hipLaunchKernelGGL(utt_dot4_kernel, dim3((C / 4 + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, dy, x, T, C, ds);
+    VP_LAUNCH_CHECK(ctx, "utt_dot");
+    return VP_OK;
+}
+
+int vp_scale_shift_rows_f32(vp_ctx* ctx, const float* dy, const float* s, const float* dm, int B, int T, int C, float* dx, vp_stream stream) {
+    if (!ctx || !dy || !s || !dm || !dx || B <= 0 || T <= 0 || C <= 0 || (C & 3) ||
+        (((uintptr_t)dy | (uintptr_t)s | (uintptr_t)dm | (uintptr_t)dx) & 15))
+        VP_FAIL(ctx, VP_EINVAL, "scale_shift_rows: bad arguments");
+    const long long total = (long long)B * T * (C / 4);
+    hipLaunchKernelGGL(scale_shift_rows4_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, dy, s, dm, T, C / 4, 1.f / (float)T,
+                       total, dx);
+    VP_LAUNCH_CHECK(ctx, "scale_shift_rows");
     return VP_OK;
 }
 

@@ -207,6 +207,8 @@ _PROTOS = {
                                      c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'vp_conv1d_wgrad_workspace_bytes': (c_size_t, [C.POINTER(Conv1dDesc)]),
     'vp_conv1d_wgrad_f32': (c_int, [c_void_p, C.POINTER(Conv1dDesc), c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'vp_conv1d_wgrad_oik_f32': (c_int, [c_void_p, C.POINTER(Conv1dDesc), c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'vp_conv_weight_layouts_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'vp_col_sums_workspace_bytes': (c_size_t, [C.c_longlong, c_int]),
     'vp_col_sums_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, C.c_longlong, c_int, c_void_p,
                                 c_void_p, c_size_t, c_void_p]),
@@ -223,6 +225,8 @@ _PROTOS = {
                                  c_float, c_int, c_float, c_void_p]),
     'vp_utt_sums_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'vp_time_stats_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
+    'vp_time_stats_bwd_add_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_int,
+                                          c_void_p, c_int, c_void_p]),
     'vp_time_stats_bwd_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_int, c_void_p]),
     'vp_attn_stats_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
                                       c_void_p, c_int, c_void_p]),
@@ -237,6 +241,8 @@ _PROTOS = {
     'vp_aff_combine_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_longlong, c_int, c_void_p, c_void_p]),
     'vp_aff_combine_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_longlong, c_void_p, c_void_p, c_void_p, c_void_p]),
     'vp_reflect_fold_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'vp_utt_dot_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'vp_scale_shift_rows_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'vp_scale_rows_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'vp_aam_ce_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_float, c_void_p,
                               c_void_p, c_void_p, c_void_p]),

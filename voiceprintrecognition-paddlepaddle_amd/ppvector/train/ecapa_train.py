@@ -5,7 +5,7 @@ chunking, the hand-off adds (y_{i-1} + x_i) and the two concatenations are tenso
 Input (B, T, F) f32 on the GPU -> embeddings (B, embd_dim)."""
 import torch
 
-from ppvector.train.functions import BNRows, ConvBlock, SEScale, TimeStats
+from ppvector.train.functions import BNRows, ConvBlock, ConvBlockSkip, SEBlockFn
 from ppvector.train.tdnn_train import asp_forward
 
 
@@ -32,16 +32,14 @@ def res2net_block(r2, x, B, T):
 def se_res2net_block(blk, x, B, T):
     if blk.shortcut is not None:
         raise NotImplementedError('SERes2NetBlock with a shortcut conv is not built')
-    residual = x
-    h = tdnn_block(blk.tdnn1, x, B, T)
+    conv, norm = blk.tdnn1.conv.conv, blk.tdnn1.norm.norm      # tdnn1 also hands x on as the residual (its gradient comes back here)
+    h, residual = ConvBlockSkip.apply(x, conv.weight, conv.bias, None, norm.weight, norm.bias, norm._mean, norm._variance,
+                                      dict(B=B, T=T, dilation=blk.tdnn1.conv.dilation, pad='reflect', relu=True,
+                                           momentum=norm.momentum, eps=norm.eps))
     h = res2net_block(blk.res2net_block, h, B, T)
     h = tdnn_block(blk.tdnn2, h, B, T)
-    se = blk.se_block
-    Cc = h.shape[1]
-    mean = TimeStats.apply(h, B, T)[:, :Cc]                     # SEBlock squeeze (ecapa_tdnn.py:78)
-    s = ConvBlock.apply(mean, se.conv1.conv.weight, se.conv1.conv.bias, None, None, None, None, None, dict(B=B, T=1, relu=True))
-    s = ConvBlock.apply(s, se.conv2.conv.weight, se.conv2.conv.bias, None, None, None, None, None, dict(B=B, T=1, sigmoid=True))
-    return SEScale.apply(h, s, residual, B, T)
+    se = blk.se_block                                           # squeeze, two dense layers, gate, + residual: one tape entry
+    return SEBlockFn.apply(h, residual, se.conv1.conv.weight, se.conv1.conv.bias, se.conv2.conv.weight, se.conv2.conv.bias, B, T)
 
 
 def ecapa_forward_train(m, feats):

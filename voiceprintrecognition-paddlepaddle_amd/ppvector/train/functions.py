@@ -77,7 +77,15 @@ class ConvBlock(torch.autograd.Function):
         tanh = N.VP_ACT_TANH if cfg.get('tanh', False) else (N.VP_ACT_SIGMOID if cfg.get('sigmoid', False) else 0)
         if x.shape != (B * T_in, Cin) or T_out < 1:
             raise ValueError(f'ConvBlock: x {tuple(x.shape)} does not match B {B}, T {T_in}, Cin {Cin}')
-        wp = weight.permute(0, 2, 1).reshape(Cout, KW * Cin).contiguous()
+        w2 = None
+        if KW > 1:          # the forward panel (Cout, tap, Cin) and the data-gradient one (Cin, reversed tap, Cout) in one launch
+            wp = torch.empty((Cout, KW * Cin), dtype=torch.float32, device=x.device)
+            if ctx.needs_input_grad[0]:
+                w2 = torch.empty((Cin, KW * Cout), dtype=torch.float32, device=x.device)
+            _chk(lib.vp_conv_weight_layouts_f32(hctx, weight.data_ptr(), Cout, Cin, KW, wp.data_ptr(),
+                                                w2.data_ptr() if w2 is not None else None, N.stream_ptr()), hctx)
+        else:
+            wp = weight.view(Cout, Cin)
         z = torch.empty((B * T_out, Cout), dtype=torch.float32, device=x.device)
         d = _conv_desc(x, B, T_in, T_out, Cin, Cout, KW, dil, _PAD[pad], pad_left, wp, bias, rowbias, relu)
         d.y = z.data_ptr()
@@ -109,78 +117,106 @@ class ConvBlock(torch.autograd.Function):
             yt = torch.empty_like(y)
             _chk(lib.vp_act_f32(hctx, tanh, y.data_ptr(), y.numel(), yt.data_ptr(), N.stream_ptr()), hctx)
             y = yt
-        ctx.save_for_backward(x, weight, z, mean, invstd, gamma, y if tanh else None)
+        ctx.save_for_backward(x, weight, z, mean, invstd, gamma, y if tanh else None, w2)
         ctx.geom = (B, T_in, T_out, Cin, Cout, KW, dil, pad, pad_left, relu, bn, tanh, bias is not None, rowbias is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight, z, mean, invstd, gamma, yt = ctx.saved_tensors
-        B, T_in, T_out, Cin, Cout, KW, dil, pad, pad_left, relu, bn, tanh, has_bias, has_rb = ctx.geom
-        lib, hctx = N.lib(), N.ctx(x.device)
-        dev = x.device
-        dy = _f32c(dy)
-        M = B * T_out
-        if tanh:
-            t = torch.empty_like(dy)
-            _chk(lib.vp_act_bwd_f32(hctx, tanh, dy.data_ptr(), yt.data_ptr(), dy.numel(), t.data_ptr(), N.stream_ptr()), hctx)
-            dy = t
-        dgamma = dbeta = None
-        if bn or relu:
-            if bn:
-                sums = col_sums(dy, z, mean, invstd)
-                dgamma, dbeta = sums[1], sums[0]             # views of a buffer this call owns: no copies
-                mu, istd, g = mean, invstd, gamma
-            else:                                   # ReLU alone: the BN backward formula with identity statistics
-                sums = torch.zeros((2, Cout), dtype=torch.float32, device=dev)
-                mu = torch.zeros(Cout, dtype=torch.float32, device=dev)
-                istd = torch.ones(Cout, dtype=torch.float32, device=dev)
-                g = None
-            dz = torch.empty_like(dy)
-            if has_bias and Cout % 4 == 0:          # the bias gradient (column sums of dz) from the pass that writes dz
-                dbias = torch.empty(Cout, dtype=torch.float32, device=dev)
-                ws = _bytes(lib.vp_bn_relu_bwd_dbias_workspace_bytes(M, Cout), dev)
-                _chk(lib.vp_bn_relu_bwd_dbias_f32(hctx, dy.data_ptr(), Cout, z.data_ptr(), Cout, mu.data_ptr(), istd.data_ptr(),
-                                                  g.data_ptr() if g is not None else None, sums.data_ptr(), M, Cout, int(relu),
-                                                  dz.data_ptr(), Cout, dbias.data_ptr(), ws.data_ptr(), ws.numel(),
-                                                  N.stream_ptr()), hctx)
-            else:
-                _chk(lib.vp_bn_relu_bwd_f32(hctx, dy.data_ptr(), Cout, z.data_ptr(), Cout, mu.data_ptr(), istd.data_ptr(),
-                                            g.data_ptr() if g is not None else None, sums.data_ptr(), M, Cout, int(relu),
-                                            dz.data_ptr(), Cout, N.stream_ptr()), hctx)
-                dbias = col_sums(dz)[0] if has_bias else None
+        return _conv_block_bwd(ctx, dy)
+
+
+def _conv_block_bwd(ctx, dy, skip=None):
+    """ConvBlock's backward.  skip: a gradient that reached x along another path (the block residual, another consumer of the
+    same tensor), added in the data-gradient conv's epilogue instead of by a separate pass."""
+    x, weight, z, mean, invstd, gamma, yt, w2 = ctx.saved_tensors
+    B, T_in, T_out, Cin, Cout, KW, dil, pad, pad_left, relu, bn, tanh, has_bias, has_rb = ctx.geom
+    lib, hctx = N.lib(), N.ctx(x.device)
+    dev = x.device
+    dy = _f32c(dy)
+    M = B * T_out
+    if tanh:
+        t = torch.empty_like(dy)
+        _chk(lib.vp_act_bwd_f32(hctx, tanh, dy.data_ptr(), yt.data_ptr(), dy.numel(), t.data_ptr(), N.stream_ptr()), hctx)
+        dy = t
+    dgamma = dbeta = None
+    if bn or relu:
+        if bn:
+            sums = col_sums(dy, z, mean, invstd)
+            dgamma, dbeta = sums[1], sums[0]             # views of a buffer this call owns: no copies
+            mu, istd, g = mean, invstd, gamma
+        else:                                   # ReLU alone: the BN backward formula with identity statistics
+            sums = torch.zeros((2, Cout), dtype=torch.float32, device=dev)
+            mu = torch.zeros(Cout, dtype=torch.float32, device=dev)
+            istd = torch.ones(Cout, dtype=torch.float32, device=dev)
+            g = None
+        dz = torch.empty_like(dy)
+        if has_bias and Cout % 4 == 0:          # the bias gradient (column sums of dz) from the pass that writes dz
+            dbias = torch.empty(Cout, dtype=torch.float32, device=dev)
+            ws = _bytes(lib.vp_bn_relu_bwd_dbias_workspace_bytes(M, Cout), dev)
+            _chk(lib.vp_bn_relu_bwd_dbias_f32(hctx, dy.data_ptr(), Cout, z.data_ptr(), Cout, mu.data_ptr(), istd.data_ptr(),
+                                              g.data_ptr() if g is not None else None, sums.data_ptr(), M, Cout, int(relu),
+                                              dz.data_ptr(), Cout, dbias.data_ptr(), ws.data_ptr(), ws.numel(),
+                                              N.stream_ptr()), hctx)
         else:
-            dz = dy
+            _chk(lib.vp_bn_relu_bwd_f32(hctx, dy.data_ptr(), Cout, z.data_ptr(), Cout, mu.data_ptr(), istd.data_ptr(),
+                                        g.data_ptr() if g is not None else None, sums.data_ptr(), M, Cout, int(relu),
+                                        dz.data_ptr(), Cout, N.stream_ptr()), hctx)
             dbias = col_sums(dz)[0] if has_bias else None
-        drb = None
-        if has_rb:
-            drb = torch.empty((B, Cout), dtype=torch.float32, device=dev)
-            _chk(lib.vp_utt_sums_f32(hctx, dz.data_ptr(), Cout, B, T_out, Cout, drb.data_ptr(), N.stream_ptr()), hctx)
-        # weight gradient
-        d = _conv_desc(x, B, T_in, T_out, Cin, Cout, KW, dil, _PAD[pad], pad_left, weight)
-        dwp = torch.empty((Cout, KW * Cin), dtype=torch.float32, device=dev)
-        ws = _bytes(lib.vp_conv1d_wgrad_workspace_bytes(C.byref(d)), dev)
-        _chk(lib.vp_conv1d_wgrad_f32(hctx, C.byref(d), dz.data_ptr(), Cout, dwp.data_ptr(), ws.data_ptr(), ws.numel(),
+    else:
+        dz = dy
+        dbias = col_sums(dz)[0] if has_bias else None
+    drb = None
+    if has_rb:
+        drb = torch.empty((B, Cout), dtype=torch.float32, device=dev)
+        _chk(lib.vp_utt_sums_f32(hctx, dz.data_ptr(), Cout, B, T_out, Cout, drb.data_ptr(), N.stream_ptr()), hctx)
+    # weight gradient
+    d = _conv_desc(x, B, T_in, T_out, Cin, Cout, KW, dil, _PAD[pad], pad_left, weight)
+    dW = torch.empty((Cout, Cin, KW), dtype=torch.float32, device=dev)      # reduced straight into the model's layout
+    ws = _bytes(lib.vp_conv1d_wgrad_workspace_bytes(C.byref(d)), dev)
+    _chk(lib.vp_conv1d_wgrad_oik_f32(hctx, C.byref(d), dz.data_ptr(), Cout, dW.data_ptr(), ws.data_ptr(), ws.numel(),
                                      N.stream_ptr()), hctx)
-        dW = dwp.view(Cout, KW, Cin).permute(0, 2, 1).contiguous()
-        # data gradient: the forward kernel over dz with reversed taps and swapped channel roles
-        dx = None
-        if ctx.needs_input_grad[0]:
-            w2 = weight.flip(2).permute(1, 2, 0).reshape(Cin, KW * Cout).contiguous()
-            dx = torch.empty((B * T_in, Cin), dtype=torch.float32, device=dev)
-            if pad == 'reflect' and pad_left > 0:
-                # gradient w.r.t. the reflect-PADDED input (a "full" zero-padded conv), then fold the mirrored frames back
-                Tp = T_in + 2 * pad_left
-                dxp = torch.empty((B * Tp, Cin), dtype=torch.float32, device=dev)
-                d2 = _conv_desc(dz, B, T_out, Tp, Cout, Cin, KW, dil, N.VP_PAD_ZERO, dil * (KW - 1), w2)
-                d2.y = dxp.data_ptr()
-                _chk(lib.vp_conv1d_fwd(hctx, C.byref(d2), N.stream_ptr()), hctx)
-                _chk(lib.vp_reflect_fold_f32(hctx, dxp.data_ptr(), B, T_in, pad_left, Cin, dx.data_ptr(), N.stream_ptr()), hctx)
-            else:
-                d2 = _conv_desc(dz, B, T_out, T_in, Cout, Cin, KW, dil, N.VP_PAD_ZERO, dil * (KW - 1) - pad_left, w2)
-                d2.y = dx.data_ptr()
-                _chk(lib.vp_conv1d_fwd(hctx, C.byref(d2), N.stream_ptr()), hctx)
-        return dx, dW, dbias, drb, dgamma, dbeta, None, None, None
+    # data gradient: the forward kernel over dz with reversed taps and swapped channel roles
+    dx = None
+    if ctx.needs_input_grad[0]:
+        if w2 is None:                                  # KW = 1: W^T
+            w2 = weight.view(Cout, Cin).t().contiguous()
+        dx = torch.empty((B * T_in, Cin), dtype=torch.float32, device=dev)
+        if pad == 'reflect' and pad_left > 0:
+            # gradient w.r.t. the reflect-PADDED input (a "full" zero-padded conv), then fold the mirrored frames back
+            Tp = T_in + 2 * pad_left
+            dxp = torch.empty((B * Tp, Cin), dtype=torch.float32, device=dev)
+            d2 = _conv_desc(dz, B, T_out, Tp, Cout, Cin, KW, dil, N.VP_PAD_ZERO, dil * (KW - 1), w2)
+            d2.y = dxp.data_ptr()
+            _chk(lib.vp_conv1d_fwd(hctx, C.byref(d2), N.stream_ptr()), hctx)
+            _chk(lib.vp_reflect_fold_f32(hctx, dxp.data_ptr(), B, T_in, pad_left, Cin, dx.data_ptr(), N.stream_ptr()), hctx)
+            if skip is not None:
+                dx += skip
+        else:
+            d2 = _conv_desc(dz, B, T_out, T_in, Cout, Cin, KW, dil, N.VP_PAD_ZERO, dil * (KW - 1) - pad_left, w2)
+            d2.y = dx.data_ptr()
+            if skip is not None:
+                skip = _f32c(skip)
+                d2.res, d2.ld_res, d2.res_off = skip.data_ptr(), Cin, 0
+            _chk(lib.vp_conv1d_fwd(hctx, C.byref(d2), N.stream_ptr()), hctx)
+    elif skip is not None:
+        dx = skip
+    return dx, dW, dbias, drb, dgamma, dbeta, None, None, None
+
+
+class ConvBlockSkip(torch.autograd.Function):
+    """ConvBlock that also hands its input on: (y, x).  A consumer of the second output (the SE-Res2 block's residual,
+    ecapa_tdnn.py:139-141) sends its gradient back here, where the data-gradient conv adds it in its epilogue -- instead of
+    autograd summing two (B*T, C) tensors afterwards."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, rowbias, gamma, beta, run_mean, run_var, cfg):
+        y = ConvBlock.forward(ctx, x, weight, bias, rowbias, gamma, beta, run_mean, run_var, cfg)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        return _conv_block_bwd(ctx, dy, dskip)
 
 
 class SEScale(torch.autograd.Function):
@@ -209,6 +245,66 @@ class SEScale(torch.autograd.Function):
         _chk(lib.vp_scale_rows_bwd_f32(hctx, dy.data_ptr(), x.data_ptr(), s.data_ptr(), B, T, Cc, dx.data_ptr(), ds.data_ptr(),
                                        N.stream_ptr()), hctx)
         return dx, ds, dy, None, None
+
+
+class _Tape:
+    """What ConvBlock.forward / .backward need of an autograd context, for the functions that run a ConvBlock inside their own
+    forward and backward."""
+
+    def __init__(self, needs_input_grad):
+        self.needs_input_grad = needs_input_grad
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+class SEBlockFn(torch.autograd.Function):
+    """SEBlock (ecapa_tdnn.py:50-82, lengths=None) and the block residual (:139-141) as one tape entry:
+    out = h * sigmoid(W2 relu(W1 mean_t(h) + b1) + b2) + res.  The two dense layers are ConvBlocks at T = 1 (same kernels, same
+    mixed-precision flavour as everywhere else).  Backward in two passes over the big tensors: ds = sum_t dout * h, the dense
+    layers' backward down to d mean, then dh = dout * s + d mean / T written once -- instead of dh = dout * s, a separate
+    mean-backward tensor and autograd's sum of the two (8 tensor passes -> 4)."""
+
+    @staticmethod
+    def forward(ctx, h, res, w1, b1, w2, b2, B, T):
+        lib, hctx = N.lib(), N.ctx(h.device)
+        h, res = _f32c(h), _f32c(res)
+        Cc = h.shape[1]
+        stats = torch.empty((B, 2 * Cc), dtype=torch.float32, device=h.device)
+        _chk(lib.vp_time_stats_f32(hctx, h.data_ptr(), Cc, B, T, Cc, 1e-12, 0, stats.data_ptr(), N.stream_ptr()), hctx)
+        mean = stats[:, :Cc].contiguous()
+        needs = (True,) * 9
+        t1, t2 = _Tape(needs), _Tape(needs)
+        a = ConvBlock.forward(t1, mean, w1, b1, None, None, None, None, None, dict(B=B, T=1, relu=True))
+        s = ConvBlock.forward(t2, a, w2, b2, None, None, None, None, None, dict(B=B, T=1, sigmoid=True))
+        out = torch.empty_like(h)
+        _chk(lib.vp_se_scale_residual(hctx, N.VP_F32, h.data_ptr(), Cc, 0, s.data_ptr(), res.data_ptr(), Cc, 0, out.data_ptr(), Cc, 0,
+                                      B, T, Cc, N.stream_ptr()), hctx)
+        ctx.save_for_backward(h, s, *t1.saved_tensors, *t2.saved_tensors)
+        ctx.n1 = len(t1.saved_tensors)
+        ctx.geoms = (B, T, t1.geom, t2.geom)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        saved = ctx.saved_tensors
+        h, s = saved[0], saved[1]
+        B, T, g1, g2 = ctx.geoms
+        lib, hctx = N.lib(), N.ctx(h.device)
+        dout = _f32c(dout)
+        Cc = h.shape[1]
+        ds = torch.empty_like(s)
+        _chk(lib.vp_utt_dot_f32(hctx, dout.data_ptr(), h.data_ptr(), B, T, Cc, ds.data_ptr(), N.stream_ptr()), hctx)
+        needs = (True,) * 9
+        t1, t2 = _Tape(needs), _Tape(needs)
+        t1.saved_tensors, t1.geom = saved[2:2 + ctx.n1], g1
+        t2.saved_tensors, t2.geom = saved[2 + ctx.n1:], g2
+        da, dw2, db2 = ConvBlock.backward(t2, ds)[:3]
+        dm, dw1, db1 = ConvBlock.backward(t1, da)[:3]
+        dh = torch.empty_like(h)
+        _chk(lib.vp_scale_shift_rows_f32(hctx, dout.data_ptr(), s.data_ptr(), dm.data_ptr(), B, T, Cc, dh.data_ptr(), N.stream_ptr()), hctx)
+        return dh, dout, dw1, db1, dw2, db2, None, None
 
 
 class TimeStats(torch.autograd.Function):
@@ -262,6 +358,67 @@ class AttnStats(torch.autograd.Function):
         _chk(lib.vp_attn_stats_bwd_f32(hctx, e.data_ptr(), x.data_ptr(), Cc, pooled.data_ptr(), _f32c(dp).data_ptr(), B, T, Cc,
                                        1e-12, de.data_ptr(), dx.data_ptr(), Cc, N.stream_ptr()), hctx)
         return de, dx, None, None
+
+
+class AspFn(torch.autograd.Function):
+    """AttentiveStatisticsPooling.forward with lengths=None (pooling.py:86-125) as one tape entry: x (B*T, C) -> (B, 2C).
+    x has three consumers (the context statistics, the attention TDNN, the weighted statistics); as separate entries their
+    three (B*T, C) gradients are written and then summed pairwise by autograd (8 tensor passes over 469 MB at C = 1536).  Here
+    the TDNN's data-gradient conv adds the weighted statistics' gradient in its epilogue and the statistics' backward adds that
+    sum in its own pass.  w: (att, 3C | C, 1) as stored; the 2C context columns act on a per-utterance constant, i.e. a
+    per-utterance bias (rowbias)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, gamma, beta, run_mean, run_var, w2, b2, cfg):
+        lib, hctx = N.lib(), N.ctx(x.device)
+        x = _f32c(x)
+        B, T, gc = cfg['B'], cfg['T'], cfg['global_context']
+        Cc = x.shape[1]
+        needs = (True,) * 9
+        t0, t1, t2 = _Tape(needs), _Tape(needs), _Tape(needs)
+        stats = rowbias = None
+        if gc:
+            stats = torch.empty((B, 2 * Cc), dtype=torch.float32, device=x.device)
+            _chk(lib.vp_time_stats_f32(hctx, x.data_ptr(), Cc, B, T, Cc, 1e-12, 0, stats.data_ptr(), N.stream_ptr()), hctx)
+            rowbias = ConvBlock.forward(t0, stats, w[:, Cc:].contiguous(), None, None, None, None, None, None, dict(B=B, T=1))
+        h = ConvBlock.forward(t1, x, w[:, :Cc].contiguous() if gc else w, bias, rowbias, gamma, beta, run_mean, run_var,
+                              dict(B=B, T=T, relu=True, tanh=True, momentum=cfg['momentum'], eps=cfg['eps']))
+        e = ConvBlock.forward(t2, h, w2, b2, None, None, None, None, None, dict(B=B, T=T))
+        pooled = torch.empty((B, 2 * Cc), dtype=torch.float32, device=x.device)
+        _chk(lib.vp_asp_softmax_stats(hctx, N.VP_F32, e.data_ptr(), x.data_ptr(), Cc, 0, B, T, Cc, 1e-12, pooled.data_ptr(),
+                                      N.stream_ptr()), hctx)
+        tapes = (t0, t1, t2) if gc else (t1, t2)
+        ctx.save_for_backward(x, stats, e, pooled, *(t for tp in tapes for t in tp.saved_tensors))
+        ctx.tape_meta = [(len(tp.saved_tensors), tp.geom) for tp in tapes]
+        ctx.geom = (B, T, gc)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dp):
+        saved = ctx.saved_tensors
+        x, stats, e, pooled = saved[:4]
+        B, T, gc = ctx.geom
+        lib, hctx = N.lib(), N.ctx(x.device)
+        Cc = x.shape[1]
+        tapes, at = [], 4
+        for n, geom in ctx.tape_meta:
+            tp = _Tape((True,) * 9)
+            tp.saved_tensors, tp.geom = saved[at:at + n], geom
+            tapes.append(tp)
+            at += n
+        t2, t1 = tapes[-1], tapes[-2]
+        de, dx = torch.empty_like(e), torch.empty_like(x)
+        _chk(lib.vp_attn_stats_bwd_f32(hctx, e.data_ptr(), x.data_ptr(), Cc, pooled.data_ptr(), _f32c(dp).data_ptr(), B, T, Cc,
+                                       1e-12, de.data_ptr(), dx.data_ptr(), Cc, N.stream_ptr()), hctx)
+        dh, dw2, db2 = _conv_block_bwd(t2, de)[:3]
+        dx, dwx, dbias, drb, dgamma, dbeta = _conv_block_bwd(t1, dh, dx)[:6]        # dx: TDNN's + the weighted statistics'
+        dw = dwx
+        if gc:
+            dstats, dwc = _conv_block_bwd(tapes[0], drb)[:2]
+            _chk(lib.vp_time_stats_bwd_add_f32(hctx, x.data_ptr(), Cc, stats.data_ptr(), dstats.data_ptr(), B, T, Cc, 1e-12, 0,
+                                               dx.data_ptr(), Cc, dx.data_ptr(), Cc, N.stream_ptr()), hctx)
+            dw = torch.cat([dwx, dwc], dim=1)
+        return dx, dw, dbias, dgamma, dbeta, None, None, dw2, db2, None
 
 
 class BNRows(torch.autograd.Function):

@@ -3,7 +3,7 @@ functions.py: batch-statistics BatchNorm, running statistics updated in place (m
 parameter.  Input (B, T, F) f32 on the GPU -> embeddings (B, embd_dim)."""
 import torch
 
-from ppvector.train.functions import AttnStats, BNRows, ConvBlock, TimeStats
+from ppvector.train.functions import AspFn, BNRows, ConvBlock
 
 
 def _bn(p):
@@ -11,22 +11,11 @@ def _bn(p):
 
 
 def asp_forward(asp, x, B, T):
-    """AttentiveStatisticsPooling.forward with lengths=None (pooling.py:86-125): x (B*T, C) -> (B, 2C)."""
-    Cc = asp.channels
-    conv, norm = asp.tdnn.conv.conv, asp.tdnn.norm.norm
-    w = conv.weight                                             # (att, 3C | C, 1)
-    if asp.global_context:
-        stats = TimeStats.apply(x, B, T)                        # (B, 2C) = [mean | std]
-        # the 2C context columns of the 1x1 conv act on a per-utterance constant: a per-utterance bias
-        rowbias = ConvBlock.apply(stats, w[:, Cc:], None, None, None, None, None, None, dict(B=B, T=1))
-        wx = w[:, :Cc]
-    else:
-        rowbias, wx = None, w
+    """AttentiveStatisticsPooling.forward with lengths=None (pooling.py:86-125): x (B*T, C) -> (B, 2C), one tape entry."""
+    conv, norm, c2 = asp.tdnn.conv.conv, asp.tdnn.norm.norm, asp.conv.conv
     g, b, rm, rv = _bn(norm)
-    h = ConvBlock.apply(x, wx, conv.bias, rowbias, g, b, rm, rv, dict(B=B, T=T, relu=True, tanh=True, momentum=norm.momentum, eps=norm.eps))
-    c2 = asp.conv.conv
-    e = ConvBlock.apply(h, c2.weight, c2.bias, None, None, None, None, None, dict(B=B, T=T))
-    return AttnStats.apply(e, x, B, T)
+    return AspFn.apply(x, conv.weight, conv.bias, g, b, rm, rv, c2.weight, c2.bias,
+                       dict(B=B, T=T, global_context=bool(asp.global_context), momentum=norm.momentum, eps=norm.eps))
 
 
 def tdnn_forward_train(m, feats):
