@@ -596,6 +596,15 @@ int vp_aff_combine_f32(vp_ctx* ctx, const float* t, const float* x, const float*
 int vp_aff_combine_bwd_f32(vp_ctx* ctx, const float* g, const float* t, const float* x, const float* y, long long n, float* dx, float* dy,
                            float* dt, vp_stream stream);
 int vp_reflect_fold_f32(vp_ctx* ctx, const float* dxp, int B, int T, int pad, int C, float* dx, vp_stream stream);
+/* Res2NetBlock as one tape entry (ecapa_tdnn.py:11-47; train/functions.py Res2Fn):
+ * vp_affine_rows_aux_f32: y = z * scale + shift into a channel slice (ldy) of the concatenated output, and (when aux) aux = y + add
+ *   -- the next chunk's input y_i + x_{i+1} -- from the same pass.
+ * vp_reflect_fold_into_f32: vp_reflect_fold_f32 written into a channel slice of d x (rows lddx apart) and, when add is given,
+ *   sum = folded + add (dense): the previous chunk's output gradient. */
+int vp_affine_rows_aux_f32(vp_ctx* ctx, const float* z, int ldz, const float* scale, const float* shift, long long M, int C, float* y, int ldy,
+                           const float* add, int ld_add, float* aux, int ld_aux, vp_stream stream);
+int vp_reflect_fold_into_f32(vp_ctx* ctx, const float* dxp, int B, int T, int pad, int C, float* dx, int lddx, const float* add, int ld_add,
+                             float* sum, vp_stream stream);
 /* The SE block's backward as two passes (SEBlock + residual, ecapa_tdnn.py:50-82, 139-141):
  * vp_utt_dot_f32: ds[b][c] = sum_t dy[b,t,c] * x[b,t,c];  vp_scale_shift_rows_f32: dx[b,t,c] = dy[b,t,c] * s[b][c] + dm[b][c] / T
  * (dm = the gradient that reached the squeeze mean through the two dense layers).  C % 4 == 0, contiguous (B*T, C) tensors. */

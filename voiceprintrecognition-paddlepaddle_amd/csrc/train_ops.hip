@@ -451,6 +451,29 @@ __global__ __launch_bounds__(256) void affine_rows_kernel(const float* z, int ld
     }
 }
 
+// y = z * scale + shift into a channel slice of a wider tensor (ldy), and aux = y + add (add: another slice of a wider tensor):
+// a Res2Net chunk's output written where the concatenation wants it, and the next chunk's input y_i + x_{i+1} from the same pass
+struct AffAuxArgs { const float* z; const float* scale; const float* shift; float* y; const float* add; float* aux;
+                    int ldz, ldy, ld_add, ld_aux, C4; long long M; };
+__global__ __launch_bounds__(256) void affine_rows_aux_kernel(AffAuxArgs a) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.M * a.C4; i += (long long)gridDim.x * 256) {
+        const long long m = i / a.C4;
+        const int c = (int)(i - m * a.C4) * 4;
+        float v[4], s[4], h[4];
+        vp_load4(a.z + m * a.ldz + c, v); vp_load4(a.scale + c, s); vp_load4(a.shift + c, h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * s[e] + h[e];
+        vp_store4(a.y + m * a.ldy + c, v);
+        if (a.aux) {
+            float ad[4];
+            vp_load4(a.add + m * a.ld_add + c, ad);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += ad[e];
+            vp_store4(a.aux + m * a.ld_aux + c, v);
+        }
+    }
+}
+
 // dz = [z > 0] * gamma * invstd * (dy - sum_dy / M - zhat * sum_dy_zhat / M),  zhat = (z - mean) * invstd
 // (BatchNorm backward through y = BN(z), then the ReLU that produced z; relu_mask = 0 skips the mask)
 struct BnBwdArgs {
@@ -651,7 +674,8 @@ __global__ __launch_bounds__(256) void attn_stats_bwd_kernel(AsBwdArgs a) {
 
 // Adjoint of reflect padding: dxp (B, T + 2p, C) is the gradient w.r.t. the reflect-padded input (from the zero-padded
 // "full" data-gradient conv); frames 1..p and T-1-p..T-2 also receive their mirror images' gradients.
-struct FoldArgs { const float* dxp; float* dx; int T, p, C4; long long total; };
+struct FoldArgs { const float* dxp; float* dx; int T, p, C4; long long total;
+                  int lddx; const float* add; int ld_add; float* sum; };     // dx rows lddx apart; sum = folded + add (dense), when add
 __global__ __launch_bounds__(256) void reflect_fold_kernel(FoldArgs a) {
     const int Tp = a.T + 2 * a.p;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.total; i += (long long)gridDim.x * 256) {
@@ -672,7 +696,13 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(FoldArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += w[e];
         }
-        vp_store4(a.dx + m * a.C4 * 4 + c, v);
+        vp_store4(a.dx + m * a.lddx + c, v);
+        if (a.add) {
+            vp_load4(a.add + m * a.ld_add + c, w);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += w[e];
+            vp_store4(a.sum + m * a.C4 * 4 + c, v);
+        }
     }
 }
 
@@ -1195,9 +1225,34 @@ int vp_act_bwd_f32(vp_ctx* ctx, int act, const float* dy, const float* y, long l
 
 int vp_reflect_fold_f32(vp_ctx* ctx, const float* dxp, int B, int T, int pad, int C, float* dx, vp_stream stream) {
     if (!ctx || !dxp || !dx || B <= 0 || T <= 0 || pad < 0 || pad >= T || C <= 0 || C & 3) VP_FAIL(ctx, VP_EINVAL, "reflect_fold: bad arguments");
-    FoldArgs a{dxp, dx, T, pad, C / 4, (long long)B * T * (C / 4)};
+    FoldArgs a{dxp, dx, T, pad, C / 4, (long long)B * T * (C / 4), C, nullptr, 0, nullptr};
     hipLaunchKernelGGL(reflect_fold_kernel, dim3(grid1d(a.total)), dim3(256), 0, (hipStream_t)stream, a);
     VP_LAUNCH_CHECK(ctx, "reflect_fold");
+    return VP_OK;
+}
+
+// the same fold written into a channel slice of a wider gradient tensor (rows lddx apart), and sum = folded + add (dense (B*T, C))
+// when add is given: a Res2Net chunk's input gradient goes to its slice of d x, and, summed with the concatenation's gradient
+// of the previous chunk's output, becomes that chunk's output gradient (ecapa_tdnn.py:36-46), in the pass that folds
+int vp_reflect_fold_into_f32(vp_ctx* ctx, const float* dxp, int B, int T, int pad, int C, float* dx, int lddx, const float* add, int ld_add,
+                             float* sum, vp_stream stream) {
+    if (!ctx || !dxp || !dx || B <= 0 || T <= 0 || pad < 0 || pad >= T || C <= 0 || (C | lddx | ld_add) & 3 || (add && !sum) ||
+        (((uintptr_t)dx | (uintptr_t)add | (uintptr_t)sum) & 15))
+        VP_FAIL(ctx, VP_EINVAL, "reflect_fold_into: bad arguments");
+    FoldArgs a{dxp, dx, T, pad, C / 4, (long long)B * T * (C / 4), lddx, add, ld_add, sum};
+    hipLaunchKernelGGL(reflect_fold_kernel, dim3(grid1d(a.total)), dim3(256), 0, (hipStream_t)stream, a);
+    VP_LAUNCH_CHECK(ctx, "reflect_fold_into");
+    return VP_OK;
+}
+
+int vp_affine_rows_aux_f32(vp_ctx* ctx, const float* z, int ldz, const float* scale, const float* shift, long long M, int C, float* y, int ldy,
+                           const float* add, int ld_add, float* aux, int ld_aux, vp_stream stream) {
+    if (!ctx || !z || !scale || !shift || !y || M <= 0 || C <= 0 || (C | ldz | ldy) & 3 || (aux && (!add || (ld_add | ld_aux) & 3)) ||
+        (((uintptr_t)z | (uintptr_t)y | (uintptr_t)add | (uintptr_t)aux) & 15))
+        VP_FAIL(ctx, VP_EINVAL, "affine_rows_aux: bad arguments");
+    AffAuxArgs a{z, scale, shift, y, add, aux, ldz, ldy, ld_add, ld_aux, C / 4, M};
+    hipLaunchKernelGGL(affine_rows_aux_kernel, dim3(grid1d(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
+    VP_LAUNCH_CHECK(ctx, "affine_rows_aux");
     return VP_OK;
 }
 

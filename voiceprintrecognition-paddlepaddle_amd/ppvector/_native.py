@@ -241,6 +241,9 @@ _PROTOS = {
     'vp_aff_combine_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_longlong, c_int, c_void_p, c_void_p]),
     'vp_aff_combine_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_longlong, c_void_p, c_void_p, c_void_p, c_void_p]),
     'vp_reflect_fold_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'vp_affine_rows_aux_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, C.c_longlong, c_int, c_void_p, c_int, c_void_p, c_int,
+                                       c_void_p, c_int, c_void_p]),
+    'vp_reflect_fold_into_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     'vp_utt_dot_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'vp_scale_shift_rows_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'vp_scale_rows_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

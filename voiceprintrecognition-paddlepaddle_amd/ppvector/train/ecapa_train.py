@@ -5,7 +5,7 @@ chunking, the hand-off adds (y_{i-1} + x_i) and the two concatenations are tenso
 Input (B, T, F) f32 on the GPU -> embeddings (B, embd_dim)."""
 import torch
 
-from ppvector.train.functions import BNRows, ConvBlock, ConvBlockSkip, SEBlockFn
+from ppvector.train.functions import BNRows, ConvBlock, ConvBlockSkip, Res2Fn, SEBlockFn
 from ppvector.train.tdnn_train import asp_forward
 
 
@@ -17,16 +17,17 @@ def tdnn_block(blk, x, B, T):
 
 
 def res2net_block(r2, x, B, T):
-    ys, y = [], None
-    for i, xi in enumerate(torch.chunk(x, r2.scale, dim=1)):
-        if i == 0:
-            y = xi
-        elif i == 1:
-            y = tdnn_block(r2.blocks[i - 1], xi, B, T)
-        else:
-            y = tdnn_block(r2.blocks[i - 1], xi + y, B, T)
-        ys.append(y)
-    return torch.cat(ys, dim=1)
+    """Res2NetBlock (ecapa_tdnn.py:11-47) as one tape entry (functions.Res2Fn)."""
+    blocks = list(r2.blocks)
+    params = []
+    for blk in blocks:
+        conv, norm = blk.conv.conv, blk.norm.norm
+        params += [conv.weight, conv.bias, norm.weight, norm.bias, norm._mean, norm._variance]
+    n0 = blocks[0].norm.norm
+    if any(b.conv.dilation != blocks[0].conv.dilation or b.norm.norm.momentum != n0.momentum or b.norm.norm.eps != n0.eps
+           for b in blocks):
+        raise NotImplementedError('Res2NetBlock chunks with different dilation / BatchNorm settings')
+    return Res2Fn.apply(x, dict(B=B, T=T, scale=r2.scale, dilation=blocks[0].conv.dilation, momentum=n0.momentum, eps=n0.eps), *params)
 
 
 def se_res2net_block(blk, x, B, T):

@@ -110,9 +110,20 @@ class ConvBlock(torch.autograd.Function):
                                           run_var.data_ptr() if run_var is not None else None, cfg.get('momentum', 0.9),
                                           cfg.get('eps', 1e-5), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
                                           shift.data_ptr(), N.stream_ptr()), hctx)
-            y = torch.empty_like(z)
-            _chk(lib.vp_affine_rows_f32(hctx, z.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(), B * T_out, Cout,
-                                        y.data_ptr(), Cout, 0, N.stream_ptr()), hctx)
+            into, add = cfg.get('y_into'), cfg.get('aux_add')
+            if into is not None or add is not None:
+                # y straight into a channel slice of a wider tensor, and aux = y + add (the next Res2Net chunk's input) in the same pass
+                y = into if into is not None else torch.empty_like(z)
+                aux = torch.empty_like(z) if add is not None else None
+                _chk(lib.vp_affine_rows_aux_f32(hctx, z.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(), B * T_out, Cout,
+                                                y.data_ptr(), y.stride(0), add.data_ptr() if add is not None else None,
+                                                add.stride(0) if add is not None else 0, aux.data_ptr() if aux is not None else None,
+                                                Cout, N.stream_ptr()), hctx)
+                ctx.aux_out = aux
+            else:
+                y = torch.empty_like(z)
+                _chk(lib.vp_affine_rows_f32(hctx, z.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(), B * T_out, Cout,
+                                            y.data_ptr(), Cout, 0, N.stream_ptr()), hctx)
         if tanh:
             yt = torch.empty_like(y)
             _chk(lib.vp_act_f32(hctx, tanh, y.data_ptr(), y.numel(), yt.data_ptr(), N.stream_ptr()), hctx)
@@ -126,9 +137,11 @@ class ConvBlock(torch.autograd.Function):
         return _conv_block_bwd(ctx, dy)
 
 
-def _conv_block_bwd(ctx, dy, skip=None):
+def _conv_block_bwd(ctx, dy, skip=None, fold=None):
     """ConvBlock's backward.  skip: a gradient that reached x along another path (the block residual, another consumer of the
-    same tensor), added in the data-gradient conv's epilogue instead of by a separate pass."""
+    same tensor), added in the data-gradient conv's epilogue instead of by a separate pass.  fold: {'dx': slice view of a wider
+    gradient tensor, 'add': slice view or None} -- d x is written into that slice and the returned tensor is d x + add (or None):
+    the Res2Net hand-off (Res2Fn)."""
     x, weight, z, mean, invstd, gamma, yt, w2 = ctx.saved_tensors
     B, T_in, T_out, Cin, Cout, KW, dil, pad, pad_left, relu, bn, tanh, has_bias, has_rb = ctx.geom
     lib, hctx = N.lib(), N.ctx(x.device)
@@ -189,7 +202,15 @@ def _conv_block_bwd(ctx, dy, skip=None):
             d2 = _conv_desc(dz, B, T_out, Tp, Cout, Cin, KW, dil, N.VP_PAD_ZERO, dil * (KW - 1), w2)
             d2.y = dxp.data_ptr()
             _chk(lib.vp_conv1d_fwd(hctx, C.byref(d2), N.stream_ptr()), hctx)
-            _chk(lib.vp_reflect_fold_f32(hctx, dxp.data_ptr(), B, T_in, pad_left, Cin, dx.data_ptr(), N.stream_ptr()), hctx)
+            if fold is not None:
+                into, add = fold['dx'], fold.get('add')
+                dx = torch.empty((B * T_in, Cin), dtype=torch.float32, device=dev) if add is not None else None
+                _chk(lib.vp_reflect_fold_into_f32(hctx, dxp.data_ptr(), B, T_in, pad_left, Cin, into.data_ptr(), into.stride(0),
+                                                  add.data_ptr() if add is not None else None, add.stride(0) if add is not None else 0,
+                                                  dx.data_ptr() if dx is not None else None, N.stream_ptr()), hctx)
+                fold = None
+            else:
+                _chk(lib.vp_reflect_fold_f32(hctx, dxp.data_ptr(), B, T_in, pad_left, Cin, dx.data_ptr(), N.stream_ptr()), hctx)
             if skip is not None:
                 dx += skip
         else:
@@ -201,6 +222,9 @@ def _conv_block_bwd(ctx, dy, skip=None):
             _chk(lib.vp_conv1d_fwd(hctx, C.byref(d2), N.stream_ptr()), hctx)
     elif skip is not None:
         dx = skip
+    if fold is not None and dx is not None:          # (a conv without reflect padding: the same hand-off with tensor ops)
+        fold['dx'].copy_(dx)
+        dx = dx + fold['add'] if fold.get('add') is not None else None
     return dx, dW, dbias, drb, dgamma, dbeta, None, None, None
 
 
@@ -245,6 +269,57 @@ class SEScale(torch.autograd.Function):
         _chk(lib.vp_scale_rows_bwd_f32(hctx, dy.data_ptr(), x.data_ptr(), s.data_ptr(), B, T, Cc, dx.data_ptr(), ds.data_ptr(),
                                        N.stream_ptr()), hctx)
         return dx, ds, dy, None, None
+
+
+class Res2Fn(torch.autograd.Function):
+    """Res2NetBlock (ecapa_tdnn.py:11-47) as one tape entry: y_0 = x_0, y_1 = f_1(x_1), y_i = f_i(x_i + y_{i-1}), concat -- f_i a
+    TDNNBlock (conv k3 'same' reflect -> ReLU -> BatchNorm).  Each chunk's BatchNorm pass writes y_i into its slice of the output and
+    the next chunk's input y_i + x_{i+1} beside it; in backward each chunk's reflect-fold writes d x_i into its slice of d x and hands
+    d y_{i-1} = d(input_i) + d out[:, i-1] on.  (As separate entries: 6 strided adds and a concatenation each way per block.)
+    params: for chunks 1..scale-1: conv weight, conv bias, BN weight, BN bias, BN running mean, BN running variance."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, *params):
+        x = _f32c(x)
+        B, T, S = cfg['B'], cfg['T'], cfg['scale']
+        w = x.shape[1] // S
+        out = torch.empty_like(x)
+        out[:, :w].copy_(x[:, :w])
+        inp = x[:, w:2 * w].contiguous()
+        saved, meta = [], []
+        for i in range(1, S):
+            wt, bs, g, b, rm, rv = params[6 * (i - 1):6 * i]
+            tp = _Tape((True,) * 9)
+            ConvBlock.forward(tp, inp, wt, bs, None, g, b, rm, rv,
+                              dict(B=B, T=T, dilation=cfg['dilation'], pad='reflect', relu=True, momentum=cfg['momentum'], eps=cfg['eps'],
+                                   y_into=out[:, i * w:(i + 1) * w], aux_add=x[:, (i + 1) * w:(i + 2) * w] if i + 1 < S else None))
+            inp = tp.aux_out
+            saved.extend(tp.saved_tensors)
+            meta.append((len(tp.saved_tensors), tp.geom))
+        ctx.save_for_backward(*saved)
+        ctx.meta, ctx.split = meta, (S, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = _f32c(dout)
+        S, w = ctx.split
+        saved, at, tapes = ctx.saved_tensors, 0, []
+        for n, geom in ctx.meta:
+            tp = _Tape((True,) * 9)
+            tp.saved_tensors, tp.geom = saved[at:at + n], geom
+            tapes.append(tp)
+            at += n
+        dx = torch.empty_like(dout)
+        dx[:, :w].copy_(dout[:, :w])
+        dy = dout[:, (S - 1) * w:].contiguous()
+        grads = [None] * (6 * (S - 1))
+        for i in range(S - 1, 0, -1):
+            r = _conv_block_bwd(tapes[i - 1], dy, None,
+                                dict(dx=dx[:, i * w:(i + 1) * w], add=dout[:, (i - 1) * w:i * w] if i > 1 else None))
+            dy = r[0]
+            grads[6 * (i - 1):6 * (i - 1) + 4] = [r[1], r[2], r[4], r[5]]
+        return (dx, None, *grads)
 
 
 class _Tape:
