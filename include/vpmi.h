@@ -554,6 +554,16 @@ size_t vp_bn_relu_bwd_dbias_workspace_bytes(long long M, int C);
 int vp_bn_relu_bwd_dbias_f32(vp_ctx* ctx, const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* invstd,
                              const float* gamma, const float* sums, long long M, int C, int relu_mask, float* dz, int lddz,
                              float* dbias, void* ws, size_t ws_bytes, vp_stream stream);
+/* Mixed precision, wide layers: operands that are already bf16 in memory.  vp_bn_relu_bwd_dbias_bf16out writes dz as bf16 (lddz in
+ * elements; dbias from the unrounded values); vp_conv1d_wgrad_bf16_oik takes x (d->x with d->dtype_in = VP_BF16) and dz both bf16
+ * and reduces dW (f32) into the model's (Cout, Cin, KW) layout.  The forward and data-gradient convs of such a layer are
+ * vp_conv1d_fwd with dtype_in = VP_BF16, dtype_out = VP_F32.  Same roundings as mfma_bf16 over f32 tensors (round-to-nearest-even of
+ * x, W and dz), half the operand bytes. */
+int vp_bn_relu_bwd_dbias_bf16out(vp_ctx* ctx, const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* invstd,
+                                 const float* gamma, const float* sums, long long M, int C, int relu_mask, void* dz, int lddz,
+                                 float* dbias, void* ws, size_t ws_bytes, vp_stream stream);
+int vp_conv1d_wgrad_bf16_oik(vp_ctx* ctx, const vp_conv1d_desc* d, const void* dz, int lddz, float* dW, void* ws, size_t ws_bytes,
+                             vp_stream stream);
 /* vp_pack_segments_f32: dst[offs[i] .. offs[i] + sizes[i]) = srcs[i] (zeros where srcs[i] is NULL), HOST arrays of n entries -- the
  * parameters' gradient tensors into the optimiser's flat buffer in one or two launches (what fleet's fused gradient buffers do for
  * the reference's DataParallel; trainer.py:213-229 only sees loss.backward() / optimizer.step()). */

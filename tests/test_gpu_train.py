@@ -758,3 +758,41 @@ def test_bn_relu_bwd_dbias_kernel_vs_float64(N, M, C, relu, gamma):
     assert torch.equal(dz == 0, dz0 == 0)      # ... but the ReLU mask is the same
     wdb = want.sum(0)
     assert (db.double().cpu() - wdb).abs().max().item() <= 2e-6 * want.abs().sum(0).max().item()
+
+
+def _tdnn_block_run(xs, w, b, gam, bet, dy, B, T, cat):
+    """One TDNNBlock (1x1 conv -> ReLU -> BatchNorm, batch statistics) forward + backward; cat: through CatConvBlock over xs."""
+    from ppvector.train.functions import CatConvBlock, ConvBlock
+    xs = [x.clone().requires_grad_() for x in xs]
+    w, b, gam, bet = (t.clone().requires_grad_() for t in (w, b, gam, bet))
+    rm, rv = torch.zeros_like(b), torch.ones_like(b)
+    cfg = dict(B=B, T=T, pad='reflect', relu=True, momentum=0.9, eps=1e-5)
+    if cat:
+        y = CatConvBlock.apply(cfg, w, b, gam, bet, rm, rv, *xs)
+    else:
+        y = ConvBlock.apply(torch.cat(xs, dim=1), w, b, None, gam, bet, rm, rv, cfg)
+    y.backward(dy)
+    return [y.detach(), rm, rv, w.grad, b.grad, gam.grad, bet.grad] + [x.grad for x in xs]
+
+
+@pytest.mark.parametrize('cat', [False, True])
+def test_wide_bf16_operands_equal_f32_operand_amp(N, amp, cat, monkeypatch):
+    """enable_amp, wide 1x1 TDNN blocks (M >= 16384, C >= 256): x and dz kept as bf16 tensors (bf16 -> f32 conv kernels, bf16-input
+    weight gradient, dz written as bf16 by the BatchNorm backward) must give what the f32-operand mixed-precision kernels give --
+    the same roundings, only the accumulation order differs.  cat: the MFA form (CatConvBlock builds the bf16 concatenation)."""
+    B, T, C, Cout = 64, 300, 256, 512
+    g = torch.Generator().manual_seed(5)
+    n_in = 2 if cat else 1
+    xs = [torch.randn(B * T, C, generator=g).cuda() for _ in range(n_in)]
+    w = (torch.randn(Cout, C * n_in, 1, generator=g) / (C * n_in) ** 0.5).cuda()
+    b, gam, bet = (torch.randn(Cout, generator=g).cuda() * s + o for s, o in ((0.3, 0.0), (0.2, 1.0), (0.2, 0.0)))
+    dy = torch.randn(B * T, Cout, generator=g).cuda()
+    monkeypatch.setenv('VPMI_TRAIN_BF16_OPS', '0')
+    ref = _tdnn_block_run(xs, w, b, gam, bet, dy, B, T, False)
+    monkeypatch.setenv('VPMI_TRAIN_BF16_OPS', '1')
+    got = _tdnn_block_run(xs, w, b, gam, bet, dy, B, T, cat)
+    names = ['y', 'running mean', 'running var', 'dW', 'dbias', 'dgamma', 'dbeta'] + [f'dx{i}' for i in range(n_in)]
+    for name, a, r in zip(names, got, ref):
+        e = rel(a, r)
+        print(f'[wide bf16 operands, cat={cat}] {name} rel-L2 {e:.2e}')
+        assert e < (2e-4 if name == 'dbias' else 2e-5), (name, e)

@@ -133,6 +133,10 @@ constexpr int WA_T = 128;              // tile edge of dW
 constexpr int WA_RC = 64;              // rows per staged chunk = two MFMA k-steps
 __device__ __forceinline__ int wa_L(int R) { return ((R >> 1) & 7) ^ ((R >> 4) & 1); }
 
+// BF: x and dz are already bf16 in memory (the wide layers' operands, see ConvBlock): 8-byte loads of four bf16, no rounding here.
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+
+template <bool BF>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_amp_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char wsm[];        // [2 stages][dz^T 16 KB | x^T 16 KB]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -154,18 +158,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_amp_kernel(WgradArgs a) {
     // 1x1 convs with identical input / output geometry (the wide layers): source row = output row
     const bool simple = a.K == a.Cin && a.stride == 1 && a.pad_left == 0 && a.T_in == a.T_out && a.F_in == 1 && a.F_out == 1;
 
-    float4 rdz[8], rx[8];
+    using ld_t = typename std::conditional<BF, uint2, float4>::type;
+    using el_t = typename std::conditional<BF, bf16_t, float>::type;
+    const el_t* __restrict__ gdz = reinterpret_cast<const el_t*>(a.dz);
+    const el_t* __restrict__ gx = reinterpret_cast<const el_t*>(a.x);
+    ld_t rdz[8], rx[8];
     auto gload = [&](int mbase) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int m = mbase + 8 * rg + r;
-            rdz[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-            rx[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rdz[r] = ld_t{};
+            rx[r] = ld_t{};
             if (m >= m_end) continue;
-            if (nvalid) rdz[r] = *reinterpret_cast<const float4*>(a.dz + (size_t)m * a.lddz + ncol);
+            if (nvalid) rdz[r] = *reinterpret_cast<const ld_t*>(gdz + (size_t)m * a.lddz + ncol);
             if (!kvalid) continue;
             if (simple) {
-                rx[r] = *reinterpret_cast<const float4*>(a.x + (size_t)m * a.ldx + a.xoff + cc);
+                rx[r] = *reinterpret_cast<const ld_t*>(gx + (size_t)m * a.ldx + a.xoff + cc);
             } else {
                 const int bt = m / a.F_out, f = m - bt * a.F_out;
                 const int b = bt / a.T_out, t = bt - b * a.T_out;
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_amp_kernel(WgradArgs a) {
                 } else {
                     ok = ok && traw >= 0 && traw < a.T_in;
                 }
-                if (ok) rx[r] = *reinterpret_cast<const float4*>(a.x + (((size_t)b * a.T_in + ts) * a.F_in + fs) * a.ldx + a.xoff + cc);
+                if (ok) rx[r] = *reinterpret_cast<const ld_t*>(gx + (((size_t)b * a.T_in + ts) * a.F_in + fs) * a.ldx + a.xoff + cc);
             }
         }
     };
@@ -188,17 +196,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_amp_kernel(WgradArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int R = 4 * cg + e;
-            bf16x8 vd, vx;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const float d = e == 0 ? rdz[r].x : (e == 1 ? rdz[r].y : (e == 2 ? rdz[r].z : rdz[r].w));
-                const float xv = e == 0 ? rx[r].x : (e == 1 ? rx[r].y : (e == 2 ? rx[r].z : rx[r].w));
-                vd[r] = (bf16_t)d;
-                vx[r] = (bf16_t)xv;
-            }
             const int pos = (rg ^ wa_L(R)) << 4;
-            *reinterpret_cast<bf16x8*>(dzs + R * 128 + pos) = vd;
-            *reinterpret_cast<bf16x8*>(xs + R * 128 + pos) = vx;
+            if constexpr (BF) {
+                u16x8 vd, vx;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const unsigned wd = e < 2 ? rdz[r].x : rdz[r].y, wx = e < 2 ? rx[r].x : rx[r].y;
+                    vd[r] = (unsigned short)((e & 1) ? (wd >> 16) : (wd & 0xffffu));
+                    vx[r] = (unsigned short)((e & 1) ? (wx >> 16) : (wx & 0xffffu));
+                }
+                *reinterpret_cast<u16x8*>(dzs + R * 128 + pos) = vd;
+                *reinterpret_cast<u16x8*>(xs + R * 128 + pos) = vx;
+            } else {
+                bf16x8 vd, vx;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float d = e == 0 ? rdz[r].x : (e == 1 ? rdz[r].y : (e == 2 ? rdz[r].z : rdz[r].w));
+                    const float xv = e == 0 ? rx[r].x : (e == 1 ? rx[r].y : (e == 2 ? rx[r].z : rx[r].w));
+                    vd[r] = (bf16_t)d;
+                    vx[r] = (bf16_t)xv;
+                }
+                *reinterpret_cast<bf16x8*>(dzs + R * 128 + pos) = vd;
+                *reinterpret_cast<bf16x8*>(xs + R * 128 + pos) = vx;
+            }
         }
     };
     f32x4 acc[4][4];
@@ -505,9 +525,13 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdArgs a) {
 // the conv in front of the ReLU) come out of the pass that writes dz instead of a second read of it.  part[chunk][C].
 struct BnBwdSumArgs { BnBwdArgs b; float* part; int M, rows_per_chunk, cl_shift; };
 
+// TO = bf16_t: dz leaves as bf16 (b.dz reinterpreted, lddz in elements) -- the operand the wide layers' data- and weight-gradient
+// GEMMs read (they would round it to bf16 anyway); the column sums are of the unrounded values.
+template <typename TO>
 __global__ __launch_bounds__(256) void bn_relu_bwd_dbias_kernel(BnBwdSumArgs p) {
     __shared__ float sm[256][4];
     const BnBwdArgs& a = p.b;
+    TO* __restrict__ gdz = reinterpret_cast<TO*>(a.dz);
     const int CL = 1 << p.cl_shift, RG = 256 >> p.cl_shift;
     const int lc = threadIdx.x & (CL - 1), rg = threadIdx.x >> p.cl_shift;
     const int c4 = blockIdx.x * CL + lc, c = c4 * 4, C = a.C4 * 4;
@@ -536,13 +560,13 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_dbias_kernel(BnBwdSumArgs p) 
                 vp_load4(a.z + (size_t)(m + u * RG) * a.ldz + c, z[u]);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { one(dy[u], z[u], o); vp_store4(a.dz + (size_t)(m + u * RG) * a.lddz + c, o); }
+            for (int u = 0; u < 4; ++u) { one(dy[u], z[u], o); vp_store4(gdz + (size_t)(m + u * RG) * a.lddz + c, o); }
         }
         for (; m < m1; m += RG) {
             float dy[4], z[4], o[4];
             vp_load4(a.dy + (size_t)m * a.lddy + c, dy); vp_load4(a.z + (size_t)m * a.ldz + c, z);
             one(dy, z, o);
-            vp_store4(a.dz + (size_t)m * a.lddz + c, o);
+            vp_store4(gdz + (size_t)m * a.lddz + c, o);
         }
     }
 #pragma unroll
@@ -969,7 +993,8 @@ size_t vp_conv1d_wgrad_workspace_bytes(const vp_conv1d_desc* d) {
 static int wgrad_impl(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int lddz, float* dW, void* ws, size_t ws_bytes,
                       vp_stream stream, bool oik) {
     if (!ctx || !d || !d->x || !dz || !dW) VP_FAIL(ctx, VP_EINVAL, "wgrad: null argument");
-    if (d->dtype_in != VP_F32) VP_FAIL(ctx, VP_EUNSUP, "wgrad: f32 tensors only (mfma_bf16 selects the bf16 matrix cores)");
+    const bool bf_in = d->dtype_in == VP_BF16;          // x AND dz bf16 in memory (vp_conv1d_wgrad_bf16_oik): bf16 matrix cores only
+    if (d->dtype_in != VP_F32 && !bf_in) VP_FAIL(ctx, VP_EUNSUP, "wgrad: f32 or bf16 tensors");
     const bool two_d = d->KF > 1 || d->F_in > 1 || d->F_out > 1;
     if (two_d && (d->KF < 1 || d->KW % d->KF || d->F_in < 1 || d->F_out < 1 || d->stride_f < 1 || d->pad_mode != VP_PAD_ZERO))
         VP_FAIL(ctx, VP_EINVAL, "wgrad: bad 2-D geometry (zero padding only)");
@@ -987,7 +1012,7 @@ static int wgrad_impl(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int
     if ((long long)S * 64 > M) S = (int)((M + 63) / 64);
     if ((d->Cin | d->Cout | d->ldx | d->xoff | lddz) & 3) VP_FAIL(ctx, VP_EINVAL, "wgrad: Cin / Cout / ldx / xoff / lddz must be multiples of 4");
     int rps = (int)((M + S - 1) / S);
-    const int rq = d->mfma_bf16 ? 64 : 32;                        // rows per staged chunk of the kernel
+    const int rq = (d->mfma_bf16 || bf_in) ? 64 : 32;             // rows per staged chunk of the kernel
     rps = (rps + rq - 1) / rq * rq;
     S = (int)((M + rps - 1) / rps);
     WgradArgs a;
@@ -998,14 +1023,17 @@ static int wgrad_impl(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int
     a.F_in = two_d ? d->F_in : 1; a.F_out = two_d ? d->F_out : 1; a.KF = two_d ? d->KF : 1;
     a.stride_f = two_d ? d->stride_f : 1; a.pad_f = two_d ? d->pad_f : 0;
     hipStream_t st = (hipStream_t)stream;
-    if (d->mfma_bf16) {
+    if (d->mfma_bf16 || bf_in) {
         constexpr int smem = 2 * 2 * WA_T * 128;
         static bool attr_set = false;
         if (!attr_set) {
-            VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_amp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_amp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_amp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
             attr_set = true;
         }
-        hipLaunchKernelGGL(conv_wgrad_amp_kernel, dim3((K + WA_T - 1) / WA_T, (d->Cout + WA_T - 1) / WA_T, S), dim3(256), smem, st, a);
+        const dim3 grid((K + WA_T - 1) / WA_T, (d->Cout + WA_T - 1) / WA_T, S);
+        if (bf_in) hipLaunchKernelGGL(conv_wgrad_amp_kernel<true>, grid, dim3(256), smem, st, a);
+        else hipLaunchKernelGGL(conv_wgrad_amp_kernel<false>, grid, dim3(256), smem, st, a);
     } else {
         hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tk, tn, S), dim3(256), 0, st, a);
     }
@@ -1025,6 +1053,13 @@ int vp_conv1d_wgrad_f32(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, i
 int vp_conv1d_wgrad_oik_f32(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int lddz, float* dW, void* ws, size_t ws_bytes,
                             vp_stream stream) {
     return wgrad_impl(ctx, d, dz, lddz, dW, ws, ws_bytes, stream, true);
+}
+
+// x (d->x, d->dtype_in == VP_BF16) and dz both bf16 in memory; dW f32 in the model's (Cout, Cin, KW) layout
+int vp_conv1d_wgrad_bf16_oik(vp_ctx* ctx, const vp_conv1d_desc* d, const void* dz, int lddz, float* dW, void* ws, size_t ws_bytes,
+                             vp_stream stream) {
+    if (!d || d->dtype_in != VP_BF16) VP_FAIL(ctx, VP_EINVAL, "wgrad_bf16: the descriptor's dtype_in must be bf16");
+    return wgrad_impl(ctx, d, (const float*)dz, lddz, dW, ws, ws_bytes, stream, true);
 }
 
 int vp_conv_weight_layouts_f32(vp_ctx* ctx, const float* w, int Cout, int Cin, int KW, float* wp, float* w2, vp_stream stream) {
@@ -1118,18 +1153,36 @@ size_t vp_bn_relu_bwd_dbias_workspace_bytes(long long M, int C) {
     return (size_t)1024 * C * sizeof(float) + 256;
 }
 
+static int bn_bwd_dbias_impl(vp_ctx* ctx, const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* invstd,
+                             const float* gamma, const float* sums, long long M, int C, int relu_mask, void* dz, int lddz, bool dz_bf16,
+                             float* dbias, void* ws, size_t ws_bytes, vp_stream stream);
+
 int vp_bn_relu_bwd_dbias_f32(vp_ctx* ctx, const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* invstd,
                              const float* gamma, const float* sums, long long M, int C, int relu_mask, float* dz, int lddz,
                              float* dbias, void* ws, size_t ws_bytes, vp_stream stream) {
+    return bn_bwd_dbias_impl(ctx, dy, lddy, z, ldz, mean, invstd, gamma, sums, M, C, relu_mask, dz, lddz, false, dbias, ws, ws_bytes, stream);
+}
+
+// the same with dz written as bf16 (lddz in elements): see bn_relu_bwd_dbias_kernel
+int vp_bn_relu_bwd_dbias_bf16out(vp_ctx* ctx, const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* invstd,
+                                 const float* gamma, const float* sums, long long M, int C, int relu_mask, void* dz, int lddz,
+                                 float* dbias, void* ws, size_t ws_bytes, vp_stream stream) {
+    return bn_bwd_dbias_impl(ctx, dy, lddy, z, ldz, mean, invstd, gamma, sums, M, C, relu_mask, dz, lddz, true, dbias, ws, ws_bytes, stream);
+}
+
+static int bn_bwd_dbias_impl(vp_ctx* ctx, const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* invstd,
+                             const float* gamma, const float* sums, long long M, int C, int relu_mask, void* dz, int lddz, bool dz_bf16,
+                             float* dbias, void* ws, size_t ws_bytes, vp_stream stream) {
     if (!ctx || !dy || !z || !mean || !invstd || !sums || !dz || !dbias || M <= 0 || M > 0x7fffffffLL || C <= 0 ||
-        (C | lddy | ldz | lddz) & 3 || (((uintptr_t)dy | (uintptr_t)z | (uintptr_t)dz) & 15))
+        (C | lddy | ldz | lddz) & 3 || (((uintptr_t)dy | (uintptr_t)z) & 15) || ((uintptr_t)dz & (dz_bf16 ? 7 : 15)))
         VP_FAIL(ctx, VP_EINVAL, "bn_relu_bwd_dbias: bad arguments");
     if (!ws || ws_bytes < vp_bn_relu_bwd_dbias_workspace_bytes(M, C)) VP_FAIL(ctx, VP_EWORKSPACE, "bn_relu_bwd_dbias: workspace too small");
     int cl_shift, colblocks, rpc, chunks;
     colsum4_geometry(M, C / 4, cl_shift, colblocks, rpc, chunks);
-    BnBwdSumArgs p{{dy, z, mean, invstd, gamma, sums, dz, lddy, ldz, lddz, C / 4, relu_mask, M}, (float*)ws, (int)M, rpc, cl_shift};
+    BnBwdSumArgs p{{dy, z, mean, invstd, gamma, sums, (float*)dz, lddy, ldz, lddz, C / 4, relu_mask, M}, (float*)ws, (int)M, rpc, cl_shift};
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_relu_bwd_dbias_kernel, dim3(colblocks, (unsigned)chunks), dim3(256), 0, st, p);
+    if (dz_bf16) hipLaunchKernelGGL(bn_relu_bwd_dbias_kernel<bf16_t>, dim3(colblocks, (unsigned)chunks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(bn_relu_bwd_dbias_kernel<float>, dim3(colblocks, (unsigned)chunks), dim3(256), 0, st, p);
     VP_LAUNCH_CHECK(ctx, "bn_relu_bwd_dbias");
     launch_sum_partials((const float*)ws, chunks, (long long)C, dbias, st);
     VP_LAUNCH_CHECK(ctx, "bn_relu_bwd_dbias_reduce");

@@ -5,7 +5,7 @@ chunking, the hand-off adds (y_{i-1} + x_i) and the two concatenations are tenso
 Input (B, T, F) f32 on the GPU -> embeddings (B, embd_dim)."""
 import torch
 
-from ppvector.train.functions import BNRows, ConvBlock, ConvBlockSkip, Res2Fn, SEBlockFn
+from ppvector.train.functions import BNRows, CatConvBlock, ConvBlock, ConvBlockSkip, Res2Fn, SEBlockFn
 from ppvector.train.tdnn_train import asp_forward
 
 
@@ -51,7 +51,9 @@ def ecapa_forward_train(m, feats):
     for blk in list(m.blocks)[1:]:
         x = se_res2net_block(blk, x, B, T)
         outs.append(x)
-    x = tdnn_block(m.mfa, torch.cat(outs, dim=1), B, T)
+    conv, norm = m.mfa.conv.conv, m.mfa.norm.norm
+    x = CatConvBlock.apply(dict(B=B, T=T, dilation=m.mfa.conv.dilation, pad='reflect', relu=True, momentum=norm.momentum, eps=norm.eps),
+                           conv.weight, conv.bias, norm.weight, norm.bias, norm._mean, norm._variance, *outs)
     p = asp_forward(m.asp, x, B, T)
     n = m.asp_bn.norm
     p = BNRows.apply(p, n.weight, n.bias, n._mean, n._variance, n.momentum, n.eps)

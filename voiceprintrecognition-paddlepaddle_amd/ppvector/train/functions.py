@@ -10,6 +10,7 @@ reference for free (ppvector/trainer.py:213-219: loss.backward()) is spelled out
   HeadLoss    cosine classifier + AAM-softmax loss      (models/fc.py:41-53, loss/aamloss.py:28-47)
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -63,13 +64,31 @@ def col_sums(a, b=None, bmean=None, bscale=None):
     return out
 
 
+def _wide_bf16(M, Cin, Cout, KW, bias, rowbias, gamma, cfg):
+    """Mixed precision, wide 1x1 TDNN blocks (tdnn1 / tdnn2 / MFA of ECAPA): the GEMM operands x and dz are kept as bf16 tensors --
+    what the matrix cores would round them to anyway -- so the forward, data-gradient and weight-gradient kernels read half the
+    bytes and skip the conversion (vp_conv1d_fwd bf16 -> f32, vp_conv1d_wgrad_bf16_oik).  VPMI_TRAIN_BF16_OPS=0 keeps f32 operands."""
+    return (ppvector.get_train_amp() and KW == 1 and gamma is not None and bias is not None and rowbias is None and Cin % 64 == 0
+            and Cin >= 256 and Cout >= 256 and Cout % 4 == 0 and M >= 16384 and not cfg.get('tanh', False)
+            and os.environ.get('VPMI_TRAIN_BF16_OPS', '1') != '0')
+
+
 class ConvBlock(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, rowbias, gamma, beta, run_mean, run_var, cfg):
         lib, hctx = N.lib(), N.ctx(x.device)
-        x, weight = _f32c(x), _f32c(weight)
+        weight = _f32c(weight)
         B, T_in, dil = cfg['B'], cfg['T'], cfg.get('dilation', 1)
         Cout, Cin, KW = weight.shape
+        wide = _wide_bf16(B * T_in, Cin, Cout, KW, bias, rowbias, gamma, cfg)
+        if x.dtype == torch.bfloat16:
+            if not wide:
+                raise N.VpmiError('ConvBlock: a bf16 input outside the wide mixed-precision layers')
+            x = x.contiguous()
+        else:
+            x = _f32c(x)
+            if wide:
+                x = x.to(torch.bfloat16)
         pad = cfg.get('pad', 'none')
         pad_left = 0 if pad == 'none' else dil * (KW - 1) // 2
         T_out = T_in - dil * (KW - 1) if pad == 'none' else T_in
@@ -87,7 +106,11 @@ class ConvBlock(torch.autograd.Function):
         else:
             wp = weight.view(Cout, Cin)
         z = torch.empty((B * T_out, Cout), dtype=torch.float32, device=x.device)
+        if wide:
+            wp = wp.to(torch.bfloat16)
         d = _conv_desc(x, B, T_in, T_out, Cin, Cout, KW, dil, _PAD[pad], pad_left, wp, bias, rowbias, relu)
+        if wide:
+            d.dtype_in = N.VP_BF16
         d.y = z.data_ptr()
         ps = pq = None
         if bn and lib.vp_conv1d_nseg(T_out) <= 8:              # the conv's fused column sums (utterances >= ~19 frames)
@@ -130,6 +153,7 @@ class ConvBlock(torch.autograd.Function):
             y = yt
         ctx.save_for_backward(x, weight, z, mean, invstd, gamma, y if tanh else None, w2)
         ctx.geom = (B, T_in, T_out, Cin, Cout, KW, dil, pad, pad_left, relu, bn, tanh, bias is not None, rowbias is not None)
+        ctx.wide = wide
         return y
 
     @staticmethod
@@ -148,6 +172,7 @@ def _conv_block_bwd(ctx, dy, skip=None, fold=None):
     dev = x.device
     dy = _f32c(dy)
     M = B * T_out
+    wide = getattr(ctx, 'wide', False)
     if tanh:
         t = torch.empty_like(dy)
         _chk(lib.vp_act_bwd_f32(hctx, tanh, dy.data_ptr(), yt.data_ptr(), dy.numel(), t.data_ptr(), N.stream_ptr()), hctx)
@@ -163,11 +188,12 @@ def _conv_block_bwd(ctx, dy, skip=None, fold=None):
             mu = torch.zeros(Cout, dtype=torch.float32, device=dev)
             istd = torch.ones(Cout, dtype=torch.float32, device=dev)
             g = None
-        dz = torch.empty_like(dy)
+        dz = torch.empty_like(dy, dtype=torch.bfloat16 if wide else torch.float32)
         if has_bias and Cout % 4 == 0:          # the bias gradient (column sums of dz) from the pass that writes dz
             dbias = torch.empty(Cout, dtype=torch.float32, device=dev)
             ws = _bytes(lib.vp_bn_relu_bwd_dbias_workspace_bytes(M, Cout), dev)
-            _chk(lib.vp_bn_relu_bwd_dbias_f32(hctx, dy.data_ptr(), Cout, z.data_ptr(), Cout, mu.data_ptr(), istd.data_ptr(),
+            fn = lib.vp_bn_relu_bwd_dbias_bf16out if wide else lib.vp_bn_relu_bwd_dbias_f32
+            _chk(fn(hctx, dy.data_ptr(), Cout, z.data_ptr(), Cout, mu.data_ptr(), istd.data_ptr(),
                                               g.data_ptr() if g is not None else None, sums.data_ptr(), M, Cout, int(relu),
                                               dz.data_ptr(), Cout, dbias.data_ptr(), ws.data_ptr(), ws.numel(),
                                               N.stream_ptr()), hctx)
@@ -187,13 +213,20 @@ def _conv_block_bwd(ctx, dy, skip=None, fold=None):
     d = _conv_desc(x, B, T_in, T_out, Cin, Cout, KW, dil, _PAD[pad], pad_left, weight)
     dW = torch.empty((Cout, Cin, KW), dtype=torch.float32, device=dev)      # reduced straight into the model's layout
     ws = _bytes(lib.vp_conv1d_wgrad_workspace_bytes(C.byref(d)), dev)
-    _chk(lib.vp_conv1d_wgrad_oik_f32(hctx, C.byref(d), dz.data_ptr(), Cout, dW.data_ptr(), ws.data_ptr(), ws.numel(),
-                                     N.stream_ptr()), hctx)
+    if wide:                                            # x (saved as bf16) and dz both bf16 in memory
+        d.dtype_in = N.VP_BF16
+        _chk(lib.vp_conv1d_wgrad_bf16_oik(hctx, C.byref(d), dz.data_ptr(), Cout, dW.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          N.stream_ptr()), hctx)
+    else:
+        _chk(lib.vp_conv1d_wgrad_oik_f32(hctx, C.byref(d), dz.data_ptr(), Cout, dW.data_ptr(), ws.data_ptr(), ws.numel(),
+                                         N.stream_ptr()), hctx)
     # data gradient: the forward kernel over dz with reversed taps and swapped channel roles
     dx = None
     if ctx.needs_input_grad[0]:
         if w2 is None:                                  # KW = 1: W^T
-            w2 = weight.view(Cout, Cin).t().contiguous()
+            w2 = weight.view(Cout, Cin).t().to(torch.bfloat16 if wide else torch.float32, memory_format=torch.contiguous_format)
+            if not wide:
+                w2 = w2.contiguous()
         dx = torch.empty((B * T_in, Cin), dtype=torch.float32, device=dev)
         if pad == 'reflect' and pad_left > 0:
             # gradient w.r.t. the reflect-PADDED input (a "full" zero-padded conv), then fold the mirrored frames back
@@ -215,6 +248,8 @@ def _conv_block_bwd(ctx, dy, skip=None, fold=None):
                 dx += skip
         else:
             d2 = _conv_desc(dz, B, T_out, T_in, Cout, Cin, KW, dil, N.VP_PAD_ZERO, dil * (KW - 1) - pad_left, w2)
+            if wide:
+                d2.dtype_in = N.VP_BF16
             d2.y = dx.data_ptr()
             if skip is not None:
                 skip = _f32c(skip)
@@ -226,6 +261,39 @@ def _conv_block_bwd(ctx, dy, skip=None, fold=None):
         fold['dx'].copy_(dx)
         dx = dx + fold['add'] if fold.get('add') is not None else None
     return dx, dW, dbias, drb, dgamma, dbeta, None, None, None
+
+
+class CatConvBlock(torch.autograd.Function):
+    """TDNNBlock over the channel concatenation of several (B*T, C_i) tensors -- the MFA layer (ecapa_tdnn.py:262-263) -- as one
+    tape entry.  In the wide mixed-precision mode the concatenation is built directly as the bf16 operand (one converting copy per
+    input into its slice; no f32 concatenation exists)."""
+
+    @staticmethod
+    def forward(ctx, cfg, weight, bias, gamma, beta, run_mean, run_var, *xs):
+        xs = [_f32c(x) for x in xs]
+        M, widths = xs[0].shape[0], [x.shape[1] for x in xs]
+        Cout, Cin, KW = weight.shape
+        if _wide_bf16(M, Cin, Cout, KW, bias, None, gamma, cfg):
+            xcat = torch.empty((M, Cin), dtype=torch.bfloat16, device=xs[0].device)
+            at = 0
+            for x, wd in zip(xs, widths):
+                xcat[:, at:at + wd].copy_(x)
+                at += wd
+        else:
+            xcat = torch.cat(xs, dim=1)
+        tp = _Tape((True,) * 9)
+        y = ConvBlock.forward(tp, xcat, weight, bias, None, gamma, beta, run_mean, run_var, cfg)
+        ctx.save_for_backward(*tp.saved_tensors)
+        ctx.inner = (tp.geom, tp.wide, widths)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        tp = _Tape((True,) * 9)
+        tp.saved_tensors = ctx.saved_tensors
+        tp.geom, tp.wide, widths = ctx.inner
+        r = _conv_block_bwd(tp, dy)
+        return (None, r[1], r[2], r[4], r[5], None, None, *r[0].split(widths, dim=1))
 
 
 class ConvBlockSkip(torch.autograd.Function):
