@@ -12,7 +12,7 @@ What moved: the reference builds features one utterance at a time on CPU DataLoa
 (`__train_epoch`, trainer.py:202-274).  Evaluation embeds the enrol / trial lists in eval mode and scores all trials with one
 cosine GEMM + the reference's EER / minDCF arithmetic (trainer.py:367-447 -> metric/metrics.py).  VisualDL logging, the
 parameter summary table and ``export`` (paddle.jit static graphs) have no counterpart: scalars go to the ``ppvector``
-logger, ``export`` raises.  AMP (``enable_amp``) is refused: the training engine is f32 (every shipped YAML sets False).
+logger, ``export`` raises.  AMP (``enable_amp``, trainer.py:209-229) selects the bf16 matrix cores with f32 master weights and statistics.
 """
 import logging
 import os
