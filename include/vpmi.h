@@ -571,6 +571,14 @@ int vp_pack_segments_f32(vp_ctx* ctx, const void* const* srcs, const long long* 
                          vp_stream stream);
 int vp_adam_step_f32(vp_ctx* ctx, float* param, const float* grad, float* m, float* v, long long n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, int step, float grad_scale, vp_stream stream);
+/* The other optimisers build_optimizer can name (optimizer/__init__.py:12-18 resolves any paddle.optimizer class; [3P-memory]
+ * update rules): vp_adamw_step_f32 = Adam with DECOUPLED decay p *= 1 - lr * coeff (paddle.optimizer.AdamW, coeff = weight_decay,
+ * default 0.01); vp_momentum_step_f32: g += wd * p; vel = mu * vel + g; p -= lr * vel, or p -= lr * (g + mu * vel) with
+ * use_nesterov (paddle.optimizer.Momentum; momentum = 0 is paddle.optimizer.SGD). */
+int vp_adamw_step_f32(vp_ctx* ctx, float* param, const float* grad, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                      float eps, float coeff, int step, float grad_scale, vp_stream stream);
+int vp_momentum_step_f32(vp_ctx* ctx, float* param, const float* grad, float* velocity, long long n, float lr, float momentum,
+                         float weight_decay, int use_nesterov, float grad_scale, vp_stream stream);
 
 /* ASP in training (models/pooling.py:69-125): per-utterance sums (gradient of the context bias), the global-context
  * statistics [mean | sqrt(max(var, eps))] and their backward, the backward of softmax-over-time + weighted mean/std

@@ -65,8 +65,16 @@ def tstp(x):
     return torch.cat((mean.flatten(1), std.flatten(1)), dim=1)
 
 
+def second_embedding(p, embed_a, training=False):
+    """two_emb_layer=True (eres2net.py:255-260, :455-460): relu -> seg_bn_1 (BatchNorm1D) -> seg_2 (Linear); the parameter set
+    carries 'seg_2.weight' only for such a model."""
+    if 'seg_2.weight' not in p:
+        return embed_a
+    return _bn(F.relu(embed_a), p, 'seg_bn_1.', training) @ p['seg_2.weight'] + p['seg_2.bias']
+
+
 def eres2net_forward(p, x, num_blocks=(3, 4, 6, 3), m_channels=32, expansion=2, base_width=32, scale=2, taps=None, training=False):
-    """ERes2Net.forward (eres2net.py:239-263), TSTP, two_emb_layer=False, eval mode.  x (B, T, F) -> (B, embd)."""
+    """ERes2Net.forward (eres2net.py:239-263), TSTP; two_emb_layer when p holds seg_2 (second_embedding).  x (B, T, F) -> (B, embd)."""
     x = x.transpose(1, 2).unsqueeze(1)
     out = F.relu(_bn(_c2d(x, p, 'conv1.', padding=1), p, 'bn1.', training))
     stage = []
@@ -83,7 +91,7 @@ def eres2net_forward(p, x, num_blocks=(3, 4, 6, 3), m_channels=32, expansion=2, 
     if taps is not None:
         taps.update(o1=o1, o2=o2, o3=o3, o4=o4, f12=f12, f123=f123, f1234=f1234)
     stats = tstp(f1234)
-    return stats @ p['seg_1.weight'] + p['seg_1.bias']
+    return second_embedding(p, stats @ p['seg_1.weight'] + p['seg_1.bias'], training)
 
 
 def eres2netv2_forward(p, x, num_blocks=(3, 4, 6, 3), m_channels=32, expansion=2, base_width=26, scale=2, training=False):
@@ -99,7 +107,7 @@ def eres2netv2_forward(p, x, num_blocks=(3, 4, 6, 3), m_channels=32, expansion=2
             out = block(out, p, f'layer{li}.{bi}.', (1 if li == 1 else 2) if bi == 0 else 1, width, scale, li >= 3, training)
         stage.append(out)
     f34 = aff(stage[3], _c2d(stage[2], p, 'layer3_ds.', stride=2, padding=1), p, 'fuse34.', training)
-    return tstp(f34) @ p['seg_1.weight'] + p['seg_1.bias']
+    return second_embedding(p, tstp(f34) @ p['seg_1.weight'] + p['seg_1.bias'], training)
 
 
 def _aff_params(p, pre, channels, rng, randomize_stats, r=4):
@@ -109,7 +117,7 @@ def _aff_params(p, pre, channels, rng, randomize_stats, r=4):
 
 
 def eres2net_params(input_size=80, embd_dim=192, num_blocks=(3, 4, 6, 3), m_channels=32, mul_channel=1, expansion=2, base_width=32,
-                    scale=2, seed=1000, randomize_stats=True, dtype=torch.float32, v2=False):
+                    scale=2, seed=1000, randomize_stats=True, dtype=torch.float32, v2=False, two_emb_layer=False):
     """Random ERes2Net parameters keyed with the reference's Paddle names (configs/eres2net.yml: m_channels 32, embd 192)."""
     rng = np.random.RandomState(seed)
     p = {}
@@ -148,4 +156,9 @@ def eres2net_params(input_size=80, embd_dim=192, num_blocks=(3, 4, 6, 3), m_chan
     b = 1.0 / math.sqrt(fin)
     p['seg_1.weight'] = rng.uniform(-b, b, (fin, embd_dim)) * math.sqrt(3.0)
     p['seg_1.bias'] = rng.uniform(-b, b, embd_dim)
+    if two_emb_layer:                                   # drawn after everything else: the other keys keep their values
+        p.update(_bn_keys('seg_bn_1.', embd_dim, rng, randomize_stats))
+        b2 = 1.0 / math.sqrt(embd_dim)
+        p['seg_2.weight'] = rng.uniform(-b2, b2, (embd_dim, embd_dim)) * math.sqrt(3.0)
+        p['seg_2.bias'] = rng.uniform(-b2, b2, embd_dim)
     return {k: torch.tensor(np.asarray(v), dtype=dtype) for k, v in p.items()}

@@ -119,3 +119,56 @@ def test_checkpoint_directory_save_resume_rotation(tmp_path):
     other = torch.nn.Sequential(TDNN(80, channels=32, embd_dim=32), SpeakerIdentification(32, 10))
     with pytest.raises(Exception):
         ck.load_checkpoint(cfg, other, Adam(other.parameters()), None, sched, None, 11, root, os.path.join(fam, 'best_model'))
+
+
+def test_momentum_state_round_trips_through_pdopt():
+    """Momentum's state leaves and returns under paddle's '<param>_velocity_0' keys; Adam's moments are not mixed up with it."""
+    from ppvector.optimizer import Momentum
+    m = _model()
+    opt = Momentum(m.parameters(), learning_rate=0.1, momentum=0.8, use_nesterov=True, weight_decay=1e-4)
+    opt.velocity.copy_(torch.randn(opt.velocity.numel())); opt.t = 3
+    pdopt = ck.optimizer_to_pdopt(opt, m)
+    k0 = next(k for k, _ in m.named_parameters())
+    assert f'{k0}_velocity_0' in pdopt and f'{k0}_moment1_0' not in pdopt and f'{k0}_beta1_pow_acc_0' not in pdopt
+    m2 = _model()
+    opt2 = Momentum(m2.parameters(), learning_rate=0.1)
+    assert ck.pdopt_to_optimizer(pdopt, opt2, m2) == []
+    assert torch.equal(opt.velocity, opt2.velocity)
+
+
+def test_optimizer_and_scheduler_factories():
+    """build_optimizer / build_lr_scheduler resolve names like the reference's getattr on its module
+    (ppvector/optimizer/__init__.py:12-33): the built classes, AttributeError for an unknown name, the filled-in defaults."""
+    import math
+    from ppvector import optimizer as O
+    m = _model()
+
+    def cfg(**oc):
+        return dict_to_object({'optimizer_conf': oc, 'train_conf': {'max_epoch': 10}})
+
+    for name, cls, args in (('Adam', O.Adam, {'weight_decay': 1e-6}), ('AdamW', O.AdamW, {}), ('SGD', O.SGD, {'weight_decay': 1e-4}),
+                            ('Momentum', O.Momentum, {'momentum': 0.95, 'use_nesterov': True})):
+        opt = O.build_optimizer(_model().parameters(), 1e-3, cfg(optimizer=name, optimizer_args=args))
+        assert type(opt) is cls
+    assert O.build_optimizer(_model().parameters(), 1e-3, cfg(optimizer='AdamW')).wd == pytest.approx(0.01)        # paddle's default
+    with pytest.raises(AttributeError):
+        O.build_optimizer(m.parameters(), 1e-3, cfg(optimizer='NoSuchOptimizer'))
+    with pytest.raises(NotImplementedError):
+        O.build_optimizer(m.parameters(), 1e-3, cfg(optimizer='Lamb'))
+    with pytest.raises(NotImplementedError):
+        O.build_optimizer(m.parameters(), 1e-3, cfg(optimizer='Adam', optimizer_args={'grad_clip': object()}))
+    s = O.build_lr_scheduler(7, cfg(scheduler='CosineAnnealingDecay', scheduler_args={'learning_rate': 0.01}))
+    assert s.T_max == int(10 * 1.2) * 7                                      # optimizer/__init__.py:24-25
+    lrs = []
+    for _ in range(s.T_max + 1):
+        lrs.append(s.get_lr()); s.step()
+    assert lrs[0] == pytest.approx(0.01) and lrs[-1] == pytest.approx(0.0, abs=1e-12) and lrs[s.T_max // 2] == pytest.approx(0.005)
+    # paddle steps it recursively: lr_t = eta + (1 + cos(pi t / T)) / (1 + cos(pi (t - 1) / T)) * (lr_{t-1} - eta); same values
+    rec, T = [0.01], s.T_max
+    for t in range(1, T):
+        rec.append((1 + math.cos(math.pi * t / T)) / (1 + math.cos(math.pi * (t - 1) / T)) * rec[-1])
+    assert max(abs(a - b) for a, b in zip(rec, lrs)) < 1e-12
+    w = O.build_lr_scheduler(7, cfg(scheduler='WarmupCosineSchedulerLR', scheduler_args={'learning_rate': 0.001, 'min_lr': 1e-5, 'warmup_epoch': 2}))
+    assert len(w.table) >= 70
+    with pytest.raises(NotImplementedError):
+        O.build_lr_scheduler(7, cfg(scheduler='StepDecay'))

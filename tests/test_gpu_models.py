@@ -132,11 +132,6 @@ def test_full_size_batch_invariance(ecapa):
 
 def test_unbuilt_model_variants_refuse():
     """What is not built refuses at construction, never a silent fallback."""
-    from ppvector.models.eres2net import ERes2Net, ERes2NetV2
-    with pytest.raises(NotImplementedError):
-        ERes2Net(80, two_emb_layer=True)
-    with pytest.raises(NotImplementedError):
-        ERes2NetV2(80, two_emb_layer=True)
     from ppvector.models.fc import DenseLayer
     with pytest.raises(NotImplementedError):
         DenseLayer(8, 8, config_str='batchnorm-prelu')

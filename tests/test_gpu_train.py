@@ -151,6 +151,41 @@ def test_adam_matches_formula(N):
         assert rel(p.detach(), r) < 1e-6
 
 
+@pytest.mark.parametrize('kind', ['AdamW', 'Momentum', 'Nesterov', 'SGD'])
+def test_other_optimizers_match_their_formulas(N, kind):
+    """paddle.optimizer.AdamW (decoupled decay), Momentum (plain and use_nesterov) and SGD on the flat buffers, three steps against
+    the update rules in float64 (optimizer/__init__.py:12-18 resolves any of them by name)."""
+    from ppvector import optimizer as O
+    g = torch.Generator().manual_seed(13)
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g).cuda()) for s in ((7, 5), (33,), (4, 3, 2))]
+    ref = [p.detach().double().cpu().clone() for p in ps]
+    st1, st2 = [torch.zeros_like(r) for r in ref], [torch.zeros_like(r) for r in ref]
+    lr, wd = 1e-2, 1e-2
+    opt = {'AdamW': lambda: O.AdamW(ps, learning_rate=lr, weight_decay=wd),
+           'Momentum': lambda: O.Momentum(ps, learning_rate=lr, momentum=0.9, weight_decay=wd),
+           'Nesterov': lambda: O.Momentum(ps, learning_rate=lr, momentum=0.9, use_nesterov=True, weight_decay=wd),
+           'SGD': lambda: O.SGD(ps, learning_rate=lr, weight_decay=wd)}[kind]()
+    for t in range(1, 4):
+        opt.clear_grad()
+        grads = [torch.randn(p.shape, generator=g) for p in ps]
+        for p, gr in zip(ps, grads):
+            p.grad = gr.cuda()
+        opt.step()
+        for i, gr in enumerate(grads):
+            gr = gr.double()
+            if kind == 'AdamW':
+                st1[i] = 0.9 * st1[i] + 0.1 * gr
+                st2[i] = 0.999 * st2[i] + 0.001 * gr * gr
+                ref[i] = ref[i] * (1 - lr * wd) - lr * (st1[i] / (1 - 0.9 ** t)) / (torch.sqrt(st2[i] / (1 - 0.999 ** t)) + 1e-8)
+            else:
+                mu = 0.0 if kind == 'SGD' else 0.9
+                gg = gr + wd * ref[i]
+                st1[i] = mu * st1[i] + gg
+                ref[i] = ref[i] - lr * (gg + mu * st1[i] if kind == 'Nesterov' else st1[i])
+    for p, r in zip(ps, ref):
+        assert rel(p.detach(), r) < 1e-6
+
+
 def test_tdnn_training_step_vs_oracle_autograd(N):
     """Whole training step of configs/tdnn.yml's model: loss, every parameter gradient and the running statistics
     against autograd over the oracle graph (train-mode BatchNorm), then one Adam step."""
@@ -367,15 +402,16 @@ def test_resnetse_training_step_vs_oracle_autograd(N):
     m.eval()
 
 
-def test_eres2net_training_step_vs_oracle_autograd(N):
+@pytest.mark.parametrize('two_emb', [False, True])
+def test_eres2net_training_step_vs_oracle_autograd(N, two_emb):
     """ERes2Net (configs/eres2net.yml architecture, one block per stage): both block kinds, the AFFs, the stride-2 fusion
-    convs and TSTP, against autograd over the oracle graph."""
+    convs and TSTP, against autograd over the oracle graph; two_emb: with the second embedding layer (eres2net.py:255-260)."""
     from oracle import eres2net as oer
     from ppvector.models.eres2net import ERes2Net
     from ppvector.train.functions import HeadLoss
-    B, T, Fdim, Cc = 3, 20, 16, 10
+    B, T, Fdim, Cc = (8 if two_emb else 3), 20, 16, 10          # (BatchNorm1D over the batch: more than 3 rows)
     nb = (1, 1, 1, 1)
-    p = oer.eres2net_params(Fdim, 192, num_blocks=nb, seed=13)
+    p = oer.eres2net_params(Fdim, 192, num_blocks=nb, seed=13, two_emb_layer=two_emb)
     g = torch.Generator().manual_seed(14)
     x = torch.randn(B, T, Fdim, generator=g) * 2
     labels = torch.randint(0, Cc, (B,), generator=g)
@@ -385,7 +421,7 @@ def test_eres2net_training_step_vs_oracle_autograd(N):
     emb_ref = oer.eres2net_forward(pr, x.double(), num_blocks=nb, training=True)
     loss_ref = om.aam_loss(om.cosine_head(emb_ref, Wr), labels, 0.2, 32.0, False, 0.0)
     loss_ref.backward()
-    m = ERes2Net(Fdim, num_blocks=list(nb))
+    m = ERes2Net(Fdim, num_blocks=list(nb), two_emb_layer=two_emb)
     m.load_state_dict(p)
     m = m.cuda().train()
     Wd = Wh.cuda().requires_grad_()
@@ -403,6 +439,12 @@ def test_eres2net_training_step_vs_oracle_autograd(N):
         if r > worst:
             worst, wk = r, k
         assert r < 5e-3, (k, r)
+    if two_emb:                                                     # and the eval path of the same model: folded BatchNorm + dense
+        m.eval()
+        p_run = {k: v.detach().double().cpu() for k, v in m.state_dict().items()}
+        with torch.no_grad():
+            e_eval = m(x.cuda())
+        assert rel(e_eval, oer.eres2net_forward(p_run, x.double(), num_blocks=nb)) < 1e-4
     print(f'[eres2net train] loss {loss.item():.5f} (oracle {loss_ref.item():.5f}); worst parameter-gradient rel-L2 {worst:.2e} ({wk})')
     m.eval()
 

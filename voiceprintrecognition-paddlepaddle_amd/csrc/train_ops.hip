@@ -584,15 +584,30 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_dbias_kernel(BnBwdSumArgs p) 
 // ---------------------------------------------------------------------------------------------- Adam (coupled L2)
 // paddle.optimizer.Adam(weight_decay=L2Decay-style float): g += wd * p;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
 // p -= lr * (m / (1 - b1^t)) / (sqrt(v / (1 - b2^t)) + eps)
+// keep = 1 - lr * coeff for paddle.optimizer.AdamW's DECOUPLED decay (the parameter shrinks first, the moments never see the decay);
+// 1 for Adam.
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2,
-                                                   float eps, float wd, float c1, float c2, float gscale) {
+                                                   float eps, float wd, float c1, float c2, float gscale, float keep) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float pv = p[i];
         const float gr = g[i] * gscale + wd * pv;
         const float mn = b1 * m[i] + (1.f - b1) * gr;
         const float vn = b2 * v[i] + (1.f - b2) * gr * gr;
         m[i] = mn; v[i] = vn;
-        p[i] = pv - lr * (mn / c1) / (sqrtf(vn / c2) + eps);
+        p[i] = pv * keep - lr * (mn / c1) / (sqrtf(vn / c2) + eps);
+    }
+}
+
+// paddle.optimizer.Momentum (and SGD = momentum 0): g += wd * p (L2Decay-style float);  vel = mu * vel + g;
+// p -= lr * vel, or with use_nesterov p -= lr * (g + mu * vel)
+__global__ __launch_bounds__(256) void momentum_kernel(float* p, const float* g, float* vel, long long n, float lr, float mu, float wd,
+                                                       float gscale, int nesterov) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float pv = p[i];
+        const float gr = g[i] * gscale + wd * pv;
+        const float vn = mu * vel[i] + gr;
+        vel[i] = vn;
+        p[i] = pv - lr * (nesterov ? gr + mu * vn : vn);
     }
 }
 
@@ -1194,8 +1209,27 @@ int vp_adam_step_f32(vp_ctx* ctx, float* param, const float* grad, float* m, flo
     if (!ctx || !param || !grad || !m || !v || n <= 0 || step < 1) VP_FAIL(ctx, VP_EINVAL, "adam: bad arguments");
     const float c1 = 1.f - powf(beta1, (float)step), c2 = 1.f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, lr, beta1, beta2, eps,
-                       weight_decay, c1, c2, grad_scale);
+                       weight_decay, c1, c2, grad_scale, 1.f);
     VP_LAUNCH_CHECK(ctx, "adam");
+    return VP_OK;
+}
+
+int vp_adamw_step_f32(vp_ctx* ctx, float* param, const float* grad, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                      float eps, float coeff, int step, float grad_scale, vp_stream stream) {
+    if (!ctx || !param || !grad || !m || !v || n <= 0 || step < 1) VP_FAIL(ctx, VP_EINVAL, "adamw: bad arguments");
+    const float c1 = 1.f - powf(beta1, (float)step), c2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, lr, beta1, beta2, eps,
+                       0.f, c1, c2, grad_scale, 1.f - lr * coeff);
+    VP_LAUNCH_CHECK(ctx, "adamw");
+    return VP_OK;
+}
+
+int vp_momentum_step_f32(vp_ctx* ctx, float* param, const float* grad, float* velocity, long long n, float lr, float momentum,
+                         float weight_decay, int use_nesterov, float grad_scale, vp_stream stream) {
+    if (!ctx || !param || !grad || !velocity || n <= 0) VP_FAIL(ctx, VP_EINVAL, "momentum: bad arguments");
+    hipLaunchKernelGGL(momentum_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, param, grad, velocity, n, lr, momentum,
+                       weight_decay, grad_scale, use_nesterov);
+    VP_LAUNCH_CHECK(ctx, "momentum");
     return VP_OK;
 }
 

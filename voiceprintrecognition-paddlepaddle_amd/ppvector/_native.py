@@ -224,6 +224,10 @@ _PROTOS = {
                                              c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'vp_conv1d_wgrad_bf16_oik': (c_int, [c_void_p, C.POINTER(Conv1dDesc), c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'vp_pack_segments_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    'vp_adamw_step_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_longlong, c_float, c_float, c_float, c_float,
+                                  c_float, c_int, c_float, c_void_p]),
+    'vp_momentum_step_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_longlong, c_float, c_float, c_float, c_int, c_float,
+                                     c_void_p]),
     'vp_adam_step_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_longlong, c_float, c_float, c_float, c_float,
                                  c_float, c_int, c_float, c_void_p]),
     'vp_utt_sums_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -8,6 +8,7 @@ zero-padded to multiples of 8 at pack time.  Training mode is built for ERes2Net
 """
 import math
 
+import torch
 from torch import nn
 
 from ppvector.models.campplus import _ConvNd
@@ -73,6 +74,34 @@ class BasicBlockERes2Net_diff_AFF(BasicBlockERes2Net):
     use_aff = True
 
 
+def _second_embedding(m, embed_a):
+    """two_emb_layer=True (eres2net.py:255-260 / :455-460): embed_b = seg_2(seg_bn_1(relu(embed_a))) on the (B, embd) output of the
+    engine (eval: ReLU, folded BatchNorm and the dense kernel; training: the Act / BNRows / Dense functions)."""
+    bn, lin = m.seg_bn_1, m.seg_2
+    if m.training and torch.is_grad_enabled() and embed_a.requires_grad:
+        from ppvector.train.functions import Act, BNRows, Dense
+        y = BNRows.apply(Act.apply(embed_a, 'relu'), bn.weight, bn.bias, bn._mean, bn._variance, bn.momentum, bn.eps)
+        return Dense.apply(y, lin.weight, lin.bias)
+    from ppvector import _native as N
+    with torch.no_grad():
+        y = embed_a.float().clone()
+        lib, ctx = N.lib(), N.ctx(y.device)
+        scale, shift = bn.folded()
+        N.check(lib.vp_act_f32(ctx, N.VP_ACT_RELU, y.data_ptr(), y.numel(), y.data_ptr(), N.stream_ptr()), ctx)
+        N.check(lib.vp_affine_rows_f32(ctx, y.data_ptr(), y.shape[1], scale.data_ptr(), shift.data_ptr(), y.shape[0], y.shape[1],
+                                       y.data_ptr(), y.shape[1], 0, N.stream_ptr()), ctx)
+        out = torch.empty((y.shape[0], lin.weight.shape[1]), dtype=torch.float32, device=y.device)
+        w = lin.weight.detach().float().contiguous()                # paddle Linear: [in, out]
+        N.check(lib.vp_dense_f32(ctx, y.data_ptr(), y.shape[1], w.data_ptr(), 1, lin.bias.detach().float().data_ptr(), y.shape[0],
+                                 out.shape[1], y.shape[1], N.VP_ACT_NONE, out.data_ptr(), out.shape[1], N.stream_ptr()), ctx)
+        return out
+
+
+def _forward_with_second_embedding(self, x, lengths=None):
+    emb = EngineMixin.forward(self, x, lengths)
+    return _second_embedding(self, emb) if self.two_emb_layer else emb
+
+
 class ERes2Net(EngineMixin, nn.Module):
     _engine_cls = Eres2netEngine
 
@@ -107,9 +136,11 @@ class ERes2Net(EngineMixin, nn.Module):
             raise Exception(f'没有{pooling_type}池化层！')
         self.seg_1 = _LinearParams(self.stats_dim * self.expansion * self.n_stats, embd_dim)
         if self.two_emb_layer:
-            raise NotImplementedError('two_emb_layer=True (ReLU -> BatchNorm -> second Linear) is not built on the HIP engine')
-        self.seg_bn_1 = nn.Identity()
-        self.seg_2 = nn.Identity()
+            self.seg_bn_1 = _BNParams(embd_dim)
+            self.seg_2 = _LinearParams(embd_dim, embd_dim)
+        else:
+            self.seg_bn_1 = nn.Identity()
+            self.seg_2 = nn.Identity()
 
     def _make_layer(self, block, planes, num_blocks, stride, base_width, scale):
         strides = [stride] + [1] * (num_blocks - 1)
@@ -119,6 +150,8 @@ class ERes2Net(EngineMixin, nn.Module):
             self.in_planes = planes * self.expansion
         return nn.Sequential(*layers)
 
+
+    forward = _forward_with_second_embedding
 
     def _train_forward(self, x):
         """Training mode: batch-statistics BatchNorm, autograd through libvpmi's backward entry points (f32 engine)."""
@@ -170,11 +203,14 @@ class ERes2NetV2(EngineMixin, nn.Module):
             raise Exception(f'没有{pooling_type}池化层！')
         self.seg_1 = _LinearParams(self.stats_dim * self.expansion * self.n_stats, embd_dim)
         if self.two_emb_layer:
-            raise NotImplementedError('two_emb_layer=True (ReLU -> BatchNorm -> second Linear) is not built on the HIP engine')
-        self.seg_bn_1 = nn.Identity()
-        self.seg_2 = nn.Identity()
+            self.seg_bn_1 = _BNParams(embd_dim)
+            self.seg_2 = _LinearParams(embd_dim, embd_dim)
+        else:
+            self.seg_bn_1 = nn.Identity()
+            self.seg_2 = nn.Identity()
 
     _make_layer = ERes2Net._make_layer
+    forward = _forward_with_second_embedding
 
     def _train_forward(self, x):
         """Training mode (f32 engine); stages 1-2 run on zero-padded chunk widths (train/eres2net_train.py)."""

@@ -95,8 +95,8 @@ def save_pdparams(state_dict, path, names=None):
 
 # ------------------------------------------------------------------------------------------------ optimizer state
 def optimizer_to_pdopt(optimizer, model, names=None):
-    """Adam state in paddle.optimizer.Adam.state_dict() form: '<param name>_moment1_0', '_moment2_0', '_beta1_pow_acc_0',
-    '_beta2_pow_acc_0' (the pow accumulators hold beta^(t+1) after t steps) and 'LR_Scheduler'."""
+    """Optimiser state in paddle's state_dict() form: Adam / AdamW '<param name>_moment1_0', '_moment2_0', '_beta1_pow_acc_0',
+    '_beta2_pow_acc_0' (the pow accumulators hold beta^(t+1) after t steps), Momentum '<param name>_velocity_0'; and 'LR_Scheduler'."""
     names = names or {}
     own = {id(p): k for k, p in model.named_parameters()}
     out = collections.OrderedDict()
@@ -104,10 +104,11 @@ def optimizer_to_pdopt(optimizer, model, names=None):
         key = own[id(p)]
         pn = names.get(key, key)
         off = optimizer._offset(p)
-        out[f'{pn}_moment1_0'] = _np(optimizer.m[off:off + p.numel()].view_as(p))
-        out[f'{pn}_moment2_0'] = _np(optimizer.v[off:off + p.numel()].view_as(p))
-        out[f'{pn}_beta1_pow_acc_0'] = np.asarray([optimizer.beta1 ** (optimizer.t + 1)], np.float32)
-        out[f'{pn}_beta2_pow_acc_0'] = np.asarray([optimizer.beta2 ** (optimizer.t + 1)], np.float32)
+        for suffix, buf in optimizer.state_slots():          # Adam / AdamW: moment1_0, moment2_0; Momentum: velocity_0
+            out[f'{pn}_{suffix}'] = _np(buf[off:off + p.numel()].view_as(p))
+        if hasattr(optimizer, 'beta1'):
+            out[f'{pn}_beta1_pow_acc_0'] = np.asarray([optimizer.beta1 ** (optimizer.t + 1)], np.float32)
+            out[f'{pn}_beta2_pow_acc_0'] = np.asarray([optimizer.beta2 ** (optimizer.t + 1)], np.float32)
     sched = optimizer.lr
     out['LR_Scheduler'] = {'last_epoch': int(getattr(sched, 'i', optimizer.t)), 'last_lr': float(optimizer.get_lr())}
     return out
@@ -121,15 +122,15 @@ def pdopt_to_optimizer(state, optimizer, model, names=None):
     for p in optimizer.params:
         key = own[id(p)]
         pn = names.get(key, key)
-        m1, m2 = state.get(f'{pn}_moment1_0'), state.get(f'{pn}_moment2_0')
-        if m1 is None or m2 is None or tuple(np.shape(m1)) != tuple(p.shape):
+        slots = [(state.get(f'{pn}_{suffix}'), buf) for suffix, buf in optimizer.state_slots()]
+        if any(a is None or tuple(np.shape(a)) != tuple(p.shape) for a, _ in slots):
             missing.append(key)
             continue
         off = optimizer._offset(p)
-        optimizer.m[off:off + p.numel()].copy_(torch.from_numpy(np.ascontiguousarray(m1)).reshape(-1))
-        optimizer.v[off:off + p.numel()].copy_(torch.from_numpy(np.ascontiguousarray(m2)).reshape(-1))
+        for a, buf in slots:
+            buf[off:off + p.numel()].copy_(torch.from_numpy(np.ascontiguousarray(a)).reshape(-1))
         b1 = state.get(f'{pn}_beta1_pow_acc_0')
-        if t is None and b1 is not None and 0.0 < float(np.reshape(b1, -1)[0]) < 1.0:
+        if t is None and b1 is not None and hasattr(optimizer, 'beta1') and 0.0 < float(np.reshape(b1, -1)[0]) < 1.0:
             t = int(round(math.log(float(np.reshape(b1, -1)[0])) / math.log(optimizer.beta1))) - 1
     if t is None:
         t = int((state.get('LR_Scheduler') or {}).get('last_epoch', 0))
