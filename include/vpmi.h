@@ -564,6 +564,16 @@ int vp_bn_relu_bwd_dbias_bf16out(vp_ctx* ctx, const float* dy, int lddy, const f
                                  float* dbias, void* ws, size_t ws_bytes, vp_stream stream);
 int vp_conv1d_wgrad_bf16_oik(vp_ctx* ctx, const vp_conv1d_desc* d, const void* dz, int lddz, float* dW, void* ws, size_t ws_bytes,
                              vp_stream stream);
+/* ... and the pre-BatchNorm activation z of such a layer kept as bf16 (the forward conv is then vp_conv1d_fwd bf16 -> bf16, i.e. the
+ * 256-wide LDS-DMA kernel, its fused column sums taken from the f32 accumulators): the BatchNorm apply, the two backward
+ * reductions and the backward itself with z (and dz) bf16 in memory, everything else f32 as in the functions they mirror. */
+int vp_affine_rows_b16_f32(vp_ctx* ctx, const void* z, int ldz, const float* scale, const float* shift, long long M, int C, float* y,
+                           int ldy, int relu, vp_stream stream);
+int vp_col_sums_f32_b16(vp_ctx* ctx, const float* a, int lda, const void* b, int ldb, const float* bmean, const float* bscale, long long M,
+                        int C, float* sums, void* ws, size_t ws_bytes, vp_stream stream);
+int vp_bn_relu_bwd_dbias_b16(vp_ctx* ctx, const float* dy, int lddy, const void* z, int ldz, const float* mean, const float* invstd,
+                             const float* gamma, const float* sums, long long M, int C, int relu_mask, void* dz, int lddz,
+                             float* dbias, void* ws, size_t ws_bytes, vp_stream stream);
 /* vp_pack_segments_f32: dst[offs[i] .. offs[i] + sizes[i]) = srcs[i] (zeros where srcs[i] is NULL), HOST arrays of n entries -- the
  * parameters' gradient tensors into the optimiser's flat buffer in one or two launches (what fleet's fused gradient buffers do for
  * the reference's DataParallel; trainer.py:213-229 only sees loss.backward() / optimizer.step()). */

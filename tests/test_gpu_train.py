@@ -817,11 +817,14 @@ def _tdnn_block_run(xs, w, b, gam, bet, dy, B, T, cat):
     return [y.detach(), rm, rv, w.grad, b.grad, gam.grad, bet.grad] + [x.grad for x in xs]
 
 
-@pytest.mark.parametrize('cat', [False, True])
-def test_wide_bf16_operands_equal_f32_operand_amp(N, amp, cat, monkeypatch):
-    """enable_amp, wide 1x1 TDNN blocks (M >= 16384, C >= 256): x and dz kept as bf16 tensors (bf16 -> f32 conv kernels, bf16-input
-    weight gradient, dz written as bf16 by the BatchNorm backward) must give what the f32-operand mixed-precision kernels give --
-    the same roundings, only the accumulation order differs.  cat: the MFA form (CatConvBlock builds the bf16 concatenation)."""
+@pytest.mark.parametrize('cat,level', [(False, 1), (True, 1), (False, 2), (True, 2)])
+def test_wide_bf16_operands_equal_f32_operand_amp(N, amp, cat, level, monkeypatch):
+    """enable_amp, wide 1x1 TDNN blocks (M >= 16384, C >= 256).  Level 1: x and dz kept as bf16 tensors (bf16 -> f32 conv kernels,
+    bf16-input weight gradient, dz written as bf16 by the BatchNorm backward) must give what the f32-operand mixed-precision kernels
+    give -- the same roundings, only the accumulation order differs (2e-5).  Level 2 (the default): the pre-BatchNorm activation z is
+    stored as bf16 too (forward on the 256-wide bf16 -> bf16 kernel, batch statistics from its f32 accumulators): ONE more rounding of
+    2^-9 relative per element of z, so outputs and gradients stay within 5e-3 rel-L2 of level 0 (measured ~1e-3).
+    cat: the MFA form (CatConvBlock builds the bf16 concatenation)."""
     B, T, C, Cout = 64, 300, 256, 512
     g = torch.Generator().manual_seed(5)
     n_in = 2 if cat else 1
@@ -831,10 +834,15 @@ def test_wide_bf16_operands_equal_f32_operand_amp(N, amp, cat, monkeypatch):
     dy = torch.randn(B * T, Cout, generator=g).cuda()
     monkeypatch.setenv('VPMI_TRAIN_BF16_OPS', '0')
     ref = _tdnn_block_run(xs, w, b, gam, bet, dy, B, T, False)
-    monkeypatch.setenv('VPMI_TRAIN_BF16_OPS', '1')
+    monkeypatch.setenv('VPMI_TRAIN_BF16_OPS', str(level))
     got = _tdnn_block_run(xs, w, b, gam, bet, dy, B, T, cat)
     names = ['y', 'running mean', 'running var', 'dW', 'dbias', 'dgamma', 'dbeta'] + [f'dx{i}' for i in range(n_in)]
     for name, a, r in zip(names, got, ref):
         e = rel(a, r)
-        print(f'[wide bf16 operands, cat={cat}] {name} rel-L2 {e:.2e}')
-        assert e < (2e-4 if name == 'dbias' else 2e-5), (name, e)
+        print(f'[wide bf16 operands level {level}, cat={cat}] {name} rel-L2 {e:.2e}')
+        if name.startswith('running'):
+            assert e < 2e-5, (name, e)               # statistics come from the f32 accumulators at every level
+        elif level == 1:
+            assert e < (2e-4 if name == 'dbias' else 2e-5), (name, e)
+        else:
+            assert e < (2e-2 if name == 'dbias' else 5e-3), (name, e)

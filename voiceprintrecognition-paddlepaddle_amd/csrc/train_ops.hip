@@ -360,8 +360,9 @@ __global__ __launch_bounds__(256) void col_sums_kernel(ColSumArgs p) {
 // over rows_per_chunk rows; CL = 64 / 32 / 16 by width so that 64-channel tensors (the Res2 convs) still fill the lanes.
 struct ColSum4Args { const float* a; const float* b; const float* bmean; const float* bscale; float* part; int lda, ldb, M, C4, rows_per_chunk, cl_shift; };
 
-template <bool HASB>
+template <bool HASB, typename TB = float>
 __global__ __launch_bounds__(256) void col_sums4_kernel(ColSum4Args p) {
+    const TB* __restrict__ gb = reinterpret_cast<const TB*>(p.b);
     __shared__ float sm[2][256][4];
     const int CL = 1 << p.cl_shift, RG = 256 >> p.cl_shift;
     const int lc = threadIdx.x & (CL - 1), rg = threadIdx.x >> p.cl_shift;
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(256) void col_sums4_kernel(ColSum4Args p) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 vp_load4(p.a + (size_t)(m + u * RG) * p.lda + c, av[u]);
-                if (HASB) vp_load4(p.b + (size_t)(m + u * RG) * p.ldb + c, bv[u]);
+                if (HASB) vp_load4(gb + (size_t)(m + u * RG) * p.ldb + c, bv[u]);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(256) void col_sums4_kernel(ColSum4Args p) {
         for (; m < m1; m += RG) {
             float av[4], bv[4];
             vp_load4(p.a + (size_t)m * p.lda + c, av);
-            if (HASB) vp_load4(p.b + (size_t)m * p.ldb + c, bv);
+            if (HASB) vp_load4(gb + (size_t)m * p.ldb + c, bv);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 s1[e] += av[e];
@@ -458,7 +459,8 @@ __global__ __launch_bounds__(256) void bn_train_finalize_kernel(BnFinArgs a) {
 }
 
 // y = z * scale + shift
-__global__ __launch_bounds__(256) void affine_rows_kernel(const float* z, int ldz, const float* scale, const float* shift, long long M,
+template <typename TZ>
+__global__ __launch_bounds__(256) void affine_rows_kernel(const TZ* z, int ldz, const float* scale, const float* shift, long long M,
                                                           int C4, float* y, int ldy, int relu) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < M * C4; i += (long long)gridDim.x * 256) {
         const long long m = i / C4;
@@ -527,11 +529,12 @@ struct BnBwdSumArgs { BnBwdArgs b; float* part; int M, rows_per_chunk, cl_shift;
 
 // TO = bf16_t: dz leaves as bf16 (b.dz reinterpreted, lddz in elements) -- the operand the wide layers' data- and weight-gradient
 // GEMMs read (they would round it to bf16 anyway); the column sums are of the unrounded values.
-template <typename TO>
+template <typename TO, typename TZ = float>
 __global__ __launch_bounds__(256) void bn_relu_bwd_dbias_kernel(BnBwdSumArgs p) {
     __shared__ float sm[256][4];
     const BnBwdArgs& a = p.b;
     TO* __restrict__ gdz = reinterpret_cast<TO*>(a.dz);
+    const TZ* __restrict__ gz = reinterpret_cast<const TZ*>(a.z);
     const int CL = 1 << p.cl_shift, RG = 256 >> p.cl_shift;
     const int lc = threadIdx.x & (CL - 1), rg = threadIdx.x >> p.cl_shift;
     const int c4 = blockIdx.x * CL + lc, c = c4 * 4, C = a.C4 * 4;
@@ -557,14 +560,14 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_dbias_kernel(BnBwdSumArgs p) 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 vp_load4(a.dy + (size_t)(m + u * RG) * a.lddy + c, dy[u]);
-                vp_load4(a.z + (size_t)(m + u * RG) * a.ldz + c, z[u]);
+                vp_load4(gz + (size_t)(m + u * RG) * a.ldz + c, z[u]);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) { one(dy[u], z[u], o); vp_store4(gdz + (size_t)(m + u * RG) * a.lddz + c, o); }
         }
         for (; m < m1; m += RG) {
             float dy[4], z[4], o[4];
-            vp_load4(a.dy + (size_t)m * a.lddy + c, dy); vp_load4(a.z + (size_t)m * a.ldz + c, z);
+            vp_load4(a.dy + (size_t)m * a.lddy + c, dy); vp_load4(gz + (size_t)m * a.ldz + c, z);
             one(dy, z, o);
             vp_store4(gdz + (size_t)m * a.lddz + c, o);
         }
@@ -1133,6 +1136,24 @@ int vp_col_sums_f32(vp_ctx* ctx, const float* a, int lda, const float* b, int ld
     return VP_OK;
 }
 
+// the same two sums with b stored as bf16 (ldb in elements): the BatchNorm-backward reductions over a bf16 pre-BN activation
+int vp_col_sums_f32_b16(vp_ctx* ctx, const float* a, int lda, const void* b, int ldb, const float* bmean, const float* bscale, long long M,
+                        int C, float* sums, void* ws, size_t ws_bytes, vp_stream stream) {
+    if (!ctx || !a || !b || !bmean || !bscale || !sums || M <= 0 || M > 0x7fffffffLL || C <= 0 || (C | lda | ldb) & 3 ||
+        ((uintptr_t)a & 15) || ((uintptr_t)b & 7))
+        VP_FAIL(ctx, VP_EINVAL, "col_sums_b16: bad arguments");
+    if (!ws || ws_bytes < vp_col_sums_workspace_bytes(M, C)) VP_FAIL(ctx, VP_EWORKSPACE, "col_sums_b16: workspace too small");
+    int cl_shift, colblocks, rpc, chunks;
+    colsum4_geometry(M, C / 4, cl_shift, colblocks, rpc, chunks);
+    ColSum4Args p{a, (const float*)b, bmean, bscale, (float*)ws, lda, ldb, (int)M, C / 4, rpc, cl_shift};
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((col_sums4_kernel<true, bf16_t>), dim3(colblocks, (unsigned)chunks), dim3(256), 0, st, p);
+    VP_LAUNCH_CHECK(ctx, "col_sums_b16");
+    launch_sum_partials((const float*)ws, chunks, (long long)2 * C, sums, st);
+    VP_LAUNCH_CHECK(ctx, "col_sums_b16_reduce");
+    return VP_OK;
+}
+
 int vp_bn_train_finalize(vp_ctx* ctx, const float* psum, const float* psumsq, int nparts, long long M, int C, const float* gamma,
                          const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* mean,
                          float* invstd, float* scale, float* shift, vp_stream stream) {
@@ -1147,8 +1168,18 @@ int vp_bn_train_finalize(vp_ctx* ctx, const float* psum, const float* psumsq, in
 int vp_affine_rows_f32(vp_ctx* ctx, const float* z, int ldz, const float* scale, const float* shift, long long M, int C, float* y,
                        int ldy, int relu, vp_stream stream) {
     if (!ctx || !z || !scale || !shift || !y || M <= 0 || C <= 0 || (C | ldz | ldy) & 3) VP_FAIL(ctx, VP_EINVAL, "affine_rows: bad arguments");
-    hipLaunchKernelGGL(affine_rows_kernel, dim3(grid1d(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, z, ldz, scale, shift, M, C / 4, y, ldy, relu);
+    hipLaunchKernelGGL(affine_rows_kernel<float>, dim3(grid1d(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, z, ldz, scale, shift, M, C / 4, y, ldy, relu);
     VP_LAUNCH_CHECK(ctx, "affine_rows");
+    return VP_OK;
+}
+
+// z stored as bf16 (the wide mixed-precision layers keep the conv output in the low precision, as Paddle's O1 does): y f32
+int vp_affine_rows_b16_f32(vp_ctx* ctx, const void* z, int ldz, const float* scale, const float* shift, long long M, int C, float* y,
+                           int ldy, int relu, vp_stream stream) {
+    if (!ctx || !z || !scale || !shift || !y || M <= 0 || C <= 0 || (C | ldz | ldy) & 3) VP_FAIL(ctx, VP_EINVAL, "affine_rows_b16: bad arguments");
+    hipLaunchKernelGGL(affine_rows_kernel<bf16_t>, dim3(grid1d(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z, ldz, scale,
+                       shift, M, C / 4, y, ldy, relu);
+    VP_LAUNCH_CHECK(ctx, "affine_rows_b16");
     return VP_OK;
 }
 
@@ -1168,9 +1199,9 @@ size_t vp_bn_relu_bwd_dbias_workspace_bytes(long long M, int C) {
     return (size_t)1024 * C * sizeof(float) + 256;
 }
 
-static int bn_bwd_dbias_impl(vp_ctx* ctx, const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* invstd,
+static int bn_bwd_dbias_impl(vp_ctx* ctx, const float* dy, int lddy, const void* z, int ldz, const float* mean, const float* invstd,
                              const float* gamma, const float* sums, long long M, int C, int relu_mask, void* dz, int lddz, bool dz_bf16,
-                             float* dbias, void* ws, size_t ws_bytes, vp_stream stream);
+                             float* dbias, void* ws, size_t ws_bytes, vp_stream stream, bool z_bf16 = false);
 
 int vp_bn_relu_bwd_dbias_f32(vp_ctx* ctx, const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* invstd,
                              const float* gamma, const float* sums, long long M, int C, int relu_mask, float* dz, int lddz,
@@ -1185,18 +1216,27 @@ int vp_bn_relu_bwd_dbias_bf16out(vp_ctx* ctx, const float* dy, int lddy, const f
     return bn_bwd_dbias_impl(ctx, dy, lddy, z, ldz, mean, invstd, gamma, sums, M, C, relu_mask, dz, lddz, true, dbias, ws, ws_bytes, stream);
 }
 
-static int bn_bwd_dbias_impl(vp_ctx* ctx, const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* invstd,
-                             const float* gamma, const float* sums, long long M, int C, int relu_mask, void* dz, int lddz, bool dz_bf16,
+// z AND dz bf16: the wide layers with the pre-BN activation kept in the low precision
+int vp_bn_relu_bwd_dbias_b16(vp_ctx* ctx, const float* dy, int lddy, const void* z, int ldz, const float* mean, const float* invstd,
+                             const float* gamma, const float* sums, long long M, int C, int relu_mask, void* dz, int lddz,
                              float* dbias, void* ws, size_t ws_bytes, vp_stream stream) {
+    return bn_bwd_dbias_impl(ctx, dy, lddy, z, ldz, mean, invstd, gamma, sums, M, C, relu_mask, dz, lddz, true, dbias, ws, ws_bytes, stream, true);
+}
+
+static int bn_bwd_dbias_impl(vp_ctx* ctx, const float* dy, int lddy, const void* z, int ldz, const float* mean, const float* invstd,
+                             const float* gamma, const float* sums, long long M, int C, int relu_mask, void* dz, int lddz, bool dz_bf16,
+                             float* dbias, void* ws, size_t ws_bytes, vp_stream stream, bool z_bf16) {
     if (!ctx || !dy || !z || !mean || !invstd || !sums || !dz || !dbias || M <= 0 || M > 0x7fffffffLL || C <= 0 ||
-        (C | lddy | ldz | lddz) & 3 || (((uintptr_t)dy | (uintptr_t)z) & 15) || ((uintptr_t)dz & (dz_bf16 ? 7 : 15)))
+        (C | lddy | ldz | lddz) & 3 || ((uintptr_t)dy & 15) || ((uintptr_t)z & (z_bf16 ? 7 : 15)) || ((uintptr_t)dz & (dz_bf16 ? 7 : 15)) ||
+        (z_bf16 && !dz_bf16))
         VP_FAIL(ctx, VP_EINVAL, "bn_relu_bwd_dbias: bad arguments");
     if (!ws || ws_bytes < vp_bn_relu_bwd_dbias_workspace_bytes(M, C)) VP_FAIL(ctx, VP_EWORKSPACE, "bn_relu_bwd_dbias: workspace too small");
     int cl_shift, colblocks, rpc, chunks;
     colsum4_geometry(M, C / 4, cl_shift, colblocks, rpc, chunks);
-    BnBwdSumArgs p{{dy, z, mean, invstd, gamma, sums, (float*)dz, lddy, ldz, lddz, C / 4, relu_mask, M}, (float*)ws, (int)M, rpc, cl_shift};
+    BnBwdSumArgs p{{dy, (const float*)z, mean, invstd, gamma, sums, (float*)dz, lddy, ldz, lddz, C / 4, relu_mask, M}, (float*)ws, (int)M, rpc, cl_shift};
     hipStream_t st = (hipStream_t)stream;
-    if (dz_bf16) hipLaunchKernelGGL(bn_relu_bwd_dbias_kernel<bf16_t>, dim3(colblocks, (unsigned)chunks), dim3(256), 0, st, p);
+    if (z_bf16) hipLaunchKernelGGL((bn_relu_bwd_dbias_kernel<bf16_t, bf16_t>), dim3(colblocks, (unsigned)chunks), dim3(256), 0, st, p);
+    else if (dz_bf16) hipLaunchKernelGGL(bn_relu_bwd_dbias_kernel<bf16_t>, dim3(colblocks, (unsigned)chunks), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(bn_relu_bwd_dbias_kernel<float>, dim3(colblocks, (unsigned)chunks), dim3(256), 0, st, p);
     VP_LAUNCH_CHECK(ctx, "bn_relu_bwd_dbias");
     launch_sum_partials((const float*)ws, chunks, (long long)C, dbias, st);

@@ -223,6 +223,11 @@ _PROTOS = {
     'vp_bn_relu_bwd_dbias_bf16out': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, C.c_longlong,
                                              c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'vp_conv1d_wgrad_bf16_oik': (c_int, [c_void_p, C.POINTER(Conv1dDesc), c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'vp_affine_rows_b16_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, C.c_longlong, c_int, c_void_p, c_int, c_int, c_void_p]),
+    'vp_col_sums_f32_b16': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, C.c_longlong, c_int, c_void_p,
+                                    c_void_p, c_size_t, c_void_p]),
+    'vp_bn_relu_bwd_dbias_b16': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, C.c_longlong,
+                                         c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'vp_pack_segments_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     'vp_adamw_step_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_longlong, c_float, c_float, c_float, c_float,
                                   c_float, c_int, c_float, c_void_p]),

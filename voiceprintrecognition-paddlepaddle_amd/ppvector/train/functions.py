@@ -68,9 +68,15 @@ def _wide_bf16(M, Cin, Cout, KW, bias, rowbias, gamma, cfg):
     """Mixed precision, wide 1x1 TDNN blocks (tdnn1 / tdnn2 / MFA of ECAPA): the GEMM operands x and dz are kept as bf16 tensors --
     what the matrix cores would round them to anyway -- so the forward, data-gradient and weight-gradient kernels read half the
     bytes and skip the conversion (vp_conv1d_fwd bf16 -> f32, vp_conv1d_wgrad_bf16_oik).  VPMI_TRAIN_BF16_OPS=0 keeps f32 operands."""
-    return (ppvector.get_train_amp() and KW == 1 and gamma is not None and bias is not None and rowbias is None and Cin % 64 == 0
-            and Cin >= 256 and Cout >= 256 and Cout % 4 == 0 and M >= 16384 and not cfg.get('tanh', False)
-            and os.environ.get('VPMI_TRAIN_BF16_OPS', '1') != '0')
+    if not (ppvector.get_train_amp() and KW == 1 and gamma is not None and bias is not None and rowbias is None and Cin % 64 == 0
+            and Cin >= 256 and Cout >= 256 and Cout % 4 == 0 and M >= 16384 and not cfg.get('tanh', False)):
+        return 0
+    return int(os.environ.get('VPMI_TRAIN_BF16_OPS', '2'))
+
+
+# _wide_bf16 levels: 1 = bf16 GEMM operands (x, dz), same roundings as the f32-operand kernels;  2 (default) = also the pre-BatchNorm
+# activation z stored as bf16 -- one more rounding (2^-9 relative per element, what Paddle's O1 does to every conv output) that lets
+# the forward run the 256-wide LDS-DMA kernel (bf16 -> bf16, statistics from the f32 accumulators) and halves z's three later reads.
 
 
 class ConvBlock(torch.autograd.Function):
@@ -105,12 +111,14 @@ class ConvBlock(torch.autograd.Function):
                                                 w2.data_ptr() if w2 is not None else None, N.stream_ptr()), hctx)
         else:
             wp = weight.view(Cout, Cin)
-        z = torch.empty((B * T_out, Cout), dtype=torch.float32, device=x.device)
+        z = torch.empty((B * T_out, Cout), dtype=torch.bfloat16 if wide >= 2 else torch.float32, device=x.device)
         if wide:
             wp = wp.to(torch.bfloat16)
         d = _conv_desc(x, B, T_in, T_out, Cin, Cout, KW, dil, _PAD[pad], pad_left, wp, bias, rowbias, relu)
         if wide:
             d.dtype_in = N.VP_BF16
+            if wide >= 2:
+                d.dtype_out = N.VP_BF16
         d.y = z.data_ptr()
         ps = pq = None
         if bn and lib.vp_conv1d_nseg(T_out) <= 8:              # the conv's fused column sums (utterances >= ~19 frames)
@@ -119,6 +127,8 @@ class ConvBlock(torch.autograd.Function):
             pq = torch.empty_like(ps)
             d.psum, d.psumsq = ps.data_ptr(), pq.data_ptr()
         _chk(lib.vp_conv1d_fwd(hctx, C.byref(d), N.stream_ptr()), hctx)
+        if bn and ps is None and wide >= 2:
+            raise N.VpmiError('ConvBlock: bf16 pre-BN activation needs the conv\'s fused column sums (utterances of >= ~19 frames)')
         if bn and ps is None:                                   # very short utterances: a separate column-sum pass
             zeros = torch.zeros(Cout, dtype=torch.float32, device=x.device)
             ones = torch.ones(Cout, dtype=torch.float32, device=x.device)
@@ -134,7 +144,11 @@ class ConvBlock(torch.autograd.Function):
                                           cfg.get('eps', 1e-5), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
                                           shift.data_ptr(), N.stream_ptr()), hctx)
             into, add = cfg.get('y_into'), cfg.get('aux_add')
-            if into is not None or add is not None:
+            if wide >= 2:
+                y = torch.empty(z.shape, dtype=torch.float32, device=x.device)
+                _chk(lib.vp_affine_rows_b16_f32(hctx, z.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(), B * T_out, Cout,
+                                                y.data_ptr(), Cout, 0, N.stream_ptr()), hctx)
+            elif into is not None or add is not None:
                 # y straight into a channel slice of a wider tensor, and aux = y + add (the next Res2Net chunk's input) in the same pass
                 y = into if into is not None else torch.empty_like(z)
                 aux = torch.empty_like(z) if add is not None else None
@@ -180,7 +194,13 @@ def _conv_block_bwd(ctx, dy, skip=None, fold=None):
     dgamma = dbeta = None
     if bn or relu:
         if bn:
-            sums = col_sums(dy, z, mean, invstd)
+            if z.dtype == torch.bfloat16:
+                sums = torch.empty((2, Cout), dtype=torch.float32, device=dev)
+                ws = _bytes(lib.vp_col_sums_workspace_bytes(M, Cout), dev)
+                _chk(lib.vp_col_sums_f32_b16(hctx, dy.data_ptr(), Cout, z.data_ptr(), Cout, mean.data_ptr(), invstd.data_ptr(), M, Cout,
+                                             sums.data_ptr(), ws.data_ptr(), ws.numel(), N.stream_ptr()), hctx)
+            else:
+                sums = col_sums(dy, z, mean, invstd)
             dgamma, dbeta = sums[1], sums[0]             # views of a buffer this call owns: no copies
             mu, istd, g = mean, invstd, gamma
         else:                                   # ReLU alone: the BN backward formula with identity statistics
@@ -192,7 +212,8 @@ def _conv_block_bwd(ctx, dy, skip=None, fold=None):
         if has_bias and Cout % 4 == 0:          # the bias gradient (column sums of dz) from the pass that writes dz
             dbias = torch.empty(Cout, dtype=torch.float32, device=dev)
             ws = _bytes(lib.vp_bn_relu_bwd_dbias_workspace_bytes(M, Cout), dev)
-            fn = lib.vp_bn_relu_bwd_dbias_bf16out if wide else lib.vp_bn_relu_bwd_dbias_f32
+            fn = (lib.vp_bn_relu_bwd_dbias_b16 if z.dtype == torch.bfloat16 else
+                  lib.vp_bn_relu_bwd_dbias_bf16out if wide else lib.vp_bn_relu_bwd_dbias_f32)
             _chk(fn(hctx, dy.data_ptr(), Cout, z.data_ptr(), Cout, mu.data_ptr(), istd.data_ptr(),
                                               g.data_ptr() if g is not None else None, sums.data_ptr(), M, Cout, int(relu),
                                               dz.data_ptr(), Cout, dbias.data_ptr(), ws.data_ptr(), ws.numel(),
