@@ -168,6 +168,7 @@ class ConvBlock(torch.autograd.Function):
         ctx.save_for_backward(x, weight, z, mean, invstd, gamma, y if tanh else None, w2)
         ctx.geom = (B, T_in, T_out, Cin, Cout, KW, dil, pad, pad_left, relu, bn, tanh, bias is not None, rowbias is not None)
         ctx.wide = wide
+        ctx.zero_dbias = bool(cfg.get('zero_bias_grad', False))
         return y
 
     @staticmethod
@@ -225,7 +226,10 @@ def _conv_block_bwd(ctx, dy, skip=None, fold=None):
             dbias = col_sums(dz)[0] if has_bias else None
     else:
         dz = dy
-        dbias = col_sums(dz)[0] if has_bias else None
+        if has_bias and getattr(ctx, 'zero_dbias', False):      # the caller knows sum_rows dz == 0 (a bias in front of a softmax over time)
+            dbias = torch.zeros(Cout, dtype=torch.float32, device=dev)
+        else:
+            dbias = col_sums(dz)[0] if has_bias else None
     drb = None
     if has_rb:
         drb = torch.empty((B, Cout), dtype=torch.float32, device=dev)
@@ -547,13 +551,15 @@ class AspFn(torch.autograd.Function):
             rowbias = ConvBlock.forward(t0, stats, w[:, Cc:].contiguous(), None, None, None, None, None, None, dict(B=B, T=1))
         h = ConvBlock.forward(t1, x, w[:, :Cc].contiguous() if gc else w, bias, rowbias, gamma, beta, run_mean, run_var,
                               dict(B=B, T=T, relu=True, tanh=True, momentum=cfg['momentum'], eps=cfg['eps']))
-        e = ConvBlock.forward(t2, h, w2, b2, None, None, None, None, None, dict(B=B, T=T))
+        # the logits' bias shifts every frame of an utterance alike and the softmax over time removes it: its gradient,
+        # sum_t alpha_t (dalpha_t - S) = S - S, is exactly zero -- no 469 MB column-sum pass over d e for it
+        e = ConvBlock.forward(t2, h, w2, b2, None, None, None, None, None, dict(B=B, T=T, zero_bias_grad=True))
         pooled = torch.empty((B, 2 * Cc), dtype=torch.float32, device=x.device)
         _chk(lib.vp_asp_softmax_stats(hctx, N.VP_F32, e.data_ptr(), x.data_ptr(), Cc, 0, B, T, Cc, 1e-12, pooled.data_ptr(),
                                       N.stream_ptr()), hctx)
         tapes = (t0, t1, t2) if gc else (t1, t2)
         ctx.save_for_backward(x, stats, e, pooled, *(t for tp in tapes for t in tp.saved_tensors))
-        ctx.tape_meta = [(len(tp.saved_tensors), tp.geom) for tp in tapes]
+        ctx.tape_meta = [(len(tp.saved_tensors), tp.geom, tp.zero_dbias) for tp in tapes]
         ctx.geom = (B, T, gc)
         return pooled
 
@@ -565,9 +571,9 @@ class AspFn(torch.autograd.Function):
         lib, hctx = N.lib(), N.ctx(x.device)
         Cc = x.shape[1]
         tapes, at = [], 4
-        for n, geom in ctx.tape_meta:
+        for n, geom, zero_dbias in ctx.tape_meta:
             tp = _Tape((True,) * 9)
-            tp.saved_tensors, tp.geom = saved[at:at + n], geom
+            tp.saved_tensors, tp.geom, tp.zero_dbias = saved[at:at + n], geom, zero_dbias
             tapes.append(tp)
             at += n
         t2, t1 = tapes[-1], tapes[-2]
