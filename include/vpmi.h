@@ -603,6 +603,10 @@ int vp_time_stats_bwd_f32(vp_ctx* ctx, const float* x, int ldx, const float* sta
                           int unbiased, float* dx, int lddx, vp_stream stream);
 int vp_attn_stats_bwd_f32(vp_ctx* ctx, const float* e, const float* x, int ldx, const float* pooled, const float* dpooled, int B, int T,
                           int C, float eps, float* de, float* dx, int lddx, vp_stream stream);
+/* vp_attn_stats_bwd_de16: the same with d e written as bf16 (mixed precision: the logits conv's data- and weight-gradient GEMMs read it
+ * through vp_conv1d_fwd bf16 -> f32 and vp_conv1d_wgrad_bf16_oik). */
+int vp_attn_stats_bwd_de16(vp_ctx* ctx, const float* e, const float* x, int ldx, const float* pooled, const float* dpooled, int B, int T,
+                           int C, float eps, void* de, float* dx, int lddx, vp_stream stream);
 int vp_act_f32(vp_ctx* ctx, int act /* VP_ACT_RELU .. VP_ACT_SILU; the backward takes the OUTPUT y, except SiLU: the input */, const float* x, long long n, float* y, vp_stream stream);
 int vp_act_bwd_f32(vp_ctx* ctx, int act, const float* dy, const float* y, long long n, float* dz, vp_stream stream);
 /* vp_reflect_fold_f32: adjoint of the reflect padding of Conv1d (models/utils.py:89-91): dxp (B, T + 2 pad, C) -> dx (B, T, C).

@@ -846,3 +846,35 @@ def test_wide_bf16_operands_equal_f32_operand_amp(N, amp, cat, level, monkeypatc
             assert e < (2e-4 if name == 'dbias' else 2e-5), (name, e)
         else:
             assert e < (2e-2 if name == 'dbias' else 5e-3), (name, e)
+
+
+def test_asp_bf16_logit_gradient_stays_within_bf16_of_the_f32_path(N, amp, monkeypatch):
+    """enable_amp, ASP at M >= 16384 rows: the statistics' backward writes d e as bf16 (vp_attn_stats_bwd_de16) and the logits conv's
+    two backward GEMMs read that tensor instead of rounding an f32 one on the fly -- the same rounding, so every gradient must
+    match the f32-d e path (VPMI_TRAIN_BF16_OPS=0) to accumulation order; the logits' bias gradient is exactly zero either way."""
+    from ppvector.models.pooling import AttentiveStatisticsPooling
+    from ppvector.train.tdnn_train import asp_forward
+    B, T, C = 64, 300, 256
+    torch.manual_seed(3)
+    asp = AttentiveStatisticsPooling(C, attention_channels=128, global_context=True).cuda().train()
+    x0 = torch.randn(B * T, C, device='cuda')
+    dp = torch.randn(B, 2 * C, device='cuda')
+
+    def run(level):
+        monkeypatch.setenv('VPMI_TRAIN_BF16_OPS', level)
+        for p in asp.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_()
+        out = asp_forward(asp, x, B, T)
+        out.backward(dp)
+        return [out.detach(), x.grad] + [p.grad for p in asp.parameters()], [n for n, _ in asp.named_parameters()]
+
+    ref, names = run('0')
+    got, _ = run('2')
+    for name, a, r in zip(['pooled', 'dx'] + names, got, ref):
+        if r.norm().item() < 1e-9:
+            assert a.abs().max().item() < 1e-6, name
+            continue
+        e = rel(a, r)
+        print(f'[asp de16] {name} rel-L2 {e:.2e}')
+        assert e < 2e-5, (name, e)

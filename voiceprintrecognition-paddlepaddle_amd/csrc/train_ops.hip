@@ -677,6 +677,8 @@ __global__ __launch_bounds__(256) void time_stats_bwd_kernel(TsBwdArgs a) {
 //   de_t = alpha_t (dalpha_t - S);   dx_t = alpha_t (dmu + 2 dv (x_t - mu))
 // One workgroup = 64 channels of one utterance, three passes over its frames (max; normaliser and S; outputs).
 struct AsBwdArgs { const float* e; const float* x; const float* pooled; const float* dpooled; float* de; float* dx; int ldx, lddx, T, C; float eps; };
+// TE = bf16_t: d e leaves as bf16 (a.de reinterpreted) -- the operand the logits conv's two backward GEMMs would round it to anyway
+template <typename TE>
 __global__ __launch_bounds__(256) void attn_stats_bwd_kernel(AsBwdArgs a) {
     __shared__ float sm[2][4][64];
     const int lc = threadIdx.x & 63, rg = threadIdx.x >> 6;
@@ -709,7 +711,7 @@ __global__ __launch_bounds__(256) void attn_stats_bwd_kernel(AsBwdArgs a) {
     for (int t = rg; t < a.T; t += 4) {
         const float al = expf(eb[(size_t)t * a.C] - mx) / z;
         const float xv = xb[(size_t)t * a.ldx], d = xv - mu;
-        a.de[((size_t)b * a.T + t) * a.C + c] = al * (dmu * xv + dv * d * d - S);
+        reinterpret_cast<TE*>(a.de)[((size_t)b * a.T + t) * a.C + c] = (TE)(al * (dmu * xv + dv * d * d - S));
         a.dx[((size_t)b * a.T + t) * a.lddx + c] = al * (dmu + 2.f * dv * d);
     }
 }
@@ -1331,8 +1333,18 @@ int vp_attn_stats_bwd_f32(vp_ctx* ctx, const float* e, const float* x, int ldx, 
                           int C, float eps, float* de, float* dx, int lddx, vp_stream stream) {
     if (!ctx || !e || !x || !pooled || !dpooled || !de || !dx || B <= 0 || T <= 0 || C <= 0 || B > 65535) VP_FAIL(ctx, VP_EINVAL, "attn_stats_bwd: bad arguments");
     AsBwdArgs a{e, x, pooled, dpooled, de, dx, ldx, lddx, T, C, eps};
-    hipLaunchKernelGGL(attn_stats_bwd_kernel, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(attn_stats_bwd_kernel<float>, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, a);
     VP_LAUNCH_CHECK(ctx, "attn_stats_bwd");
+    return VP_OK;
+}
+
+// d e written as bf16 ((B*T, C) dense): mixed precision, the logits conv's backward GEMMs then read bf16 operands
+int vp_attn_stats_bwd_de16(vp_ctx* ctx, const float* e, const float* x, int ldx, const float* pooled, const float* dpooled, int B, int T,
+                           int C, float eps, void* de, float* dx, int lddx, vp_stream stream) {
+    if (!ctx || !e || !x || !pooled || !dpooled || !de || !dx || B <= 0 || T <= 0 || C <= 0 || B > 65535) VP_FAIL(ctx, VP_EINVAL, "attn_stats_bwd: bad arguments");
+    AsBwdArgs a{e, x, pooled, dpooled, (float*)de, dx, ldx, lddx, T, C, eps};
+    hipLaunchKernelGGL(attn_stats_bwd_kernel<bf16_t>, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, a);
+    VP_LAUNCH_CHECK(ctx, "attn_stats_bwd_de16");
     return VP_OK;
 }
 

@@ -185,9 +185,18 @@ def _conv_block_bwd(ctx, dy, skip=None, fold=None):
     B, T_in, T_out, Cin, Cout, KW, dil, pad, pad_left, relu, bn, tanh, has_bias, has_rb = ctx.geom
     lib, hctx = N.lib(), N.ctx(x.device)
     dev = x.device
-    dy = _f32c(dy)
     M = B * T_out
     wide = getattr(ctx, 'wide', False)
+    if dy.dtype == torch.bfloat16:
+        # a plain conv (no BatchNorm / activation behind it) handed its output gradient as bf16 -- the ASP logits conv, whose d e the
+        # statistics' backward writes in that form: dz = dy is the bf16 GEMM operand, x (small here) is converted to match
+        if bn or relu or tanh or has_rb or KW != 1 or not ppvector.get_train_amp():
+            raise N.VpmiError('ConvBlock backward: a bf16 output gradient is only taken by a plain 1x1 conv under enable_amp')
+        dy, wide = dy.contiguous(), wide or 1
+        if x.dtype != torch.bfloat16:
+            x = x.to(torch.bfloat16)
+    else:
+        dy = _f32c(dy)
     if tanh:
         t = torch.empty_like(dy)
         _chk(lib.vp_act_bwd_f32(hctx, tanh, dy.data_ptr(), yt.data_ptr(), dy.numel(), t.data_ptr(), N.stream_ptr()), hctx)
@@ -229,7 +238,7 @@ def _conv_block_bwd(ctx, dy, skip=None, fold=None):
         if has_bias and getattr(ctx, 'zero_dbias', False):      # the caller knows sum_rows dz == 0 (a bias in front of a softmax over time)
             dbias = torch.zeros(Cout, dtype=torch.float32, device=dev)
         else:
-            dbias = col_sums(dz)[0] if has_bias else None
+            dbias = col_sums(dz if dz.dtype == torch.float32 else dz.float())[0] if has_bias else None
     drb = None
     if has_rb:
         drb = torch.empty((B, Cout), dtype=torch.float32, device=dev)
@@ -577,9 +586,12 @@ class AspFn(torch.autograd.Function):
             tapes.append(tp)
             at += n
         t2, t1 = tapes[-1], tapes[-2]
-        de, dx = torch.empty_like(e), torch.empty_like(x)
-        _chk(lib.vp_attn_stats_bwd_f32(hctx, e.data_ptr(), x.data_ptr(), Cc, pooled.data_ptr(), _f32c(dp).data_ptr(), B, T, Cc,
-                                       1e-12, de.data_ptr(), dx.data_ptr(), Cc, N.stream_ptr()), hctx)
+        de16 = ppvector.get_train_amp() and B * T >= 16384 and Cc % 4 == 0 and os.environ.get('VPMI_TRAIN_BF16_OPS', '2') != '0'
+        de = torch.empty_like(e, dtype=torch.bfloat16 if de16 else torch.float32)
+        dx = torch.empty_like(x)
+        fn = lib.vp_attn_stats_bwd_de16 if de16 else lib.vp_attn_stats_bwd_f32
+        _chk(fn(hctx, e.data_ptr(), x.data_ptr(), Cc, pooled.data_ptr(), _f32c(dp).data_ptr(), B, T, Cc, 1e-12, de.data_ptr(),
+                dx.data_ptr(), Cc, N.stream_ptr()), hctx)
         dh, dw2, db2 = _conv_block_bwd(t2, de)[:3]
         dx, dwx, dbias, drb, dgamma, dbeta = _conv_block_bwd(t1, dh, dx)[:6]        # dx: TDNN's + the weighted statistics'
         dw = dwx
