@@ -173,18 +173,22 @@ __global__ __launch_bounds__(C32_THREADS) void conv3x3_c32_kernel(const C32Args 
     // residual: the workgroup's output range of `res` (a descriptor of zero records when there is none: every load returns zero)
     const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.res ? a.res + out0 * C32 : a.x), 0,
                                                                          a.res ? (unsigned)(tvalid * 64) : 0u, 0x00020000);
-    for (int tile = wv; tile < ntile; tile += C32_THREADS / 64) {
+    // the residual in the accumulator layout (4 channels of position p); no residual, a position past the utterance or a tile past
+    // the last: an out-of-range offset, zeros.  Fetched TWO tiles of this wave ahead (two register sets, each refilled right after
+    // its use): issued at the top of its own tile the load's HBM latency sat exposed in every one of a wave's ~12 tiles --
+    // the residual convs ran 197 us at B = 256, F = 40 where the same conv without a residual took 100.
+    auto res_load = [&](int tile, u32x2_t (&r)[2]) {
+        const int p = tile * 16 + li;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            r[nt] = __builtin_amdgcn_raw_buffer_load_b64(rsrd, (tile < ntile && p < tvalid) ? (unsigned)(p * 64 + (nt * 16 + g * 4) * 2) : 0xfffffff0u, 0, 0);
+    };
+    auto do_tile = [&](int tile, const u32x2_t (&rraw)[2]) {
         const int p = tile * 16 + li;
         const int pc = min(p, npos - 1);
         const int tt = pc / a.F_out, fo = pc - tt * a.F_out;
         const char* base = slab + ((size_t)tt * Fp + fo * SF) * 64 + g * 16;     // tap (kt, kf): + (kt * Fp + kf) * 64
         f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0, s0 = acc0, s1 = acc0;
-        // the residual in the accumulator layout (4 channels of position p), fetched before the MFMAs; no residual or a position
-        // past the utterance: an out-of-range offset, zeros
-        u32x2_t rraw[2];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-            rraw[nt] = __builtin_amdgcn_raw_buffer_load_b64(rsrd, p < tvalid ? (unsigned)(p * 64 + (nt * 16 + g * 4) * 2) : 0xfffffff0u, 0, 0);
         bf16x8 xf[9];
 #pragma unroll
         for (int kt = 0; kt < 3; ++kt)
@@ -241,6 +245,18 @@ __global__ __launch_bounds__(C32_THREADS) void conv3x3_c32_kernel(const C32Args 
             }
         }
         __builtin_amdgcn_wave_barrier();
+    };
+    constexpr int WPG = C32_THREADS / 64;
+    u32x2_t rA[2], rB[2];
+    res_load(wv, rA);
+    res_load(wv + WPG, rB);
+    for (int tile = wv; tile < ntile; tile += 2 * WPG) {
+        do_tile(tile, rA);
+        res_load(tile + 2 * WPG, rA);
+        if (tile + WPG < ntile) {
+            do_tile(tile + WPG, rB);
+            res_load(tile + 3 * WPG, rB);
+        }
     }
 }
 
