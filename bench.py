@@ -324,47 +324,64 @@ def build_ecapa(dev, dtype_name):
     return fz, model, head, state, head_w
 
 
-def run_infer(args, rank, local_rank, world, dist):
+def make_infer_step(dev, dtype, streams, wav, labels, graph=True, parts=None):
+    """The timed step of --mode infer, built in ONE place (tests/test_gpu_timed_path.py checks exactly this object against the
+    oracle): waveforms resident in HBM -> Fbank + CMN -> ECAPA forward -> cosine head -> AAM loss; `streams` concurrent launch
+    sequences per GPU (each shard's featurizer + backbone on its own stream, head + loss over the whole batch behind the join),
+    the whole thing replayed from one captured HIP graph when `graph`.  Returns (run, info): run() -> loss scalar tensor (a static
+    buffer under a graph); info carries the modules, the last embeddings holder and whether the capture succeeded."""
     from ppvector.loss.aamloss import AAMLoss
+    fz, model, head, state, head_w = parts if parts is not None else build_ecapa(dev, dtype)
+    model.eval()
+    head.eval()                            # eval-mode forward: logits without the autograd tape
+    crit = AAMLoss(margin=0.2, scale=32, easy_margin=False, label_smoothing=0.0)
+    eng = model.engine(dtype)
+    want16 = dtype == 'bfloat16'
+    info = {'fz': fz, 'model': model, 'head': head, 'state': state, 'head_w': head_w, 'crit': crit, 'engine': eng, 'graph': False,
+            'emb': None}
+
+    def step():
+        if streams > 1:                    # featurizer + backbone of each shard on its own stream; head + loss over the whole batch
+            emb = eng.forward_streams(wav, streams, producer=lambda w: fz(w, want_bf16=want16))
+        else:
+            emb = eng.forward(fz(wav, want_bf16=want16))
+        info['emb'] = emb
+        return crit(head(emb), labels)
+
+    if not graph:
+        return step, info
+    # the whole step (every shard's featurizer + backbone on its stream, head + loss behind the join) as ONE captured HIP
+    # graph: with several launch sequences per GPU the host would otherwise issue ~40 launches per shard per step
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    try:
+        g = torch.cuda.CUDAGraph()
+        # thread-local error mode: with world > 1 the collective library's watchdog thread polls its events while we capture
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):
+            static_loss = step()
+        info['graph'] = True
+        info['hip_graph'] = g
+
+        def run():
+            g.replay()
+            return static_loss
+        return run, info
+    except Exception as e:                 # noqa: BLE001 -- a failed capture must not cost the measurement: launch eagerly
+        print(f'bench: HIP graph capture failed ({type(e).__name__}: {e}); launching eagerly', file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
+        return step, info
+
+
+def run_infer(args, rank, local_rank, world, dist):
     dev = torch.device('cuda', local_rank)
     # synthetic inputs, resident in HBM before the timed region (seed per rank: distinct shards)
     wav = torch.from_numpy(synth_waves(BATCH, N_SAMPLES, seed=shard_seed(1000, rank))).to(dev)
     labels = (torch.arange(BATCH, device=dev) * 7 + rank) % N_CLASSES
-    fz, model, head, state, head_w = build_ecapa(dev, args.dtype)
-    model.eval()
-    head.eval()                            # eval-mode forward: logits without the autograd tape
-    crit = AAMLoss(margin=0.2, scale=32, easy_margin=False, label_smoothing=0.0)
-    eng = model.engine(args.dtype)
+    run, info = make_infer_step(dev, args.dtype, args.streams, wav, labels, graph=bool(args.graph))
+    args.graph = int(info['graph'])
+    state, head_w = info['state'], info['head_w']
     want16 = args.dtype == 'bfloat16'
-
-    def step():
-        if args.streams > 1:               # featurizer + backbone of each shard on its own stream; head + loss over the whole batch
-            emb = eng.forward_streams(wav, args.streams, producer=lambda w: fz(w, want_bf16=want16))
-        else:
-            emb = eng.forward(fz(wav, want_bf16=want16))
-        return crit(head(emb), labels)
-
-    run = step
-    if args.graph:
-        # the whole step (every shard's featurizer + backbone on its stream, head + loss behind the join) as ONE captured HIP
-        # graph: with several launch sequences per GPU the host would otherwise issue ~40 launches per shard per step
-        for _ in range(3):
-            step()
-        torch.cuda.synchronize()
-        try:
-            graph = torch.cuda.CUDAGraph()
-            # thread-local error mode: with world > 1 the collective library's watchdog thread polls its events while we capture
-            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
-                static_loss = step()
-
-            def run():
-                graph.replay()
-                return static_loss
-        except Exception as e:             # noqa: BLE001 -- a failed capture must not cost the measurement: launch eagerly
-            print(f'bench: HIP graph capture failed ({type(e).__name__}: {e}); launching eagerly', file=sys.stderr, flush=True)
-            args.graph = 0
-            torch.cuda.synchronize()
-            run = step
 
     dt, loss = run_timed(run, args.steps, args.warmup, dist, dev)
     loss_v = float(loss)
@@ -403,8 +420,14 @@ def run_infer(args, rank, local_rank, world, dist):
             dog = threading.Timer(float(os.environ.get('VP_BENCH_TRAIN_TIMEOUT', '300')), bail, args=('dp_train did not finish in time',))
             dog.daemon = True
             dog.start()
+        dp_f32 = None
         try:
             dp_train = run_train(args, rank, local_rank, world, dist, steps=args.train_steps, warmup=3, emit=False)
+            # the reference's DEFAULT training precision (enable_amp: False in every shipped YAML, configs/ecapa_tdnn.yml:100):
+            # the same step on the exact-f32 matrix cores, a shorter run
+            a32 = argparse.Namespace(**vars(args))
+            a32.amp = 0
+            dp_f32 = run_train(a32, rank, local_rank, world, dist, steps=max(4, args.train_steps // 3), warmup=3, emit=False)
         except Exception as e:             # noqa: BLE001 -- anything here must not cost the headline line
             dp_err = f'{type(e).__name__}: {e}'[:300]
         if dog is not None:
@@ -421,6 +444,10 @@ def run_infer(args, rank, local_rank, world, dist):
         out['dp_train'] = {k: dp_train[k] for k in keep if k in dp_train}
         out['dp_train']['global_batch'] = dp_train['config']['global_batch']
         out['dp_train']['steps'] = dp_train['steps']
+        out['dp_train']['backward_stages'] = dp_train['config'].get('backward_stages')
+        if dp_f32 is not None:
+            out['dp_train_f32'] = {k: dp_f32[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'loss', 'stage_roofline_frac', 'steps')
+                                   if k in dp_f32}
     if world == 1 and not args.no_roofline and want16:
         out['roofline'] = roofline_pass(reps=10)
     if world == 1 and not args.no_cpu_baseline:
@@ -482,19 +509,18 @@ def run_train(args, rank, local_rank, world, dist, steps=None, warmup=None, emit
             allreduce_mean_(g, bucket_bytes=16 << 20)
         torch.cuda.synchronize()
         ar_ms = (time.perf_counter() - t0) / reps * 1e3
-        # the same step without the collective: hooks removed, nothing to finish (graph mode: the all-reduce call is skipped)
+        # the same step without the collective: hooks removed, nothing to finish (graph mode: the per-stage all-reduces are skipped)
         if step_obj.reducer is not None:
             step_obj.reducer.remove()
             step_obj.reducer.world = 1
-        else:
-            step_obj.skip_allreduce = True
+        step_obj.skip_allreduce = True
         dt0, _ = run_timed(step, max(5, steps // 4), 2, dist, dev)
         ms_nocomm = dt0 / max(5, steps // 4) * 1e3
         exposed = max(0.0, ms_step - ms_nocomm)
         comm = {'rccl_ranks': ranks, 'allreduce_ms': round(ar_ms, 4), 'allreduce_bytes': int(g.numel() * 4),
                 'allreduce_algbw_GBps': round(g.numel() * 4 / ar_ms / 1e6, 2), 'step_ms_without_collective': round(ms_nocomm, 4),
                 'comm_exposed_ms': round(exposed, 4), 'overlap_frac': round(1.0 - min(1.0, exposed / ar_ms), 4) if ar_ms > 0 else None,
-                'grad_buckets': len(step_obj.reducer.buckets) if step_obj.reducer is not None else -(-int(g.numel() * 4) // (16 << 20))}
+                'grad_buckets': len(step_obj.reducer.buckets) if step_obj.reducer is not None else max(1, getattr(step_obj, 'n_stages', 1))}
     if rank != 0:
         return None
     value = gbatch * steps / dt
@@ -509,10 +535,12 @@ def run_train(args, rank, local_rank, world, dist, steps=None, warmup=None, emit
                                
                                f'global batch {gbatch}, inputs resident in HBM, random-init weights',
                    'batch_per_gpu': B, 'global_batch': gbatch,
-                   'parallelism': (f'dp{world} (bucketed gradient all-reduce over RCCL, ' +
-                                   ('after the replayed backward)' if graphed and getattr(step_obj, 'capture_error', None) is None
-                                    else 'overlapped with backward)')) if world > 1 else 'dp1',
-                   'hip_graph': bool(graphed and getattr(step_obj, 'capture_error', None) is None)},
+                   'parallelism': (f'dp{world} (gradient all-reduce over RCCL, ' +
+                                   (f'one per backward stage under the next stage\'s graph replay: {step_obj.n_stages} stages)'
+                                    if graphed and getattr(step_obj, 'capture_error', None) is None
+                                    else 'bucketed, launched from autograd hooks while backward runs)')) if world > 1 else 'dp1',
+                   'hip_graph': bool(graphed and getattr(step_obj, 'capture_error', None) is None),
+                   'backward_stages': getattr(step_obj, 'n_stages', 1) if graphed else 1},
         'loss': round(loss_v, 5),
         'stage_roofline_frac': round(value * 3 * ALG_GFLOP_PER_UTT / 1e3 / world / (PEAK_BF16_TFLOPS if args.amp else PEAK_F32_TFLOPS), 4),
         'stage_roofline_peak': ('bf16 MFMA 2500' if args.amp else 'f32 MFMA 157.3') + ' TFLOP/s per GPU, 3 x forward flops per utterance',

@@ -41,6 +41,12 @@ int vp_version(void);
 vp_ctx* vp_create(int device);                      /* NULL on failure                                */
 void vp_destroy(vp_ctx* ctx);
 const char* vp_last_error(vp_ctx* ctx);             /* host string, valid until the next failing call */
+/* Margin of the margin-softmax losses as DEVICE data: table = 5 device floats [m, cos m, sin m, cos(pi - m), 1 + cos(pi - m)]
+ * (or NULL: back to the `margin` launch scalars).  While set, every loss entry point below reads the margin from the table
+ * when its kernel RUNS, so a launch sequence captured in a HIP graph follows MarginScheduler.step (optimizer/scheduler.py:69,76:
+ * criterion.update(margin=...) every step of the ramp) without being re-captured.  Replaces nothing in the reference: there the
+ * margin is a Python attribute read by eager ops (loss/aamloss.py:49-53). */
+int vp_set_margin_table(vp_ctx* ctx, const float* table);
 
 /* ------------------------------------------------------------------------------------------------
  * Fbank + CMN  -- replaces AudioFeaturizer.forward (ppvector/data_utils/featurizer.py:33-60) with

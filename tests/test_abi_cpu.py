@@ -223,3 +223,15 @@ def test_audio_segment_front_end(tmp_path):
     assert seg.sample_rate == 16000 and abs(len(seg.samples) - 16000) <= 1
     seg.normalize(target_db=-20)
     assert abs(seg.rms_db - (-20.0)) < 1e-3
+
+
+def test_optimizer_options_that_change_the_update_raise():
+    """paddle.optimizer.Adam keyword arguments: the ones that change the update rule and are not built must raise, not be
+    dropped (a config naming amsgrad=True would silently train with another optimiser); the no-ops are accepted."""
+    from ppvector.optimizer.adam import _no_unbuilt_options
+    _no_unbuilt_options('Adam', dict(name='x', lazy_mode=False, multi_precision=True, use_multi_tensor=False, amsgrad=False, rescale_grad=1.0))
+    for bad in (dict(amsgrad=True), dict(rescale_grad=0.5), dict(grad_clip=object())):
+        with pytest.raises(NotImplementedError):
+            _no_unbuilt_options('Adam', dict(bad))
+    with pytest.raises(TypeError):
+        _no_unbuilt_options('Adam', dict(no_such_option=1))

@@ -96,8 +96,8 @@ def _overlap_worker(rank, world, port, q):
     red = OverlappedReducer(opt, bucket_bytes=1024)                     # several buckets
     idx = list(shard_batch(10, rank, world))
     ((net(x[idx]) - y[idx]) ** 2).sum().div(len(idx)).backward()       # rank-local mean; equal shards -> mean of means = global mean
-    red.finish()
-    err = max((p.grad - r.grad).abs().max().item() for p, r in zip(net.parameters(), full.parameters()))
+    red.finish()                                                       # the flat buffer now holds the SUM over the ranks; the 1 / world
+    err = max((p.grad / world - r.grad).abs().max().item() for p, r in zip(net.parameters(), full.parameters()))   # rides on optimizer.step(grad_scale=)
     # second step as the trainer runs it: clear_grad() drops the .grad tensors, autograd hands over fresh ones, every bucket is
     # PACKED into the flat buffer just before its all-reduce, and the averaged gradients sit in the flat buffer only
     opt.clear_grad()
@@ -108,7 +108,7 @@ def _overlap_worker(rank, world, port, q):
     assert opt._packed
     for p, r in zip(net.parameters(), full.parameters()):
         o = opt._offset(p)
-        err = max(err, (opt.grad[o:o + p.numel()].view_as(r.grad) - r.grad).abs().max().item())
+        err = max(err, (opt.grad[o:o + p.numel()].view_as(r.grad) / world - r.grad).abs().max().item())
     q.put((rank, len(red.buckets), err))
     dist.barrier()
     dist.destroy_process_group()
@@ -197,3 +197,47 @@ def test_reducer_buckets_follow_backward_order():
     assert r.buckets[0][1] == o.grad.numel()                                # bucket 0 = the tail of the buffer
     assert r.bucket_of[o.params[-1]] == 0 and r.bucket_of[o.params[0]] == len(r.buckets) - 1
     assert len(r.buckets) >= 2
+
+
+def test_cut_points_split_backward_into_a_chain_of_stages():
+    """ppvector/train/segments.py on plain torch (CPU): a network with ECAPA's skip structure (every block output feeds the next
+    block AND a final concatenation) differentiated stage by stage -- last stage first, `between` called after each -- gives
+    exactly the gradients of one backward(); outside a Recorder `cut` is the identity."""
+    sys.path.insert(0, os.path.join(ROOT, 'voiceprintrecognition-paddlepaddle_amd'))
+    from ppvector.train.segments import Recorder, cut
+    torch.manual_seed(3)
+    blocks = [torch.nn.Linear(8, 8) for _ in range(4)]
+    tail = torch.nn.Linear(24, 5)
+
+    def forward(x):
+        x = torch.tanh(blocks[0](x))
+        outs = []
+        for b in blocks[1:]:
+            x = torch.tanh(b(x)) + x
+            outs.append(x)
+            outs = list(cut(*outs))
+            x = outs[-1]
+        return tail(torch.cat(outs, dim=1)).square().mean()
+
+    params = [p for m in blocks + [tail] for p in m.parameters()]
+    x = torch.randn(6, 8)
+    forward(x).backward()
+    ref = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    rec = Recorder()
+    order = []
+    with rec:
+        loss = forward(x)
+
+        def between(i):
+            order.append((i, sorted(k for k, p in enumerate(params) if p.grad is not None)))
+
+        rec.backward(loss, between)
+    assert rec.n_stages == 4 and [i for i, _ in order] == [0, 1, 2, 3]
+    # stage 0 = the tail only; each later stage adds exactly one earlier block (the first stage of the forward holds two)
+    assert order[0][1] == [8, 9] and order[1][1] == [6, 7, 8, 9] and order[2][1] == [4, 5, 6, 7, 8, 9] and order[3][1] == list(range(10))
+    for p, r in zip(params, ref):
+        assert torch.allclose(p.grad, r, rtol=1e-6, atol=1e-7)
+    a, b = torch.randn(2, requires_grad=True), torch.randn(2)
+    assert cut(a, b) == (a, b) or all(u is v for u, v in zip(cut(a, b), (a, b)))

@@ -347,13 +347,15 @@ def test_conv1d_split_destination(N, dtype):
 @pytest.mark.parametrize('case', [
     # B, T, Cin, Cout, kw, dil, pad  -- M = B*T >= 16384 rows, Cin % 64 == 0, Cout >= 256: the 256 x 256 LDS-DMA kernel
     (70, 241, 128, 320, 1, 1, 'reflect'),    # ragged M (not a multiple of 128), ragged N, utterances straddle tiles
+    (57, 298, 512, 512, 1, 1, 'reflect'),    # the SE-Res2 1x1 layers at the bench utterance length (8 K-steps; M % 128 != 0)
+    (60, 200, 192, 256, 1, 1, 'reflect'),    # odd K-step count (3): the ring's padded step must contribute zeros
     (66, 250, 64, 256, 3, 2, 'reflect'),     # taps: one tap per 64-wide K step, reflect at both utterance ends
     (64, 260, 128, 256, 3, 3, 'none'),       # un-padded (TDNN)
     (65, 255, 64, 384, 5, 1, 'zero'),        # zero padding = out-of-range DMA offsets
     (70, 241, 80, 512, 5, 1, 'reflect'),     # ECAPA block0 geometry: Cin % 64 != 0, K-steps straddle taps, ragged K tail
     (66, 250, 72, 256, 3, 2, 'zero'),
 ])
-@pytest.mark.parametrize('sched', [3, 4, 5])     # 3 = two-stage role-split schedule, 4 = half-tile ring (default), 5 = ring + resident workgroups
+@pytest.mark.parametrize('sched', [3, 4, 5, 6])  # 3 = two-stage role-split schedule, 4 = half-tile ring, 5 = ring + resident workgroups, 6 = 128 x 256 ring, two workgroups per CU
 def test_conv1d_wide_tiles_bf16(N, case, sched):
     prev = N.lib().vp_conv256_select(sched)
     try:

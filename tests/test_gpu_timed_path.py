@@ -1,0 +1,110 @@
+"""Parity of the path bench.py TIMES -- not a sibling of it.
+
+bench.py's headline step (BASELINE configs[1]) is `bench.make_infer_step`: waveforms -> Fbank + CMN -> ECAPA-TDNN forward -> cosine
+head -> AAM loss, the batch cut into shards that run as concurrent launch sequences on side streams (engine.forward_streams with
+the featurizer as each shard's producer), everything replayed from ONE captured HIP graph.  These tests hold exactly that object:
+  (a) forward_streams(wav, S, producer=featurizer) is bit-identical to forward(featurizer(wav)) for S = 2, 4, both engines;
+  (b) the captured graph, replayed twice with NEW inputs, reproduces the eager single-stream embeddings and loss bit for bit;
+  (c) wave -> oracle Fbank -> oracle ECAPA -> all-pairs cosine scores at B = 256 x 3 s (the oracle fed its OWN features, nothing
+      from the HIP front end) within north_star's 1e-4, for the bf16 engine the bench runs and for the f32 engine.
+Every measured value is printed (run with -s; the log is committed under profiles/)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fbank as ofb
+from oracle import models as om
+
+pytestmark = pytest.mark.gpu
+
+B, L, T = 256, 48000, 298
+
+
+@pytest.fixture(scope='module')
+def rig():
+    if not torch.cuda.is_available():
+        pytest.fail('no GPU visible: these tests must run on an MI355X (no CPU fallback exists)')
+    import bench
+    dev = torch.device('cuda', 0)
+    parts = {dt: bench.build_ecapa(dev, dt) for dt in ('bfloat16',)}
+    parts['float32'] = parts['bfloat16']              # same modules: the engine dtype is chosen per call
+    wavs = [torch.from_numpy(bench.synth_waves(B, L, seed=s)).to(dev) for s in (1000, 4321, 777)]
+    labels = (torch.arange(B, device=dev) * 7) % bench.N_CLASSES
+    return bench, dev, parts, wavs, labels
+
+
+@pytest.mark.parametrize('dtype', ['bfloat16', 'float32'])
+@pytest.mark.parametrize('streams', [2, 4])
+def test_forward_streams_with_producer_is_bit_identical(rig, dtype, streams):
+    bench, dev, parts, wavs, labels = rig
+    fz, model, head, _, _ = parts[dtype]
+    model.eval()
+    eng = model.engine(dtype)
+    want16 = dtype == 'bfloat16'
+    ref = eng.forward(fz(wavs[0], want_bf16=want16))
+    for rep in range(2):                               # twice: the shards' workspaces are reused
+        emb = eng.forward_streams(wavs[0], streams, producer=lambda w: fz(w, want_bf16=want16))
+        torch.cuda.synchronize()
+        assert emb.shape == (B, 192)
+        d = (emb - ref).abs().max().item()
+        print(f'[timed path] forward_streams S={streams} {dtype} rep {rep}: max |emb - single-stream emb| = {d:.1e} (bit-identical: {torch.equal(emb, ref)})')
+        assert torch.equal(emb, ref)
+
+
+@pytest.mark.parametrize('dtype', ['bfloat16', 'float32'])
+def test_captured_step_replays_equal_the_eager_single_stream_step(rig, dtype):
+    """bench.make_infer_step(streams=2, graph=True) -- the object run_infer times -- against the plain eager call chain on one
+    stream, on inputs the capture never saw."""
+    bench, dev, parts, wavs, labels = rig
+    static_wav = wavs[0].clone()
+    run, info = bench.make_infer_step(dev, dtype, 2, static_wav, labels, graph=True, parts=parts[dtype])
+    assert info['graph'], 'HIP graph capture of the bench step failed'
+    fz, model, head, crit = info['fz'], info['model'], info['head'], info['crit']
+    eng = model.engine(dtype)
+    want16 = dtype == 'bfloat16'
+    for k in (1, 2, 1):                                 # new inputs, then back again
+        static_wav.copy_(wavs[k])
+        loss_g = run()
+        torch.cuda.synchronize()
+        emb_g = info['emb'].clone()
+        loss_g = float(loss_g)
+        emb_e = eng.forward(fz(wavs[k], want_bf16=want16))
+        loss_e = float(crit(head(emb_e), labels))
+        d = (emb_g - emb_e).abs().max().item()
+        print(f'[timed path] graph replay {dtype} input {k}: loss {loss_g:.6f} vs eager {loss_e:.6f}; max |emb diff| {d:.1e}')
+        assert torch.equal(emb_g, emb_e)
+        assert loss_g == loss_e
+
+
+def test_bench_shape_scores_vs_oracle_on_its_own_features(rig):
+    """wave -> ORACLE Fbank + CMN -> ORACLE ECAPA (f32, CPU) -> all-pairs cosine scores of 256 utterances, against the timed HIP
+    path's embeddings (graph replay, 2 streams, bf16) and the f32 engine's.  north_star: scores within 1e-4 of the fp32
+    reference."""
+    bench, dev, parts, wavs, labels = rig
+    fz, model, head, state, head_w = parts['bfloat16']
+    w = wavs[1]
+    torch.set_num_threads(min(32, len(os.sched_getaffinity(0))))
+    feats_ref = ofb.featurize(w.cpu().numpy(), method_args=dict(sr=16000, n_mels=80))
+    assert feats_ref.shape == (B, T, 80)
+    with torch.no_grad():
+        ref = om.ecapa_forward({k: v.detach().cpu().float() for k, v in model.state_dict().items()}, torch.from_numpy(feats_ref)).double()
+    rn = ref / ref.norm(dim=1, keepdim=True)
+    sref = rn @ rn.t()
+    feats_hip = fz(w).cpu().numpy()
+    print(f'[timed path] Fbank+CMN at the bench shape: max |HIP - oracle| = {np.abs(feats_hip - feats_ref).max():.3e} (log-mel units)')
+    static_wav = w.clone()
+    res = {}
+    for dt in ('bfloat16', 'float32'):
+        run, info = bench.make_infer_step(dev, dt, 2, static_wav, labels, graph=True, parts=parts[dt])
+        run()
+        torch.cuda.synchronize()
+        e = info['emb'].double().cpu()
+        en = e / e.norm(dim=1, keepdim=True)
+        res[dt] = ((en @ en.t()) - sref).abs().max().item()
+        worst = (1 - (en * rn).sum(1)).max().item()
+        print(f'[timed path] wave -> scores, {dt} engine (graph, 2 streams) vs oracle on its OWN features: all-pairs ({B} x {B}) '
+              f'max |score - oracle| = {res[dt]:.3e}; worst 1 - cos(emb, oracle) = {worst:.3e}')
+    assert res['float32'] < 1e-4, res
+    assert res['bfloat16'] < 1e-4, res

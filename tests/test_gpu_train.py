@@ -1,5 +1,7 @@
 """GPU parity tests of the training path (f32 engine): every backward entry point and the whole TDNN training step
 against PyTorch autograd over the CPU oracle graph (float64 where cheap).  Run with -m gpu on an MI355X."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -703,49 +705,193 @@ def test_ecapa_training_step_mixed_precision(N, amp):
     m.eval()
 
 
-def test_graphed_train_step_equals_the_eager_step(N):
-    """GraphedTrainStep (forward + backward replayed from one captured HIP graph; all-reduce, Adam and the schedulers eager) against
-    TrainStep from the same initial state on the same batches: losses of every step, the trained parameters and the BatchNorm
-    running statistics.  Six steps: three eager warm-up steps inside GraphedTrainStep, the capture, two replays with NEW inputs
-    (the static buffers must be refreshed), and a changed loss margin (a launch scalar: must re-capture)."""
+def _graphed_vs_eager(make_model, xs, ys, n_classes, margin_at=None):
     from ppvector.loss.aamloss import AAMLoss
-    from ppvector.models.fc import SpeakerIdentification
-    from ppvector.models.tdnn import TDNN
     from ppvector.optimizer.adam import Adam
     from ppvector.train.step import GraphedTrainStep, TrainStep
-    g = torch.Generator().manual_seed(11)
-    xs = [(torch.randn(6, 90, 80, generator=g) * 2).cuda() for _ in range(7)]
-    ys = [torch.randint(0, 12, (6,), generator=g).cuda() for _ in range(7)]
 
     def run(cls):
         torch.manual_seed(0)
+        model = make_model()
+        crit = AAMLoss(margin=0.2, scale=32)
+        opt = Adam(model.parameters(), learning_rate=2e-3, weight_decay=1e-6)
+        step = cls(model, crit, opt)
+        losses, accs = [], []
+        for i, (x, y) in enumerate(zip(xs, ys)):
+            if margin_at is not None and i >= margin_at:
+                crit.update(0.2 + 0.05 * (i - margin_at + 1))    # MarginScheduler's ramp: a new margin every step
+            loss, acc = step(x, y)
+            losses.append(loss)                                   # collected as returned: every step must own its scalars
+            accs.append(acc)
+        torch.cuda.synchronize()
+        return [float(v) for v in losses], [float(v) for v in accs], {k: v.detach().clone() for k, v in model.state_dict().items()}, step
+
+    le, ae, se, _ = run(TrainStep)
+    lg, ag, sg, st = run(GraphedTrainStep)
+    assert st.capture_error is None, st.capture_error
+    assert st.n_stages >= 1 and len(st._plans) == 1               # ONE capture: the margin ramp must not re-capture
+    print(f'[graphed step, {st.n_stages} backward stage(s)] losses eager', [f'{v:.5f}' for v in le], 'graphed', [f'{v:.5f}' for v in lg])
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (le, lg)
+    assert ae == ag, (ae, ag)
+    worst = 0.0
+    for k in se:
+        d = (se[k].double() - sg[k].double()).abs().max().item()
+        worst = max(worst, d / max(1.0, se[k].abs().max().item()))
+        assert d <= 1e-5 * max(1.0, se[k].abs().max().item()), (k, d)
+    print(f'[graphed step] worst relative parameter / running-statistic difference after {len(xs)} steps: {worst:.2e}')
+    return st
+
+
+def test_graphed_train_step_equals_the_eager_step(N):
+    """GraphedTrainStep (forward + backward replayed from captured HIP graphs; all-reduce, Adam and the schedulers eager) against
+    TrainStep from the same initial state on the same batches: losses and accuracies of every step, the trained parameters and
+    the BatchNorm running statistics.  Eight steps: three eager sightings of the shape, the capture, replays with NEW inputs (the
+    static buffers must be refreshed) and a loss margin that changes on every one of the last three steps -- device data
+    (vp_set_margin_table): the graph must follow it WITHOUT a re-capture."""
+    from ppvector.models.fc import SpeakerIdentification
+    from ppvector.models.tdnn import TDNN
+    g = torch.Generator().manual_seed(11)
+    xs = [(torch.randn(6, 90, 80, generator=g) * 2).cuda() for _ in range(8)]
+    ys = [torch.randint(0, 12, (6,), generator=g).cuda() for _ in range(8)]
+
+    def make():
         m = TDNN(80)
         m.load_state_dict(om.tdnn_params(80, seed=5))
         head = SpeakerIdentification(192, 12)
         head.load_state_dict({'weight': om.head_params(192, 12, seed=6)})
-        model = torch.nn.Sequential(m, head).cuda()
-        crit = AAMLoss(margin=0.2, scale=32)
-        opt = Adam(model.parameters(), learning_rate=2e-3, weight_decay=1e-6)
-        step = cls(model, crit, opt)
-        losses = []
-        for i, (x, y) in enumerate(zip(xs, ys)):
-            if i == 6:
-                crit.update(0.3)
-            loss, acc = step(x, y)
-            losses.append(float(loss))
-        torch.cuda.synchronize()
-        return losses, {k: v.detach().clone() for k, v in model.state_dict().items()}, step
+        return torch.nn.Sequential(m, head).cuda()
 
-    le, se, _ = run(TrainStep)
-    lg, sg, st = run(GraphedTrainStep)
-    assert st.capture_error is None, st.capture_error
-    assert st._graph is not None
-    print('[graphed step] losses eager', [f'{v:.5f}' for v in le], 'graphed', [f'{v:.5f}' for v in lg])
-    for a, b in zip(le, lg):
-        assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (le, lg)
-    for k in se:
-        d = (se[k].double() - sg[k].double()).abs().max().item()
-        assert d <= 1e-5 * max(1.0, se[k].abs().max().item()), (k, d)
+    st = _graphed_vs_eager(make, xs, ys, 12, margin_at=5)
+    assert st.n_stages == 1                                       # TDNN declares no cut points
+
+
+def test_graphed_ecapa_step_in_backward_stages_equals_the_eager_step(N):
+    """ECAPA-TDNN declares cut points after every SE-Res2 block (train/ecapa_train.py): the captured step is FOUR graphs (head + ASP +
+    MFA | block 3 | block 2 | blocks 0-1), each ending with its gradients gathered into the flat buffer -- the slices a data-parallel
+    run all-reduces while the next graph replays.  Same losses, parameters and running statistics as the eager step, and the
+    stages' flat-buffer spans tile the gradient buffer exactly, last parameters first."""
+    from ppvector.models.ecapa_tdnn import EcapaTdnn
+    from ppvector.models.fc import SpeakerIdentification
+    g = torch.Generator().manual_seed(12)
+    xs = [(torch.randn(5, 140, 80, generator=g) * 2).cuda() for _ in range(7)]
+    ys = [torch.randint(0, 9, (5,), generator=g).cuda() for _ in range(7)]
+
+    def make():
+        m = EcapaTdnn(80, embd_dim=192, pooling_type='ASP', channels=[512, 512, 512, 512, 1536])
+        m.load_state_dict(om.ecapa_params(80, seed=21))
+        head = SpeakerIdentification(192, 9)
+        head.load_state_dict({'weight': om.head_params(192, 9, seed=22)})
+        return torch.nn.Sequential(m, head).cuda()
+
+    st = _graphed_vs_eager(make, xs, ys, 9, margin_at=5)
+    assert st.n_stages == 4
+    plan = next(iter(st._plans.values()))
+    spans = [sp for stage in plan['spans'] for sp in stage]
+    assert all(len(stage) == 1 for stage in plan['spans']), plan['spans']        # registration order = forward order: one slice per stage
+    assert spans[0][1] == st.optimizer.grad.numel() and spans[-1][0] == 0
+    assert all(a[0] == b[1] for a, b in zip(spans, spans[1:])), spans           # later stages = earlier parameters, no gap, no overlap
+    print('[graphed ecapa] flat-gradient slices per backward stage (elements):', spans)
+
+
+def _two_rank_graphed_worker(rank, world, port, q):
+    import os
+    import sys
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)                                       # both ranks share the one GPU of the test box; gloo carries the sums
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from oracle import models as om
+    from ppvector.loss.aamloss import AAMLoss
+    from ppvector.models.ecapa_tdnn import EcapaTdnn
+    from ppvector.models.fc import SpeakerIdentification
+    from ppvector.optimizer.adam import Adam
+    from ppvector.train.ddp import shard_batch
+    from ppvector.train.step import GraphedTrainStep
+    g = torch.Generator().manual_seed(31)
+    xs = [(torch.randn(8, 120, 80, generator=g) * 2) for _ in range(6)]
+    ys = [torch.randint(0, 9, (8,), generator=g) for _ in range(6)]
+    m = EcapaTdnn(80, embd_dim=192, pooling_type='ASP', channels=[512, 512, 512, 512, 1536])
+    m.load_state_dict(om.ecapa_params(80, seed=21))
+    head = SpeakerIdentification(192, 9)
+    head.load_state_dict({'weight': om.head_params(192, 9, seed=22)})
+    model = torch.nn.Sequential(m, head).cuda()
+    opt = Adam(model.parameters(), learning_rate=2e-3, weight_decay=1e-6)
+    step = GraphedTrainStep(model, AAMLoss(margin=0.2, scale=32), opt)
+    idx = list(shard_batch(8, rank, world))
+    losses = []
+    for x, y in zip(xs, ys):
+        loss, _ = step(x[idx].cuda(), y[idx].cuda())
+        losses.append(float(loss))
+    torch.cuda.synchronize()
+    q.put((rank, losses, step.n_stages, step.capture_error, opt.flat.detach().cpu(),
+           {k: v.detach().cpu() for k, v in model.state_dict().items() if k.endswith(('_mean', '_variance'))}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_graphed_train_step_under_two_ranks_equals_the_sharded_reference(N):
+    """GraphedTrainStep with world size 2 (two processes on this box's one GPU, gloo between them -- the collective is the only
+    thing that differs from the RCCL run): every rank replays its four stage graphs on ITS shard and all-reduces each stage's slice
+    of the flat gradient buffer.  Reference, in this process: the two shards differentiated one after the other on two replicas
+    (BatchNorm statistics are rank-local in the reference: plain BatchNorm under fleet, trainer.py:318-320), gradients averaged,
+    one Adam step on each replica.  After six steps (three eager, the capture, two replays) the ranks' parameters equal the
+    reference's and each other's; each rank's running statistics equal its replica's."""
+    import torch.multiprocessing as mp
+    from ppvector.loss.aamloss import AAMLoss
+    from ppvector.models.ecapa_tdnn import EcapaTdnn
+    from ppvector.models.fc import SpeakerIdentification
+    from ppvector.optimizer.adam import Adam
+    from ppvector.train.ddp import shard_batch
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_two_rank_graphed_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    # the reference while the ranks run
+    g = torch.Generator().manual_seed(31)
+    xs = [(torch.randn(8, 120, 80, generator=g) * 2) for _ in range(6)]
+    ys = [torch.randint(0, 9, (8,), generator=g) for _ in range(6)]
+    reps = []
+    for r in range(2):
+        m = EcapaTdnn(80, embd_dim=192, pooling_type='ASP', channels=[512, 512, 512, 512, 1536])
+        m.load_state_dict(om.ecapa_params(80, seed=21))
+        head = SpeakerIdentification(192, 9)
+        head.load_state_dict({'weight': om.head_params(192, 9, seed=22)})
+        model = torch.nn.Sequential(m, head).cuda().train()
+        reps.append((model, Adam(model.parameters(), learning_rate=2e-3, weight_decay=1e-6), AAMLoss(margin=0.2, scale=32)))
+    ref_losses = [[], []]
+    for x, y in zip(xs, ys):
+        for r, (model, opt, crit) in enumerate(reps):
+            idx = list(shard_batch(8, r, 2))
+            loss = crit(model(x[idx].cuda()), y[idx].cuda())
+            loss.backward()
+            opt.pack_grads()
+            ref_losses[r].append(float(loss))
+        gsum = reps[0][1].grad + reps[1][1].grad
+        for model, opt, _ in reps:
+            opt.grad.copy_(gsum)
+            opt.step(grad_scale=0.5)
+            opt.clear_grad()
+    torch.cuda.synchronize()
+    res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    flat_ref = reps[0][1].flat.detach().cpu()
+    assert torch.equal(flat_ref, reps[1][1].flat.detach().cpu())
+    for rank, losses, n_stages, err, flat, stats in res:
+        assert err is None and n_stages == 4, (err, n_stages)
+        dl = max(abs(a - b) / max(1.0, abs(a)) for a, b in zip(ref_losses[rank], losses))
+        dp = ((flat - flat_ref).abs().max() / flat_ref.abs().max()).item()
+        sd = reps[rank][0].state_dict()
+        ds = max(((stats[k] - sd[k].cpu()).abs().max() / max(1.0, sd[k].abs().max().item())).item() for k in stats)
+        print(f'[2-rank graphed step] rank {rank}: losses {[f"{v:.5f}" for v in losses]}  rel loss diff {dl:.2e}  '
+              f'parameters vs sharded reference {dp:.2e}  running statistics {ds:.2e}')
+        assert dl < 1e-5 and dp < 1e-5 and ds < 1e-5, (dl, dp, ds)
+    assert torch.equal(res[0][4], res[1][4])                      # the ranks hold bit-identical parameters
 
 
 @pytest.mark.parametrize('M,C,two', [(76288, 512, True), (5000, 64, True), (777, 128, False), (1234, 1536, True), (256, 192, True),

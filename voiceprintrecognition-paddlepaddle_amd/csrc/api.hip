@@ -26,4 +26,10 @@ void vp_destroy(vp_ctx* ctx) {
 
 const char* vp_last_error(vp_ctx* ctx) { return ctx ? ctx->err : "null context"; }
 
+int vp_set_margin_table(vp_ctx* ctx, const float* table) {
+    if (!ctx) return VP_EINVAL;
+    ctx->margin_table = table;
+    return VP_OK;
+}
+
 }  // extern "C"

@@ -29,6 +29,8 @@ struct vp_ctx {
     int* ms_mel_start;
     int* ms_mel_bin0;
     float* ms_mel_w;
+    // device margin table of the margin-softmax losses (vp_set_margin_table): [margin, cos m, sin m, cos(pi - m), 1 + cos(pi - m)]
+    const float* margin_table;
 };
 
 #define VP_FAIL(ctx, code, ...)                                      \

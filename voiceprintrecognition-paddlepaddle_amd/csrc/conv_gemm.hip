@@ -32,6 +32,7 @@ int vp_conv_launch256_bf16(vp_ctx* ctx, const void* args, int mode, int sched, h
 
 // Schedule of the 256-wide kernel: 0 pins the 128-wide kernel; 1 = interleaved DMA, 2 = ping-pong phases, 3 = role-split
 // DMA (two 64 KB stages; the tapped convs always take it), 4 = half-tile ring, 5 = half-tile ring with resident workgroups.
+// 6 = half-tile ring on 128 x 256 tiles, two 4-wave workgroups per CU (1x1 layers; the rest as 4), 7 = 6 for K <= 1024, else 4.
 // Default (-1) = 4: measured on MI355X, 1536 -> 1536 / 512 -> 512 with fused time sums: 3: 376 / 78 us, 4: 340 / 75, 5: 361 / 85.
 // VPMI_CONV256 presets it; vp_conv256_select() switches at run time (A/B in one process).
 static int g_conv256 = -2;
@@ -44,7 +45,7 @@ extern "C" {
 
 int vp_conv256_select(int schedule) {
     const int prev = use_conv256();
-    if (schedule >= -1 && schedule <= 5) g_conv256 = schedule;
+    if (schedule >= -1 && schedule <= 7) g_conv256 = schedule;
     return prev;
 }
 
@@ -134,7 +135,21 @@ int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream) {
         if (a.group_m < 1) a.group_m = 1;
         if (a.group_m > 16) a.group_m = 16;
         { static int gm = -1; if (gm < 0) { const char* e = getenv("VPMI_GROUP_M"); gm = e ? atoi(e) : 0; } if (gm > 0) a.group_m = gm; }
-        const int sched = use_conv256() < 0 ? 4 : use_conv256();
+        int sched = use_conv256() < 0 ? 4 : use_conv256();
+        if (sched == 7) sched = a.K <= 1024 ? 6 : 4;
+        if (sched == 6 && mode != MODE_1X1) sched = 4;
+        // the ring kernels address a 1x1 layer as "source row m for output row m" with wave-uniform piece offsets and let the
+        // buffer range check zero what lies past M / N / K: anything else (strided / padded 1x1, operands near 4 GiB) takes the
+        // two-stage schedule with its per-row offsets
+        if (sched >= 4 && mode == MODE_1X1 &&
+            (d->stride != 1 || d->pad_left != 0 || d->T_in != d->T_out || xbytes >= 0xe0000000ull || wbytes >= 0xe0000000ull))
+            sched = 3;
+        if (sched == 6) {                       // 128-row tiles, two workgroups per CU: ~64 workgroups of an XCD share a group's panels
+            a.tiles_m = (a.M + 127) / 128;
+            a.group_m = 64 / a.tiles_n;
+            if (a.group_m < 1) a.group_m = 1;
+            if (a.group_m > 32) a.group_m = 32;
+        }
         return vp_conv_launch256_bf16(ctx, &a, mode, sched - 1, st);
     }
     if (d->dtype_in == VP_BF16 && d->dtype_out == VP_BF16) return vp_conv_launch_bf16_bf16(ctx, &a, bn, mode, st);

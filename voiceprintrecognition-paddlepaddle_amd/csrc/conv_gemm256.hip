@@ -35,17 +35,19 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // RS = 64 uses 155,648 B from ebase (the whole LDS); RS = 32 uses 86,016 B: the resident-workgroup ring kernel runs it beside
 // the first four half-tiles of its NEXT tile, which `prefetch` (called once, after the first parameter loads went out, so
 // that their vmcnt wait does not cover the DMAs) stages into the other 64 KB.
-template <int RS, typename Prefetch>
+// NW = waves of the workgroup: 8 (256-row tile, four row groups of two waves) or 4 (the 128-row tile of the two-per-CU kernel).
+template <int RS, int NW = 8, typename Prefetch>
 __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8], char* ebase, int tid, int tm, int m0, int n0,
                                             Prefetch&& prefetch) {
     constexpr int OROW = 272;
     constexpr int NP = 64 / RS;                                // row passes per 64-channel half
+    constexpr int NWM = NW / 2;                                // row groups (wm) of the tile
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 1, wn = wv & 1;
     const int li = lane & 15, g = lane >> 4;
     char* slab = ebase + wv * (RS * OROW);
-    float* red = reinterpret_cast<float*>(ebase + 8 * RS * OROW);     // [2 stats][4 wm][2 seg][256 col]
+    float* red = reinterpret_cast<float*>(ebase + NW * RS * OROW);    // [2 stats][NWM wm][2 seg][256 col]
     bf16_t* __restrict__ Y = static_cast<bf16_t*>(a.y);
     bf16_t* __restrict__ Y2 = static_cast<bf16_t*>(a.y2);
     const bf16_t* __restrict__ ADD = static_cast<const bf16_t*>(a.add_in);
@@ -250,8 +252,8 @@ __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8
             }
             if (lane < 8) {
                 const int col = wn * 128 + h * 64 + c8;
-                float* ra = &red[((0 * 4 + wm) * 2 + (bb - bfirst)) * T2 + col];
-                float* rq = &red[((1 * 4 + wm) * 2 + (bb - bfirst)) * T2 + col];
+                float* ra = &red[((0 * NWM + wm) * 2 + (bb - bfirst)) * T2 + col];
+                float* rq = &red[((1 * NWM + wm) * 2 + (bb - bfirst)) * T2 + col];
                 if (rb >= 64) {
                     if (bb - bfirst < 2) {
 #pragma unroll
@@ -271,12 +273,12 @@ __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8
         } else if (a.psum) {
             const int col = wn * 128 + h * 64 + lane;
             if (bb - bfirst < 2) {
-                red[((0 * 4 + wm) * 2 + (bb - bfirst)) * T2 + col] = s1a;
-                red[((1 * 4 + wm) * 2 + (bb - bfirst)) * T2 + col] = s2a;
+                red[((0 * NWM + wm) * 2 + (bb - bfirst)) * T2 + col] = s1a;
+                red[((1 * NWM + wm) * 2 + (bb - bfirst)) * T2 + col] = s2a;
             }
             if (rb < 64 && bb + 1 - bfirst < 2) {
-                red[((0 * 4 + wm) * 2 + (bb + 1 - bfirst)) * T2 + col] = s1b;
-                red[((1 * 4 + wm) * 2 + (bb + 1 - bfirst)) * T2 + col] = s2b;
+                red[((0 * NWM + wm) * 2 + (bb + 1 - bfirst)) * T2 + col] = s1b;
+                red[((1 * NWM + wm) * 2 + (bb + 1 - bfirst)) * T2 + col] = s2b;
             }
         }
     }
@@ -296,11 +298,11 @@ __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8
                     const int mlo = m0 + wmx * 64, mhi = min(mlo + 63, a.M - 1);
                     // did wave wmx own rows of utterance bf + sgi?
                     if (mlo < a.M && mlo / a.T_out <= bf + sgi && bf + sgi <= mhi / a.T_out) {
-                        s1 += red[((0 * 4 + wmx) * 2 + sgi) * T2 + col];
-                        s2 += red[((1 * 4 + wmx) * 2 + sgi) * T2 + col];
+                        s1 += red[((0 * NWM + wmx) * 2 + sgi) * T2 + col];
+                        s2 += red[((1 * NWM + wmx) * 2 + sgi) * T2 + col];
                     }
                 }
-                const size_t o = ((size_t)(tm * 2 + half) * a.nseg + sgi) * a.N + n0 + col;
+                const size_t o = ((size_t)(tm * (NWM / 2) + half) * a.nseg + sgi) * a.N + n0 + col;
                 a.psum[o] = s1;
                 if (a.psumsq) a.psumsq[o] = s2;
             }
@@ -712,6 +714,14 @@ __global__ __launch_bounds__(512) void conv_gemm256_ring_kernel(const ConvArgs a
     unsigned xo[2][2], wo[2][2];             // [half][piece]
     int xp[2][2];
     int tm, m0, n0;
+    // MODE_1X1 (host-checked: T_in == T_out, stride 1, no padding -- source row m for output row m): every source offset is a
+    // lane part (row-in-piece x row bytes + swizzled chunk, one VGPR per operand) plus a wave-uniform part (tile, piece row,
+    // K-step); rows past M / N and K-steps past K land past num_records = zeros.  Eight offset VGPRs and their selects less.
+    const unsigned ldwb = (unsigned)a.K * 2u;
+    const unsigned xl = (unsigned)srow * ldxb + cb + (unsigned)a.xoff * 2u;
+    const unsigned wl = (unsigned)srow * ldwb + cb;
+    unsigned xs0 = 0, ws0 = 0;               // scalar: byte offset of the wave's first row of XA / WA in this tile
+    constexpr unsigned PAST = 0xf0000000u;
     // tile `bid` of the XCD-aware grouped order (conv_gemm_impl.h) and this wave's DMA source offsets in it
     auto setup = [&](int bid) {
     const int nblk = ntiles;
@@ -723,6 +733,11 @@ __global__ __launch_bounds__(512) void conv_gemm256_ring_kernel(const ConvArgs a
     const int tn = rem / gm;
     tm = grp * a.group_m + (rem - tn * gm);
     m0 = tm * T2; n0 = tn * T2;
+    if constexpr (MODE == MODE_1X1) {
+        xs0 = (unsigned)(m0 + (wv >> 1) * 64 + (wv & 1) * 16) * ldxb;
+        ws0 = (unsigned)(n0 + (wv >> 2) * 128 + (wv & 3) * 16) * ldwb;
+        return;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -757,7 +772,15 @@ __global__ __launch_bounds__(512) void conv_gemm256_ring_kernel(const ConvArgs a
         const bool tv = t < KT;
         const unsigned kb = (unsigned)t * (unsigned)ROWB;
         const int h = kind & 1;
-        if (kind >= K_WA) {
+        if constexpr (MODE == MODE_1X1) {
+            if (kind >= K_WA) {
+                const unsigned so = tv ? ws0 + (unsigned)(h * 64 + i * 8) * ldwb + kb : PAST;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)dst, 16, wl + so, 0, 0, 0);
+            } else {
+                const unsigned so = tv ? xs0 + (unsigned)(h * 32 + i * 8) * ldxb + kb : PAST;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_ptr_t)dst, 16, xl + so, 0, 0, 0);
+            }
+        } else if (kind >= K_WA) {
             const unsigned off = wo[h][i];
             bool ok = tv && off != OOB;
             if constexpr (MODE == MODE_TAPS_GEN) ok = ok && (t * 8 + (int)(cb >> 4)) < a.KC;
@@ -971,6 +994,211 @@ __global__ __launch_bounds__(512) void conv_gemm256_ring_kernel(const ConvArgs a
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Two workgroups per CU (schedule 6): the half-tile ring on a 128-position x 256-channel tile, 4 waves, 80 KB of LDS.
+// Why: with one 8-wave workgroup per CU a tile's prologue (first HBM round trip), K-loop and epilogue (128 KB of stores when
+// every CU of the chip stores at once) run back to back and nothing overlaps them -- for a K = 512 layer they are 40 % of the
+// tile -- and 596 full tiles on 256 CUs are 2.33 rounds.  Here each SIMD hosts one wave of EACH of two independent
+// workgroups: one workgroup's barrier waits, prologue and epilogue run under the other's MFMAs, and the last round is made
+// of half-size tiles.  Per wave nothing changes (64 x 128 accumulators, quadrant phases, fragments one phase ahead).
+// The ring holds seven half-tiles: XA / XB (64 rows, 8 KB) and WA (128 rows, 16 KB) of two K-steps, WB of ONE:
+//   phase    computes    reads                DMA                                  pieces per wave
+//   P1(t)    XA x WA     XB(t)                XA(t+2)                              2
+//   P2(t)    XB x WA     WB(t)                XB(t+2)                              2
+//   P3(t)    XB x WB     WA(t+1)              WB(t+1) -> the buffer P2(t) read     4
+//   P4(t)    XA x WB     XA(t+1)              WA(t+3)                              4
+// WB (weights: always L2-resident) is the one half-tile with a short lead: issued in P3(t-1), waited for at the end of
+// P1(t) -- own pieces by vmcnt(6) (WA(t+2) and XA(t+2) were issued after it), the barrier publishes everyone's; every other
+// half-tile is older than WB(t) at that wait, so it is the only counted wait of a K-step.
+constexpr int HX = 64 * ROWB;                // X half-tile of the 128-row tile
+constexpr int HW = 128 * ROWB;               // W half-tile
+constexpr int R2_XA0 = 0, R2_XB0 = HX, R2_XA1 = 2 * HX, R2_XB1 = 3 * HX, R2_WA0 = 4 * HX, R2_WA1 = 4 * HX + HW, R2_WB = 4 * HX + 2 * HW;
+constexpr int R2_BYTES = 4 * HX + 3 * HW;    // 81,920 B: two workgroups fill the CU's 160 KB
+
+__global__ __launch_bounds__(256, 2) void conv_gemm128x256_ring_kernel(const ConvArgs a) {
+    constexpr int MI = 4, NI = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const int li = lane & 15, g = lane >> 4;
+    constexpr unsigned OOB = 0xfffffff0u;
+    const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.w_bytes, 0x00020000);
+
+    // tile of the XCD-aware grouped order (conv_gemm_impl.h)
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int qq = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
+    const int swz = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    const int gsz = a.group_m * a.tiles_n;
+    const int grp = swz / gsz, rem = swz - grp * gsz;
+    const int gm = min(a.group_m, a.tiles_m - grp * a.group_m);
+    const int tn = rem / gm;
+    const int tm = grp * a.group_m + (rem - tn * gm);
+    const int m0 = tm * 128, n0 = tn * T2;
+
+    // staging: a DMA piece is 8 rows x 128 B; lane l lands at row l >> 3, position l & 7 and fetches chunk position ^ row.
+    // Wave wv fills rows [16 wv, +16) of an X half-tile (2 pieces) and rows [32 wv, +32) of a W half-tile (4 pieces).
+    // A 1x1 conv with T_in == T_out reads row m of x for output row m (host-checked), so every source offset is
+    //   (lane part: row-in-piece x row bytes + swizzled chunk)  +  (wave-uniform part: piece row, K-step)
+    // -- two VGPRs for all twelve pieces; rows past M / N and K-steps past K are past num_records = zeros, no select.
+    const int srow = lane >> 3;
+    const unsigned cb = (unsigned)((lane & 7) ^ srow) << 4;
+    const unsigned ldxb = (unsigned)a.ldx * 2u, ldwb = (unsigned)a.K * 2u;
+    const unsigned xl = (unsigned)srow * ldxb + cb + (unsigned)a.xoff * 2u;
+    const unsigned wl = (unsigned)srow * ldwb + cb;
+    const unsigned xs0 = (unsigned)(m0 + (wv >> 1) * 64 + (wv & 1) * 16) * ldxb;      // scalar: the wave's first row of XA
+    const unsigned ws0 = (unsigned)(n0 + (wv >> 1) * 128 + (wv & 1) * 32) * ldwb;     // scalar: the wave's first row of WA
+    constexpr unsigned PAST = 0xf0000000u;                                           // + lane part: past any operand (host-checked)
+    const int KT = a.KT;
+    const int KTp = (KT + 1) & ~1;
+
+    // piece i of half h (A = 0 / B = 1) of K-step t into the ring buffer at byte offset `buf`
+    auto issue_x = [&](int t, int buf, int h, int i) {
+        const unsigned so = t < KT ? xs0 + (unsigned)(h * 32 + i * 8) * ldxb + (unsigned)t * (unsigned)ROWB : PAST;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_ptr_t)(smem + buf + (wv * 16 + i * 8) * ROWB), 16, xl + so, 0, 0, 0);
+    };
+    auto issue_w = [&](int t, int buf, int h, int i) {
+        const unsigned so = t < KT ? ws0 + (unsigned)(h * 64 + i * 8) * ldwb + (unsigned)t * (unsigned)ROWB : PAST;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)(smem + buf + (wv * 32 + i * 8) * ROWB), 16, wl + so, 0, 0, 0);
+    };
+
+    // fragment reads: X half-tile rows wm * 32 + mi2 * 16 + li, W half-tile rows wn * 64 + ni4 * 16 + li
+    const int sw0 = (g ^ (li & 7)) << 4, sw1 = ((4 + g) ^ (li & 7)) << 4;
+    const char* const bx0 = smem + (wm * 32 + li) * ROWB + sw0;
+    const char* const bx1 = smem + (wm * 32 + li) * ROWB + sw1;
+    const char* const bw0 = smem + (wn * 64 + li) * ROWB + sw0;
+    const char* const bw1 = smem + (wn * 64 + li) * ROWB + sw1;
+    auto read_x = [&](int buf, Frag<bf16_t> (&f)[4]) {
+#pragma unroll
+        for (int mi2 = 0; mi2 < 2; ++mi2) {
+            f[mi2 * 2 + 0].v = *reinterpret_cast<const bf16x8*>(bx0 + buf + mi2 * 16 * ROWB);
+            f[mi2 * 2 + 1].v = *reinterpret_cast<const bf16x8*>(bx1 + buf + mi2 * 16 * ROWB);
+        }
+    };
+    auto read_w = [&](int buf, Frag<bf16_t> (&f)[8]) {
+#pragma unroll
+        for (int ni4 = 0; ni4 < 4; ++ni4) {
+            f[ni4 * 2 + 0].v = *reinterpret_cast<const bf16x8*>(bw0 + buf + ni4 * 16 * ROWB);
+            f[ni4 * 2 + 1].v = *reinterpret_cast<const bf16x8*>(bw1 + buf + ni4 * 16 * ROWB);
+        }
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto quad_mma = [&](const Frag<bf16_t> (&x)[4], const Frag<bf16_t> (&w)[8], int mi0, int ni0, int e0, int e1) {
+#pragma unroll
+        for (int e = e0; e < e1; ++e) {
+            const int ks = e >> 3, mi2 = (e >> 2) & 1, ni4 = e & 3;
+            mma(w[ni4 * 2 + ks], x[mi2 * 2 + ks], acc[mi0 + mi2][ni0 + ni4]);
+        }
+    };
+
+    // prologue: the seven half-tiles of K-steps 0 and 1 in the order they are read, 20 pieces per wave
+    Frag<bf16_t> xpf[4], xqf[4], waf[8], wbf[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_w(0, R2_WA0, 0, i);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) issue_x(0, R2_XA0, 0, i);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) issue_x(0, R2_XB0, 1, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_w(0, R2_WB, 1, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_w(1, R2_WA1, 0, i);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) issue_x(1, R2_XA1, 0, i);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) issue_x(1, R2_XB1, 1, i);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // WA(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_w(R2_WA0, waf);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(14)" ::: "memory");          // XA(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_w(2, R2_WA0, 0, i);      // phase "P4(-1)": every wave has read WA(0)
+    read_x(R2_XA0, xpf);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // XB(0): WB, WA(1), XA(1), XB(1), WA(2) were issued after it
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    // One phase: a memory half (the reads, one or two per MFMA, then the DMA pieces two MFMAs apart) and an MFMA-only half.
+    //   RX: 4 reads of an X half-tile (buffer rbuf) into xr[], 2 DMA pieces of an X half-tile; !RX: 8 reads of a W half-tile
+    //   into wr[], 4 DMA pieces of a W half-tile.  dh = half (A = 0 / B = 1) of the staged half-tile, td its K-step.
+    auto phase = [&](auto rx, int rbuf, Frag<bf16_t> (&xr)[4], Frag<bf16_t> (&wr)[8], auto dx, int td, int dbuf, int dh,
+                     const Frag<bf16_t> (&xc)[4], const Frag<bf16_t> (&wc)[8], int mi0, int ni0, auto tight) {
+        constexpr bool RX = decltype(rx)::value;
+        constexpr bool DX = decltype(dx)::value;
+        constexpr int NPC = DX ? 2 : 4;
+        __builtin_amdgcn_sched_barrier(0);
+        quad_mma(xc, wc, mi0, ni0, 4 + 2 * NPC, 16);            // MFMA-only half first
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (RX) read_x(rbuf, xr); else read_w(rbuf, wr);
+        quad_mma(xc, wc, mi0, ni0, 0, 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                           // MFMA, then one (X) or two (W) reads, four times
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if constexpr (RX) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) {
+            if constexpr (DX) issue_x(td, dbuf, dh, i); else issue_w(td, dbuf, dh, i);
+            __builtin_amdgcn_sched_barrier(0);
+            quad_mma(xc, wc, mi0, ni0, 4 + 2 * i, 6 + 2 * i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (decltype(tight)::value) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    constexpr std::true_type X{};
+    constexpr std::false_type W{};
+    constexpr std::true_type TIGHT{};
+    constexpr std::false_type LOOSE{};
+    for (int t = 0; t < KTp; t += 2) {
+        // even K-step t (set 0): XA in xpf, XB -> xqf
+        phase(X, R2_XB0, xqf, wbf, X, t + 2, R2_XA0, 0, xpf, waf, 0, 0, TIGHT);
+        phase(W, R2_WB, xqf, wbf, X, t + 2, R2_XB0, 1, xqf, waf, 2, 0, LOOSE);
+        phase(W, R2_WA1, xqf, waf, W, t + 1, R2_WB, 1, xqf, wbf, 2, 4, LOOSE);
+        phase(X, R2_XA1, xqf, wbf, W, t + 3, R2_WA1, 0, xpf, wbf, 0, 4, LOOSE);
+        // odd K-step t + 1 (set 1): XA in xqf, XB -> xpf
+        phase(X, R2_XB1, xpf, wbf, X, t + 3, R2_XA1, 0, xqf, waf, 0, 0, TIGHT);
+        phase(W, R2_WB, xpf, wbf, X, t + 3, R2_XB1, 1, xpf, waf, 2, 0, LOOSE);
+        phase(W, R2_WA0, xpf, waf, W, t + 2, R2_WB, 1, xpf, wbf, 2, 4, LOOSE);
+        phase(X, R2_XA0, xpf, wbf, W, t + 4, R2_WA0, 0, xqf, wbf, 0, 4, LOOSE);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // zero-fill DMAs of the tail still target the buffers
+    __syncthreads();                                           // every wave is done reading the ring
+    epilogue256<64, 4>(a, acc, smem, tid, tm, m0, n0, [] {});
+}
+
+int launch128x256_ring(vp_ctx* ctx, const ConvArgs& a, hipStream_t st) {
+    constexpr int smem = R2_BYTES;                             // >= the epilogue's 4 x 64 x 272 slabs + 8 KB of column-sum partials
+    static_assert(4 * 64 * 272 + 2 * 2 * 2 * T2 * 4 <= R2_BYTES, "epilogue image must fit the ring");
+    static bool attr_set = false;
+    if (!attr_set) {
+        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm128x256_ring_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_gemm128x256_ring_kernel, dim3(a.tiles_m * a.tiles_n), dim3(256), smem, st, a);
+    VP_LAUNCH_CHECK(ctx, "conv_gemm128x256_ring");
+    return VP_OK;
+}
+
 static int cu_count(vp_ctx* ctx) {
     static int n = 0;
     if (n == 0) {
@@ -1037,6 +1265,9 @@ int vp_conv_launch256_bf16(vp_ctx* ctx, const void* args, int mode, int sched, h
     } else if (sched == 1) {
         if (mode == MODE_1X1) return launch256<MODE_1X1, 1>(ctx, a, st);
         if (mode == MODE_TAPS) return launch256<MODE_TAPS, 1>(ctx, a, st);
+    } else if (sched == 5) {
+        // two workgroups per CU on 128 x 256 tiles (1x1 layers); args carry tiles_m in 128-row units
+        if (mode == MODE_1X1) return launch128x256_ring(ctx, a, st);
     } else if (sched == 3 || sched == 4) {
         // half-tile ring: one workgroup per tile (3) or resident workgroups (4)
         if (mode == MODE_1X1) return sched == 3 ? launch256_ring<MODE_1X1>(ctx, a, st) : launch256_ring_persist<MODE_1X1>(ctx, a, st);

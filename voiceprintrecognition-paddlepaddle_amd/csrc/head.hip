@@ -45,10 +45,12 @@ __global__ __launch_bounds__(256) void col_inv_norm_kernel(const float* w, int D
 struct AamArgs {
     const float* logits; const long long* labels; float* row_loss;
     int B, C; float cos_m, sin_m, th, mmm, scale, ls; int easy;
+    const float* mt;                 // device margin table (vp_set_margin_table) or NULL: the launch scalars above
 };
 
 __global__ __launch_bounds__(256) void aam_ce_rows_kernel(AamArgs a) {
     __shared__ float sm[3][4];
+    if (a.mt) { a.cos_m = a.mt[1]; a.sin_m = a.mt[2]; a.th = a.mt[3]; a.mmm = a.mt[4]; }
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float* row = a.logits + (size_t)b * a.C;
     const int y = (int)a.labels[b];
@@ -110,11 +112,13 @@ __global__ __launch_bounds__(256) void mean_kernel(const float* v, int n, float*
 struct AamBwdArgs {
     const float* logits; const long long* labels; const float* cinv; float* G; float* row_loss;
     int B, C; float cos_m, sin_m, th, mmm, scale, ls, gscale; int easy;
+    const float* mt;
 };
 
 __global__ __launch_bounds__(256) void aam_ce_bwd_rows_kernel(AamBwdArgs a) {
     __shared__ float sm[3][4];
     __shared__ float s_lse;
+    if (a.mt) { a.cos_m = a.mt[1]; a.sin_m = a.mt[2]; a.th = a.mt[3]; a.mmm = a.mt[4]; }
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float* row = a.logits + (size_t)b * a.C;
     const int y = (int)a.labels[b];
@@ -246,7 +250,7 @@ int vp_aam_ce_fwd(vp_ctx* ctx, const float* logits, const int64_t* labels, int B
     a.logits = logits; a.labels = (const long long*)labels; a.row_loss = row_loss; a.B = B; a.C = C;
     a.cos_m = (float)cos((double)margin); a.sin_m = (float)sin((double)margin);
     a.th = (float)cos(M_PI - (double)margin); a.mmm = (float)(1.0 + cos(M_PI - (double)margin));
-    a.scale = scale; a.ls = label_smoothing; a.easy = easy_margin;
+    a.scale = scale; a.ls = label_smoothing; a.easy = easy_margin; a.mt = ctx->margin_table;
     hipLaunchKernelGGL(aam_ce_rows_kernel, dim3(B), dim3(256), 0, st, a);
     VP_LAUNCH_CHECK(ctx, "aam_ce_rows");
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, st, row_loss, B, loss);
@@ -299,7 +303,7 @@ int vp_cosine_aam_ce_bwd(vp_ctx* ctx, const float* emb, const float* W, const in
     a.B = B; a.C = C;
     a.cos_m = (float)cos((double)margin); a.sin_m = (float)sin((double)margin);
     a.th = (float)cos(M_PI - (double)margin); a.mmm = (float)(1.0 + cos(M_PI - (double)margin));
-    a.scale = scale; a.ls = label_smoothing; a.gscale = grad_scale; a.easy = easy_margin;
+    a.scale = scale; a.ls = label_smoothing; a.gscale = grad_scale; a.easy = easy_margin; a.mt = ctx->margin_table;
     hipLaunchKernelGGL(aam_ce_bwd_rows_kernel, dim3(B), dim3(256), 0, st, a);
     VP_LAUNCH_CHECK(ctx, "aam_ce_bwd_rows");
     if (loss) {
@@ -329,7 +333,7 @@ int vp_aam_ce_bwd(vp_ctx* ctx, const float* logits, const int64_t* labels, int B
     a.B = B; a.C = C;
     a.cos_m = (float)cos((double)margin); a.sin_m = (float)sin((double)margin);
     a.th = (float)cos(M_PI - (double)margin); a.mmm = (float)(1.0 + cos(M_PI - (double)margin));
-    a.scale = scale; a.ls = label_smoothing; a.gscale = grad_scale; a.easy = easy_margin;
+    a.scale = scale; a.ls = label_smoothing; a.gscale = grad_scale; a.easy = easy_margin; a.mt = ctx->margin_table;
     hipLaunchKernelGGL(aam_ce_bwd_rows_kernel, dim3(B), dim3(256), 0, st, a);
     VP_LAUNCH_CHECK(ctx, "aam_ce_bwd_rows");
     if (loss) {

@@ -21,6 +21,7 @@ struct MarginArgs {
     const float* logits; const long long* labels; float* G; float* row_loss;
     int B, C, K, kind, easy;
     float cos_m, sin_m, th, mmm, margin, scale, ls, gscale;
+    const float* mt;                 // device margin table (vp_set_margin_table) or NULL
 };
 
 // value of class c: its logit, or the max over its K sub-centres (first max wins; arg = winning sub-centre)
@@ -63,6 +64,10 @@ __device__ __forceinline__ float margin_out(const MarginArgs& a, bool target, fl
 __global__ __launch_bounds__(256) void margin_ce_rows_kernel(MarginArgs a) {
     __shared__ float sm[3][4];
     __shared__ float s_lse;
+    if (a.mt) {
+        a.cos_m = a.mt[1]; a.sin_m = a.mt[2]; a.th = a.mt[3]; a.mmm = a.mt[4];
+        if (a.kind == VP_LOSS_AM || a.kind == VP_LOSS_ARM) a.margin = a.mt[0];
+    }
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float* row = a.logits + (size_t)b * a.C * a.K;
     const int y = (int)a.labels[b];
@@ -116,6 +121,7 @@ struct SphereArgs {
     const float* logits; const long long* labels; const float* bias; float* G; float* row_loss; float* row_dbias;
     int B, C, t, type_a;
     float cos_m, sin_m, th, mmm, margin, scale, lam, gscale;
+    const float* mt;
 };
 
 __device__ __forceinline__ float softplus(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
@@ -156,6 +162,7 @@ __device__ __forceinline__ float sphere_term(const SphereArgs& a, bool target, f
 
 __global__ __launch_bounds__(256) void sphereface2_rows_kernel(SphereArgs a) {
     __shared__ float sm[2][4];
+    if (a.mt) { a.margin = a.mt[0]; a.cos_m = a.mt[1]; a.sin_m = a.mt[2]; a.th = a.mt[3]; a.mmm = a.mt[4]; }
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float* row = a.logits + (size_t)b * a.C;
     const int y = (int)a.labels[b];
@@ -198,7 +205,7 @@ int launch_margin(vp_ctx* ctx, const float* logits, const int64_t* labels, int B
     a.th = (float)cos(M_PI - (double)margin); a.mmm = (float)(1.0 + cos(M_PI - (double)margin));
     a.margin = (kind == VP_LOSS_AM || kind == VP_LOSS_ARM) ? margin : 0.f;
     a.scale = kind == VP_LOSS_CE ? 1.f : scale;
-    a.ls = ls; a.gscale = gscale;
+    a.ls = ls; a.gscale = gscale; a.mt = ctx->margin_table;
     hipLaunchKernelGGL(margin_ce_rows_kernel, dim3(B), dim3(256), 0, st, a);
     VP_LAUNCH_CHECK(ctx, "margin_ce_rows");
     if (loss) {
@@ -246,7 +253,7 @@ int vp_sphereface2(vp_ctx* ctx, const float* logits, const int64_t* labels, cons
     a.B = B; a.C = C; a.t = t; a.type_a = margin_type_a;
     a.cos_m = (float)cos((double)margin); a.sin_m = (float)sin((double)margin);
     a.th = (float)cos(M_PI - (double)margin); a.mmm = (float)(1.0 + cos(M_PI - (double)margin));
-    a.margin = margin; a.scale = scale; a.lam = lanbuda; a.gscale = grad_scale;
+    a.margin = margin; a.scale = scale; a.lam = lanbuda; a.gscale = grad_scale; a.mt = ctx->margin_table;
     hipLaunchKernelGGL(sphereface2_rows_kernel, dim3(B), dim3(256), 0, st, a);
     VP_LAUNCH_CHECK(ctx, "sphereface2_rows");
     hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, st, row_loss, B, 1, loss);

@@ -148,6 +148,7 @@ _PROTOS = {
     'vp_create': (c_void_p, [c_int]),
     'vp_destroy': (None, [c_void_p]),
     'vp_last_error': (C.c_char_p, [c_void_p]),
+    'vp_set_margin_table': (c_int, [c_void_p, c_void_p]),
     'vp_fbank_default_opts': (None, [C.POINTER(FbankOpts)]),
     'vp_fbank_num_frames': (c_int, [C.POINTER(FbankOpts), c_int]),
     'vp_fbank_workspace_bytes': (c_size_t, [C.POINTER(FbankOpts), c_int, c_int]),

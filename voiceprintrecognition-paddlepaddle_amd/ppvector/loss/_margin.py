@@ -1,9 +1,47 @@
 """Shared body of the margin-softmax criteria (AM / ARM / CE / SubCenter): argument checks, the eval-time forward through
 vp_margin_ce_fwd and the training-time forward + backward through ppvector.train.functions.MarginCe (csrc/losses.hip)."""
+import math
+
 import torch
 from torch import nn
 
 from ppvector import _native as N
+
+
+class MarginTable:
+    """The criterion's margin as five device floats [m, cos m, sin m, cos(pi - m), 1 + cos(pi - m)] (vp_set_margin_table): while
+    the table is installed (`with table:`) every loss launch reads the margin from it when the kernel RUNS, so a captured HIP
+    graph follows MarginScheduler (optimizer/scheduler.py:69,76) without a re-capture.  `sync()` uploads the criterion's current
+    margin when it changed; the values are the same double -> float roundings the launch-scalar path makes."""
+
+    def __init__(self, criterion, device):
+        self.criterion, self.device = criterion, torch.device(device)
+        self.has_margin = hasattr(criterion, 'margin')
+        self.buf = torch.zeros(5, dtype=torch.float32, device=self.device) if self.has_margin else None
+        self._last = None
+        self.sync()
+
+    def sync(self):
+        if not self.has_margin:
+            return
+        m = float(self.criterion.margin)
+        if m != self._last:
+            vals = [m, math.cos(m), math.sin(m), math.cos(math.pi - m), 1.0 + math.cos(math.pi - m)]
+            self.buf.copy_(torch.tensor(vals, dtype=torch.float64).to(torch.float32))
+            self._last = m
+
+    def __enter__(self):
+        if self.has_margin:
+            self.sync()
+            c = N.ctx(self.device)
+            N.check(N.lib().vp_set_margin_table(c, self.buf.data_ptr()), c)
+        return self
+
+    def __exit__(self, *exc):
+        if self.has_margin:
+            c = N.ctx(self.device)
+            N.lib().vp_set_margin_table(c, None)
+        return False
 
 
 class MarginSoftmax(nn.Module):

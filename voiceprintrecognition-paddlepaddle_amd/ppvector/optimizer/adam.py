@@ -21,7 +21,11 @@ def _no_unbuilt_options(name, kwargs):
     for k in ('grad_clip', 'lr_ratio', 'apply_decay_param_fun'):
         if kwargs.pop(k, None) is not None:
             raise NotImplementedError(f'{name}({k}=...) is not built on the HIP engine')
-    for k in ('name', 'lazy_mode', 'multi_precision', 'use_multi_tensor', 'amsgrad', 'rescale_grad'):
+    if kwargs.pop('amsgrad', False):
+        raise NotImplementedError(f'{name}(amsgrad=True) changes the update rule and is not built on the HIP engine')
+    if kwargs.pop('rescale_grad', None) not in (None, 1, 1.0):
+        raise NotImplementedError(f'{name}(rescale_grad != 1) changes the update rule and is not built on the HIP engine')
+    for k in ('name', 'lazy_mode', 'multi_precision', 'use_multi_tensor'):       # no effect on the arithmetic of an f32 flat buffer
         kwargs.pop(k, None)
     if kwargs:
         raise TypeError(f'{name}: unexpected keyword arguments {sorted(kwargs)}')

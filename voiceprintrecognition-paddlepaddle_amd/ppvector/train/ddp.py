@@ -12,6 +12,30 @@ def shard_batch(n_items, rank, world):
     return range(min(rank * per, n_items), min((rank + 1) * per, n_items))
 
 
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class _Done:
+    """Handle of a collective that already completed (the staged gloo path)."""
+
+    def wait(self):
+        return True
+
+
+def all_reduce_sum_(t, async_op=False):
+    """In-place sum over the ranks.  "nccl" (= RCCL) reduces device tensors directly; "gloo" (the CPU tests, and the 2-rank tests
+    that share one GPU) gets a device tensor staged through host memory.  Returns a handle with .wait() when async_op."""
+    if world_size() == 1:
+        return _Done() if async_op else None
+    if t.is_cuda and dist.get_backend() == 'gloo':
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+        return _Done() if async_op else None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
+
+
 def allreduce_mean_(flat_grad, bucket_bytes=256 << 20):
     """In-place average of a flat gradient buffer over all ranks, in buckets (one collective per bucket_bytes)."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
@@ -19,7 +43,7 @@ def allreduce_mean_(flat_grad, bucket_bytes=256 << 20):
     world = dist.get_world_size()
     n = flat_grad.numel()
     step = max(1, bucket_bytes // flat_grad.element_size())
-    works = [dist.all_reduce(flat_grad[i:min(i + step, n)], op=dist.ReduceOp.SUM, async_op=True) for i in range(0, n, step)]
+    works = [all_reduce_sum_(flat_grad[i:min(i + step, n)], async_op=True) for i in range(0, n, step)]
     for w in works:
         w.wait()
     flat_grad.div_(world)
@@ -33,7 +57,8 @@ class OverlappedReducer:
     backwards: backward produces gradients in reverse parameter order, so the bucket holding the head and the last layers
     completes first and its all-reduce runs while autograd is still computing the early layers.  A post-accumulate hook on
     every parameter counts the bucket's pending gradients; a complete bucket is all-reduced asynchronously.  `finish()` waits
-    for the handles and divides by the world size.  Default 16 MB: ECAPA's 26.9 MB of gradients become two buckets, CAM++'s
+    for the handles; the flat buffer then holds the SUM over the ranks -- the caller passes grad_scale = 1 / world to
+    optimizer.step, which applies it inside the update kernel (no division pass over the buffer).  Default 16 MB: ECAPA's 26.9 MB of gradients become two buckets, CAM++'s
     33 MB three (a single 64 MB bucket would start its one collective only after backward ended = no overlap), while each
     message is still large enough for the xGMI ring (per-link bound: 8 ranks x 7 links x ~153 GB/s)."""
 
@@ -70,20 +95,19 @@ class OverlappedReducer:
         b[3] += 1
         if b[3] == b[2]:
             self._pack(bi)
-            b[4] = dist.all_reduce(self.flat[b[0]:b[1]], op=dist.ReduceOp.SUM, async_op=True)
+            b[4] = all_reduce_sum_(self.flat[b[0]:b[1]], async_op=True)
 
     def finish(self):
-        """Call after backward, before optimizer.step(): waits for every bucket and turns the sums into means."""
+        """Call after backward, before optimizer.step(grad_scale=1 / world): waits for every bucket's sum."""
         if self.world == 1:
             return
         for bi, b in enumerate(self.buckets):
             if b[4] is None:                      # a bucket with a parameter that received no gradient this step
                 self._pack(bi)
-                b[4] = dist.all_reduce(self.flat[b[0]:b[1]], op=dist.ReduceOp.SUM, async_op=True)
+                b[4] = all_reduce_sum_(self.flat[b[0]:b[1]], async_op=True)
         for b in self.buckets:
             b[4].wait()
             b[3], b[4] = 0, None
-        self.flat.div_(self.world)
         if hasattr(self.opt, '_packed'):
             self.opt._packed = True               # every bucket was gathered before its all-reduce: step() must not re-pack
 

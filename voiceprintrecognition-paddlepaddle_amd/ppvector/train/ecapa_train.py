@@ -6,6 +6,7 @@ Input (B, T, F) f32 on the GPU -> embeddings (B, embd_dim)."""
 import torch
 
 from ppvector.train.functions import BNRows, CatConvBlock, ConvBlock, ConvBlockSkip, Res2Fn, SEBlockFn
+from ppvector.train.segments import cut
 from ppvector.train.tdnn_train import asp_forward
 
 
@@ -51,6 +52,10 @@ def ecapa_forward_train(m, feats):
     for blk in list(m.blocks)[1:]:
         x = se_res2net_block(blk, x, B, T)
         outs.append(x)
+        # backward stage boundary (train/segments.py): every block output is live across it -- the next block reads the last
+        # one, the MFA concatenation all of them.  Stages from the end: head + ASP + MFA | block 3 | block 2 | blocks 0-1
+        outs = list(cut(*outs))
+        x = outs[-1]
     conv, norm = m.mfa.conv.conv, m.mfa.norm.norm
     x = CatConvBlock.apply(dict(B=B, T=T, dilation=m.mfa.conv.dilation, pad='reflect', relu=True, momentum=norm.momentum, eps=norm.eps),
                            conv.weight, conv.bias, norm.weight, norm.bias, norm._mean, norm._variance, *outs)

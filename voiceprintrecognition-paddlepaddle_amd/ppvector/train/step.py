@@ -4,10 +4,25 @@
     scheduler.step(); margin_scheduler.step()
 
 with the data-parallel gradient average (fleet.distributed_model in the reference, trainer.py:318-320) made explicit:
-one all-reduce over the optimiser's flat gradient buffer between backward and the Adam kernel."""
-import torch
+a sum-all-reduce over the optimiser's flat gradient buffer between backward and the optimiser kernel, whose 1 / world scale
+rides on the optimiser's `grad_scale` launch scalar (no pass over the buffer for the division).
 
-from ppvector.train.ddp import OverlappedReducer, allreduce_mean_
+`TrainStep` is the eager step (autograd hooks launch each bucket's all-reduce while backward runs).  `GraphedTrainStep` is what
+PPVectorTrainer and bench.py run: forward + backward replayed from captured HIP graphs, cut into stages
+(ppvector/train/segments.py) so that stage k's gradients are all-reduced while stage k + 1 replays."""
+import torch
+import torch.distributed as dist
+
+from ppvector.train.ddp import OverlappedReducer, all_reduce_sum_, world_size
+from ppvector.train.segments import Recorder
+
+
+def batch_accuracy(outputs, labels, K=1):
+    """trainer.py:233-236: argmax of the logits against the labels; SubCenter heads score a class by its best sub-centre."""
+    logits = outputs['logits'].detach()
+    if K > 1:
+        logits = logits.reshape(logits.shape[0], -1, K).max(dim=2)[0]
+    return (logits.argmax(dim=1) == labels.to(logits.device)).float().mean()
 
 
 class TrainStep:
@@ -17,59 +32,10 @@ class TrainStep:
         self.scheduler, self.margin_scheduler = scheduler, margin_scheduler
         self.featurizer, self.spec_augment = featurizer, spec_augment
         self.step_id = 0
+        self.K = int(getattr(criterion, 'K', 1) or 1)
         # data-parallel gradient average: bucketed all-reduce launched from autograd hooks while backward is still running
         self.reducer = OverlappedReducer(optimizer) if overlap_allreduce else None
-
-    def __call__(self, inputs, labels):
-        """inputs: waveforms (B, L) when a featurizer was given, else features (B, T, F).  Returns (loss, accuracy) tensors."""
-        self.model.train()
-        feats = inputs
-        if self.featurizer is not None:
-            with torch.no_grad():
-                feats = self.featurizer(inputs)
-                if self.spec_augment is not None:
-                    feats = self.spec_augment.batch(feats)
-        outputs = self.model(feats)
-        loss = self.criterion(outputs, labels)
-        loss.backward()
-        if self.reducer is not None:
-            self.reducer.finish()
-        else:
-            self.optimizer.pack_grads()
-            allreduce_mean_(self.optimizer.grad)
-        self.optimizer.step()
-        self.optimizer.clear_grad()
-        with torch.no_grad():
-            acc = (outputs['logits'].argmax(dim=1) == labels.to(outputs['logits'].device)).float().mean()
-        if self.scheduler is not None:
-            self.scheduler.step()
-        if self.margin_scheduler is not None:
-            self.margin_scheduler.step()
-        self.step_id += 1
-        return loss.detach(), acc
-
-
-class GraphedTrainStep(TrainStep):
-    """The same step with forward + backward replayed from ONE captured HIP graph.
-
-    The step is ~1000 kernel launches whose count does not depend on the batch.  At the 32 utterances per GPU of the
-    strong-scaled configuration (global batch 256 over 8 GPUs) the eager step is bound by the host issuing them (9.4 ms where
-    the GPU needs a fraction of that): data-parallel scaling would stall at ~2x.  Here the first `warm` calls run eagerly (the
-    plain step: identical semantics, and every lazy table / kernel attribute gets set up outside a capture), then the featurizer
-    output is copied into a static buffer and model forward -> criterion -> backward are captured once and replayed.  What stays
-    outside the graph, eager, every step: the featurizer (+ SpecAugment, whose masks the host draws), the gradient all-reduce
-    (bucketed over the flat buffer; a collective inside a capture is not attempted), flat Adam (the learning rate is a launch
-    scalar) and the schedulers.  The loss margin is a launch scalar too: a changed margin (MarginScheduler's ramp) re-captures.
-    BatchNorm running statistics are updated by the replayed kernels in place, as in the eager step."""
-
-    def __init__(self, *a, warm=3, bucket_bytes=16 << 20, **kw):
-        kw['overlap_allreduce'] = False
-        super().__init__(*a, **kw)
-        self.warm, self.bucket_bytes = warm, bucket_bytes
-        self._graph, self._key = None, None
-        self._static = {}
-        self.capture_error = None
-        self.skip_allreduce = False
+        self.skip_allreduce = False            # measurement switch (bench.py: the same step without the collective)
 
     def _features(self, inputs):
         feats = inputs
@@ -80,53 +46,173 @@ class GraphedTrainStep(TrainStep):
                     feats = self.spec_augment.batch(feats)
         return feats
 
-    def _capture(self, feats, labels):
-        st = self._static
-        st['feats'], st['labels'] = feats.clone(), labels.clone()
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        # thread-local error mode: another thread of the process (the collective library's watchdog polling its events) must not
-        # invalidate the capture
-        with torch.cuda.graph(g, capture_error_mode='thread_local'):
-            outputs = self.model(st['feats'])
-            loss = self.criterion(outputs, st['labels'])
-            loss.backward()
-            self.optimizer.pack_grads()                     # gradients -> flat buffer: part of the replayed sequence
-            st['loss'] = loss.detach()
-            st['acc'] = (outputs['logits'].detach().argmax(dim=1) == st['labels']).float().mean()
-        self._graph = g
-
-    def __call__(self, inputs, labels):
-        from ppvector import _native as N
-        if self.capture_error is not None or self.step_id < self.warm:
-            return super().__call__(inputs, labels)
-        self.model.train()
-        feats = self._features(inputs)
-        labels = labels.to(feats.device)
-        key = (tuple(feats.shape), feats.dtype, tuple(labels.shape), float(getattr(self.criterion, 'margin', 0.0)))
-        if self._graph is None or key != self._key:
-            try:
-                self.optimizer.clear_grad()
-                self._capture(feats, labels)
-                self._key = key
-                self.optimizer.clear_grad()                     # a capture executes nothing, but keep the buffer defined
-            except Exception as e:                              # noqa: BLE001 -- fall back to the eager step for good
-                self.capture_error = f'{type(e).__name__}: {e}'[:300]
-                self._graph = None
-                return super().__call__(inputs, labels)
-        else:
-            self._static['feats'].copy_(feats)
-            self._static['labels'].copy_(labels)
-        self._graph.replay()
-        self.optimizer._packed = True                           # the replay gathered the gradients
-        N.bump_weights_epoch()                                  # the replayed forward rewrote the BatchNorm running statistics
-        if not self.skip_allreduce:
-            allreduce_mean_(self.optimizer.grad, bucket_bytes=self.bucket_bytes)
-        self.optimizer.step()
-        self.optimizer.clear_grad()
+    def _after(self):
         if self.scheduler is not None:
             self.scheduler.step()
         if self.margin_scheduler is not None:
             self.margin_scheduler.step()
         self.step_id += 1
-        return self._static['loss'], self._static['acc']
+
+    def _eager(self, feats, labels):
+        outputs = self.model(feats)
+        loss = self.criterion(outputs, labels)
+        loss.backward()
+        world = 1 if self.skip_allreduce else world_size()
+        if self.reducer is not None:
+            self.reducer.finish()
+        else:
+            self.optimizer.pack_grads()
+            if world > 1:
+                all_reduce_sum_(self.optimizer.grad)
+        self.optimizer.step(grad_scale=1.0 / world)
+        self.optimizer.clear_grad()
+        with torch.no_grad():
+            acc = batch_accuracy(outputs, labels, self.K)
+        self._after()
+        return loss.detach(), acc
+
+    def __call__(self, inputs, labels):
+        """inputs: waveforms (B, L) when a featurizer was given, else features (B, T, F).  Returns (loss, accuracy) tensors."""
+        self.model.train()
+        return self._eager(self._features(inputs), labels)
+
+
+class GraphedTrainStep(TrainStep):
+    """The same step with forward + backward replayed from captured HIP graphs, one per backward stage.
+
+    The step is several hundred kernel launches whose count does not depend on the batch; at the 32 utterances per GPU of the
+    strong-scaled configuration (global batch 256 over 8 GPUs) the eager step is bound by the host issuing them.  A batch
+    shape's first `warm` sightings run the eager step (identical semantics; every lazy table / kernel attribute gets set up
+    outside a capture); then the features are copied into a static buffer and
+
+        graph 0: model forward -> criterion -> accuracy -> backward of the last stage -> its gradients into the flat buffer
+        graph k: backward of the k-th stage from the end -> its gradients into the flat buffer
+
+    are captured once (stages = the backbone's `cut` points, ppvector/train/segments.py; a model without cuts is one graph).
+    Per step: replay graph 0, START the all-reduce of its slice of the flat gradient buffer (async, the collective library's
+    stream), replay graph 1 underneath it, ... wait for the collectives, one optimiser launch (1 / world folded into it).
+    Outside the graphs, eager, every step: the featurizer (+ SpecAugment, whose masks the host draws), the collectives, the
+    optimiser (the learning rate is a launch scalar) and the schedulers.  The loss margin is DEVICE data while captured
+    (vp_set_margin_table): MarginScheduler's ramp moves it without a re-capture.  BatchNorm running statistics are updated by the
+    replayed kernels in place, as in the eager step.  Up to `max_graphs` batch shapes keep their graphs (a ragged training set
+    yields a few distinct padded lengths); others run eagerly."""
+
+    def __init__(self, *a, warm=3, max_graphs=6, **kw):
+        kw['overlap_allreduce'] = False          # an autograd hook cannot launch a collective from inside a capture
+        super().__init__(*a, **kw)
+        self.warm, self.max_graphs = warm, max_graphs
+        self._plans, self._seen = {}, {}
+        self.capture_error = None
+        self._margin = None
+
+    # ------------------------------------------------------------------------------------------------ capture
+    def _spans(self, params):
+        """Contiguous [begin, end) element ranges of the flat gradient buffer covered by `params`."""
+        opt = self.optimizer
+        iv = sorted((opt._offset(p), opt._offset(p) + p.numel()) for p in params)
+        out = []
+        for lo, hi in iv:
+            if out and lo <= out[-1][1]:
+                out[-1][1] = max(out[-1][1], hi)
+            else:
+                out.append([lo, hi])
+        return [tuple(v) for v in out]
+
+    def _capture(self, feats, labels):
+        from ppvector.loss._margin import MarginTable
+        opt = self.optimizer
+        st = {'feats': feats.clone(), 'labels': labels.clone()}
+        if self._margin is None:
+            self._margin = MarginTable(self.criterion, feats.device)
+        opt.clear_grad()
+        torch.cuda.synchronize()
+        graphs, spans, done = [], [], set()
+        cur = {}
+
+        def open_graph():
+            g = torch.cuda.CUDAGraph()
+            # thread-local error mode: another thread of the process (the collective library's watchdog polling its events) must
+            # not invalidate the capture; later graphs read tensors the earlier ones saved: one memory pool
+            cm = torch.cuda.graph(g, pool=graphs[0].pool() if graphs else None, capture_error_mode='thread_local')
+            cm.__enter__()
+            cur['g'], cur['cm'] = g, cm
+
+        def close_graph(last):
+            new = [p for p in opt.params if id(p) not in done and (p.grad is not None or last)]
+            done.update(id(p) for p in new)
+            opt.pack_range(new)                           # the stage's gradients -> flat buffer: part of the replayed sequence
+            cm = cur.pop('cm')
+            cm.__exit__(None, None, None)
+            graphs.append(cur.pop('g'))
+            spans.append(self._spans(new))
+
+        rec = Recorder()
+        try:
+            with rec, self._margin:
+                open_graph()
+                outputs = self.model(st['feats'])
+                loss = self.criterion(outputs, st['labels'])
+                st['loss'] = loss.detach()
+                st['acc'] = batch_accuracy(outputs, st['labels'], self.K)
+
+                def between(i):
+                    close_graph(last=(i == rec.n_stages - 1))
+                    if i < rec.n_stages - 1:
+                        open_graph()
+
+                rec.backward(loss, between)
+        except BaseException as e:
+            if 'cm' in cur:                               # leave the open capture before anything else touches the stream
+                try:
+                    cur['cm'].__exit__(type(e), e, e.__traceback__)
+                except Exception:                         # noqa: BLE001
+                    pass
+            raise
+        opt.clear_grad()                                  # a capture executes nothing: the .grad tensors hold no data
+        return {'graphs': graphs, 'spans': spans, 'static': st}
+
+    # ------------------------------------------------------------------------------------------------ step
+    def __call__(self, inputs, labels):
+        from ppvector import _native as N
+        self.model.train()
+        feats = self._features(inputs)
+        labels = labels.to(feats.device)
+        key = (tuple(feats.shape), feats.dtype, tuple(labels.shape))
+        plan = self._plans.get(key)
+        if plan is None:
+            seen = self._seen[key] = self._seen.get(key, 0) + 1
+            if self.capture_error is not None or seen <= self.warm or len(self._plans) >= self.max_graphs:
+                return self._eager(feats, labels)
+            try:
+                plan = self._plans[key] = self._capture(feats, labels)
+            except Exception as e:                        # noqa: BLE001 -- fall back to the eager step for good
+                self.capture_error = f'{type(e).__name__}: {e}'[:300]
+                # the aborted capture left .grad tensors that point into its private pool and were never written: drop them
+                self.optimizer.clear_grad()
+                torch.cuda.synchronize()
+                return self._eager(feats, labels)
+        else:
+            plan['static']['feats'].copy_(feats)
+            plan['static']['labels'].copy_(labels)
+        self._margin.sync()                               # the margin the criterion holds NOW (MarginScheduler stepped it)
+        world = 1 if self.skip_allreduce else world_size()
+        works = []
+        for g, spans in zip(plan['graphs'], plan['spans']):
+            g.replay()
+            if world > 1:
+                for lo, hi in spans:                      # this stage's gradients travel while the next stage replays
+                    works.append(all_reduce_sum_(self.optimizer.grad[lo:hi], async_op=True))
+        for w in works:
+            if w is not None:
+                w.wait()
+        self.optimizer._packed = True                     # the replays gathered every gradient
+        N.bump_weights_epoch()                            # the replayed forward rewrote the BatchNorm running statistics
+        self.optimizer.step(grad_scale=1.0 / world)
+        self.optimizer.clear_grad()
+        self._after()
+        return plan['static']['loss'].clone(), plan['static']['acc'].clone()
+
+    @property
+    def n_stages(self):
+        """Backward stages of the captured step(s) (1 = no cut points: the all-reduce follows the whole backward)."""
+        return max((len(p['graphs']) for p in self._plans.values()), default=0)

@@ -37,7 +37,7 @@ from ppvector.metric.metrics import evaluate_trials
 from ppvector.models import build_model
 from ppvector.models.fc import SpeakerIdentification
 from ppvector.optimizer import MarginScheduler, build_lr_scheduler, build_optimizer
-from ppvector.train.ddp import OverlappedReducer
+from ppvector.train.step import GraphedTrainStep
 from ppvector.utils.checkpoint import load_checkpoint, load_pretrained, save_checkpoint
 from ppvector.utils.utils import dict_to_object
 
@@ -109,7 +109,7 @@ class PPVectorTrainer(object):
         self.model = self.backbone = self.optimizer = self.scheduler = self.audio_featurizer = None
         self.train_dataset = self.train_loader = None
         self.enroll_dataset = self.enroll_loader = self.trials_dataset = self.trials_loader = None
-        self.margin_scheduler = self.amp_scaler = self.loss = self.reducer = None
+        self.margin_scheduler = self.amp_scaler = self.loss = self.train_step_fn = None
         self.max_step, self.train_step = None, None
         self.train_loss, self.train_acc = None, None
         self.train_eta_sec = None
@@ -240,37 +240,32 @@ class PPVectorTrainer(object):
             features, label = self._features(items, self.train_dataset)
             if spec is not None:                                # the reference masks each utterance's OWN feature before the
                 features = spec.batch(features, lengths=self._last_frames)      # collate (reader.py:105-107): T = its frames
-            if self.train_step < 3:                             # a wrong num_speakers / speed-perturb label offset reads outside
-                lo, hi = int(label.min()), int(label.max())     # the logits row in the loss kernels; paddle raises here too
+            if self._label_checks < 3:                          # a wrong num_speakers / speed-perturb label offset reads outside
+                self._label_checks += 1                         # the logits row in the loss kernels; paddle raises here too.
+                lo, hi = int(label.min()), int(label.max())     # First batches of every run (also after a resume).
                 if lo < 0 or hi >= outputs_classes(self.model, K):
                     raise ValueError(f'label range [{lo}, {hi}] outside the classifier\'s {outputs_classes(self.model, K)} classes')
-            outputs = self.model(features)
-            los = self.loss(outputs, label)
-            los.backward()
-            self.reducer.finish()                          # data-parallel gradient average (no-op for one process)
-            self.optimizer.step()
-            self.optimizer.clear_grad()
-            with torch.no_grad():
-                logits = outputs['logits']
-                if K > 1:
-                    logits = logits.reshape(logits.shape[0], -1, K).max(dim=2)[0]
-                acc = (logits.argmax(dim=1) == label).float().mean()
-            accuracies.append(acc)                              # device scalars: read back at the log interval only (the
-            loss_sum.append(los.detach())                       # reference syncs twice per step, trainer.py:237-238)
+            # forward -> loss -> backward -> data-parallel gradient all-reduce -> optimiser (trainer.py:206-231):
+            # ONE implementation, ppvector/train/step.py -- the step bench.py times
+            los, acc = self.train_step_fn(features, label)
+            if local_rank == 0:                                 # device scalars, read back at the log interval only (the reference
+                accuracies.append(acc)                          # syncs twice per step, trainer.py:237-238); other ranks never log
+                loss_sum.append(los)
             train_times.append((time.time() - start) * 1000)
             self.train_step += 1
-            if batch_id % self.configs.train_conf.log_interval == 0 and local_rank == 0:
-                per = sum(train_times) / len(train_times)
-                world = dist.get_world_size() if dist.is_initialized() else 1
-                train_speed = len(items) * world / (per / 1000)          # GLOBAL utterances per second
-                self.train_eta_sec = per * (self.max_step - self.train_step) / 1000
-                self.train_loss = float(torch.stack(loss_sum).mean())
-                self.train_acc = float(torch.stack(accuracies).mean())
-                margin_str = f'margin: {self.margin_scheduler.get_margin()}' if self.margin_scheduler else ''
-                _LOG.info('Train epoch: [%d/%d], batch: [%d/%d], loss: %.5f, accuracy: %.5f, learning rate: %.8f, %s speed: %.2f data/sec, '
-                          'eta: %s', epoch_id, self.configs.train_conf.max_epoch, batch_id, len(self.train_loader), self.train_loss,
-                          self.train_acc, self.scheduler.get_lr(), margin_str, train_speed, timedelta(seconds=int(self.train_eta_sec)))
-                self.train_log_step += 1
+            if batch_id % self.configs.train_conf.log_interval == 0:
+                if local_rank == 0:
+                    per = sum(train_times) / len(train_times)
+                    world = dist.get_world_size() if dist.is_initialized() else 1
+                    train_speed = len(items) * world / (per / 1000)          # GLOBAL utterances per second
+                    self.train_eta_sec = per * (self.max_step - self.train_step) / 1000
+                    self.train_loss = float(torch.stack(loss_sum).mean())
+                    self.train_acc = float(torch.stack(accuracies).mean())
+                    margin_str = f'margin: {self.margin_scheduler.get_margin()}' if self.margin_scheduler else ''
+                    _LOG.info('Train epoch: [%d/%d], batch: [%d/%d], loss: %.5f, accuracy: %.5f, learning rate: %.8f, %s speed: %.2f data/sec, '
+                              'eta: %s', epoch_id, self.configs.train_conf.max_epoch, batch_id, len(self.train_loader), self.train_loss,
+                              self.train_acc, self.scheduler.get_lr(), margin_str, train_speed, timedelta(seconds=int(self.train_eta_sec)))
+                    self.train_log_step += 1
                 train_times, accuracies, loss_sum = [], [], []
             if batch_id % 10000 == 0 and batch_id != 0 and local_rank == 0:
                 save_checkpoint(configs=self.configs, model=self.model, optimizer=self.optimizer, amp_scaler=self.amp_scaler,
@@ -297,7 +292,11 @@ class PPVectorTrainer(object):
             load_checkpoint(configs=self.configs, model=self.model, optimizer=self.optimizer, amp_scaler=self.amp_scaler,
                             scheduler=self.scheduler, margin_scheduler=self.margin_scheduler, step_epoch=len(self.train_loader),
                             save_model_path=save_model_path, resume_model=resume_model)
-        self.reducer = OverlappedReducer(self.optimizer)
+        # the optimisation step: HIP-graph replays of forward + backward in stages, each stage's gradient all-reduce (RCCL) under
+        # the next stage's replay, one optimiser launch; shapes seen fewer than four times run the same step eagerly
+        # (the LR / margin schedulers stay in the epoch loop below, stepped after the log line as in the reference)
+        self.train_step_fn = GraphedTrainStep(self.model, self.loss, self.optimizer)
+        self._label_checks = 0
         _LOG.info('训练数据：%d', len(self.train_dataset))
         self.train_loss, self.train_acc = None, None
         self.test_log_step, self.train_log_step = 0, 0
