@@ -140,7 +140,7 @@ def roofline_pass(reps):
                 traffic = tj.get('conv_gemm256_bytes_per_launch')
         except Exception:
             traffic = None
-    return {'bound': 'mfma', 'kernel': 'conv_gemm256_ring_kernel<MODE_1X1> (7 launches/step: 6 x 512->512 + MFA 1536->1536, 87% of forward flops)',
+    return {'bound': 'mfma', 'kernel': 'conv_gemm128x256_ring_kernel (7 launches/step: 6 x 512->512 + MFA 1536->1536, 87% of forward flops)',
             'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
             'flop_per_launch': total_flop / n, 'avg_launch_ms': round(total_ms / n, 4),

@@ -33,7 +33,10 @@ int vp_conv_launch256_bf16(vp_ctx* ctx, const void* args, int mode, int sched, h
 // Schedule of the 256-wide kernel: 0 pins the 128-wide kernel; 1 = interleaved DMA, 2 = ping-pong phases, 3 = role-split
 // DMA (two 64 KB stages; the tapped convs always take it), 4 = half-tile ring, 5 = half-tile ring with resident workgroups.
 // 6 = half-tile ring on 128 x 256 tiles, two 4-wave workgroups per CU (1x1 layers; the rest as 4), 7 = 6 for K <= 1024, else 4.
-// Default (-1) = 4: measured on MI355X, 1536 -> 1536 / 512 -> 512 with fused time sums: 3: 376 / 78 us, 4: 340 / 75, 5: 361 / 85.
+// Default (-1) = 6.  Measured on MI355X, 1536 -> 1536 / 512 -> 512 launches at 256 x 298 rows (round 3, one session, with the fused
+// time sums): 4: 322 / 70.6 us, 5: 362 / 83, 6: 332 / 64.4; without sums 4: 313 / 62.0, 6: 320 / 55.2.  Inside the two-stream step
+// (bench.py) 6 for every 1x1 layer beats 7: 1.282 vs 1.301 ms (4: 1.313) -- a 4-wave workgroup with 80 KB of LDS leaves half a CU to
+// the other launch sequence's memory-bound kernels.
 // VPMI_CONV256 presets it; vp_conv256_select() switches at run time (A/B in one process).
 static int g_conv256 = -2;
 static int use_conv256() {
@@ -135,7 +138,7 @@ int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream) {
         if (a.group_m < 1) a.group_m = 1;
         if (a.group_m > 16) a.group_m = 16;
         { static int gm = -1; if (gm < 0) { const char* e = getenv("VPMI_GROUP_M"); gm = e ? atoi(e) : 0; } if (gm > 0) a.group_m = gm; }
-        int sched = use_conv256() < 0 ? 4 : use_conv256();
+        int sched = use_conv256() < 0 ? 6 : use_conv256();
         if (sched == 7) sched = a.K <= 1024 ? 6 : 4;
         if (sched == 6 && mode != MODE_1X1) sched = 4;
         // the ring kernels address a 1x1 layer as "source row m for output row m" with wave-uniform piece offsets and let the

@@ -144,6 +144,7 @@ __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8
                         *reinterpret_cast<bf16x8*>(dst) = o;
                         dst += dstep;
                         if (split) { *reinterpret_cast<bf16x8*>(dst2) = o; dst2 += dstep2; }
+#ifndef VP_EXP_NOSUMADD
                         if (sums) {
                             const float mk = row < rb ? 1.f : 0.f;
 #pragma unroll
@@ -158,6 +159,7 @@ __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8
                                 }
                             }
                         }
+#endif
                         row += 8;
                         cell += 8 * OROW;
                     }
@@ -233,44 +235,42 @@ __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8
                 }
             }
         }
+#ifdef VP_EXP_NOSUMRED
+        if (false) {
+#else
         if (a.psum && fastw) {
-            if (a.act2 == VP_ACT_NONE) {             // sums were taken before the BN affine (see the row loop)
+#endif
+            // The 8 lanes of a channel group (equal lane & 7) hold partial sums of their 8 channels over disjoint rows.  Transposed
+            // through the wave's slab (free after the last pass; one wave's LDS operations retire in order): every lane stores its
+            // 8 partials of a quantity as one slab row segment, then lane = channel adds the 8 rows of its column -- 2 stores +
+            // 8 loads + 7 adds per quantity instead of 24 cross-lane shuffles, and the result already sits one channel per lane.
+            const bool two = rb < 64;                  // wave-uniform: rows [0, rb) belong to utterance bb, the rest to bb + 1
+            const bool sq = a.psumsq != nullptr || a.act2 != VP_ACT_NONE;
+            char* wr = slab + (lane >> 3) * OROW + (lane & 7) * 32;
+            auto put = [&](int q, const float (&v)[8]) {
+                *reinterpret_cast<f32x4*>(wr + q * 8 * OROW) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(wr + q * 8 * OROW + 16) = f32x4{v[4], v[5], v[6], v[7]};
+            };
+            put(0, p1);
+            if (sq) put(1, p2);
+            if (two) { put(2, q1); if (sq) put(3, q2); }
+            const char* rd = slab + lane * 4;
+            auto get = [&](int q) {
+                float t = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float s2 = sc[e] * sc[e];
-                    p1[e] *= sc[e]; q1[e] *= sc[e]; p2[e] *= s2; q2[e] *= s2;
-                }
+                for (int r = 0; r < 8; ++r) t += *reinterpret_cast<const float*>(rd + (q * 8 + r) * OROW);
+                return t;
+            };
+            float P1 = get(0), P2 = sq ? get(1) : 0.f, Q1 = 0.f, Q2 = 0.f;
+            if (two) { Q1 = get(2); if (sq) Q2 = get(3); }
+            if (a.act2 == VP_ACT_NONE && a.bn_scale) {     // sums were taken before the BN affine (see the row loop)
+                const float scl = a.bn_scale[nh + lane];
+                P1 *= scl; Q1 *= scl; P2 *= scl * scl; Q2 *= scl * scl;
             }
-            // the 8 lanes of a channel group (equal lane & 7) hold partial sums over disjoint rows
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-#pragma unroll
-                for (int o = 8; o < 64; o <<= 1) {
-                    p1[e] += __shfl_xor(p1[e], o); p2[e] += __shfl_xor(p2[e], o);
-                    if (rb < 64) { q1[e] += __shfl_xor(q1[e], o); q2[e] += __shfl_xor(q2[e], o); }
-                }
-            }
-            if (lane < 8) {
-                const int col = wn * 128 + h * 64 + c8;
-                float* ra = &red[((0 * NWM + wm) * 2 + (bb - bfirst)) * T2 + col];
-                float* rq = &red[((1 * NWM + wm) * 2 + (bb - bfirst)) * T2 + col];
-                if (rb >= 64) {
-                    if (bb - bfirst < 2) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) { ra[e] = p1[e]; rq[e] = p2[e]; }
-                    }
-                } else {
-                    if (bb - bfirst < 2) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) { ra[e] = q1[e]; rq[e] = q2[e]; }
-                    }
-                    if (bb + 1 - bfirst < 2) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) { ra[T2 + e] = p1[e] - q1[e]; rq[T2 + e] = p2[e] - q2[e]; }
-                    }
-                }
-            }
-        } else if (a.psum) {
+            if (two) { s1a = Q1; s2a = Q2; s1b = P1 - Q1; s2b = P2 - Q2; }
+            else { s1a = P1; s2a = P2; }
+        }
+        if (a.psum) {
             const int col = wn * 128 + h * 64 + lane;
             if (bb - bfirst < 2) {
                 red[((0 * NWM + wm) * 2 + (bb - bfirst)) * T2 + col] = s1a;
@@ -282,7 +282,11 @@ __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8
             }
         }
     }
+#ifdef VP_EXP_NOSUMFIN
+    if (false) {
+#else
     if (a.psum) {
+#endif
         // per 128-row half (= one M-tile of the 128-wide kernel's psum layout): the two waves' partials.
         // T_out >= 128 (host-checked, nseg == 2): a wave's 64 rows touch at most two utterances and
         // flush each (wave, segment) slot at most once; slots never flushed are never read.
@@ -1023,7 +1027,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm128x256_ring_kernel(const Con
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 1, wn = wv & 1;
     const int li = lane & 15, g = lane >> 4;
-    constexpr unsigned OOB = 0xfffffff0u;
     const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.w_bytes, 0x00020000);
 
