@@ -179,7 +179,7 @@ def conv_ref(x, w, bias, kw, dil, pad_mode, stride=1):
 
 
 def run_conv(N, x, w, bias, kw, dil, pad_mode, dtype, out_dtype=None, relu=False, bn=None, act2=0, rowbias=None,
-             add_in=None, want_sums=False, ysplit=0, T_out=None, amp=False):
+             add_in=None, want_sums=False, ysplit=0, T_out=None, amp=False, res=None):
     lib, ctx = N.lib(), N.ctx(0)
     B, T, Cin = x.shape
     Cout = w.shape[0]
@@ -222,6 +222,9 @@ def run_conv(N, x, w, bias, kw, dil, pad_mode, dtype, out_dtype=None, relu=False
         keep += [ad, aux]
         d.add_in, d.ld_add, d.add_off = ad.data_ptr(), Cout, 0
         d.aux, d.ld_aux, d.aux_off = aux.data_ptr(), Cout, 0
+    if res is not None:
+        rs = dev(res, odt); keep.append(rs)
+        d.res, d.ld_res, d.res_off = rs.data_ptr(), Cout, 0
     ps = pq = None
     if want_sums:
         tiles, nseg = lib.vp_conv1d_tiles_m(B, T_out), lib.vp_conv1d_nseg(T_out)
@@ -408,6 +411,29 @@ def _wide_tiles_case(N, case):
         s2 = sum(pq[tm, b - (tm * 128) // To] for tm in range((b * To) // 128, ((b + 1) * To - 1) // 128 + 1))
         assert (s1 - dref[b].sum(0)).abs().max().item() < 1e-4 * max(1.0, dref[b].sum(0).abs().max().item())
         assert (s2 - (dref[b] ** 2).sum(0)).abs().max().item() < 1e-4 * (dref[b] ** 2).sum(0).abs().max().item()
+
+
+@pytest.mark.parametrize('case', [(40, 149, 512, 512), (33, 298, 1536, 512), (35, 130, 256, 320)])
+def test_conv1d_wide_bf16_operands_f32_output(N, case):
+    """bf16 operands -> f32 output on the 128 x 256 ring kernel (the training engine's data-gradient GEMMs over bf16 dz, with the
+    other path's gradient added in the epilogue): float64 conv of the same bf16 operands + the f32 residual; with and without
+    the residual, bias and ReLU; ragged M and N."""
+    B, T, Cin, Cout = case
+    g = torch.Generator().manual_seed(B + Cin)
+    x = torch.randn(B, T, Cin, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, 1, generator=g, dtype=torch.float64) / Cin ** 0.5
+    bias = torch.randn(Cout, generator=g, dtype=torch.float64)
+    res = torch.randn(B, T, Cout, generator=g, dtype=torch.float64)
+    z = conv_ref(q(x, 'bf16'), q(w, 'bf16'), None, 1, 1, 'zero')
+    y, _, _, _ = run_conv(N, x, w, None, 1, 1, 'zero', 'bf16', out_dtype='f32', res=res)
+    assert y.dtype == torch.float32
+    e1 = (y.double().cpu() - (z + q(res, 'f32'))).abs().max().item()
+    y, _, _, _ = run_conv(N, x, w, None, 1, 1, 'zero', 'bf16', out_dtype='f32')
+    e2 = (y.double().cpu() - z).abs().max().item()
+    y, _, _, _ = run_conv(N, x, w, bias, 1, 1, 'zero', 'bf16', out_dtype='f32', relu=True)
+    e3 = (y.double().cpu() - torch.relu(z + bias)).abs().max().item()
+    print(f'[conv bf16 -> f32, {B}x{T} rows, {Cin} -> {Cout}] max abs err: with residual {e1:.2e}, plain {e2:.2e}, bias + relu {e3:.2e}')
+    assert max(e1, e2, e3) < 2e-4
 
 
 def test_conv1d_rejects_bad_shapes(N):

@@ -28,7 +28,7 @@ int vp_conv_launch_bf16_bf16(vp_ctx* ctx, const void* args, int bn, int mode, hi
 int vp_conv_launch_bf16_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
 int vp_conv_launch_f32_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
 int vp_conv_launch_amp_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
-int vp_conv_launch256_bf16(vp_ctx* ctx, const void* args, int mode, int sched, hipStream_t st);
+int vp_conv_launch256_bf16(vp_ctx* ctx, const void* args, int mode, int sched, int out_f32, hipStream_t st);
 
 // Schedule of the 256-wide kernel: 0 pins the 128-wide kernel; 1 = interleaved DMA, 2 = ping-pong phases, 3 = role-split
 // DMA (two 64 KB stages; the tapped convs always take it), 4 = half-tile ring, 5 = half-tile ring with resident workgroups.
@@ -128,18 +128,14 @@ int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream) {
     if (a.group_m > 16) a.group_m = 16;
     if (d->psum && a.nseg > NSEG_MAX) VP_FAIL(ctx, VP_EUNSUP, "conv1d: T_out %d too short for fused time sums", d->T_out);
     hipStream_t st = (hipStream_t)stream;
-    // wide bf16 layers: 256 x 256 tiles fed by LDS-DMA (conv_gemm256.hip)
-    if (d->dtype_in == VP_BF16 && d->dtype_out == VP_BF16 && (mode == MODE_1X1 || mode == MODE_TAPS) &&
+    // wide bf16 layers: 128 x 256 / 256 x 256 tiles fed by LDS-DMA (conv_gemm256.hip).  bf16 -> f32 (the training engine's
+    // data-gradient GEMMs over bf16 dz) is built on the default schedule (6) for plain 1x1 layers.
+    if (d->dtype_in == VP_BF16 && (mode == MODE_1X1 || mode == MODE_TAPS) &&
         (d->Cin % 64 == 0 || (mode == MODE_TAPS && (use_conv256() >= 3 || use_conv256() < 0))) &&
-        d->Cout >= 256 && a.M >= 256 * 64 && !d->gate && (!d->psum || d->T_out >= 128) && use_conv256()) {
-        a.tiles_m = (a.M + 255) / 256;
-        a.tiles_n = (a.N + 255) / 256;
-        a.group_m = 32 / a.tiles_n;
-        if (a.group_m < 1) a.group_m = 1;
-        if (a.group_m > 16) a.group_m = 16;
-        { static int gm = -1; if (gm < 0) { const char* e = getenv("VPMI_GROUP_M"); gm = e ? atoi(e) : 0; } if (gm > 0) a.group_m = gm; }
+        d->Cout >= 256 && !d->gate && (!d->psum || d->T_out >= 128) && use_conv256()) {
         int sched = use_conv256() < 0 ? 6 : use_conv256();
         if (sched == 7) sched = a.K <= 1024 ? 6 : 4;
+        if (sched == 5) sched = 4;              // resident workgroups: no longer built
         if (sched == 6 && mode != MODE_1X1) sched = 4;
         // the ring kernels address a 1x1 layer as "source row m for output row m" with wave-uniform piece offsets and let the
         // buffer range check zero what lies past M / N / K: anything else (strided / padded 1x1, operands near 4 GiB) takes the
@@ -147,13 +143,23 @@ int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream) {
         if (sched >= 4 && mode == MODE_1X1 &&
             (d->stride != 1 || d->pad_left != 0 || d->T_in != d->T_out || xbytes >= 0xe0000000ull || wbytes >= 0xe0000000ull))
             sched = 3;
-        if (sched == 6) {                       // 128-row tiles, two workgroups per CU: ~64 workgroups of an XCD share a group's panels
-            a.tiles_m = (a.M + 127) / 128;
-            a.group_m = 64 / a.tiles_n;
+        const bool out_f32 = d->dtype_out == VP_F32;
+        const long long min_rows = sched == 6 ? 128 * 32 : 256 * 64;          // enough tiles to be worth a wide-tile launch
+        if ((!out_f32 || sched == 6) && a.M >= min_rows) {
+            a.tiles_m = (a.M + 255) / 256;
+            a.tiles_n = (a.N + 255) / 256;
+            a.group_m = 32 / a.tiles_n;
             if (a.group_m < 1) a.group_m = 1;
-            if (a.group_m > 32) a.group_m = 32;
+            if (a.group_m > 16) a.group_m = 16;
+            { static int gm = -1; if (gm < 0) { const char* e = getenv("VPMI_GROUP_M"); gm = e ? atoi(e) : 0; } if (gm > 0) a.group_m = gm; }
+            if (sched == 6) {                   // 128-row tiles, two workgroups per CU: ~64 workgroups of an XCD share a group's panels
+                a.tiles_m = (a.M + 127) / 128;
+                a.group_m = 64 / a.tiles_n;
+                if (a.group_m < 1) a.group_m = 1;
+                if (a.group_m > 32) a.group_m = 32;
+            }
+            return vp_conv_launch256_bf16(ctx, &a, mode, sched - 1, out_f32 ? 1 : 0, st);
         }
-        return vp_conv_launch256_bf16(ctx, &a, mode, sched - 1, st);
     }
     if (d->dtype_in == VP_BF16 && d->dtype_out == VP_BF16) return vp_conv_launch_bf16_bf16(ctx, &a, bn, mode, st);
     if (d->dtype_in == VP_BF16 && d->dtype_out == VP_F32) return vp_conv_launch_bf16_f32(ctx, &a, bn, mode, st);

@@ -21,24 +21,31 @@ constexpr int MODE_TAPS_GEN = 4;             // tapped 1-D conv with Cin % 64 !=
 constexpr int STAGE2 = 2 * T2 * ROWB;        // X panel + W panel
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-// Epilogue of one 256 x 256 tile, shared by every K-loop schedule.  Entered by all 512 threads with the wave's 64 x 128
-// accumulators in registers, after a barrier behind which the LDS range [ebase, ebase + 8 RS 272 + 16 KB) is dead.
+// Epilogue of one tile, shared by every K-loop schedule.  Entered by all threads with each wave's 64 x 128 accumulators in
+// registers, after a barrier behind which the LDS range [ebase, ebase + NW x 64 x 272 + NW x 2 KB) is dead.
 //   y = act2( bn( act( acc + bias + rowbias ) ) + res );  aux = y + add_in;  psum/psumsq over (y - shift)
 // (conv_gemm_impl.h semantics, no gate).  Written as ROLLED loops over an LDS image of the accumulators: the fully
 // unrolled per-register form of the 128-wide kernel is ~25k instructions for 128 accumulators per lane and ran 15 us per
-// tile on instruction fetch alone.  Per 64-channel half h and per pass of RS of the wave's 64 rows:
-//   A. dump RS x 64 f32 accumulators into the wave's own LDS slab (row stride 272 B: conflict-free both ways);
+// tile on instruction fetch alone.  Per 64-channel half h of the wave's 128 channels:
+//   A. dump 64 x 64 f32 accumulators into the wave's own LDS slab (row stride 272 B: conflict-free both ways);
 //   B. rolled row loop -- fast form (whole block inside the problem, per-channel terms only): lane = (row 8j + lane/8,
 //      channels 8 (lane%8)..+7), one 16-B store per lane, 8 lanes = 128 contiguous bytes of a position; general form:
 //      lane = (row 4j + lane/16, 4 channels), masks / rowbias / residual / aux / tanh / SiLU; (y - shift) goes back to the slab;
-//   C. column sums: lane = one channel, the pass's rows split at the wave's utterance boundary, kept in registers.
-// RS = 64 uses 155,648 B from ebase (the whole LDS); RS = 32 uses 86,016 B: the resident-workgroup ring kernel runs it beside
-// the first four half-tiles of its NEXT tile, which `prefetch` (called once, after the first parameter loads went out, so
-// that their vmcnt wait does not cover the DMAs) stages into the other 64 KB.
+//   C. column sums: the fast rows keep 8 partial sums per lane, transposed through the slab (lane = channel adds 8 rows); the
+//      general rows re-read their column.
+// Measured and NOT kept (round 3, same-session A/B, 512 -> 512 / 1536 -> 1536 launches): the arithmetic on the accumulators
+// (lane = position, 4 channels) writing a bf16 image that a copy-out loop stores without arithmetic -- fewer VALU instructions and
+// half the LDS bytes on paper, but 63.8 -> 73.5 us / 309 -> 333 us on the 8-wave kernel (57 -> 60 / equal on the 4-wave one): with
+// the arithmetic and the stores in separate phases the waves of a workgroup use the VALU and the store path in turns.  Folding the
+// bias into the accumulators' initial value likewise lost: hipcc waits vmcnt(0) for an ordinary load's result while LDS-DMAs are
+// in flight, so the first MFMA drained the whole prologue.
 // NW = waves of the workgroup: 8 (256-row tile, four row groups of two waves) or 4 (the 128-row tile of the two-per-CU kernel).
-template <int RS, int NW = 8, typename Prefetch>
-__device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8], char* ebase, int tid, int tm, int m0, int n0,
-                                            Prefetch&& prefetch) {
+// TO: bf16 (inference, training forward) or float (the training engine's data-gradient GEMMs: bf16 operands, f32 gradients; the fast
+// rows then also take an f32 residual -- the other path's gradient -- from a coalesced load).
+template <int NW, typename TO>
+__device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8], char* ebase, int tid, int tm, int m0, int n0) {
+    constexpr int RS = 64;
+    constexpr bool F32O = sizeof(TO) == 4;
     constexpr int OROW = 272;
     constexpr int NP = 64 / RS;                                // row passes per 64-channel half
     constexpr int NWM = NW / 2;                                // row groups (wm) of the tile
@@ -48,11 +55,11 @@ __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8
     const int li = lane & 15, g = lane >> 4;
     char* slab = ebase + wv * (RS * OROW);
     float* red = reinterpret_cast<float*>(ebase + NW * RS * OROW);    // [2 stats][NWM wm][2 seg][256 col]
-    bf16_t* __restrict__ Y = static_cast<bf16_t*>(a.y);
-    bf16_t* __restrict__ Y2 = static_cast<bf16_t*>(a.y2);
-    const bf16_t* __restrict__ ADD = static_cast<const bf16_t*>(a.add_in);
-    const bf16_t* __restrict__ RES = static_cast<const bf16_t*>(a.res);
-    bf16_t* __restrict__ AUX = static_cast<bf16_t*>(a.aux);
+    TO* __restrict__ Y = static_cast<TO*>(a.y);
+    TO* __restrict__ Y2 = static_cast<TO*>(a.y2);
+    const TO* __restrict__ ADD = static_cast<const TO*>(a.add_in);
+    const TO* __restrict__ RES = static_cast<const TO*>(a.res);
+    TO* __restrict__ AUX = static_cast<TO*>(a.aux);
     const int mw = m0 + wm * 64;                               // first position of this wave
     const int bfirst = (m0 + (wm >> 1) * 128) / a.T_out;       // first utterance of the 128-row half
     const int q4 = lane >> 4, c4 = (lane & 15) * 4;
@@ -74,10 +81,13 @@ __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8
             if (a.bn_scale) load4(a.bn_scale + nb, sc4);
             if (a.bn_shift) load4(a.bn_shift + nb, sh4);
         }
-        const bool fast_cols = nh + 64 <= a.N && !a.rowbias && !RES && !AUX && a.act2 != VP_ACT_TANH && a.act2 != VP_ACT_SILU &&
-                               (a.ysplit <= nh || a.ysplit >= nh + 64) && ((a.ldy | a.yoff) & 7) == 0 &&
+        constexpr int AL = F32O ? 3 : 7;                       // elements per 16 bytes - 1
+        const bool res_ok = !RES || (F32O && !a.psum && a.act2 == VP_ACT_NONE && ((a.ld_res | a.res_off) & 3) == 0 &&
+                                     (reinterpret_cast<uintptr_t>(a.res) & 15) == 0);
+        const bool fast_cols = nh + 64 <= a.N && !a.rowbias && res_ok && !AUX && a.act2 != VP_ACT_TANH && a.act2 != VP_ACT_SILU &&
+                               (a.ysplit <= nh || a.ysplit >= nh + 64) && ((a.ldy | a.yoff) & AL) == 0 &&
                                (reinterpret_cast<uintptr_t>(a.y) & 15) == 0 &&
-                               (a.ysplit <= nh || (((a.ldy2 | a.y2off) & 7) == 0 && (reinterpret_cast<uintptr_t>(a.y2) & 15) == 0));
+                               (a.ysplit <= nh || (((a.ldy2 | a.y2off) & AL) == 0 && (reinterpret_cast<uintptr_t>(a.y2) & 15) == 0));
         float bs[8], sc[8], sh[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { bs[e] = 0.f; sc[e] = 1.f; sh[e] = 0.f; }
@@ -86,7 +96,6 @@ __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8
             if (a.bn_scale) { load4(a.bn_scale + nc, sc); load4(a.bn_scale + nc + 4, sc + 4); }
             if (a.bn_shift) { load4(a.bn_shift + nc, sh); load4(a.bn_shift + nc + 4, sh + 4); }
         }
-        if (h == 0) prefetch();
         float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;      // general rows: column sums of this lane's channel, utterance bb / bb + 1
         // fast rows: sums of this lane's 8 channels over its rows -- p = every row, q = the rows of utterance bb (only when the
         // wave's rows straddle two utterances); reduced over the 8 lanes of a channel group after the passes
@@ -106,11 +115,13 @@ __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8
                 const float lo1 = a.act == VP_ACT_RELU ? 0.f : -INFINITY;
                 const float lo2 = (a.act2 == VP_ACT_RELU || a.act2 == VP_ACT_HARDTANH20) ? 0.f : -INFINITY;
                 const float hi2 = a.act2 == VP_ACT_HARDTANH20 ? 20.f : INFINITY;
-                bf16_t* dst = Y + (size_t)(mwp + q8) * a.ldy + a.yoff + nc;
+                TO* dst = Y + (size_t)(mwp + q8) * a.ldy + a.yoff + nc;
                 const size_t dstep = (size_t)8 * a.ldy;
                 const bool split = a.ysplit > nh;
-                bf16_t* dst2 = split ? Y2 + (size_t)(mwp + q8) * a.ldy2 + a.y2off + nc : nullptr;
+                TO* dst2 = split ? Y2 + (size_t)(mwp + q8) * a.ldy2 + a.y2off + nc : nullptr;
                 const size_t dstep2 = (size_t)8 * a.ldy2;
+                [[maybe_unused]] const TO* rsrc = RES ? RES + (size_t)(mwp + q8) * a.ld_res + a.res_off + nc : nullptr;
+                [[maybe_unused]] const size_t rstep = (size_t)8 * a.ld_res;
                 const bool sums = a.psum != nullptr;
                 char* cell = slab + q8 * OROW + c8 * 4;
                 // two instances of the row loop: without a second activation (conv -> ReLU -> BN, the TDNN block) the clamp
@@ -138,13 +149,24 @@ __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8
                                 v[e + 4] = fminf(fmaxf(v[e + 4], lo2), hi2);
                             }
                         }
-                        bf16x8 o;
+                        if constexpr (F32O) {
+                            f32x4 o0 = f32x4{v[0], v[1], v[2], v[3]}, o1 = f32x4{v[4], v[5], v[6], v[7]};
+                            if (RES) {                     // (no second activation with a residual here: res_ok)
+                                o0 += *reinterpret_cast<const f32x4*>(rsrc);
+                                o1 += *reinterpret_cast<const f32x4*>(rsrc + 4);
+                                rsrc += rstep;
+                            }
+                            *reinterpret_cast<f32x4*>(dst) = o0;
+                            *reinterpret_cast<f32x4*>(dst + 4) = o1;
+                            if (split) { *reinterpret_cast<f32x4*>(dst2) = o0; *reinterpret_cast<f32x4*>(dst2 + 4) = o1; dst2 += dstep2; }
+                        } else {
+                            bf16x8 o;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-                        *reinterpret_cast<bf16x8*>(dst) = o;
+                            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+                            *reinterpret_cast<bf16x8*>(dst) = o;
+                            if (split) { *reinterpret_cast<bf16x8*>(dst2) = o; dst2 += dstep2; }
+                        }
                         dst += dstep;
-                        if (split) { *reinterpret_cast<bf16x8*>(dst2) = o; dst2 += dstep2; }
-#ifndef VP_EXP_NOSUMADD
                         if (sums) {
                             const float mk = row < rb ? 1.f : 0.f;
 #pragma unroll
@@ -159,7 +181,6 @@ __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8
                                 }
                             }
                         }
-#endif
                         row += 8;
                         cell += 8 * OROW;
                     }
@@ -195,10 +216,10 @@ __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8
                         float x = av[r] + bias4[r] + rbias[r];
                         if (a.act == VP_ACT_RELU) x = fmaxf(x, 0.f);
                         x = x * sc4[r] + sh4[r] + rs[r];
-                        if (a.act2 == VP_ACT_TANH) x = vp_tanh_for<bf16_t>(x);
+                        if (a.act2 == VP_ACT_TANH) x = vp_tanh_for<TO>(x);
                         else if (a.act2 == VP_ACT_RELU) x = fmaxf(x, 0.f);
                         else if (a.act2 == VP_ACT_HARDTANH20) x = fminf(fmaxf(x, 0.f), 20.f);
-                        else if (a.act2 == VP_ACT_SILU) x = vp_silu_for<bf16_t>(x);
+                        else if (a.act2 == VP_ACT_SILU) x = vp_silu_for<TO>(x);
                         v[r] = x;
                     }
                     if (ok) {
@@ -235,11 +256,7 @@ __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8
                 }
             }
         }
-#ifdef VP_EXP_NOSUMRED
-        if (false) {
-#else
         if (a.psum && fastw) {
-#endif
             // The 8 lanes of a channel group (equal lane & 7) hold partial sums of their 8 channels over disjoint rows.  Transposed
             // through the wave's slab (free after the last pass; one wave's LDS operations retire in order): every lane stores its
             // 8 partials of a quantity as one slab row segment, then lane = channel adds the 8 rows of its column -- 2 stores +
@@ -282,11 +299,7 @@ __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8
             }
         }
     }
-#ifdef VP_EXP_NOSUMFIN
-    if (false) {
-#else
     if (a.psum) {
-#endif
         // per 128-row half (= one M-tile of the 128-wide kernel's psum layout): the two waves' partials.
         // T_out >= 128 (host-checked, nseg == 2): a wave's 64 rows touch at most two utterances and
         // flush each (wave, segment) slot at most once; slots never flushed are never read.
@@ -656,7 +669,7 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(const ConvArgs a) {
     const unsigned long long te0 = wall_clock64();
 #endif
     __syncthreads();                                           // every wave is done reading the K panels
-    epilogue256<64>(a, acc, smem, tid, tm, m0, n0, [] {});
+    epilogue256<8, bf16_t>(a, acc, smem, tid, tm, m0, n0);
 #ifdef VP_TIMING
     if (!a.aux && a.add_in) {          // debug build only: per-workgroup phase stamps (100 MHz counter)
         __syncthreads();
@@ -875,6 +888,8 @@ __global__ __launch_bounds__(512) void conv_gemm256_ring_kernel(const ConvArgs a
 #ifdef VP_TIMING
     const unsigned long long tk0 = wall_clock64();
 #endif
+    // (acc = bias would save the epilogue's add per value, but hipcc waits vmcnt(0) for an ordinary load's result while LDS-DMAs are in
+    // flight: the first MFMA then drains the whole prologue -- measured +10 % on the 512 -> 512 layers.  Zero it is.)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -972,19 +987,8 @@ __global__ __launch_bounds__(512) void conv_gemm256_ring_kernel(const ConvArgs a
     const int ctm = tm, cm0 = m0, cn0 = n0;
     const int nbid = PERSIST ? bid + (int)gridDim.x : ntiles;
     __syncthreads();                                           // every wave is done reading the ring
-    if constexpr (PERSIST) {
-        // resident workgroup: the epilogue's LDS image lives in the set-1 buffers and the spare 32 KB while set 0 of the NEXT
-        // tile is staged behind it -- that tile's first MFMA then waits for no HBM round trip
-        epilogue256<32>(a, acc, smem + 4 * HT, tid, ctm, cm0, cn0, [&] {
-            if (nbid < ntiles) {
-                setup(nbid);
-                stage_set(0);
-            }
-        });
-        __syncthreads();                                       // the epilogue's LDS image is dead before set 1 is staged on it
-    } else {
-        epilogue256<64>(a, acc, smem, tid, ctm, cm0, cn0, [] {});
-    }
+    static_assert(!PERSIST, "the resident-workgroup variant (round 2, schedule 5: slower than one workgroup per tile) is no longer built");
+    epilogue256<8, bf16_t>(a, acc, smem, tid, ctm, cm0, cn0);
 #ifdef VP_TIMING
     if (!a.aux && a.add_in) {
         __syncthreads();
@@ -1019,6 +1023,7 @@ constexpr int HW = 128 * ROWB;               // W half-tile
 constexpr int R2_XA0 = 0, R2_XB0 = HX, R2_XA1 = 2 * HX, R2_XB1 = 3 * HX, R2_WA0 = 4 * HX, R2_WA1 = 4 * HX + HW, R2_WB = 4 * HX + 2 * HW;
 constexpr int R2_BYTES = 4 * HX + 3 * HW;    // 81,920 B: two workgroups fill the CU's 160 KB
 
+template <typename TO>
 __global__ __launch_bounds__(256, 2) void conv_gemm128x256_ring_kernel(const ConvArgs a) {
     constexpr int MI = 4, NI = 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1089,6 +1094,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm128x256_ring_kernel(const Con
     };
 
     f32x4 acc[MI][NI];
+    // (acc = bias would save the epilogue's add per value, but hipcc waits vmcnt(0) for an ordinary load's result while LDS-DMAs are in
+    // flight: the first MFMA then drains the whole prologue -- measured +10 % on the 512 -> 512 layers.  Zero it is.)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -1185,47 +1192,21 @@ __global__ __launch_bounds__(256, 2) void conv_gemm128x256_ring_kernel(const Con
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // zero-fill DMAs of the tail still target the buffers
     __syncthreads();                                           // every wave is done reading the ring
-    epilogue256<64, 4>(a, acc, smem, tid, tm, m0, n0, [] {});
+    epilogue256<4, TO>(a, acc, smem, tid, tm, m0, n0);
 }
 
+template <typename TO>
 int launch128x256_ring(vp_ctx* ctx, const ConvArgs& a, hipStream_t st) {
-    constexpr int smem = R2_BYTES;                             // >= the epilogue's 4 x 64 x 272 slabs + 8 KB of column-sum partials
+    constexpr int smem = R2_BYTES;                             // >= the epilogue's 4 x 64 x 272 images + 8 KB of column-sum partials
     static_assert(4 * 64 * 272 + 2 * 2 * 2 * T2 * 4 <= R2_BYTES, "epilogue image must fit the ring");
     static bool attr_set = false;
     if (!attr_set) {
-        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm128x256_ring_kernel),
+        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm128x256_ring_kernel<TO>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv_gemm128x256_ring_kernel, dim3(a.tiles_m * a.tiles_n), dim3(256), smem, st, a);
+    hipLaunchKernelGGL(conv_gemm128x256_ring_kernel<TO>, dim3(a.tiles_m * a.tiles_n), dim3(256), smem, st, a);
     VP_LAUNCH_CHECK(ctx, "conv_gemm128x256_ring");
-    return VP_OK;
-}
-
-static int cu_count(vp_ctx* ctx) {
-    static int n = 0;
-    if (n == 0) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || v <= 0) v = 256;
-        n = v - v % 8;                 // stride % 8 == 0 keeps a resident workgroup on its XCD's run of the tile order
-        if (n < 8) n = 8;
-    }
-    return n;
-}
-
-template <int MODE>
-int launch256_ring_persist(vp_ctx* ctx, const ConvArgs& a, hipStream_t st) {
-    constexpr int smem = 8 * 64 * 272 + 2 * 4 * 2 * T2 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm256_ring_kernel<MODE, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
-    const int ntiles = a.tiles_m * a.tiles_n;
-    const int grid = ntiles < cu_count(ctx) ? ntiles : cu_count(ctx);
-    hipLaunchKernelGGL((conv_gemm256_ring_kernel<MODE, true>), dim3(grid), dim3(512), smem, st, a);
-    VP_LAUNCH_CHECK(ctx, "conv_gemm256_ring_persist");
     return VP_OK;
 }
 
@@ -1260,8 +1241,10 @@ int launch256(vp_ctx* ctx, const ConvArgs& a, hipStream_t st) {
 }  // namespace
 
 // args: ConvArgs with tiles_m / tiles_n / group_m already set for 256-wide tiles
-int vp_conv_launch256_bf16(vp_ctx* ctx, const void* args, int mode, int sched, hipStream_t st) {
+// out_f32: bf16 operands, f32 output (the training engine's data-gradient GEMMs) -- schedule 6 only
+int vp_conv_launch256_bf16(vp_ctx* ctx, const void* args, int mode, int sched, int out_f32, hipStream_t st) {
     const ConvArgs& a = *static_cast<const ConvArgs*>(args);
+    if (out_f32 && (sched != 5 || mode != MODE_1X1)) VP_FAIL(ctx, VP_EUNSUP, "conv256: f32 output needs the 128 x 256 schedule on a 1x1 layer");
     if (sched == 0) {
         if (mode == MODE_1X1) return launch256<MODE_1X1, 0>(ctx, a, st);
         if (mode == MODE_TAPS) return launch256<MODE_TAPS, 0>(ctx, a, st);
@@ -1270,10 +1253,10 @@ int vp_conv_launch256_bf16(vp_ctx* ctx, const void* args, int mode, int sched, h
         if (mode == MODE_TAPS) return launch256<MODE_TAPS, 1>(ctx, a, st);
     } else if (sched == 5) {
         // two workgroups per CU on 128 x 256 tiles (1x1 layers); args carry tiles_m in 128-row units
-        if (mode == MODE_1X1) return launch128x256_ring(ctx, a, st);
+        if (mode == MODE_1X1) return out_f32 ? launch128x256_ring<float>(ctx, a, st) : launch128x256_ring<bf16_t>(ctx, a, st);
     } else if (sched == 3 || sched == 4) {
         // half-tile ring: one workgroup per tile (3) or resident workgroups (4)
-        if (mode == MODE_1X1) return sched == 3 ? launch256_ring<MODE_1X1>(ctx, a, st) : launch256_ring_persist<MODE_1X1>(ctx, a, st);
+        if (mode == MODE_1X1) return launch256_ring<MODE_1X1>(ctx, a, st);      // (4 = resident workgroups: no longer built, runs as 3)
         // tapped convs stay on the two-stage schedule: their per-piece tap / reflect arithmetic pushes the ring loop past
         // 256 VGPRs (scratch reloads inside the loop wait vmcnt(0) and drain the ring)
         if (mode == MODE_TAPS) return a.Cin % 64 == 0 ? launch256<MODE_TAPS, 2>(ctx, a, st) : launch256<MODE_TAPS_GEN, 2>(ctx, a, st);

@@ -69,7 +69,7 @@ def _wide_bf16(M, Cin, Cout, KW, bias, rowbias, gamma, cfg):
     what the matrix cores would round them to anyway -- so the forward, data-gradient and weight-gradient kernels read half the
     bytes and skip the conversion (vp_conv1d_fwd bf16 -> f32, vp_conv1d_wgrad_bf16_oik).  VPMI_TRAIN_BF16_OPS=0 keeps f32 operands."""
     if not (ppvector.get_train_amp() and KW == 1 and gamma is not None and bias is not None and rowbias is None and Cin % 64 == 0
-            and Cin >= 256 and Cout >= 256 and Cout % 4 == 0 and M >= 16384 and not cfg.get('tanh', False)):
+            and Cin >= 256 and Cout >= 256 and Cout % 4 == 0 and M >= 4096 and not cfg.get('tanh', False)):
         return 0
     return int(os.environ.get('VPMI_TRAIN_BF16_OPS', '2'))
 
