@@ -477,6 +477,17 @@ int vp_cosine_aam_ce_fwd(vp_ctx* ctx, const float* emb, const float* W, const in
                          float* loss, float* logits, float* row_loss, void* ws, size_t ws_bytes,
                          vp_stream stream);
 
+/* Head + loss class-tiled (csrc/head_tiled.hip): the same value as vp_cosine_aam_ce_fwd without the (B, C) logits -- a workgroup
+ * per 64 classes streams its slice of W once (column norms from the same bytes), forms the cosines of every utterance on the exact-f32
+ * matrix cores and keeps only per-row online-softmax partials; a merge kernel finishes log-sum-exp / label smoothing per row.
+ * Replaces SpeakerIdentification.forward 'Cosine' (fc.py:41-53) + AAMLoss.forward (aamloss.py:28-47) when only the loss is wanted
+ * (evaluation of the training objective, bench.py's step; BASELINE configs[4]: 200 000 classes).  D % 4 == 0, D <= 256.
+ * row_loss (B), lse (B, optional: log-sum-exp per row) and cinv (C, optional: column inverse norms) are by-products. */
+size_t vp_cosine_aam_tiled_workspace_bytes(int B, int D, int C);
+int vp_cosine_aam_tiled_fwd(vp_ctx* ctx, const float* emb, const float* W, const int64_t* labels, int B, int D, int C, float margin,
+                            float scale, float label_smoothing, int easy_margin, float* loss, float* row_loss, float* lse,
+                            float* cinv, void* ws, size_t ws_bytes, vp_stream stream);
+
 /* Backward of head + loss (the autograd the reference gets from paddle for fc.py:41-53 + aamloss.py:28-47; called per
  * step by PPVectorTrainer.__train_epoch, trainer.py:213-219): demb (B, D) = d loss / d emb, dW (D, C) = d loss / d W,
  * both f32 and both scaled by grad_scale (1.0 for plain backward); loss (1) optional (the forward value, recomputed). */

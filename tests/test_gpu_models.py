@@ -21,6 +21,19 @@ def _cos_rows(a, b):
     return np.sum(a * b, 1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
 
 
+# north_star's parity bound is on cosine SCORES: all-pairs scores of a batch against the oracle's.  The f32 engines are held to
+# 1e-4 everywhere.  bf16 storage of activations (2^-9 relative per element, f32 accumulation and statistics) meets 1e-4 on ECAPA-TDNN /
+# TDNN (tests above and tests/test_gpu_timed_path.py); on the deep 2-D backbones it does not: their measured bound is asserted here,
+# printed, and stated in README.md -- which is why 'float32' is the package default (ppvector.set_compute_dtype) and bf16 is opt-in.
+BF16_SCORE_BOUND = {'campplus': 1.5e-3, 'resnetse': 3e-3, 'eres2net': 6e-3}
+
+
+def _score_err(emb, ref):
+    e, r = np.asarray(emb, np.float64), np.asarray(ref, np.float64)
+    e, r = e / np.linalg.norm(e, axis=1, keepdims=True), r / np.linalg.norm(r, axis=1, keepdims=True)
+    return float(np.abs(e @ e.T - r @ r.T).max())
+
+
 @pytest.fixture(scope='module')
 def ecapa():
     if not torch.cuda.is_available():
@@ -401,6 +414,30 @@ def test_eres2net_large_matches_reference_golden(golden_dir):
         assert rel < tol, (dtype, rel)
 
 
+def test_eres2net_large_all_pairs_scores_vs_oracle():
+    """BASELINE configs[4]'s backbone (ERes2Net-large, 55.2 M parameters) on 8 utterances x 1.5 s: all-pairs cosine scores against the
+    oracle graph (itself pinned on the reference's eres2net.py by the golden above).  f32 engine: north_star's 1e-4; bf16 engine: the
+    stated bound of the 2-D backbones (46 convolutions deep; bf16 activations)."""
+    from oracle import eres2net as oer
+    from ppvector.models.eres2net import ERes2Net
+    LARGE = dict(m_channels=64, mul_channel=2, expansion=4, base_width=24, scale=3)
+    p = oer.eres2net_params(80, 192, seed=77, **LARGE)
+    w = ofb.synth_waves(8, 24000, seed=13, lowpass=0.9)
+    feats = ofb.featurize(w, method_args=dict(sr=16000, n_mels=80))
+    torch.set_num_threads(min(32, len(__import__('os').sched_getaffinity(0))))
+    with torch.no_grad():
+        ref = oer.eres2net_forward(p, torch.from_numpy(feats), m_channels=64, expansion=4, base_width=24, scale=3).numpy()
+    m = ERes2Net(80, embd_dim=192, **LARGE)
+    m.load_state_dict(p)
+    m = m.cuda().eval()
+    x = torch.from_numpy(feats).cuda()
+    for dtype in ('float32', 'bfloat16'):
+        emb = m.engine(dtype).forward(x).cpu().numpy()
+        se = _score_err(emb, ref)
+        print(f'[eres2net-large {dtype}, 8 x 1.5 s] rel-L2 {np.linalg.norm(emb - ref) / np.linalg.norm(ref):.3e}  all-pairs max |score - oracle| {se:.3e}')
+        assert se < (1e-4 if dtype == 'float32' else BF16_SCORE_BOUND['eres2net']), (dtype, se)
+
+
 @pytest.mark.parametrize('Cn,B', [(7205, 64), (200000, 128)])
 def test_cosine_head_and_aam_at_named_class_counts(Cn, B):
     """BASELINE configs[2] (CAM++: 7 205 classes) and configs[4] (200 000-class ArcFace head, 128 utterances per GPU): cosine
@@ -432,6 +469,68 @@ def test_cosine_head_and_aam_at_named_class_counts(Cn, B):
     head.load_state_dict({'weight': W})
     lg = head.cuda().eval()(emb.cuda())['logits'].double().cpu()
     assert (lg - om.cosine_head(emb.double(), W.double())).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize('Cn,B,ls,easy', [(2796, 256, 0.0, False), (200000, 128, 0.0, False), (1003, 37, 0.1, True), (7205, 64, 0.05, False)])
+def test_class_tiled_head_and_loss_vs_float64(Cn, B, ls, easy):
+    """csrc/head_tiled.hip (cosine head + AAM loss per 64-class tile, online log-sum-exp, no (B, C) tensor) against float64 and
+    against the unfused path (logits tensor + row kernel): BASELINE configs[1] (2 796 x 256), configs[4] (200 000 x 128), a ragged
+    class count with label smoothing and the easy margin, configs[2]'s head.  Also prints what the pass costs."""
+    from ppvector.loss.aamloss import AAMLoss
+    from ppvector.models.fc import CosineHeadOutputs, SpeakerIdentification
+    D = 192
+    g = torch.Generator().manual_seed(Cn % 1000 + B)
+    W = om.head_params(D, Cn, seed=5)
+    emb = torch.randn(B, D, generator=g) * 3
+    labels = torch.randint(0, Cn, (B,), generator=g)
+    labels[0], labels[-1] = 0, Cn - 1
+    m, sc = 0.25, 32.0
+    e64, W64 = emb.double(), W.double()
+    cos = torch.nn.functional.normalize(e64, dim=1) @ torch.nn.functional.normalize(W64, dim=0)
+    idx = torch.arange(B)
+    ct = cos[idx, labels]
+    phi = ct * np.cos(m) - torch.sqrt(1 - ct * ct) * np.sin(m)
+    tgt = torch.where(ct > 0, phi, ct) if easy else torch.where(ct > np.cos(np.pi - m), phi, ct - (1 + np.cos(np.pi - m)))
+    out = cos.clone()
+    out[idx, labels] = tgt
+    out = out * sc
+    lse = torch.logsumexp(out, dim=1)
+    ref_rows = (1 - ls) * (lse - out[idx, labels]) + ls * (lse - out.mean(dim=1))
+    head = SpeakerIdentification(D, Cn)
+    head.load_state_dict({'weight': W})
+    head = head.cuda().eval()
+    crit = AAMLoss(margin=m, scale=sc, easy_margin=easy, label_smoothing=ls)
+    outs = head(emb.cuda())
+    assert isinstance(outs, CosineHeadOutputs) and not dict.__contains__(outs, 'logits')
+    loss = crit(outs, labels.cuda())
+    assert not dict.__contains__(outs, 'logits')                      # the logits were never formed
+    rows = crit.row_loss.double().cpu()
+    rl = abs(loss.item() - ref_rows.mean().item()) / abs(ref_rows.mean().item())
+    rr = ((rows - ref_rows).abs().max() / ref_rows.abs().max()).item()
+    # the unfused path on the same operands
+    outs2 = head(emb.cuda())
+    lg = outs2['logits']
+    loss2 = crit(outs2, labels.cuda())
+    assert (lg.double().cpu() - cos).abs().max().item() < 2e-6
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    x = emb.cuda()
+    for _ in range(2):
+        crit(head(x), labels.cuda())
+    ev[0].record()
+    for _ in range(5):
+        crit(head(x), labels.cuda())
+    ev[1].record()
+    for _ in range(2):
+        o = head(x); o['logits']; crit(o, labels.cuda())
+    ev[2].record()
+    for _ in range(5):
+        o = head(x); o['logits']; crit(o, labels.cuda())
+    ev[3].record()
+    torch.cuda.synchronize()
+    print(f'[tiled head C={Cn} B={B} ls={ls} easy={easy}] loss {loss.item():.6f} (float64 {ref_rows.mean().item():.6f}, rel {rl:.1e}; unfused {loss2.item():.6f}); '
+          f'worst row {rr:.1e}; head + loss per call: tiled {ev[0].elapsed_time(ev[1]) / 5 * 1e3:.0f} us, logits tensor + row kernel {ev[2].elapsed_time(ev[3]) / 5 * 1e3:.0f} us')
+    assert rl < 2e-5 and rr < 5e-5
+    assert abs(loss.item() - loss2.item()) < 2e-5 * abs(loss2.item())
 
 
 def test_resnetse_melspectrogram_specaugment_pipeline():
@@ -468,8 +567,10 @@ def test_resnetse_melspectrogram_specaugment_pipeline():
         emb = m.engine(dtype).forward(aug).cpu().numpy()
         rel = np.linalg.norm(emb - ref) / np.linalg.norm(ref)
         c = _cos_rows(emb, ref)
-        print(f'[resnetse <- mel64 <- specaug {dtype}] rel-L2 {rel:.3e}  1-cos {1 - c.min():.3e}')
+        se = _score_err(emb, ref)
+        print(f'[resnetse <- mel64 <- specaug {dtype}] rel-L2 {rel:.3e}  1-cos {1 - c.min():.3e}  all-pairs (32 x 32) max |score - oracle| {se:.3e}')
         assert rel < tol, (dtype, rel)
+        assert se < (1e-4 if dtype == 'float32' else BF16_SCORE_BOUND['resnetse']), (dtype, se)
 
 
 def test_campplus_named_config_shapes():
@@ -492,8 +593,13 @@ def test_campplus_named_config_shapes():
     feats = AudioFeaturizer('Fbank', dict(sr=16000, n_mels=80))(torch.from_numpy(w).cuda())
     emb = m.engine('float32').forward(feats)
     rel = np.linalg.norm(emb.cpu().numpy() - ref) / np.linalg.norm(ref)
-    print(f'[cam++ B=64 x 3 s float32] rel-L2 {rel:.3e}')
-    assert rel < 5e-4
+    se = _score_err(emb.cpu().numpy(), ref)
+    print(f'[cam++ B=64 x 3 s float32] rel-L2 {rel:.3e}  all-pairs (64 x 64) max |score - oracle| {se:.3e}')
+    assert rel < 5e-4 and se < 1e-4
+    e16 = m.engine('bfloat16').forward(feats).cpu().numpy()
+    se16 = _score_err(e16, ref)
+    print(f'[cam++ B=64 x 3 s bfloat16] rel-L2 {np.linalg.norm(e16 - ref) / np.linalg.norm(ref):.3e}  all-pairs max |score - oracle| {se16:.3e}')
+    assert se16 < BF16_SCORE_BOUND['campplus'], se16
     W = om.head_params(192, 7205, seed=3)
     head = SpeakerIdentification(192, 7205)
     head.load_state_dict({'weight': W})

@@ -108,3 +108,22 @@ def test_bench_shape_scores_vs_oracle_on_its_own_features(rig):
               f'max |score - oracle| = {res[dt]:.3e}; worst 1 - cos(emb, oracle) = {worst:.3e}')
     assert res['float32'] < 1e-4, res
     assert res['bfloat16'] < 1e-4, res
+
+
+def test_concurrent_launch_sequences_stay_bit_identical_under_load(rig):
+    """Race / interference screen of what bench.py runs (two launch sequences) and of four: 40 forwards each, every embedding
+    compared bit for bit with the single-stream result.  Round 3 found the bf16 128-column conv tile corrupting kernels that ran
+    beside it here (2 % of forwards at two streams, 70 % at four; csrc/conv_gemm.hip); it is no longer dispatched."""
+    bench, dev, parts, wavs, labels = rig
+    fz, model, head, _, _ = parts['bfloat16']
+    model.eval()
+    eng = model.engine('bfloat16')
+    ref = eng.forward(fz(wavs[2], want_bf16=True)).clone()
+    bad = {2: 0, 4: 0}
+    for _ in range(40):
+        for S in (2, 4):
+            e = eng.forward_streams(wavs[2], S, producer=lambda w: fz(w, want_bf16=True))
+            torch.cuda.synchronize()
+            bad[S] += int(not torch.equal(e, ref))
+    print(f'[timed path] 40 forwards per setting, embeddings differing from the single-stream run: {bad}')
+    assert bad == {2: 0, 4: 0}, bad

@@ -967,9 +967,11 @@ def _tdnn_block_run(xs, w, b, gam, bet, dy, B, T, cat):
 
 @pytest.mark.parametrize('cat,level', [(False, 1), (True, 1), (False, 2), (True, 2)])
 def test_wide_bf16_operands_equal_f32_operand_amp(N, amp, cat, level, monkeypatch):
-    """enable_amp, wide 1x1 TDNN blocks (M >= 16384, C >= 256).  Level 1: x and dz kept as bf16 tensors (bf16 -> f32 conv kernels,
-    bf16-input weight gradient, dz written as bf16 by the BatchNorm backward) must give what the f32-operand mixed-precision kernels
-    give -- the same roundings, only the accumulation order differs (2e-5).  Level 2 (the default): the pre-BatchNorm activation z is
+    """enable_amp, wide 1x1 TDNN blocks (M >= 4096, C >= 256).  Level 1: x and dz kept as bf16 tensors (bf16 -> f32 conv kernels --
+    since round 3 the 128 x 256 LDS-DMA kernel for forward and data gradient --, bf16-input weight gradient, dz written as bf16 by
+    the BatchNorm backward) must give what the f32-operand mixed-precision kernels give: the same roundings, only the accumulation
+    order differs.  y: 2e-5.  The gradients see the order through the ReLU mask: a pre-activation within an ulp of 0
+    lands on the other side in a handful of the 9.8 M elements and moves dz there by a whole gradient value -- 3e-4 (measured 9e-5).  Level 2 (the default): the pre-BatchNorm activation z is
     stored as bf16 too (forward on the 256-wide bf16 -> bf16 kernel, batch statistics from its f32 accumulators): ONE more rounding of
     2^-9 relative per element of z, so outputs and gradients stay within 5e-3 rel-L2 of level 0 (measured ~1e-3).
     cat: the MFA form (CatConvBlock builds the bf16 concatenation)."""
@@ -991,7 +993,7 @@ def test_wide_bf16_operands_equal_f32_operand_amp(N, amp, cat, level, monkeypatc
         if name.startswith('running'):
             assert e < 2e-5, (name, e)               # statistics come from the f32 accumulators at every level
         elif level == 1:
-            assert e < (2e-4 if name == 'dbias' else 2e-5), (name, e)
+            assert e < (2e-5 if name == 'y' else 3e-4), (name, e)
         else:
             assert e < (2e-2 if name == 'dbias' else 5e-3), (name, e)
 
@@ -1031,7 +1033,9 @@ def test_asp_bf16_logit_gradient_stays_within_bf16_of_the_f32_path(N, amp, monke
 def test_ecapa_amp_operand_levels_agree_at_bench_scale(N, monkeypatch):
     """ECAPA-TDNN training step under enable_amp at the bench utterance length (56 x 298 frames = 16 688 rows: the wide layers take
     their bf16-operand paths), against the f32 engine's step on the same batch (itself within 7e-4 of float64 autograd).
-    Level 1 (bf16 GEMM operands) must reproduce level 0 (f32 operands rounded on the fly) bit for bit.  Level 2 (the default: the
+    Level 1 (bf16 GEMM operands: the same roundings as level 0's f32 operands rounded on the fly, but since round 3 on the 128 x 256
+    LDS-DMA kernel -- another accumulation order, and through ReLU masks / train-mode BatchNorm an ulp is amplified like any other
+    perturbation of this graph) must be no further from the f32 step than level 0 is (x 1.1).  Level 2 (the default: the
     pre-BatchNorm activation of the seven wide layers stored as bf16) is one more rounding of 2^-9 per element of those tensors; on
     this random-init graph every bf16 rounding is amplified by the train-mode BatchNorm backward (see
     test_ecapa_training_step_mixed_precision), so the yardstick is the distance to the f32 step: level 2 must be no further from
@@ -1072,6 +1076,6 @@ def test_ecapa_amp_operand_levels_agree_at_bench_scale(N, monkeypatch):
     print(f'[ecapa amp levels] loss f32 {lx:.5f}, levels 0 / 1 / 2: {l0:.5f} / {l1:.5f} / {l2:.5f};  emb rel-L2 vs f32: {rel(e0, ex):.2e} / '
           f'{rel(e1, ex):.2e} / {rel(e2, ex):.2e};  whole-gradient rel-L2 vs f32: {whole(g0, gx):.2e} / {whole(g1, gx):.2e} / '
           f'{whole(g2, gx):.2e};  level 2 vs level 0: emb {rel(e2, e0):.2e}, gradient {whole(g2, g0):.2e}')
-    assert l1 == l0 and rel(e1, e0) == 0.0 and whole(g1, g0) == 0.0
+    assert abs(l1 - lx) < 2e-3 * abs(lx) and rel(e1, ex) < 1.1 * rel(e0, ex) + 1e-3 and whole(g1, gx) < 1.1 * whole(g0, gx)
     assert abs(l2 - lx) < 2e-3 * abs(lx) and rel(e2, ex) < 1.25 * rel(e0, ex) + 1e-3
     assert whole(g2, gx) < 1.25 * whole(g0, gx)

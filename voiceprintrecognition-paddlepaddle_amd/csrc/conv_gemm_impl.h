@@ -3,6 +3,8 @@
 #pragma once
 #include "common.h"
 
+#include <stdlib.h>
+
 #include <type_traits>
 
 namespace {

@@ -11,6 +11,8 @@
 // global-context concat of ASP (its mean/std columns collapse to a per-utterance bias).
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 struct Carver {
@@ -55,7 +57,8 @@ int vp_run_asp(vp_ctx* ctx, const vp_asp_weights& A, int dtype, const void* x, i
     d.y = w.h; d.ldy = A.att; d.yoff = 0;
     rc = vp_conv1d_fwd(ctx, &d, st);
     if (rc) return rc;
-    if (dtype == VP_BF16) {       // logits GEMM + softmax + weighted stats in one kernel; no (B*T, C) f32 logits
+    static const bool asp_unfused = getenv("VPMI_ASP_UNFUSED") != nullptr;           // A/B and race screens
+    if (dtype == VP_BF16 && !asp_unfused) {       // logits GEMM + softmax + weighted stats in one kernel; no (B*T, C) f32 logits
         rc = vp_asp_fused_bf16(ctx, w.h, A.conv_w, A.conv_b, x, ldx, w.stats, 2 * C, B, T, C, A.att, 1e-12f, w.pooled, st);
         if (rc != VP_EUNSUP) return rc;
     }
@@ -186,7 +189,8 @@ int vp_ecapa_fwd(vp_ctx* ctx, const vp_ecapa_weights* w, const void* feats, int 
         if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
         // Res2Net chain: fused per-utterance kernel when it fits LDS, else one launch per conv
         int fused = VP_EUNSUP;
-        if (dt == VP_BF16) fused = vp_res2_chain_bf16(ctx, blk.res2, sc - 1, p.t1, p.r2, B, T, C, width, st);
+        static const bool res2_unfused = getenv("VPMI_RES2_UNFUSED") != nullptr;      // A/B and race screens: one launch per conv
+        if (dt == VP_BF16 && !res2_unfused) fused = vp_res2_chain_bf16(ctx, blk.res2, sc - 1, p.t1, p.r2, B, T, C, width, st);
         if (fused != VP_OK && fused != VP_EUNSUP) return fused;
         void* tin = nullptr;
         void* tout = p.tmpA;

@@ -3,6 +3,8 @@
 // All HBM/L2-bound or tiny; kept in f32 so that they add no error on top of the f32 reference.
 #include "common.h"
 
+#include <stdlib.h>
+
 #include <type_traits>
 
 namespace {

@@ -22,6 +22,10 @@ class AAMLoss(nn.Module):
         self.update(margin)
 
     def forward(self, inputs, labels):
+        from ppvector.models.fc import CosineHeadOutputs
+        if isinstance(inputs, CosineHeadOutputs) and not dict.__contains__(inputs, 'logits') and inputs.W.shape[0] % 4 == 0 \
+                and inputs.W.shape[0] <= 256:
+            return self._tiled(inputs, labels)          # evaluation-mode head + loss in one pass over the class weights
         features, logits = inputs['features'], inputs['logits']
         if not logits.is_cuda:
             raise N.VpmiError('AAMLoss needs GPU tensors: the engine has no CPU fallback')
@@ -39,6 +43,22 @@ class AAMLoss(nn.Module):
                                   loss.data_ptr(), row.data_ptr(), N.stream_ptr()), ctx)
         self.row_loss = row
         return loss[0]
+
+    def _tiled(self, inputs, labels):
+        """csrc/head_tiled.hip: cosine logits (exact f32 matrix cores) -> margin -> online log-sum-exp per 64-class tile, merged per
+        row; the (B, C) logits never exist."""
+        x, W = inputs.x, inputs.W
+        labels = labels.to(device=x.device, dtype=torch.int64).reshape(-1).contiguous()
+        B, D = x.shape
+        Cn = W.shape[1]
+        lib, ctx = N.lib(), N.ctx(x.device)
+        out = torch.empty((1 + 2 * B,), dtype=torch.float32, device=x.device)            # loss | row losses | row log-sum-exps
+        ws = inputs._ws.get(lib.vp_cosine_aam_tiled_workspace_bytes(B, D, Cn), x.device)
+        N.check(lib.vp_cosine_aam_tiled_fwd(ctx, x.data_ptr(), W.data_ptr(), labels.data_ptr(), B, D, Cn, float(self.margin), float(self.scale),
+                                            float(self.label_smoothing), int(bool(self.easy_margin)), out.data_ptr(), out[1:].data_ptr(),
+                                            out[1 + B:].data_ptr(), None, ws.data_ptr(), ws.numel(), N.stream_ptr()), ctx)
+        self.row_loss = out[1:1 + B]
+        return out[0]
 
     def update(self, margin=0.2):
         self.margin = margin

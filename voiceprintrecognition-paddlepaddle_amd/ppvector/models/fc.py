@@ -86,6 +86,54 @@ class _LinearParams(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_features))
 
 
+class CosineHeadOutputs(dict):
+    """The reference's {"features", "logits"} dict (fc.py:53) whose (B, C) cosine logits exist only if somebody reads them: the
+    evaluation-mode forward of the 'Cosine' head defers the GEMM, so that AAMLoss can run head + loss class-tiled in one pass over the
+    weights (csrc/head_tiled.hip: no (B, C) tensor -- 102 MB for 200 000 classes x 128 utterances) while `outputs["logits"]` still
+    works for every other consumer."""
+
+    def __init__(self, features, x, W, ws):
+        super().__init__(features=features)
+        self.x, self.W, self._ws = x, W, ws
+
+    def _logits(self):
+        if not dict.__contains__(self, 'logits'):
+            x, W = self.x, self.W
+            B, D = x.shape
+            Cn = W.shape[1]
+            lib, ctx = N.lib(), N.ctx(x.device)
+            logits = torch.empty((B, Cn), dtype=torch.float32, device=x.device)
+            ws = self._ws.get(lib.vp_cosine_logits_workspace_bytes(B, D, Cn), x.device)
+            N.check(lib.vp_cosine_logits_f32(ctx, x.data_ptr(), W.data_ptr(), B, D, Cn, logits.data_ptr(),
+                                             ws.data_ptr(), ws.numel(), N.stream_ptr()), ctx)
+            dict.__setitem__(self, 'logits', logits)
+        return dict.__getitem__(self, 'logits')
+
+    def __getitem__(self, k):
+        return self._logits() if k == 'logits' else dict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        return self._logits() if k == 'logits' else dict.get(self, k, default)
+
+    def __contains__(self, k):
+        return k == 'logits' or dict.__contains__(self, k)
+
+    def keys(self):
+        return ['features', 'logits']
+
+    def items(self):
+        return [('features', dict.__getitem__(self, 'features')), ('logits', self._logits())]
+
+    def values(self):
+        return [v for _, v in self.items()]
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return 2
+
+
 class SpeakerIdentification(nn.Module):
     def __init__(self, input_dim, num_speakers, classifier_type='Cosine', K=1, num_blocks=0, inter_dim=512):
         super().__init__()
@@ -123,11 +171,4 @@ class SpeakerIdentification(nn.Module):
             return {"features": features, "logits": CosineLogits.apply(x.float(), self.weight)}
         x = x.contiguous().float()
         W = self.weight.detach().contiguous().float()
-        B, D = x.shape
-        Cn = W.shape[1]
-        lib, ctx = N.lib(), N.ctx(x.device)
-        logits = torch.empty((B, Cn), dtype=torch.float32, device=x.device)
-        ws = self._ws.get(lib.vp_cosine_logits_workspace_bytes(B, D, Cn), x.device)
-        N.check(lib.vp_cosine_logits_f32(ctx, x.data_ptr(), W.data_ptr(), B, D, Cn, logits.data_ptr(),
-                                         ws.data_ptr(), ws.numel(), N.stream_ptr()), ctx)
-        return {"features": features, "logits": logits}
+        return CosineHeadOutputs(features, x, W, self._ws)
