@@ -482,11 +482,21 @@ int vp_cosine_aam_ce_fwd(vp_ctx* ctx, const float* emb, const float* W, const in
  * matrix cores and keeps only per-row online-softmax partials; a merge kernel finishes log-sum-exp / label smoothing per row.
  * Replaces SpeakerIdentification.forward 'Cosine' (fc.py:41-53) + AAMLoss.forward (aamloss.py:28-47) when only the loss is wanted
  * (evaluation of the training objective, bench.py's step; BASELINE configs[4]: 200 000 classes).  D % 4 == 0, D <= 256.
- * row_loss (B), lse (B, optional: log-sum-exp per row) and cinv (C, optional: column inverse norms) are by-products. */
+ * row_loss (B), lse (B, optional: log-sum-exp per row), cinv (C, optional: column inverse norms) and pred (B int32, optional: argmax of
+ * the un-margined cosine = the prediction trainer.py:233-236 takes from outputs["logits"], first index on ties) are by-products. */
 size_t vp_cosine_aam_tiled_workspace_bytes(int B, int D, int C);
 int vp_cosine_aam_tiled_fwd(vp_ctx* ctx, const float* emb, const float* W, const int64_t* labels, int B, int D, int C, float margin,
                             float scale, float label_smoothing, int easy_margin, float* loss, float* row_loss, float* lse,
-                            float* cinv, void* ws, size_t ws_bytes, vp_stream stream);
+                            float* cinv, int* pred, void* ws, size_t ws_bytes, vp_stream stream);
+
+/* The training step's head: forward value + d emb + d W class-tiled (no (B, C) cosine / gradient tensors; W streamed twice instead of
+ * four times): per 64-class tile the cosines are recomputed and three f32-MFMA products run out of LDS / registers.  B <= 128 (the per-GPU
+ * batch of BASELINE configs[4]) and D == 192, else VP_EUNSUP -- callers then take vp_cosine_aam_ce_bwd.  Same results as that entry point
+ * to f32 rounding.  Replaces the autograd of fc.py:41-53 + aamloss.py:28-47 (trainer.py:213-219). */
+size_t vp_cosine_aam_tiled_bwd_workspace_bytes(int B, int D, int C);
+int vp_cosine_aam_tiled_bwd(vp_ctx* ctx, const float* emb, const float* W, const int64_t* labels, int B, int D, int C, float margin,
+                            float scale, float label_smoothing, int easy_margin, float grad_scale, float* demb, float* dW, float* loss,
+                            int* pred, void* ws, size_t ws_bytes, vp_stream stream);
 
 /* Backward of head + loss (the autograd the reference gets from paddle for fc.py:41-53 + aamloss.py:28-47; called per
  * step by PPVectorTrainer.__train_epoch, trainer.py:213-219): demb (B, D) = d loss / d emb, dW (D, C) = d loss / d W,

@@ -455,7 +455,7 @@ def test_cosine_head_and_aam_at_named_class_counts(Cn, B):
     ref = om.aam_loss(om.cosine_head(e64, W64), labels, 0.2, 32.0, False, 0.0)
     ref.backward()
     ed, Wd = emb.cuda().requires_grad_(), W.cuda().requires_grad_()
-    loss = HeadLoss.apply(ed, Wd, labels.cuda(), 0.2, 32.0, 0.0, False)
+    loss = HeadLoss.apply(ed, Wd, labels.cuda(), 0.2, 32.0, 0.0, False)[0]
     loss.backward()
     torch.cuda.synchronize()
     rl = abs(loss.item() - ref.item()) / abs(ref.item())
@@ -605,3 +605,40 @@ def test_campplus_named_config_shapes():
     head.load_state_dict({'weight': W})
     lg = head.cuda().eval()(emb)['logits'].double().cpu()
     assert (lg - om.cosine_head(torch.from_numpy(ref).double(), W.double())).abs().max().item() < 5e-4
+
+
+def test_training_head_runs_class_tiled_and_reports_predictions():
+    """The product's training objects (nn.Sequential(backbone, SpeakerIdentification) -> AAMLoss, trainer.py:175-213): in train mode the
+    head hands AAMLoss embeddings + weights, HeadLoss runs class-tiled (no logits tensor), and the batch accuracy comes from the
+    kernel's argmax -- equal to argmax over explicitly formed logits; gradients equal the logits-tensor path's."""
+    from ppvector.loss.aamloss import AAMLoss
+    from ppvector.models.fc import CosineHeadOutputs, SpeakerIdentification
+    from ppvector.train.step import batch_accuracy
+    B, D, Cn = 96, 192, 5003
+    g = torch.Generator().manual_seed(4)
+    emb0 = (torch.randn(B, D, generator=g) * 2).cuda()
+    labels = torch.randint(0, Cn, (B,), generator=g).cuda()
+    head = SpeakerIdentification(D, Cn).cuda().train()
+    crit = AAMLoss(margin=0.2, scale=32, label_smoothing=0.05)
+    with torch.no_grad():                                            # make some predictions right: pull a few embeddings onto their class
+        head.weight[:, labels[:40]] = 0.02 * emb0[:40].t() + head.weight[:, labels[:40]]       # cosine ~0.6: well inside (-1, 1)
+    res = {}
+    for mode in ('tiled', 'logits'):
+        head.weight.grad = None
+        emb = emb0.clone().requires_grad_()
+        out = head(emb)
+        assert isinstance(out, CosineHeadOutputs)
+        if mode == 'logits':
+            _ = out['logits']                                        # somebody reads the logits: the criterion must then use them
+        loss = crit(out, labels)
+        assert (out.pred is not None) == (mode == 'tiled')
+        assert dict.__contains__(out, 'logits') == (mode == 'logits')
+        acc = batch_accuracy(out, labels)
+        loss.backward()
+        res[mode] = (loss.item(), acc.item(), emb.grad.clone(), head.weight.grad.clone())
+    (l1, a1, ge1, gw1), (l2, a2, ge2, gw2) = res['tiled'], res['logits']
+    re = ((ge1 - ge2).norm() / ge2.norm()).item()
+    rw = ((gw1 - gw2).norm() / gw2.norm()).item()
+    print(f'[training head] loss tiled {l1:.6f} / logits path {l2:.6f}; accuracy {a1:.4f} / {a2:.4f}; d emb rel-L2 {re:.1e}, d W rel-L2 {rw:.1e}')
+    assert abs(l1 - l2) < 2e-5 * abs(l2) and a1 == a2 and 0.3 < a1 < 0.6
+    assert re < 1e-4 and rw < 1e-4

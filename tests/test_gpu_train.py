@@ -124,7 +124,7 @@ def test_head_loss_grads_vs_autograd(N, cfg):
     loss = om.aam_loss(om.cosine_head(emb, W), labels, margin, 32.0, easy, ls)
     loss.backward()
     ed, Wd = emb.detach().float().cuda().requires_grad_(), W.detach().float().cuda().requires_grad_()
-    lo = HeadLoss.apply(ed, Wd, labels.cuda(), margin, 32.0, ls, easy)
+    lo = HeadLoss.apply(ed, Wd, labels.cuda(), margin, 32.0, ls, easy)[0]
     (lo * 1.0).backward()
     assert abs(lo.item() - loss.item()) < 1e-4 * max(1.0, abs(loss.item()))
     assert rel(ed.grad, emb.grad) < 5e-5 and rel(Wd.grad, W.grad) < 5e-5
@@ -215,7 +215,7 @@ def test_tdnn_training_step_vs_oracle_autograd(N):
         head.weight.copy_(Wh.cuda())
     emb = m(x.cuda())
     assert rel(emb, emb_ref.detach()) < 2e-5
-    loss = HeadLoss.apply(emb, head.weight, labels.cuda(), 0.2, 32.0, 0.0, False)
+    loss = HeadLoss.apply(emb, head.weight, labels.cuda(), 0.2, 32.0, 0.0, False)[0]
     assert abs(loss.item() - loss_ref.item()) < 2e-4 * abs(loss_ref.item())
     loss.backward()
     worst = 0.0
@@ -261,7 +261,7 @@ def test_ecapa_training_step_vs_oracle_autograd(N):
     Wd = Wh.cuda().requires_grad_()
     emb = m(x.cuda())
     assert rel(emb, emb_ref.detach()) < 5e-5
-    loss = HeadLoss.apply(emb, Wd, labels.cuda(), 0.2, 32.0, 0.0, False)
+    loss = HeadLoss.apply(emb, Wd, labels.cuda(), 0.2, 32.0, 0.0, False)[0]
     assert abs(loss.item() - loss_ref.item()) < 2e-4 * abs(loss_ref.item())
     loss.backward()
     worst, wk = 0.0, ''
@@ -388,7 +388,7 @@ def test_resnetse_training_step_vs_oracle_autograd(N):
     Wd = Wh.cuda().requires_grad_()
     emb = m(x.cuda())
     assert rel(emb, emb_ref.detach()) < 1e-4
-    loss = HeadLoss.apply(emb, Wd, labels.cuda(), 0.2, 32.0, 0.0, False)
+    loss = HeadLoss.apply(emb, Wd, labels.cuda(), 0.2, 32.0, 0.0, False)[0]
     assert abs(loss.item() - loss_ref.item()) < 5e-4 * abs(loss_ref.item())
     loss.backward()
     worst, wk = 0.0, ''
@@ -429,7 +429,7 @@ def test_eres2net_training_step_vs_oracle_autograd(N, two_emb):
     Wd = Wh.cuda().requires_grad_()
     emb = m(x.cuda())
     assert rel(emb, emb_ref.detach()) < 1e-4
-    loss = HeadLoss.apply(emb, Wd, labels.cuda(), 0.2, 32.0, 0.0, False)
+    loss = HeadLoss.apply(emb, Wd, labels.cuda(), 0.2, 32.0, 0.0, False)[0]
     assert abs(loss.item() - loss_ref.item()) < 5e-4 * abs(loss_ref.item())
     loss.backward()
     worst, wk = 0.0, ''
@@ -476,7 +476,7 @@ def test_eres2netv2_training_step_vs_oracle_autograd(N):
     Wd = Wh.cuda().requires_grad_()
     emb = m(x.cuda())
     assert rel(emb, emb_ref.detach()) < 1e-4
-    loss = HeadLoss.apply(emb, Wd, labels.cuda(), 0.2, 32.0, 0.0, False)
+    loss = HeadLoss.apply(emb, Wd, labels.cuda(), 0.2, 32.0, 0.0, False)[0]
     assert abs(loss.item() - loss_ref.item()) < 5e-4 * abs(loss_ref.item())
     loss.backward()
     worst, wk = 0.0, ''
@@ -526,7 +526,7 @@ def test_campplus_training_step_vs_oracle_autograd(N, B, gtol):
     emb = m(x.cuda())
     # the closing BatchNorm over a batch of 3 divides by a tiny batch variance: f32-vs-f64 noise is amplified there
     assert rel(emb, emb_ref.detach()) < 2e-3
-    loss = HeadLoss.apply(emb, Wd, labels.cuda(), 0.2, 32.0, 0.0, False)
+    loss = HeadLoss.apply(emb, Wd, labels.cuda(), 0.2, 32.0, 0.0, False)[0]
     assert abs(loss.item() - loss_ref.item()) < 2e-3 * abs(loss_ref.item())
     loss.backward()
     worst, wk = 0.0, ''
@@ -581,7 +581,7 @@ def test_eval_engine_follows_training_updates(N):
         m.train()
         for _ in range(3):
             opt.clear_grad()
-            loss = HeadLoss.apply(m(x), W, y, 0.2, 32.0, 0.0, False)
+            loss = HeadLoss.apply(m(x), W, y, 0.2, 32.0, 0.0, False)[0]
             loss.backward()
             opt.step()
         m.eval()
@@ -686,7 +686,7 @@ def test_ecapa_training_step_mixed_precision(N, amp):
     m = m.cuda().train()
     Wd = Wh.cuda().requires_grad_()
     emb = m(x.cuda())
-    loss = HeadLoss.apply(emb, Wd, labels.cuda(), 0.2, 32.0, 0.0, False)
+    loss = HeadLoss.apply(emb, Wd, labels.cuda(), 0.2, 32.0, 0.0, False)[0]
     loss.backward()
     got = {k: v.grad.double().cpu() for k, v in m.named_parameters()}
 
@@ -1060,7 +1060,7 @@ def test_ecapa_amp_operand_levels_agree_at_bench_scale(N, monkeypatch):
             m = m.cuda().train()
             Wd = Wh.cuda().requires_grad_()
             emb = m(x)
-            loss = HeadLoss.apply(emb, Wd, labels, 0.2, 32.0, 0.0, False)
+            loss = HeadLoss.apply(emb, Wd, labels, 0.2, 32.0, 0.0, False)[0]
             loss.backward()
             return loss.item(), emb.detach().double().cpu(), {k: v.grad.double().cpu() for k, v in m.named_parameters()}
         finally:

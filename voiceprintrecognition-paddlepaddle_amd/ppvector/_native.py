@@ -150,8 +150,11 @@ _PROTOS = {
     'vp_last_error': (C.c_char_p, [c_void_p]),
     'vp_set_margin_table': (c_int, [c_void_p, c_void_p]),
     'vp_cosine_aam_tiled_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
-    'vp_cosine_aam_tiled_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_int,
+    'vp_cosine_aam_tiled_bwd_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'vp_cosine_aam_tiled_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_int, c_float,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'vp_cosine_aam_tiled_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_int,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'vp_fbank_default_opts': (None, [C.POINTER(FbankOpts)]),
     'vp_fbank_num_frames': (c_int, [C.POINTER(FbankOpts), c_int]),
     'vp_fbank_workspace_bytes': (c_size_t, [C.POINTER(FbankOpts), c_int, c_int]),

@@ -23,9 +23,15 @@ class AAMLoss(nn.Module):
 
     def forward(self, inputs, labels):
         from ppvector.models.fc import CosineHeadOutputs
-        if isinstance(inputs, CosineHeadOutputs) and not dict.__contains__(inputs, 'logits') and inputs.W.shape[0] % 4 == 0 \
-                and inputs.W.shape[0] <= 256:
-            return self._tiled(inputs, labels)          # evaluation-mode head + loss in one pass over the class weights
+        if isinstance(inputs, CosineHeadOutputs) and not dict.__contains__(inputs, 'logits'):
+            if inputs.training:
+                if torch.is_grad_enabled():             # training: head + loss + d emb + d W class-tiled when the shape allows it
+                    from ppvector.train.functions import HeadLoss
+                    loss, pred = HeadLoss.apply(inputs.x, inputs.W, labels, self.margin, self.scale, self.label_smoothing, self.easy_margin)
+                    inputs.pred = pred if pred.numel() else None
+                    return loss
+            elif inputs.W.shape[0] % 4 == 0 and inputs.W.shape[0] <= 256:
+                return self._tiled(inputs, labels)      # evaluation-mode head + loss in one pass over the class weights
         features, logits = inputs['features'], inputs['logits']
         if not logits.is_cuda:
             raise N.VpmiError('AAMLoss needs GPU tensors: the engine has no CPU fallback')
@@ -53,11 +59,13 @@ class AAMLoss(nn.Module):
         Cn = W.shape[1]
         lib, ctx = N.lib(), N.ctx(x.device)
         out = torch.empty((1 + 2 * B,), dtype=torch.float32, device=x.device)            # loss | row losses | row log-sum-exps
+        pred = torch.empty((B,), dtype=torch.int32, device=x.device)
         ws = inputs._ws.get(lib.vp_cosine_aam_tiled_workspace_bytes(B, D, Cn), x.device)
         N.check(lib.vp_cosine_aam_tiled_fwd(ctx, x.data_ptr(), W.data_ptr(), labels.data_ptr(), B, D, Cn, float(self.margin), float(self.scale),
                                             float(self.label_smoothing), int(bool(self.easy_margin)), out.data_ptr(), out[1:].data_ptr(),
-                                            out[1 + B:].data_ptr(), None, ws.data_ptr(), ws.numel(), N.stream_ptr()), ctx)
+                                            out[1 + B:].data_ptr(), None, pred.data_ptr(), ws.data_ptr(), ws.numel(), N.stream_ptr()), ctx)
         self.row_loss = out[1:1 + B]
+        inputs.pred = pred
         return out[0]
 
     def update(self, margin=0.2):

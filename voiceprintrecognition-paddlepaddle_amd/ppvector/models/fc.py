@@ -92,11 +92,15 @@ class CosineHeadOutputs(dict):
     weights (csrc/head_tiled.hip: no (B, C) tensor -- 102 MB for 200 000 classes x 128 utterances) while `outputs["logits"]` still
     works for every other consumer."""
 
-    def __init__(self, features, x, W, ws):
+    def __init__(self, features, x, W, ws, training=False):
         super().__init__(features=features)
-        self.x, self.W, self._ws = x, W, ws
+        self.x, self.W, self._ws, self.training = x, W, ws, training
+        self.pred = None                  # (B,) int32 predictions, set by a criterion that ran head + loss class-tiled
 
     def _logits(self):
+        if not dict.__contains__(self, 'logits') and self.training:
+            from ppvector.train.functions import CosineLogits       # training: logits with their backward (csrc/head.hip)
+            dict.__setitem__(self, 'logits', CosineLogits.apply(self.x, self.W))
         if not dict.__contains__(self, 'logits'):
             x, W = self.x, self.W
             B, D = x.shape
@@ -167,8 +171,9 @@ class SpeakerIdentification(nn.Module):
                 logits = _dense(x, w.detach().float().contiguous(), 1, b.detach().float(), w.shape[1])
             return {"features": features, "logits": logits}
         if _training(self, x, self.weight):
-            from ppvector.train.functions import CosineLogits       # training: logits with their backward (csrc/head.hip)
-            return {"features": features, "logits": CosineLogits.apply(x.float(), self.weight)}
+            # training: the logits (CosineLogits, with their backward) are formed only if somebody reads outputs["logits"]; AAMLoss
+            # takes embeddings + weights instead and runs head + loss + both gradients class-tiled (functions.HeadLoss)
+            return CosineHeadOutputs(features, x.float(), self.weight, self._ws, training=True)
         x = x.contiguous().float()
         W = self.weight.detach().contiguous().float()
         return CosineHeadOutputs(features, x, W, self._ws)

@@ -643,7 +643,9 @@ class BNRows(torch.autograd.Function):
 
 
 class HeadLoss(torch.autograd.Function):
-    """loss = AAMLoss(cosine_classifier(emb, W), labels); the kernels produce d emb and d W with the forward value."""
+    """loss = AAMLoss(cosine_classifier(emb, W), labels); the kernels produce d emb and d W with the forward value.  Returns
+    (loss, pred): pred (B int32, non-differentiable) = argmax of the un-margined cosines = what trainer.py:233-236 reads off
+    outputs["logits"], or an empty tensor when the logits-tensor path ran (B > 128 or D != 192)."""
 
     @staticmethod
     def forward(ctx, emb, W, labels, margin, scale, label_smoothing, easy_margin):
@@ -653,16 +655,31 @@ class HeadLoss(torch.autograd.Function):
         Cc = W.shape[1]
         demb, dW = torch.empty_like(emb), torch.empty_like(W)
         loss = torch.empty(1, dtype=torch.float32, device=emb.device)
-        ws = _bytes(lib.vp_cosine_aam_ce_bwd_workspace_bytes(B, D, Cc), emb.device)
         lab = labels.to(torch.int64).contiguous()
-        _chk(lib.vp_cosine_aam_ce_bwd(hctx, emb.data_ptr(), W.data_ptr(), lab.data_ptr(), B, D, Cc, float(margin), float(scale),
-                                      float(label_smoothing), int(easy_margin), 1.0, demb.data_ptr(), dW.data_ptr(),
-                                      loss.data_ptr(), ws.data_ptr(), ws.numel(), N.stream_ptr()), hctx)
+        rc = N.VP_EUNSUP
+        pred = torch.empty((0,), dtype=torch.int32, device=emb.device)
+        if B <= 128 and D == 192 and os.environ.get('VPMI_HEAD_UNTILED') is None:
+            # class-tiled head (csrc/head_tiled.hip): no (B, C) cosine / gradient tensors -- 2 x 102 MB at 200 000 classes x 128 utterances
+            pred = torch.empty((B,), dtype=torch.int32, device=emb.device)
+            ws = _bytes(lib.vp_cosine_aam_tiled_bwd_workspace_bytes(B, D, Cc), emb.device)
+            rc = lib.vp_cosine_aam_tiled_bwd(hctx, emb.data_ptr(), W.data_ptr(), lab.data_ptr(), B, D, Cc, float(margin), float(scale),
+                                             float(label_smoothing), int(easy_margin), 1.0, demb.data_ptr(), dW.data_ptr(), loss.data_ptr(),
+                                             pred.data_ptr(), ws.data_ptr(), ws.numel(), N.stream_ptr())
+            if rc not in (N.VP_OK, N.VP_EUNSUP):
+                _chk(rc, hctx)
+            if rc != N.VP_OK:
+                pred = torch.empty((0,), dtype=torch.int32, device=emb.device)
+        if rc != N.VP_OK:
+            ws = _bytes(lib.vp_cosine_aam_ce_bwd_workspace_bytes(B, D, Cc), emb.device)
+            _chk(lib.vp_cosine_aam_ce_bwd(hctx, emb.data_ptr(), W.data_ptr(), lab.data_ptr(), B, D, Cc, float(margin), float(scale),
+                                          float(label_smoothing), int(easy_margin), 1.0, demb.data_ptr(), dW.data_ptr(),
+                                          loss.data_ptr(), ws.data_ptr(), ws.numel(), N.stream_ptr()), hctx)
         ctx.save_for_backward(demb, dW)
-        return loss[0]
+        ctx.mark_non_differentiable(pred)
+        return loss[0], pred
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _gp):
         demb, dW = ctx.saved_tensors
         return demb * g, dW * g, None, None, None, None, None
 

@@ -19,6 +19,9 @@ from ppvector.train.segments import Recorder
 
 def batch_accuracy(outputs, labels, K=1):
     """trainer.py:233-236: argmax of the logits against the labels; SubCenter heads score a class by its best sub-centre."""
+    pred = getattr(outputs, 'pred', None)
+    if pred is not None and K == 1:                   # the class-tiled head already holds the argmax of the cosines
+        return (pred.to(labels.device) == labels.to(torch.int32)).float().mean()
     logits = outputs['logits'].detach()
     if K > 1:
         logits = logits.reshape(logits.shape[0], -1, K).max(dim=2)[0]
