@@ -664,6 +664,38 @@ int vp_affine_rows_aux_f32(vp_ctx* ctx, const float* z, int ldz, const float* sc
                            const float* add, int ld_add, float* aux, int ld_aux, vp_stream stream);
 int vp_reflect_fold_into_f32(vp_ctx* ctx, const float* dxp, int B, int T, int pad, int C, float* dx, int lddx, const float* add, int ld_add,
                              float* sum, vp_stream stream);
+/* Res2NetBlock in training mode under enable_amp, ONE launch per direction (csrc/res2_train.hip; ecapa_tdnn.py:11-47 forward, the
+ * autograd paddle derives from it backward; trainer.py:209-244): a workgroup per utterance walks the scale - 1 chunk convs
+ * (k = 3, dilation `dil`, reflect 'same' padding, 64 -> 64 channels) with the batch statistics of every chunk's BatchNorm exchanged
+ * through an in-kernel grid barrier -- needs B <= the device's CU count, T <= 368, 2 dil + 2 <= T, width == 64, C == scale * 64;
+ * otherwise VP_EUNSUP and callers run the per-chunk entry points (vp_conv1d_fwd / vp_bn_train_finalize / ...).
+ * Forward:  x (B*T, C) -> out (B*T, C); saves z (scale-1, B*T, 64) f32 = ReLU(conv + bias), inb (scale-1, B*T, 64) bf16 = each conv's input
+ *           as the matrix cores read it, stats (scale-1, 2, 64) = batch mean and 1 / sqrt(var + eps); run_mean / run_var updated in place.
+ * Backward: x = d out, out = d x; reads z, stats, w, gamma; writes dzb (scale-1, B*T, 64) bf16 = d(conv output) -- the operand of the
+ *           weight gradients, which the caller takes with vp_conv1d_wgrad_bf16_oik(x = inb[j], dz = dzb[j]) -- and
+ *           dvec (scale-1, 3, 64) = d bias, d gamma, d beta of every chunk. */
+typedef struct {
+    int B, T, C, scale, width, dil;
+    float momentum, eps;
+    const float* x;
+    float* out;
+    const float* w[7];            /* (64, 64, 3) f32 each: the model's Conv1D weights */
+    const float* bias[7];
+    const float* gamma[7];
+    const float* beta[7];
+    float* run_mean[7];           /* may be NULL */
+    float* run_var[7];
+    float* z;
+    void* inb;
+    void* dzb;
+    float* stats;
+    float* dvec;
+} vp_res2_train_desc;
+size_t vp_res2_train_workspace_bytes(int B, int scale);
+int vp_res2_train_fwd(vp_ctx* ctx, const vp_res2_train_desc* d, void* ws, size_t ws_bytes, vp_stream stream);
+int vp_res2_train_bwd(vp_ctx* ctx, const vp_res2_train_desc* d, void* ws, size_t ws_bytes, vp_stream stream);
+/* 0 unless a grid barrier of this context ever gave up waiting (it never does on a healthy launch; tests assert it). */
+int vp_grid_barrier_status(vp_ctx* ctx);
 /* The SE block's backward as two passes (SEBlock + residual, ecapa_tdnn.py:50-82, 139-141):
  * vp_utt_dot_f32: ds[b][c] = sum_t dy[b,t,c] * x[b,t,c];  vp_scale_shift_rows_f32: dx[b,t,c] = dy[b,t,c] * s[b][c] + dm[b][c] / T
  * (dm = the gradient that reached the squeeze mean through the two dense layers).  C % 4 == 0, contiguous (B*T, C) tensors. */

@@ -1076,6 +1076,64 @@ def test_ecapa_amp_operand_levels_agree_at_bench_scale(N, monkeypatch):
     print(f'[ecapa amp levels] loss f32 {lx:.5f}, levels 0 / 1 / 2: {l0:.5f} / {l1:.5f} / {l2:.5f};  emb rel-L2 vs f32: {rel(e0, ex):.2e} / '
           f'{rel(e1, ex):.2e} / {rel(e2, ex):.2e};  whole-gradient rel-L2 vs f32: {whole(g0, gx):.2e} / {whole(g1, gx):.2e} / '
           f'{whole(g2, gx):.2e};  level 2 vs level 0: emb {rel(e2, e0):.2e}, gradient {whole(g2, g0):.2e}')
-    assert abs(l1 - lx) < 2e-3 * abs(lx) and rel(e1, ex) < 1.1 * rel(e0, ex) + 1e-3 and whole(g1, gx) < 1.1 * whole(g0, gx)
+    # (levels 0 and 1 differ by summation order only; through 21 chained Res2 chunks and train-mode BatchNorm that is the same ~15 % as
+    # either has to f32 -- the yardstick is 'no further from f32', with 25 % slack for the run-to-run spread of that figure)
+    assert abs(l1 - lx) < 2e-3 * abs(lx) and rel(e1, ex) < 1.25 * rel(e0, ex) + 1e-3 and whole(g1, gx) < 1.25 * whole(g0, gx)
     assert abs(l2 - lx) < 2e-3 * abs(lx) and rel(e2, ex) < 1.25 * rel(e0, ex) + 1e-3
     assert whole(g2, gx) < 1.25 * whole(g0, gx)
+
+
+@pytest.mark.parametrize('S,B,T,dil', [(2, 6, 100, 2), (2, 7, 298, 3), (2, 64, 298, 4), (3, 5, 67, 4), (3, 9, 298, 2), (8, 6, 100, 2), (8, 256, 298, 4)])
+def test_res2_chain_one_launch_per_direction_equals_the_per_chunk_path(N, amp, monkeypatch, S, B, T, dil):
+    """enable_amp: Res2NetBlock forward / backward as ONE launch each (csrc/res2_train.hip: a workgroup per utterance, batch statistics
+    through an in-kernel grid barrier) against the per-chunk launch sequence (VPMI_RES2_TRAIN_UNFUSED=1).  Same roundings (conv
+    operands to bf16, f32 accumulation and statistics); what differs is summation order (1e-7).  A chain AMPLIFIES that: a chunk input
+    within 1e-7 of a bf16 rounding boundary rounds the other way (2^-9 on that element), the next chunk sees 1e-5, ... up to the bf16
+    noise floor after a few chunks, and in backward every ReLU mask that flips moves dz by a whole gradient value (error = sqrt of the
+    flipped share).  So: scale 2 (one conv, no amplification) pins the kernels -- outputs 2e-6, gradients 2e-4; scale 3 adds the
+    hand-off -- 1e-4 / 5e-3; scale 8 (ECAPA) is bounded at the noise floor the per-chunk path has against ITSELF under a reordered
+    sum -- 3e-3 / 5e-2 (measured values printed).  (8, 256, 298, 4) is the bench batch: 256 co-resident workgroups meet 7 + 8 times."""
+    from ppvector.train.functions import Res2Fn
+    w = 64
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    x0 = torch.randn(B * T, S * w, generator=g).cuda()
+    dout = torch.randn(B * T, S * w, generator=g).cuda()
+    base = []
+    for i in range(S - 1):
+        base += [(torch.randn(w, w, 3, generator=g) / (3 * w) ** 0.5).cuda(), (torch.randn(w, generator=g) * 0.3).cuda(),
+                 (torch.randn(w, generator=g) * 0.2 + 1.0).cuda(), (torch.randn(w, generator=g) * 0.2).cuda(),
+                 torch.zeros(w).cuda(), torch.ones(w).cuda()]
+    cfg = dict(B=B, T=T, scale=S, dilation=dil, momentum=0.9, eps=1e-5)
+
+    def run(unfused):
+        if unfused:
+            monkeypatch.setenv('VPMI_RES2_TRAIN_UNFUSED', '1')
+        else:
+            monkeypatch.delenv('VPMI_RES2_TRAIN_UNFUSED', raising=False)
+        params = [p.clone() for p in base]
+        for i in range(S - 1):
+            for k in range(4):
+                params[6 * i + k].requires_grad_()
+        x = x0.clone().requires_grad_()
+        out = Res2Fn.apply(x, cfg, *params)
+        out.backward(dout)
+        torch.cuda.synchronize()
+        res = {'out': out.detach(), 'dx': x.grad}
+        for i in range(S - 1):
+            res[f'run_mean{i}'], res[f'run_var{i}'] = params[6 * i + 4], params[6 * i + 5]
+            for k, nm in enumerate(('dW', 'dbias', 'dgamma', 'dbeta')):
+                res[f'{nm}{i}'] = params[6 * i + k].grad
+        return res
+
+    ref, got = run(True), run(False)
+    assert N.lib().vp_grid_barrier_status(N.ctx(x0.device)) == 0, 'a grid barrier gave up waiting'
+    worst = {}
+    for k in ref:
+        e = rel(got[k], ref[k])
+        kind = k.rstrip('0123456789')
+        worst[kind] = max(worst.get(kind, 0.0), e)
+    print(f'[res2 train chain scale={S} B={B} T={T} dil={dil}] out / dx per 64-channel slice: ' + ' '.join(f"{rel(got['out'][:, i * w:(i + 1) * w], ref['out'][:, i * w:(i + 1) * w]):.1e}/{rel(got['dx'][:, i * w:(i + 1) * w], ref['dx'][:, i * w:(i + 1) * w]):.1e}" for i in range(S)))
+    print(f'[res2 train chain scale={S} B={B} T={T} dil={dil}] worst rel-L2 vs the per-chunk path: ' + ', '.join(f'{k} {v:.1e}' for k, v in worst.items()))
+    fwd_tol, bwd_tol = {2: (2e-6, 2e-4), 3: (1e-4, 5e-3)}.get(S, (3e-3, 5e-2))
+    for kind, e in worst.items():
+        assert e < (fwd_tol if kind in ('out', 'run_mean', 'run_var') else bwd_tol), (kind, e)

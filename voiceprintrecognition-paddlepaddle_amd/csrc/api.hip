@@ -14,6 +14,8 @@ vp_ctx* vp_create(int device) {
     vp_ctx* c = (vp_ctx*)calloc(1, sizeof(vp_ctx));
     if (!c) return nullptr;
     c->device = device;
+    // grid-barrier counters (res2_train.hip): allocated here so that no launcher allocates during a stream capture
+    if (hipMalloc(&c->grid_bar, 2048) != hipSuccess || hipMemset(c->grid_bar, 0, 2048) != hipSuccess) c->grid_bar = nullptr;
     return c;
 }
 
@@ -21,6 +23,7 @@ void vp_destroy(vp_ctx* ctx) {
     if (!ctx) return;
     vp_fbank_release_tables(ctx);
     vp_mel_release_tables(ctx);
+    if (ctx->grid_bar) (void)hipFree(ctx->grid_bar);
     free(ctx);
 }
 

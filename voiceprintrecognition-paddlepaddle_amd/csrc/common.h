@@ -31,6 +31,8 @@ struct vp_ctx {
     float* ms_mel_w;
     // device margin table of the margin-softmax losses (vp_set_margin_table): [margin, cos m, sin m, cos(pi - m), 1 + cos(pi - m)]
     const float* margin_table;
+    // counters of the in-kernel grid barrier (res2_train.hip): [0] arrivals, [1] departures, [2] bail-out flag; zero between launches
+    unsigned* grid_bar;
 };
 
 #define VP_FAIL(ctx, code, ...)                                      \

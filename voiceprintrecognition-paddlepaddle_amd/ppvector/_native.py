@@ -54,6 +54,14 @@ class Conv1dDesc(C.Structure):
                 ('gate', c_void_p), ('gate_len', c_int), ('gate_nseg', c_int), ('mfma_bf16', c_int)]
 
 
+class Res2TrainDesc(C.Structure):
+    _fields_ = [('B', c_int), ('T', c_int), ('C', c_int), ('scale', c_int), ('width', c_int), ('dil', c_int),
+                ('momentum', c_float), ('eps', c_float), ('x', c_void_p), ('out', c_void_p),
+                ('w', c_void_p * 7), ('bias', c_void_p * 7), ('gamma', c_void_p * 7), ('beta', c_void_p * 7),
+                ('run_mean', c_void_p * 7), ('run_var', c_void_p * 7),
+                ('z', c_void_p), ('inb', c_void_p), ('dzb', c_void_p), ('stats', c_void_p), ('dvec', c_void_p)]
+
+
 class TdnnLayer(C.Structure):
     _fields_ = [('w', c_void_p), ('bias', c_void_p), ('bn_scale', c_void_p), ('bn_shift', c_void_p),
                 ('cin', c_int), ('cout', c_int), ('kw', c_int), ('dil', c_int)]
@@ -149,6 +157,10 @@ _PROTOS = {
     'vp_destroy': (None, [c_void_p]),
     'vp_last_error': (C.c_char_p, [c_void_p]),
     'vp_set_margin_table': (c_int, [c_void_p, c_void_p]),
+    'vp_res2_train_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'vp_res2_train_fwd': (c_int, [c_void_p, C.POINTER(Res2TrainDesc), c_void_p, c_size_t, c_void_p]),
+    'vp_res2_train_bwd': (c_int, [c_void_p, C.POINTER(Res2TrainDesc), c_void_p, c_size_t, c_void_p]),
+    'vp_grid_barrier_status': (c_int, [c_void_p]),
     'vp_cosine_aam_tiled_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'vp_cosine_aam_tiled_bwd_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'vp_cosine_aam_tiled_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_int, c_float,

@@ -381,11 +381,55 @@ class Res2Fn(torch.autograd.Function):
     params: for chunks 1..scale-1: conv weight, conv bias, BN weight, BN bias, BN running mean, BN running variance."""
 
     @staticmethod
+    def _fused_desc(x, out, cfg, params, S):
+        d = N.Res2TrainDesc()
+        d.B, d.T, d.C, d.scale, d.width, d.dil = cfg['B'], cfg['T'], x.shape[1], S, x.shape[1] // S, cfg['dilation']
+        d.momentum, d.eps = cfg['momentum'], cfg['eps']
+        d.x, d.out = x.data_ptr(), out.data_ptr()
+        for i in range(S - 1):
+            wt, bs, g, b, rm, rv = params[6 * i:6 * i + 6]
+            d.w[i], d.bias[i], d.gamma[i], d.beta[i] = wt.data_ptr(), bs.data_ptr(), g.data_ptr(), b.data_ptr()
+            d.run_mean[i] = rm.data_ptr() if rm is not None else None
+            d.run_var[i] = rv.data_ptr() if rv is not None else None
+        return d
+
+    @staticmethod
+    def _fused_ok(x, cfg, params, S):
+        """The one-launch-per-direction chain (csrc/res2_train.hip): enable_amp steps, 64-channel chunks, contiguous f32 parameters
+        in the model's layout.  VPMI_RES2_TRAIN_UNFUSED=1 keeps the per-chunk launches (A/B, parity tests)."""
+        if not ppvector.get_train_amp() or os.environ.get('VPMI_RES2_TRAIN_UNFUSED') or x.shape[1] != 64 * S or not 2 <= S <= 8:
+            return False
+        for i in range(S - 1):
+            wt, bs, g, b = params[6 * i:6 * i + 4]
+            if wt is None or bs is None or g is None or b is None or tuple(wt.shape) != (64, 64, 3):
+                return False
+            if any(t.dtype != torch.float32 or not t.is_contiguous() for t in (wt, bs, g, b)):
+                return False
+        return True
+
+    @staticmethod
     def forward(ctx, x, cfg, *params):
         x = _f32c(x)
         B, T, S = cfg['B'], cfg['T'], cfg['scale']
         w = x.shape[1] // S
         out = torch.empty_like(x)
+        ctx.fused = False
+        if Res2Fn._fused_ok(x, cfg, params, S):
+            lib, hctx = N.lib(), N.ctx(x.device)
+            M = x.shape[0]
+            z = torch.empty((S - 1, M, 64), dtype=torch.float32, device=x.device)
+            inb = torch.empty((S - 1, M, 64), dtype=torch.bfloat16, device=x.device)
+            stats = torch.empty((S - 1, 2, 64), dtype=torch.float32, device=x.device)
+            d = Res2Fn._fused_desc(x, out, cfg, params, S)
+            d.z, d.inb, d.stats = z.data_ptr(), inb.data_ptr(), stats.data_ptr()
+            ws = _bytes(lib.vp_res2_train_workspace_bytes(B, S), x.device)
+            rc = lib.vp_res2_train_fwd(hctx, C.byref(d), ws.data_ptr(), ws.numel(), N.stream_ptr())
+            if rc == 0:
+                ctx.save_for_backward(z, inb, stats, *[params[6 * i + k] for i in range(S - 1) for k in (0, 2)])
+                ctx.fused, ctx.split, ctx.cfg = True, (S, w), dict(cfg)
+                return out
+            if rc != N.VP_EUNSUP:
+                _chk(rc, hctx)
         out[:, :w].copy_(x[:, :w])
         inp = x[:, w:2 * w].contiguous()
         saved, meta = [], []
@@ -406,6 +450,38 @@ class Res2Fn(torch.autograd.Function):
     def backward(ctx, dout):
         dout = _f32c(dout)
         S, w = ctx.split
+        if ctx.fused:
+            lib, hctx = N.lib(), N.ctx(dout.device)
+            cfg = ctx.cfg
+            B, T = cfg['B'], cfg['T']
+            z, inb, stats = ctx.saved_tensors[:3]
+            wg = ctx.saved_tensors[3:]                                   # conv weight, BN weight per chunk
+            M = dout.shape[0]
+            dx = torch.empty_like(dout)
+            dzb = torch.empty((S - 1, M, 64), dtype=torch.bfloat16, device=dout.device)
+            dvec = torch.empty((S - 1, 3, 64), dtype=torch.float32, device=dout.device)
+            d = N.Res2TrainDesc()
+            d.B, d.T, d.C, d.scale, d.width, d.dil = B, T, dout.shape[1], S, w, cfg['dilation']
+            d.momentum, d.eps = cfg['momentum'], cfg['eps']
+            d.x, d.out = dout.data_ptr(), dx.data_ptr()
+            for i in range(S - 1):
+                d.w[i], d.gamma[i] = wg[2 * i].data_ptr(), wg[2 * i + 1].data_ptr()
+            d.z, d.stats, d.dzb, d.dvec = z.data_ptr(), stats.data_ptr(), dzb.data_ptr(), dvec.data_ptr()
+            ws = _bytes(lib.vp_res2_train_workspace_bytes(B, S), dout.device)
+            _chk(lib.vp_res2_train_bwd(hctx, C.byref(d), ws.data_ptr(), ws.numel(), N.stream_ptr()), hctx)
+            grads = [None] * (6 * (S - 1))
+            dw_all = torch.empty((S - 1, 64, 64, 3), dtype=torch.float32, device=dout.device)
+            wd = N.Conv1dDesc()
+            wd.dtype_in = wd.dtype_out = N.VP_BF16
+            wd.B, wd.T_in, wd.T_out, wd.Cin, wd.Cout, wd.KW, wd.dilation, wd.stride = B, T, T, 64, 64, 3, cfg['dilation'], 1
+            wd.pad_mode, wd.pad_left, wd.ldx, wd.xoff, wd.ldy, wd.mfma_bf16 = N.VP_PAD_REFLECT, cfg['dilation'], 64, 0, 64, 1
+            wws = _bytes(lib.vp_conv1d_wgrad_workspace_bytes(C.byref(wd)), dout.device)
+            for i in range(S - 1):                                       # weight gradients: dz_i^T x in_i, both bf16 in memory
+                wd.x, wd.w = inb[i].data_ptr(), wg[2 * i].data_ptr()
+                _chk(lib.vp_conv1d_wgrad_bf16_oik(hctx, C.byref(wd), dzb[i].data_ptr(), 64, dw_all[i].data_ptr(), wws.data_ptr(),
+                                                  wws.numel(), N.stream_ptr()), hctx)
+                grads[6 * i:6 * i + 4] = [dw_all[i], dvec[i, 0], dvec[i, 1], dvec[i, 2]]
+            return (dx, None, *grads)
         saved, at, tapes = ctx.saved_tensors, 0, []
         for n, geom in ctx.meta:
             tp = _Tape((True,) * 9)
