@@ -314,7 +314,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 3) void fbank_frames16_kernel(Fbank1
     const int f = lane >> 4, j = lane & 15;
 
     for (int i = tid; i < FB_NFFT; i += FB_WAVES * 64) s_win[i] = i < a.win ? a.window[i] : 0.f;
-    { const int n2 = tid >> 4, k1 = tid & 15; s_tw1[tid] = a.tw[(2 * n2 * k1) & (FB_NFFT - 1)]; }
+    { const int k1 = tid >> 4, n2 = tid & 15; s_tw1[tid] = a.tw[(2 * n2 * k1) & (FB_NFFT - 1)]; }   // [k1][n2]: a wave's 16 lanes (n2) read 128 contiguous bytes
     for (int i = tid; i < a.wpad_len; i += FB_WAVES * 64) s_wpad[i] = a.wpad[i];
     for (int i = tid; i < FB_MAX_MEL; i += FB_WAVES * 64) s_mbin0[i] = i < a.n_mels ? a.mel_bin0[i] : 0;
     v2f twu[8];
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 3) void fbank_frames16_kernel(Fbank1
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) {
         v2f o = DFT16_OUT(v, k1);
-        if (k1 > 0) { const float2 w = s_tw1[j * 16 + k1]; o = c_mul(o, v2f{w.x, w.y}); }
+        if (k1 > 0) { const float2 w = s_tw1[k1 * 16 + j]; o = c_mul(o, v2f{w.x, w.y}); }      // (was [n2][k1]: 16 lanes 128 B apart = one bank pair, PMC: 64 % of the LDS cycles were conflicts)
         *reinterpret_cast<v2f*>(xb + (k1 * 17 + j) * 8) = o;
     }
     __builtin_amdgcn_wave_barrier();
@@ -407,8 +407,10 @@ __global__ __launch_bounds__(FB_WAVES * 64, 3) void fbank_frames16_kernel(Fbank1
     __builtin_amdgcn_wave_barrier();
     // ---- real-FFT unpack of the pairs (k, 256 - k): 2 X[k] = e + w o, 2 X[256 - k] = conj(e - w o),
     //      e = Z[k] + conj(Z[256 - k]), o = (Z[k] - conj(Z[256 - k])) / i, w = W512^k.  The mel weights carry the 0.25.
-#pragma unroll
-    for (int r = 0; r < F16_MAX_TAPS / 16; ++r) *reinterpret_cast<float*>(xb + (256 + j + 16 * r) * 8) = 0.f;   // taps past bin 255 (zero weight) must read finite
+    //      All pairs are read first; the powers then go back as a COMPACT float array P[k] at xb + 4 k (over the dead Z): the mel
+    //      taps below read consecutive dwords instead of every other one.
+    float pw[16];
+    float p128 = 0.f;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int k = j + 16 * r;
@@ -418,13 +420,23 @@ __global__ __launch_bounds__(FB_WAVES * 64, 3) void fbank_frames16_kernel(Fbank1
         const v2f o = v2f{zk.y + zn.y, zn.x - zk.x};
         const v2f wo = c_mul(o, twu[r]);
         const v2f p = e + wo, q = e - wo;
-        *reinterpret_cast<float*>(xb + k * 8) = p.x * p.x + p.y * p.y;
-        if (k > 0) *reinterpret_cast<float*>(xb + (256 - k) * 8) = q.x * q.x + q.y * q.y;
+        pw[2 * r] = p.x * p.x + p.y * p.y;
+        pw[2 * r + 1] = q.x * q.x + q.y * q.y;
     }
     if (j == 0) {                                       // bin 128 pairs with itself: |X[128]|^2 = |Z[128]|^2 (scaled like the rest)
         const v2f z = *reinterpret_cast<const v2f*>(xb + 128 * 8);
-        *reinterpret_cast<float*>(xb + 128 * 8) = 4.f * (z.x * z.x + z.y * z.y);
+        p128 = 4.f * (z.x * z.x + z.y * z.y);
     }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int k = j + 16 * r;
+        *reinterpret_cast<float*>(xb + k * 4) = pw[2 * r];
+        if (k > 0) *reinterpret_cast<float*>(xb + (256 - k) * 4) = pw[2 * r + 1];
+    }
+    if (j == 0) *reinterpret_cast<float*>(xb + 128 * 4) = p128;
+#pragma unroll
+    for (int r = 0; r < F16_MAX_TAPS / 16; ++r) *reinterpret_cast<float*>(xb + (256 + j + 16 * r) * 4) = 0.f;   // taps past bin 255 (zero weight) must read finite
     __builtin_amdgcn_wave_barrier();
     // ---- mel rounds: lane j = filter 16 r + j
     float* orow = a.out + ((size_t)b * a.T + tl) * a.n_mels;
@@ -436,13 +448,13 @@ __global__ __launch_bounds__(FB_WAVES * 64, 3) void fbank_frames16_kernel(Fbank1
         if (r < a.n_rounds) {                           // uniform
             const int m = 16 * r + j;
             const float* wp = s_wpad + a.round_off[r] + j;
-            const char* pp = xb + s_mbin0[min(m, FB_MAX_MEL - 1)] * 8;
+            const char* pp = xb + s_mbin0[min(m, FB_MAX_MEL - 1)] * 4;
             const int nq = a.round_max[r];              // multiple of 4 (host-padded)
             float e0 = 0.f, e1 = 0.f;
             for (int q = 0; q < nq; q += 4) {
                 const float w0 = wp[(q + 0) * 16], w1 = wp[(q + 1) * 16], w2 = wp[(q + 2) * 16], w3 = wp[(q + 3) * 16];
-                const float p0 = *reinterpret_cast<const float*>(pp + q * 8), p1 = *reinterpret_cast<const float*>(pp + q * 8 + 8);
-                const float p2 = *reinterpret_cast<const float*>(pp + q * 8 + 16), p3 = *reinterpret_cast<const float*>(pp + q * 8 + 24);
+                const float p0 = *reinterpret_cast<const float*>(pp + q * 4), p1 = *reinterpret_cast<const float*>(pp + q * 4 + 4);
+                const float p2 = *reinterpret_cast<const float*>(pp + q * 4 + 8), p3 = *reinterpret_cast<const float*>(pp + q * 4 + 12);
                 e0 += w0 * p0; e1 += w1 * p1; e0 += w2 * p2; e1 += w3 * p3;
             }
             const float val = __logf(fmaxf(e0 + e1, a.log_floor));
