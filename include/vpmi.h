@@ -691,6 +691,10 @@ typedef struct {
     float* stats;
     float* dvec;
 } vp_res2_train_desc;
+/* nbatch convs of identical geometry in one launch (the chunk convs of a Res2Net block after vp_res2_train_bwd): conv c reads
+ * x + c * x_bstride and dz + c * dz_bstride (bf16 elements), writes dW + c * Cout * Cin * KW; ws = nbatch x vp_conv1d_wgrad_workspace_bytes(d). */
+int vp_conv1d_wgrad_bf16_oik_batched(vp_ctx* ctx, const vp_conv1d_desc* d, const void* dz, int lddz, float* dW, int nbatch, long long x_bstride,
+                                     long long dz_bstride, void* ws, size_t ws_bytes, vp_stream stream);
 size_t vp_res2_train_workspace_bytes(int B, int scale);
 int vp_res2_train_fwd(vp_ctx* ctx, const vp_res2_train_desc* d, void* ws, size_t ws_bytes, vp_stream stream);
 int vp_res2_train_bwd(vp_ctx* ctx, const vp_res2_train_desc* d, void* ws, size_t ws_bytes, vp_stream stream);

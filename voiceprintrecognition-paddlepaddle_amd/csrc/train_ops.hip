@@ -19,6 +19,8 @@ struct WgradArgs {
     const float* x; const float* dz; float* part;
     int ldx, xoff, lddz, M, N, K, Cin, T_in, T_out, dilation, stride, pad_left, pad_mode, rows_per_split;
     int F_in, F_out, KF, stride_f, pad_f;        // 2-D convs (zero padding): rows are (b, t, f), taps (kt, kf); F_in = F_out = KF = 1 for 1-D
+    // batched launch (amp kernel): blockIdx.z = conv * splits + split; conv c reads x + c * xb, dz + c * dzb (elements of their dtype)
+    int splits; long long xb, dzb;
 };
 
 // LDS-tiled: per 32-row chunk the workgroup stages dz[32][64 n] and the tap-shifted x[32][64 k-columns] with 16-byte loads
@@ -143,7 +145,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_amp_kernel(WgradArgs a) {
     const int i = lane & 15, g = lane >> 4;
     const int wn = wv & 1, wk = wv >> 1;
     const int nb = blockIdx.y * WA_T, kb = blockIdx.x * WA_T;
-    const int m_begin = blockIdx.z * a.rows_per_split;
+    const int zb = blockIdx.z / a.splits, sp = blockIdx.z - zb * a.splits;
+    const int m_begin = sp * a.rows_per_split;
     const int m_end = min(a.M, m_begin + a.rows_per_split);
     // staging role: rows 8 rg .. 8 rg + 7 of the chunk, columns 4 cg .. 4 cg + 3 of the tile
     const int cg = tid & 31, rg = tid >> 5;
@@ -160,8 +163,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_amp_kernel(WgradArgs a) {
 
     using ld_t = typename std::conditional<BF, uint2, float4>::type;
     using el_t = typename std::conditional<BF, bf16_t, float>::type;
-    const el_t* __restrict__ gdz = reinterpret_cast<const el_t*>(a.dz);
-    const el_t* __restrict__ gx = reinterpret_cast<const el_t*>(a.x);
+    const el_t* __restrict__ gdz = reinterpret_cast<const el_t*>(a.dz) + zb * a.dzb;
+    const el_t* __restrict__ gx = reinterpret_cast<const el_t*>(a.x) + zb * a.xb;
     ld_t rdz[8], rx[8];
     auto gload = [&](int mbase) {
 #pragma unroll
@@ -282,6 +285,8 @@ __device__ __forceinline__ long long oik_index(long long idx, int Cin, int KW) {
 
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* part, int S, long long n, float* out, int Cin, int KW) {
     __shared__ float sm[16][17];
+    part += (size_t)blockIdx.y * S * n;               // batched weight gradients: one (S, n) slab and one output per blockIdx.y
+    out += (size_t)blockIdx.y * n;
     const int ol = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const long long idx = (long long)blockIdx.x * 16 + ol;
     float s = 0.f;
@@ -309,6 +314,8 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* part, in
 __global__ __launch_bounds__(256) void sum_partials_wide_kernel(const float* part, int S, long long n, float* out, int Cin, int KW) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    part += (size_t)blockIdx.y * S * n;
+    out += (size_t)blockIdx.y * n;
     float s = 0.f;
     for (int k = 0; k < S; ++k) s += part[(size_t)k * n + i];
     out[oik_index(i, Cin, KW)] = s;
@@ -990,9 +997,9 @@ unsigned grid1d(long long total) {
 }  // namespace
 
 // many outputs: one thread per output (coalesced over the outputs); few outputs, many partials: 16 x 16 per workgroup
-static void launch_sum_partials(const float* part, int S, long long n, float* out, hipStream_t st, int Cin = 1, int KW = 1) {
-    if (n >= 32768) hipLaunchKernelGGL(sum_partials_wide_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, S, n, out, Cin, KW);
-    else hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, part, S, n, out, Cin, KW);
+static void launch_sum_partials(const float* part, int S, long long n, float* out, hipStream_t st, int Cin = 1, int KW = 1, int batch = 1) {
+    if (n >= 32768) hipLaunchKernelGGL(sum_partials_wide_kernel, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, st, part, S, n, out, Cin, KW);
+    else hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n + 15) / 16), batch), dim3(256), 0, st, part, S, n, out, Cin, KW);
 }
 
 extern "C" {
@@ -1011,7 +1018,7 @@ size_t vp_conv1d_wgrad_workspace_bytes(const vp_conv1d_desc* d) {
 
 // d: the FORWARD conv's descriptor (x / ldx / xoff and the geometry; w, y, epilogue fields ignored).  dz (B*T_out, lddz) f32.
 static int wgrad_impl(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int lddz, float* dW, void* ws, size_t ws_bytes,
-                      vp_stream stream, bool oik) {
+                      vp_stream stream, bool oik, int nbatch = 1, long long x_bstride = 0, long long dz_bstride = 0) {
     if (!ctx || !d || !d->x || !dz || !dW) VP_FAIL(ctx, VP_EINVAL, "wgrad: null argument");
     const bool bf_in = d->dtype_in == VP_BF16;          // x AND dz bf16 in memory (vp_conv1d_wgrad_bf16_oik): bf16 matrix cores only
     if (d->dtype_in != VP_F32 && !bf_in) VP_FAIL(ctx, VP_EUNSUP, "wgrad: f32 or bf16 tensors");
@@ -1020,8 +1027,9 @@ static int wgrad_impl(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int
         VP_FAIL(ctx, VP_EINVAL, "wgrad: bad 2-D geometry (zero padding only)");
     if (d->B <= 0 || d->T_in <= 0 || d->T_out <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KW <= 0 || d->stride <= 0 || d->dilation <= 0)
         VP_FAIL(ctx, VP_EINVAL, "wgrad: bad shape");
-    const size_t need = vp_conv1d_wgrad_workspace_bytes(d);
+    const size_t need = vp_conv1d_wgrad_workspace_bytes(d) * (size_t)nbatch;
     if (!ws || ws_bytes < need) VP_FAIL(ctx, VP_EWORKSPACE, "wgrad: workspace %zu < %zu", ws_bytes, need);
+    if (nbatch < 1 || (nbatch > 1 && !(d->dtype_in == VP_BF16))) VP_FAIL(ctx, VP_EINVAL, "wgrad: batched launches take bf16 operands");
     const long long M = (long long)d->B * d->T_out * (two_d ? d->F_out : 1);
     if (M > 0x7fffffffLL / 2) VP_FAIL(ctx, VP_EINVAL, "wgrad: too many rows");
     const int K = d->KW * d->Cin;
@@ -1029,6 +1037,7 @@ static int wgrad_impl(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int
     int S = 2048 / (tn * tk);
     if (S < 1) S = 1;
     if (S > 256) S = 256;
+    if (nbatch > 1 && S > 512 / nbatch) S = 512 / nbatch > 1 ? 512 / nbatch : 1;      // the batch fills the chip: fewer, longer row splits (less to reduce)
     if ((long long)S * 64 > M) S = (int)((M + 63) / 64);
     if ((d->Cin | d->Cout | d->ldx | d->xoff | lddz) & 3) VP_FAIL(ctx, VP_EINVAL, "wgrad: Cin / Cout / ldx / xoff / lddz must be multiples of 4");
     int rps = (int)((M + S - 1) / S);
@@ -1042,6 +1051,7 @@ static int wgrad_impl(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int
     a.pad_mode = d->pad_mode; a.rows_per_split = rps;
     a.F_in = two_d ? d->F_in : 1; a.F_out = two_d ? d->F_out : 1; a.KF = two_d ? d->KF : 1;
     a.stride_f = two_d ? d->stride_f : 1; a.pad_f = two_d ? d->pad_f : 0;
+    a.splits = S; a.xb = x_bstride; a.dzb = dz_bstride;
     hipStream_t st = (hipStream_t)stream;
     if (d->mfma_bf16 || bf_in) {
         constexpr int smem = 2 * 2 * WA_T * 128;
@@ -1051,7 +1061,7 @@ static int wgrad_impl(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int
             VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_amp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
             attr_set = true;
         }
-        const dim3 grid((K + WA_T - 1) / WA_T, (d->Cout + WA_T - 1) / WA_T, S);
+        const dim3 grid((K + WA_T - 1) / WA_T, (d->Cout + WA_T - 1) / WA_T, S * nbatch);
         if (bf_in) hipLaunchKernelGGL(conv_wgrad_amp_kernel<true>, grid, dim3(256), smem, st, a);
         else hipLaunchKernelGGL(conv_wgrad_amp_kernel<false>, grid, dim3(256), smem, st, a);
     } else {
@@ -1059,7 +1069,7 @@ static int wgrad_impl(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int
     }
     VP_LAUNCH_CHECK(ctx, "conv_wgrad");
     const long long n = (long long)d->Cout * K;
-    launch_sum_partials((const float*)ws, S, n, dW, st, d->Cin, oik ? d->KW : 1);
+    launch_sum_partials((const float*)ws, S, n, dW, st, d->Cin, oik ? d->KW : 1, nbatch);
     VP_LAUNCH_CHECK(ctx, "wgrad_reduce");
     return VP_OK;
 }
@@ -1080,6 +1090,14 @@ int vp_conv1d_wgrad_bf16_oik(vp_ctx* ctx, const vp_conv1d_desc* d, const void* d
                              vp_stream stream) {
     if (!d || d->dtype_in != VP_BF16) VP_FAIL(ctx, VP_EINVAL, "wgrad_bf16: the descriptor's dtype_in must be bf16");
     return wgrad_impl(ctx, d, (const float*)dz, lddz, dW, ws, ws_bytes, stream, true);
+}
+
+// nbatch convs of identical geometry in ONE launch: conv c reads x + c * x_bstride and dz + c * dz_bstride (bf16 elements) and writes
+// dW + c * Cout * Cin * KW; ws = nbatch x vp_conv1d_wgrad_workspace_bytes(d).  (The seven chunk convs of a Res2Net block.)
+int vp_conv1d_wgrad_bf16_oik_batched(vp_ctx* ctx, const vp_conv1d_desc* d, const void* dz, int lddz, float* dW, int nbatch, long long x_bstride,
+                                     long long dz_bstride, void* ws, size_t ws_bytes, vp_stream stream) {
+    if (!d || d->dtype_in != VP_BF16) VP_FAIL(ctx, VP_EINVAL, "wgrad_bf16: the descriptor's dtype_in must be bf16");
+    return wgrad_impl(ctx, d, (const float*)dz, lddz, dW, ws, ws_bytes, stream, true, nbatch, x_bstride, dz_bstride);
 }
 
 int vp_conv_weight_layouts_f32(vp_ctx* ctx, const float* w, int Cout, int Cin, int KW, float* wp, float* w2, vp_stream stream) {

@@ -157,6 +157,8 @@ _PROTOS = {
     'vp_destroy': (None, [c_void_p]),
     'vp_last_error': (C.c_char_p, [c_void_p]),
     'vp_set_margin_table': (c_int, [c_void_p, c_void_p]),
+    'vp_conv1d_wgrad_bf16_oik_batched': (c_int, [c_void_p, C.POINTER(Conv1dDesc), c_void_p, c_int, c_void_p, c_int, C.c_longlong, C.c_longlong, c_void_p,
+                                         c_size_t, c_void_p]),
     'vp_res2_train_workspace_bytes': (c_size_t, [c_int, c_int]),
     'vp_res2_train_fwd': (c_int, [c_void_p, C.POINTER(Res2TrainDesc), c_void_p, c_size_t, c_void_p]),
     'vp_res2_train_bwd': (c_int, [c_void_p, C.POINTER(Res2TrainDesc), c_void_p, c_size_t, c_void_p]),

@@ -475,11 +475,11 @@ class Res2Fn(torch.autograd.Function):
             wd.dtype_in = wd.dtype_out = N.VP_BF16
             wd.B, wd.T_in, wd.T_out, wd.Cin, wd.Cout, wd.KW, wd.dilation, wd.stride = B, T, T, 64, 64, 3, cfg['dilation'], 1
             wd.pad_mode, wd.pad_left, wd.ldx, wd.xoff, wd.ldy, wd.mfma_bf16 = N.VP_PAD_REFLECT, cfg['dilation'], 64, 0, 64, 1
-            wws = _bytes(lib.vp_conv1d_wgrad_workspace_bytes(C.byref(wd)), dout.device)
-            for i in range(S - 1):                                       # weight gradients: dz_i^T x in_i, both bf16 in memory
-                wd.x, wd.w = inb[i].data_ptr(), wg[2 * i].data_ptr()
-                _chk(lib.vp_conv1d_wgrad_bf16_oik(hctx, C.byref(wd), dzb[i].data_ptr(), 64, dw_all[i].data_ptr(), wws.data_ptr(),
-                                                  wws.numel(), N.stream_ptr()), hctx)
+            wws = _bytes(lib.vp_conv1d_wgrad_workspace_bytes(C.byref(wd)) * (S - 1), dout.device)
+            wd.x, wd.w = inb.data_ptr(), wg[0].data_ptr()                # weight gradients dz_i^T in_i of all chunks in one launch
+            _chk(lib.vp_conv1d_wgrad_bf16_oik_batched(hctx, C.byref(wd), dzb.data_ptr(), 64, dw_all.data_ptr(), S - 1, M * 64, M * 64,
+                                                      wws.data_ptr(), wws.numel(), N.stream_ptr()), hctx)
+            for i in range(S - 1):
                 grads[6 * i:6 * i + 4] = [dw_all[i], dvec[i, 0], dvec[i, 1], dvec[i, 2]]
             return (dx, None, *grads)
         saved, at, tapes = ctx.saved_tensors, 0, []
