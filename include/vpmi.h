@@ -190,6 +190,11 @@ int vp_cast_f32_bf16(vp_ctx* ctx, const float* x, void* y, long long n, vp_strea
 int vp_se_scale_residual(vp_ctx* ctx, int dtype, const void* x, int ldx, int xoff, const float* s,
                          const void* res, int ldr, int roff, void* out, int ldo, int ooff,
                          int B, int T, int C, vp_stream stream);
+/* The same on f32 tensors, plus the result once more as bf16 at shadow[m * ld_shadow + shadow_off + c]: under enable_amp the block
+ * output (ecapa_tdnn.py:139-142) is the GEMM operand of the next block's tdnn1 and of the MFA concatenation (:262-263). */
+int vp_se_scale_residual_shadow(vp_ctx* ctx, const float* x, int ldx, int xoff, const float* s, const float* res, int ldr, int roff,
+                                float* out, int ldo, int ooff, void* shadow, int ld_shadow, int shadow_off, int B, int T, int C,
+                                vp_stream stream);
 
 /* attention softmax over time + weighted mean/std (pooling.py:114-123):
  * logits (B*T, C) f32, x (B*T, ldx) -> pooled (B, 2C) f32 = [mean | std]. */
@@ -690,6 +695,7 @@ typedef struct {
     void* dzb;
     float* stats;
     float* dvec;
+    void* out_bf16;               /* forward, optional: out once more as bf16 (B*T, C), the operand of the conv behind the block */
 } vp_res2_train_desc;
 /* nbatch convs of identical geometry in one launch (the chunk convs of a Res2Net block after vp_res2_train_bwd): conv c reads
  * x + c * x_bstride and dz + c * dz_bstride (bf16 elements), writes dW + c * Cout * Cin * KW; ws = nbatch x vp_conv1d_wgrad_workspace_bytes(d). */

@@ -1137,3 +1137,38 @@ def test_res2_chain_one_launch_per_direction_equals_the_per_chunk_path(N, amp, m
     fwd_tol, bwd_tol = {2: (2e-6, 2e-4), 3: (1e-4, 5e-3)}.get(S, (3e-3, 5e-2))
     for kind, e in worst.items():
         assert e < (fwd_tol if kind in ('out', 'run_mean', 'run_var') else bwd_tol), (kind, e)
+
+
+def test_block_outputs_written_as_bf16_by_their_producer_change_nothing(N, amp, monkeypatch):
+    """enable_amp, ECAPA at >= 4096 rows: the SE-Res2 block outputs reach the next block's tdnn1 and the MFA layer as bf16 operands.
+    By default the kernel that produces them (vp_se_scale_residual_shadow) also writes the bf16 copy into its column slice of the MFA
+    operand; VPMI_NO_SHADOW=1 converts afterwards (x.to(bfloat16) per consumer + three strided copies).  Same rounding of the same
+    values: loss and every parameter gradient must be bit-identical."""
+    import ppvector
+    from ppvector.models.ecapa_tdnn import EcapaTdnn
+    from ppvector.train.ecapa_train import ecapa_forward_train
+    torch.manual_seed(11)
+    m0 = EcapaTdnn(80).cuda().train()
+    state = {k: v.clone() for k, v in m0.state_dict().items()}
+    x = torch.randn(16, 298, 80, device='cuda')
+    g = torch.randn(16, 192, device='cuda')
+
+    def run(no_shadow):
+        if no_shadow:
+            monkeypatch.setenv('VPMI_NO_SHADOW', '1')
+        else:
+            monkeypatch.delenv('VPMI_NO_SHADOW', raising=False)
+        m0.load_state_dict(state)
+        for p in m0.parameters():
+            p.grad = None
+        emb = ecapa_forward_train(m0, x)
+        emb.backward(g)
+        torch.cuda.synchronize()
+        return emb.detach().clone(), {k: p.grad.clone() for k, p in m0.named_parameters()}
+
+    e0, g0 = run(True)
+    e1, g1 = run(False)
+    worst = max((g1[k] - g0[k]).abs().max().item() for k in g0)
+    print(f'[bf16 shadows] embeddings identical: {torch.equal(e0, e1)}; worst |gradient difference| {worst:.1e}')
+    assert torch.equal(e0, e1)
+    assert all(torch.equal(g0[k], g1[k]) for k in g0)

@@ -46,6 +46,7 @@ struct Res2TrainArgs {
     float* z;                               // [nconv][M][64] f32
     bf16_t* inb;                            // [nconv][M][64] bf16   (forward only)
     bf16_t* dzb;                            // [nconv][M][64] bf16   (backward only)
+    bf16_t* outb;                           // forward, optional: out once more as bf16 (M, C) -- the operand of the conv that follows
     float* stats;                           // [nconv][2][64]: mean, invstd
     float* dvec;                            // [nconv][3][64]: d bias, d gamma, d beta  (backward only)
     float* part;                            // workspace [nconv][B][128] (+ backward: [nconv][B][64] behind it)
@@ -223,6 +224,8 @@ __global__ __launch_bounds__(RT_THREADS) void res2_train_fwd_kernel(Res2TrainArg
     const unsigned lx = (unsigned)(rl * a.C + cq) * 4, lz = (unsigned)(rl * RT_W + cq) * 4, lb = (unsigned)(rl * RT_W + cq) * 2;
     const unsigned pitch = (unsigned)a.C * 4;
     const __amdgpu_buffer_rsrc_t rp = rt_rsrc(a.part, (size_t)a.nconv * a.B * (128 + 64) * 4);
+    const __amdgpu_buffer_rsrc_t rob = rt_rsrc(a.outb ? (const void*)a.outb : (const void*)a.out, a.outb ? (size_t)Mrows * a.C * 2 : 0);   // (absent: every store out of range)
+    const unsigned lxb = (unsigned)(rl * a.C + cq) * 2;
 
     // ---- prologue: out[:, 0:64] = x[:, 0:64]; in_1 = x[:, 64:128] -> LDS (bf16) and the saved operand; weights of conv 0
     rt_load_w<false>(a.w[0], wts, tid);
@@ -237,6 +240,11 @@ __global__ __launch_bounds__(RT_THREADS) void res2_train_fwd_kernel(Res2TrainArg
             const float4 v0 = rt_ld(rx, ok ? lx : RT_PAST, so);
             const float4 v1 = rt_ld(rx, ok ? lx : RT_PAST, so + RT_W * 4);
             rt_st(ro, v0, ok ? lx : RT_PAST, so);
+            {
+                bf16x4 ob;
+                ob[0] = (bf16_t)v0.x; ob[1] = (bf16_t)v0.y; ob[2] = (bf16_t)v0.z; ob[3] = (bf16_t)v0.w;
+                rt_st8(rob, ob, ok ? lxb : RT_PAST, so >> 1);
+            }
             bf16x4 o;
             o[0] = (bf16_t)v1.x; o[1] = (bf16_t)v1.y; o[2] = (bf16_t)v1.z; o[3] = (bf16_t)v1.w;
             if (ok) *reinterpret_cast<bf16x4*>(act + rt_pos(t, cq)) = o;
@@ -375,6 +383,11 @@ __global__ __launch_bounds__(RT_THREADS) void res2_train_fwd_kernel(Res2TrainArg
                     y.x = rr[r][k].x * sc.x + sh.x; y.y = rr[r][k].y * sc.y + sh.y;
                     y.z = rr[r][k].z * sc.z + sh.z; y.w = rr[r][k].w * sc.w + sh.w;
                     rt_st(ro, y, ok ? lx : RT_PAST, (row0 + mt * 16 + 4 * k) * pitch + (j + 1) * (RT_W * 4));
+                    {
+                        bf16x4 ob;
+                        ob[0] = (bf16_t)y.x; ob[1] = (bf16_t)y.y; ob[2] = (bf16_t)y.z; ob[3] = (bf16_t)y.w;
+                        rt_st8(rob, ob, ok ? lxb : RT_PAST, ((row0 + mt * 16 + 4 * k) * pitch + (j + 1) * (RT_W * 4)) >> 1);
+                    }
                     if (has_next) {
                         bf16x4 o;
                         o[0] = (bf16_t)(y.x + xn[r][k].x); o[1] = (bf16_t)(y.y + xn[r][k].y);
@@ -660,7 +673,7 @@ static int rt_fill(vp_ctx* ctx, const vp_res2_train_desc* d, void* ws, size_t ws
          reinterpret_cast<uintptr_t>(d->inb) | reinterpret_cast<uintptr_t>(d->dzb)) & 15)
         VP_FAIL(ctx, VP_EINVAL, "res2_train: tensors must be 16-byte aligned");
     memset(&a, 0, sizeof(a));
-    a.x = d->x; a.out = d->out; a.z = d->z; a.inb = (bf16_t*)d->inb; a.dzb = (bf16_t*)d->dzb; a.stats = d->stats; a.dvec = d->dvec;
+    a.x = d->x; a.out = d->out; a.z = d->z; a.inb = (bf16_t*)d->inb; a.dzb = (bf16_t*)d->dzb; a.outb = bwd ? nullptr : (bf16_t*)d->out_bf16; a.stats = d->stats; a.dvec = d->dvec;
     a.part = (float*)ws; a.bar = ctx->grid_bar;
     for (int j = 0; j < nconv; ++j) {
         if (!d->w[j] || !d->gamma[j] || (!bwd && (!d->bias[j] || !d->beta[j]))) VP_FAIL(ctx, VP_EINVAL, "res2_train: null parameter");

@@ -167,6 +167,7 @@ template <typename T>
 struct SeArgs {
     const T* x; const float* s; const T* res; T* out;
     int ldx, xoff, ldr, roff, ldo, ooff, T_, C, relu; long long total;
+    bf16_t* shadow; int lds_, soff;          // f32 flavour only: the same values once more as bf16 (the next GEMM's operand), or NULL
 };
 
 template <typename T>
@@ -191,6 +192,14 @@ __global__ __launch_bounds__(256) void se_scale_residual_kernel(SeArgs<T> a) {
             oe[e] = vp_from_f32<T>(v);
         }
         *reinterpret_cast<uint4*>(a.out + m * a.ldo + a.ooff + c) = o;
+        if constexpr (sizeof(T) == 4) {
+            if (a.shadow) {
+                bf16x4 q;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) q[e] = (bf16_t)vp_to_f32(oe[e]);
+                *reinterpret_cast<bf16x4*>(a.shadow + m * a.lds_ + a.soff + c) = q;
+            }
+        }
     }
 }
 
@@ -247,10 +256,12 @@ __global__ __launch_bounds__(256) void asp_softmax_stats_kernel(AspArgs<T> a) {
 
 }  // namespace
 
-int vp_se_scale_residual_ex(vp_ctx* ctx, int dtype, const void* x, int ldx, int xoff, const float* s,
-                            const void* res, int ldr, int roff, void* out, int ldo, int ooff, int B, int T, int C,
-                            int relu, hipStream_t st) {
+static int se_scale_residual_impl(vp_ctx* ctx, int dtype, const void* x, int ldx, int xoff, const float* s,
+                                  const void* res, int ldr, int roff, void* out, int ldo, int ooff, int B, int T, int C,
+                                  int relu, void* shadow, int ld_shadow, int shadow_off, hipStream_t st) {
     if (!ctx || !x || !s || !res || !out || B <= 0 || T <= 0 || C <= 0) VP_FAIL(ctx, VP_EINVAL, "se: bad arguments");
+    if (shadow && (dtype != VP_F32 || (ld_shadow | shadow_off) & 3 || reinterpret_cast<uintptr_t>(shadow) & 7))
+        VP_FAIL(ctx, VP_EINVAL, "se: the bf16 shadow goes with f32 tensors, ld / offset multiples of 4");
     const int V = dtype == VP_BF16 ? 8 : 4;
     if (C % V || ldx % V || xoff % V || ldr % V || roff % V || ldo % V || ooff % V)
         VP_FAIL(ctx, VP_EINVAL, "se: C/ld/off must be multiples of %d", V);
@@ -258,16 +269,23 @@ int vp_se_scale_residual_ex(vp_ctx* ctx, int dtype, const void* x, int ldx, int 
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (dtype == VP_BF16) {
-        SeArgs<bf16_t> a{(const bf16_t*)x, s, (const bf16_t*)res, (bf16_t*)out, ldx, xoff, ldr, roff, ldo, ooff, T, C, relu, total};
+        SeArgs<bf16_t> a{(const bf16_t*)x, s, (const bf16_t*)res, (bf16_t*)out, ldx, xoff, ldr, roff, ldo, ooff, T, C, relu, total, nullptr, 0, 0};
         hipLaunchKernelGGL(se_scale_residual_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, a);
     } else if (dtype == VP_F32) {
-        SeArgs<float> a{(const float*)x, s, (const float*)res, (float*)out, ldx, xoff, ldr, roff, ldo, ooff, T, C, relu, total};
+        SeArgs<float> a{(const float*)x, s, (const float*)res, (float*)out, ldx, xoff, ldr, roff, ldo, ooff, T, C, relu, total,
+                        (bf16_t*)shadow, ld_shadow, shadow_off};
         hipLaunchKernelGGL(se_scale_residual_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, a);
     } else {
         VP_FAIL(ctx, VP_EINVAL, "se: bad dtype");
     }
     VP_LAUNCH_CHECK(ctx, "se_scale_residual");
     return VP_OK;
+}
+
+int vp_se_scale_residual_ex(vp_ctx* ctx, int dtype, const void* x, int ldx, int xoff, const float* s,
+                            const void* res, int ldr, int roff, void* out, int ldo, int ooff, int B, int T, int C,
+                            int relu, hipStream_t st) {
+    return se_scale_residual_impl(ctx, dtype, x, ldx, xoff, s, res, ldr, roff, out, ldo, ooff, B, T, C, relu, nullptr, 0, 0, st);
 }
 
 // mean / std over time straight from the activations (small T): stats[b] = [mean(C) | sqrt(max(E[(x-m)^2], eps))]
@@ -596,6 +614,15 @@ int vp_dense_f32(vp_ctx* ctx, const float* a, int lda, const float* w, int w_is_
                  int M, int N, int K, int act, float* out, int ldo, vp_stream stream) {
     if (!ctx) return VP_EINVAL;
     return vp_dense_f32_ex(ctx, a, lda, w, w_is_kn, bias, nullptr, nullptr, M, N, K, act, out, ldo, (hipStream_t)stream);
+}
+
+// f32 tensors, plus the result once more as bf16 at shadow[m * ld_shadow + shadow_off + c] -- the operand of the GEMMs that consume the
+// block output under mixed precision (next block's tdnn1, the MFA concatenation), written by the pass that produces it
+int vp_se_scale_residual_shadow(vp_ctx* ctx, const float* x, int ldx, int xoff, const float* s, const float* res, int ldr, int roff,
+                                float* out, int ldo, int ooff, void* shadow, int ld_shadow, int shadow_off, int B, int T, int C,
+                                vp_stream stream) {
+    return se_scale_residual_impl(ctx, VP_F32, x, ldx, xoff, s, res, ldr, roff, out, ldo, ooff, B, T, C, 0, shadow, ld_shadow, shadow_off,
+                                  (hipStream_t)stream);
 }
 
 int vp_se_scale_residual(vp_ctx* ctx, int dtype, const void* x, int ldx, int xoff, const float* s,

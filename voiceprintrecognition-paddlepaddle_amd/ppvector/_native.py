@@ -59,7 +59,7 @@ class Res2TrainDesc(C.Structure):
                 ('momentum', c_float), ('eps', c_float), ('x', c_void_p), ('out', c_void_p),
                 ('w', c_void_p * 7), ('bias', c_void_p * 7), ('gamma', c_void_p * 7), ('beta', c_void_p * 7),
                 ('run_mean', c_void_p * 7), ('run_var', c_void_p * 7),
-                ('z', c_void_p), ('inb', c_void_p), ('dzb', c_void_p), ('stats', c_void_p), ('dvec', c_void_p)]
+                ('z', c_void_p), ('inb', c_void_p), ('dzb', c_void_p), ('stats', c_void_p), ('dvec', c_void_p), ('out_bf16', c_void_p)]
 
 
 class TdnnLayer(C.Structure):
@@ -159,6 +159,8 @@ _PROTOS = {
     'vp_set_margin_table': (c_int, [c_void_p, c_void_p]),
     'vp_conv1d_wgrad_bf16_oik_batched': (c_int, [c_void_p, C.POINTER(Conv1dDesc), c_void_p, c_int, c_void_p, c_int, C.c_longlong, C.c_longlong, c_void_p,
                                          c_size_t, c_void_p]),
+    'vp_se_scale_residual_shadow': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
+                                    c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'vp_res2_train_workspace_bytes': (c_size_t, [c_int, c_int]),
     'vp_res2_train_fwd': (c_int, [c_void_p, C.POINTER(Res2TrainDesc), c_void_p, c_size_t, c_void_p]),
     'vp_res2_train_bwd': (c_int, [c_void_p, C.POINTER(Res2TrainDesc), c_void_p, c_size_t, c_void_p]),

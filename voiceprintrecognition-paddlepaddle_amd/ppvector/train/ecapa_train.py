@@ -3,8 +3,11 @@ functions.py.  Every conv / BatchNorm / SE gate / ASP / projection runs in libvp
 chunking, the hand-off adds (y_{i-1} + x_i) and the two concatenations are tensor slicing / torch.cat / `+` on 2-D
 (B*T, C) tensors -- data movement and three elementwise adds per block that PyTorch's tape needs to see.
 Input (B, T, F) f32 on the GPU -> embeddings (B, embd_dim)."""
+import os
+
 import torch
 
+import ppvector
 from ppvector.train.functions import BNRows, CatConvBlock, ConvBlock, ConvBlockSkip, Res2Fn, SEBlockFn
 from ppvector.train.segments import cut
 from ppvector.train.tdnn_train import asp_forward
@@ -28,10 +31,17 @@ def res2net_block(r2, x, B, T):
     if any(b.conv.dilation != blocks[0].conv.dilation or b.norm.norm.momentum != n0.momentum or b.norm.norm.eps != n0.eps
            for b in blocks):
         raise NotImplementedError('Res2NetBlock chunks with different dilation / BatchNorm settings')
-    return Res2Fn.apply(x, dict(B=B, T=T, scale=r2.scale, dilation=blocks[0].conv.dilation, momentum=n0.momentum, eps=n0.eps), *params)
+    # bf16_twin: under enable_amp the fused chain kernel writes its output once more as bf16 -- the operand tdnn2 reads
+    cfg = dict(B=B, T=T, scale=r2.scale, dilation=blocks[0].conv.dilation, momentum=n0.momentum, eps=n0.eps,
+               bf16_twin=bool(ppvector.get_train_amp()) and os.environ.get('VPMI_TRAIN_BF16_OPS', '2') != '0'
+               and not os.environ.get('VPMI_NO_SHADOW') and B * T >= 4096 and x.shape[1] >= 256)
+    out = Res2Fn.apply(x, cfg, *params)
+    if cfg.get('_twin') is not None:
+        out._vp_bf16 = cfg['_twin']
+    return out
 
 
-def se_res2net_block(blk, x, B, T):
+def se_res2net_block(blk, x, B, T, shadow=None):
     if blk.shortcut is not None:
         raise NotImplementedError('SERes2NetBlock with a shortcut conv is not built')
     conv, norm = blk.tdnn1.conv.conv, blk.tdnn1.norm.norm      # tdnn1 also hands x on as the residual (its gradient comes back here)
@@ -41,7 +51,10 @@ def se_res2net_block(blk, x, B, T):
     h = res2net_block(blk.res2net_block, h, B, T)
     h = tdnn_block(blk.tdnn2, h, B, T)
     se = blk.se_block                                           # squeeze, two dense layers, gate, + residual: one tape entry
-    return SEBlockFn.apply(h, residual, se.conv1.conv.weight, se.conv1.conv.bias, se.conv2.conv.weight, se.conv2.conv.bias, B, T)
+    out = SEBlockFn.apply(h, residual, se.conv1.conv.weight, se.conv1.conv.bias, se.conv2.conv.weight, se.conv2.conv.bias, B, T, shadow)
+    if shadow is not None:
+        out._vp_bf16 = shadow                                    # ConvBlock / CatConvBlock take the operand from here instead of converting
+    return out
 
 
 def ecapa_forward_train(m, feats):
@@ -49,15 +62,23 @@ def ecapa_forward_train(m, feats):
     x = feats.reshape(B * T, F)
     x = tdnn_block(m.blocks[0], x, B, T)
     outs = []
-    for blk in list(m.blocks)[1:]:
-        x = se_res2net_block(blk, x, B, T)
+    blocks = list(m.blocks)[1:]
+    # enable_amp: the block outputs are GEMM operands twice (next block's tdnn1, the MFA concatenation) -- the kernel that produces
+    # them also writes them as bf16, straight into their column slice of the MFA operand (VPMI_TRAIN_BF16_OPS=0: f32 operands)
+    Cb = x.shape[1]
+    xcat = None
+    if ppvector.get_train_amp() and os.environ.get('VPMI_TRAIN_BF16_OPS', '2') != '0' and not os.environ.get('VPMI_NO_SHADOW') \
+            and B * T >= 4096 and Cb % 64 == 0 and Cb >= 256 and m.mfa.conv.conv.weight.shape[1] == Cb * len(blocks):
+        xcat = torch.empty((B * T, Cb * len(blocks)), dtype=torch.bfloat16, device=x.device)
+    for i, blk in enumerate(blocks):
+        x = se_res2net_block(blk, x, B, T, xcat[:, i * Cb:(i + 1) * Cb] if xcat is not None else None)
         outs.append(x)
         # backward stage boundary (train/segments.py): every block output is live across it -- the next block reads the last
         # one, the MFA concatenation all of them.  Stages from the end: head + ASP + MFA | block 3 | block 2 | blocks 0-1
         outs = list(cut(*outs))
         x = outs[-1]
     conv, norm = m.mfa.conv.conv, m.mfa.norm.norm
-    x = CatConvBlock.apply(dict(B=B, T=T, dilation=m.mfa.conv.dilation, pad='reflect', relu=True, momentum=norm.momentum, eps=norm.eps),
+    x = CatConvBlock.apply(dict(B=B, T=T, dilation=m.mfa.conv.dilation, pad='reflect', relu=True, momentum=norm.momentum, eps=norm.eps, xcat=xcat),
                            conv.weight, conv.bias, norm.weight, norm.bias, norm._mean, norm._variance, *outs)
     p = asp_forward(m.asp, x, B, T)
     n = m.asp_bn.norm

@@ -40,7 +40,7 @@ def _conv_desc(x, B, T_in, T_out, Cin, Cout, KW, dil, pad_mode, pad_left, w, bia
     d.dtype_in = d.dtype_out = N.VP_F32
     d.B, d.T_in, d.T_out, d.Cin, d.Cout, d.KW, d.dilation, d.stride = B, T_in, T_out, Cin, Cout, KW, dil, 1
     d.pad_mode, d.pad_left = pad_mode, pad_left
-    d.x, d.ldx, d.xoff = x.data_ptr(), Cin, 0
+    d.x, d.ldx, d.xoff = x.data_ptr(), (x.stride(0) if x.dim() == 2 and x.shape[0] > 1 else Cin), 0     # (a column slice of a wider buffer keeps its pitch)
     d.w = w.data_ptr()
     if bias is not None:
         d.bias = bias.data_ptr()
@@ -90,11 +90,13 @@ class ConvBlock(torch.autograd.Function):
         if x.dtype == torch.bfloat16:
             if not wide:
                 raise N.VpmiError('ConvBlock: a bf16 input outside the wide mixed-precision layers')
-            x = x.contiguous()
+            if x.stride(1) != 1 or x.stride(0) % 4:
+                x = x.contiguous()
         else:
+            shadow = getattr(x, '_vp_bf16', None)         # the producer already wrote x as bf16 (SEBlockFn: a slice of the MFA operand)
             x = _f32c(x)
             if wide:
-                x = x.to(torch.bfloat16)
+                x = shadow if shadow is not None and shadow.shape == x.shape else x.to(torch.bfloat16)
         pad = cfg.get('pad', 'none')
         pad_left = 0 if pad == 'none' else dil * (KW - 1) // 2
         T_out = T_in - dil * (KW - 1) if pad == 'none' else T_in
@@ -308,11 +310,13 @@ class CatConvBlock(torch.autograd.Function):
         M, widths = xs[0].shape[0], [x.shape[1] for x in xs]
         Cout, Cin, KW = weight.shape
         if _wide_bf16(M, Cin, Cout, KW, bias, None, gamma, cfg):
-            xcat = torch.empty((M, Cin), dtype=torch.bfloat16, device=xs[0].device)
-            at = 0
-            for x, wd in zip(xs, widths):
-                xcat[:, at:at + wd].copy_(x)
-                at += wd
+            xcat = cfg.get('xcat')                         # filled slice by slice by the producers of xs (SEBlockFn's bf16 shadow), or:
+            if xcat is None or tuple(xcat.shape) != (M, Cin) or xcat.dtype != torch.bfloat16:
+                xcat = torch.empty((M, Cin), dtype=torch.bfloat16, device=xs[0].device)
+                at = 0
+                for x, wd in zip(xs, widths):
+                    xcat[:, at:at + wd].copy_(x)
+                    at += wd
         else:
             xcat = torch.cat(xs, dim=1)
         tp = _Tape((True,) * 9)
@@ -421,12 +425,15 @@ class Res2Fn(torch.autograd.Function):
             inb = torch.empty((S - 1, M, 64), dtype=torch.bfloat16, device=x.device)
             stats = torch.empty((S - 1, 2, 64), dtype=torch.float32, device=x.device)
             d = Res2Fn._fused_desc(x, out, cfg, params, S)
+            outb = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if cfg.get('bf16_twin') else None
             d.z, d.inb, d.stats = z.data_ptr(), inb.data_ptr(), stats.data_ptr()
+            d.out_bf16 = outb.data_ptr() if outb is not None else None
             ws = _bytes(lib.vp_res2_train_workspace_bytes(B, S), x.device)
             rc = lib.vp_res2_train_fwd(hctx, C.byref(d), ws.data_ptr(), ws.numel(), N.stream_ptr())
             if rc == 0:
                 ctx.save_for_backward(z, inb, stats, *[params[6 * i + k] for i in range(S - 1) for k in (0, 2)])
                 ctx.fused, ctx.split, ctx.cfg = True, (S, w), dict(cfg)
+                cfg['_twin'] = outb                                      # (handed to the caller, who hangs it on the returned tensor)
                 return out
             if rc != N.VP_EUNSUP:
                 _chk(rc, hctx)
@@ -520,7 +527,7 @@ class SEBlockFn(torch.autograd.Function):
     mean-backward tensor and autograd's sum of the two (8 tensor passes -> 4)."""
 
     @staticmethod
-    def forward(ctx, h, res, w1, b1, w2, b2, B, T):
+    def forward(ctx, h, res, w1, b1, w2, b2, B, T, shadow=None):
         lib, hctx = N.lib(), N.ctx(h.device)
         h, res = _f32c(h), _f32c(res)
         Cc = h.shape[1]
@@ -532,8 +539,12 @@ class SEBlockFn(torch.autograd.Function):
         a = ConvBlock.forward(t1, mean, w1, b1, None, None, None, None, None, dict(B=B, T=1, relu=True))
         s = ConvBlock.forward(t2, a, w2, b2, None, None, None, None, None, dict(B=B, T=1, sigmoid=True))
         out = torch.empty_like(h)
-        _chk(lib.vp_se_scale_residual(hctx, N.VP_F32, h.data_ptr(), Cc, 0, s.data_ptr(), res.data_ptr(), Cc, 0, out.data_ptr(), Cc, 0,
-                                      B, T, Cc, N.stream_ptr()), hctx)
+        if shadow is not None:                       # (B*T, Cc) bf16 view, unit column stride: the block output as the next GEMMs read it
+            _chk(lib.vp_se_scale_residual_shadow(hctx, h.data_ptr(), Cc, 0, s.data_ptr(), res.data_ptr(), Cc, 0, out.data_ptr(), Cc, 0,
+                                                 shadow.data_ptr(), shadow.stride(0), 0, B, T, Cc, N.stream_ptr()), hctx)
+        else:
+            _chk(lib.vp_se_scale_residual(hctx, N.VP_F32, h.data_ptr(), Cc, 0, s.data_ptr(), res.data_ptr(), Cc, 0, out.data_ptr(), Cc, 0,
+                                          B, T, Cc, N.stream_ptr()), hctx)
         ctx.save_for_backward(h, s, *t1.saved_tensors, *t2.saved_tensors)
         ctx.n1 = len(t1.saved_tensors)
         ctx.geoms = (B, T, t1.geom, t2.geom)
@@ -557,7 +568,7 @@ class SEBlockFn(torch.autograd.Function):
         dm, dw1, db1 = ConvBlock.backward(t1, da)[:3]
         dh = torch.empty_like(h)
         _chk(lib.vp_scale_shift_rows_f32(hctx, dout.data_ptr(), s.data_ptr(), dm.data_ptr(), B, T, Cc, dh.data_ptr(), N.stream_ptr()), hctx)
-        return dh, dout, dw1, db1, dw2, db2, None, None
+        return dh, dout, dw1, db1, dw2, db2, None, None, None
 
 
 class TimeStats(torch.autograd.Function):

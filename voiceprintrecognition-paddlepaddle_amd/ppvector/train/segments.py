@@ -45,6 +45,9 @@ class Recorder:
         if not keep:
             return tensors
         leaves = [t.detach().requires_grad_(True) for t in keep]
+        for t, l in zip(keep, leaves):                    # (a producer's bf16 twin of the tensor travels with it: train/functions.py)
+            if getattr(t, '_vp_bf16', None) is not None:
+                l._vp_bf16 = t._vp_bf16
         self.cuts.append((keep, leaves))
         it = iter(leaves)
         return tuple(next(it) if t.requires_grad else t for t in tensors)
