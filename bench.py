@@ -63,7 +63,7 @@ def conv_family_shapes(T):
 
 
 def kernel_git_hash():
-    """Hash of the kernel sources the PMC traffic numbers were taken on (profiles/pmc_traffic.json: "csrc_hash")."""
+    """Hash of the kernel sources the PMC traffic numbers were taken on (profiles/r03_pmc_infer.json: "csrc_hash")."""
     import hashlib
     h = hashlib.sha1()
     for f in ('conv_gemm256.hip', 'conv_gemm_impl.h', 'conv_gemm.hip'):
@@ -130,14 +130,17 @@ def roofline_pass(reps):
     total_flop = sum(2.0 * M * p['cout'] * p['kw'] * p['cin'] for p in dom)
     n = len(dom)
     achieved = total_flop / (total_ms * 1e-3) / 1e12
-    # HBM bytes per launch from the PMC passes (tools/pmc_probe.sh): only while the file was taken on THESE kernel sources
+    # HBM bytes per launch (average over the same seven launches) from the PMC passes of tools/pmc_step.sh, kept in profiles/: only
+    # while that file was taken on THESE kernel sources
     traffic = None
-    tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    tfile = os.path.join(ROOT, 'profiles', 'r03_pmc_infer.json')
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
             if tj.get('csrc_hash') == kernel_git_hash():
-                traffic = tj.get('conv_gemm256_bytes_per_launch')
+                for name, v in tj['kernels'].items():
+                    if 'conv_gemm128x256_ring_kernel' in name:
+                        traffic = round((v['read_MB'] + v['write_MB']) * 1e6)
         except Exception:
             traffic = None
     return {'bound': 'mfma', 'kernel': 'conv_gemm128x256_ring_kernel (7 launches/step: 6 x 512->512 + MFA 1536->1536, 87% of forward flops)',

@@ -59,5 +59,10 @@ for k, c in cnt.items():
     if 'SQ_LDS_IDX_ACTIVE' in m:
         e['lds_conflict_frac'] = round(m['SQ_LDS_BANK_CONFLICT'] / max(1.0, m['SQ_LDS_IDX_ACTIVE']), 4)
     out[k] = e
-json.dump({'_source': f'tools/pmc_step.sh {tag}: rocprofv3 --kernel-trace --pmc <group>, one group per pass, per-launch averages over every launch '
+import hashlib, os  # noqa: E402
+_h = hashlib.sha1()
+for _f in ('conv_gemm256.hip', 'conv_gemm_impl.h', 'conv_gemm.hip'):       # the same hash bench.py compares before quoting roofline.traffic
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'voiceprintrecognition-paddlepaddle_amd', 'csrc', _f), 'rb') as _fh:
+        _h.update(_fh.read())
+json.dump({'csrc_hash': _h.hexdigest()[:12], '_source': f'tools/pmc_step.sh {tag}: rocprofv3 --kernel-trace --pmc <group>, one group per pass, per-launch averages over every launch '
                       'of the kernel in the command; corrections in tools/pmc_aggregate.py', 'kernels': out}, sys.stdout, indent=1)
