@@ -17,7 +17,8 @@
 namespace {
 
 constexpr int HT_CT = 64;            // classes per tile
-constexpr int HT_RB = 64;            // utterances per block
+constexpr int HT_RB = 64;            // utterances per block (backward kernel)
+constexpr int HT_RF = 32;            // utterances per block of the forward kernel: 79 KB of LDS, two workgroups per CU
 constexpr int HT_DMAX = 256;         // embedding width supported (192 in every shipped config)
 constexpr int HT_SW = HT_CT + 2;     // LDS strides = 2 mod 32 banks: see the operand reads below
 typedef __attribute__((ext_vector_type(4))) float v4f;
@@ -27,6 +28,7 @@ struct HeadTileArgs {
     float* part;                     // [5][B][tiles]: max, sum exp(out - max), sum out, best cosine, its class (as float bits of an int)
     float* tgt;                      // [B] scaled, margined target logit
     float* cinv;                     // [C] column inverse norms (by-product; NULL = not wanted)
+    const float* rinv;               // [B] row inverse norms of the embeddings (vp_row_inv_norm ahead of the launch)
     int B, D, C, tiles, SE;          // SE = D + 2
     float cos_m, sin_m, th, mmm, scale; int easy;
     const float* mt;
@@ -86,17 +88,20 @@ __device__ __forceinline__ void ht_load_w(const float* W, int D, int C, int c0, 
 }
 
 // embeddings of utterances [b0, b0 + 64) -> Es[r][SE]; rows past B read as zero (out-of-range offsets)
-template <int NE>                    // 16-byte chunks per thread = ceil(64 * D / 4 / 256)
-__device__ __forceinline__ void ht_load_e(const float* emb, int B, int D, int SE, int b0, int tid, float* Es) {
+template <int NE, int ROWS = HT_RB>  // NE: 16-byte chunks per thread = ceil(ROWS * D / 4 / 256)
+__device__ __forceinline__ void ht_issue_e(const float* emb, int B, int D, int b0, int tid, ht_u32x4 (&v)[NE]) {
     const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(emb), 0, (unsigned)((size_t)B * D * 4), 0x00020000);
-    const int per_row = D >> 2, total = HT_RB * per_row;
-    ht_u32x4 v[NE];
+    const int per_row = D >> 2, total = ROWS * per_row;
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         const int idx = tid + 256 * i;
         const int r = idx / per_row, kq = (idx - r * per_row) * 4;
         v[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, (idx < total && b0 + r < B) ? (unsigned)(((size_t)(b0 + r) * D + kq) * 4) : HT_OOB, 0, 0);
     }
+}
+template <int NE, int ROWS = HT_RB>
+__device__ __forceinline__ void ht_commit_e(int D, int SE, int tid, float* Es, const ht_u32x4 (&v)[NE]) {
+    const int per_row = D >> 2, total = ROWS * per_row;
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         const int idx = tid + 256 * i;
@@ -109,15 +114,21 @@ __device__ __forceinline__ void ht_load_e(const float* emb, int B, int D, int SE
         }
     }
 }
+template <int NE, int ROWS = HT_RB>
+__device__ __forceinline__ void ht_load_e(const float* emb, int B, int D, int SE, int b0, int tid, float* Es) {
+    ht_u32x4 v[NE];
+    ht_issue_e<NE, ROWS>(emb, B, D, b0, tid, v);
+    ht_commit_e<NE, ROWS>(D, SE, tid, Es, v);
+}
 
-__global__ __launch_bounds__(256) void head_tile_fwd_kernel(HeadTileArgs a) {
+__global__ __launch_bounds__(256, 2) void head_tile_fwd_kernel(HeadTileArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Ws = reinterpret_cast<float*>(smem);                   // [D][HT_SW]
-    float* Es = Ws + a.D * HT_SW;                                 // [HT_RB][SE]
-    float* cinv_s = Es + HT_RB * a.SE;                            // [64]
-    float* rinv_s = cinv_s + HT_CT;                               // [64]
-    float* red = rinv_s + HT_RB;                                  // [5][4 waves][64 rows]
-    int* lab_s = reinterpret_cast<int*>(red + 5 * 4 * 64);        // [64] labels of the row block (-1 past B)
+    float* Es = Ws + a.D * HT_SW;                                 // [HT_RF][SE]
+    float* cinv_s = Es + HT_RF * a.SE;                            // [64]
+    float* rinv_s = cinv_s + HT_CT;                               // [HT_RF]
+    float* red = rinv_s + HT_RF;                                  // [5][4 waves][HT_RF rows] (and [4][64] / [8][HT_RF] for the norms)
+    int* lab_s = reinterpret_cast<int*>(red + 5 * 4 * HT_RF);     // [HT_RF] labels of the row block (-1 past B)
     if (a.mt) { a.cos_m = a.mt[1]; a.sin_m = a.mt[2]; a.th = a.mt[3]; a.mmm = a.mt[4]; }
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
@@ -141,47 +152,48 @@ __global__ __launch_bounds__(256) void head_tile_fwd_kernel(HeadTileArgs a) {
     // wave wv owns the 16 classes [16 wv, 16 wv + 16) of the tile, against every row block
     const int cw = wv * 16;
     // small heads (few class tiles): the row blocks are spread over blockIdx.y as well (the W tile is then read once per row split)
-    for (int b0 = blockIdx.y * HT_RB; b0 < a.B; b0 += gridDim.y * HT_RB) {
+    // the embeddings of a row block are fetched into registers while the previous block is multiplied (they come from L2: every
+    // class tile reads the same B x D floats), and their inverse norms were taken once, ahead of the launch
+    constexpr int NE = HT_RF * HT_DMAX / 4 / 256;
+    ht_u32x4 ev[NE];
+    if ((int)(blockIdx.y * HT_RF) < a.B) ht_issue_e<NE, HT_RF>(a.emb, a.B, a.D, blockIdx.y * HT_RF, tid, ev);
+    for (int b0 = blockIdx.y * HT_RF; b0 < a.B; b0 += gridDim.y * HT_RF) {
         __syncthreads();                                          // previous block's Es / red readers are done
-        if (tid < HT_RB) lab_s[tid] = b0 + tid < a.B ? (int)a.labels[b0 + tid] : -1;
-        ht_load_e<HT_RB * HT_DMAX / 4 / 256>(a.emb, a.B, a.D, a.SE, b0, tid, Es);
-        __syncthreads();
-        {
-            const int r = tid & 63, q = tid >> 6;
-            float s = 0.f;
-            for (int k = q; k < a.D; k += 4) { const float v = Es[r * a.SE + k]; s += v * v; }
-            red[q * 64 + r] = s;
-            __syncthreads();
-            if (tid < 64) rinv_s[r] = 1.f / fmaxf(sqrtf(red[r] + red[64 + r] + red[128 + r] + red[192 + r]), 1e-12f);
-            __syncthreads();
+        if (tid < HT_RF) {
+            lab_s[tid] = b0 + tid < a.B ? (int)a.labels[b0 + tid] : -1;
+            rinv_s[tid] = b0 + tid < a.B ? a.rinv[b0 + tid] : 0.f;
         }
+        ht_commit_e<NE, HT_RF>(a.D, a.SE, tid, Es, ev);
+        __syncthreads();
+        if (b0 + (int)gridDim.y * HT_RF < a.B) ht_issue_e<NE, HT_RF>(a.emb, a.B, a.D, b0 + gridDim.y * HT_RF, tid, ev);
         // ---- cos tile: C[row = utterance][col = class]; A = E (lane: row li, k g), B = W (lane: k g, class li)
-        v4f acc[4];
+        constexpr int MI = HT_RF / 16;
+        v4f acc[MI];
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) acc[mi] = v4f{0.f, 0.f, 0.f, 0.f};
+        for (int mi = 0; mi < MI; ++mi) acc[mi] = v4f{0.f, 0.f, 0.f, 0.f};
         const float* wp = Ws + g * HT_SW + cw + li;               // banks g 2 + li: two-way at worst
         const float* ep = Es + li * a.SE + g;                     // banks li 2 + g: conflict-free
         const int se16 = 16 * a.SE;
         for (int k = 0; k < a.D; k += 16) {                       // four k-steps of operands in flight ahead of their MFMAs (D % 16 handled below)
-            float bv[4], av[4][4];
+            float bv[4], av[4][MI];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int kk = k + 4 * u < a.D ? k + 4 * u : 0;   // past D: re-read step 0 and multiply by zero
                 bv[u] = k + 4 * u < a.D ? wp[kk * HT_SW] : 0.f;
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) av[u][mi] = ep[mi * se16 + kk];
+                for (int mi = 0; mi < MI; ++mi) av[u][mi] = ep[mi * se16 + kk];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][mi], bv[u], acc[mi], 0, 0, 0);
+                for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][mi], bv[u], acc[mi], 0, 0, 0);
         }
         // ---- epilogue: lane holds rows mi 16 + g 4 + r, class cw + li
         const int c = c0 + cw + li;
         const bool cvalid = c < a.C;
         const float ci = cinv_s[cw + li];
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = mi * 16 + g * 4 + r;
@@ -205,27 +217,27 @@ __global__ __launch_bounds__(256) void head_tile_fwd_kernel(HeadTileArgs a) {
                 const float bc = row16_max(cv);
                 const float bi = -row16_max(cv == bc ? -(float)c : -INFINITY);     // smallest class index holding the maximum (exact below 2^24)
                 if (li == 0) {
-                    red[(0 * 4 + wv) * 64 + row] = m; red[(1 * 4 + wv) * 64 + row] = s; red[(2 * 4 + wv) * 64 + row] = so;
-                    red[(3 * 4 + wv) * 64 + row] = bc; red[(4 * 4 + wv) * 64 + row] = bi;
+                    red[(0 * 4 + wv) * HT_RF + row] = m; red[(1 * 4 + wv) * HT_RF + row] = s; red[(2 * 4 + wv) * HT_RF + row] = so;
+                    red[(3 * 4 + wv) * HT_RF + row] = bc; red[(4 * 4 + wv) * HT_RF + row] = bi;
                 }
             }
         }
         __syncthreads();
-        if (tid < 64 && b0 + tid < a.B) {                         // merge the four waves' 16-class partials (fixed order)
+        if (tid < HT_RF && b0 + tid < a.B) {                      // merge the four waves' 16-class partials (fixed order)
             const int row = tid;
-            float M = fmaxf(fmaxf(red[0 * 64 + row], red[1 * 64 + row]), fmaxf(red[2 * 64 + row], red[3 * 64 + row]));
+            float M = fmaxf(fmaxf(red[0 * HT_RF + row], red[1 * HT_RF + row]), fmaxf(red[2 * HT_RF + row], red[3 * HT_RF + row]));
             float S = 0.f, O = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                const float mw = red[(0 * 4 + w) * 64 + row];
-                S += mw == -INFINITY ? 0.f : red[(1 * 4 + w) * 64 + row] * expf(mw - M);
-                O += red[(2 * 4 + w) * 64 + row];
+                const float mw = red[(0 * 4 + w) * HT_RF + row];
+                S += mw == -INFINITY ? 0.f : red[(1 * 4 + w) * HT_RF + row] * expf(mw - M);
+                O += red[(2 * 4 + w) * HT_RF + row];
             }
             float BC = -INFINITY, BI = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {                           // waves hold ascending class ranges: strict > keeps the first maximum
-                const float v = red[(3 * 4 + w) * 64 + row];
-                if (v > BC) { BC = v; BI = red[(4 * 4 + w) * 64 + row]; }
+                const float v = red[(3 * 4 + w) * HT_RF + row];
+                if (v > BC) { BC = v; BI = red[(4 * 4 + w) * HT_RF + row]; }
             }
             const size_t o = (size_t)(b0 + row) * a.tiles + tile;
             const size_t st = (size_t)a.B * a.tiles;
@@ -529,7 +541,7 @@ extern "C" {
 size_t vp_cosine_aam_tiled_workspace_bytes(int B, int D, int C) {
     (void)D;
     const size_t tiles = (size_t)(C + HT_CT - 1) / HT_CT;
-    return vp_align_up(5 * (size_t)B * tiles * 4, 256) + vp_align_up((size_t)B * 4, 256);
+    return vp_align_up(5 * (size_t)B * tiles * 4, 256) + 2 * vp_align_up((size_t)B * 4, 256);       // partials, target logits, row inverse norms
 }
 
 int vp_cosine_aam_tiled_fwd(vp_ctx* ctx, const float* emb, const float* W, const int64_t* labels, int B, int D, int C, float margin,
@@ -546,18 +558,21 @@ int vp_cosine_aam_tiled_fwd(vp_ctx* ctx, const float* emb, const float* W, const
     a.part = (float*)ws;
     a.tgt = (float*)((char*)ws + vp_align_up(5 * (size_t)B * a.tiles * 4, 256));
     a.cinv = cinv;
+    float* rinv = (float*)((char*)a.tgt + vp_align_up((size_t)B * 4, 256));
+    { const int rc = vp_row_inv_norm(ctx, emb, B, D, D, 1e-12f, rinv, st); if (rc != VP_OK) return rc; }
+    a.rinv = rinv;
     a.B = B; a.D = D; a.C = C; a.SE = D + 2;
     a.cos_m = (float)cos((double)margin); a.sin_m = (float)sin((double)margin);
     a.th = (float)cos(M_PI - (double)margin); a.mmm = (float)(1.0 + cos(M_PI - (double)margin));
     a.scale = scale; a.easy = easy_margin; a.mt = ctx->margin_table;
-    const int smem = (D * HT_SW + HT_RB * (D + 2) + HT_CT + HT_RB + 5 * 4 * 64 + HT_RB) * 4;
+    const int smem = (D * HT_SW + HT_RF * (D + 2) + HT_CT + HT_RF + 5 * 4 * HT_RF + HT_RF) * 4;
     static bool attr_set = false;
     if (!attr_set) {
         VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(head_tile_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (HT_DMAX * HT_SW + HT_RB * (HT_DMAX + 2) + HT_CT + HT_RB + 5 * 4 * 64 + HT_RB) * 4));
+                                        (HT_DMAX * HT_SW + HT_RF * (HT_DMAX + 2) + HT_CT + HT_RF + 5 * 4 * HT_RF + HT_RF) * 4));
         attr_set = true;
     }
-    const int rblocks = (B + HT_RB - 1) / HT_RB;
+    const int rblocks = (B + HT_RF - 1) / HT_RF;
     int ysplit = 1;
     while (ysplit < rblocks && a.tiles * ysplit < 192) ++ysplit;
     hipLaunchKernelGGL(head_tile_fwd_kernel, dim3(a.tiles, ysplit), dim3(256), smem, st, a);
