@@ -176,6 +176,11 @@ int vp_conv256_select(int schedule);
  * (lengths=None, the only branch the shipped entry points reach, trainer.py:210). */
 int vp_moments_finalize(vp_ctx* ctx, const float* psum, const float* psumsq, const float* shift,
                         int B, int T, int C, float eps, int want_std, float* stats, vp_stream stream);
+/* The same from the fused sums of a TRAINING conv -- sums of z = ReLU(conv + bias), the layer's output being y = scale z + shift
+ * (batch-statistics BatchNorm): SEBlock's squeeze mean (ecapa_tdnn.py:66-71) and ASP's context statistics (pooling.py:97-104) without a
+ * pass over y. */
+int vp_moments_finalize_affine(vp_ctx* ctx, const float* psum, const float* psumsq, const float* scale, const float* shift,
+                               int B, int T, int C, float eps, int want_std, float* stats, vp_stream stream);
 
 /* small dense layer in exact f32 (f32 MFMA): out[M][N] = act(a[M][K] @ W + bias).
  * w_is_kn = 0: W given as [N][K];  1: W given as [K][N] (Paddle Linear / fc.py weight layout). */

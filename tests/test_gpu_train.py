@@ -1172,3 +1172,51 @@ def test_block_outputs_written_as_bf16_by_their_producer_change_nothing(N, amp, 
     print(f'[bf16 shadows] embeddings identical: {torch.equal(e0, e1)}; worst |gradient difference| {worst:.1e}')
     assert torch.equal(e0, e1)
     assert all(torch.equal(g0[k], g1[k]) for k in g0)
+
+
+def test_time_statistics_from_the_convs_fused_sums_stay_as_close_to_the_f32_step(N, monkeypatch):
+    """enable_amp only: SEBlock's squeeze mean (ecapa_tdnn.py:66-71) and ASP's context mean / std (pooling.py:97-104) of a TDNNBlock
+    output y = BN(z) come from the conv's fused per-utterance sums of z and the layer's scale / shift (vp_moments_finalize_affine)
+    instead of a pass over y (VPMI_NO_TSUMS=1 keeps the pass).  The sums are of the f32 accumulators, the pass reads the bf16-stored z:
+    the two differ by the storage rounding (1e-4 on a mean), which the chain of bf16 operand roundings behind it amplifies like any
+    other perturbation of a mixed-precision step.  Yardstick: the f32 engine's step on the same batch (exact statistics; it never
+    takes the shortcut: measured 3e-5 on its embeddings, too much for the parity instrument) -- the shortcut must be no further
+    from it than the pass is (25 % slack for the spread of that figure)."""
+    import ppvector
+    from ppvector.models.ecapa_tdnn import EcapaTdnn
+    from ppvector.train.ecapa_train import ecapa_forward_train
+    torch.manual_seed(5)
+    m0 = EcapaTdnn(80).cuda().train()
+    state = {k: v.clone() for k, v in m0.state_dict().items()}
+    B, T = 16, 298
+    x = torch.randn(B, T, 80, device='cuda')
+    g = torch.randn(B, 192, device='cuda')
+
+    def run(use_amp, no_tsums):
+        ppvector.set_train_amp(use_amp)
+        try:
+            if no_tsums:
+                monkeypatch.setenv('VPMI_NO_TSUMS', '1')
+            else:
+                monkeypatch.delenv('VPMI_NO_TSUMS', raising=False)
+            m0.load_state_dict(state)
+            for p in m0.parameters():
+                p.grad = None
+            emb = ecapa_forward_train(m0, x)
+            emb.backward(g)
+            torch.cuda.synchronize()
+            return emb.detach().clone(), {k: p.grad.clone() for k, p in m0.named_parameters()}
+        finally:
+            ppvector.set_train_amp(False)
+
+    def whole(a, b):
+        return (sum((a[k].double() - b[k].double()).pow(2).sum().item() for k in b) / sum(b[k].double().pow(2).sum().item() for k in b)) ** 0.5
+
+    ex, gx = run(False, False)
+    ex2, gx2 = run(False, True)
+    assert torch.equal(ex, ex2) and all(torch.equal(gx[k], gx2[k]) for k in gx), 'the f32 engine must not take the shortcut'
+    e0, g0 = run(True, True)
+    e1, g1 = run(True, False)
+    print(f'[fused time sums] vs the f32 step: embeddings rel-L2 pass {rel(e0, ex):.2e} / fused sums {rel(e1, ex):.2e}; whole-gradient '
+          f'rel-L2 pass {whole(g0, gx):.2e} / fused sums {whole(g1, gx):.2e}; fused sums vs pass: {rel(e1, e0):.2e} / {whole(g1, g0):.2e}')
+    assert rel(e1, ex) < 1.25 * rel(e0, ex) + 1e-3 and whole(g1, gx) < 1.25 * whole(g0, gx)

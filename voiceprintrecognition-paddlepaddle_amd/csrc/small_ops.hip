@@ -14,6 +14,7 @@ namespace {
 struct MomArgs {
     const float* psum; const float* psumsq; const float* shift; float* stats;
     int B, T, C, nseg, want_std; float eps;
+    const float* scale;              // NULL: the sums are of y - shift (inference: BN folded into the conv); else of z with y = scale z + shift
 };
 
 __global__ __launch_bounds__(256) void moments_kernel(MomArgs a) {
@@ -32,10 +33,11 @@ __global__ __launch_bounds__(256) void moments_kernel(MomArgs a) {
     const float invT = 1.f / (float)a.T;
     const float md = s1 * invT;
     const float sh = a.shift ? a.shift[c] : 0.f;
+    const float sc = a.scale ? a.scale[c] : 1.f;
     const int ld = a.want_std ? 2 * a.C : a.C;
-    a.stats[(size_t)b * ld + c] = sh + md;
+    a.stats[(size_t)b * ld + c] = sh + sc * md;
     if (a.want_std) {
-        const float var = s2 * invT - md * md;
+        const float var = (s2 * invT - md * md) * sc * sc;
         a.stats[(size_t)b * ld + a.C + c] = sqrtf(fmaxf(var, a.eps));
     }
 }
@@ -597,13 +599,28 @@ int vp_row_inv_norm(vp_ctx* ctx, const float* x, int rows, int D, int ld, float 
 
 extern "C" {
 
+// training: the conv's fused sums are of z = ReLU(conv + bias), the layer output is y = scale z + shift (batch-statistics BatchNorm):
+// stats[b] = [mean_t y | sqrt(max(var_t y, eps))] without a pass over y (SEBlock's squeeze, ecapa_tdnn.py:66-71; ASP's context, pooling.py:97-104)
+int vp_moments_finalize_affine(vp_ctx* ctx, const float* psum, const float* psumsq, const float* scale, const float* shift,
+                               int B, int T, int C, float eps, int want_std, float* stats, vp_stream stream) {
+    if (!ctx || !psum || !stats || !scale || !shift || (want_std && !psumsq) || B <= 0 || T <= 0 || C <= 0)
+        VP_FAIL(ctx, VP_EINVAL, "moments: bad arguments");
+    if (B > 65535) VP_FAIL(ctx, VP_EINVAL, "moments: batch too large");
+    MomArgs a;
+    a.psum = psum; a.psumsq = psumsq; a.shift = shift; a.scale = scale; a.stats = stats; a.B = B; a.T = T; a.C = C;
+    a.nseg = vp_conv1d_nseg(T); a.want_std = want_std; a.eps = eps;
+    hipLaunchKernelGGL(moments_kernel, dim3((C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, a);
+    VP_LAUNCH_CHECK(ctx, "moments");
+    return VP_OK;
+}
+
 int vp_moments_finalize(vp_ctx* ctx, const float* psum, const float* psumsq, const float* shift,
                         int B, int T, int C, float eps, int want_std, float* stats, vp_stream stream) {
     if (!ctx || !psum || !stats || (want_std && !psumsq) || B <= 0 || T <= 0 || C <= 0)
         VP_FAIL(ctx, VP_EINVAL, "moments: bad arguments");
     if (B > 65535) VP_FAIL(ctx, VP_EINVAL, "moments: batch too large");
     MomArgs a;
-    a.psum = psum; a.psumsq = psumsq; a.shift = shift; a.stats = stats; a.B = B; a.T = T; a.C = C;
+    a.psum = psum; a.psumsq = psumsq; a.shift = shift; a.scale = nullptr; a.stats = stats; a.B = B; a.T = T; a.C = C;
     a.nseg = vp_conv1d_nseg(T); a.want_std = want_std; a.eps = eps;
     hipLaunchKernelGGL(moments_kernel, dim3((C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, a);
     VP_LAUNCH_CHECK(ctx, "moments");

@@ -13,11 +13,15 @@ from ppvector.train.segments import cut
 from ppvector.train.tdnn_train import asp_forward
 
 
-def tdnn_block(blk, x, B, T):
-    """TDNNBlock (models/utils.py:122-148): BN(ReLU(Conv1d 'same' reflect))."""
+def tdnn_block(blk, x, B, T, want_tsums=False):
+    """TDNNBlock (models/utils.py:122-148): BN(ReLU(Conv1d 'same' reflect)).  want_tsums: the consumer takes time statistics of the
+    output (SE squeeze): the conv's fused per-utterance sums travel with the tensor instead of a pass over it."""
     conv, norm = blk.conv.conv, blk.norm.norm
-    return ConvBlock.apply(x, conv.weight, conv.bias, None, norm.weight, norm.bias, norm._mean, norm._variance,
-                           dict(B=B, T=T, dilation=blk.conv.dilation, pad='reflect', relu=True, momentum=norm.momentum, eps=norm.eps))
+    cfg = dict(B=B, T=T, dilation=blk.conv.dilation, pad='reflect', relu=True, momentum=norm.momentum, eps=norm.eps, want_tsums=want_tsums)
+    y = ConvBlock.apply(x, conv.weight, conv.bias, None, norm.weight, norm.bias, norm._mean, norm._variance, cfg)
+    if cfg.get('_tsums') is not None:
+        y._vp_tsums = cfg.pop('_tsums')
+    return y
 
 
 def res2net_block(r2, x, B, T):
@@ -49,7 +53,7 @@ def se_res2net_block(blk, x, B, T, shadow=None):
                                       dict(B=B, T=T, dilation=blk.tdnn1.conv.dilation, pad='reflect', relu=True,
                                            momentum=norm.momentum, eps=norm.eps))
     h = res2net_block(blk.res2net_block, h, B, T)
-    h = tdnn_block(blk.tdnn2, h, B, T)
+    h = tdnn_block(blk.tdnn2, h, B, T, want_tsums=True)
     se = blk.se_block                                           # squeeze, two dense layers, gate, + residual: one tape entry
     out = SEBlockFn.apply(h, residual, se.conv1.conv.weight, se.conv1.conv.bias, se.conv2.conv.weight, se.conv2.conv.bias, B, T, shadow)
     if shadow is not None:
@@ -78,8 +82,11 @@ def ecapa_forward_train(m, feats):
         outs = list(cut(*outs))
         x = outs[-1]
     conv, norm = m.mfa.conv.conv, m.mfa.norm.norm
-    x = CatConvBlock.apply(dict(B=B, T=T, dilation=m.mfa.conv.dilation, pad='reflect', relu=True, momentum=norm.momentum, eps=norm.eps, xcat=xcat),
-                           conv.weight, conv.bias, norm.weight, norm.bias, norm._mean, norm._variance, *outs)
+    cfg = dict(B=B, T=T, dilation=m.mfa.conv.dilation, pad='reflect', relu=True, momentum=norm.momentum, eps=norm.eps, xcat=xcat,
+               want_tsums=True)                                  # ASP's context statistics come from the MFA conv's fused sums
+    x = CatConvBlock.apply(cfg, conv.weight, conv.bias, norm.weight, norm.bias, norm._mean, norm._variance, *outs)
+    if cfg.get('_tsums') is not None:
+        x._vp_tsums = cfg.pop('_tsums')
     p = asp_forward(m.asp, x, B, T)
     n = m.asp_bn.norm
     p = BNRows.apply(p, n.weight, n.bias, n._mean, n._variance, n.momentum, n.eps)

@@ -167,6 +167,9 @@ class ConvBlock(torch.autograd.Function):
             yt = torch.empty_like(y)
             _chk(lib.vp_act_f32(hctx, tanh, y.data_ptr(), y.numel(), yt.data_ptr(), N.stream_ptr()), hctx)
             y = yt
+        if bn and not tanh and cfg.get('want_tsums') and ps is not None and ps.shape[0] > 1:
+            # the conv's fused per-(tile, utterance) sums of z + this layer's affine: a consumer's time statistics of y need no pass over y
+            cfg['_tsums'] = (ps, pq, scale, shift, B, T_out)
         ctx.save_for_backward(x, weight, z, mean, invstd, gamma, y if tanh else None, w2)
         ctx.geom = (B, T_in, T_out, Cin, Cout, KW, dil, pad, pad_left, relu, bn, tanh, bias is not None, rowbias is not None)
         ctx.wide = wide
@@ -519,6 +522,25 @@ class _Tape:
         self.saved_tensors = tensors
 
 
+def _time_stats(x, B, T, eps, want_std):
+    """[mean | std] (or the mean alone) over time of x (B*T, C): from the producing conv's fused sums when it left them on the tensor
+    (`_vp_tsums`: ConvBlock with cfg['want_tsums']), else by a pass over x."""
+    lib, hctx = N.lib(), N.ctx(x.device)
+    Cc = x.shape[1]
+    ts = getattr(x, '_vp_tsums', None)
+    # (mixed precision only: the f32 engine is the parity instrument and takes its statistics from the tensor itself -- the
+    # E[z^2] - E[z]^2 form of the fused sums costs it 3e-5 on the embeddings)
+    if ts is not None and ppvector.get_train_amp() and ts[4] == B and ts[5] == T and ts[0].shape[1] == Cc and not os.environ.get('VPMI_NO_TSUMS'):
+        ps, pq, scale, shift = ts[:4]
+        stats = torch.empty((B, 2 * Cc if want_std else Cc), dtype=torch.float32, device=x.device)
+        _chk(lib.vp_moments_finalize_affine(hctx, ps.data_ptr(), pq.data_ptr(), scale.data_ptr(), shift.data_ptr(), B, T, Cc, eps,
+                                            int(want_std), stats.data_ptr(), N.stream_ptr()), hctx)
+        return stats
+    stats = torch.empty((B, 2 * Cc), dtype=torch.float32, device=x.device)
+    _chk(lib.vp_time_stats_f32(hctx, x.data_ptr(), Cc, B, T, Cc, eps, 0, stats.data_ptr(), N.stream_ptr()), hctx)
+    return stats if want_std else stats[:, :Cc].contiguous()
+
+
 class SEBlockFn(torch.autograd.Function):
     """SEBlock (ecapa_tdnn.py:50-82, lengths=None) and the block residual (:139-141) as one tape entry:
     out = h * sigmoid(W2 relu(W1 mean_t(h) + b1) + b2) + res.  The two dense layers are ConvBlocks at T = 1 (same kernels, same
@@ -529,11 +551,10 @@ class SEBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, res, w1, b1, w2, b2, B, T, shadow=None):
         lib, hctx = N.lib(), N.ctx(h.device)
-        h, res = _f32c(h), _f32c(res)
+        res = _f32c(res)
         Cc = h.shape[1]
-        stats = torch.empty((B, 2 * Cc), dtype=torch.float32, device=h.device)
-        _chk(lib.vp_time_stats_f32(hctx, h.data_ptr(), Cc, B, T, Cc, 1e-12, 0, stats.data_ptr(), N.stream_ptr()), hctx)
-        mean = stats[:, :Cc].contiguous()
+        h = _f32c(h)                                          # (a contiguous tensor comes back as itself, with what its producer hung on it)
+        mean = _time_stats(h, B, T, 1e-12, False)
         needs = (True,) * 9
         t1, t2 = _Tape(needs), _Tape(needs)
         a = ConvBlock.forward(t1, mean, w1, b1, None, None, None, None, None, dict(B=B, T=1, relu=True))
@@ -635,15 +656,14 @@ class AspFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, gamma, beta, run_mean, run_var, w2, b2, cfg):
         lib, hctx = N.lib(), N.ctx(x.device)
-        x = _f32c(x)
+        x = _f32c(x)                                          # (may carry the producing conv's fused time sums)
         B, T, gc = cfg['B'], cfg['T'], cfg['global_context']
         Cc = x.shape[1]
         needs = (True,) * 9
         t0, t1, t2 = _Tape(needs), _Tape(needs), _Tape(needs)
         stats = rowbias = None
         if gc:
-            stats = torch.empty((B, 2 * Cc), dtype=torch.float32, device=x.device)
-            _chk(lib.vp_time_stats_f32(hctx, x.data_ptr(), Cc, B, T, Cc, 1e-12, 0, stats.data_ptr(), N.stream_ptr()), hctx)
+            stats = _time_stats(x, B, T, 1e-12, True)
             rowbias = ConvBlock.forward(t0, stats, w[:, Cc:].contiguous(), None, None, None, None, None, None, dict(B=B, T=1))
         h = ConvBlock.forward(t1, x, w[:, :Cc].contiguous() if gc else w, bias, rowbias, gamma, beta, run_mean, run_var,
                               dict(B=B, T=T, relu=True, tanh=True, momentum=cfg['momentum'], eps=cfg['eps']))

@@ -274,6 +274,12 @@ class PPVectorTrainer(object):
             self.scheduler.step()
             if self.margin_scheduler:
                 self.margin_scheduler.step()
+        # the fused Res2Net training kernels meet at an in-kernel grid barrier; it gives up (and says so here) instead of hanging
+        # the device if its workgroups were not co-resident -- e.g. two training processes sharing one GPU
+        from ppvector import _native as N
+        if torch.cuda.is_available() and N.lib().vp_grid_barrier_status(N.ctx(torch.device('cuda', torch.cuda.current_device()))) > 0:
+            raise N.VpmiError('a grid barrier of the fused Res2Net training kernels timed out during this epoch (is another process '
+                              'using this GPU?); set VPMI_RES2_TRAIN_UNFUSED=1 to run the per-chunk kernels')
 
     def train(self, save_model_path='models/', log_dir='log/', resume_model=None, pretrained_model=None, do_eval=True):
         torch.manual_seed(1000)
