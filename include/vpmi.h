@@ -706,6 +706,15 @@ typedef struct {
  * x + c * x_bstride and dz + c * dz_bstride (bf16 elements), writes dW + c * Cout * Cin * KW; ws = nbatch x vp_conv1d_wgrad_workspace_bytes(d). */
 int vp_conv1d_wgrad_bf16_oik_batched(vp_ctx* ctx, const vp_conv1d_desc* d, const void* dz, int lddz, float* dW, int nbatch, long long x_bstride,
                                      long long dz_bstride, void* ws, size_t ws_bytes, vp_stream stream);
+/* SEBlock's two dense layers in training (ecapa_tdnn.py:50-82 with lengths=None; csrc/se_train.hip): mean (B, C) -> a = ReLU(W1 mean + b1) (B, H)
+ * -> s = sigmoid(W2 a + b2) (B, C), W1 (H, C) and W2 (C, H) as the model's Conv1D weights; one launch forward, two backward (d mean and the
+ * four parameter gradients from d s).  round_bf16 = enable_amp (operands rounded where the matrix cores round them).  C, H <= 1024. */
+int vp_se_dense_train_fwd(vp_ctx* ctx, const float* mean, const float* w1, const float* b1, const float* w2, const float* b2, int B, int C,
+                          int H, int round_bf16, float* a, float* s, vp_stream stream);
+size_t vp_se_dense_train_bwd_workspace_bytes(int B, int C, int H);
+int vp_se_dense_train_bwd(vp_ctx* ctx, const float* ds, const float* mean, const float* a, const float* s, const float* w1, const float* w2,
+                          int B, int C, int H, int round_bf16, float* dmean, float* dw1, float* db1, float* dw2, float* db2, void* ws,
+                          size_t ws_bytes, vp_stream stream);
 size_t vp_res2_train_workspace_bytes(int B, int scale);
 int vp_res2_train_fwd(vp_ctx* ctx, const vp_res2_train_desc* d, void* ws, size_t ws_bytes, vp_stream stream);
 int vp_res2_train_bwd(vp_ctx* ctx, const vp_res2_train_desc* d, void* ws, size_t ws_bytes, vp_stream stream);

@@ -1220,3 +1220,51 @@ def test_time_statistics_from_the_convs_fused_sums_stay_as_close_to_the_f32_step
     print(f'[fused time sums] vs the f32 step: embeddings rel-L2 pass {rel(e0, ex):.2e} / fused sums {rel(e1, ex):.2e}; whole-gradient '
           f'rel-L2 pass {whole(g0, gx):.2e} / fused sums {whole(g1, gx):.2e}; fused sums vs pass: {rel(e1, e0):.2e} / {whole(g1, g0):.2e}')
     assert rel(e1, ex) < 1.25 * rel(e0, ex) + 1e-3 and whole(g1, gx) < 1.25 * whole(g0, gx)
+
+
+@pytest.mark.parametrize('B,T,C,H', [(5, 40, 512, 128), (32, 120, 256, 64), (3, 33, 64, 16)])
+def test_se_block_with_its_dense_layers_in_one_launch_vs_float64_autograd(N, monkeypatch, B, T, C, H):
+    """SEBlock + block residual (ecapa_tdnn.py:50-82, 139-141) as SEBlockFn with the two dense layers in csrc/se_train.hip (one launch
+    forward, two backward) against float64 autograd of the same formulas, f32 engine: output 2e-6, gradients 2e-5; and against the
+    previous form of the layers (two 1x1 ConvBlocks, VPMI_SE_DENSE_UNFUSED=1) under enable_amp: same operand roundings, 2e-3."""
+    import ppvector
+    from ppvector.train.functions import SEBlockFn
+    g = torch.Generator().manual_seed(B * 100 + C)
+    h0 = torch.randn(B * T, C, generator=g).cuda()
+    r0 = torch.randn(B * T, C, generator=g).cuda()
+    w1 = (torch.randn(H, C, 1, generator=g) / C ** 0.5).cuda()
+    b1 = (torch.randn(H, generator=g) * 0.1).cuda()
+    w2 = (torch.randn(C, H, 1, generator=g) / H ** 0.5).cuda()
+    b2 = (torch.randn(C, generator=g) * 0.1).cuda()
+    dout = torch.randn(B * T, C, generator=g).cuda()
+
+    def run():
+        ts = [t.clone().requires_grad_() for t in (h0, r0, w1, b1, w2, b2)]
+        out = SEBlockFn.apply(ts[0], ts[1], ts[2], ts[3], ts[4], ts[5], B, T)
+        out.backward(dout)
+        torch.cuda.synchronize()
+        return [out.detach()] + [t.grad for t in ts]
+
+    got = run()
+    hd, rd, w1d, b1d, w2d, b2d = (t.double().clone().requires_grad_() for t in (h0, r0, w1, b1, w2, b2))
+    mean = hd.reshape(B, T, C).mean(1)
+    a = torch.relu(mean @ w1d[:, :, 0].t() + b1d)
+    s = torch.sigmoid(a @ w2d[:, :, 0].t() + b2d)
+    ref_out = (hd.reshape(B, T, C) * s[:, None, :]).reshape(B * T, C) + rd
+    ref_out.backward(dout.double())
+    ref = [ref_out.detach(), hd.grad, rd.grad, w1d.grad, b1d.grad, w2d.grad, b2d.grad]
+    names = ['out', 'd h', 'd res', 'd W1', 'd b1', 'd W2', 'd b2']
+    errs = {n: rel(x, y) for n, x, y in zip(names, got, ref)}
+    print(f'[se dense B={B} T={T} C={C} H={H}] f32 vs float64: ' + ', '.join(f'{k} {v:.1e}' for k, v in errs.items()))
+    assert errs['out'] < 2e-6 and all(v < 2e-5 for v in errs.values()), errs
+    ppvector.set_train_amp(True)
+    try:
+        fused = run()
+        monkeypatch.setenv('VPMI_SE_DENSE_UNFUSED', '1')
+        unfused = run()
+    finally:
+        ppvector.set_train_amp(False)
+        monkeypatch.delenv('VPMI_SE_DENSE_UNFUSED', raising=False)
+    errs = {n: rel(x, y) for n, x, y in zip(names, fused, unfused)}
+    print(f'[se dense B={B} T={T} C={C} H={H}] enable_amp, one launch vs two 1x1 ConvBlocks: ' + ', '.join(f'{k} {v:.1e}' for k, v in errs.items()))
+    assert all(v < 2e-3 for v in errs.values()), errs

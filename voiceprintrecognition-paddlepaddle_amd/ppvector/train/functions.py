@@ -557,8 +557,18 @@ class SEBlockFn(torch.autograd.Function):
         mean = _time_stats(h, B, T, 1e-12, False)
         needs = (True,) * 9
         t1, t2 = _Tape(needs), _Tape(needs)
-        a = ConvBlock.forward(t1, mean, w1, b1, None, None, None, None, None, dict(B=B, T=1, relu=True))
-        s = ConvBlock.forward(t2, a, w2, b2, None, None, None, None, None, dict(B=B, T=1, sigmoid=True))
+        H = w1.shape[0]
+        fused = (not os.environ.get('VPMI_SE_DENSE_UNFUSED') and tuple(w1.shape) == (H, Cc, 1) and tuple(w2.shape) == (Cc, H, 1)
+                 and Cc <= 1024 and H <= 1024 and b1 is not None and b2 is not None
+                 and all(t.dtype == torch.float32 and t.is_contiguous() for t in (w1, b1, w2, b2)))
+        if fused:                                    # the two dense layers: one launch (csrc/se_train.hip) instead of two GEMM launches
+            a = torch.empty((B, H), dtype=torch.float32, device=h.device)
+            s = torch.empty((B, Cc), dtype=torch.float32, device=h.device)
+            _chk(lib.vp_se_dense_train_fwd(hctx, mean.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), B, Cc, H,
+                                           int(ppvector.get_train_amp()), a.data_ptr(), s.data_ptr(), N.stream_ptr()), hctx)
+        else:
+            a = ConvBlock.forward(t1, mean, w1, b1, None, None, None, None, None, dict(B=B, T=1, relu=True))
+            s = ConvBlock.forward(t2, a, w2, b2, None, None, None, None, None, dict(B=B, T=1, sigmoid=True))
         out = torch.empty_like(h)
         if shadow is not None:                       # (B*T, Cc) bf16 view, unit column stride: the block output as the next GEMMs read it
             _chk(lib.vp_se_scale_residual_shadow(hctx, h.data_ptr(), Cc, 0, s.data_ptr(), res.data_ptr(), Cc, 0, out.data_ptr(), Cc, 0,
@@ -566,9 +576,13 @@ class SEBlockFn(torch.autograd.Function):
         else:
             _chk(lib.vp_se_scale_residual(hctx, N.VP_F32, h.data_ptr(), Cc, 0, s.data_ptr(), res.data_ptr(), Cc, 0, out.data_ptr(), Cc, 0,
                                           B, T, Cc, N.stream_ptr()), hctx)
-        ctx.save_for_backward(h, s, *t1.saved_tensors, *t2.saved_tensors)
-        ctx.n1 = len(t1.saved_tensors)
-        ctx.geoms = (B, T, t1.geom, t2.geom)
+        if fused:
+            ctx.save_for_backward(h, s, mean, a, w1, w2)
+            ctx.n1, ctx.geoms = -1, (B, T, int(ppvector.get_train_amp()), None)
+        else:
+            ctx.save_for_backward(h, s, *t1.saved_tensors, *t2.saved_tensors)
+            ctx.n1 = len(t1.saved_tensors)
+            ctx.geoms = (B, T, t1.geom, t2.geom)
         return out
 
     @staticmethod
@@ -581,6 +595,20 @@ class SEBlockFn(torch.autograd.Function):
         Cc = h.shape[1]
         ds = torch.empty_like(s)
         _chk(lib.vp_utt_dot_f32(hctx, dout.data_ptr(), h.data_ptr(), B, T, Cc, ds.data_ptr(), N.stream_ptr()), hctx)
+        if ctx.n1 < 0:                               # the fused dense layers: d mean and the four parameter gradients in two launches
+            mean, a, w1, w2 = saved[2:6]
+            H = w1.shape[0]
+            dm = torch.empty_like(mean)
+            dw1, dw2 = torch.empty_like(w1), torch.empty_like(w2)
+            db1 = torch.empty(H, dtype=torch.float32, device=h.device)
+            db2 = torch.empty(Cc, dtype=torch.float32, device=h.device)
+            ws = _bytes(lib.vp_se_dense_train_bwd_workspace_bytes(B, Cc, H), h.device)
+            _chk(lib.vp_se_dense_train_bwd(hctx, ds.data_ptr(), mean.data_ptr(), a.data_ptr(), s.data_ptr(), w1.data_ptr(), w2.data_ptr(),
+                                           B, Cc, H, g1, dm.data_ptr(), dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), N.stream_ptr()), hctx)
+            dh = torch.empty_like(h)
+            _chk(lib.vp_scale_shift_rows_f32(hctx, dout.data_ptr(), s.data_ptr(), dm.data_ptr(), B, T, Cc, dh.data_ptr(), N.stream_ptr()), hctx)
+            return dh, dout, dw1, db1, dw2, db2, None, None, None
         needs = (True,) * 9
         t1, t2 = _Tape(needs), _Tape(needs)
         t1.saved_tensors, t1.geom = saved[2:2 + ctx.n1], g1
