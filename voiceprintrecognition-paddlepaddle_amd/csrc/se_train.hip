@@ -23,32 +23,55 @@ struct SeTrainArgs {
     int B, C, H, rnd;
 };
 
+// out[o] = sum_k W[o][k] x[k] for o < N, W output-major (rows of K floats), x in LDS.  LPO lanes share an output (each takes float4 columns
+// j, j + LPO, ...), 1024 / LPO outputs per pass, every lane's loads of a pass issued before the first is used: the first version gave a
+// wave one output at a time -- 32 dependent global round trips per wave for the 512 outputs of the second layer, 66 us per launch.
+template <int LPO>
+__device__ __forceinline__ void st_matvec(const float* __restrict__ W, int K, int N, const float* x, int rnd, float* out_s) {
+    const int tid = threadIdx.x, j = tid % LPO, og = tid / LPO;
+    constexpr int OPP = ST_THREADS / LPO;                      // outputs per pass
+    const int kv = K >> 2;                                      // float4 columns (K % 4 == 0: host-checked)
+    for (int o0 = 0; o0 < N; o0 += OPP) {
+        const int o = o0 + og;
+        float acc = 0.f;
+        if (o < N) {
+            const float4* w = reinterpret_cast<const float4*>(W + (size_t)o * K);
+            for (int c0 = j; c0 < kv; c0 += 8 * LPO) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = c0 + u * LPO < kv ? w[c0 + u * LPO] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = 4 * min(c0 + u * LPO, kv - 1);
+                    acc += st_rnd(v[u].x, rnd) * x[k] + st_rnd(v[u].y, rnd) * x[k + 1] + st_rnd(v[u].z, rnd) * x[k + 2] + st_rnd(v[u].w, rnd) * x[k + 3];
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < LPO; m <<= 1) acc += __shfl_xor(acc, m);
+        if (j == 0 && o < N) out_s[o] = acc;
+    }
+}
+
 __global__ __launch_bounds__(ST_THREADS) void se_dense_fwd_kernel(SeTrainArgs p) {
-    extern __shared__ float sm[];        // mean[C] | a[H]
+    extern __shared__ float sm[];        // mean[C] | a[H] | z[max(C, H)]
     float* mean_s = sm;
     float* a_s = sm + p.C;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = ST_THREADS / 64;
+    float* z_s = a_s + p.H;
+    const int b = blockIdx.x, tid = threadIdx.x;
     for (int c = tid; c < p.C; c += ST_THREADS) mean_s[c] = st_rnd(p.mean[(size_t)b * p.C + c], p.rnd);
     __syncthreads();
-    for (int o = wv; o < p.H; o += nw) {                       // a wave per output row: 256 contiguous bytes of W1 per load
-        const float* w = p.w1 + (size_t)o * p.C;
-        float acc = 0.f;
-        for (int k = lane; k < p.C; k += 64) acc += st_rnd(w[k], p.rnd) * mean_s[k];
-        acc = vp_wave_sum(acc);
-        if (lane == 0) {
-            const float v = fmaxf(acc + p.b1[o], 0.f);
-            p.a[(size_t)b * p.H + o] = v;
-            a_s[o] = st_rnd(v, p.rnd);
-        }
+    st_matvec<16>(p.w1, p.C, p.H, mean_s, p.rnd, z_s);
+    __syncthreads();
+    for (int o = tid; o < p.H; o += ST_THREADS) {
+        const float v = fmaxf(z_s[o] + p.b1[o], 0.f);
+        p.a[(size_t)b * p.H + o] = v;
+        a_s[o] = st_rnd(v, p.rnd);
     }
     __syncthreads();
-    for (int o = wv; o < p.C; o += nw) {
-        const float* w = p.w2 + (size_t)o * p.H;
-        float acc = 0.f;
-        for (int k = lane; k < p.H; k += 64) acc += st_rnd(w[k], p.rnd) * a_s[k];
-        acc = vp_wave_sum(acc);
-        if (lane == 0) p.s[(size_t)b * p.C + o] = 1.f / (1.f + __expf(-(acc + p.b2[o])));
-    }
+    st_matvec<4>(p.w2, p.H, p.C, a_s, p.rnd, z_s);
+    __syncthreads();
+    for (int o = tid; o < p.C; o += ST_THREADS) p.s[(size_t)b * p.C + o] = 1.f / (1.f + __expf(-(z_s[o] + p.b2[o])));
 }
 
 // per utterance: d z2 = d s * s (1 - s);  d a = W2^T d z2;  d z1 = d a [a > 0];  d mean = W1^T d z1
@@ -136,11 +159,11 @@ extern "C" {
 int vp_se_dense_train_fwd(vp_ctx* ctx, const float* mean, const float* w1, const float* b1, const float* w2, const float* b2, int B, int C,
                           int H, int round_bf16, float* a, float* s, vp_stream stream) {
     if (!ctx || !mean || !w1 || !b1 || !w2 || !b2 || !a || !s || B <= 0) VP_FAIL(ctx, VP_EINVAL, "se_dense_train_fwd: bad arguments");
-    if (C < 1 || H < 1 || C > 1024 || H > 1024) return VP_EUNSUP;
+    if (C < 4 || H < 4 || C > 1024 || H > 1024 || (C | H) & 3) return VP_EUNSUP;
     SeTrainArgs p;
     memset(&p, 0, sizeof(p));
     p.mean = mean; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.a = a; p.s = s; p.B = B; p.C = C; p.H = H; p.rnd = round_bf16;
-    hipLaunchKernelGGL(se_dense_fwd_kernel, dim3(B), dim3(ST_THREADS), (size_t)(C + H) * sizeof(float), (hipStream_t)stream, p);
+    hipLaunchKernelGGL(se_dense_fwd_kernel, dim3(B), dim3(ST_THREADS), (size_t)(C + H + (C > H ? C : H)) * sizeof(float), (hipStream_t)stream, p);
     VP_LAUNCH_CHECK(ctx, "se_dense_fwd");
     return VP_OK;
 }

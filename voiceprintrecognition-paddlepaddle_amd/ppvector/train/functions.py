@@ -559,7 +559,7 @@ class SEBlockFn(torch.autograd.Function):
         t1, t2 = _Tape(needs), _Tape(needs)
         H = w1.shape[0]
         fused = (not os.environ.get('VPMI_SE_DENSE_UNFUSED') and tuple(w1.shape) == (H, Cc, 1) and tuple(w2.shape) == (Cc, H, 1)
-                 and Cc <= 1024 and H <= 1024 and b1 is not None and b2 is not None
+                 and Cc <= 1024 and H <= 1024 and Cc % 4 == 0 and H % 4 == 0 and b1 is not None and b2 is not None
                  and all(t.dtype == torch.float32 and t.is_contiguous() for t in (w1, b1, w2, b2)))
         if fused:                                    # the two dense layers: one launch (csrc/se_train.hip) instead of two GEMM launches
             a = torch.empty((B, H), dtype=torch.float32, device=h.device)
