@@ -272,6 +272,122 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_amp_kernel(WgradArgs a) {
         }
 }
 
+// The same contraction for a NARROW layer: N <= 64 outputs x K <= 256 k-columns (the Res2Net chunk convs: 64 x 192), bf16 operands in
+// memory.  The square 128 x 128 tile above spends 63 % of its MFMAs and LDS traffic on rows / columns that do not exist there (7 convs x
+// 3 blocks per step: 0.36 ms at B = 256); here the four waves split the k-columns (64 each) and share all 64 outputs.
+// LDS: 2 stages x (dz^T 64 x 128 B | x^T 256 x 128 B).  1-D convs, stride 1, T_in == T_out (host-checked).
+__global__ __launch_bounds__(256, 2) void conv_wgrad_n64_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char wsm[];
+    constexpr int STAGE = (64 + 256) * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int zb = blockIdx.z / a.splits, sp = blockIdx.z - zb * a.splits;
+    const int m_begin = sp * a.rows_per_split;
+    const int m_end = min(a.M, m_begin + a.rows_per_split);
+    const int cg = tid & 31, rg = tid >> 5;
+    const bf16_t* __restrict__ gdz = reinterpret_cast<const bf16_t*>(a.dz) + zb * a.dzb;
+    const bf16_t* __restrict__ gx = reinterpret_cast<const bf16_t*>(a.x) + zb * a.xb;
+    const bool nvalid = cg < 16 && 4 * cg < a.N;
+    int cc[2], tapoff[2];
+    bool kvalid[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int kcol = 128 * u + 4 * cg;
+        kvalid[u] = kcol < a.K;
+        const int j = kvalid[u] ? kcol / a.Cin : 0;
+        cc[u] = kvalid[u] ? kcol - j * a.Cin : 0;
+        tapoff[u] = j * a.dilation - a.pad_left;
+    }
+    uint2 rdz[8], rx[2][8];
+    auto gload = [&](int mbase) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int m = mbase + 8 * rg + r;
+            rdz[r] = uint2{0u, 0u}; rx[0][r] = uint2{0u, 0u}; rx[1][r] = uint2{0u, 0u};
+            if (m >= m_end) continue;
+            if (nvalid) rdz[r] = *reinterpret_cast<const uint2*>(gdz + (size_t)m * a.lddz + 4 * cg);
+            const int b = m / a.T_out, t = m - b * a.T_out;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (!kvalid[u]) continue;
+                int ts = t + tapoff[u];
+                bool ok = true;
+                if (a.pad_mode == VP_PAD_REFLECT) {
+                    ts = ts < 0 ? -ts : ts;
+                    ts = ts >= a.T_in ? 2 * (a.T_in - 1) - ts : ts;
+                } else {
+                    ok = ts >= 0 && ts < a.T_in;
+                }
+                if (ok) rx[u][r] = *reinterpret_cast<const uint2*>(gx + ((size_t)b * a.T_in + ts) * a.ldx + a.xoff + cc[u]);
+            }
+        }
+    };
+    auto put = [&](char* base, int R, int e, const uint2 (&v)[8]) {
+        u16x8 o;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const unsigned w = e < 2 ? v[r].x : v[r].y;
+            o[r] = (unsigned short)((e & 1) ? (w >> 16) : (w & 0xffffu));
+        }
+        *reinterpret_cast<u16x8*>(base + R * 128 + ((rg ^ wa_L(R)) << 4)) = o;
+    };
+    auto swrite = [&](int s) {
+        char* dzs = wsm + s * STAGE;
+        char* xs = dzs + 64 * 128;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (cg < 16) put(dzs, 4 * cg + e, e, rdz);
+            put(xs, 4 * cg + e, e, rx[0]);
+            put(xs, 128 + 4 * cg + e, e, rx[1]);
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gload(m_begin);
+    int s = 0;
+    for (int mb = m_begin; mb < m_end; mb += WA_RC) {
+        swrite(s);
+        __syncthreads();
+        gload(mb + WA_RC);
+        const char* dzs = wsm + s * STAGE;
+        const char* xs = dzs + 64 * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], bf[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int R = p * 16 + i;
+                af[p] = *reinterpret_cast<const bf16x8*>(dzs + R * 128 + (((ks * 4 + g) ^ wa_L(R)) << 4));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int R = wv * 64 + q * 16 + i;
+                bf[q] = *reinterpret_cast<const bf16x8*>(xs + R * 128 + (((ks * 4 + g) ^ wa_L(R)) << 4));
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[p], bf[q], acc[p][q], 0, 0, 0);
+        }
+        s ^= 1;
+    }
+    float* out = a.part + (size_t)blockIdx.z * a.N * a.K;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = wv * 64 + q * 16 + i;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = p * 16 + g * 4 + r;
+                if (n < a.N && col < a.K) out[(size_t)n * a.K + col] = acc[p][q][r];
+            }
+        }
+}
+
 // out[i] = sum_k part[k][i]: 16 outputs x 16 partial-lanes per workgroup, fixed order (one thread walking all S partials
 // serially took 33 us per call -- 3.6 ms of a 39 ms training step over ~110 calls)
 // (KW > 1: the weight gradient leaves in the model's (Cout, Cin, KW) layout: partial index (o, tap, c) -> (o, c, tap))
@@ -1062,7 +1178,15 @@ static int wgrad_impl(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int
             attr_set = true;
         }
         const dim3 grid((K + WA_T - 1) / WA_T, (d->Cout + WA_T - 1) / WA_T, S * nbatch);
-        if (bf_in) hipLaunchKernelGGL(conv_wgrad_amp_kernel<true>, grid, dim3(256), smem, st, a);
+        if (bf_in && d->Cout <= 64 && K <= 256 && K > 128 && !two_d && d->stride == 1 && d->T_in == d->T_out) {      // narrow layer: its own tile shape
+            constexpr int smem64 = 2 * (64 + 256) * 128;
+            static bool attr64 = false;
+            if (!attr64) {
+                VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_n64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem64));
+                attr64 = true;
+            }
+            hipLaunchKernelGGL(conv_wgrad_n64_kernel, dim3(1, 1, S * nbatch), dim3(256), smem64, st, a);
+        } else if (bf_in) hipLaunchKernelGGL(conv_wgrad_amp_kernel<true>, grid, dim3(256), smem, st, a);
         else hipLaunchKernelGGL(conv_wgrad_amp_kernel<false>, grid, dim3(256), smem, st, a);
     } else {
         hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tk, tn, S), dim3(256), 0, st, a);
