@@ -839,6 +839,75 @@ __global__ __launch_bounds__(256) void attn_stats_bwd_kernel(AsBwdArgs a) {
     }
 }
 
+// The same with the thread's share of e and x kept in REGISTERS between the passes: one workgroup = 64 channels of one utterance,
+// 512 threads = 8 frame groups, NT = ceil(T / 8) <= 40 values of each per thread (T <= 320).  The plain kernel above re-reads both
+// slices from HBM in its second and third pass (PMC: 2.35 GB read per launch at B = 256 for 0.94 GB of inputs -- 552 us, the largest
+// kernel of the backward pass bar the weight gradients); here every input byte is read once.  (An LDS-resident variant -- 76 KB per
+// workgroup, two per CU -- measured SLOWER than the plain kernel: 8 waves per CU cannot keep enough loads in flight.)
+template <typename TE, int NT>
+__global__ __launch_bounds__(512) void attn_stats_bwd_reg_kernel(AsBwdArgs a) {
+    __shared__ float sm[2][8][64];
+    const int lc = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int b = blockIdx.y, c = blockIdx.x * 64 + lc;
+    const bool ok = c < a.C;
+    const int cc = ok ? c : 0;
+    const float* eb = a.e + (size_t)b * a.T * a.C + cc;
+    const float* xb = a.x + (size_t)b * a.T * a.ldx + cc;
+    const float mu = a.pooled[(size_t)b * 2 * a.C + cc], sd = a.pooled[(size_t)b * 2 * a.C + a.C + cc];
+    const float dmu = a.dpooled[(size_t)b * 2 * a.C + cc], dsd = a.dpooled[(size_t)b * 2 * a.C + a.C + cc];
+    const float dv = (sd * sd > a.eps) ? dsd / (2.f * sd) : 0.f;
+    float ev[NT], xv[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {                  // (unconditional loads on a clamped frame; the uses below are predicated)
+        const int t = min(rg + 8 * i, a.T - 1);
+        ev[i] = eb[(size_t)t * a.C];
+        xv[i] = xb[(size_t)t * a.ldx];
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) if (rg + 8 * i < a.T) mx = fmaxf(mx, ev[i]);
+    sm[0][rg][lc] = mx;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) mx = fmaxf(mx, sm[0][q][lc]);
+    __syncthreads();
+    float z = 0.f, u = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const float p = rg + 8 * i < a.T ? expf(ev[i] - mx) : 0.f;
+        const float d = xv[i] - mu;
+        ev[i] = p;                                  // exp(e - max): the third pass needs nothing else of e
+        z += p; u += p * (dmu * xv[i] + dv * d * d);
+    }
+    sm[0][rg][lc] = z; sm[1][rg][lc] = u;
+    __syncthreads();
+    z = 0.f; u = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { z += sm[0][q][lc]; u += sm[1][q][lc]; }
+    const float S = u / z;
+    if (!ok) return;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int t = rg + 8 * i;
+        if (t < a.T) {
+            const float al = ev[i] / z;
+            const float d = xv[i] - mu;
+            reinterpret_cast<TE*>(a.de)[((size_t)b * a.T + t) * a.C + c] = (TE)(al * (dmu * xv[i] + dv * d * d - S));
+            a.dx[((size_t)b * a.T + t) * a.lddx + c] = al * (dmu + 2.f * dv * d);
+        }
+    }
+}
+
+template <typename TE>
+static int launch_attn_stats_bwd(vp_ctx* ctx, const AsBwdArgs& a, int B, hipStream_t st) {
+    (void)ctx;
+    const dim3 grid((a.C + 63) / 64, B);
+    if (a.T <= 160 && !getenv("VPMI_ASB_PLAIN")) hipLaunchKernelGGL((attn_stats_bwd_reg_kernel<TE, 20>), grid, dim3(512), 0, st, a);
+    else if (a.T <= 320 && !getenv("VPMI_ASB_PLAIN")) hipLaunchKernelGGL((attn_stats_bwd_reg_kernel<TE, 40>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL(attn_stats_bwd_kernel<TE>, grid, dim3(256), 0, st, a);
+    return VP_OK;
+}
+
 // Adjoint of reflect padding: dxp (B, T + 2p, C) is the gradient w.r.t. the reflect-padded input (from the zero-padded
 // "full" data-gradient conv); frames 1..p and T-1-p..T-2 also receive their mirror images' gradients.
 struct FoldArgs { const float* dxp; float* dx; int T, p, C4; long long total;
@@ -1475,7 +1544,7 @@ int vp_attn_stats_bwd_f32(vp_ctx* ctx, const float* e, const float* x, int ldx, 
                           int C, float eps, float* de, float* dx, int lddx, vp_stream stream) {
     if (!ctx || !e || !x || !pooled || !dpooled || !de || !dx || B <= 0 || T <= 0 || C <= 0 || B > 65535) VP_FAIL(ctx, VP_EINVAL, "attn_stats_bwd: bad arguments");
     AsBwdArgs a{e, x, pooled, dpooled, de, dx, ldx, lddx, T, C, eps};
-    hipLaunchKernelGGL(attn_stats_bwd_kernel<float>, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, a);
+    { const int rc = launch_attn_stats_bwd<float>(ctx, a, B, (hipStream_t)stream); if (rc) return rc; }
     VP_LAUNCH_CHECK(ctx, "attn_stats_bwd");
     return VP_OK;
 }
@@ -1485,7 +1554,7 @@ int vp_attn_stats_bwd_de16(vp_ctx* ctx, const float* e, const float* x, int ldx,
                            int C, float eps, void* de, float* dx, int lddx, vp_stream stream) {
     if (!ctx || !e || !x || !pooled || !dpooled || !de || !dx || B <= 0 || T <= 0 || C <= 0 || B > 65535) VP_FAIL(ctx, VP_EINVAL, "attn_stats_bwd: bad arguments");
     AsBwdArgs a{e, x, pooled, dpooled, (float*)de, dx, ldx, lddx, T, C, eps};
-    hipLaunchKernelGGL(attn_stats_bwd_kernel<bf16_t>, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, a);
+    { const int rc = launch_attn_stats_bwd<bf16_t>(ctx, a, B, (hipStream_t)stream); if (rc) return rc; }
     VP_LAUNCH_CHECK(ctx, "attn_stats_bwd_de16");
     return VP_OK;
 }
