@@ -725,8 +725,18 @@ int vp_grid_barrier_status(vp_ctx* ctx);
  * (dm = the gradient that reached the squeeze mean through the two dense layers).  C % 4 == 0, contiguous (B*T, C) tensors. */
 int vp_utt_dot_f32(vp_ctx* ctx, const float* dy, const float* x, int B, int T, int C, float* ds, vp_stream stream);
 int vp_scale_shift_rows_f32(vp_ctx* ctx, const float* dy, const float* s, const float* dm, int B, int T, int C, float* dx, vp_stream stream);
+/* [mean | std] over the frames of f32 (B, T, C) for MANY frames per utterance (the (B, T*F', C) feature maps of ResNetSE's SE squeeze,
+ * resnet_se.py:60-66): the frames spread over ~2048 workgroups, chunk partials reduced in order.  Else VP_EUNSUP -> vp_time_stats_f32. */
+size_t vp_time_stats_workspace_bytes(int B, int T, int C);
+int vp_time_stats_ws_f32(vp_ctx* ctx, const float* x, int ldx, int B, int T, int C, float eps, int unbiased, float* stats, void* ws,
+                         size_t ws_bytes, vp_stream stream);
 int vp_scale_rows_bwd_f32(vp_ctx* ctx, const float* dy, const float* x, const float* s, int B, int T, int C, float* dx, float* ds,
                           vp_stream stream);
+/* The same for utterances of many positions (the (B, T*F', C) feature maps of ResNetSE / ERes2Net, resnet_se.py:60-75): positions spread over
+ * ~2048 workgroups, per-chunk partial sums reduced in fixed order.  C % 4 == 0, C <= 1024, 16-byte aligned tensors; else VP_EUNSUP. */
+size_t vp_scale_rows_bwd_workspace_bytes(int B, int T, int C);
+int vp_scale_rows_bwd_ws_f32(vp_ctx* ctx, const float* dy, const float* x, const float* s, int B, int T, int C, float* dx, float* ds, void* ws,
+                             size_t ws_bytes, vp_stream stream);
 
 /* Trial scoring -- replaces the per-trial sklearn cosine_similarity loop of
  * PPVectorTrainer.evaluate (trainer.py:416-423) and PPVectorPredictor.contrast (predict.py:282):

@@ -1268,3 +1268,40 @@ def test_se_block_with_its_dense_layers_in_one_launch_vs_float64_autograd(N, mon
     errs = {n: rel(x, y) for n, x, y in zip(names, fused, unfused)}
     print(f'[se dense B={B} T={T} C={C} H={H}] enable_amp, one launch vs two 1x1 ConvBlocks: ' + ', '.join(f'{k} {v:.1e}' for k, v in errs.items()))
     assert all(v < 2e-3 for v in errs.values()), errs
+
+
+@pytest.mark.parametrize('B,T,C', [(3, 5000, 32), (4, 2048, 128), (2, 1500, 256), (5, 1024, 12)])
+def test_se_scale_backward_over_many_positions_vs_float64(N, B, T, C):
+    """SEScale (out = x * s[b] + res: the SE gate of ResNetSE / ERes2Net on (B, T*F', C) feature maps, resnet_se.py:60-75) with thousands of
+    positions per utterance: the backward spreads the positions over the chip (vp_scale_rows_bwd_ws_f32, per-chunk partial sums) instead
+    of one workgroup per 64 channels of an utterance.  d x = d y * s, d s = sum_positions d y * x: against float64, 2e-6."""
+    from ppvector.train.functions import SEScale
+    g = torch.Generator().manual_seed(T + C)
+    x = torch.randn(B * T, C, generator=g).cuda().requires_grad_()
+    s = torch.rand(B, C, generator=g).cuda().requires_grad_()
+    res = torch.randn(B * T, C, generator=g).cuda().requires_grad_()
+    dy = torch.randn(B * T, C, generator=g).cuda()
+    out = SEScale.apply(x, s, res, B, T)
+    out.backward(dy)
+    torch.cuda.synchronize()
+    xd, sd, dd = x.detach().double().reshape(B, T, C), s.detach().double(), dy.double().reshape(B, T, C)
+    e_dx = rel(x.grad, (dd * sd[:, None, :]).reshape(B * T, C))
+    e_ds = rel(s.grad, (dd * xd).sum(1))
+    print(f'[se scale bwd B={B} T={T} C={C}] d x {e_dx:.1e}, d s {e_ds:.1e}, d res exact: {torch.equal(res.grad, dy)}')
+    assert e_dx < 2e-6 and e_ds < 2e-6 and torch.equal(res.grad, dy)
+
+
+@pytest.mark.parametrize('B,T,C,tstp', [(3, 5000, 32, False), (4, 2048, 128, True), (2, 1100, 256, False)])
+def test_time_statistics_over_many_frames_vs_float64(N, B, T, C, tstp):
+    """TimeStats ([mean | std] over the frames) on utterances of thousands of positions (the SE squeeze of ResNetSE on (B, T*F', C) maps):
+    the frames are spread over the chip (vp_time_stats_ws_f32).  Against float64: 2e-6; backward unchanged."""
+    from ppvector.train.functions import TimeStats
+    g = torch.Generator().manual_seed(T)
+    x = (torch.randn(B * T, C, generator=g) * 2 + 3).cuda().requires_grad_()
+    st = TimeStats.apply(x, B, T, tstp)
+    xd = x.detach().double().reshape(B, T, C)
+    mean = xd.mean(1)
+    std = (xd.var(1, unbiased=True) + 1e-8).sqrt() if tstp else xd.var(1, unbiased=False).clamp_min(1e-12).sqrt()
+    e1, e2 = rel(st[:, :C], mean), rel(st[:, C:], std)
+    print(f'[time stats B={B} T={T} C={C} tstp={tstp}] mean {e1:.1e}, std {e2:.1e}')
+    assert e1 < 2e-6 and e2 < 2e-6

@@ -369,6 +369,103 @@ __global__ __launch_bounds__(256) void time_moments4_kernel(TmArgs<float> a) {
 }
 }  // namespace
 
+namespace {
+// Many positions per utterance (2-D feature maps): the frames are cut into chunks (grid = channel blocks x B x chunks), partial
+// sums of (x - x[first frame]) and its square per chunk, then a finalize over the chunks in order.  part: [B][chunks][2][C].
+struct TmChunkArgs { const float* x; float* part; int ldx, Tn, C, chunks, rows_per_chunk; };
+__global__ __launch_bounds__(256) void time_moments_chunk_kernel(TmChunkArgs a) {
+    __shared__ float sm[2][256][4];
+    const int lc = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int b = blockIdx.y, ch = blockIdx.z, c4 = blockIdx.x * 32 + lc;
+    const int C4 = a.C >> 2;
+    const bool ok = c4 < C4;
+    const int c = ok ? c4 * 4 : 0;
+    const float* xb = a.x + (size_t)b * a.Tn * a.ldx + c;
+    const int t0 = ch * a.rows_per_chunk, t1 = min(a.Tn, t0 + a.rows_per_chunk);
+    float c0[4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    vp_load4(xb, c0);
+    int t = t0 + rg;
+    for (; t + 24 < t1; t += 32) {
+        float v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vp_load4(xb + (size_t)(t + 8 * u) * a.ldx, v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[u][e] - c0[e]; s1[e] += d; s2[e] += d * d; }
+    }
+    for (; t < t1; t += 8) {
+        float v[4];
+        vp_load4(xb + (size_t)t * a.ldx, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[e] - c0[e]; s1[e] += d; s2[e] += d * d; }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sm[0][threadIdx.x][e] = s1[e]; sm[1][threadIdx.x][e] = s2[e]; }
+    __syncthreads();
+    if (rg != 0 || !ok) return;
+    float t1s[4], t2s[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        t1s[e] = 0.f; t2s[e] = 0.f;
+        for (int r = 0; r < 8; ++r) { t1s[e] += sm[0][r * 32 + lc][e]; t2s[e] += sm[1][r * 32 + lc][e]; }
+    }
+    float* p = a.part + ((size_t)b * a.chunks + ch) * 2 * a.C;
+    vp_store4(p + c, t1s);
+    vp_store4(p + a.C + c, t2s);
+}
+struct TmFinArgs { const float* x; const float* part; float* stats; int ldx, Tn, C, chunks, unbiased; float eps; };
+__global__ __launch_bounds__(256) void time_moments_fin_kernel(TmFinArgs a) {
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= a.C) return;
+    float t1 = 0.f, t2 = 0.f;
+    for (int ch = 0; ch < a.chunks; ++ch) {
+        const float* p = a.part + ((size_t)b * a.chunks + ch) * 2 * a.C;
+        t1 += p[c]; t2 += p[a.C + c];
+    }
+    const float c0 = a.x[(size_t)b * a.Tn * a.ldx + c];
+    const float md = t1 / (float)a.Tn;
+    a.stats[(size_t)b * 2 * a.C + c] = c0 + md;
+    const float ss = fmaxf(t2 - (float)a.Tn * md * md, 0.f);
+    a.stats[(size_t)b * 2 * a.C + a.C + c] = a.unbiased ? sqrtf(ss / (float)(a.Tn > 1 ? a.Tn - 1 : 1) + a.eps) : sqrtf(fmaxf(ss / (float)a.Tn, a.eps));
+}
+static void tm_geometry(int B, int T, int C, int& chunks, int& rpc) {
+    const int cblocks = (C / 4 + 31) / 32;
+    long long ch = 2048 / ((long long)B * cblocks > 0 ? (long long)B * cblocks : 1);
+    if (ch < 1) ch = 1;
+    long long r = (T + ch - 1) / ch;
+    if (r < 64) r = 64;
+    rpc = (int)r;
+    chunks = (T + rpc - 1) / rpc;
+}
+}  // namespace
+
+extern "C" size_t vp_time_stats_workspace_bytes(int B, int T, int C) {
+    if (B <= 0 || T <= 0 || C <= 0) return 0;
+    int chunks, rpc;
+    tm_geometry(B, T, C, chunks, rpc);
+    return (size_t)B * chunks * 2 * C * sizeof(float) + 256;
+}
+
+// f32 (B, T, C) with MANY frames per utterance (ResNetSE / ERes2Net feature maps as (B, T*F', C)): [mean | std] with the frames spread over
+// ~2048 workgroups.  C % 4 == 0, ldx % 4 == 0, 16-byte aligned; else VP_EUNSUP (callers use vp_time_stats_f32).
+extern "C" int vp_time_stats_ws_f32(vp_ctx* ctx, const float* x, int ldx, int B, int T, int C, float eps, int unbiased, float* stats, void* ws,
+                                    size_t ws_bytes, vp_stream stream) {
+    if (!ctx || !x || !stats || B <= 0 || T <= 0 || C <= 0 || B > 65535) VP_FAIL(ctx, VP_EINVAL, "time_stats_ws: bad arguments");
+    if (((C | ldx) & 3) || ((uintptr_t)x & 15)) return VP_EUNSUP;
+    if (!ws || ws_bytes < vp_time_stats_workspace_bytes(B, T, C)) VP_FAIL(ctx, VP_EWORKSPACE, "time_stats_ws: workspace too small");
+    int chunks, rpc;
+    tm_geometry(B, T, C, chunks, rpc);
+    hipStream_t st = (hipStream_t)stream;
+    TmChunkArgs a{x, (float*)ws, ldx, T, C, chunks, rpc};
+    hipLaunchKernelGGL(time_moments_chunk_kernel, dim3((C / 4 + 31) / 32, B, chunks), dim3(256), 0, st, a);
+    VP_LAUNCH_CHECK(ctx, "time_moments_chunk");
+    TmFinArgs f{x, (const float*)ws, stats, ldx, T, C, chunks, unbiased, eps};
+    hipLaunchKernelGGL(time_moments_fin_kernel, dim3((C + 255) / 256, B), dim3(256), 0, st, f);
+    VP_LAUNCH_CHECK(ctx, "time_moments_fin");
+    return VP_OK;
+}
+
 int vp_time_moments(vp_ctx* ctx, int dtype, const void* x, int ldx, int B, int T, int C, float eps, int unbiased,
                     float* stats, hipStream_t st) {
     if (B > 65535) VP_FAIL(ctx, VP_EINVAL, "time_moments: batch too large");

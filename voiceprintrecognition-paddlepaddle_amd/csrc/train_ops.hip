@@ -964,6 +964,59 @@ __global__ __launch_bounds__(256) void scale_rows_bwd_kernel(const float* dy, co
     if (rg == 0 && c < C) ds[(size_t)b * C + c] = sm[0][lc] + sm[1][lc] + sm[2][lc] + sm[3][lc];
 }
 
+// The same for utterances of MANY positions (ResNetSE / ERes2Net feature maps: T x F' = 10^4 positions of 32-256 channels): the kernel
+// above gives one workgroup per (utterance, 64 channels) -- 32 workgroups walking 19 072 rows each on the stage-1 maps, 574 us per call
+// and a quarter of the ResNetSE training step.  Here the positions are cut into chunks (grid = chunks x B), four channels per lane,
+// partial sums per chunk reduced by sum_partials (fixed order).  part: [B][chunks][C].
+struct SrbArgs { const float* dy; const float* x; const float* s; float* dx; float* part; int T, C4, chunks, rows_per_chunk, cl_shift; };
+__global__ __launch_bounds__(256) void scale_rows_bwd_chunk_kernel(SrbArgs a) {
+    __shared__ float sm[256][4];
+    const int CL = 1 << a.cl_shift, RG = 256 >> a.cl_shift;
+    const int lc = threadIdx.x & (CL - 1), rg = threadIdx.x >> a.cl_shift;
+    const int b = blockIdx.y, ch = blockIdx.x;
+    const int p0 = ch * a.rows_per_chunk, p1 = min(a.T, p0 + a.rows_per_chunk);
+    const int C = a.C4 * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (lc < a.C4) {
+        float sv[4];
+        vp_load4(a.s + (size_t)b * C + 4 * lc, sv);
+        int p = p0 + rg;
+        for (; p + 3 * RG < p1; p += 4 * RG) {                   // four rows of loads in flight
+            float g[4][4], xv[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t o = ((size_t)b * a.T + p + u * RG) * C + 4 * lc;
+                vp_load4(a.dy + o, g[u]); vp_load4(a.x + o, xv[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float o4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { acc[e] += g[u][e] * xv[u][e]; o4[e] = g[u][e] * sv[e]; }
+                vp_store4(a.dx + ((size_t)b * a.T + p + u * RG) * C + 4 * lc, o4);
+            }
+        }
+        for (; p < p1; p += RG) {
+            const size_t o = ((size_t)b * a.T + p) * C + 4 * lc;
+            float g[4], xv[4], o4[4];
+            vp_load4(a.dy + o, g); vp_load4(a.x + o, xv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[e] += g[e] * xv[e]; o4[e] = g[e] * sv[e]; }
+            vp_store4(a.dx + o, o4);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sm[threadIdx.x][e] = acc[e];
+    __syncthreads();
+    if (rg == 0 && lc < a.C4) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < RG; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] += sm[q * CL + lc][e];
+        vp_store4(a.part + ((size_t)b * a.chunks + ch) * C + 4 * lc, t);
+    }
+}
+
 // The SE gate's backward in two passes (see SEBlockFn in train/functions.py): ds[b,c] = sum_t dy * x first -- the squeeze path's
 // gradient dm[b,c] (through the two dense layers) depends on it -- then dx = dy * s[b,c] + dm[b,c] / T in one write of dx, instead
 // of dx = dy * s, a separate mean-backward tensor and their sum.  Four channels per lane; 32 lanes x 8 frame groups per utterance.
@@ -1603,6 +1656,45 @@ int vp_affine_rows_aux_f32(vp_ctx* ctx, const float* z, int ldz, const float* sc
     AffAuxArgs a{z, scale, shift, y, add, aux, ldz, ldy, ld_add, ld_aux, C / 4, M};
     hipLaunchKernelGGL(affine_rows_aux_kernel, dim3(grid1d(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
     VP_LAUNCH_CHECK(ctx, "affine_rows_aux");
+    return VP_OK;
+}
+
+static void srb_geometry(int B, int T, int C, int& cl_shift, int& chunks, int& rpc) {
+    const int C4 = C / 4;
+    cl_shift = 0;
+    while ((1 << cl_shift) < C4 && cl_shift < 8) ++cl_shift;
+    const int RG = 256 >> cl_shift;
+    long long ch = 2048 / (B > 0 ? B : 1);                      // ~2048 workgroups
+    if (ch < 1) ch = 1;
+    long long r = (T + ch - 1) / ch;
+    if (r < 8LL * RG) r = 8LL * RG;                              // at least two four-row trips per thread
+    rpc = (int)r;
+    chunks = (T + rpc - 1) / rpc;
+}
+
+size_t vp_scale_rows_bwd_workspace_bytes(int B, int T, int C) {
+    if (B <= 0 || T <= 0 || C <= 0 || (C & 3) || C > 1024) return 0;
+    int cl, chunks, rpc;
+    srb_geometry(B, T, C, cl, chunks, rpc);
+    return (size_t)B * chunks * C * sizeof(float) + 256;
+}
+
+// out = x * s[b] (+ res) backward with the positions of an utterance spread over many workgroups (ws from vp_scale_rows_bwd_workspace_bytes;
+// C % 4 == 0, C <= 1024, 16-byte aligned tensors -- otherwise, or for few positions, callers use vp_scale_rows_bwd_f32)
+int vp_scale_rows_bwd_ws_f32(vp_ctx* ctx, const float* dy, const float* x, const float* s, int B, int T, int C, float* dx, float* ds, void* ws,
+                             size_t ws_bytes, vp_stream stream) {
+    if (!ctx || !dy || !x || !s || !dx || !ds || B <= 0 || T <= 0 || C <= 0 || B > 65535) VP_FAIL(ctx, VP_EINVAL, "scale_rows_bwd: bad arguments");
+    if ((C & 3) || C > 1024 || (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)s | (uintptr_t)dx) & 15)) return VP_EUNSUP;
+    const size_t need = vp_scale_rows_bwd_workspace_bytes(B, T, C);
+    if (!ws || ws_bytes < need) VP_FAIL(ctx, VP_EWORKSPACE, "scale_rows_bwd: workspace %zu < %zu", ws_bytes, need);
+    int cl, chunks, rpc;
+    srb_geometry(B, T, C, cl, chunks, rpc);
+    SrbArgs a{dy, x, s, dx, (float*)ws, T, C / 4, chunks, rpc, cl};
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(scale_rows_bwd_chunk_kernel, dim3(chunks, B), dim3(256), 0, st, a);
+    VP_LAUNCH_CHECK(ctx, "scale_rows_bwd_chunk");
+    launch_sum_partials((const float*)ws, chunks, C, ds, st, 1, 1, B);
+    VP_LAUNCH_CHECK(ctx, "scale_rows_bwd_reduce");
     return VP_OK;
 }
 

@@ -375,8 +375,16 @@ class SEScale(torch.autograd.Function):
         dy = _f32c(dy)
         Cc = x.shape[1]
         dx, ds = torch.empty_like(x), torch.empty_like(s)
-        _chk(lib.vp_scale_rows_bwd_f32(hctx, dy.data_ptr(), x.data_ptr(), s.data_ptr(), B, T, Cc, dx.data_ptr(), ds.data_ptr(),
-                                       N.stream_ptr()), hctx)
+        rc = N.VP_EUNSUP
+        if T >= 1024 and Cc % 4 == 0:                # many positions per utterance (2-D feature maps): spread over the chip
+            ws = _bytes(lib.vp_scale_rows_bwd_workspace_bytes(B, T, Cc), x.device)
+            rc = lib.vp_scale_rows_bwd_ws_f32(hctx, dy.data_ptr(), x.data_ptr(), s.data_ptr(), B, T, Cc, dx.data_ptr(), ds.data_ptr(),
+                                              ws.data_ptr(), ws.numel(), N.stream_ptr())
+            if rc not in (0, N.VP_EUNSUP):
+                _chk(rc, hctx)
+        if rc == N.VP_EUNSUP:
+            _chk(lib.vp_scale_rows_bwd_f32(hctx, dy.data_ptr(), x.data_ptr(), s.data_ptr(), B, T, Cc, dx.data_ptr(), ds.data_ptr(),
+                                           N.stream_ptr()), hctx)
         return dx, ds, dy, None, None
 
 
@@ -522,6 +530,21 @@ class _Tape:
         self.saved_tensors = tensors
 
 
+def _time_stats_launch(x, B, T, eps, unbiased, stats):
+    """vp_time_stats_f32, or its many-frames flavour (frames spread over the chip) for the 2-D feature maps."""
+    lib, hctx = N.lib(), N.ctx(x.device)
+    Cc = x.shape[1]
+    if T >= 1024 and Cc % 4 == 0:
+        ws = _bytes(lib.vp_time_stats_workspace_bytes(B, T, Cc), x.device)
+        rc = lib.vp_time_stats_ws_f32(hctx, x.data_ptr(), Cc, B, T, Cc, eps, int(unbiased), stats.data_ptr(), ws.data_ptr(), ws.numel(),
+                                      N.stream_ptr())
+        if rc == 0:
+            return
+        if rc != N.VP_EUNSUP:
+            _chk(rc, hctx)
+    _chk(lib.vp_time_stats_f32(hctx, x.data_ptr(), Cc, B, T, Cc, eps, int(unbiased), stats.data_ptr(), N.stream_ptr()), hctx)
+
+
 def _time_stats(x, B, T, eps, want_std):
     """[mean | std] (or the mean alone) over time of x (B*T, C): from the producing conv's fused sums when it left them on the tensor
     (`_vp_tsums`: ConvBlock with cfg['want_tsums']), else by a pass over x."""
@@ -537,7 +560,7 @@ def _time_stats(x, B, T, eps, want_std):
                                             int(want_std), stats.data_ptr(), N.stream_ptr()), hctx)
         return stats
     stats = torch.empty((B, 2 * Cc), dtype=torch.float32, device=x.device)
-    _chk(lib.vp_time_stats_f32(hctx, x.data_ptr(), Cc, B, T, Cc, eps, 0, stats.data_ptr(), N.stream_ptr()), hctx)
+    _time_stats_launch(x, B, T, eps, 0, stats)
     return stats if want_std else stats[:, :Cc].contiguous()
 
 
@@ -631,7 +654,7 @@ class TimeStats(torch.autograd.Function):
         Cc = x.shape[1]
         eps = eps if eps is not None else (1e-8 if tstp else 1e-12)
         stats = torch.empty((B, 2 * Cc), dtype=torch.float32, device=x.device)
-        _chk(lib.vp_time_stats_f32(hctx, x.data_ptr(), Cc, B, T, Cc, eps, int(tstp), stats.data_ptr(), N.stream_ptr()), hctx)
+        _time_stats_launch(x, B, T, eps, int(tstp), stats)
         ctx.save_for_backward(x, stats)
         ctx.geom = (B, T, eps, int(tstp))
         return stats
