@@ -1,5 +1,8 @@
+"""Eight eager enable_amp training steps of CAM++ (cam), ResNetSE (res) or ERes2Net (eres) at the per-GPU batch of their BASELINE config,
+for rocprofv3 --kernel-trace --stats (that is how the ResNetSE SE-gate backward was found).
+Usage: rocprofv3 --kernel-trace --stats -- python tools/train_prof_other.py cam|res|eres"""
 import os, sys, time
-ROOT='/root/repo'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT,'voiceprintrecognition-paddlepaddle_amd'))
 import torch, ppvector
 from ppvector.loss.aamloss import AAMLoss
