@@ -481,7 +481,8 @@ __global__ __launch_bounds__(256) void col_sums_kernel(ColSumArgs p) {
 // Four channels per lane (C and the row pitches multiples of 4, 16-byte aligned bases): a wave-instruction moves 1 KB of a row
 // instead of 256 B, and four rows' loads are issued before the first add.  Workgroup = CL column lanes x (256 / CL) row groups
 // over rows_per_chunk rows; CL = 64 / 32 / 16 by width so that 64-channel tensors (the Res2 convs) still fill the lanes.
-struct ColSum4Args { const float* a; const float* b; const float* bmean; const float* bscale; float* part; int lda, ldb, M, C4, rows_per_chunk, cl_shift; };
+struct ColSum4Args { const float* a; const float* b; const float* bmean; const float* bscale; float* part; int lda, ldb, M, C4, rows_per_chunk, cl_shift;
+                     const float* ms; const float* mh; };   // optional: a counts only where b * ms + mh > 0 (a ReLU BEHIND the BatchNorm, resnet_se.py:72-74)
 
 template <bool HASB, typename TB = float>
 __global__ __launch_bounds__(256) void col_sums4_kernel(ColSum4Args p) {
@@ -495,6 +496,8 @@ __global__ __launch_bounds__(256) void col_sums4_kernel(ColSum4Args p) {
     if (c4 < p.C4) {
         float mu[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {0.f, 0.f, 0.f, 0.f};
         if (HASB) { vp_load4(p.bmean + c, mu); vp_load4(p.bscale + c, sc); }
+        float ms[4] = {0.f, 0.f, 0.f, 0.f}, mh[4] = {1.f, 1.f, 1.f, 1.f};          // (no mask: 0 * b + 1 > 0 always)
+        if (HASB && p.ms) { vp_load4(p.ms + c, ms); vp_load4(p.mh + c, mh); }
         int m = m0 + rg;
         for (; m + 3 * RG < m1; m += 4 * RG) {
             float av[4][4], bv[4][4];
@@ -507,8 +510,9 @@ __global__ __launch_bounds__(256) void col_sums4_kernel(ColSum4Args p) {
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    s1[e] += av[u][e];
-                    if (HASB) s2[e] += av[u][e] * (bv[u][e] - mu[e]) * sc[e];
+                    const float g = (!HASB || (float)bv[u][e] * ms[e] + mh[e] > 0.f) ? av[u][e] : 0.f;
+                    s1[e] += g;
+                    if (HASB) s2[e] += g * (bv[u][e] - mu[e]) * sc[e];
                 }
         }
         for (; m < m1; m += RG) {
@@ -517,8 +521,9 @@ __global__ __launch_bounds__(256) void col_sums4_kernel(ColSum4Args p) {
             if (HASB) vp_load4(gb + (size_t)m * p.ldb + c, bv);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                s1[e] += av[e];
-                if (HASB) s2[e] += av[e] * (bv[e] - mu[e]) * sc[e];
+                const float g = (!HASB || (float)bv[e] * ms[e] + mh[e] > 0.f) ? av[e] : 0.f;
+                s1[e] += g;
+                if (HASB) s2[e] += g * (bv[e] - mu[e]) * sc[e];
             }
         }
     }
@@ -624,6 +629,7 @@ __global__ __launch_bounds__(256) void affine_rows_aux_kernel(AffAuxArgs a) {
 struct BnBwdArgs {
     const float* dy; const float* z; const float* mean; const float* invstd; const float* gamma; const float* sums;   // sums [2][C]
     float* dz; int lddy, ldz, lddz, C4, relu_mask; long long M;
+    const float* ms; const float* mh;       // optional: d y counts only where z * ms + mh > 0 (a ReLU BEHIND the BatchNorm)
 };
 
 __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdArgs a) {
@@ -636,6 +642,12 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdArgs a) {
         vp_load4(a.dy + m * a.lddy + c, dy); vp_load4(a.z + m * a.ldz + c, z);
         vp_load4(a.mean + c, mu); vp_load4(a.invstd + c, is); vp_load4(a.sums + c, s1); vp_load4(a.sums + C + c, s2);
         if (a.gamma) vp_load4(a.gamma + c, g); else { g[0] = g[1] = g[2] = g[3] = 1.f; }
+        if (a.ms) {
+            float ms[4], mh[4];
+            vp_load4(a.ms + c, ms); vp_load4(a.mh + c, mh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dy[e] = z[e] * ms[e] + mh[e] > 0.f ? dy[e] : 0.f;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float zh = (z[e] - mu[e]) * is[e];
@@ -1374,8 +1386,29 @@ size_t vp_col_sums_workspace_bytes(long long M, int C) {
 }
 
 // sums [2][C]: sum_m a[m][c] and (when b) sum_m a[m][c] * (b[m][c] - bmean[c]) * bscale[c]
+static int col_sums_impl(vp_ctx* ctx, const float* a, int lda, const float* b, int ldb, const float* bmean, const float* bscale,
+                         const float* mask_scale, const float* mask_shift, long long M, int C, float* sums, void* ws, size_t ws_bytes,
+                         vp_stream stream);
+
 int vp_col_sums_f32(vp_ctx* ctx, const float* a, int lda, const float* b, int ldb, const float* bmean, const float* bscale,
                     long long M, int C, float* sums, void* ws, size_t ws_bytes, vp_stream stream) {
+    return col_sums_impl(ctx, a, lda, b, ldb, bmean, bscale, nullptr, nullptr, M, C, sums, ws, ws_bytes, stream);
+}
+
+// BatchNorm -> ReLU units (resnet_se.py:72-74, eres2net.py): the ReLU's backward folded into the two BatchNorm-backward passes.  a (= d y)
+// counts only where the unit's output b * mask_scale + mask_shift (the BatchNorm affine of the saved pre-BN tensor b) was positive -- the
+// same expression the forward's vp_affine_rows_f32 evaluates.  C % 4 == 0, 16-byte aligned; else VP_EUNSUP.
+int vp_col_sums_masked_f32(vp_ctx* ctx, const float* a, int lda, const float* b, int ldb, const float* bmean, const float* bscale,
+                           const float* mask_scale, const float* mask_shift, long long M, int C, float* sums, void* ws, size_t ws_bytes,
+                           vp_stream stream) {
+    if (!b || !mask_scale || !mask_shift) VP_FAIL(ctx, VP_EINVAL, "col_sums_masked: bad arguments");
+    if (((C | lda | ldb) & 3) || (((uintptr_t)a | (uintptr_t)b) & 15)) return VP_EUNSUP;
+    return col_sums_impl(ctx, a, lda, b, ldb, bmean, bscale, mask_scale, mask_shift, M, C, sums, ws, ws_bytes, stream);
+}
+
+static int col_sums_impl(vp_ctx* ctx, const float* a, int lda, const float* b, int ldb, const float* bmean, const float* bscale,
+                         const float* mask_scale, const float* mask_shift, long long M, int C, float* sums, void* ws, size_t ws_bytes,
+                         vp_stream stream) {
     if (!ctx || !a || !sums || M <= 0 || C <= 0 || (b && (!bmean || !bscale))) VP_FAIL(ctx, VP_EINVAL, "col_sums: bad arguments");
     if (!ws || ws_bytes < vp_col_sums_workspace_bytes(M, C)) VP_FAIL(ctx, VP_EWORKSPACE, "col_sums: workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -1385,7 +1418,7 @@ int vp_col_sums_f32(vp_ctx* ctx, const float* a, int lda, const float* b, int ld
         int cl_shift, colblocks, rpc, ch;
         colsum4_geometry(M, C / 4, cl_shift, colblocks, rpc, ch);
         chunks = ch;
-        ColSum4Args p{a, b, bmean, bscale, (float*)ws, lda, ldb, (int)M, C / 4, rpc, cl_shift};
+        ColSum4Args p{a, b, bmean, bscale, (float*)ws, lda, ldb, (int)M, C / 4, rpc, cl_shift, mask_scale, mask_shift};
         if (b) hipLaunchKernelGGL(col_sums4_kernel<true>, dim3(colblocks, (unsigned)chunks), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(col_sums4_kernel<false>, dim3(colblocks, (unsigned)chunks), dim3(256), 0, st, p);
     } else {
@@ -1411,7 +1444,7 @@ int vp_col_sums_f32_b16(vp_ctx* ctx, const float* a, int lda, const void* b, int
     if (!ws || ws_bytes < vp_col_sums_workspace_bytes(M, C)) VP_FAIL(ctx, VP_EWORKSPACE, "col_sums_b16: workspace too small");
     int cl_shift, colblocks, rpc, chunks;
     colsum4_geometry(M, C / 4, cl_shift, colblocks, rpc, chunks);
-    ColSum4Args p{a, (const float*)b, bmean, bscale, (float*)ws, lda, ldb, (int)M, C / 4, rpc, cl_shift};
+    ColSum4Args p{a, (const float*)b, bmean, bscale, (float*)ws, lda, ldb, (int)M, C / 4, rpc, cl_shift, nullptr, nullptr};
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL((col_sums4_kernel<true, bf16_t>), dim3(colblocks, (unsigned)chunks), dim3(256), 0, st, p);
     VP_LAUNCH_CHECK(ctx, "col_sums_b16");
@@ -1454,9 +1487,21 @@ int vp_bn_relu_bwd_f32(vp_ctx* ctx, const float* dy, int lddy, const float* z, i
                        vp_stream stream) {
     if (!ctx || !dy || !z || !mean || !invstd || !sums || !dz || M <= 0 || C <= 0 || (C | lddy | ldz | lddz) & 3)
         VP_FAIL(ctx, VP_EINVAL, "bn_relu_bwd: bad arguments");
-    BnBwdArgs a{dy, z, mean, invstd, gamma, sums, dz, lddy, ldz, lddz, C / 4, relu_mask, M};
+    BnBwdArgs a{dy, z, mean, invstd, gamma, sums, dz, lddy, ldz, lddz, C / 4, relu_mask, M, nullptr, nullptr};
     hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(grid1d(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
     VP_LAUNCH_CHECK(ctx, "bn_relu_bwd");
+    return VP_OK;
+}
+
+// BatchNorm backward with a ReLU BEHIND the BatchNorm folded in (see vp_col_sums_masked_f32): d y counts only where z * mask_scale + mask_shift > 0
+int vp_bn_relu_bwd_masked_f32(vp_ctx* ctx, const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* invstd,
+                              const float* gamma, const float* sums, const float* mask_scale, const float* mask_shift, long long M, int C,
+                              float* dz, int lddz, vp_stream stream) {
+    if (!ctx || !dy || !z || !mean || !invstd || !sums || !dz || !mask_scale || !mask_shift || M <= 0 || C <= 0 || (C | lddy | ldz | lddz) & 3)
+        VP_FAIL(ctx, VP_EINVAL, "bn_relu_bwd_masked: bad arguments");
+    BnBwdArgs a{dy, z, mean, invstd, gamma, sums, dz, lddy, ldz, lddz, C / 4, 0, M, mask_scale, mask_shift};
+    hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(grid1d(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
+    VP_LAUNCH_CHECK(ctx, "bn_relu_bwd_masked");
     return VP_OK;
 }
 
@@ -1499,7 +1544,7 @@ static int bn_bwd_dbias_impl(vp_ctx* ctx, const float* dy, int lddy, const void*
     if (!ws || ws_bytes < vp_bn_relu_bwd_dbias_workspace_bytes(M, C)) VP_FAIL(ctx, VP_EWORKSPACE, "bn_relu_bwd_dbias: workspace too small");
     int cl_shift, colblocks, rpc, chunks;
     colsum4_geometry(M, C / 4, cl_shift, colblocks, rpc, chunks);
-    BnBwdSumArgs p{{dy, (const float*)z, mean, invstd, gamma, sums, (float*)dz, lddy, ldz, lddz, C / 4, relu_mask, M}, (float*)ws, (int)M, rpc, cl_shift};
+    BnBwdSumArgs p{{dy, (const float*)z, mean, invstd, gamma, sums, (float*)dz, lddy, ldz, lddz, C / 4, relu_mask, M, nullptr, nullptr}, (float*)ws, (int)M, rpc, cl_shift};
     hipStream_t st = (hipStream_t)stream;
     if (z_bf16) hipLaunchKernelGGL((bn_relu_bwd_dbias_kernel<bf16_t, bf16_t>), dim3(colblocks, (unsigned)chunks), dim3(256), 0, st, p);
     else if (dz_bf16) hipLaunchKernelGGL(bn_relu_bwd_dbias_kernel<bf16_t>, dim3(colblocks, (unsigned)chunks), dim3(256), 0, st, p);

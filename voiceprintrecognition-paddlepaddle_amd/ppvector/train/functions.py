@@ -1025,7 +1025,11 @@ class Conv2dBlock(torch.autograd.Function):
         if act and not (bn and act == N.VP_ACT_RELU):
             y = torch.empty_like(pre)
             _chk(lib.vp_act_f32(hctx, act, pre.data_ptr(), pre.numel(), y.data_ptr(), N.stream_ptr()), hctx)
-        ctx.save_for_backward(x, weight, z, mean, invstd, gamma, (pre if act == N.VP_ACT_SILU else y) if act else None)
+        # BatchNorm -> ReLU: the backward folds the ReLU mask into the BatchNorm-backward passes (it re-evaluates z * scale + shift > 0);
+        # then the output is not kept for backward
+        fold = bn and act == N.VP_ACT_RELU and Cout % 4 == 0 and not os.environ.get('VPMI_BN_RELU_UNFOLDED')
+        ctx.fold = (scale, shift) if fold else None
+        ctx.save_for_backward(x, weight, z, mean, invstd, gamma, None if fold else ((pre if act == N.VP_ACT_SILU else y) if act else None))
         ctx.geom = (B, T, Fq, To, Fo, Cin, Cout, KT, KF, s, pad, act, bn, bias is not None)
         return y
 
@@ -1037,12 +1041,34 @@ class Conv2dBlock(torch.autograd.Function):
         dev = x.device
         dy = _f32c(dy)
         M = B * To * Fo
-        if relu:                                      # `relu` holds the activation code here
+        fold = getattr(ctx, 'fold', None)
+        if fold is not None:                          # BatchNorm -> ReLU with the mask folded into the two passes below
+            ms, mh = fold
+            sums = torch.empty((2, Cout), dtype=torch.float32, device=dev)
+            ws = _bytes(lib.vp_col_sums_workspace_bytes(M, Cout), dev)
+            rc = lib.vp_col_sums_masked_f32(hctx, dy.data_ptr(), Cout, z.data_ptr(), Cout, mean.data_ptr(), invstd.data_ptr(), ms.data_ptr(),
+                                            mh.data_ptr(), M, Cout, sums.data_ptr(), ws.data_ptr(), ws.numel(), N.stream_ptr())
+            if rc == N.VP_EUNSUP:                     # (misaligned views: materialise the mask the plain way)
+                yr = torch.empty_like(z)
+                _chk(lib.vp_affine_rows_f32(hctx, z.data_ptr(), Cout, ms.data_ptr(), mh.data_ptr(), M, Cout, yr.data_ptr(), Cout, 1,
+                                            N.stream_ptr()), hctx)
+                fold = None
+            else:
+                _chk(rc, hctx)
+        if fold is not None:
+            dgamma, dbeta = sums[1], sums[0]
+            dz = torch.empty_like(dy)
+            _chk(lib.vp_bn_relu_bwd_masked_f32(hctx, dy.data_ptr(), Cout, z.data_ptr(), Cout, mean.data_ptr(), invstd.data_ptr(),
+                                               gamma.data_ptr(), sums.data_ptr(), ms.data_ptr(), mh.data_ptr(), M, Cout, dz.data_ptr(), Cout,
+                                               N.stream_ptr()), hctx)
+            bn = False                                # (done)
+        elif relu:                                    # `relu` holds the activation code here
             t = torch.empty_like(dy)
             _chk(lib.vp_act_bwd_f32(hctx, relu, dy.data_ptr(), yr.data_ptr(), dy.numel(), t.data_ptr(), N.stream_ptr()), hctx)
             dy = t
-        dgamma = dbeta = None
-        dz = dy
+        if fold is None:
+            dgamma = dbeta = None
+            dz = dy
         if bn:
             sums = col_sums(dy, z, mean, invstd)
             dgamma, dbeta = sums[1], sums[0]
