@@ -21,6 +21,22 @@ from ppvector import _native as N
 _PAD = {'none': N.VP_PAD_NONE, 'zero': N.VP_PAD_ZERO, 'reflect': N.VP_PAD_REFLECT}
 
 
+_CONSTS = {}
+
+
+def _const(value, n, device):
+    """A read-only vector of n zeros / ones on `device`, made once (two fill launches per BatchNorm unit and step otherwise).  Never
+    created under a stream capture: GraphedTrainStep runs eager warm-up steps first, and a capture that finds the cache empty falls back
+    to a fresh tensor."""
+    key = (float(value), int(n), str(device))
+    t = _CONSTS.get(key)
+    if t is None:
+        t = torch.full((n,), float(value), dtype=torch.float32, device=device)
+        if not torch.cuda.is_current_stream_capturing():
+            _CONSTS[key] = t
+    return t
+
+
 def _chk(rc, ctx):
     N.check(rc, ctx)
 
@@ -132,8 +148,7 @@ class ConvBlock(torch.autograd.Function):
         if bn and ps is None and wide >= 2:
             raise N.VpmiError('ConvBlock: bf16 pre-BN activation needs the conv\'s fused column sums (utterances of >= ~19 frames)')
         if bn and ps is None:                                   # very short utterances: a separate column-sum pass
-            zeros = torch.zeros(Cout, dtype=torch.float32, device=x.device)
-            ones = torch.ones(Cout, dtype=torch.float32, device=x.device)
+            zeros, ones = _const(0.0, Cout, x.device), _const(1.0, Cout, x.device)
             sums = col_sums(z, z, zeros, ones)
             ps, pq = sums[0:1], sums[1:2]
         mean = invstd = None
@@ -220,8 +235,7 @@ def _conv_block_bwd(ctx, dy, skip=None, fold=None):
             mu, istd, g = mean, invstd, gamma
         else:                                   # ReLU alone: the BN backward formula with identity statistics
             sums = torch.zeros((2, Cout), dtype=torch.float32, device=dev)
-            mu = torch.zeros(Cout, dtype=torch.float32, device=dev)
-            istd = torch.ones(Cout, dtype=torch.float32, device=dev)
+            mu, istd = _const(0.0, Cout, dev), _const(1.0, Cout, dev)
             g = None
         dz = torch.empty_like(dy, dtype=torch.bfloat16 if wide else torch.float32)
         if has_bias and Cout % 4 == 0:          # the bias gradient (column sums of dz) from the pass that writes dz
@@ -769,8 +783,7 @@ class BNRows(torch.autograd.Function):
         lib, hctx = N.lib(), N.ctx(x.device)
         x = _f32c(x)
         M, Cc = x.shape
-        zeros = torch.zeros(Cc, dtype=torch.float32, device=x.device)
-        ones = torch.ones(Cc, dtype=torch.float32, device=x.device)
+        zeros, ones = _const(0.0, Cc, x.device), _const(1.0, Cc, x.device)
         sums = col_sums(x, x, zeros, ones)                     # [sum x | sum x^2]
         mean, invstd, scale, shift = (torch.empty(Cc, dtype=torch.float32, device=x.device) for _ in range(4))
         _chk(lib.vp_bn_train_finalize(hctx, sums[0].data_ptr(), sums[1].data_ptr(), 1, M, Cc, gamma.data_ptr(), beta.data_ptr(),
@@ -1009,8 +1022,7 @@ class Conv2dBlock(torch.autograd.Function):
         mean = invstd = None
         y = z
         if bn:
-            zeros = torch.zeros(Cout, dtype=torch.float32, device=x.device)
-            ones = torch.ones(Cout, dtype=torch.float32, device=x.device)
+            zeros, ones = _const(0.0, Cout, x.device), _const(1.0, Cout, x.device)
             sums = col_sums(z, z, zeros, ones)
             mean, invstd, scale, shift = (torch.empty(Cout, dtype=torch.float32, device=x.device) for _ in range(4))
             _chk(lib.vp_bn_train_finalize(hctx, sums[0].data_ptr(), sums[1].data_ptr(), 1, z.shape[0], Cout, gamma.data_ptr(),
