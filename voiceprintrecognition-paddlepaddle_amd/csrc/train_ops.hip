@@ -914,8 +914,9 @@ template <typename TE>
 static int launch_attn_stats_bwd(vp_ctx* ctx, const AsBwdArgs& a, int B, hipStream_t st) {
     (void)ctx;
     const dim3 grid((a.C + 63) / 64, B);
-    if (a.T <= 160 && !getenv("VPMI_ASB_PLAIN")) hipLaunchKernelGGL((attn_stats_bwd_reg_kernel<TE, 20>), grid, dim3(512), 0, st, a);
-    else if (a.T <= 320 && !getenv("VPMI_ASB_PLAIN")) hipLaunchKernelGGL((attn_stats_bwd_reg_kernel<TE, 40>), grid, dim3(512), 0, st, a);
+    static const bool plain = getenv("VPMI_ASB_PLAIN") != nullptr;      // A/B switch, read once per process
+    if (a.T <= 160 && !plain) hipLaunchKernelGGL((attn_stats_bwd_reg_kernel<TE, 20>), grid, dim3(512), 0, st, a);
+    else if (a.T <= 320 && !plain) hipLaunchKernelGGL((attn_stats_bwd_reg_kernel<TE, 40>), grid, dim3(512), 0, st, a);
     else hipLaunchKernelGGL(attn_stats_bwd_kernel<TE>, grid, dim3(256), 0, st, a);
     return VP_OK;
 }
