@@ -88,7 +88,7 @@ __device__ __forceinline__ void rt_wait(unsigned* bar, unsigned round, int nwg) 
             const unsigned v = lane < RT_NBAR ? __hip_atomic_load(bar + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
             if (__all(v >= target)) break;
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 24)) {       // never on a healthy launch (B <= #CUs): leave instead of hanging the device
+            if (++spins > (1u << 21)) {       // ~3 s; never on a healthy launch (B <= #CUs, waits are < 1 ms): leave instead of hanging the device
                 if (lane == 0) __hip_atomic_store(bar + RT_NBAR * 32 + 1, 0xdeadu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
