@@ -272,31 +272,39 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_amp_kernel(WgradArgs a) {
         }
 }
 
-// The same contraction for a NARROW layer: N <= 64 outputs x K <= 256 k-columns (the Res2Net chunk convs: 64 x 192), bf16 operands in
-// memory.  The square 128 x 128 tile above spends 63 % of its MFMAs and LDS traffic on rows / columns that do not exist there (7 convs x
-// 3 blocks per step: 0.36 ms at B = 256); here the four waves split the k-columns (64 each) and share all 64 outputs.
-// LDS: 2 stages x (dz^T 64 x 128 B | x^T 256 x 128 B).  1-D convs, stride 1, T_in == T_out (host-checked).
+// The same contraction for a NARROW layer: N <= 64 outputs (the Res2Net chunk convs: 64 x 192; the 32- and 64-channel 2-D convs of
+// ResNetSE / ERes2Net on their largest feature maps).  The square 128 x 128 tile above spends up to 3/4 of its MFMAs and LDS traffic on
+// output rows that do not exist there; here a workgroup takes all N <= 64 outputs x 256 k-columns (blockIdx.x), the four waves 64
+// k-columns each.  LDS: 2 stages x (dz^T 64 x 128 B | x^T 256 x 128 B).  BF: bf16 operands in memory (1-D only, as the caller has them);
+// else f32 operands rounded on the way in, 1-D or 2-D taps as in the kernel above.
+__device__ __forceinline__ uint2 wg_pack4(float4 v) {
+    bf16x4 o;
+    o[0] = (bf16_t)v.x; o[1] = (bf16_t)v.y; o[2] = (bf16_t)v.z; o[3] = (bf16_t)v.w;
+    return __builtin_bit_cast(uint2, o);
+}
+template <bool BF>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_n64_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char wsm[];
     constexpr int STAGE = (64 + 256) * 128;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
+    const int kb = blockIdx.x * 256;
     const int zb = blockIdx.z / a.splits, sp = blockIdx.z - zb * a.splits;
     const int m_begin = sp * a.rows_per_split;
     const int m_end = min(a.M, m_begin + a.rows_per_split);
     const int cg = tid & 31, rg = tid >> 5;
-    const bf16_t* __restrict__ gdz = reinterpret_cast<const bf16_t*>(a.dz) + zb * a.dzb;
-    const bf16_t* __restrict__ gx = reinterpret_cast<const bf16_t*>(a.x) + zb * a.xb;
     const bool nvalid = cg < 16 && 4 * cg < a.N;
-    int cc[2], tapoff[2];
+    int cc[2], tapoff[2], tapf[2];
     bool kvalid[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const int kcol = 128 * u + 4 * cg;
+        const int kcol = kb + 128 * u + 4 * cg;
         kvalid[u] = kcol < a.K;
         const int j = kvalid[u] ? kcol / a.Cin : 0;
         cc[u] = kvalid[u] ? kcol - j * a.Cin : 0;
-        tapoff[u] = j * a.dilation - a.pad_left;
+        const int kt = j / a.KF;
+        tapoff[u] = kt * a.dilation - a.pad_left;
+        tapf[u] = (j - kt * a.KF) - a.pad_f;
     }
     uint2 rdz[8], rx[2][8];
     auto gload = [&](int mbase) {
@@ -305,20 +313,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_n64_kernel(WgradArgs a) {
             const int m = mbase + 8 * rg + r;
             rdz[r] = uint2{0u, 0u}; rx[0][r] = uint2{0u, 0u}; rx[1][r] = uint2{0u, 0u};
             if (m >= m_end) continue;
-            if (nvalid) rdz[r] = *reinterpret_cast<const uint2*>(gdz + (size_t)m * a.lddz + 4 * cg);
-            const int b = m / a.T_out, t = m - b * a.T_out;
+            if (nvalid) {
+                if constexpr (BF) rdz[r] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.dz) + zb * a.dzb + (size_t)m * a.lddz + 4 * cg);
+                else rdz[r] = wg_pack4(*reinterpret_cast<const float4*>(a.dz + (size_t)m * a.lddz + 4 * cg));
+            }
+            const int bt = m / a.F_out, f = m - bt * a.F_out;
+            const int b = bt / a.T_out, t = bt - b * a.T_out;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 if (!kvalid[u]) continue;
-                int ts = t + tapoff[u];
-                bool ok = true;
+                const int traw = t * a.stride + tapoff[u], fs = f * a.stride_f + tapf[u];
+                int ts = traw;
+                bool ok = fs >= 0 && fs < a.F_in;
                 if (a.pad_mode == VP_PAD_REFLECT) {
                     ts = ts < 0 ? -ts : ts;
                     ts = ts >= a.T_in ? 2 * (a.T_in - 1) - ts : ts;
                 } else {
-                    ok = ts >= 0 && ts < a.T_in;
+                    ok = ok && traw >= 0 && traw < a.T_in;
                 }
-                if (ok) rx[u][r] = *reinterpret_cast<const uint2*>(gx + ((size_t)b * a.T_in + ts) * a.ldx + a.xoff + cc[u]);
+                if (!ok) continue;
+                const size_t o = (((size_t)b * a.T_in + ts) * a.F_in + fs) * a.ldx + a.xoff + cc[u];
+                if constexpr (BF) rx[u][r] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.x) + zb * a.xb + o);
+                else rx[u][r] = wg_pack4(*reinterpret_cast<const float4*>(a.x + o));
             }
         }
     };
@@ -379,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_n64_kernel(WgradArgs a) {
     for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int col = wv * 64 + q * 16 + i;
+            const int col = kb + wv * 64 + q * 16 + i;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = p * 16 + g * 4 + r;
@@ -1248,6 +1264,11 @@ unsigned grid1d(long long total) {
 }  // namespace
 
 // many outputs: one thread per output (coalesced over the outputs); few outputs, many partials: 16 x 16 per workgroup
+static bool getenv_once(const char* name) {       // A/B switches: read at first use (the few names used are distinct call sites)
+    static const bool v = getenv(name) != nullptr;
+    return v;
+}
+
 static void launch_sum_partials(const float* part, int S, long long n, float* out, hipStream_t st, int Cin = 1, int KW = 1, int batch = 1) {
     if (n >= 32768) hipLaunchKernelGGL(sum_partials_wide_kernel, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, st, part, S, n, out, Cin, KW);
     else hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n + 15) / 16), batch), dim3(256), 0, st, part, S, n, out, Cin, KW);
@@ -1313,14 +1334,21 @@ static int wgrad_impl(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int
             attr_set = true;
         }
         const dim3 grid((K + WA_T - 1) / WA_T, (d->Cout + WA_T - 1) / WA_T, S * nbatch);
-        if (bf_in && d->Cout <= 64 && K <= 256 && K > 128 && !two_d && d->stride == 1 && d->T_in == d->T_out) {      // narrow layer: its own tile shape
+        // narrow layer with bf16 operands in memory (the batched Res2Net chunk convs): its own tile shape.  The f32-operand flavour of the
+        // kernel (2-D taps too: the 32- / 64-channel convs of ResNetSE / ERes2Net / the FCM head) is built but NOT dispatched: measured
+        // slower than the square tile there (ResNetSE step 22.7 -> 23.8 ms, ERes2Net 31.4 -> 33.9 ms, CAM++ 30.1 -> 31.8 ms;
+        // VPMI_WGRAD_NARROW_F32=1 dispatches it for study)
+        if (d->Cout <= 64 && K > 128 && ((bf_in && !two_d && d->stride == 1) || (!bf_in && getenv_once("VPMI_WGRAD_NARROW_F32")))) {
             constexpr int smem64 = 2 * (64 + 256) * 128;
             static bool attr64 = false;
             if (!attr64) {
-                VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_n64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem64));
+                VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_n64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem64));
+                VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_n64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem64));
                 attr64 = true;
             }
-            hipLaunchKernelGGL(conv_wgrad_n64_kernel, dim3(1, 1, S * nbatch), dim3(256), smem64, st, a);
+            const dim3 g64((K + 255) / 256, 1, S * nbatch);
+            if (bf_in) hipLaunchKernelGGL(conv_wgrad_n64_kernel<true>, g64, dim3(256), smem64, st, a);
+            else hipLaunchKernelGGL(conv_wgrad_n64_kernel<false>, g64, dim3(256), smem64, st, a);
         } else if (bf_in) hipLaunchKernelGGL(conv_wgrad_amp_kernel<true>, grid, dim3(256), smem, st, a);
         else hipLaunchKernelGGL(conv_wgrad_amp_kernel<false>, grid, dim3(256), smem, st, a);
     } else {
