@@ -11,17 +11,19 @@ timing barrier / max-reduce.  Inside a GPU the batch runs as --streams concurren
 results; ppvector/models/engine.py: forward_streams).
 
 --mode train.  One step = the reference's optimisation step (ppvector/trainer.py:206-274): Fbank+CMN -> train-mode forward
-(batch-statistics BN) -> cosine head + AAM loss -> backward -> data-parallel gradient average (bucketed all-reduce over
-RCCL / xGMI, launched from autograd hooks while backward runs; ppvector/train/ddp.py) -> flat Adam.  Strong scaling by
-default (global batch 256 split over the ranks, as north_star states it); --weak keeps 256 per GPU.
+(batch-statistics BN) -> cosine head + AAM loss -> backward -> data-parallel gradient average -> flat Adam, as
+ppvector/train/step.py::GraphedTrainStep runs it (the class PPVectorTrainer uses): forward + backward replayed from HIP graphs
+captured per backward stage, each stage's slice of the flat gradient buffer all-reduced (RCCL / xGMI) while the next stage
+replays.  Strong scaling by default (global batch 256 split over the ranks, as north_star states it); --weak keeps 256 per GPU.
 
 `python bench.py --gpus N` launches its own N ranks (one process per GPU, rendezvous on 127.0.0.1); under
 torch.distributed.run (RANK / WORLD_SIZE in the environment) it joins the existing job instead.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  "roofline"     : the dominant kernel (the 256 x 256 LDS-DMA conv GEMM, bf16 in / bf16 out -- seven launches per step,
-                   87 % of the forward's flops) timed launch-by-launch with HIP events on the launching stream, against
-                   the dense bf16 MFMA peak; "family" adds the two other conv launches (block0, ASP attention TDNN);
+  "roofline"     : the dominant kernel (conv_gemm128x256_ring_kernel, the LDS-DMA conv GEMM, bf16 in / bf16 out -- seven launches
+                   per step, 87 % of the forward's flops): every shape replayed back to back between HIP events on the launching
+                   stream, against the dense bf16 MFMA peak; "traffic" = HBM bytes per launch from the committed PMC passes
+                   (profiles/r03_pmc_infer.json, while its source hash matches); "family" adds the two other conv launches;
   "cpu_baseline" : the CPU oracle (reference algorithm restated on NumPy + PyTorch-CPU fp32 -- NOT the PaddlePaddle
                    binary) timed on this host's cores on a bounded sample;
   train mode     : "rccl_ranks" (world size seen by a real all-reduce), "allreduce_ms" (the gradient buffer's all-reduce
