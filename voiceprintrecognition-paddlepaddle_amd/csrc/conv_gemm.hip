@@ -39,6 +39,13 @@ int vp_conv_launch256_bf16(vp_ctx* ctx, const void* args, int mode, int sched, i
 // the other launch sequence's memory-bound kernels.
 // VPMI_CONV256 presets it; vp_conv256_select() switches at run time (A/B in one process).
 static int g_conv256 = -2;
+// narrowest layer the 256-column LDS-DMA tiles take (columns past Cout are zero-filled operands and masked stores: a 128-channel layer
+// pays for 256); VPMI_RING_MIN_COUT overrides for A/B
+static int ring_min_cout() {
+    static const int v = [] { const char* e = getenv("VPMI_RING_MIN_COUT"); return e ? atoi(e) : 256; }();
+    return v;
+}
+
 static int use_conv256() {
     if (g_conv256 == -2) { const char* e = getenv("VPMI_CONV256"); g_conv256 = e ? atoi(e) : -1; }
     return g_conv256;
@@ -140,7 +147,7 @@ int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream) {
     // data-gradient GEMMs over bf16 dz) is built on the default schedule (6) for plain 1x1 layers.
     if (d->dtype_in == VP_BF16 && (mode == MODE_1X1 || mode == MODE_TAPS) &&
         (d->Cin % 64 == 0 || (mode == MODE_TAPS && (use_conv256() >= 3 || use_conv256() < 0))) &&
-        d->Cout >= 256 && !d->gate && (!d->psum || d->T_out >= 128) && use_conv256()) {
+        d->Cout >= ring_min_cout() && !d->gate && (!d->psum || d->T_out >= 128) && use_conv256()) {
         int sched = use_conv256() < 0 ? 6 : use_conv256();
         if (sched == 7) sched = a.K <= 1024 ? 6 : 4;
         if (sched == 5) sched = 4;              // resident workgroups: no longer built
