@@ -241,3 +241,24 @@ def test_cut_points_split_backward_into_a_chain_of_stages():
         assert torch.allclose(p.grad, r, rtol=1e-6, atol=1e-7)
     a, b = torch.randn(2, requires_grad=True), torch.randn(2)
     assert cut(a, b) == (a, b) or all(u is v for u, v in zip(cut(a, b), (a, b)))
+
+
+def test_cut_carries_the_producers_bf16_twin_to_the_next_stage():
+    """A tensor's `_vp_bf16` attribute (the bf16 GEMM operand its producer wrote, train/functions.py) must survive a stage cut: the
+    leaf that replaces the tensor in the next stage is what the next block's tdnn1 / the MFA layer receive."""
+    import torch
+    from ppvector.train.segments import Recorder, cut
+    a = torch.randn(6, 4, requires_grad=True)
+    y = a * 2
+    twin = y.detach().to(torch.bfloat16)
+    y._vp_bf16 = twin
+    z = torch.randn(6, 4)                                  # no grad: passes through unchanged
+    with Recorder() as rec:
+        y2, z2 = cut(y, z)
+        assert y2 is not y and z2 is z
+        assert getattr(y2, '_vp_bf16', None) is twin
+        loss = (y2 * y2).sum()
+        rec.backward(loss)
+    assert torch.allclose(a.grad, 8 * a.detach())
+    y3, = cut(y)                                           # outside a recorder: identity
+    assert y3 is y
