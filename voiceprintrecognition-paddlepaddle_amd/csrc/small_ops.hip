@@ -747,6 +747,55 @@ int vp_se_scale_residual(vp_ctx* ctx, int dtype, const void* x, int ldx, int xof
 
 }  // extern "C"
 
+namespace {
+// f32 x (the training engine), T <= 8 NT: a thread keeps its share of an utterance's logits and x in registers -- all loads issued up front
+// (the streaming kernel above has two loads in flight per thread and a divergent branch per frame: 4.2 TB/s) -- then max, then the sums.
+template <int NT>
+__global__ __launch_bounds__(512) void asp_softmax_stats_reg_kernel(AspArgs<float> a) {
+    __shared__ float sm[4][8][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 64 + lane;
+    const bool ok = c < a.C;
+    const int cc = ok ? c : 0;
+    const float mu0 = a.center ? a.center[(size_t)b * a.ldc + cc] : 0.f;
+    const size_t row0 = (size_t)b * a.T_;
+    float ev[NT], xv[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int t = min(rg + 8 * i, a.T_ - 1);
+        ev[i] = a.logits[(row0 + t) * a.C + cc];
+        xv[i] = a.x[(row0 + t) * a.ldx + a.xoff + cc];
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) if (rg + 8 * i < a.T_) mx = fmaxf(mx, ev[i]);
+    sm[0][rg][lane] = mx;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) mx = fmaxf(mx, sm[0][q][lane]);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        if (rg + 8 * i < a.T_) {
+            const float p = expf(ev[i] - mx), d = xv[i] - mu0;
+            s0 += p; s1 += p * d; s2 += p * d * d;
+        }
+    }
+    sm[1][rg][lane] = s0; sm[2][rg][lane] = s1; sm[3][rg][lane] = s2;
+    __syncthreads();
+    if (rg == 0 && ok) {
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { t0 += sm[1][q][lane]; t1 += sm[2][q][lane]; t2 += sm[3][q][lane]; }
+        const float md = t1 / t0;
+        const float var = t2 / t0 - md * md;
+        a.pooled[(size_t)b * 2 * a.C + c] = mu0 + md;
+        a.pooled[(size_t)b * 2 * a.C + a.C + c] = sqrtf(fmaxf(var, a.eps));
+    }
+}
+}  // namespace
+
 int vp_asp_softmax_stats_ex(vp_ctx* ctx, int dtype, const float* logits, const void* x, int ldx, int xoff,
                             const float* center, int ldc, int B, int T, int C, float eps, float* pooled, hipStream_t st) {
     if (!ctx || !logits || !x || !pooled || B <= 0 || T <= 0 || C <= 0) VP_FAIL(ctx, VP_EINVAL, "asp: bad arguments");
@@ -757,7 +806,10 @@ int vp_asp_softmax_stats_ex(vp_ctx* ctx, int dtype, const float* logits, const v
         hipLaunchKernelGGL(asp_softmax_stats_kernel<bf16_t>, grid, dim3(256), 0, st, a);
     } else if (dtype == VP_F32) {
         AspArgs<float> a{logits, (const float*)x, center, pooled, ldx, xoff, ldc, B, T, C, eps};
-        hipLaunchKernelGGL(asp_softmax_stats_kernel<float>, grid, dim3(256), 0, st, a);
+        static const bool plain = getenv("VPMI_ASP_STATS_PLAIN") != nullptr;          // A/B switch
+        if (T <= 160 && !plain) hipLaunchKernelGGL(asp_softmax_stats_reg_kernel<20>, grid, dim3(512), 0, st, a);
+        else if (T <= 320 && !plain) hipLaunchKernelGGL(asp_softmax_stats_reg_kernel<40>, grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL(asp_softmax_stats_kernel<float>, grid, dim3(256), 0, st, a);
     } else {
         VP_FAIL(ctx, VP_EINVAL, "asp: bad dtype");
     }
