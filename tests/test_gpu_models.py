@@ -642,3 +642,34 @@ def test_training_head_runs_class_tiled_and_reports_predictions():
     print(f'[training head] loss tiled {l1:.6f} / logits path {l2:.6f}; accuracy {a1:.4f} / {a2:.4f}; d emb rel-L2 {re:.1e}, d W rel-L2 {rw:.1e}')
     assert abs(l1 - l2) < 2e-5 * abs(l2) and a1 == a2 and 0.3 < a1 < 0.6
     assert re < 1e-4 and rw < 1e-4
+
+
+@pytest.mark.parametrize('name', ['campplus', 'resnetse', 'eres2net'])
+def test_other_backbones_concurrent_launch_sequences_bit_identical(name):
+    """Co-run screen of the CAM++ / ResNetSE / ERes2Net bf16 engines (only ECAPA had one): the batch as 2 and 4
+    concurrent launch sequences against the single-stream forward, 12 forwards per setting, bit for bit.  Their 128-wide conv GEMMs
+    (bf16 input, 64 / 128-column tiles) are the neighbours that exposed the packed-f32 hazard of DESIGN.md section 8."""
+    from ppvector.models.campplus import CAMPPlus
+    from ppvector.models.eres2net import ERes2Net
+    from ppvector.models.resnet_se import ResNetSE
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(3)
+    if name == 'campplus':
+        m, B, T, F = CAMPPlus(80, embd_dim=192), 32, 298, 80
+    elif name == 'resnetse':
+        m, B, T, F = ResNetSE(64, embd_dim=192), 16, 151, 64
+    else:
+        m, B, T, F = ERes2Net(80, embd_dim=192), 16, 298, 80
+    m = m.cuda().eval()
+    feats = torch.randn((B, T, F), generator=g).cuda()
+    for dt in ('bfloat16', 'float32'):
+        eng = m.engine(dt)
+        ref = eng.forward(feats).clone()
+        bad = {2: 0, 4: 0}
+        for _ in range(12 if dt == 'bfloat16' else 3):
+            for S in (2, 4):
+                e = eng.forward_streams(feats, S)
+                torch.cuda.synchronize()
+                bad[S] += int(not torch.equal(e, ref))
+        print(f'[{name} {dt}] forwards as 2 / 4 launch sequences differing from the single-stream forward: {bad}')
+        assert bad == {2: 0, 4: 0}, (name, dt, bad)

@@ -8,7 +8,12 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libvpmi.so')
 SOURCES = ['api.hip', 'fbank.hip', 'melspec.hip', 'conv_gemm.hip', 'conv_gemm_bf16.hip', 'conv_gemm256.hip', 'conv_gemm_f32.hip', 'small_ops.hip', 'head.hip', 'head_tiled.hip', 'losses.hip', 'res2_chain.hip', 'asp_fused.hip', 'ecapa.hip', 'campplus.hip', 'cam_block.hip', 'fcm_conv.hip', 'pointwise.hip', 'resnet_se.hip', 'eres2net.hip', 'augment.hip', 'train_ops.hip', 'res2_train.hip', 'se_train.hip']
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+# -packed-fp32-ops: NO v_pk_{fma,mul,add}_f32 anywhere in the library.  On gfx950 a packed-f32 VALU instruction that reads registers a
+# vector-memory load has just returned can see stale data in lanes 48-63 when an MFMA-heavy wave of another kernel shares its SIMD
+# (reproducer tools/canary.hip + tools/stress_canary.py; tests/test_isa_cpu.py keeps the count at zero).  The
+# flag is a device target feature; the host pass prints "not a recognized feature" for it, filtered below.
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
+         '-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
 
 
 def hipcc():
@@ -43,6 +48,7 @@ def build(force=False, verbose=True):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f'hipcc failed on {s}:\n{out}')
+        out = '\n'.join(l for l in out.splitlines() if 'is not a recognized feature for this target' not in l)
         if verbose and out.strip():
             print(out)
     cmd = [hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs

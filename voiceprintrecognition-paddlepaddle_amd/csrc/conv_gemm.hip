@@ -127,14 +127,10 @@ int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream) {
     int bn = d->Cout <= 32 ? 32 : (d->Cout <= 64 ? 64 : 128);
     if (mode == MODE_1X1_PRO && bn > 64) bn = 64;
     if (d->dtype_in == VP_BF16 && d->dtype_out == VP_F32) bn = 128;
-    // Round 3: the bf16-INPUT instantiations of the 128-column tile (bf16 and f32 output) are NOT dispatched.  Under concurrent launch sequences (engine.
-    // forward_streams, bench.py's two streams) kernels that ran beside it or right behind it in the same queue returned wrong values in
-    // a few lanes (se_gate: one float4 component of 16 consecutive lanes of one K-slice; whole utterances off by 1e-3 .. 2e-2, rate 2 %
-    // of forwards at two streams, 70 % at four) although every kernel involved is race-free on its own, reads only its own LDS and
-    // passes every single-stream test -- tools/stress_kernels.py / tools/stress_identity.py reproduce it; the 64-column tile, the f32 and
-    // f32-tensor / bf16-MFMA tiles and the 256-wide kernels are clean under the same screens (tools/stress_corun.py).  Cause not found (an LDS over-allocation of 16 KB did not
-    // change it); until it is, Cout >= 128 takes two 64-column tiles (ASP attention TDNN: 86 -> ~95 us).  VPMI_BN128=1 re-enables it.
-    { static const bool bn128 = getenv("VPMI_BN128") != nullptr; if (!bn128 && d->dtype_in == VP_BF16 && bn == 128) bn = 64; }
+    // (Round 3 pinned the bf16-input 128-column tile to 64 columns: kernels running beside it returned wrong lanes.  Round 4 found the
+    // cause in the VICTIMS, not here -- packed-f32 VALU instructions reading freshly loaded registers next to an MFMA-heavy wave,
+    // DESIGN.md section 8 -- and the library is now built without packed-f32 instructions; VPMI_BN64=1 keeps the narrow tile for A/B.)
+    { static const bool bn64 = getenv("VPMI_BN64") != nullptr; if (bn64 && d->dtype_in == VP_BF16 && bn == 128) bn = 64; }
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + bn - 1) / bn;
     a.nseg = vp_conv1d_nseg(d->T_out);
