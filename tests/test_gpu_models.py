@@ -664,12 +664,17 @@ def test_other_backbones_concurrent_launch_sequences_bit_identical(name):
     feats = torch.randn((B, T, F), generator=g).cuda()
     for dt in ('bfloat16', 'float32'):
         eng = m.engine(dt)
-        ref = eng.forward(feats).clone()
+        full = eng.forward(feats).clone()
         bad = {2: 0, 4: 0}
-        for _ in range(12 if dt == 'bfloat16' else 3):
-            for S in (2, 4):
+        for S in (2, 4):
+            # the quiet twin of a sharded forward: the same shards one after the other on one stream (the kernel a layer takes can
+            # depend on the row count, so the full batch is not the bit-exact reference of a shard on these models)
+            bounds = [(B * i) // S for i in range(S + 1)]
+            ref = torch.cat([eng.forward(feats[bounds[i]:bounds[i + 1]].contiguous()) for i in range(S)]).clone()
+            assert (ref - full).abs().max().item() < (2e-2 if dt == 'bfloat16' else 1e-4)
+            for _ in range(12 if dt == 'bfloat16' else 3):
                 e = eng.forward_streams(feats, S)
                 torch.cuda.synchronize()
                 bad[S] += int(not torch.equal(e, ref))
-        print(f'[{name} {dt}] forwards as 2 / 4 launch sequences differing from the single-stream forward: {bad}')
+        print(f'[{name} {dt}] forwards as 2 / 4 launch sequences differing from the same shards run one after the other: {bad}')
         assert bad == {2: 0, 4: 0}, (name, dt, bad)
