@@ -718,8 +718,13 @@ int vp_se_dense_train_bwd(vp_ctx* ctx, const float* ds, const float* mean, const
 size_t vp_res2_train_workspace_bytes(int B, int scale);
 int vp_res2_train_fwd(vp_ctx* ctx, const vp_res2_train_desc* d, void* ws, size_t ws_bytes, vp_stream stream);
 int vp_res2_train_bwd(vp_ctx* ctx, const vp_res2_train_desc* d, void* ws, size_t ws_bytes, vp_stream stream);
-/* 0 unless a grid barrier of this context ever gave up waiting (it never does on a healthy launch; tests assert it). */
+/* 0 unless a grid barrier of this context gave up waiting since the last reset (it never does on a healthy launch; tests assert it).
+   Host-synchronising 4-byte read.  While the word is set the optimiser entry points (vp_adam_step_f32 ...) leave the parameters
+   untouched and vp_res2_train_fwd leaves the BatchNorm running statistics untouched: a step computed from incomplete statistics
+   never reaches the weights (reference: trainer.py:206-274 has no such failure mode -- this guards OUR fused kernels). */
 int vp_grid_barrier_status(vp_ctx* ctx);
+/* Clears the barrier words (after a bail-out, once the caller has switched to the per-chunk kernels). */
+int vp_grid_barrier_reset(vp_ctx* ctx, vp_stream stream);
 /* The SE block's backward as two passes (SEBlock + residual, ecapa_tdnn.py:50-82, 139-141):
  * vp_utt_dot_f32: ds[b][c] = sum_t dy[b,t,c] * x[b,t,c];  vp_scale_shift_rows_f32: dx[b,t,c] = dy[b,t,c] * s[b][c] + dm[b][c] / T
  * (dm = the gradient that reached the squeeze mean through the two dense layers).  C % 4 == 0, contiguous (B*T, C) tensors. */

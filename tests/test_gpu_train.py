@@ -794,7 +794,7 @@ def test_graphed_ecapa_step_in_backward_stages_equals_the_eager_step(N):
     print('[graphed ecapa] flat-gradient slices per backward stage (elements):', spans)
 
 
-def _two_rank_graphed_worker(rank, world, port, q):
+def _two_rank_graphed_worker(rank, world, port, q, ragged=False):
     import os
     import sys
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -821,10 +821,20 @@ def _two_rank_graphed_worker(rank, world, port, q):
     step = GraphedTrainStep(model, AAMLoss(margin=0.2, scale=32), opt)
     idx = list(shard_batch(8, rank, world))
     losses = []
-    for x, y in zip(xs, ys):
-        loss, _ = step(x[idx].cuda(), y[idx].cuda())
+    for i, (x, y) in enumerate(zip(xs, ys)):
+        xi = x[idx]
+        if ragged and rank == 1 and i >= 4:
+            xi = xi[:, :96 + 8 * (i - 4)]        # a padded length this rank has never seen: it steps eagerly while rank 0 replays graphs
+            import time
+            time.sleep(0.05)                     # ... and late: the peer's collective waits for it
+        loss, _ = step(xi.cuda(), y[idx].cuda())
         losses.append(float(loss))
     torch.cuda.synchronize()
+    if ragged:
+        q.put((rank, losses, step.n_stages, step.capture_error, opt.flat.detach().cpu().numpy(), step.faults, len(step._plans)))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     # numpy (pickled by value): a torch tensor would travel as a file descriptor of this process, which may be gone by the read
     q.put((rank, losses, step.n_stages, step.capture_error, opt.flat.detach().cpu().numpy(),
            {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if k.endswith(('_mean', '_variance'))}))
@@ -894,6 +904,33 @@ def test_graphed_train_step_under_two_ranks_equals_the_sharded_reference(N):
               f'parameters vs sharded reference {dp:.2e}  running statistics {ds:.2e}')
         assert dl < 1e-5 and dp < 1e-5 and ds < 1e-5, (dl, dp, ds)
     assert np.array_equal(res[0][4], res[1][4])                   # the ranks hold bit-identical parameters
+
+
+def test_ranks_in_different_step_modes_issue_the_same_collectives(N):
+    """GraphedTrainStep picks eager or graphed from rank-local state, and the graphed step used to all-reduce one
+    slice per backward stage while the eager step reduced the whole buffer -- ranks whose padded lengths differ would have enqueued
+    mismatched collectives.  The schedule is now `reduce_chunks(n_params)`: fixed chunks, last to first, in every mode.  Here rank 1
+    meets two NEW padded lengths at steps 5 and 6 (eager, and 50 ms late) while rank 0 replays its four stage graphs: the job must
+    finish, and the ranks must hold bit-identical parameters (they applied the same summed gradients)."""
+    import torch.multiprocessing as mp
+    from ppvector.train.step import reduce_chunks
+    ch = reduce_chunks(10 * (4 << 20) + 5)
+    assert ch[0][1] == 10 * (4 << 20) + 5 and ch[-1][0] == 0 and all(a[0] == b[1] for a, b in zip(ch, ch[1:])) and len(ch) == 11
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 37500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_two_rank_graphed_worker, args=(r, 2, port, q, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, losses, n_stages, err, flat, faults, plans in res:
+        assert err is None and faults == 0 and np.all(np.isfinite(losses)), (rank, err, faults, losses)
+        print(f'[mixed step modes] rank {rank}: losses {[f"{v:.5f}" for v in losses]}  graphs kept for {plans} shape(s), {n_stages} stages')
+    assert res[0][6] == 1 and res[1][6] == 1                      # each rank captured its one repeated shape; rank 1's new lengths ran eagerly
+    assert np.array_equal(res[0][4], res[1][4])                   # same summed gradients everywhere -> bit-identical parameters
 
 
 @pytest.mark.parametrize('M,C,two', [(76288, 512, True), (5000, 64, True), (777, 128, False), (1234, 1536, True), (256, 192, True),

@@ -31,9 +31,13 @@ struct vp_ctx {
     float* ms_mel_w;
     // device margin table of the margin-softmax losses (vp_set_margin_table): [margin, cos m, sin m, cos(pi - m), 1 + cos(pi - m)]
     const float* margin_table;
-    // counters of the in-kernel grid barrier (res2_train.hip): [0] arrivals, [1] departures, [2] bail-out flag; zero between launches
+    // counters of the in-kernel grid barrier (res2_train.hip): eight arrival counters 32 words apart, [256] departures, [257] bail-out
+    // flag (VP_FAULT_WORD); zero between launches
     unsigned* grid_bar;
 };
+constexpr int VP_FAULT_WORD = 8 * 32 + 1;
+// the bail-out word the optimiser kernels test before they update anything (nullptr: no barrier words on this context)
+static inline const unsigned* vp_fault_word(const vp_ctx* ctx) { return ctx && ctx->grid_bar ? ctx->grid_bar + VP_FAULT_WORD : nullptr; }
 
 #define VP_FAIL(ctx, code, ...)                                      \
     do {                                                             \

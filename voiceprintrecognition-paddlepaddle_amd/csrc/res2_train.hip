@@ -363,8 +363,11 @@ __global__ __launch_bounds__(RT_THREADS) void res2_train_fwd_kernel(Res2TrainArg
             if (b == 0) {
                 a.stats[(j * 2 + 0) * 64 + tid] = mu;
                 a.stats[(j * 2 + 1) * 64 + tid] = is;
-                if (a.rmean[j]) a.rmean[j][tid] = a.momentum * a.rmean[j][tid] + (1.f - a.momentum) * mu;
-                if (a.rvar[j]) a.rvar[j][tid] = a.momentum * a.rvar[j][tid] + (1.f - a.momentum) * var;
+                // a barrier that gave up has produced these from incomplete sums: the running statistics keep their values (the
+                // optimiser kernel drops the step's update on the same word, train_ops.hip)
+                const bool sound = __hip_atomic_load(a.bar + RT_NBAR * 32 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+                if (sound && a.rmean[j]) a.rmean[j][tid] = a.momentum * a.rmean[j][tid] + (1.f - a.momentum) * mu;
+                if (sound && a.rvar[j]) a.rvar[j][tid] = a.momentum * a.rvar[j][tid] + (1.f - a.momentum) * var;
             }
         }
         __syncthreads();
@@ -722,7 +725,16 @@ int vp_res2_train_bwd(vp_ctx* ctx, const vp_res2_train_desc* d, void* ws, size_t
     return VP_OK;
 }
 
-// 0 while no grid barrier of this context ever gave up waiting (tests)
+// Re-arms the barrier words after a bail-out (arrival / departure counters are left unbalanced by it, the flag stays set until
+// cleared): the caller switches to the per-chunk kernels first, or the next fused launch meets the same residency problem.
+int vp_grid_barrier_reset(vp_ctx* ctx, vp_stream stream) {
+    if (!ctx || !ctx->grid_bar) return VP_EINVAL;
+    VP_HIP(ctx, hipMemsetAsync(ctx->grid_bar, 0, 2048, (hipStream_t)stream));
+    return VP_OK;
+}
+
+// 0 while no grid barrier of this context gave up waiting since the last reset; synchronises the host with the device (a 4-byte
+// copy): GraphedTrainStep polls it every few steps and before every checkpoint, the optimiser kernels test the word on the device
 int vp_grid_barrier_status(vp_ctx* ctx) {
     if (!ctx || !ctx->grid_bar) return -1;
     unsigned v = 0;

@@ -740,8 +740,12 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_dbias_kernel(BnBwdSumArgs p) 
 // p -= lr * (m / (1 - b1^t)) / (sqrt(v / (1 - b2^t)) + eps)
 // keep = 1 - lr * coeff for paddle.optimizer.AdamW's DECOUPLED decay (the parameter shrinks first, the moments never see the decay);
 // 1 for Adam.
+// fault: the context's grid-barrier bail-out word (csrc/res2_train.hip).  A fused training kernel whose grid barrier timed out has
+// produced statistics from incomplete sums: the update of that step is DROPPED on the device -- the host polls the word only every
+// few steps (a D2H sync per step would stall the launch pipeline) and must not find the bad step in the weights or Adam's moments.
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2,
-                                                   float eps, float wd, float c1, float c2, float gscale, float keep) {
+                                                   float eps, float wd, float c1, float c2, float gscale, float keep, const unsigned* fault) {
+    if (fault && __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float pv = p[i];
         const float gr = g[i] * gscale + wd * pv;
@@ -755,7 +759,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
 // paddle.optimizer.Momentum (and SGD = momentum 0): g += wd * p (L2Decay-style float);  vel = mu * vel + g;
 // p -= lr * vel, or with use_nesterov p -= lr * (g + mu * vel)
 __global__ __launch_bounds__(256) void momentum_kernel(float* p, const float* g, float* vel, long long n, float lr, float mu, float wd,
-                                                       float gscale, int nesterov) {
+                                                       float gscale, int nesterov, const unsigned* fault) {
+    if (fault && __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float pv = p[i];
         const float gr = g[i] * gscale + wd * pv;
@@ -1589,7 +1594,7 @@ int vp_adam_step_f32(vp_ctx* ctx, float* param, const float* grad, float* m, flo
     if (!ctx || !param || !grad || !m || !v || n <= 0 || step < 1) VP_FAIL(ctx, VP_EINVAL, "adam: bad arguments");
     const float c1 = 1.f - powf(beta1, (float)step), c2 = 1.f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, lr, beta1, beta2, eps,
-                       weight_decay, c1, c2, grad_scale, 1.f);
+                       weight_decay, c1, c2, grad_scale, 1.f, vp_fault_word(ctx));
     VP_LAUNCH_CHECK(ctx, "adam");
     return VP_OK;
 }
@@ -1599,7 +1604,7 @@ int vp_adamw_step_f32(vp_ctx* ctx, float* param, const float* grad, float* m, fl
     if (!ctx || !param || !grad || !m || !v || n <= 0 || step < 1) VP_FAIL(ctx, VP_EINVAL, "adamw: bad arguments");
     const float c1 = 1.f - powf(beta1, (float)step), c2 = 1.f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, lr, beta1, beta2, eps,
-                       0.f, c1, c2, grad_scale, 1.f - lr * coeff);
+                       0.f, c1, c2, grad_scale, 1.f - lr * coeff, vp_fault_word(ctx));
     VP_LAUNCH_CHECK(ctx, "adamw");
     return VP_OK;
 }
@@ -1608,7 +1613,7 @@ int vp_momentum_step_f32(vp_ctx* ctx, float* param, const float* grad, float* ve
                          float weight_decay, int use_nesterov, float grad_scale, vp_stream stream) {
     if (!ctx || !param || !grad || !velocity || n <= 0) VP_FAIL(ctx, VP_EINVAL, "momentum: bad arguments");
     hipLaunchKernelGGL(momentum_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, param, grad, velocity, n, lr, momentum,
-                       weight_decay, grad_scale, use_nesterov);
+                       weight_decay, grad_scale, use_nesterov, vp_fault_word(ctx));
     VP_LAUNCH_CHECK(ctx, "momentum");
     return VP_OK;
 }

@@ -65,3 +65,18 @@ def set_train_amp(on):
 
 def get_train_amp():
     return _TRAIN_AMP
+
+
+_FUSED_GRID_KERNELS = True
+
+
+def set_fused_grid_kernels(on):
+    """The training kernels that meet at an in-kernel grid barrier (csrc/res2_train.hip).  GraphedTrainStep switches them off for the
+    rest of the process when a barrier gives up (workgroups not co-resident: another process on the GPU); the per-chunk kernels run
+    instead."""
+    global _FUSED_GRID_KERNELS
+    _FUSED_GRID_KERNELS = bool(on)
+
+
+def get_fused_grid_kernels():
+    return _FUSED_GRID_KERNELS

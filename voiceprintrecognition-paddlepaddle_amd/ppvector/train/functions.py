@@ -426,7 +426,8 @@ class Res2Fn(torch.autograd.Function):
     def _fused_ok(x, cfg, params, S):
         """The one-launch-per-direction chain (csrc/res2_train.hip): enable_amp steps, 64-channel chunks, contiguous f32 parameters
         in the model's layout.  VPMI_RES2_TRAIN_UNFUSED=1 keeps the per-chunk launches (A/B, parity tests)."""
-        if not ppvector.get_train_amp() or os.environ.get('VPMI_RES2_TRAIN_UNFUSED') or x.shape[1] != 64 * S or not 2 <= S <= 8:
+        if (not ppvector.get_train_amp() or os.environ.get('VPMI_RES2_TRAIN_UNFUSED') or not ppvector.get_fused_grid_kernels()
+                or x.shape[1] != 64 * S or not 2 <= S <= 8):
             return False
         for i in range(S - 1):
             wt, bs, g, b = params[6 * i:6 * i + 4]

@@ -16,6 +16,18 @@ import torch.distributed as dist
 from ppvector.train.ddp import OverlappedReducer, all_reduce_sum_, world_size
 from ppvector.train.segments import Recorder
 
+CHUNK_ELEMS = 4 << 20          # 16 MB of f32 gradients per collective (OverlappedReducer's bucket size: large enough for the xGMI ring)
+
+
+def reduce_chunks(n, chunk=CHUNK_ELEMS):
+    """THE collective schedule of a data-parallel step: the flat gradient buffer [0, n) cut into fixed chunks, all-reduced from the LAST
+    chunk to the first (backward produces the late layers' gradients first).  It depends on the parameter count alone -- never on the
+    batch shape, on whether this rank replays graphs or runs eagerly, or on where the backward stages were cut -- so every rank
+    issues the same collectives in the same order whatever its local state (a rank whose padded length differs, or whose capture
+    failed, must not desynchronise the job: ADVICE r03)."""
+    k = max(1, (n + chunk - 1) // chunk)
+    return [(i * chunk, min(n, (i + 1) * chunk)) for i in reversed(range(k))]
+
 
 def batch_accuracy(outputs, labels, K=1):
     """trainer.py:233-236: argmax of the logits against the labels; SubCenter heads score a class by its best sub-centre."""
@@ -65,8 +77,10 @@ class TrainStep:
             self.reducer.finish()
         else:
             self.optimizer.pack_grads()
-            if world > 1:
-                all_reduce_sum_(self.optimizer.grad)
+            if world > 1:                                 # the same chunks, in the same order, as the graphed step of a peer
+                works = [all_reduce_sum_(self.optimizer.grad[lo:hi], async_op=True) for lo, hi in reduce_chunks(self.optimizer.grad.numel())]
+                for w in works:
+                    w.wait()
         self.optimizer.step(grad_scale=1.0 / world)
         self.optimizer.clear_grad()
         with torch.no_grad():
@@ -100,13 +114,39 @@ class GraphedTrainStep(TrainStep):
     replayed kernels in place, as in the eager step.  Up to `max_graphs` batch shapes keep their graphs (a ragged training set
     yields a few distinct padded lengths); others run eagerly."""
 
-    def __init__(self, *a, warm=3, max_graphs=6, **kw):
+    def __init__(self, *a, warm=3, max_graphs=6, fault_every=25, **kw):
         kw['overlap_allreduce'] = False          # an autograd hook cannot launch a collective from inside a capture
         super().__init__(*a, **kw)
         self.warm, self.max_graphs = warm, max_graphs
         self._plans, self._seen = {}, {}
         self.capture_error = None
         self._margin = None
+        self.fault_every = fault_every           # steps between polls of the grid-barrier bail-out word (a host sync each)
+        self.faults = 0
+
+    def check_faults(self):
+        """Did a grid barrier of the fused training kernels give up since the last poll?  The device has already protected the
+        weights (the optimiser kernels and the running-statistics update test the same word); here the host finds out, switches the
+        fused kernels off for the rest of the process, re-arms the barrier words and drops the captured graphs (they replay the
+        fused kernels).  Called every `fault_every` steps, and by the trainer before every checkpoint / at the end of an epoch.
+        Returns True when a fault was found (the steps since the last poll did not update the model)."""
+        from ppvector import _native as N
+        import ppvector
+        if not torch.cuda.is_available():
+            return False
+        ctx = N.ctx(torch.device('cuda', torch.cuda.current_device()))
+        if N.lib().vp_grid_barrier_status(ctx) <= 0:
+            return False
+        self.faults += 1
+        ppvector.set_fused_grid_kernels(False)
+        N.check(N.lib().vp_grid_barrier_reset(ctx, N.stream_ptr()), ctx)
+        torch.cuda.synchronize()
+        self._plans.clear()
+        self._seen.clear()
+        import warnings
+        warnings.warn('a grid barrier of the fused Res2Net training kernels timed out (is another process using this GPU?): the '
+                      'optimiser dropped the affected steps on the device; continuing on the per-chunk kernels', RuntimeWarning)
+        return True
 
     # ------------------------------------------------------------------------------------------------ capture
     def _spans(self, params):
@@ -130,6 +170,7 @@ class GraphedTrainStep(TrainStep):
         opt.clear_grad()
         torch.cuda.synchronize()
         graphs, spans, done = [], [], set()
+        packed = {}
         cur = {}
 
         def open_graph():
@@ -148,6 +189,7 @@ class GraphedTrainStep(TrainStep):
             cm.__exit__(None, None, None)
             graphs.append(cur.pop('g'))
             spans.append(self._spans(new))
+            packed.update((id(p), p.grad._version) for p in new if p.grad is not None)
 
         rec = Recorder()
         try:
@@ -171,8 +213,25 @@ class GraphedTrainStep(TrainStep):
                 except Exception:                         # noqa: BLE001
                     pass
             raise
+        # a parameter whose gradient was accumulated into AFTER its stage packed it (tied weights, a parameter used on both sides of a
+        # cut) would lose the later contributions under replay: refuse the capture (the eager step has no such limit)
+        late = [p for p in opt.params if p.grad is not None and id(p) in packed and p.grad._version != packed[id(p)]]
+        if late:
+            raise RuntimeError(f'{len(late)} parameter(s) receive gradient in more than one backward stage: not capturable')
         opt.clear_grad()                                  # a capture executes nothing: the .grad tensors hold no data
-        return {'graphs': graphs, 'spans': spans, 'static': st}
+        # chunk c of the fixed collective schedule may start once every element of it has been packed: after stage ready[c]
+        chunks = reduce_chunks(opt.grad.numel())
+        ready = []
+        for lo, hi in chunks:
+            r = 0
+            for k, sp in enumerate(spans):
+                if any(a < hi and b > lo for a, b in sp):
+                    r = k
+            ready.append(r)
+        # launch order = the schedule's order: a chunk also waits for the chunks ahead of it (identical sequence on every rank)
+        for c in range(1, len(ready)):
+            ready[c] = max(ready[c], ready[c - 1])
+        return {'graphs': graphs, 'spans': spans, 'static': st, 'chunks': chunks, 'ready': ready}
 
     # ------------------------------------------------------------------------------------------------ step
     def __call__(self, inputs, labels):
@@ -200,11 +259,13 @@ class GraphedTrainStep(TrainStep):
         self._margin.sync()                               # the margin the criterion holds NOW (MarginScheduler stepped it)
         world = 1 if self.skip_allreduce else world_size()
         works = []
-        for g, spans in zip(plan['graphs'], plan['spans']):
+        nxt = 0
+        for k, g in enumerate(plan['graphs']):
             g.replay()
-            if world > 1:
-                for lo, hi in spans:                      # this stage's gradients travel while the next stage replays
-                    works.append(all_reduce_sum_(self.optimizer.grad[lo:hi], async_op=True))
+            while world > 1 and nxt < len(plan['chunks']) and plan['ready'][nxt] <= k:
+                lo, hi = plan['chunks'][nxt]              # complete after this stage: travels while the next stage replays
+                works.append(all_reduce_sum_(self.optimizer.grad[lo:hi], async_op=True))
+                nxt += 1
         for w in works:
             if w is not None:
                 w.wait()
@@ -213,7 +274,10 @@ class GraphedTrainStep(TrainStep):
         self.optimizer.step(grad_scale=1.0 / world)
         self.optimizer.clear_grad()
         self._after()
-        return plan['static']['loss'].clone(), plan['static']['acc'].clone()
+        out = plan['static']['loss'].clone(), plan['static']['acc'].clone()
+        if self.fault_every and self.step_id % self.fault_every == 0:
+            self.check_faults()
+        return out
 
     @property
     def n_stages(self):

@@ -267,6 +267,8 @@ class PPVectorTrainer(object):
                               self.train_acc, self.scheduler.get_lr(), margin_str, train_speed, timedelta(seconds=int(self.train_eta_sec)))
                     self.train_log_step += 1
                 train_times, accuracies, loss_sum = [], [], []
+            if batch_id % 10000 == 0 and batch_id != 0:
+                self.train_step_fn.check_faults()          # never checkpoint across an unnoticed grid-barrier bail-out
             if batch_id % 10000 == 0 and batch_id != 0 and local_rank == 0:
                 save_checkpoint(configs=self.configs, model=self.model, optimizer=self.optimizer, amp_scaler=self.amp_scaler,
                                 margin_scheduler=self.margin_scheduler, save_model_path=save_model_path, epoch_id=epoch_id)
@@ -274,12 +276,11 @@ class PPVectorTrainer(object):
             self.scheduler.step()
             if self.margin_scheduler:
                 self.margin_scheduler.step()
-        # the fused Res2Net training kernels meet at an in-kernel grid barrier; it gives up (and says so here) instead of hanging
-        # the device if its workgroups were not co-resident -- e.g. two training processes sharing one GPU
-        from ppvector import _native as N
-        if torch.cuda.is_available() and N.lib().vp_grid_barrier_status(N.ctx(torch.device('cuda', torch.cuda.current_device()))) > 0:
-            raise N.VpmiError('a grid barrier of the fused Res2Net training kernels timed out during this epoch (is another process '
-                              'using this GPU?); set VPMI_RES2_TRAIN_UNFUSED=1 to run the per-chunk kernels')
+        # the fused Res2Net training kernels meet at an in-kernel grid barrier that gives up instead of hanging the device when its
+        # workgroups are not co-resident (two training processes on one GPU).  The device drops the update of such a step itself
+        # (csrc/train_ops.hip: adam_kernel's fault word); GraphedTrainStep polls the word every 25 steps, here before the epoch's
+        # evaluation / checkpoint, and continues on the per-chunk kernels after a warning.
+        self.train_step_fn.check_faults()
 
     def train(self, save_model_path='models/', log_dir='log/', resume_model=None, pretrained_model=None, do_eval=True):
         torch.manual_seed(1000)
