@@ -914,8 +914,10 @@ def test_ranks_in_different_step_modes_issue_the_same_collectives(N):
     finish, and the ranks must hold bit-identical parameters (they applied the same summed gradients)."""
     import torch.multiprocessing as mp
     from ppvector.train.step import reduce_chunks
-    ch = reduce_chunks(10 * (4 << 20) + 5)
-    assert ch[0][1] == 10 * (4 << 20) + 5 and ch[-1][0] == 0 and all(a[0] == b[1] for a, b in zip(ch, ch[1:])) and len(ch) == 11
+    for n in (5, (1 << 20) + 3, 6_700_000, 94_000_000):
+        ch = reduce_chunks(n)
+        assert ch[0][1] == n and ch[-1][0] == 0 and all(a[0] == b[1] for a, b in zip(ch, ch[1:])) and len(ch) <= 17, (n, len(ch))
+    assert len(reduce_chunks(6_700_000)) == 7
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = 37500 + os.getpid() % 2000

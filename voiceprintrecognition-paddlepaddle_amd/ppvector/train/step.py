@@ -16,28 +16,21 @@ import torch.distributed as dist
 from ppvector.train.ddp import OverlappedReducer, all_reduce_sum_, world_size
 from ppvector.train.segments import Recorder
 
-CHUNK_ELEMS = 4 << 20          # 16 MB of f32 gradients per collective (OverlappedReducer's bucket size: large enough for the xGMI ring)
+MIN_CHUNK = 1 << 20            # 4 MB of f32 gradients: below this a ring all-reduce over xGMI is latency-bound
+MAX_CHUNKS = 16
 
 
-def reduce_chunks(n, chunk=CHUNK_ELEMS):
-    """THE collective schedule of a data-parallel step: the flat gradient buffer [0, n) cut into fixed chunks, all-reduced from the LAST
-    chunk to the first (backward produces the late layers' gradients first).  It depends on the parameter count alone -- never on the
-    batch shape, on whether this rank replays graphs or runs eagerly, or on where the backward stages were cut -- so every rank
-    issues the same collectives in the same order whatever its local state (a rank whose padded length differs, or whose capture
-    failed, must not desynchronise the job: ADVICE r03)."""
+def reduce_chunks(n, chunk=None):
+    """THE collective schedule of a data-parallel step: the flat gradient buffer [0, n) cut into equal chunks (4 MB, or n / 16 rounded
+    up to whole 4 MB units for the large models), all-reduced from the LAST chunk to the first (backward produces the late layers'
+    gradients first).  It depends on the parameter count alone -- never on the batch shape, on whether this rank replays graphs or
+    runs eagerly, or on where the backward stages were cut -- so every rank issues the same collectives in the same order whatever
+    its local state (a rank whose padded length differs, or whose capture failed, must not desynchronise the job: ADVICE r03).
+    ECAPA-TDNN (6.7 M parameters): seven chunks, the one that waits for the last backward stage is 15 % of the buffer."""
+    if chunk is None:
+        chunk = max(MIN_CHUNK, -(-n // MAX_CHUNKS + MIN_CHUNK - 1) // MIN_CHUNK * MIN_CHUNK) if n > MIN_CHUNK * MAX_CHUNKS else MIN_CHUNK
     k = max(1, (n + chunk - 1) // chunk)
     return [(i * chunk, min(n, (i + 1) * chunk)) for i in reversed(range(k))]
-
-
-def batch_accuracy(outputs, labels, K=1):
-    """trainer.py:233-236: argmax of the logits against the labels; SubCenter heads score a class by its best sub-centre."""
-    pred = getattr(outputs, 'pred', None)
-    if pred is not None and K == 1:                   # the class-tiled head already holds the argmax of the cosines
-        return (pred.to(labels.device) == labels.to(torch.int32)).float().mean()
-    logits = outputs['logits'].detach()
-    if K > 1:
-        logits = logits.reshape(logits.shape[0], -1, K).max(dim=2)[0]
-    return (logits.argmax(dim=1) == labels.to(logits.device)).float().mean()
 
 
 class TrainStep:
