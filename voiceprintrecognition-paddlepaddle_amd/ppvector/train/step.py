@@ -28,7 +28,8 @@ def reduce_chunks(n, chunk=None):
     its local state (a rank whose padded length differs, or whose capture failed, must not desynchronise the job: ADVICE r03).
     ECAPA-TDNN (6.7 M parameters): seven chunks, the one that waits for the last backward stage is 15 % of the buffer."""
     if chunk is None:
-        chunk = max(MIN_CHUNK, -(-n // MAX_CHUNKS + MIN_CHUNK - 1) // MIN_CHUNK * MIN_CHUNK) if n > MIN_CHUNK * MAX_CHUNKS else MIN_CHUNK
+        per = (n + MAX_CHUNKS - 1) // MAX_CHUNKS
+        chunk = max(MIN_CHUNK, (per + MIN_CHUNK - 1) // MIN_CHUNK * MIN_CHUNK)
     k = max(1, (n + chunk - 1) // chunk)
     return [(i * chunk, min(n, (i + 1) * chunk)) for i in reversed(range(k))]
 
