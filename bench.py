@@ -23,7 +23,8 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
   "roofline"     : the dominant kernel (conv_gemm128x256_ring_kernel, the LDS-DMA conv GEMM, bf16 in / bf16 out -- seven launches
                    per step, 87 % of the forward's flops): every shape replayed back to back between HIP events on the launching
                    stream, against the dense bf16 MFMA peak; "traffic" = HBM bytes per launch from the committed PMC passes
-                   (profiles/r03_pmc_infer.json, while its source hash matches); "family" adds the two other conv launches;
+                   (profiles/r04_pmc_infer.json, while the hash of csrc/conv_gemm256.hip matches); "family" adds the two other conv launches;
+  "single_stream_ms" : the same step as one launch sequence; "clocks": rocm-smi before / after the timed region;
   "cpu_baseline" : the CPU oracle (reference algorithm restated on NumPy + PyTorch-CPU fp32 -- NOT the PaddlePaddle
                    binary) timed on this host's cores on a bounded sample;
   train mode     : "rccl_ranks" (world size seen by a real all-reduce), "allreduce_ms" (the gradient buffer's all-reduce
@@ -64,14 +65,34 @@ def conv_family_shapes(T):
     return s
 
 
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r04_pmc_infer.json')
+
+
 def kernel_git_hash():
-    """Hash of the kernel sources the PMC traffic numbers were taken on (profiles/r03_pmc_infer.json: "csrc_hash")."""
+    """Hash of the source of the dominant kernel the PMC traffic numbers were taken on ("csrc_hash" of PMC_FILE): conv_gemm256.hip
+    alone -- round 3 also hashed the dispatch file and an unrelated A/B switch there blanked `traffic` on the driver's line."""
     import hashlib
     h = hashlib.sha1()
-    for f in ('conv_gemm256.hip', 'conv_gemm_impl.h', 'conv_gemm.hip'):
-        with open(os.path.join(PKG, 'csrc', f), 'rb') as fh:
-            h.update(fh.read())
+    with open(os.path.join(PKG, 'csrc', 'conv_gemm256.hip'), 'rb') as fh:
+        h.update(fh.read())
     return h.hexdigest()[:12]
+
+
+def gpu_clocks(index=0):
+    """sclk / mclk / package power of GPU `index` as rocm-smi reports them NOW (outside the timed region; None when the tool is
+    absent).  The driver's box and the builder's boxes disagreed by 10 % in round 3 with identical code: the line says what it ran at."""
+    try:
+        r = subprocess.run(['rocm-smi', '-d', str(index), '--showclocks', '--showpower', '--json'], stdout=subprocess.PIPE,
+                           stderr=subprocess.DEVNULL, timeout=20, text=True)
+        card = next(iter(json.loads(r.stdout).values()))
+        out = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if 'sclk' in kl or 'mclk' in kl or 'fclk' in kl or 'power' in kl:
+                out[k.strip()] = v
+        return out or None
+    except Exception:                      # noqa: BLE001 -- a missing tool must not cost the measurement
+        return None
 
 
 def roofline_pass(reps):
@@ -137,7 +158,7 @@ def roofline_pass(reps):
     # HBM bytes per launch (average over the same seven launches) from the PMC passes of tools/pmc_step.sh, kept in profiles/: only
     # while that file was taken on THESE kernel sources
     traffic = None
-    tfile = os.path.join(ROOT, 'profiles', 'r03_pmc_infer.json')
+    tfile = PMC_FILE
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
@@ -151,7 +172,9 @@ def roofline_pass(reps):
             'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
             'flop_per_launch': total_flop / n, 'avg_launch_ms': round(total_ms / n, 4),
-            'family': {'kernels': 'the 7 ring launches + conv_gemm256_kernel<TAPS_GEN> (block0) + conv_gemm_kernel<bf16,bf16,128> (ASP TDNN): 9 launches/step, 90% of forward flops',
+            'family': {'kernels': 'the 7 ring launches + block0 (80 -> 512, k5: conv_gemm256_kernel<TAPS_GEN>) + the ASP attention TDNN (1536 -> 128 '
+                                  'with per-utterance bias + tanh: whichever kernel vp_conv1d_fwd dispatches for it): 9 launches/step, 90% of '
+                                  'forward flops; timed as back-to-back replays of one buffer set (MALL-warm), NOT the in-step cost',
                        'achieved': round(fam_flop / (fam_ms * 1e-3) / 1e12, 2), 'avg_launch_ms': round(fam_ms / len(per_shape), 4)},
             'launches': per_shape}
 
@@ -390,10 +413,20 @@ def run_infer(args, rank, local_rank, world, dist):
     state, head_w = info['state'], info['head_w']
     want16 = args.dtype == 'bfloat16'
 
+    clocks = [gpu_clocks(local_rank)] if rank == 0 else None
     dt, loss = run_timed(run, args.steps, args.warmup, dist, dev)
+    if rank == 0:
+        clocks.append(gpu_clocks(local_rank))
     loss_v = float(loss)
     assert np.isfinite(loss_v)
     value = world * BATCH * args.steps / dt
+    # the same step as ONE launch sequence (no second stream), same K and W: what the concurrent sequences buy on THIS box
+    single_ms = None
+    if args.streams > 1 and world == 1:
+        run1, _ = make_infer_step(dev, args.dtype, 1, wav, labels, graph=bool(args.graph),
+                                  parts=(info['fz'], info['model'], info['head'], info['state'], info['head_w']))
+        dt1, _ = run_timed(run1, args.steps, args.warmup, None, dev)
+        single_ms = round(dt1 / args.steps * 1e3, 4)
     out = {
         'metric': 'utterances/sec (3 s, 16 kHz) ECAPA-TDNN fwd+AAM', 'value': round(value, 1),
         'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -406,6 +439,8 @@ def run_infer(args, rank, local_rank, world, dist):
                    'streams_per_gpu': args.streams, 'hip_graph': bool(args.graph)},
         'loss': round(loss_v, 5),
         'stage_roofline_frac': round(value / world * ALG_GFLOP_PER_UTT / 1e3 / PEAK_BF16_TFLOPS, 4),
+        'single_stream_ms': single_ms,
+        'clocks': {'before_timed_region': clocks[0], 'after_timed_region': clocks[1]} if rank == 0 else None,
     }
     # the path that COMMUNICATES, measured in the same job: the data-parallel training step (global batch 256 split over the
     # ranks, gradient all-reduce over RCCL overlapped with backward) -- reported beside the headline line as "dp_train".

@@ -1,0 +1,395 @@
+// Attentive statistics pooling as ONE kernel per utterance (bf16 engine) -- AttentiveStatisticsPooling.forward, pooling.py:105-123:
+//   h      = tanh(BN(ReLU(W_t x + b + rowbias)))          self.tdnn on cat([x, mean, std]): the [mean; std] columns of its weight are
+//                                                          the per-utterance bias `rowbias` (a small dense layer ahead of this launch)
+//   logits = W_c h (+ b_c: constant over time, it cancels in the softmax);  attn = softmax over time;
+//   pooled = [sum_t attn x | sqrt(sum_t attn x^2 - mean^2)]
+// Replaces two launches (the 1536 -> 128 conv GEMM on the 128-wide kernel, 84 us, + asp_fused, 85 us, at 256 x 298 frames).  A
+// 512-thread workgroup owns ONE utterance (T <= 304 frames) and streams its x rows (T x C bf16, 0.92 MB) through LDS twice, both
+// times as K-major stages of 32 channels fed by LDS-DMA rings with four stages in flight (the kernel is HBM-bound: 2 x 234 MB per
+// batch; one workgroup per CU must keep ~100 KB in flight to reach the memory's rate):
+//   phase 1  h = GEMM 320 x 128 x C: waves 4 (M) x 2 (N), 5 x 4 MFMA tiles each; stage = x (320 x 64 B) + W_t (128 x 64 B)
+//   between  h -> bf16 -> LDS in the A-operand layout; every wave takes ITS frame quarter's fragments (5 tiles x 4 k-steps = 80 VGPRs)
+//            into registers for good: the h tensor exists nowhere else
+//   phase 2  per 32-channel block: logits tile = h (registers) x W_c block (8 KB of the stage); wave = (16 channels, frame quarter);
+//            a lane holds its channel's 20 logits, takes max / exp2 / the three weighted sums over them (no online rescaling inside a
+//            block), the four frame groups merge by shuffles, the four quarters through a small LDS area one block later.
+//            Nothing in the loop is an ordinary load: beside LDS-DMAs in flight hipcc waits vmcnt(0) for any VGPR load and drains the
+//            ring (first version: 161 us; 95 us of it was this phase issuing ~900 latency-exposed instructions per block).
+// Roofline: HBM (algorithmic bytes: 2 x T*C*2 B per utterance).
+#include "common.h"
+
+#include <stdlib.h>
+
+#include <type_traits>
+
+namespace {
+
+constexpr int AU_ATT = 128;
+constexpr int AU_THREADS = 512;
+constexpr int AU_MAXT = 304;                 // 19 MFMA row tiles
+constexpr float AU_LOG2E = 1.4426950408889634f;
+// phase 1 ring
+constexpr int AU_KS = 32;                    // K per stage: 64-byte LDS rows
+constexpr int AU_XROWS = 320;
+constexpr int AU_XST = AU_XROWS * 64;        // 20,480 B
+constexpr int AU_WST = AU_ATT * 64;          // 8,192 B
+constexpr int AU_STAGE = AU_XST + AU_WST;    // 28,672 B
+constexpr int AU_NST = 5;                    // 143,360 B; four stages in flight
+// phase 2: h image (transient), then a five-slot ring of x (304 x 64 B) + W_c (32 x 256 B) stages, the centres, the merge area
+constexpr int AU_HBYTES = AU_MAXT * 256;     // 77,824 B: h rows of 128 bf16, 16-byte chunks XOR-swizzled by row & 15
+constexpr int AU_XST2 = AU_MAXT * 64;        // 19,456 B
+constexpr int AU_STAGE2 = AU_XST2 + 32 * 256;              // 27,648 B
+constexpr int AU_CEN = 5 * AU_STAGE2;                      // 138,240: C floats (C <= 1536)
+constexpr int AU_MAXC = 1536;
+constexpr int AU_MRG = AU_CEN + AU_MAXC * 4;               // 144,384: [2 parity][2 channel tiles][3 quarters][16][4] floats
+constexpr int AU_SMEM = AU_MRG + 2 * 2 * 3 * 16 * 4 * 4;   // 147,456 B
+static_assert(AU_NST * AU_STAGE <= AU_SMEM && 3 * AU_STAGE2 >= AU_HBYTES, "phase-1 ring fits; slots 3 and 4 lie above the h image");
+
+typedef __attribute__((address_space(3))) void* au_lds_t;
+
+struct AspUttArgs {
+    const bf16_t* x;        // (B*T, ldx)
+    const bf16_t* wt;       // [128][C]
+    const float* bias; const float* rowbias; const float* bn_scale; const float* bn_shift;     // [128], (B, 128) or null, [128], [128]
+    const bf16_t* wc;       // [C][128]
+    const float* cbias;     // [C]
+    const float* center;    // (B, ldc)
+    float* pooled;          // (B, 2C)
+    int ldx, ldc, T, C; float eps;
+    unsigned long long* stamps;   // timing study (VPMI_ASP_DBG bit 256): s_memtime of workgroup 0, wave 0
+    int dbg;                // timing study (VPMI_ASP_DBG): 1 = no phase-1 K loop, 2 = no phase-2 block loop, 256 = print s_memtime stamps
+};
+
+__device__ __forceinline__ float au_tanh(float v) {
+    // tanh(v) = 1 - 2 / (exp(2 v) + 1) on the hardware exp2 / rcp (the conv epilogue's form)
+    const float e = __builtin_amdgcn_exp2f(v * (2.f * AU_LOG2E));
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+}
+
+// (m, s0, s1, s2) <- merged with (m2, a0, a1, a2): running maximum (log2 domain) and the three sums relative to it.
+// ROBUST: a side that holds no frame (weight sum 0: a lane or a frame quarter entirely past T) contributes nothing, whatever its
+// maximum field says (the first version merged such a state arithmetically and produced NaN for every utterance shorter than 241
+// frames); the plain form is for sides that always hold frames (the lanes of a quarter without frames past T).
+template <bool ROBUST>
+__device__ __forceinline__ void au_merge(float& m, float& s0, float& s1, float& s2, float m2, float a0, float a1, float a2) {
+    if constexpr (ROBUST) {
+        const bool e1 = !(s0 > 0.f), e2 = !(a0 > 0.f);
+        const float ma = e1 ? m2 : m, mb = e2 ? ma : m2;
+        const float M = fmaxf(ma, mb);
+        const float f1 = e1 ? 0.f : __builtin_amdgcn_exp2f(m - M), f2 = e2 ? 0.f : __builtin_amdgcn_exp2f(m2 - M);
+        s0 = e1 ? 0.f : s0 * f1; s1 = e1 ? 0.f : s1 * f1; s2 = e1 ? 0.f : s2 * f1;
+        s0 += e2 ? 0.f : a0 * f2; s1 += e2 ? 0.f : a1 * f2; s2 += e2 ? 0.f : a2 * f2;
+        m = M;
+    } else {
+        const float M = fmaxf(m, m2);
+        const float f1 = __builtin_amdgcn_exp2f(m - M), f2 = __builtin_amdgcn_exp2f(m2 - M);
+        s0 = fmaf(s0, f1, a0 * f2); s1 = fmaf(s1, f1, a1 * f2); s2 = fmaf(s2, f1, a2 * f2);
+        m = M;
+    }
+}
+
+__global__ __launch_bounds__(AU_THREADS, 1) void asp_utt_kernel(const AspUttArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x;
+    const int T = a.T, C = a.C;
+    auto stamp = [&](int i) { if (a.stamps && b == 0 && tid == 0) a.stamps[i] = __builtin_readcyclecounter(); };
+    stamp(0);
+    const bf16_t* xb = a.x + (size_t)b * T * a.ldx;
+    // rows past T read as zeros: the descriptor ends with the utterance
+    const unsigned xbytes = (unsigned)(((size_t)(T - 1) * a.ldx + C) * 2);
+    const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xb), 0, xbytes, 0x00020000);
+    constexpr unsigned PAST = 0xf0000000u;
+    const unsigned ldxb = (unsigned)a.ldx * 2u;
+    // An x piece = 16 rows x 64 B: lane l lands at row l >> 2, position l & 3 and fetches the 16-byte chunk position ^ f(row).
+    //   phase 1 reads MFMA fragments (ds_read_b128; rows li, chunk g):       f(row) = (-(row >> 2)) & 3   (conv_gemm_impl.h: amp_pos)
+    //   phase 2 reads single values in the accumulator layout (rows 4 g + r, 32 B per frame group): f(row) = ((row >> 2) & 1) << 1 --
+    //           a ds_read_u16 serves lanes 0-31 = frame groups g, g + 1 together, 256 B = one bank row apart: they get different halves
+    const int prow = lane >> 2;
+    const unsigned xl1 = (unsigned)prow * ldxb + (unsigned)(((lane & 3) ^ ((0 - (prow >> 2)) & 3)) << 4);
+    const unsigned xl2 = (unsigned)prow * ldxb + (unsigned)(((lane & 3) ^ (((prow >> 2) & 1) << 1)) << 4);
+
+    // ------------------------------------------------------------------------------------------------ phase 1
+    {
+    const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.wt), 0, (unsigned)(AU_ATT * C * 2), 0x00020000);
+    const unsigned ldwb = (unsigned)C * 2u;
+    const unsigned wl = (unsigned)prow * ldwb + (unsigned)(((lane & 3) ^ ((0 - (prow >> 2)) & 3)) << 4);
+    const int NK = (a.dbg & 1) ? 0 : C / AU_KS;
+    // x pieces wv, wv + 8, (wv + 16 for waves 0-3) of the stage's 20; W_t piece wv of its 8
+    const bool four = wv < 4;
+    auto issue = [&](int k, int slot) {
+        char* st = smem + slot * AU_STAGE;
+        const unsigned ko = k < NK ? (unsigned)k * (AU_KS * 2) : PAST;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = wv + 8 * i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (au_lds_t)(st + p * 1024), 16, xl1 + (ko + (unsigned)(p * 16) * ldxb), 0, 0, 0);
+        }
+        if (four) {
+            const int p = wv + 16;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (au_lds_t)(st + p * 1024), 16, xl1 + (ko + (unsigned)(p * 16) * ldxb), 0, 0, 0);
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (au_lds_t)(st + AU_XST + wv * 1024), 16, wl + (ko + (unsigned)(wv * 16) * ldwb), 0, 0, 0);
+    };
+    const int wm = wv >> 1, wn = wv & 1;
+    const int fsw = ((g ^ ((0 - (li >> 2)) & 3)) << 4);                   // fragment chunk position (row = tile row li)
+    const char* fx = smem + (wm * 80 + li) * 64 + fsw;
+    const char* fw = smem + AU_XST + (wn * 64 + li) * 64 + fsw;
+    f32x4 acc[5][4];
+#pragma unroll
+    for (int mi = 0; mi < 5; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    issue(0, 0); issue(1, 1); issue(2, 2); issue(3, 3);
+    int slot = 0;
+    for (int k = 0; k < NK; ++k) {
+        // stage k has landed when at most the three younger stages' pieces are outstanding
+        if (four) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                    // ... everyone's, and everyone is done reading stage k - 1
+        asm volatile("" ::: "memory");
+        issue(k + 4, slot == 0 ? AU_NST - 1 : slot - 1);                 // into the buffer stage k - 1 used
+        const int so = slot * AU_STAGE;
+        bf16x8 xf[5], wf[4];
+#pragma unroll
+        for (int mi = 0; mi < 5; ++mi) xf[mi] = *reinterpret_cast<const bf16x8*>(fx + so + mi * 16 * 64);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) wf[ni] = *reinterpret_cast<const bf16x8*>(fw + so + ni * 16 * 64);
+#pragma unroll
+        for (int mi = 0; mi < 5; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[mi][ni], 0, 0, 0);
+        slot = slot == AU_NST - 1 ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the tail's zero-fill DMAs still target the ring
+    __syncthreads();                                                     // the ring is dead
+    stamp(1);
+    // h = tanh(bn(relu(acc + bias + rowbias))) -> bf16 rows in LDS [0, 76 KB), 16-byte chunks XOR-swizzled by row & 15 (the A-operand
+    // layout of phase 2).  acc[mi][ni][r]: frame wm*80 + mi*16 + li, att wn*64 + ni*16 + g*4 + r.  (Ordinary loads: no DMA in flight here.)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int n0 = wn * 64 + ni * 16 + g * 4;
+        float bs[4], sc[4], sh[4];
+        vp_load4(a.bias + n0, bs);
+        if (a.rowbias) { float rb[4]; vp_load4(a.rowbias + (size_t)b * AU_ATT + n0, rb); bs[0] += rb[0]; bs[1] += rb[1]; bs[2] += rb[2]; bs[3] += rb[3]; }
+        vp_load4(a.bn_scale + n0, sc);
+        vp_load4(a.bn_shift + n0, sh);
+        const int chunk = n0 >> 3, sub = (n0 & 7) * 2;
+#pragma unroll
+        for (int mi = 0; mi < 5; ++mi) {
+            const int m = wm * 80 + mi * 16 + li;
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)au_tanh(fmaxf(acc[mi][ni][r] + bs[r], 0.f) * sc[r] + sh[r]);
+            if (m < AU_MAXT) *reinterpret_cast<bf16x4*>(smem + m * 256 + ((chunk ^ (m & 15)) << 4) + sub) = o;
+        }
+    }
+    }
+
+    // ------------------------------------------------------------------------------------------------ phase 2
+    // stage n = 32 channels: x (304 rows x 64 B = 19 pieces) + W_c rows (32 x 256 B = 8 pieces of 4 rows: lane l at row l >> 4, position
+    // l & 15, fetching chunk position ^ (row & 15)).  Pieces per wave: x wv, wv + 8, (wv + 16 for waves 0-2), W_c wv.
+    const __amdgpu_buffer_rsrc_t csrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.wc), 0, (unsigned)(C * AU_ATT * 2), 0x00020000);
+    const int NC = (a.dbg & 2) ? 0 : C / 32;
+    const bool four2 = wv < 3;
+    auto issue2 = [&](int n, int slot) {
+        char* st = smem + slot * AU_STAGE2;
+        const bool live = n < NC;
+        const unsigned xo = live ? (unsigned)n * 64u : PAST;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = wv + 8 * i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (au_lds_t)(st + p * 1024), 16, xl2 + (xo + (unsigned)(p * 16) * ldxb), 0, 0, 0);
+        }
+        if (four2) {
+            const int p = wv + 16;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (au_lds_t)(st + p * 1024), 16, xl2 + (xo + (unsigned)(p * 16) * ldxb), 0, 0, 0);
+        }
+        // W_c piece wv: rows 4 wv .. 4 wv + 3 of the block; chunk swizzle by (row & 15) = (4 wv + (l >> 4)) & 15
+        const unsigned sw = (unsigned)((((lane & 15) ^ ((4 * wv + (lane >> 4)) & 15))) << 4);
+        const unsigned co = live ? (unsigned)(n * 32 + wv * 4 + (lane >> 4)) * 256u + sw : PAST;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(csrd, (au_lds_t)(st + AU_XST2 + wv * 1024), 16, co, 0, 0, 0);
+    };
+    // stages 0 and 1 go to slots 3 and 4, which lie above the h image; the wave then pulls its h fragments
+    issue2(0, 3); issue2(1, 4);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                        // every wave's rows of h (and the centres) are in LDS
+    asm volatile("" ::: "memory");
+    const int ct = wv & 1, fq = wv >> 1;                                // 16 channels of the block; frame tiles [5 fq, 5 fq + 5)
+    bf16x8 hf[5][4];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int row = (fq * 5 + i) * 16 + li;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + min(row, AU_MAXT - 1) * 256 + (((ks * 4 + g) ^ li) << 4));
+            if (row >= AU_MAXT) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};       // tile 19 of the last quarter does not exist
+            hf[i][ks] = v;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                        // everyone holds its fragments: the h image is dead
+    asm volatile("" ::: "memory");
+    issue2(2, 0); issue2(3, 1);
+    stamp(2);
+    // frames of this lane: t(i, r) = (5 fq + i) * 16 + 4 g + r; whole tiles past T only in the last quarter(s)
+    const int tbase = fq * 80 + g * 4;
+    const bool tail = fq * 80 + 80 > T;                                  // wave-uniform: this quarter holds frames past T
+    // x values of channel ct*16 + li: chunk ct*2 + (li >> 3) of the 64-byte row, swizzled by (row >> 2) & 3 = g
+    const int xoff = tbase * 64 + ((((ct * 2 + (li >> 3)) ^ ((g & 1) << 1))) << 4) + (li & 7) * 2;
+    const int woff = AU_XST2 + (ct * 16 + li) * 256;
+    float* mg = reinterpret_cast<float*>(smem + AU_MRG);                // [parity][ct][quarter 1..3][16 channels][m, s0, s1, s2]
+    float pm = -1e30f, ps0 = 0.f, ps1 = 0.f, ps2 = 0.f;       // quarter 0: state of the previous block, finished one block later
+    auto finish = [&](int n) {                                           // n = the block whose states were published by the last barrier
+        if (fq == 0 && g == 0) {
+            const float* q = mg + ((n & 1) * 2 + ct) * 192 + li * 4;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float4 o = *reinterpret_cast<const float4*>(q + k * 64);
+                au_merge<true>(pm, ps0, ps1, ps2, o.x, o.y, o.z, o.w);
+            }
+            const float md = ps1 / ps0;
+            const float var = ps2 / ps0 - md * md;
+            const int c = n * 32 + ct * 16 + li;
+            a.pooled[(size_t)b * 2 * C + c] = md;
+            a.pooled[(size_t)b * 2 * C + C + c] = sqrtf(fmaxf(var, a.eps));
+        }
+    };
+    float xf[5][4];                                                      // x values: low halves stay zero (ds_read_u16_d16_hi)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { xf[i][0] = 0.f; xf[i][1] = 0.f; xf[i][2] = 0.f; xf[i][3] = 0.f; }
+    int slot = 3;
+    for (int n = 0; n < NC; ++n) {
+        // stage n has landed when at most the three younger stages' pieces are outstanding (quarter 0's two result stores are older)
+        // (lgkmcnt: the raw s_barrier does not wait for this wave's LDS store of its quarter state -- without it the quarter-0 waves
+        // read a stale state once in ~80 forwards)
+        if (four2) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                    // ... everyone's; stage n - 1 is read out; its states are published
+        asm volatile("" ::: "memory");
+        if (n > 0) finish(n - 1);
+        issue2(n + 4, slot == 0 ? 4 : slot - 1);                         // the slot stage n - 1 used
+        const char* st = smem + slot * AU_STAGE2;
+        bf16x8 wf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wf[ks] = *reinterpret_cast<const bf16x8*>(st + woff + (((ks * 4 + g) ^ li) << 4));
+        f32x4 lg[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            lg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) lg[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf[i][ks], wf[ks], lg[i], 0, 0, 0);
+        }
+        // the lane's 20 x values, one address register (offset (i, r) = i * 1024 + r * 64), by ds_read_u16_d16_hi: the bf16 lands in the
+        // HIGH half of a register whose low half stays zero = the f32 value, no conversion instruction.  Inline asm (no builtin): hipcc
+        // does not count these reads, the lgkmcnt(0) below does (its own counted waits only get stronger by them).
+        {
+            const unsigned xa = (unsigned)(uintptr_t)(st + xoff);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                asm volatile("ds_read_u16_d16_hi %0, %4 offset:%5\n\tds_read_u16_d16_hi %1, %4 offset:%6\n\t"
+                             "ds_read_u16_d16_hi %2, %4 offset:%7\n\tds_read_u16_d16_hi %3, %4 offset:%8"
+                             : "+v"(xf[i][0]), "+v"(xf[i][1]), "+v"(xf[i][2]), "+v"(xf[i][3])
+                             : "v"(xa), "i"(i * 1024), "i"(i * 1024 + 64), "i"(i * 1024 + 128), "i"(i * 1024 + 192));
+            }
+        }
+        float mraw = -1e30f, s0 = 0.f, s1 = 0.f, s2 = 0.f, t0 = 0.f, t1 = 0.f, t2 = 0.f;
+        // two instances of the statistics: a quarter that holds frames past T (wave-uniform) masks them by SELECTS -- their logits and x
+        // values may be anything (rows past T of a stage are whatever the LDS held), and a lane may have no live frame at all
+        auto stats = [&](auto masked) {
+            constexpr bool MASKED = decltype(masked)::value;
+            if constexpr (MASKED) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mraw = (tbase + i * 16 + r < T) ? fmaxf(mraw, lg[i][r]) : mraw;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) mraw = fmaxf(fmaxf(mraw, fmaxf(lg[i][0], lg[i][1])), fmaxf(lg[i][2], lg[i][3]));
+            }
+            const float moff = -mraw * AU_LOG2E;
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[0][0]), "+v"(xf[0][1]), "+v"(xf[0][2]), "+v"(xf[0][3]), "+v"(xf[1][0]), "+v"(xf[1][1]),
+                         "+v"(xf[1][2]), "+v"(xf[1][3]), "+v"(xf[2][0]), "+v"(xf[2][1]), "+v"(xf[2][2]), "+v"(xf[2][3]), "+v"(xf[3][0]),
+                         "+v"(xf[3][1]), "+v"(xf[3][2]), "+v"(xf[3][3]), "+v"(xf[4][0]), "+v"(xf[4][1]), "+v"(xf[4][2]), "+v"(xf[4][3]));
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool live = !MASKED || tbase + i * 16 + r < T;
+                    float p = __builtin_amdgcn_exp2f(fmaf(lg[i][r], AU_LOG2E, moff));
+                    float xv = xf[i][r];
+                    if (MASKED) { p = live ? p : 0.f; xv = live ? xv : 0.f; }
+                    const float tp = p * xv;
+                    if (r & 1) { t0 += p; t1 += tp; t2 = fmaf(tp, xv, t2); }         // two accumulator sets: shorter dependency chains
+                    else { s0 += p; s1 += tp; s2 = fmaf(tp, xv, s2); }
+                }
+            }
+        };
+        if (tail) stats(std::true_type{}); else stats(std::false_type{});
+        s0 += t0; s1 += t1; s2 += t2;
+        float mx = mraw * AU_LOG2E;                                      // log2 domain, like au_merge
+        // the four frame groups of a channel (lanes l, l ^ 16, l ^ 32, l ^ 48)
+        if (tail) {
+#pragma unroll
+            for (int off = 16; off < 64; off <<= 1)
+                au_merge<true>(mx, s0, s1, s2, __shfl_xor(mx, off), __shfl_xor(s0, off), __shfl_xor(s1, off), __shfl_xor(s2, off));
+        } else {
+#pragma unroll
+            for (int off = 16; off < 64; off <<= 1)
+                au_merge<false>(mx, s0, s1, s2, __shfl_xor(mx, off), __shfl_xor(s0, off), __shfl_xor(s1, off), __shfl_xor(s2, off));
+        }
+        if (g == 0) {
+            if (fq == 0) { pm = mx; ps0 = s0; ps1 = s1; ps2 = s2; }
+            else *reinterpret_cast<float4*>(mg + ((n & 1) * 2 + ct) * 192 + (fq - 1) * 64 + li * 4) = make_float4(mx, s0, s1, s2);
+        }
+        slot = slot == 4 ? 0 : slot + 1;
+        if (n < 8 || n == NC - 1) stamp(3 + (n < 8 ? n : 8));
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (NC > 0) finish(NC - 1);
+    stamp(12);
+}
+
+}  // namespace
+
+// VP_EUNSUP when the shape is not covered (the caller runs the conv GEMM + asp_fused pair instead).
+int vp_asp_utt_bf16(vp_ctx* ctx, const void* x, int ldx, const vp_tdnn_layer* tdnn, const float* rowbias, const void* conv_w,
+                    const float* conv_b, const float* center, int ldc, int B, int T, int C, int att, float eps, float* pooled,
+                    hipStream_t st) {
+    static const bool off = getenv("VPMI_ASP_SPLIT") != nullptr;      // A/B: the two-launch path
+    if (off || att != AU_ATT || T < 1 || T > AU_MAXT || C < 64 || C % 64 || C > AU_MAXC || (ldx & 7) || !tdnn->bn_scale || !tdnn->bn_shift || !tdnn->bias ||
+        tdnn->cin != C || tdnn->cout != att || tdnn->kw != 1 || !center ||
+        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(tdnn->w) | reinterpret_cast<uintptr_t>(conv_w)) & 15) ||
+        (size_t)T * ldx * 2 >= 0xe0000000ull)
+        return VP_EUNSUP;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(asp_utt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, AU_SMEM));
+        attr_set = true;
+    }
+    AspUttArgs a;
+    a.x = (const bf16_t*)x; a.wt = (const bf16_t*)tdnn->w; a.bias = tdnn->bias; a.rowbias = rowbias; a.bn_scale = tdnn->bn_scale;
+    a.bn_shift = tdnn->bn_shift; a.wc = (const bf16_t*)conv_w; a.cbias = conv_b; a.center = center; a.pooled = pooled;
+    a.ldx = ldx; a.ldc = ldc; a.T = T; a.C = C; a.eps = eps;
+    { static const int dbg = getenv("VPMI_ASP_DBG") ? atoi(getenv("VPMI_ASP_DBG")) : 0; a.dbg = dbg; }
+    a.stamps = nullptr;
+    if (a.dbg & 256) {                                                   // timing study only: synchronises and prints
+        static int calls = 0;
+        unsigned long long* d = nullptr;
+        if (hipMalloc(&d, 16 * 8) == hipSuccess && hipMemset(d, 0, 16 * 8) == hipSuccess) a.stamps = d;
+        hipLaunchKernelGGL(asp_utt_kernel, dim3(B), dim3(AU_THREADS), AU_SMEM, st, a);
+        (void)hipDeviceSynchronize();
+        unsigned long long h[16];
+        if (a.stamps && hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && ++calls <= 3) {
+            fprintf(stderr, "asp_utt stamps (cycles from start): phase1 %llu  setup %llu  blocks", h[1] - h[0], h[2] - h[0]);
+            for (int i = 3; i < 12; ++i) fprintf(stderr, " %llu", h[i] - h[0]);
+            fprintf(stderr, "  end %llu\n", h[12] - h[0]);
+        }
+        (void)hipFree(d);
+        return VP_OK;
+    }
+    hipLaunchKernelGGL(asp_utt_kernel, dim3(B), dim3(AU_THREADS), AU_SMEM, st, a);
+    VP_LAUNCH_CHECK(ctx, "asp_utt");
+    return VP_OK;
+}

@@ -51,6 +51,11 @@ int vp_run_asp(vp_ctx* ctx, const vp_asp_weights& A, int dtype, const void* x, i
                              w.rowbias, A.att, st);
         if (rc) return rc;
     }
+    if (dtype == VP_BF16) {                       // one kernel per utterance: attention TDNN + logits + softmax + weighted statistics
+        rc = vp_asp_utt_bf16(ctx, x, ldx, &A.tdnn, A.w_ctx ? w.rowbias : nullptr, A.conv_w, A.conv_b, w.stats, 2 * C, B, T, C, A.att, 1e-12f,
+                             w.pooled, st);
+        if (rc != VP_EUNSUP) return rc;
+    }
     vp_conv1d_desc d;
     tdnn_desc(d, A.tdnn, dtype, B, T, T, VP_PAD_REFLECT);
     d.x = x; d.ldx = ldx; d.xoff = 0; d.rowbias = A.w_ctx ? w.rowbias : nullptr; d.act2 = VP_ACT_TANH;

@@ -34,6 +34,17 @@ def reduce_chunks(n, chunk=None):
     return [(i * chunk, min(n, (i + 1) * chunk)) for i in reversed(range(k))]
 
 
+def batch_accuracy(outputs, labels, K=1):
+    """trainer.py:233-236: argmax of the logits against the labels; SubCenter heads score a class by its best sub-centre."""
+    pred = getattr(outputs, 'pred', None)
+    if pred is not None and K == 1:                   # the class-tiled head already holds the argmax of the cosines
+        return (pred.to(labels.device) == labels.to(torch.int32)).float().mean()
+    logits = outputs['logits'].detach()
+    if K > 1:
+        logits = logits.reshape(logits.shape[0], -1, K).max(dim=2)[0]
+    return (logits.argmax(dim=1) == labels.to(logits.device)).float().mean()
+
+
 class TrainStep:
     def __init__(self, model, criterion, optimizer, scheduler=None, margin_scheduler=None, featurizer=None, spec_augment=None,
                  overlap_allreduce=True):
