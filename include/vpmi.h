@@ -267,6 +267,14 @@ int vp_asp_fused_fwd(vp_ctx* ctx, const void* h, const void* w, const float* bia
                      int ldc, int B, int T, int C, int att, float eps, float* pooled, vp_stream stream);
 int vp_se_gate_fwd(vp_ctx* ctx, const float* psum, const float* shift, int B, int T, int C, int H, const float* w1, const float* b1,
                    const float* w2, const float* b2, float* out, vp_stream stream);
+/* vp_asp_utt_fwd: the WHOLE AttentiveStatisticsPooling.forward (pooling.py:105-123) of the bf16 engine as one kernel per utterance:
+ *   h = tanh(BN(ReLU(tdnn.w x + tdnn.bias + rowbias[b]))) (rowbias = the [mean; std] columns of the attention TDNN applied to the global
+ *   context, (B, att) f32 or NULL), logits = conv_w h (+ conv_b: constant over time, cancels), softmax over time, pooled (B, 2C) f32 =
+ *   [sum_t a x | sqrt(max(sum_t a x^2 - mean^2, eps))] -- the reference's own uncentred form.  x (B*T, ldx) bf16, tdnn.w [att][C] bf16,
+ *   conv_w [C][att] bf16.  VP_EUNSUP unless att == 128, C % 64 == 0, T <= 304, tdnn = 1x1 with BN (vp_ecapa_fwd then runs the
+ *   conv GEMM + vp_asp_fused_fwd pair). */
+int vp_asp_utt_fwd(vp_ctx* ctx, const void* x, int ldx, const vp_tdnn_layer* tdnn, const float* rowbias, const void* conv_w,
+                   const float* conv_b, int B, int T, int C, int att, float eps, float* pooled, vp_stream stream);
 
 size_t vp_ecapa_workspace_bytes(const vp_ecapa_weights* w, int B, int T);
 /* feats: (B, T, feat_dim) in w->dtype; emb: (B, embd_dim) f32. */

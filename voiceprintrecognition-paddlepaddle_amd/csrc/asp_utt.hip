@@ -39,10 +39,8 @@ constexpr int AU_NST = 5;                    // 143,360 B; four stages in flight
 constexpr int AU_HBYTES = AU_MAXT * 256;     // 77,824 B: h rows of 128 bf16, 16-byte chunks XOR-swizzled by row & 15
 constexpr int AU_XST2 = AU_MAXT * 64;        // 19,456 B
 constexpr int AU_STAGE2 = AU_XST2 + 32 * 256;              // 27,648 B
-constexpr int AU_CEN = 5 * AU_STAGE2;                      // 138,240: C floats (C <= 1536)
-constexpr int AU_MAXC = 1536;
-constexpr int AU_MRG = AU_CEN + AU_MAXC * 4;               // 144,384: [2 parity][2 channel tiles][3 quarters][16][4] floats
-constexpr int AU_SMEM = AU_MRG + 2 * 2 * 3 * 16 * 4 * 4;   // 147,456 B
+constexpr int AU_MRG = AU_NST * AU_STAGE;                  // 143,360 (above BOTH rings): [2 group parity][4 blocks][2 channel tiles][4 quarters][16][4] floats
+constexpr int AU_SMEM = AU_MRG + 2 * 4 * 2 * 4 * 16 * 4 * 4;       // 159,744 B
 static_assert(AU_NST * AU_STAGE <= AU_SMEM && 3 * AU_STAGE2 >= AU_HBYTES, "phase-1 ring fits; slots 3 and 4 lie above the h image");
 
 typedef __attribute__((address_space(3))) void* au_lds_t;
@@ -52,10 +50,8 @@ struct AspUttArgs {
     const bf16_t* wt;       // [128][C]
     const float* bias; const float* rowbias; const float* bn_scale; const float* bn_shift;     // [128], (B, 128) or null, [128], [128]
     const bf16_t* wc;       // [C][128]
-    const float* cbias;     // [C]
-    const float* center;    // (B, ldc)
     float* pooled;          // (B, 2C)
-    int ldx, ldc, T, C; float eps;
+    int ldx, T, C; float eps;
     unsigned long long* stamps;   // timing study (VPMI_ASP_DBG bit 256): s_memtime of workgroup 0, wave 0
     int dbg;                // timing study (VPMI_ASP_DBG): 1 = no phase-1 K loop, 2 = no phase-2 block loop, 256 = print s_memtime stamps
 };
@@ -146,10 +142,11 @@ __global__ __launch_bounds__(AU_THREADS, 1) void asp_utt_kernel(const AspUttArgs
     int slot = 0;
     for (int k = 0; k < NK; ++k) {
         // stage k has landed when at most the three younger stages' pieces are outstanding
-        if (four) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        if ((a.dbg & 4) || ((a.dbg & 32) && k + 4 > NK)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (four) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                    // ... everyone's, and everyone is done reading stage k - 1
         asm volatile("" ::: "memory");
-        issue(k + 4, slot == 0 ? AU_NST - 1 : slot - 1);                 // into the buffer stage k - 1 used
+        if (!((a.dbg & 32) && k + 4 >= NK)) issue(k + 4, slot == 0 ? AU_NST - 1 : slot - 1);                 // into the buffer stage k - 1 used
         const int so = slot * AU_STAGE;
         bf16x8 xf[5], wf[4];
 #pragma unroll
@@ -212,7 +209,7 @@ __global__ __launch_bounds__(AU_THREADS, 1) void asp_utt_kernel(const AspUttArgs
         __builtin_amdgcn_raw_ptr_buffer_load_lds(csrd, (au_lds_t)(st + AU_XST2 + wv * 1024), 16, co, 0, 0, 0);
     };
     // stages 0 and 1 go to slots 3 and 4, which lie above the h image; the wave then pulls its h fragments
-    issue2(0, 3); issue2(1, 4);
+    if (!(a.dbg & 16)) { issue2(0, 3); issue2(1, 4); }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                        // every wave's rows of h (and the centres) are in LDS
     asm volatile("" ::: "memory");
@@ -231,6 +228,7 @@ __global__ __launch_bounds__(AU_THREADS, 1) void asp_utt_kernel(const AspUttArgs
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                        // everyone holds its fragments: the h image is dead
     asm volatile("" ::: "memory");
+    if (a.dbg & 16) { issue2(0, 3); issue2(1, 4); }
     issue2(2, 0); issue2(3, 1);
     stamp(2);
     // frames of this lane: t(i, r) = (5 fq + i) * 16 + 4 g + r; whole tiles past T only in the last quarter(s)
@@ -239,35 +237,40 @@ __global__ __launch_bounds__(AU_THREADS, 1) void asp_utt_kernel(const AspUttArgs
     // x values of channel ct*16 + li: chunk ct*2 + (li >> 3) of the 64-byte row, swizzled by (row >> 2) & 3 = g
     const int xoff = tbase * 64 + ((((ct * 2 + (li >> 3)) ^ ((g & 1) << 1))) << 4) + (li & 7) * 2;
     const int woff = AU_XST2 + (ct * 16 + li) * 256;
-    float* mg = reinterpret_cast<float*>(smem + AU_MRG);                // [parity][ct][quarter 1..3][16 channels][m, s0, s1, s2]
-    float pm = -1e30f, ps0 = 0.f, ps1 = 0.f, ps2 = 0.f;       // quarter 0: state of the previous block, finished one block later
-    auto finish = [&](int n) {                                           // n = the block whose states were published by the last barrier
-        if (fq == 0 && g == 0) {
-            const float* q = mg + ((n & 1) * 2 + ct) * 192 + li * 4;
+    // Per block every quarter's wave leaves (max, sum p, sum p x, sum p x^2) of its 16 channels in the merge area; the four quarters of
+    // FOUR blocks are merged in one go (64 lanes = 4 blocks x 16 channels) by the waves of quarter G & 3 after the group's last
+    // barrier -- a finish per block cost its two waves ~140 instructions while the other six waited at the barrier.
+    float* mg = reinterpret_cast<float*>(smem + AU_MRG);                // [group & 1][block & 3][ct][quarter][16 channels][m, s0, s1, s2]
+    auto finish = [&](int G) {                                           // group G = blocks 4 G .. 4 G + 3, published by the last barrier
+        if (fq == (G & 3)) {
+            const int blk = lane >> 4, n = 4 * G + blk;
+            const float* q = mg + ((((G & 1) * 4 + blk) * 2 + ct) * 4) * 64 + li * 4;
+            float4 o = *reinterpret_cast<const float4*>(q);
+            float m = o.x, s0 = o.y, s1 = o.z, s2 = o.w;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float4 o = *reinterpret_cast<const float4*>(q + k * 64);
-                au_merge<true>(pm, ps0, ps1, ps2, o.x, o.y, o.z, o.w);
+            for (int k = 1; k < 4; ++k) {
+                o = *reinterpret_cast<const float4*>(q + k * 64);
+                au_merge<true>(m, s0, s1, s2, o.x, o.y, o.z, o.w);
             }
-            const float md = ps1 / ps0;
-            const float var = ps2 / ps0 - md * md;
+            const float md = s1 / s0;
+            const float var = s2 / s0 - md * md;
             const int c = n * 32 + ct * 16 + li;
-            a.pooled[(size_t)b * 2 * C + c] = md;
-            a.pooled[(size_t)b * 2 * C + C + c] = sqrtf(fmaxf(var, a.eps));
+            if (n < NC) {
+                a.pooled[(size_t)b * 2 * C + c] = md;
+                a.pooled[(size_t)b * 2 * C + C + c] = sqrtf(fmaxf(var, a.eps));
+            }
         }
     };
-    float xf[5][4];                                                      // x values: low halves stay zero (ds_read_u16_d16_hi)
-#pragma unroll
-    for (int i = 0; i < 5; ++i) { xf[i][0] = 0.f; xf[i][1] = 0.f; xf[i][2] = 0.f; xf[i][3] = 0.f; }
     int slot = 3;
     for (int n = 0; n < NC; ++n) {
         // stage n has landed when at most the three younger stages' pieces are outstanding (quarter 0's two result stores are older)
         // (lgkmcnt: the raw s_barrier does not wait for this wave's LDS store of its quarter state -- without it the quarter-0 waves
         // read a stale state once in ~80 forwards)
-        if (four2) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+        if (a.dbg & 8) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if (four2) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                    // ... everyone's; stage n - 1 is read out; its states are published
         asm volatile("" ::: "memory");
-        if (n > 0) finish(n - 1);
+        if (n > 0 && (n & 3) == 0) finish((n >> 2) - 1);
         issue2(n + 4, slot == 0 ? 4 : slot - 1);                         // the slot stage n - 1 used
         const char* st = smem + slot * AU_STAGE2;
         bf16x8 wf[4];
@@ -280,19 +283,15 @@ __global__ __launch_bounds__(AU_THREADS, 1) void asp_utt_kernel(const AspUttArgs
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) lg[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf[i][ks], wf[ks], lg[i], 0, 0, 0);
         }
-        // the lane's 20 x values, one address register (offset (i, r) = i * 1024 + r * 64), by ds_read_u16_d16_hi: the bf16 lands in the
-        // HIGH half of a register whose low half stays zero = the f32 value, no conversion instruction.  Inline asm (no builtin): hipcc
-        // does not count these reads, the lgkmcnt(0) below does (its own counted waits only get stronger by them).
-        {
-            const unsigned xa = (unsigned)(uintptr_t)(st + xoff);
+        // the lane's 20 x values (offset (i, r) = i * 1024 + r * 64 from one address).  Plain ds_read_u16 + shift: an inline-asm
+        // ds_read_u16_d16_hi (bf16 straight into the high half, no shift) measured 6-7 of 200 launches with one wave's block-0 result
+        // off on a box where this form gave 0 of 200 twice (same session, tools/asp_determinism.py) -- not pursued further.
+        float xf[5][4];
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                asm volatile("ds_read_u16_d16_hi %0, %4 offset:%5\n\tds_read_u16_d16_hi %1, %4 offset:%6\n\t"
-                             "ds_read_u16_d16_hi %2, %4 offset:%7\n\tds_read_u16_d16_hi %3, %4 offset:%8"
-                             : "+v"(xf[i][0]), "+v"(xf[i][1]), "+v"(xf[i][2]), "+v"(xf[i][3])
-                             : "v"(xa), "i"(i * 1024), "i"(i * 1024 + 64), "i"(i * 1024 + 128), "i"(i * 1024 + 192));
-            }
-        }
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                xf[i][r] = __builtin_bit_cast(float, (unsigned)*reinterpret_cast<const unsigned short*>(st + xoff + i * 1024 + r * 64) << 16);
         float mraw = -1e30f, s0 = 0.f, s1 = 0.f, s2 = 0.f, t0 = 0.f, t1 = 0.f, t2 = 0.f;
         // two instances of the statistics: a quarter that holds frames past T (wave-uniform) masks them by SELECTS -- their logits and x
         // values may be anything (rows past T of a stage are whatever the LDS held), and a lane may have no live frame at all
@@ -308,9 +307,6 @@ __global__ __launch_bounds__(AU_THREADS, 1) void asp_utt_kernel(const AspUttArgs
                 for (int i = 0; i < 5; ++i) mraw = fmaxf(fmaxf(mraw, fmaxf(lg[i][0], lg[i][1])), fmaxf(lg[i][2], lg[i][3]));
             }
             const float moff = -mraw * AU_LOG2E;
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[0][0]), "+v"(xf[0][1]), "+v"(xf[0][2]), "+v"(xf[0][3]), "+v"(xf[1][0]), "+v"(xf[1][1]),
-                         "+v"(xf[1][2]), "+v"(xf[1][3]), "+v"(xf[2][0]), "+v"(xf[2][1]), "+v"(xf[2][2]), "+v"(xf[2][3]), "+v"(xf[3][0]),
-                         "+v"(xf[3][1]), "+v"(xf[3][2]), "+v"(xf[3][3]), "+v"(xf[4][0]), "+v"(xf[4][1]), "+v"(xf[4][2]), "+v"(xf[4][3]));
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
 #pragma unroll
@@ -338,16 +334,13 @@ __global__ __launch_bounds__(AU_THREADS, 1) void asp_utt_kernel(const AspUttArgs
             for (int off = 16; off < 64; off <<= 1)
                 au_merge<false>(mx, s0, s1, s2, __shfl_xor(mx, off), __shfl_xor(s0, off), __shfl_xor(s1, off), __shfl_xor(s2, off));
         }
-        if (g == 0) {
-            if (fq == 0) { pm = mx; ps0 = s0; ps1 = s1; ps2 = s2; }
-            else *reinterpret_cast<float4*>(mg + ((n & 1) * 2 + ct) * 192 + (fq - 1) * 64 + li * 4) = make_float4(mx, s0, s1, s2);
-        }
+        if (g == 0) *reinterpret_cast<float4*>(mg + (((((n >> 2) & 1) * 4 + (n & 3)) * 2 + ct) * 4 + fq) * 64 + li * 4) = make_float4(mx, s0, s1, s2);
         slot = slot == 4 ? 0 : slot + 1;
         if (n < 8 || n == NC - 1) stamp(3 + (n < 8 ? n : 8));
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    if (NC > 0) finish(NC - 1);
+    if (NC > 0) finish((NC - 1) >> 2);
     stamp(12);
 }
 
@@ -355,11 +348,10 @@ __global__ __launch_bounds__(AU_THREADS, 1) void asp_utt_kernel(const AspUttArgs
 
 // VP_EUNSUP when the shape is not covered (the caller runs the conv GEMM + asp_fused pair instead).
 int vp_asp_utt_bf16(vp_ctx* ctx, const void* x, int ldx, const vp_tdnn_layer* tdnn, const float* rowbias, const void* conv_w,
-                    const float* conv_b, const float* center, int ldc, int B, int T, int C, int att, float eps, float* pooled,
-                    hipStream_t st) {
+                    const float* conv_b, int B, int T, int C, int att, float eps, float* pooled, hipStream_t st) {
     static const bool off = getenv("VPMI_ASP_SPLIT") != nullptr;      // A/B: the two-launch path
-    if (off || att != AU_ATT || T < 1 || T > AU_MAXT || C < 64 || C % 64 || C > AU_MAXC || (ldx & 7) || !tdnn->bn_scale || !tdnn->bn_shift || !tdnn->bias ||
-        tdnn->cin != C || tdnn->cout != att || tdnn->kw != 1 || !center ||
+    if (off || att != AU_ATT || T < 1 || T > AU_MAXT || C < 64 || C % 64 || (ldx & 7) || !tdnn->bn_scale || !tdnn->bn_shift || !tdnn->bias ||
+        tdnn->cin != C || tdnn->cout != att || tdnn->kw != 1 ||
         ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(tdnn->w) | reinterpret_cast<uintptr_t>(conv_w)) & 15) ||
         (size_t)T * ldx * 2 >= 0xe0000000ull)
         return VP_EUNSUP;
@@ -370,8 +362,9 @@ int vp_asp_utt_bf16(vp_ctx* ctx, const void* x, int ldx, const vp_tdnn_layer* td
     }
     AspUttArgs a;
     a.x = (const bf16_t*)x; a.wt = (const bf16_t*)tdnn->w; a.bias = tdnn->bias; a.rowbias = rowbias; a.bn_scale = tdnn->bn_scale;
-    a.bn_shift = tdnn->bn_shift; a.wc = (const bf16_t*)conv_w; a.cbias = conv_b; a.center = center; a.pooled = pooled;
-    a.ldx = ldx; a.ldc = ldc; a.T = T; a.C = C; a.eps = eps;
+    a.bn_shift = tdnn->bn_shift; a.wc = (const bf16_t*)conv_w; a.pooled = pooled;
+    (void)conv_b;                                                        // constant over time: cancels in the softmax
+    a.ldx = ldx; a.T = T; a.C = C; a.eps = eps;
     { static const int dbg = getenv("VPMI_ASP_DBG") ? atoi(getenv("VPMI_ASP_DBG")) : 0; a.dbg = dbg; }
     a.stamps = nullptr;
     if (a.dbg & 256) {                                                   // timing study only: synchronises and prints

@@ -52,8 +52,7 @@ int vp_run_asp(vp_ctx* ctx, const vp_asp_weights& A, int dtype, const void* x, i
         if (rc) return rc;
     }
     if (dtype == VP_BF16) {                       // one kernel per utterance: attention TDNN + logits + softmax + weighted statistics
-        rc = vp_asp_utt_bf16(ctx, x, ldx, &A.tdnn, A.w_ctx ? w.rowbias : nullptr, A.conv_w, A.conv_b, w.stats, 2 * C, B, T, C, A.att, 1e-12f,
-                             w.pooled, st);
+        rc = vp_asp_utt_bf16(ctx, x, ldx, &A.tdnn, A.w_ctx ? w.rowbias : nullptr, A.conv_w, A.conv_b, B, T, C, A.att, 1e-12f, w.pooled, st);
         if (rc != VP_EUNSUP) return rc;
     }
     vp_conv1d_desc d;
@@ -141,6 +140,14 @@ int vp_res2_chain_fwd(vp_ctx* ctx, const vp_tdnn_layer* layers, int nconv, const
     if (!ctx || !layers || !t1 || !r2 || B <= 0 || T <= 0 || C <= 0) VP_FAIL(ctx, VP_EINVAL, "res2_chain: bad arguments");
     const int rc = vp_res2_chain_bf16(ctx, layers, nconv, t1, r2, B, T, C, width, (hipStream_t)stream);
     if (rc == VP_EUNSUP) VP_FAIL(ctx, VP_EUNSUP, "res2_chain: shape not covered by the fused kernel (width 64, equal dilations, 2 <= T <= 384)");
+    return rc;
+}
+
+int vp_asp_utt_fwd(vp_ctx* ctx, const void* x, int ldx, const vp_tdnn_layer* tdnn, const float* rowbias, const void* conv_w,
+                   const float* conv_b, int B, int T, int C, int att, float eps, float* pooled, vp_stream stream) {
+    if (!ctx || !x || !tdnn || !conv_w || !pooled || B <= 0) VP_FAIL(ctx, VP_EINVAL, "asp_utt: bad arguments");
+    const int rc = vp_asp_utt_bf16(ctx, x, ldx, tdnn, rowbias, conv_w, conv_b, B, T, C, att, eps, pooled, (hipStream_t)stream);
+    if (rc == VP_EUNSUP) VP_FAIL(ctx, VP_EUNSUP, "asp_utt: shape not covered (attention width 128, C %% 64 == 0, T <= 304, 1x1 TDNN with BatchNorm)");
     return rc;
 }
 

@@ -317,6 +317,7 @@ _PROTOS = {
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'vp_pointwise_fwd': (c_int, [c_void_p, C.POINTER(Conv1dDesc), c_void_p]),
     'vp_res2_chain_fwd': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'vp_asp_utt_fwd': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     'vp_asp_fused_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                  c_float, c_void_p, c_void_p]),
     'vp_se_gate_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
