@@ -945,6 +945,49 @@ def test_asp_fused_kernel_vs_float64(N, B, T, Cc):
     assert err.max().item() < 2e-4 * max(1.0, ref.abs().max().item()), err.max().item()
 
 
+@pytest.mark.parametrize('B,T,Cc', [(3, 298, 1536), (2, 64, 1536), (5, 241, 512), (2, 304, 192), (4, 17, 64)])
+def test_asp_utt_kernel_vs_float64(N, B, T, Cc):
+    """vp_asp_utt_fwd -- the whole AttentiveStatisticsPooling.forward (pooling.py:105-123) of the bf16 engine in one kernel per
+    utterance -- against float64 over the same bf16 operands: attention TDNN (1x1 + per-utterance bias + ReLU + BN + tanh), logits,
+    softmax over time, weighted mean / std.  Lengths that leave whole frame quarters empty (T = 64: three of four; T = 17), that end
+    inside a quarter (241), the longest covered (304); channel counts of ECAPA (1536), TDNN-style (512) and narrow (192, 64).
+    Also: twenty launches must be bit-identical (a first version with inline-asm d16 loads was not)."""
+    lib, ctx = N.lib(), N.ctx(0)
+    att = 128
+    g = torch.Generator().manual_seed(T + Cc)
+    x = _bf(torch.randn(B, T, Cc, generator=g, dtype=torch.float64) * 2 + 0.5 * torch.randn(1, 1, Cc, generator=g, dtype=torch.float64))
+    wt = _bf(torch.randn(att, Cc, generator=g, dtype=torch.float64) / Cc ** 0.5)
+    wc = _bf(torch.randn(Cc, att, generator=g, dtype=torch.float64) * (3.0 / att ** 0.5))
+    bias = torch.randn(att, generator=g, dtype=torch.float64).float().double()
+    sc = (torch.rand(att, generator=g, dtype=torch.float64) + 0.5).float().double()
+    sh = (torch.randn(att, generator=g, dtype=torch.float64) * 0.1).float().double()
+    rb = (torch.randn(B, att, generator=g, dtype=torch.float64) * 0.3).float().double()
+    cb = torch.randn(Cc, generator=g, dtype=torch.float64).float().double()           # constant over time: must not matter
+    h = _bf(torch.tanh(torch.relu(x @ wt.t() + bias + rb[:, None, :]) * sc + sh))      # the kernel keeps h as bf16
+    e = h @ wc.t() + cb
+    al = torch.softmax(e, dim=1)
+    mu = (al * x).sum(1)
+    sd = torch.sqrt(((al * x * x).sum(1) - mu * mu).clamp(min=1e-12))
+    ref = torch.cat([mu, sd], 1)
+    xd, wtd, wcd = dev(x.reshape(B * T, Cc), torch.bfloat16), dev(wt, torch.bfloat16), dev(wc, torch.bfloat16)
+    bd, scd, shd, rbd, cbd = (dev(t, torch.float32) for t in (bias, sc, sh, rb, cb))
+    L = N.TdnnLayer()
+    L.w, L.bias, L.bn_scale, L.bn_shift, L.cin, L.cout, L.kw, L.dil = wtd.data_ptr(), bd.data_ptr(), scd.data_ptr(), shd.data_ptr(), Cc, att, 1, 1
+    outs = []
+    for _ in range(20):
+        pooled = torch.full((B, 2 * Cc), float('nan'), dtype=torch.float32, device='cuda')
+        N.check(lib.vp_asp_utt_fwd(ctx, xd.data_ptr(), Cc, C.byref(L), rbd.data_ptr(), wcd.data_ptr(), cbd.data_ptr(), B, T, Cc, att, 1e-12,
+                                   pooled.data_ptr(), N.stream_ptr()), ctx)
+        torch.cuda.synchronize()
+        outs.append(pooled)
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
+    assert not torch.isnan(outs[0]).any()
+    err = (outs[0].double().cpu() - ref).abs()
+    # h is rounded to bf16 between the two GEMMs (as the two-launch path stores it): a logit moves by ~|w_c| 2^-9 sqrt(att)
+    print(f'[asp_utt B={B} T={T} C={Cc}] max err mean {err[:, :Cc].max().item():.3e} std {err[:, Cc:].max().item():.3e} (max |ref| {ref.abs().max().item():.2f})')
+    assert err.max().item() < 2e-2 * max(1.0, ref.abs().max().item()), err.max().item()
+
+
 def test_asp_fused_softmax_survives_a_spike(N):
     """One frame whose logit dominates (the online softmax's new-maximum path): weights collapse on it, mean = its x, std = floor."""
     lib, ctx = N.lib(), N.ctx(0)

@@ -25,7 +25,9 @@ def _cos_rows(a, b):
 # 1e-4 everywhere.  bf16 storage of activations (2^-9 relative per element, f32 accumulation and statistics) meets 1e-4 on ECAPA-TDNN /
 # TDNN (tests above and tests/test_gpu_timed_path.py); on the deep 2-D backbones it does not: their measured bound is asserted here,
 # printed, and stated in README.md -- which is why 'float32' is the package default (ppvector.set_compute_dtype) and bf16 is opt-in.
-BF16_SCORE_BOUND = {'campplus': 1.5e-3, 'resnetse': 3e-3, 'eres2net': 6e-3}
+# Bounds = ~2 x the values measured on MI355X (profiles/r04_gpu_parity.log: CAM++ 1.1e-6, ResNetSE 2.1e-4, ERes2Net-large 1.8e-4): a
+# regression to 2e-3 must fail.  model.engine('bfloat16') of ResNetSE / ERes2Net warns that it is outside the reference tolerance.
+BF16_SCORE_BOUND = {'campplus': 4e-6, 'resnetse': 4.5e-4, 'eres2net': 4e-4}
 
 
 def _score_err(emb, ref):
@@ -678,3 +680,20 @@ def test_other_backbones_concurrent_launch_sequences_bit_identical(name):
                 bad[S] += int(not torch.equal(e, ref))
         print(f'[{name} {dt}] forwards as 2 / 4 launch sequences differing from the same shards run one after the other: {bad}')
         assert bad == {2: 0, 4: 0}, (name, dt, bad)
+
+
+def test_bf16_engine_of_the_2d_backbones_warns_about_the_reference_tolerance():
+    """ResNetSE / ERes2Net: the bf16 engine's all-pairs scores sit at ~2e-4 from the f32 reference, outside north_star's 1e-4 -- asking for
+    it must say so (f32 is the default and meets 1e-4); ECAPA-TDNN and CAM++ stay silent."""
+    import warnings
+    from ppvector.models.campplus import CAMPPlus
+    from ppvector.models.ecapa_tdnn import EcapaTdnn
+    from ppvector.models.resnet_se import ResNetSE
+    for cls, feat, expect in ((ResNetSE, 64, True), (EcapaTdnn, 80, False), (CAMPPlus, 80, False)):
+        m = cls(feat, embd_dim=192).cuda().eval()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            m.engine('bfloat16')
+            m.engine('float32')
+        hit = [x for x in w if 'reference tolerance' in str(x.message)]
+        assert bool(hit) == expect, (cls.__name__, [str(x.message) for x in w])

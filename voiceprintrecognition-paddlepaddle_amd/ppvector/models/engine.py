@@ -487,6 +487,11 @@ class EngineMixin:
         cache = self.__dict__.setdefault('_engines', {})
         e = cache.get(dtype_name)
         if e is None or e.versions != _versions(self) or e.device != next(self.parameters()).device:
+            if dtype_name == 'bfloat16' and getattr(self, '_bf16_outside_tolerance', False):
+                import warnings
+                warnings.warn(f'{type(self).__name__}: the bf16 engine differs from the f32 reference by ~2e-4 on all-pairs cosine scores '
+                              '(measured on MI355X, tests/test_gpu_models.py) -- outside the 1e-4 reference tolerance; the f32 engine '
+                              '(the default) meets it', RuntimeWarning, stacklevel=2)
             with torch.no_grad():
                 e = self._engine_cls(self, dtype_name)
             cache[dtype_name] = e

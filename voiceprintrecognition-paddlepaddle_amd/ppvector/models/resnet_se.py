@@ -53,6 +53,7 @@ class SEBottleneck(nn.Module):
 
 
 class ResNetSE(EngineMixin, nn.Module):
+    _bf16_outside_tolerance = True          # engine('bfloat16') warns (models/engine.py)
     _engine_cls = ResNetSEEngine
 
     def __init__(self, input_size, layers=[3, 4, 6, 3], num_filters=[32, 64, 128, 256], embd_dim=192,
