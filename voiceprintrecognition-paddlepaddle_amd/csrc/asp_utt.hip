@@ -52,8 +52,7 @@ struct AspUttArgs {
     const bf16_t* wc;       // [C][128]
     float* pooled;          // (B, 2C)
     int ldx, T, C; float eps;
-    unsigned long long* stamps;   // timing study (VPMI_ASP_DBG bit 256): s_memtime of workgroup 0, wave 0
-    int dbg;                // timing study (VPMI_ASP_DBG): 1 = no phase-1 K loop, 2 = no phase-2 block loop, 256 = print s_memtime stamps
+    int dbg;                // timing study (VPMI_ASP_DBG, tools/prof_asp.sh): 1 = no phase-1 K loop, 2 = no phase-2 block loop
 };
 
 __device__ __forceinline__ float au_tanh(float v) {
@@ -91,8 +90,6 @@ __global__ __launch_bounds__(AU_THREADS, 1) void asp_utt_kernel(const AspUttArgs
     const int li = lane & 15, g = lane >> 4;
     const int b = blockIdx.x;
     const int T = a.T, C = a.C;
-    auto stamp = [&](int i) { if (a.stamps && b == 0 && tid == 0) a.stamps[i] = __builtin_readcyclecounter(); };
-    stamp(0);
     const bf16_t* xb = a.x + (size_t)b * T * a.ldx;
     // rows past T read as zeros: the descriptor ends with the utterance
     const unsigned xbytes = (unsigned)(((size_t)(T - 1) * a.ldx + C) * 2);
@@ -142,11 +139,10 @@ __global__ __launch_bounds__(AU_THREADS, 1) void asp_utt_kernel(const AspUttArgs
     int slot = 0;
     for (int k = 0; k < NK; ++k) {
         // stage k has landed when at most the three younger stages' pieces are outstanding
-        if ((a.dbg & 4) || ((a.dbg & 32) && k + 4 > NK)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (four) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        if (four) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                    // ... everyone's, and everyone is done reading stage k - 1
         asm volatile("" ::: "memory");
-        if (!((a.dbg & 32) && k + 4 >= NK)) issue(k + 4, slot == 0 ? AU_NST - 1 : slot - 1);                 // into the buffer stage k - 1 used
+        issue(k + 4, slot == 0 ? AU_NST - 1 : slot - 1);                 // into the buffer stage k - 1 used
         const int so = slot * AU_STAGE;
         bf16x8 xf[5], wf[4];
 #pragma unroll
@@ -161,7 +157,6 @@ __global__ __launch_bounds__(AU_THREADS, 1) void asp_utt_kernel(const AspUttArgs
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the tail's zero-fill DMAs still target the ring
     __syncthreads();                                                     // the ring is dead
-    stamp(1);
     // h = tanh(bn(relu(acc + bias + rowbias))) -> bf16 rows in LDS [0, 76 KB), 16-byte chunks XOR-swizzled by row & 15 (the A-operand
     // layout of phase 2).  acc[mi][ni][r]: frame wm*80 + mi*16 + li, att wn*64 + ni*16 + g*4 + r.  (Ordinary loads: no DMA in flight here.)
 #pragma unroll
@@ -209,7 +204,7 @@ __global__ __launch_bounds__(AU_THREADS, 1) void asp_utt_kernel(const AspUttArgs
         __builtin_amdgcn_raw_ptr_buffer_load_lds(csrd, (au_lds_t)(st + AU_XST2 + wv * 1024), 16, co, 0, 0, 0);
     };
     // stages 0 and 1 go to slots 3 and 4, which lie above the h image; the wave then pulls its h fragments
-    if (!(a.dbg & 16)) { issue2(0, 3); issue2(1, 4); }
+    issue2(0, 3); issue2(1, 4);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                        // every wave's rows of h (and the centres) are in LDS
     asm volatile("" ::: "memory");
@@ -228,12 +223,11 @@ __global__ __launch_bounds__(AU_THREADS, 1) void asp_utt_kernel(const AspUttArgs
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                        // everyone holds its fragments: the h image is dead
     asm volatile("" ::: "memory");
-    if (a.dbg & 16) { issue2(0, 3); issue2(1, 4); }
     issue2(2, 0); issue2(3, 1);
-    stamp(2);
     // frames of this lane: t(i, r) = (5 fq + i) * 16 + 4 g + r; whole tiles past T only in the last quarter(s)
     const int tbase = fq * 80 + g * 4;
     const bool tail = fq * 80 + 80 > T;                                  // wave-uniform: this quarter holds frames past T
+    const int qlive = T - fq * 80;                                       // live frames of the quarter (may be <= 0 or > 80)
     // x values of channel ct*16 + li: chunk ct*2 + (li >> 3) of the 64-byte row, swizzled by (row >> 2) & 3 = g
     const int xoff = tbase * 64 + ((((ct * 2 + (li >> 3)) ^ ((g & 1) << 1))) << 4) + (li & 7) * 2;
     const int woff = AU_XST2 + (ct * 16 + li) * 256;
@@ -261,87 +255,146 @@ __global__ __launch_bounds__(AU_THREADS, 1) void asp_utt_kernel(const AspUttArgs
             }
         }
     };
-    int slot = 3;
-    for (int n = 0; n < NC; ++n) {
-        // stage n has landed when at most the three younger stages' pieces are outstanding (quarter 0's two result stores are older)
-        // (lgkmcnt: the raw s_barrier does not wait for this wave's LDS store of its quarter state -- without it the quarter-0 waves
-        // read a stale state once in ~80 forwards)
-        if (a.dbg & 8) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else if (four2) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                    // ... everyone's; stage n - 1 is read out; its states are published
-        asm volatile("" ::: "memory");
-        if (n > 0 && (n & 3) == 0) finish((n >> 2) - 1);
-        issue2(n + 4, slot == 0 ? 4 : slot - 1);                         // the slot stage n - 1 used
+    // The block loop is software-pipelined inside every wave: iteration n issues block n's MFMAs and x reads, then takes the statistics
+    // of block n - 1 from the registers the previous iteration filled.  Measured with s_memtime stamps per wave (round 4, B = 256,
+    // T = 298): a block takes ~4.2 k cycles = top (wait + barrier + DMA issue) ~1.1 k, front ~0.8 k, back ~2.4 k.  The back stretch is
+    // VALU issue of the TWO waves that share a SIMD (2 x (170 VALU x 4 + 20 v_exp x 16) cycles): the older wave (0-3) finishes its
+    // statistics in ~1.2 k cycles and waits at the barrier, the younger one (4-7) gets the issue slots it leaves and finishes ~1 k
+    // later -- also when its quarter is entirely past T and it has nothing to compute.  The per-block barrier keeps all eight waves in
+    // the same phase, so the VALU idles through top + front; a ring with two blocks per barrier does not fit the LDS beside the merge area.
+    auto front = [&](int slot, f32x4 (&lg)[5], unsigned short (&xr)[5][4]) {       // block in `slot`: logits + its x values
         const char* st = smem + slot * AU_STAGE2;
         bf16x8 wf[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) wf[ks] = *reinterpret_cast<const bf16x8*>(st + woff + (((ks * 4 + g) ^ li) << 4));
-        f32x4 lg[5];
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             lg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) lg[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf[i][ks], wf[ks], lg[i], 0, 0, 0);
         }
-        // the lane's 20 x values (offset (i, r) = i * 1024 + r * 64 from one address).  Plain ds_read_u16 + shift: an inline-asm
+        // the lane's 20 x values (offset (i, r) = i * 1024 + r * 64 from one address).  Plain ds_read_u16: an inline-asm
         // ds_read_u16_d16_hi (bf16 straight into the high half, no shift) measured 6-7 of 200 launches with one wave's block-0 result
         // off on a box where this form gave 0 of 200 twice (same session, tools/asp_determinism.py) -- not pursued further.
-        float xf[5][4];
 #pragma unroll
         for (int i = 0; i < 5; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                xf[i][r] = __builtin_bit_cast(float, (unsigned)*reinterpret_cast<const unsigned short*>(st + xoff + i * 1024 + r * 64) << 16);
+            for (int r = 0; r < 4; ++r) xr[i][r] = *reinterpret_cast<const unsigned short*>(st + xoff + i * 1024 + r * 64);
+    };
+    auto back = [&](int n, const f32x4 (&lg)[5], const unsigned short (&xr)[5][4]) {       // statistics of block n -> its quarter state
         float mraw = -1e30f, s0 = 0.f, s1 = 0.f, s2 = 0.f, t0 = 0.f, t1 = 0.f, t2 = 0.f;
-        // two instances of the statistics: a quarter that holds frames past T (wave-uniform) masks them by SELECTS -- their logits and x
-        // values may be anything (rows past T of a stage are whatever the LDS held), and a lane may have no live frame at all
-        auto stats = [&](auto masked) {
-            constexpr bool MASKED = decltype(masked)::value;
-            if constexpr (MASKED) {
-#pragma unroll
-                for (int i = 0; i < 5; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) mraw = (tbase + i * 16 + r < T) ? fmaxf(mraw, lg[i][r]) : mraw;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 5; ++i) mraw = fmaxf(fmaxf(mraw, fmaxf(lg[i][0], lg[i][1])), fmaxf(lg[i][2], lg[i][3]));
-            }
-            const float moff = -mraw * AU_LOG2E;
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool live = !MASKED || tbase + i * 16 + r < T;
-                    float p = __builtin_amdgcn_exp2f(fmaf(lg[i][r], AU_LOG2E, moff));
-                    float xv = xf[i][r];
-                    if (MASKED) { p = live ? p : 0.f; xv = live ? xv : 0.f; }
-                    const float tp = p * xv;
-                    if (r & 1) { t0 += p; t1 += tp; t2 = fmaf(tp, xv, t2); }         // two accumulator sets: shorter dependency chains
-                    else { s0 += p; s1 += tp; s2 = fmaf(tp, xv, s2); }
-                }
-            }
+        // A tile of 16 frames is wave-uniformly whole, cut by T, or past T: whole tiles run the plain code, tiles past T are skipped,
+        // and the (at most one) cut tile masks its dead frames by ONE select on the softmax weight -- the x values and logits of frames
+        // past T are finite (zero fill), so 0 x them is 0.  v_max3 by hand: fmaxf() costs a canonicalising v_max per MFMA output.
+        auto max4 = [&](const f32x4& v) {
+            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mraw) : "v"(v[0]), "v"(v[1]));
+            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mraw) : "v"(v[2]), "v"(v[3]));
         };
-        if (tail) stats(std::true_type{}); else stats(std::false_type{});
-        s0 += t0; s1 += t1; s2 += t2;
-        float mx = mraw * AU_LOG2E;                                      // log2 domain, like au_merge
-        // the four frame groups of a channel (lanes l, l ^ 16, l ^ 32, l ^ 48)
-        if (tail) {
+        if (!tail) {
 #pragma unroll
-            for (int off = 16; off < 64; off <<= 1)
-                au_merge<true>(mx, s0, s1, s2, __shfl_xor(mx, off), __shfl_xor(s0, off), __shfl_xor(s1, off), __shfl_xor(s2, off));
+            for (int i = 0; i < 5; ++i) max4(lg[i]);
         } else {
 #pragma unroll
-            for (int off = 16; off < 64; off <<= 1)
-                au_merge<false>(mx, s0, s1, s2, __shfl_xor(mx, off), __shfl_xor(s0, off), __shfl_xor(s1, off), __shfl_xor(s2, off));
+            for (int i = 0; i < 5; ++i) {
+                const int lim = qlive - i * 16;                           // live frames of tile i (wave-uniform)
+                if (lim >= 16) max4(lg[i]);
+                else if (lim > 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mraw = (g * 4 + r < lim) ? fmaxf(mraw, lg[i][r]) : mraw;
+                }
+            }
         }
-        if (g == 0) *reinterpret_cast<float4*>(mg + (((((n >> 2) & 1) * 4 + (n & 3)) * 2 + ct) * 4 + fq) * 64 + li * 4) = make_float4(mx, s0, s1, s2);
+        // The channel's four lanes (l, l ^ 16, l ^ 32, l ^ 48) agree on ONE maximum before the exponentials, so their sums add up
+        // without rescaling.  v_permlane32_swap a, b exchanges a's lanes 32-63 with b's lanes 0-31: with a = b = v, a (op) b is
+        // v[l] (op) v[l ^ 32] in every lane; v_permlane16_swap does the same for the 16-lane rows.
+        {
+            float u = mraw, w = mraw;
+            asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(u), "+v"(w));
+            asm("v_max_f32 %0, %1, %2" : "=v"(mraw) : "v"(u), "v"(w));
+            u = mraw; w = mraw;
+            asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(u), "+v"(w));
+            asm("v_max_f32 %0, %1, %2" : "=v"(mraw) : "v"(u), "v"(w));
+        }
+        const float moff = -mraw * AU_LOG2E;
+        auto tile = [&](int i, auto masked, int lim) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float p = __builtin_amdgcn_exp2f(fmaf(lg[i][r], AU_LOG2E, moff));
+                const float xv = __builtin_bit_cast(float, (unsigned)xr[i][r] << 16);
+                if constexpr (decltype(masked)::value) p = (g * 4 + r < lim) ? p : 0.f;
+                const float tp = p * xv;
+                if (r & 1) { t0 += p; t1 += tp; t2 = fmaf(tp, xv, t2); }             // two accumulator sets: shorter dependency chains
+                else { s0 += p; s1 += tp; s2 = fmaf(tp, xv, s2); }
+            }
+        };
+        if (!tail) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) tile(i, std::false_type{}, 16);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int lim = qlive - i * 16;
+                if (lim >= 16) tile(i, std::false_type{}, 16);
+                else if (lim > 0) tile(i, std::true_type{}, lim);
+            }
+        }
+        s0 += t0; s1 += t1; s2 += t2;
+        // butterfly: swap32(s0, s1) leaves sum s0 in lanes 0-31 and sum s1 in lanes 32-63; s2 against itself; swap16 of the two then
+        // gives row 0 = S0, row 1 = S2, row 2 = S1 (row 3 = S2 again): lane (g, li) stores ONE word of channel li's state
+        {
+            float w = s2;
+            asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(s0), "+v"(s1));
+            asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(s2), "+v"(w));
+            float u = s0 + s1;
+            w += s2;
+            asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(u), "+v"(w));
+            u += w;
+            const float word = g == 3 ? mraw * AU_LOG2E : u;             // log2 domain, like au_merge
+            const int comp = g == 0 ? 1 : g == 1 ? 3 : g == 2 ? 2 : 0;
+            mg[(((((n >> 2) & 1) * 4 + (n & 3)) * 2 + ct) * 4 + fq) * 64 + li * 4 + comp] = word;
+        }
+    };
+    int slot = 3, nextG = 0;
+    // top of iteration n: stage n has landed when at most the three younger stages' pieces are outstanding (the finishing waves' result
+    // stores are older); lgkmcnt: the raw s_barrier does not wait for this wave's LDS store of its quarter state.  After the barrier:
+    // everyone's pieces of stage n are in; stage n - 1 is read out (its slot is re-filled 4 stages ahead); the states of block n - 2 are
+    // published -- a group of four blocks is merged as soon as its last state is.
+    auto top = [&](int n) {
+        if (four2) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (n >= 2 && ((n - 2) & 3) == 3) finish(nextG++);              // block n - 2 was the group's last
+        issue2(n + 4, slot == 0 ? 4 : slot - 1);                         // the slot stage n - 1 used
+    };
+    f32x4 lgA[5], lgB[5];
+    unsigned short xrA[5][4], xrB[5][4];
+    if (NC > 0) {
+        top(0);
+        front(slot, lgA, xrA);
         slot = slot == 4 ? 0 : slot + 1;
-        if (n < 8 || n == NC - 1) stamp(3 + (n < 8 ? n : 8));
+        int n = 1;
+        for (; n + 1 < NC; n += 2) {
+            top(n);
+            front(slot, lgB, xrB);
+            back(n - 1, lgA, xrA);
+            slot = slot == 4 ? 0 : slot + 1;
+            top(n + 1);
+            front(slot, lgA, xrA);
+            back(n, lgB, xrB);
+            slot = slot == 4 ? 0 : slot + 1;
+        }
+        if (n < NC) {                                                    // NC even: one block left for the B set
+            top(n);
+            front(slot, lgB, xrB);
+            back(n - 1, lgA, xrA);
+            back(n, lgB, xrB);
+        } else {
+            back(n - 1, lgA, xrA);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    if (NC > 0) finish((NC - 1) >> 2);
-    stamp(12);
+    while (nextG * 4 < NC) finish(nextG++);
 }
 
 }  // namespace
@@ -366,22 +419,6 @@ int vp_asp_utt_bf16(vp_ctx* ctx, const void* x, int ldx, const vp_tdnn_layer* td
     (void)conv_b;                                                        // constant over time: cancels in the softmax
     a.ldx = ldx; a.T = T; a.C = C; a.eps = eps;
     { static const int dbg = getenv("VPMI_ASP_DBG") ? atoi(getenv("VPMI_ASP_DBG")) : 0; a.dbg = dbg; }
-    a.stamps = nullptr;
-    if (a.dbg & 256) {                                                   // timing study only: synchronises and prints
-        static int calls = 0;
-        unsigned long long* d = nullptr;
-        if (hipMalloc(&d, 16 * 8) == hipSuccess && hipMemset(d, 0, 16 * 8) == hipSuccess) a.stamps = d;
-        hipLaunchKernelGGL(asp_utt_kernel, dim3(B), dim3(AU_THREADS), AU_SMEM, st, a);
-        (void)hipDeviceSynchronize();
-        unsigned long long h[16];
-        if (a.stamps && hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && ++calls <= 3) {
-            fprintf(stderr, "asp_utt stamps (cycles from start): phase1 %llu  setup %llu  blocks", h[1] - h[0], h[2] - h[0]);
-            for (int i = 3; i < 12; ++i) fprintf(stderr, " %llu", h[i] - h[0]);
-            fprintf(stderr, "  end %llu\n", h[12] - h[0]);
-        }
-        (void)hipFree(d);
-        return VP_OK;
-    }
     hipLaunchKernelGGL(asp_utt_kernel, dim3(B), dim3(AU_THREADS), AU_SMEM, st, a);
     VP_LAUNCH_CHECK(ctx, "asp_utt");
     return VP_OK;
