@@ -985,7 +985,8 @@ def test_asp_utt_kernel_vs_float64(N, B, T, Cc):
     err = (outs[0].double().cpu() - ref).abs()
     # h is rounded to bf16 between the two GEMMs (as the two-launch path stores it): a logit moves by ~|w_c| 2^-9 sqrt(att)
     print(f'[asp_utt B={B} T={T} C={Cc}] max err mean {err[:, :Cc].max().item():.3e} std {err[:, Cc:].max().item():.3e} (max |ref| {ref.abs().max().item():.2f})')
-    assert err.max().item() < 2e-2 * max(1.0, ref.abs().max().item()), err.max().item()
+    # measured (round 4, MI355X): <= 1.3e-4 over the five shapes, for |ref| ~ 2.5-3.5; the bound is ~2x that
+    assert err.max().item() < 3e-4, err.max().item()
 
 
 def test_asp_fused_softmax_survives_a_spike(N):
