@@ -954,6 +954,40 @@ def test_col_sums_kernel_vs_float64(N, M, C, two):
     assert (got[0].double().cpu() - want0).abs().max().item() <= 2e-6 * a.abs().double().sum(0).max().item()
 
 
+@pytest.mark.parametrize('M,Cout,Cin,ldx,xoff', [(4133, 512, 256, 256, 0), (9000, 256, 768, 1032, 264), (76288, 512, 512, 512, 0), (64, 256, 256, 256, 0),
+                                                  (2500, 1536, 1536, 1536, 0), (3000, 192, 512, 512, 0)])
+def test_wgrad_of_bf16_operands_vs_float64(N, M, Cout, Cin, ldx, xoff):
+    """vp_conv1d_wgrad_bf16_oik on the wide 1x1 layers: the 256-tile kernel on transposing LDS reads (csrc/wgrad_tr.hip; the last case has
+    Cout % 256 != 0 and runs the 128-tile kernel).  bf16 products are exact in f32, so the only error is the f32 accumulation order:
+    1e-5 of sum |dz| |x| per output (measured ~1e-6); twenty launches are bit-identical."""
+    import ctypes as C
+    lib, ctx = N.lib(), N.ctx(torch.device('cuda', 0))
+    g = torch.Generator().manual_seed(M + Cout)
+    x = torch.randn(M, ldx, generator=g).to(torch.bfloat16)
+    dz = (torch.randn(M, Cout, generator=g) * 0.1).to(torch.bfloat16)
+    xd, dzd = x.cuda(), dz.cuda()
+    d = N.Conv1dDesc()
+    d.dtype_in, d.dtype_out = N.VP_BF16, N.VP_F32
+    d.B, d.T_in, d.T_out, d.Cin, d.Cout, d.KW, d.dilation, d.stride = 1, M, M, Cin, Cout, 1, 1, 1
+    d.pad_mode, d.pad_left = N.VP_PAD_ZERO, 0
+    d.x, d.ldx, d.xoff = xd.data_ptr(), ldx, xoff
+    d.mfma_bf16 = 1
+    ws = torch.empty(lib.vp_conv1d_wgrad_workspace_bytes(C.byref(d)), dtype=torch.uint8, device='cuda')
+    outs = []
+    for _ in range(20):
+        dW = torch.full((Cout, Cin), float('nan'), dtype=torch.float32, device='cuda')
+        N.check(lib.vp_conv1d_wgrad_bf16_oik(ctx, C.byref(d), dzd.data_ptr(), Cout, dW.data_ptr(), ws.data_ptr(), ws.numel(), N.stream_ptr()), ctx)
+        torch.cuda.synchronize()
+        outs.append(dW)
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
+    xs = x[:, xoff:xoff + Cin].double()
+    want = dz.double().t() @ xs
+    scale = (dz.double().abs().t() @ xs.abs()).max().item()
+    err = (outs[0].double().cpu() - want).abs().max().item()
+    print(f'[wgrad bf16 M={M} {Cout}x{Cin}] max err {err:.3e} against sum |dz||x| {scale:.3e}')
+    assert err <= 1e-5 * scale, (err, scale)
+
+
 @pytest.mark.parametrize('M,C,relu,gamma', [(76288, 512, 1, True), (4097, 64, 1, True), (300, 128, 0, True), (1000, 1536, 1, False),
                                             (23, 192, 1, True)])
 def test_bn_relu_bwd_dbias_kernel_vs_float64(N, M, C, relu, gamma):

@@ -118,6 +118,9 @@ int vp_run_asp(vp_ctx* ctx, const vp_asp_weights& A, int dtype, const void* x, i
                int B, int T, const VpAspBufs& w, hipStream_t st);
 int vp_asp_utt_bf16(vp_ctx* ctx, const void* x, int ldx, const vp_tdnn_layer* tdnn, const float* rowbias, const void* conv_w,
                     const float* conv_b, int B, int T, int C, int att, float eps, float* pooled, hipStream_t st);
+int vp_wgrad_tr256_splits(long long M, int N, int K);
+int vp_wgrad_tr256_bf16(vp_ctx* ctx, const void* x, int ldx, int xoff, const void* dz, int lddz, long long M, int N, int K, float* part,
+                        int* splits_out, hipStream_t st);
 int vp_conv3x3_c1(vp_ctx* ctx, int dtype, const void* feats, void* out, const float* w, const float* bias,
                   const float* scale, const float* shift, int B, int T, int F, int C, hipStream_t st);
 int vp_se_scale_residual_ex(vp_ctx* ctx, int dtype, const void* x, int ldx, int xoff, const float* s,

@@ -1290,6 +1290,11 @@ size_t vp_conv1d_wgrad_workspace_bytes(const vp_conv1d_desc* d) {
     if (S < 1) S = 1;
     if (S > 256) S = 256;
     if ((long long)S * 64 > M) S = (int)((M + 63) / 64);
+    // the 256-tile kernel of the wide 1x1 layers (wgrad_tr.hip) splits the rows differently
+    if (d->KW == 1 && d->Cout % 256 == 0 && K % 256 == 0 && M >= 32) {
+        const int s2 = vp_wgrad_tr256_splits(M, d->Cout, K);
+        if (s2 > S) S = s2;
+    }
     return (size_t)S * d->Cout * K * sizeof(float) + 256;
 }
 
@@ -1330,7 +1335,17 @@ static int wgrad_impl(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int
     a.stride_f = two_d ? d->stride_f : 1; a.pad_f = two_d ? d->pad_f : 0;
     a.splits = S; a.xb = x_bstride; a.dzb = dz_bstride;
     hipStream_t st = (hipStream_t)stream;
-    if (d->mfma_bf16 || bf_in) {
+    static const bool no_tr256 = getenv("VPMI_WGRAD_TR256_OFF") != nullptr;      // A/B switch (tools/train_probe.py)
+    const bool simple = K == d->Cin && d->stride == 1 && d->pad_left == 0 && d->T_in == d->T_out && !two_d;
+    int tr = VP_EUNSUP;
+    if (bf_in && simple && nbatch == 1 && !no_tr256) {
+        int s2 = 0;
+        tr = vp_wgrad_tr256_bf16(ctx, d->x, d->ldx, d->xoff, dz, lddz, M, d->Cout, K, (float*)ws, &s2, st);
+        if (tr == VP_OK) S = s2;
+        else if (tr != VP_EUNSUP) return tr;
+    }
+    if (tr == VP_OK) {
+    } else if (d->mfma_bf16 || bf_in) {
         constexpr int smem = 2 * 2 * WA_T * 128;
         static bool attr_set = false;
         if (!attr_set) {
