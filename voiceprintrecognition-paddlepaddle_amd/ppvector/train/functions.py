@@ -280,7 +280,8 @@ def _conv_block_bwd(ctx, dy, skip=None, fold=None):
             w2 = weight.view(Cout, Cin).t().to(torch.bfloat16 if wide else torch.float32, memory_format=torch.contiguous_format)
             if not wide:
                 w2 = w2.contiguous()
-        dx = torch.empty((B * T_in, Cin), dtype=torch.float32, device=dev)
+        splits = getattr(ctx, 'out_splits', None) if (KW == 1 and skip is None and fold is None) else None
+        dx = torch.empty((B * T_in, Cin), dtype=torch.float32, device=dev) if not splits else None
         if pad == 'reflect' and pad_left > 0:
             # gradient w.r.t. the reflect-PADDED input (a "full" zero-padded conv), then fold the mirrored frames back
             Tp = T_in + 2 * pad_left
@@ -299,6 +300,20 @@ def _conv_block_bwd(ctx, dy, skip=None, fold=None):
                 _chk(lib.vp_reflect_fold_f32(hctx, dxp.data_ptr(), B, T_in, pad_left, Cin, dx.data_ptr(), N.stream_ptr()), hctx)
             if skip is not None:
                 dx += skip
+        elif splits:
+            # a concatenated input (CatConvBlock): one launch per input over its rows of W^T, each gradient a contiguous tensor of its
+            # own -- a column slice of one wide d x is copied once more when autograd stores it as a leaf's .grad (3 x 55 us on the MFA layer)
+            dx, at = [], 0
+            for wd in splits:
+                part = torch.empty((B * T_in, wd), dtype=torch.float32, device=dev)
+                d2 = _conv_desc(dz, B, T_out, T_in, Cout, wd, 1, 1, N.VP_PAD_ZERO, 0, w2[at:at + wd])
+                if wide:
+                    d2.dtype_in = N.VP_BF16
+                d2.y = part.data_ptr()
+                _chk(lib.vp_conv1d_fwd(hctx, C.byref(d2), N.stream_ptr()), hctx)
+                dx.append(part)
+                at += wd
+            dx = tuple(dx)
         else:
             d2 = _conv_desc(dz, B, T_out, T_in, Cout, Cin, KW, dil, N.VP_PAD_ZERO, dil * (KW - 1) - pad_left, w2)
             if wide:
@@ -347,8 +362,10 @@ class CatConvBlock(torch.autograd.Function):
         tp = _Tape((True,) * 9)
         tp.saved_tensors = ctx.saved_tensors
         tp.geom, tp.wide, widths = ctx.inner
+        tp.out_splits = widths
         r = _conv_block_bwd(tp, dy)
-        return (None, r[1], r[2], r[4], r[5], None, None, *r[0].split(widths, dim=1))
+        dxs = r[0] if isinstance(r[0], tuple) else r[0].split(widths, dim=1)
+        return (None, r[1], r[2], r[4], r[5], None, None, *dxs)
 
 
 class ConvBlockSkip(torch.autograd.Function):

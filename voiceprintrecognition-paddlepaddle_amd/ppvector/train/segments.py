@@ -59,7 +59,19 @@ class Recorder:
         if between is not None:
             between(0)
         for i, (origs, leaves) in enumerate(reversed(self.cuts), start=1):
-            pairs = [(o, l.grad) for o, l in zip(origs, leaves) if l.grad is not None]
+            pairs = []
+            for o, l in zip(origs, leaves):
+                g = l.grad
+                if g is None:
+                    continue
+                l.grad = None
+                if o.grad_fn is None and o.is_leaf and o.grad is None:
+                    # a tensor that only travels through this cut (a leaf of the previous one, consumed further down): its gradient so
+                    # far IS the later leaf's -- handed on as the same tensor (autograd.backward on a leaf would clone it: 60 us per
+                    # (B*T, 512) tensor); what the stage adds to it is accumulated in place by autograd
+                    o.grad = g
+                else:
+                    pairs.append((o, g))
             if pairs:
                 torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
             if between is not None:
