@@ -173,8 +173,9 @@ def roofline_pass(reps):
             'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
             'flop_per_launch': total_flop / n, 'avg_launch_ms': round(total_ms / n, 4),
             'family': {'kernels': 'the 7 ring launches + block0 (80 -> 512, k5: conv_gemm256_kernel<TAPS_GEN>) + the ASP attention TDNN (1536 -> 128 '
-                                  'with per-utterance bias + tanh: whichever kernel vp_conv1d_fwd dispatches for it): 9 launches/step, 90% of '
-                                  'forward flops; timed as back-to-back replays of one buffer set (MALL-warm), NOT the in-step cost',
+                                  'with per-utterance bias + tanh) as the standalone conv vp_conv1d_fwd dispatches -- in the step that GEMM '
+                                  'runs inside asp_utt_kernel since round 4; 90% of forward flops; timed as back-to-back replays of one '
+                                  'buffer set (MALL-warm), NOT the in-step cost',
                        'achieved': round(fam_flop / (fam_ms * 1e-3) / 1e12, 2), 'avg_launch_ms': round(fam_ms / len(per_shape), 4)},
             'launches': per_shape}
 

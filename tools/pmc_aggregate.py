@@ -61,7 +61,7 @@ for k, c in cnt.items():
     out[k] = e
 import hashlib, os  # noqa: E402
 _h = hashlib.sha1()
-for _f in ('conv_gemm256.hip', 'conv_gemm_impl.h', 'conv_gemm.hip'):       # the same hash bench.py compares before quoting roofline.traffic
+for _f in ('conv_gemm256.hip',):       # the same hash bench.py (kernel_git_hash) compares before quoting roofline.traffic
     with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'voiceprintrecognition-paddlepaddle_amd', 'csrc', _f), 'rb') as _fh:
         _h.update(_fh.read())
 json.dump({'csrc_hash': _h.hexdigest()[:12], '_source': f'tools/pmc_step.sh {tag}: rocprofv3 --kernel-trace --pmc <group>, one group per pass, per-launch averages over every launch '

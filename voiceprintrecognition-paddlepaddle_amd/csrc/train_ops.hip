@@ -782,6 +782,14 @@ __global__ __launch_bounds__(256) void pack_segments_kernel(const PackArgs a) {
     const float* __restrict__ src = a.src[sgm];
     float* __restrict__ dst = a.dst + a.off[sgm];
     const long long n = a.n[sgm];
+    // 16 bytes per lane where the segment allows it (the 9.4 MB MFA weight gradient took 63 us at 4 bytes per lane on 64 workgroups)
+    if (src && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        const long long n4 = n >> 2;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
+            reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+        for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = src[i];
+        return;
+    }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = src ? src[i] : 0.f;
 }
 
@@ -1648,7 +1656,7 @@ int vp_pack_segments_f32(vp_ctx* ctx, const void* const* srcs, const long long* 
         a.dst = dst;
         long long bx = (big + 4 * 256 - 1) / (4 * 256);
         if (bx < 1) bx = 1;
-        if (bx > 64) bx = 64;
+        if (bx > 512) bx = 512;
         hipLaunchKernelGGL(pack_segments_kernel, dim3((unsigned)bx, cnt), dim3(256), 0, (hipStream_t)stream, a);
         VP_LAUNCH_CHECK(ctx, "pack_segments");
     }
