@@ -13,4 +13,4 @@ find /tmp/fm_s -name "*kernel_stats.csv" | head -n 1 | xargs -I{} cp {} gpurun_o
 (cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/fm_t -o b -- python3 $GRAFT_REPO_ROOT/bench.py --mode train --global-batch 256 --steps 10 --warmup 5 > $GRAFT_REPO_ROOT/gpurun_out/prof_train_$TAG.log 2>&1)
 find /tmp/fm_t -name "*kernel_stats.csv" | head -n 1 | xargs -I{} cp {} gpurun_out/kernel_stats_train_$TAG.csv
 echo "stats done"; head -n 4 gpurun_out/kernel_stats_infer_$TAG.csv | cut -c1-150
-bash tools/pmc_step.sh infer_$TAG python3 bench.py --steps 6 --warmup 2 --graph 0 --streams 1 --no-cpu-baseline --no-roofline --no-train-line 2>&1 | tail -n 14
+bash tools/pmc_step.sh infer_$TAG python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --graph 0 --streams 1 --no-cpu-baseline --no-roofline --no-train-line 2>&1 | tail -n 14
