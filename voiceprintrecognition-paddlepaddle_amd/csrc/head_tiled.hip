@@ -549,6 +549,9 @@ int vp_cosine_aam_tiled_fwd(vp_ctx* ctx, const float* emb, const float* W, const
                             float* cinv, int* pred, void* ws, size_t ws_bytes, vp_stream stream) {
     if (!ctx || !emb || !W || !labels || !loss || !row_loss || B <= 0 || C <= 0) VP_FAIL(ctx, VP_EINVAL, "cosine_aam_tiled: bad arguments");
     if (C >= (1 << 24)) VP_FAIL(ctx, VP_EUNSUP, "cosine_aam_tiled: %d classes (class indices travel as exact f32)", C);
+    // W and emb are addressed through 32-bit buffer offsets (D = 192: up to ~5.59 M classes)
+    if ((unsigned long long)D * C * 4 >= 0xfffffff0ull || (unsigned long long)B * D * 4 >= 0xfffffff0ull)
+        VP_FAIL(ctx, VP_EUNSUP, "cosine_aam_tiled: W (%d x %d) or emb larger than 4 GiB", D, C);
     if (D < 4 || D > HT_DMAX || (D & 3)) VP_FAIL(ctx, VP_EUNSUP, "cosine_aam_tiled: embedding width %d (multiples of 4 up to %d)", D, HT_DMAX);
     if (!ws || ws_bytes < vp_cosine_aam_tiled_workspace_bytes(B, D, C)) VP_FAIL(ctx, VP_EWORKSPACE, "cosine_aam_tiled: workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -566,11 +569,12 @@ int vp_cosine_aam_tiled_fwd(vp_ctx* ctx, const float* emb, const float* W, const
     a.th = (float)cos(M_PI - (double)margin); a.mmm = (float)(1.0 + cos(M_PI - (double)margin));
     a.scale = scale; a.easy = easy_margin; a.mt = ctx->margin_table;
     const int smem = (D * HT_SW + HT_RF * (D + 2) + HT_CT + HT_RF + 5 * 4 * HT_RF + HT_RF) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};                                 // the attribute is per DEVICE: a process that drives several GPUs sets it on each
+    bool& attr_dev = attr_set[ctx->device & 63];
+    if (!attr_dev) {
         VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(head_tile_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (HT_DMAX * HT_SW + HT_RF * (HT_DMAX + 2) + HT_CT + HT_RF + 5 * 4 * HT_RF + HT_RF) * 4));
-        attr_set = true;
+        attr_dev = true;
     }
     const int rblocks = (B + HT_RF - 1) / HT_RF;
     int ysplit = 1;
@@ -618,11 +622,12 @@ int vp_cosine_aam_tiled_bwd(vp_ctx* ctx, const float* emb, const float* W, const
     a.scale = scale; a.ls = label_smoothing; a.gscale = grad_scale; a.easy = easy_margin; a.mt = ctx->margin_table;
     const int nwg = a.tiles < 256 ? a.tiles : 256;
     const int smem = (D * HT_SW + HT_RB * (D + 2) + HT_RB * HT_SG + 64 * 3 + 4 * 64 + 64) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};
+    bool& attr_dev = attr_set[ctx->device & 63];
+    if (!attr_dev) {
         VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(head_tile_bwd_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (192 * HT_SW + HT_RB * 194 + HT_RB * HT_SG + 64 * 3 + 4 * 64 + 64) * 4));
-        attr_set = true;
+        attr_dev = true;
     }
     hipLaunchKernelGGL(head_tile_bwd_kernel<12>, dim3(nwg), dim3(256), smem, st, a);
     VP_LAUNCH_CHECK(ctx, "head_tile_bwd");

@@ -29,6 +29,7 @@ class AAMLoss(nn.Module):
                     from ppvector.train.functions import HeadLoss
                     loss, pred = HeadLoss.apply(inputs.x, inputs.W, labels, self.margin, self.scale, self.label_smoothing, self.easy_margin)
                     inputs.pred = pred if pred.numel() else None
+                    self.row_loss = None                # (the fused training head reports the mean only; the evaluation paths set row losses)
                     return loss
             elif inputs.W.shape[0] % 4 == 0 and inputs.W.shape[0] <= 256:
                 return self._tiled(inputs, labels)      # evaluation-mode head + loss in one pass over the class weights
@@ -54,6 +55,8 @@ class AAMLoss(nn.Module):
         """csrc/head_tiled.hip: cosine logits (exact f32 matrix cores) -> margin -> online log-sum-exp per 64-class tile, merged per
         row; the (B, C) logits never exist."""
         x, W = inputs.x, inputs.W
+        if not x.is_cuda:
+            raise N.VpmiError('AAMLoss needs GPU tensors: the engine has no CPU fallback')
         labels = labels.to(device=x.device, dtype=torch.int64).reshape(-1).contiguous()
         B, D = x.shape
         Cn = W.shape[1]

@@ -851,7 +851,9 @@ class HeadLoss(torch.autograd.Function):
         Cc = W.shape[1]
         demb, dW = torch.empty_like(emb), torch.empty_like(W)
         loss = torch.empty(1, dtype=torch.float32, device=emb.device)
-        lab = labels.to(torch.int64).contiguous()
+        if not emb.is_cuda:
+            raise N.VpmiError('HeadLoss needs GPU tensors: the engine has no CPU fallback')
+        lab = labels.to(device=emb.device, dtype=torch.int64).reshape(-1).contiguous()       # (labels may arrive on the host)
         rc = N.VP_EUNSUP
         pred = torch.empty((0,), dtype=torch.int32, device=emb.device)
         if B <= 128 and D == 192 and os.environ.get('VPMI_HEAD_UNTILED') is None:
