@@ -66,6 +66,7 @@ def conv_family_shapes(T):
 
 
 PMC_FILE = os.path.join(ROOT, 'profiles', 'r04_pmc_infer.json')
+CPU_THREADS = 32
 
 
 def kernel_git_hash():
@@ -218,7 +219,9 @@ def cpu_baseline(state, W, target_s=15.0):
         avail = len(os.sched_getaffinity(0))
     except Exception:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 32))           # oneDNN/OpenMP oversubscribe badly beyond this on big hosts
+    # thread count: VPMI_CPU_THREADS, else 32 -- the sweep of tools/cpu_threads_sweep.py on the GPU box's host (256 logical CPUs:
+    # profiles/r04_cpu_threads_sweep.log) decides the default; oneDNN / OpenMP oversubscribe badly beyond it
+    cores = max(1, min(avail, int(os.environ.get('VPMI_CPU_THREADS', CPU_THREADS))))
     torch.set_num_threads(cores)
     p = {k: v.detach().cpu().float() for k, v in state.items()}
     W = W.detach().cpu().float()
