@@ -137,7 +137,7 @@ def asp(x, p, prefix, global_context=True, training=False, stats_out=None, eps=1
         return mean, std
 
     if global_context:
-        m = torch.full((B, 1, L), 1.0 / L, dtype=x.dtype)
+        m = torch.full((B, 1, L), 1.0 / L, dtype=x.dtype, device=x.device)
         mean, std = stats(x, m)
         attn = torch.cat([x, mean.unsqueeze(2).expand(B, C, L), std.unsqueeze(2).expand(B, C, L)], dim=1)
     else:
