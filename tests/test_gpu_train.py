@@ -1212,6 +1212,62 @@ def test_res2_chain_one_launch_per_direction_equals_the_per_chunk_path(N, amp, m
         assert e < (fwd_tol if kind in ('out', 'run_mean', 'run_var') else bwd_tol), (kind, e)
 
 
+@pytest.mark.parametrize('S,B,T,dil', [(2, 6, 100, 2), (2, 7, 298, 3), (3, 5, 67, 4), (3, 9, 298, 2)])
+def test_res2_chain_one_launch_per_direction_vs_float64_amp_emulation(N, amp, S, B, T, dil):
+    """vp_res2_train_fwd / _bwd against an INDEPENDENT reference: float64 autograd over the oracle's Res2NetBlock (ecapa_tdnn.py:11-47) with
+    the mixed-precision roundings emulated (conv operands and the conv's output gradient rounded to bf16, everything else exact:
+    oracle/models.py AMP).  Scale 2 and 3, where the chain does not amplify a flipped rounding (see the test above): absolute bounds as a
+    fraction of each tensor's largest magnitude -- outputs 3e-4 (measured <= 1.0e-4), gradients 4e-3 (measured <= 1.4e-3; scale 2: 3.6e-4)."""
+    from ppvector.train.functions import Res2Fn
+    w = 64
+    g = torch.Generator().manual_seed(B * 77 + T)
+    x0 = torch.randn(B * T, S * w, generator=g)
+    dout = torch.randn(B * T, S * w, generator=g)
+    base = []
+    for i in range(S - 1):
+        base += [torch.randn(w, w, 3, generator=g) / (3 * w) ** 0.5, torch.randn(w, generator=g) * 0.3,
+                 torch.randn(w, generator=g) * 0.2 + 1.0, torch.randn(w, generator=g) * 0.2, torch.zeros(w), torch.ones(w)]
+    # float64 reference, (B, C, T) layout
+    pr = {}
+    for i in range(S - 1):
+        for k, nm in enumerate(('conv.conv.weight', 'conv.conv.bias', 'norm.norm.weight', 'norm.norm.bias')):
+            pr[f'blocks.{i}.{nm}'] = base[6 * i + k].double().requires_grad_()
+    xr = x0.double().view(B, T, S * w).transpose(1, 2).contiguous().requires_grad_()
+    om.AMP = True
+    try:
+        out_r = om.res2net_block(xr, pr, '', S, dil, training=True)
+        out_r.backward(dout.double().view(B, T, S * w).transpose(1, 2))
+    finally:
+        om.AMP = False
+    ref = {'out': out_r.detach().transpose(1, 2).reshape(B * T, S * w), 'dx': xr.grad.transpose(1, 2).reshape(B * T, S * w)}
+    for i in range(S - 1):
+        for k, nm in enumerate(('conv.conv.weight', 'conv.conv.bias', 'norm.norm.weight', 'norm.norm.bias')):
+            ref[f'{("dW", "dbias", "dgamma", "dbeta")[k]}{i}'] = pr[f'blocks.{i}.{nm}'].grad
+    # the one-launch-per-direction kernels
+    params = [t.clone().cuda() for t in base]
+    for i in range(S - 1):
+        for k in range(4):
+            params[6 * i + k].requires_grad_()
+    x = x0.clone().cuda().requires_grad_()
+    cfg = dict(B=B, T=T, scale=S, dilation=dil, momentum=0.9, eps=1e-5)
+    out = Res2Fn.apply(x, cfg, *params)
+    out.backward(dout.cuda())
+    torch.cuda.synchronize()
+    assert N.lib().vp_grid_barrier_status(N.ctx(x.device)) == 0, 'a grid barrier gave up waiting'
+    got = {'out': out.detach(), 'dx': x.grad}
+    for i in range(S - 1):
+        for k, nm in enumerate(('dW', 'dbias', 'dgamma', 'dbeta')):
+            got[f'{nm}{i}'] = params[6 * i + k].grad
+    worst = {}
+    for k, r in ref.items():
+        e = (got[k].double().cpu() - r).abs().max().item() / max(r.abs().max().item(), 1e-30)
+        kind = k.rstrip('0123456789')
+        worst[kind] = max(worst.get(kind, 0.0), e)
+    print(f'[res2 train chain vs float64 AMP emulation, scale={S} B={B} T={T} dil={dil}] max |err| / max |ref|: ' + ', '.join(f'{k} {v:.1e}' for k, v in worst.items()))
+    for kind, e in worst.items():
+        assert e < (3e-4 if kind == 'out' else 4e-3), (kind, e)
+
+
 def test_block_outputs_written_as_bf16_by_their_producer_change_nothing(N, amp, monkeypatch):
     """enable_amp, ECAPA at >= 4096 rows: the SE-Res2 block outputs reach the next block's tdnn1 and the MFA layer as bf16 operands.
     By default the kernel that produces them (vp_se_scale_residual_shadow) also writes the bf16 copy into its column slice of the MFA
