@@ -95,6 +95,12 @@ def _wide_bf16(M, Cin, Cout, KW, bias, rowbias, gamma, cfg):
 # the forward run the 256-wide LDS-DMA kernel (bf16 -> bf16, statistics from the f32 accumulators) and halves z's three later reads.
 
 
+def _narrow_to_wide(M, Cin, Cout, KW):
+    """A plain 1x1 GEMM with few input and many output channels under enable_amp: worth a bf16 copy of its small operand."""
+    return (ppvector.get_train_amp() and KW == 1 and Cin % 64 == 0 and Cout >= 256 and 4 * Cin <= Cout and M >= 4096
+            and os.environ.get('VPMI_TRAIN_BF16_OPS', '2') != '0')
+
+
 class ConvBlock(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, rowbias, gamma, beta, run_mean, run_var, cfg):
@@ -132,8 +138,14 @@ class ConvBlock(torch.autograd.Function):
         z = torch.empty((B * T_out, Cout), dtype=torch.bfloat16 if wide >= 2 else torch.float32, device=x.device)
         if wide:
             wp = wp.to(torch.bfloat16)
-        d = _conv_desc(x, B, T_in, T_out, Cin, Cout, KW, dil, _PAD[pad], pad_left, wp, bias, rowbias, relu)
-        if wide:
+        xin = x
+        if _narrow_to_wide(B * T_in, Cin, Cout, KW) and not wide and not bn and rowbias is None and pad == 'none':
+            # enable_amp, few inputs -> many outputs (ASP's logits conv, 128 -> 1536): the kernel rounds x to bf16 anyway; rounding it up
+            # front (39 MB) lets the launch take the LDS-DMA ring kernel with f32 output instead of the 128-wide register-staged one,
+            # which is bound by its 469 MB of stores (206 -> ~115 us).  Saved for backward: the f32 x, as before.
+            xin, wp = x.to(torch.bfloat16), wp.to(torch.bfloat16)
+        d = _conv_desc(xin, B, T_in, T_out, Cin, Cout, KW, dil, _PAD[pad], pad_left, wp, bias, rowbias, relu)
+        if wide or xin is not x:
             d.dtype_in = N.VP_BF16
             if wide >= 2:
                 d.dtype_out = N.VP_BF16
@@ -322,8 +334,14 @@ def _conv_block_bwd(ctx, dy, skip=None, fold=None):
                 at += wd
             dx = tuple(dx)
         else:
-            d2 = _conv_desc(dz, B, T_out, T_in, Cout, Cin, KW, dil, N.VP_PAD_ZERO, dil * (KW - 1) - pad_left, w2)
-            if wide:
+            dzin = dz
+            if not wide and dz.dtype == torch.float32 and pad == 'none' and _narrow_to_wide(B * T_out, Cout, Cin, KW):
+                # the data gradient of a many-inputs -> few-outputs layer (ASP's attention TDNN, 1536 -> 128) is a few -> many GEMM over
+                # dz: the same up-front rounding of the small operand, the same kernel (341 -> ~215 us with the other path's gradient
+                # added in its epilogue)
+                dzin, w2 = dz.to(torch.bfloat16), w2.to(torch.bfloat16)
+            d2 = _conv_desc(dzin, B, T_out, T_in, Cout, Cin, KW, dil, N.VP_PAD_ZERO, dil * (KW - 1) - pad_left, w2)
+            if wide or dzin is not dz:
                 d2.dtype_in = N.VP_BF16
             d2.y = dx.data_ptr()
             if skip is not None:
