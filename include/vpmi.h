@@ -652,6 +652,12 @@ int vp_attn_stats_bwd_f32(vp_ctx* ctx, const float* e, const float* x, int ldx, 
  * through vp_conv1d_fwd bf16 -> f32 and vp_conv1d_wgrad_bf16_oik). */
 int vp_attn_stats_bwd_de16(vp_ctx* ctx, const float* e, const float* x, int ldx, const float* pooled, const float* dpooled, int B, int T,
                            int C, float eps, void* de, float* dx, int lddx, vp_stream stream);
+/* The same pair with the LOGITS stored as bf16 (enable_amp: the logits conv writes bf16, as Paddle's O1 conv does; pooling.py:114-123 then
+ * takes the softmax in f32).  T <= 320, else VP_EUNSUP and the caller keeps f32 logits. */
+int vp_asp_softmax_stats_l16(vp_ctx* ctx, const void* logits_bf16, const float* x, int ldx, int xoff, int B, int T, int C, float eps,
+                             float* pooled, vp_stream stream);
+int vp_attn_stats_bwd_e16(vp_ctx* ctx, const void* e_bf16, const float* x, int ldx, const float* pooled, const float* dpooled, int B, int T,
+                          int C, float eps, void* de_bf16, float* dx, int lddx, vp_stream stream);
 int vp_act_f32(vp_ctx* ctx, int act /* VP_ACT_RELU .. VP_ACT_SILU; the backward takes the OUTPUT y, except SiLU: the input */, const float* x, long long n, float* y, vp_stream stream);
 int vp_act_bwd_f32(vp_ctx* ctx, int act, const float* dy, const float* y, long long n, float* dz, vp_stream stream);
 /* vp_reflect_fold_f32: adjoint of the reflect padding of Conv1d (models/utils.py:89-91): dxp (B, T + 2 pad, C) -> dx (B, T, C).

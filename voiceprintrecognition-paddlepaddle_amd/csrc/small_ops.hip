@@ -750,8 +750,11 @@ int vp_se_scale_residual(vp_ctx* ctx, int dtype, const void* x, int ldx, int xof
 namespace {
 // f32 x (the training engine), T <= 8 NT: a thread keeps its share of an utterance's logits and x in registers -- all loads issued up front
 // (the streaming kernel above has two loads in flight per thread and a divergent branch per frame: 4.2 TB/s) -- then max, then the sums.
-template <int NT>
+// TL: the logits as stored -- float, or bf16 under enable_amp (a.logits reinterpreted: what Paddle's O1 hands the softmax is the bf16
+// output of the logits conv, cast up)
+template <int NT, typename TL = float>
 __global__ __launch_bounds__(512) void asp_softmax_stats_reg_kernel(AspArgs<float> a) {
+    const TL* __restrict__ lg = reinterpret_cast<const TL*>(a.logits);
     __shared__ float sm[4][8][64];
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int b = blockIdx.y;
@@ -764,7 +767,7 @@ __global__ __launch_bounds__(512) void asp_softmax_stats_reg_kernel(AspArgs<floa
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         const int t = min(rg + 8 * i, a.T_ - 1);
-        ev[i] = a.logits[(row0 + t) * a.C + cc];
+        ev[i] = vp_to_f32(lg[(row0 + t) * a.C + cc]);
         xv[i] = a.x[(row0 + t) * a.ldx + a.xoff + cc];
     }
     float mx = -INFINITY;
@@ -822,6 +825,19 @@ extern "C" {
 int vp_asp_softmax_stats(vp_ctx* ctx, int dtype, const float* logits, const void* x, int ldx, int xoff,
                          int B, int T, int C, float eps, float* pooled, vp_stream stream) {
     return vp_asp_softmax_stats_ex(ctx, dtype, logits, x, ldx, xoff, nullptr, 0, B, T, C, eps, pooled, (hipStream_t)stream);
+}
+
+// f32 x, logits stored as bf16 (the training engine under enable_amp; T <= 320, else VP_EUNSUP: the caller keeps f32 logits)
+int vp_asp_softmax_stats_l16(vp_ctx* ctx, const void* logits_bf16, const float* x, int ldx, int xoff, int B, int T, int C, float eps,
+                             float* pooled, vp_stream stream) {
+    if (!ctx || !logits_bf16 || !x || !pooled || B <= 0 || T <= 0 || C <= 0 || B > 65535) VP_FAIL(ctx, VP_EINVAL, "asp_l16: bad arguments");
+    if (T > 320) return VP_EUNSUP;
+    AspArgs<float> a{(const float*)logits_bf16, x, nullptr, pooled, ldx, xoff, 0, B, T, C, eps};
+    const dim3 grid((C + 63) / 64, B);
+    if (T <= 160) hipLaunchKernelGGL((asp_softmax_stats_reg_kernel<20, bf16_t>), grid, dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((asp_softmax_stats_reg_kernel<40, bf16_t>), grid, dim3(512), 0, (hipStream_t)stream, a);
+    VP_LAUNCH_CHECK(ctx, "asp_softmax_stats_l16");
+    return VP_OK;
 }
 
 }  // extern "C"

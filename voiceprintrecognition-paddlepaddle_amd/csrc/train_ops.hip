@@ -885,14 +885,14 @@ __global__ __launch_bounds__(256) void attn_stats_bwd_kernel(AsBwdArgs a) {
 // slices from HBM in its second and third pass (PMC: 2.35 GB read per launch at B = 256 for 0.94 GB of inputs -- 552 us, the largest
 // kernel of the backward pass bar the weight gradients); here every input byte is read once.  (An LDS-resident variant -- 76 KB per
 // workgroup, two per CU -- measured SLOWER than the plain kernel: 8 waves per CU cannot keep enough loads in flight.)
-template <typename TE, int NT>
+template <typename TE, int NT, typename TL = float>
 __global__ __launch_bounds__(512) void attn_stats_bwd_reg_kernel(AsBwdArgs a) {
     __shared__ float sm[2][8][64];
     const int lc = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int b = blockIdx.y, c = blockIdx.x * 64 + lc;
     const bool ok = c < a.C;
     const int cc = ok ? c : 0;
-    const float* eb = a.e + (size_t)b * a.T * a.C + cc;
+    const TL* eb = reinterpret_cast<const TL*>(a.e) + (size_t)b * a.T * a.C + cc;        // TL = bf16: the logits as the forward stored them
     const float* xb = a.x + (size_t)b * a.T * a.ldx + cc;
     const float mu = a.pooled[(size_t)b * 2 * a.C + cc], sd = a.pooled[(size_t)b * 2 * a.C + a.C + cc];
     const float dmu = a.dpooled[(size_t)b * 2 * a.C + cc], dsd = a.dpooled[(size_t)b * 2 * a.C + a.C + cc];
@@ -901,7 +901,7 @@ __global__ __launch_bounds__(512) void attn_stats_bwd_reg_kernel(AsBwdArgs a) {
 #pragma unroll
     for (int i = 0; i < NT; ++i) {                  // (unconditional loads on a clamped frame; the uses below are predicated)
         const int t = min(rg + 8 * i, a.T - 1);
-        ev[i] = eb[(size_t)t * a.C];
+        ev[i] = vp_to_f32(eb[(size_t)t * a.C]);
         xv[i] = xb[(size_t)t * a.ldx];
     }
     float mx = -INFINITY;
@@ -1705,6 +1705,20 @@ int vp_attn_stats_bwd_f32(vp_ctx* ctx, const float* e, const float* x, int ldx, 
 }
 
 // d e written as bf16 ((B*T, C) dense): mixed precision, the logits conv's backward GEMMs then read bf16 operands
+// d e bf16 AND e stored as bf16 (vp_asp_softmax_stats_l16's logits); T <= 320, else VP_EUNSUP
+int vp_attn_stats_bwd_e16(vp_ctx* ctx, const void* e_bf16, const float* x, int ldx, const float* pooled, const float* dpooled, int B, int T,
+                          int C, float eps, void* de_bf16, float* dx, int lddx, vp_stream stream) {
+    if (!ctx || !e_bf16 || !x || !pooled || !dpooled || !de_bf16 || !dx || B <= 0 || T <= 0 || C <= 0 || B > 65535)
+        VP_FAIL(ctx, VP_EINVAL, "attn_stats_bwd_e16: bad arguments");
+    if (T > 320) return VP_EUNSUP;
+    AsBwdArgs a{(const float*)e_bf16, x, pooled, dpooled, (float*)de_bf16, dx, ldx, lddx, T, C, eps};
+    const dim3 grid((C + 63) / 64, B);
+    if (T <= 160) hipLaunchKernelGGL((attn_stats_bwd_reg_kernel<bf16_t, 20, bf16_t>), grid, dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((attn_stats_bwd_reg_kernel<bf16_t, 40, bf16_t>), grid, dim3(512), 0, (hipStream_t)stream, a);
+    VP_LAUNCH_CHECK(ctx, "attn_stats_bwd_e16");
+    return VP_OK;
+}
+
 int vp_attn_stats_bwd_de16(vp_ctx* ctx, const float* e, const float* x, int ldx, const float* pooled, const float* dpooled, int B, int T,
                            int C, float eps, void* de, float* dx, int lddx, vp_stream stream) {
     if (!ctx || !e || !x || !pooled || !dpooled || !de || !dx || B <= 0 || T <= 0 || C <= 0 || B > 65535) VP_FAIL(ctx, VP_EINVAL, "attn_stats_bwd: bad arguments");

@@ -135,11 +135,13 @@ class ConvBlock(torch.autograd.Function):
                                                 w2.data_ptr() if w2 is not None else None, N.stream_ptr()), hctx)
         else:
             wp = weight.view(Cout, Cin)
-        z = torch.empty((B * T_out, Cout), dtype=torch.bfloat16 if wide >= 2 else torch.float32, device=x.device)
+        narrow = bool(_narrow_to_wide(B * T_in, Cin, Cout, KW) and not wide and not bn and rowbias is None and cfg.get('pad', 'none') == 'none')
+        out16 = narrow and bool(cfg.get('out_bf16')) and not cfg.get('tanh', False) and not cfg.get('sigmoid', False)
+        z = torch.empty((B * T_out, Cout), dtype=torch.bfloat16 if (wide >= 2 or out16) else torch.float32, device=x.device)
         if wide:
             wp = wp.to(torch.bfloat16)
         xin = x
-        if _narrow_to_wide(B * T_in, Cin, Cout, KW) and not wide and not bn and rowbias is None and pad == 'none':
+        if narrow:
             # enable_amp, few inputs -> many outputs (ASP's logits conv, 128 -> 1536): the kernel rounds x to bf16 anyway; rounding it up
             # front (39 MB) lets the launch take the LDS-DMA ring kernel with f32 output instead of the 128-wide register-staged one,
             # which is bound by its 469 MB of stores (206 -> ~115 us).  Saved for backward: the f32 x, as before.
@@ -147,7 +149,7 @@ class ConvBlock(torch.autograd.Function):
         d = _conv_desc(xin, B, T_in, T_out, Cin, Cout, KW, dil, _PAD[pad], pad_left, wp, bias, rowbias, relu)
         if wide or xin is not x:
             d.dtype_in = N.VP_BF16
-            if wide >= 2:
+            if wide >= 2 or out16:
                 d.dtype_out = N.VP_BF16
         d.y = z.data_ptr()
         ps = pq = None
@@ -753,6 +755,11 @@ class AttnStats(torch.autograd.Function):
         return de, dx, None, None
 
 
+def _asp_de16(B, T, Cc):
+    """enable_amp at scale: the statistics' backward writes d e as bf16 (the operand the logits conv's two backward GEMMs round it to)."""
+    return bool(ppvector.get_train_amp() and B * T >= 16384 and Cc % 4 == 0 and os.environ.get('VPMI_TRAIN_BF16_OPS', '2') != '0')
+
+
 class AspFn(torch.autograd.Function):
     """AttentiveStatisticsPooling.forward with lengths=None (pooling.py:86-125) as one tape entry: x (B*T, C) -> (B, 2C).
     x has three consumers (the context statistics, the attention TDNN, the weighted statistics); as separate entries their
@@ -777,10 +784,16 @@ class AspFn(torch.autograd.Function):
                               dict(B=B, T=T, relu=True, tanh=True, momentum=cfg['momentum'], eps=cfg['eps']))
         # the logits' bias shifts every frame of an utterance alike and the softmax over time removes it: its gradient,
         # sum_t alpha_t (dalpha_t - S) = S - S, is exactly zero -- no 469 MB column-sum pass over d e for it
-        e = ConvBlock.forward(t2, h, w2, b2, None, None, None, None, None, dict(B=B, T=T, zero_bias_grad=True))
+        # enable_amp: the logits leave their conv as bf16 (what Paddle's O1 conv hands the f32 softmax) -- 234 instead of 469 MB written
+        # once and read twice (here and in backward); only where backward also writes d e as bf16 (_asp_de16)
+        e = ConvBlock.forward(t2, h, w2, b2, None, None, None, None, None,
+                              dict(B=B, T=T, zero_bias_grad=True, out_bf16=_asp_de16(B, T, Cc) and T <= 320))
         pooled = torch.empty((B, 2 * Cc), dtype=torch.float32, device=x.device)
-        _chk(lib.vp_asp_softmax_stats(hctx, N.VP_F32, e.data_ptr(), x.data_ptr(), Cc, 0, B, T, Cc, 1e-12, pooled.data_ptr(),
-                                      N.stream_ptr()), hctx)
+        if e.dtype == torch.bfloat16:
+            _chk(lib.vp_asp_softmax_stats_l16(hctx, e.data_ptr(), x.data_ptr(), Cc, 0, B, T, Cc, 1e-12, pooled.data_ptr(), N.stream_ptr()), hctx)
+        else:
+            _chk(lib.vp_asp_softmax_stats(hctx, N.VP_F32, e.data_ptr(), x.data_ptr(), Cc, 0, B, T, Cc, 1e-12, pooled.data_ptr(),
+                                          N.stream_ptr()), hctx)
         tapes = (t0, t1, t2) if gc else (t1, t2)
         ctx.save_for_backward(x, stats, e, pooled, *(t for tp in tapes for t in tp.saved_tensors))
         ctx.tape_meta = [(len(tp.saved_tensors), tp.geom, tp.zero_dbias) for tp in tapes]
@@ -801,10 +814,12 @@ class AspFn(torch.autograd.Function):
             tapes.append(tp)
             at += n
         t2, t1 = tapes[-1], tapes[-2]
-        de16 = ppvector.get_train_amp() and B * T >= 16384 and Cc % 4 == 0 and os.environ.get('VPMI_TRAIN_BF16_OPS', '2') != '0'
+        de16 = _asp_de16(B, T, Cc)
         de = torch.empty_like(e, dtype=torch.bfloat16 if de16 else torch.float32)
         dx = torch.empty_like(x)
-        fn = lib.vp_attn_stats_bwd_de16 if de16 else lib.vp_attn_stats_bwd_f32
+        if e.dtype == torch.bfloat16 and not de16:
+            raise N.VpmiError('AspFn: bf16 logits without a bf16 logit gradient (enable_amp changed between forward and backward?)')
+        fn = lib.vp_attn_stats_bwd_e16 if e.dtype == torch.bfloat16 else (lib.vp_attn_stats_bwd_de16 if de16 else lib.vp_attn_stats_bwd_f32)
         _chk(fn(hctx, e.data_ptr(), x.data_ptr(), Cc, pooled.data_ptr(), _f32c(dp).data_ptr(), B, T, Cc, 1e-12, de.data_ptr(),
                 dx.data_ptr(), Cc, N.stream_ptr()), hctx)
         dh, dw2, db2 = _conv_block_bwd(t2, de)[:3]
