@@ -654,10 +654,17 @@ int vp_attn_stats_bwd_de16(vp_ctx* ctx, const float* e, const float* x, int ldx,
                            int C, float eps, void* de, float* dx, int lddx, vp_stream stream);
 /* The same pair with the LOGITS stored as bf16 (enable_amp: the logits conv writes bf16, as Paddle's O1 conv does; pooling.py:114-123 then
  * takes the softmax in f32).  T <= 320, else VP_EUNSUP and the caller keeps f32 logits. */
-int vp_asp_softmax_stats_l16(vp_ctx* ctx, const void* logits_bf16, const float* x, int ldx, int xoff, int B, int T, int C, float eps,
+int vp_asp_softmax_stats_l16(vp_ctx* ctx, const void* logits_bf16, const void* x, int x_dtype, int ldx, int xoff, int B, int T, int C, float eps,
                              float* pooled, vp_stream stream);
-int vp_attn_stats_bwd_e16(vp_ctx* ctx, const void* e_bf16, const float* x, int ldx, const float* pooled, const float* dpooled, int B, int T,
-                          int C, float eps, void* de_bf16, float* dx, int lddx, vp_stream stream);
+int vp_attn_stats_bwd_e16(vp_ctx* ctx, const void* e_bf16, const void* x, int x_dtype, int ldx, const float* pooled, const float* dpooled, int B,
+                          int T, int C, float eps, void* de_bf16, float* dx, int lddx, vp_stream stream);
+/* x (the pooled tensor) stored as bf16 by its producer (x_dtype = VP_BF16 above); the pieces around it: the BatchNorm apply pass that writes
+ * it (z bf16 -> y bf16), the context statistics' backward reading it, per-utterance sums of a bf16 gradient (d rowbias). */
+int vp_affine_rows_b16_b16(vp_ctx* ctx, const void* z, int ldz, const float* scale, const float* shift, long long M, int C, void* y,
+                           int ldy, int relu, vp_stream stream);
+int vp_time_stats_bwd_add_x16(vp_ctx* ctx, const void* x_bf16, int ldx, const float* stats, const float* dstats, int B, int T, int C, float eps,
+                              int unbiased, const float* add, int ldadd, float* dx, int lddx, vp_stream stream);
+int vp_utt_sums_b16(vp_ctx* ctx, const void* a_bf16, int lda, int B, int T, int C, float* out, vp_stream stream);
 int vp_act_f32(vp_ctx* ctx, int act /* VP_ACT_RELU .. VP_ACT_SILU; the backward takes the OUTPUT y, except SiLU: the input */, const float* x, long long n, float* y, vp_stream stream);
 int vp_act_bwd_f32(vp_ctx* ctx, int act, const float* dy, const float* y, long long n, float* dz, vp_stream stream);
 /* vp_reflect_fold_f32: adjoint of the reflect padding of Conv1d (models/utils.py:89-91): dxp (B, T + 2 pad, C) -> dx (B, T, C).

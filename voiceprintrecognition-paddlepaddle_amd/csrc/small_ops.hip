@@ -752,9 +752,10 @@ namespace {
 // (the streaming kernel above has two loads in flight per thread and a divergent branch per frame: 4.2 TB/s) -- then max, then the sums.
 // TL: the logits as stored -- float, or bf16 under enable_amp (a.logits reinterpreted: what Paddle's O1 hands the softmax is the bf16
 // output of the logits conv, cast up)
-template <int NT, typename TL = float>
+template <int NT, typename TL = float, typename TX = float>
 __global__ __launch_bounds__(512) void asp_softmax_stats_reg_kernel(AspArgs<float> a) {
     const TL* __restrict__ lg = reinterpret_cast<const TL*>(a.logits);
+    const TX* __restrict__ xg = reinterpret_cast<const TX*>(a.x);
     __shared__ float sm[4][8][64];
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int b = blockIdx.y;
@@ -768,7 +769,7 @@ __global__ __launch_bounds__(512) void asp_softmax_stats_reg_kernel(AspArgs<floa
     for (int i = 0; i < NT; ++i) {
         const int t = min(rg + 8 * i, a.T_ - 1);
         ev[i] = vp_to_f32(lg[(row0 + t) * a.C + cc]);
-        xv[i] = a.x[(row0 + t) * a.ldx + a.xoff + cc];
+        xv[i] = vp_to_f32(xg[(row0 + t) * a.ldx + a.xoff + cc]);
     }
     float mx = -INFINITY;
 #pragma unroll
@@ -828,14 +829,19 @@ int vp_asp_softmax_stats(vp_ctx* ctx, int dtype, const float* logits, const void
 }
 
 // f32 x, logits stored as bf16 (the training engine under enable_amp; T <= 320, else VP_EUNSUP: the caller keeps f32 logits)
-int vp_asp_softmax_stats_l16(vp_ctx* ctx, const void* logits_bf16, const float* x, int ldx, int xoff, int B, int T, int C, float eps,
+int vp_asp_softmax_stats_l16(vp_ctx* ctx, const void* logits_bf16, const void* x, int x_dtype, int ldx, int xoff, int B, int T, int C, float eps,
                              float* pooled, vp_stream stream) {
-    if (!ctx || !logits_bf16 || !x || !pooled || B <= 0 || T <= 0 || C <= 0 || B > 65535) VP_FAIL(ctx, VP_EINVAL, "asp_l16: bad arguments");
+    if (!ctx || !logits_bf16 || !x || !pooled || B <= 0 || T <= 0 || C <= 0 || B > 65535 || (x_dtype != VP_F32 && x_dtype != VP_BF16))
+        VP_FAIL(ctx, VP_EINVAL, "asp_l16: bad arguments");
     if (T > 320) return VP_EUNSUP;
-    AspArgs<float> a{(const float*)logits_bf16, x, nullptr, pooled, ldx, xoff, 0, B, T, C, eps};
+    AspArgs<float> a{(const float*)logits_bf16, (const float*)x, nullptr, pooled, ldx, xoff, 0, B, T, C, eps};
     const dim3 grid((C + 63) / 64, B);
-    if (T <= 160) hipLaunchKernelGGL((asp_softmax_stats_reg_kernel<20, bf16_t>), grid, dim3(512), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((asp_softmax_stats_reg_kernel<40, bf16_t>), grid, dim3(512), 0, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    if (x_dtype == VP_BF16) {
+        if (T <= 160) hipLaunchKernelGGL((asp_softmax_stats_reg_kernel<20, bf16_t, bf16_t>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((asp_softmax_stats_reg_kernel<40, bf16_t, bf16_t>), grid, dim3(512), 0, st, a);
+    } else if (T <= 160) hipLaunchKernelGGL((asp_softmax_stats_reg_kernel<20, bf16_t>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((asp_softmax_stats_reg_kernel<40, bf16_t>), grid, dim3(512), 0, st, a);
     VP_LAUNCH_CHECK(ctx, "asp_softmax_stats_l16");
     return VP_OK;
 }

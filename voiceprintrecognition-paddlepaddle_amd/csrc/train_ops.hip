@@ -603,9 +603,9 @@ __global__ __launch_bounds__(256) void bn_train_finalize_kernel(BnFinArgs a) {
 }
 
 // y = z * scale + shift
-template <typename TZ>
+template <typename TZ, typename TY = float>
 __global__ __launch_bounds__(256) void affine_rows_kernel(const TZ* z, int ldz, const float* scale, const float* shift, long long M,
-                                                          int C4, float* y, int ldy, int relu) {
+                                                          int C4, TY* y, int ldy, int relu) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < M * C4; i += (long long)gridDim.x * 256) {
         const long long m = i / C4;
         const int c = (int)(i - m * C4) * 4;
@@ -795,13 +795,14 @@ __global__ __launch_bounds__(256) void pack_segments_kernel(const PackArgs a) {
 
 // ---------------------------------------------------------------------------------------------- per-utterance pieces (ASP)
 // out[b][c] = sum_t a[b, t, c]   (gradient of a per-utterance bias; one workgroup = 64 channels of one utterance)
-__global__ __launch_bounds__(256) void utt_sums_kernel(const float* a, int lda, int T, int C, float* out) {
+template <typename TA = float>
+__global__ __launch_bounds__(256) void utt_sums_kernel(const TA* a, int lda, int T, int C, float* out) {
     __shared__ float sm[4][64];
     const int lc = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int b = blockIdx.y, c = blockIdx.x * 64 + lc;
     float s = 0.f;
     if (c < C)
-        for (int t = rg; t < T; t += 4) s += a[((size_t)b * T + t) * lda + c];
+        for (int t = rg; t < T; t += 4) s += vp_to_f32(a[((size_t)b * T + t) * lda + c]);
     sm[rg][lc] = s;
     __syncthreads();
     if (rg == 0 && c < C) out[(size_t)b * C + c] = sm[0][lc] + sm[1][lc] + sm[2][lc] + sm[3][lc];
@@ -811,6 +812,7 @@ __global__ __launch_bounds__(256) void utt_sums_kernel(const float* a, int lda, 
 // dx[b,t,c] = dmean / T + [var > eps] * dstd / std * (x - mean) / T
 struct TsBwdArgs { const float* x; const float* stats; const float* dstats; float* dx; int ldx, lddx, T, C4; float eps; long long total; int unbiased;
                    const float* add; int ldadd; };     // add: other gradients of x summed in the same pass (may alias dx)
+template <typename TX = float>
 __global__ __launch_bounds__(256) void time_stats_bwd_kernel(TsBwdArgs a) {
     const int C = a.C4 * 4;
     const float invT = 1.f / (float)a.T;
@@ -819,7 +821,7 @@ __global__ __launch_bounds__(256) void time_stats_bwd_kernel(TsBwdArgs a) {
         const int c = (int)(i - m * a.C4) * 4;
         const long long b = m / a.T;
         float x[4], mu[4], sd[4], dm[4], ds[4], o[4];
-        vp_load4(a.x + m * a.ldx + c, x);
+        vp_load4(reinterpret_cast<const TX*>(a.x) + m * a.ldx + c, x);
         vp_load4(a.stats + b * 2 * C + c, mu); vp_load4(a.stats + b * 2 * C + C + c, sd);
         vp_load4(a.dstats + b * 2 * C + c, dm); vp_load4(a.dstats + b * 2 * C + C + c, ds);
 #pragma unroll
@@ -885,7 +887,7 @@ __global__ __launch_bounds__(256) void attn_stats_bwd_kernel(AsBwdArgs a) {
 // slices from HBM in its second and third pass (PMC: 2.35 GB read per launch at B = 256 for 0.94 GB of inputs -- 552 us, the largest
 // kernel of the backward pass bar the weight gradients); here every input byte is read once.  (An LDS-resident variant -- 76 KB per
 // workgroup, two per CU -- measured SLOWER than the plain kernel: 8 waves per CU cannot keep enough loads in flight.)
-template <typename TE, int NT, typename TL = float>
+template <typename TE, int NT, typename TL = float, typename TX = float>
 __global__ __launch_bounds__(512) void attn_stats_bwd_reg_kernel(AsBwdArgs a) {
     __shared__ float sm[2][8][64];
     const int lc = threadIdx.x & 63, rg = threadIdx.x >> 6;
@@ -893,7 +895,7 @@ __global__ __launch_bounds__(512) void attn_stats_bwd_reg_kernel(AsBwdArgs a) {
     const bool ok = c < a.C;
     const int cc = ok ? c : 0;
     const TL* eb = reinterpret_cast<const TL*>(a.e) + (size_t)b * a.T * a.C + cc;        // TL = bf16: the logits as the forward stored them
-    const float* xb = a.x + (size_t)b * a.T * a.ldx + cc;
+    const TX* xb = reinterpret_cast<const TX*>(a.x) + (size_t)b * a.T * a.ldx + cc;     // TX = bf16: x as its producer stored it
     const float mu = a.pooled[(size_t)b * 2 * a.C + cc], sd = a.pooled[(size_t)b * 2 * a.C + a.C + cc];
     const float dmu = a.dpooled[(size_t)b * 2 * a.C + cc], dsd = a.dpooled[(size_t)b * 2 * a.C + a.C + cc];
     const float dv = (sd * sd > a.eps) ? dsd / (2.f * sd) : 0.f;
@@ -902,7 +904,7 @@ __global__ __launch_bounds__(512) void attn_stats_bwd_reg_kernel(AsBwdArgs a) {
     for (int i = 0; i < NT; ++i) {                  // (unconditional loads on a clamped frame; the uses below are predicated)
         const int t = min(rg + 8 * i, a.T - 1);
         ev[i] = vp_to_f32(eb[(size_t)t * a.C]);
-        xv[i] = xb[(size_t)t * a.ldx];
+        xv[i] = vp_to_f32(xb[(size_t)t * a.ldx]);
     }
     float mx = -INFINITY;
 #pragma unroll
@@ -1539,6 +1541,16 @@ int vp_affine_rows_b16_f32(vp_ctx* ctx, const void* z, int ldz, const float* sca
     return VP_OK;
 }
 
+// z AND y bf16: a layer output whose only consumers read it as bf16 (ECAPA's MFA output under enable_amp: ASP's GEMM operand and statistics)
+int vp_affine_rows_b16_b16(vp_ctx* ctx, const void* z, int ldz, const float* scale, const float* shift, long long M, int C, void* y,
+                           int ldy, int relu, vp_stream stream) {
+    if (!ctx || !z || !scale || !shift || !y || M <= 0 || C <= 0 || (C | ldz | ldy) & 3) VP_FAIL(ctx, VP_EINVAL, "affine_rows_b16_b16: bad arguments");
+    hipLaunchKernelGGL((affine_rows_kernel<bf16_t, bf16_t>), dim3(grid1d(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z, ldz,
+                       scale, shift, M, C / 4, (bf16_t*)y, ldy, relu);
+    VP_LAUNCH_CHECK(ctx, "affine_rows_b16_b16");
+    return VP_OK;
+}
+
 int vp_bn_relu_bwd_f32(vp_ctx* ctx, const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* invstd,
                        const float* gamma, const float* sums, long long M, int C, int relu_mask, float* dz, int lddz,
                        vp_stream stream) {
@@ -1663,9 +1675,16 @@ int vp_pack_segments_f32(vp_ctx* ctx, const void* const* srcs, const long long* 
     return VP_OK;
 }
 
+int vp_utt_sums_b16(vp_ctx* ctx, const void* a_bf16, int lda, int B, int T, int C, float* out, vp_stream stream) {
+    if (!ctx || !a_bf16 || !out || B <= 0 || T <= 0 || C <= 0 || B > 65535) VP_FAIL(ctx, VP_EINVAL, "utt_sums_b16: bad arguments");
+    hipLaunchKernelGGL(utt_sums_kernel<bf16_t>, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a_bf16, lda, T, C, out);
+    VP_LAUNCH_CHECK(ctx, "utt_sums_b16");
+    return VP_OK;
+}
+
 int vp_utt_sums_f32(vp_ctx* ctx, const float* a, int lda, int B, int T, int C, float* out, vp_stream stream) {
     if (!ctx || !a || !out || B <= 0 || T <= 0 || C <= 0 || B > 65535) VP_FAIL(ctx, VP_EINVAL, "utt_sums: bad arguments");
-    hipLaunchKernelGGL(utt_sums_kernel, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, a, lda, T, C, out);
+    hipLaunchKernelGGL(utt_sums_kernel<float>, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, a, lda, T, C, out);
     VP_LAUNCH_CHECK(ctx, "utt_sums");
     return VP_OK;
 }
@@ -1679,7 +1698,7 @@ int vp_time_stats_bwd_f32(vp_ctx* ctx, const float* x, int ldx, const float* sta
                           int unbiased, float* dx, int lddx, vp_stream stream) {
     if (!ctx || !x || !stats || !dstats || !dx || B <= 0 || T <= 0 || C <= 0 || (C | ldx | lddx) & 3) VP_FAIL(ctx, VP_EINVAL, "time_stats_bwd: bad arguments");
     TsBwdArgs a{x, stats, dstats, dx, ldx, lddx, T, C / 4, eps, (long long)B * T * (C / 4), unbiased, nullptr, 0};
-    hipLaunchKernelGGL(time_stats_bwd_kernel, dim3(grid1d(a.total)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(time_stats_bwd_kernel<float>, dim3(grid1d(a.total)), dim3(256), 0, (hipStream_t)stream, a);
     VP_LAUNCH_CHECK(ctx, "time_stats_bwd");
     return VP_OK;
 }
@@ -1690,8 +1709,19 @@ int vp_time_stats_bwd_add_f32(vp_ctx* ctx, const float* x, int ldx, const float*
     if (!ctx || !x || !stats || !dstats || !dx || !add || B <= 0 || T <= 0 || C <= 0 || (C | ldx | lddx | ldadd) & 3)
         VP_FAIL(ctx, VP_EINVAL, "time_stats_bwd_add: bad arguments");
     TsBwdArgs a{x, stats, dstats, dx, ldx, lddx, T, C / 4, eps, (long long)B * T * (C / 4), unbiased, add, ldadd};
-    hipLaunchKernelGGL(time_stats_bwd_kernel, dim3(grid1d(a.total)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(time_stats_bwd_kernel<float>, dim3(grid1d(a.total)), dim3(256), 0, (hipStream_t)stream, a);
     VP_LAUNCH_CHECK(ctx, "time_stats_bwd_add");
+    return VP_OK;
+}
+
+// the same with x stored as bf16 (ldx in elements)
+int vp_time_stats_bwd_add_x16(vp_ctx* ctx, const void* x_bf16, int ldx, const float* stats, const float* dstats, int B, int T, int C, float eps,
+                              int unbiased, const float* add, int ldadd, float* dx, int lddx, vp_stream stream) {
+    if (!ctx || !x_bf16 || !stats || !dstats || !dx || !add || B <= 0 || T <= 0 || C <= 0 || (C | ldx | lddx | ldadd) & 3)
+        VP_FAIL(ctx, VP_EINVAL, "time_stats_bwd_add_x16: bad arguments");
+    TsBwdArgs a{(const float*)x_bf16, stats, dstats, dx, ldx, lddx, T, C / 4, eps, (long long)B * T * (C / 4), unbiased, add, ldadd};
+    hipLaunchKernelGGL(time_stats_bwd_kernel<bf16_t>, dim3(grid1d(a.total)), dim3(256), 0, (hipStream_t)stream, a);
+    VP_LAUNCH_CHECK(ctx, "time_stats_bwd_add_x16");
     return VP_OK;
 }
 
@@ -1706,15 +1736,20 @@ int vp_attn_stats_bwd_f32(vp_ctx* ctx, const float* e, const float* x, int ldx, 
 
 // d e written as bf16 ((B*T, C) dense): mixed precision, the logits conv's backward GEMMs then read bf16 operands
 // d e bf16 AND e stored as bf16 (vp_asp_softmax_stats_l16's logits); T <= 320, else VP_EUNSUP
-int vp_attn_stats_bwd_e16(vp_ctx* ctx, const void* e_bf16, const float* x, int ldx, const float* pooled, const float* dpooled, int B, int T,
-                          int C, float eps, void* de_bf16, float* dx, int lddx, vp_stream stream) {
-    if (!ctx || !e_bf16 || !x || !pooled || !dpooled || !de_bf16 || !dx || B <= 0 || T <= 0 || C <= 0 || B > 65535)
+int vp_attn_stats_bwd_e16(vp_ctx* ctx, const void* e_bf16, const void* x, int x_dtype, int ldx, const float* pooled, const float* dpooled, int B,
+                          int T, int C, float eps, void* de_bf16, float* dx, int lddx, vp_stream stream) {
+    if (!ctx || !e_bf16 || !x || !pooled || !dpooled || !de_bf16 || !dx || B <= 0 || T <= 0 || C <= 0 || B > 65535 ||
+        (x_dtype != VP_F32 && x_dtype != VP_BF16))
         VP_FAIL(ctx, VP_EINVAL, "attn_stats_bwd_e16: bad arguments");
     if (T > 320) return VP_EUNSUP;
-    AsBwdArgs a{(const float*)e_bf16, x, pooled, dpooled, (float*)de_bf16, dx, ldx, lddx, T, C, eps};
+    AsBwdArgs a{(const float*)e_bf16, (const float*)x, pooled, dpooled, (float*)de_bf16, dx, ldx, lddx, T, C, eps};
     const dim3 grid((C + 63) / 64, B);
-    if (T <= 160) hipLaunchKernelGGL((attn_stats_bwd_reg_kernel<bf16_t, 20, bf16_t>), grid, dim3(512), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((attn_stats_bwd_reg_kernel<bf16_t, 40, bf16_t>), grid, dim3(512), 0, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    if (x_dtype == VP_BF16) {
+        if (T <= 160) hipLaunchKernelGGL((attn_stats_bwd_reg_kernel<bf16_t, 20, bf16_t, bf16_t>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((attn_stats_bwd_reg_kernel<bf16_t, 40, bf16_t, bf16_t>), grid, dim3(512), 0, st, a);
+    } else if (T <= 160) hipLaunchKernelGGL((attn_stats_bwd_reg_kernel<bf16_t, 20, bf16_t>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((attn_stats_bwd_reg_kernel<bf16_t, 40, bf16_t>), grid, dim3(512), 0, st, a);
     VP_LAUNCH_CHECK(ctx, "attn_stats_bwd_e16");
     return VP_OK;
 }

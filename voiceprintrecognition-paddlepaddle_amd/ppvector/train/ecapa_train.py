@@ -82,11 +82,16 @@ def ecapa_forward_train(m, feats):
         outs = list(cut(*outs))
         x = outs[-1]
     conv, norm = m.mfa.conv.conv, m.mfa.norm.norm
+    # ASP's context statistics come from the MFA conv's fused sums; under enable_amp (bf16 operand path) the MFA output itself leaves
+    # its BatchNorm pass as bf16 -- ASP is its only consumer and reads it as a GEMM operand and in three statistics passes
     cfg = dict(B=B, T=T, dilation=m.mfa.conv.dilation, pad='reflect', relu=True, momentum=norm.momentum, eps=norm.eps, xcat=xcat,
-               want_tsums=True)                                  # ASP's context statistics come from the MFA conv's fused sums
+               want_tsums=True, y_bf16=xcat is not None and bool(m.asp.global_context) and T <= 320 and B * T >= 16384
+               and not os.environ.get('VPMI_MFA_F32_OUT'))
     x = CatConvBlock.apply(cfg, conv.weight, conv.bias, norm.weight, norm.bias, norm._mean, norm._variance, *outs)
     if cfg.get('_tsums') is not None:
         x._vp_tsums = cfg.pop('_tsums')
+    if cfg.get('_y16') is not None:                              # x is a memory-less f32 placeholder for the tape; the values are this twin
+        x._vp_bf16, x._vp_bf16_only = cfg.pop('_y16'), True
     p = asp_forward(m.asp, x, B, T)
     n = m.asp_bn.norm
     p = BNRows.apply(p, n.weight, n.bias, n._mean, n._variance, n.momentum, n.eps)

@@ -110,6 +110,8 @@ class ConvBlock(torch.autograd.Function):
         Cout, Cin, KW = weight.shape
         wide = _wide_bf16(B * T_in, Cin, Cout, KW, bias, rowbias, gamma, cfg)
         if x.dtype == torch.bfloat16:
+            if not wide and KW == 1 and ppvector.get_train_amp() and Cin % 8 == 0 and Cout % 4 == 0 and bias is not None:
+                wide = 1                                      # a producer handed over bf16 (ASP's attention TDNN on the bf16 MFA output): bf16 operands, f32 z
             if not wide:
                 raise N.VpmiError('ConvBlock: a bf16 input outside the wide mixed-precision layers')
             if x.stride(1) != 1 or x.stride(0) % 4:
@@ -182,7 +184,20 @@ class ConvBlock(torch.autograd.Function):
                                           cfg.get('eps', 1e-5), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
                                           shift.data_ptr(), N.stream_ptr()), hctx)
             into, add = cfg.get('y_into'), cfg.get('aux_add')
-            if wide >= 2:
+            y16 = (wide >= 2 and cfg.get('y_bf16') and cfg.get('want_tsums') and ps is not None and ps.shape[0] > 1 and not tanh
+                   and not os.environ.get('VPMI_NO_TSUMS'))
+            if y16:
+                # the output's only consumer reads it as bf16 and takes its time statistics from the fused sums (ECAPA's MFA -> ASP):
+                # 234 MB written instead of 469, and every later pass over it reads half
+                y16t = torch.empty(z.shape, dtype=torch.bfloat16, device=x.device)
+                _chk(lib.vp_affine_rows_b16_b16(hctx, z.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(), B * T_out, Cout,
+                                                y16t.data_ptr(), Cout, 0, N.stream_ptr()), hctx)
+                # autograd hands a tensor's gradient over in the tensor's dtype: a bf16 y would get its 469 MB f32 gradient cast down.
+                # The tape therefore sees an f32 PLACEHOLDER of the right shape that owns no memory (one zero, expanded); the values
+                # travel as its bf16 twin, the way producers' twins do everywhere else (`_vp_bf16`), marked as the only copy.
+                y = torch.zeros(1, dtype=torch.float32, device=x.device).expand(z.shape)
+                cfg['_y16'] = y16t
+            elif wide >= 2:
                 y = torch.empty(z.shape, dtype=torch.float32, device=x.device)
                 _chk(lib.vp_affine_rows_b16_f32(hctx, z.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(), B * T_out, Cout,
                                                 y.data_ptr(), Cout, 0, N.stream_ptr()), hctx)
@@ -282,7 +297,8 @@ def _conv_block_bwd(ctx, dy, skip=None, fold=None):
     drb = None
     if has_rb:
         drb = torch.empty((B, Cout), dtype=torch.float32, device=dev)
-        _chk(lib.vp_utt_sums_f32(hctx, dz.data_ptr(), Cout, B, T_out, Cout, drb.data_ptr(), N.stream_ptr()), hctx)
+        fn = lib.vp_utt_sums_b16 if dz.dtype == torch.bfloat16 else lib.vp_utt_sums_f32
+        _chk(fn(hctx, dz.data_ptr(), Cout, B, T_out, Cout, drb.data_ptr(), N.stream_ptr()), hctx)
     # weight gradient
     d = _conv_desc(x, B, T_in, T_out, Cin, Cout, KW, dil, _PAD[pad], pad_left, weight)
     dW = torch.empty((Cout, Cin, KW), dtype=torch.float32, device=dev)      # reduced straight into the model's layout
@@ -771,12 +787,21 @@ class AspFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, gamma, beta, run_mean, run_var, w2, b2, cfg):
         lib, hctx = N.lib(), N.ctx(x.device)
-        x = _f32c(x)                                          # (may carry the producing conv's fused time sums)
+        twin = getattr(x, '_vp_bf16', None) if getattr(x, '_vp_bf16_only', False) else None
+        x16 = twin is not None                                # the producer wrote x as bf16 ONLY (ConvBlock cfg['y_bf16']): x itself is a placeholder
+        if x16:
+            ts = getattr(x, '_vp_tsums', None)
+            x = twin
+            x._vp_tsums = ts
+        else:
+            x = _f32c(x)                                      # (may carry the producing conv's fused time sums)
         B, T, gc = cfg['B'], cfg['T'], cfg['global_context']
         Cc = x.shape[1]
         needs = (True,) * 9
         t0, t1, t2 = _Tape(needs), _Tape(needs), _Tape(needs)
         stats = rowbias = None
+        if x16 and not (gc and getattr(x, '_vp_tsums', None) is not None and _asp_de16(B, T, Cc) and T <= 320):
+            raise N.VpmiError('AspFn: a bf16 input needs the producer\'s fused time sums, global context and the bf16 statistics kernels (T <= 320)')
         if gc:
             stats = _time_stats(x, B, T, 1e-12, True)
             rowbias = ConvBlock.forward(t0, stats, w[:, Cc:].contiguous(), None, None, None, None, None, None, dict(B=B, T=1))
@@ -790,13 +815,16 @@ class AspFn(torch.autograd.Function):
                               dict(B=B, T=T, zero_bias_grad=True, out_bf16=_asp_de16(B, T, Cc) and T <= 320))
         pooled = torch.empty((B, 2 * Cc), dtype=torch.float32, device=x.device)
         if e.dtype == torch.bfloat16:
-            _chk(lib.vp_asp_softmax_stats_l16(hctx, e.data_ptr(), x.data_ptr(), Cc, 0, B, T, Cc, 1e-12, pooled.data_ptr(), N.stream_ptr()), hctx)
+            _chk(lib.vp_asp_softmax_stats_l16(hctx, e.data_ptr(), x.data_ptr(), N.VP_BF16 if x16 else N.VP_F32, Cc, 0, B, T, Cc, 1e-12,
+                                              pooled.data_ptr(), N.stream_ptr()), hctx)
+        elif x16:
+            raise N.VpmiError('AspFn: bf16 x with f32 logits is not built')
         else:
             _chk(lib.vp_asp_softmax_stats(hctx, N.VP_F32, e.data_ptr(), x.data_ptr(), Cc, 0, B, T, Cc, 1e-12, pooled.data_ptr(),
                                           N.stream_ptr()), hctx)
         tapes = (t0, t1, t2) if gc else (t1, t2)
         ctx.save_for_backward(x, stats, e, pooled, *(t for tp in tapes for t in tp.saved_tensors))
-        ctx.tape_meta = [(len(tp.saved_tensors), tp.geom, tp.zero_dbias) for tp in tapes]
+        ctx.tape_meta = [(len(tp.saved_tensors), tp.geom, tp.zero_dbias, getattr(tp, 'wide', 0)) for tp in tapes]
         ctx.geom = (B, T, gc)
         return pooled
 
@@ -808,27 +836,33 @@ class AspFn(torch.autograd.Function):
         lib, hctx = N.lib(), N.ctx(x.device)
         Cc = x.shape[1]
         tapes, at = [], 4
-        for n, geom, zero_dbias in ctx.tape_meta:
+        for n, geom, zero_dbias, wide in ctx.tape_meta:
             tp = _Tape((True,) * 9)
-            tp.saved_tensors, tp.geom, tp.zero_dbias = saved[at:at + n], geom, zero_dbias
+            tp.saved_tensors, tp.geom, tp.zero_dbias, tp.wide = saved[at:at + n], geom, zero_dbias, wide
             tapes.append(tp)
             at += n
         t2, t1 = tapes[-1], tapes[-2]
         de16 = _asp_de16(B, T, Cc)
         de = torch.empty_like(e, dtype=torch.bfloat16 if de16 else torch.float32)
-        dx = torch.empty_like(x)
+        dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        x16 = x.dtype == torch.bfloat16
         if e.dtype == torch.bfloat16 and not de16:
             raise N.VpmiError('AspFn: bf16 logits without a bf16 logit gradient (enable_amp changed between forward and backward?)')
-        fn = lib.vp_attn_stats_bwd_e16 if e.dtype == torch.bfloat16 else (lib.vp_attn_stats_bwd_de16 if de16 else lib.vp_attn_stats_bwd_f32)
-        _chk(fn(hctx, e.data_ptr(), x.data_ptr(), Cc, pooled.data_ptr(), _f32c(dp).data_ptr(), B, T, Cc, 1e-12, de.data_ptr(),
-                dx.data_ptr(), Cc, N.stream_ptr()), hctx)
+        if e.dtype == torch.bfloat16:
+            _chk(lib.vp_attn_stats_bwd_e16(hctx, e.data_ptr(), x.data_ptr(), N.VP_BF16 if x16 else N.VP_F32, Cc, pooled.data_ptr(),
+                                           _f32c(dp).data_ptr(), B, T, Cc, 1e-12, de.data_ptr(), dx.data_ptr(), Cc, N.stream_ptr()), hctx)
+        else:
+            fn = lib.vp_attn_stats_bwd_de16 if de16 else lib.vp_attn_stats_bwd_f32
+            _chk(fn(hctx, e.data_ptr(), x.data_ptr(), Cc, pooled.data_ptr(), _f32c(dp).data_ptr(), B, T, Cc, 1e-12, de.data_ptr(),
+                    dx.data_ptr(), Cc, N.stream_ptr()), hctx)
         dh, dw2, db2 = _conv_block_bwd(t2, de)[:3]
         dx, dwx, dbias, drb, dgamma, dbeta = _conv_block_bwd(t1, dh, dx)[:6]        # dx: TDNN's + the weighted statistics'
         dw = dwx
         if gc:
             dstats, dwc = _conv_block_bwd(tapes[0], drb)[:2]
-            _chk(lib.vp_time_stats_bwd_add_f32(hctx, x.data_ptr(), Cc, stats.data_ptr(), dstats.data_ptr(), B, T, Cc, 1e-12, 0,
-                                               dx.data_ptr(), Cc, dx.data_ptr(), Cc, N.stream_ptr()), hctx)
+            fn = lib.vp_time_stats_bwd_add_x16 if x16 else lib.vp_time_stats_bwd_add_f32
+            _chk(fn(hctx, x.data_ptr(), Cc, stats.data_ptr(), dstats.data_ptr(), B, T, Cc, 1e-12, 0,
+                    dx.data_ptr(), Cc, dx.data_ptr(), Cc, N.stream_ptr()), hctx)
             dw = torch.cat([dwx, dwc], dim=1)
         return dx, dw, dbias, dgamma, dbeta, None, None, dw2, db2, None
 
