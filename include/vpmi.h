@@ -665,6 +665,7 @@ int vp_affine_rows_b16_b16(vp_ctx* ctx, const void* z, int ldz, const float* sca
 int vp_time_stats_bwd_add_x16(vp_ctx* ctx, const void* x_bf16, int ldx, const float* stats, const float* dstats, int B, int T, int C, float eps,
                               int unbiased, const float* add, int ldadd, float* dx, int lddx, vp_stream stream);
 int vp_utt_sums_b16(vp_ctx* ctx, const void* a_bf16, int lda, int B, int T, int C, float* out, vp_stream stream);
+int vp_utt_dot_x16(vp_ctx* ctx, const float* dy, const void* x_bf16, int B, int T, int C, float* ds, vp_stream stream);   /* vp_utt_dot_f32 over a bf16 x */
 int vp_act_f32(vp_ctx* ctx, int act /* VP_ACT_RELU .. VP_ACT_SILU; the backward takes the OUTPUT y, except SiLU: the input */, const float* x, long long n, float* y, vp_stream stream);
 int vp_act_bwd_f32(vp_ctx* ctx, int act, const float* dy, const float* y, long long n, float* dz, vp_stream stream);
 /* vp_reflect_fold_f32: adjoint of the reflect padding of Conv1d (models/utils.py:89-91): dxp (B, T + 2 pad, C) -> dx (B, T, C).

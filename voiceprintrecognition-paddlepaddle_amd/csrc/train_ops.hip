@@ -1064,14 +1064,15 @@ __global__ __launch_bounds__(256) void scale_rows_bwd_chunk_kernel(SrbArgs a) {
 // The SE gate's backward in two passes (see SEBlockFn in train/functions.py): ds[b,c] = sum_t dy * x first -- the squeeze path's
 // gradient dm[b,c] (through the two dense layers) depends on it -- then dx = dy * s[b,c] + dm[b,c] / T in one write of dx, instead
 // of dx = dy * s, a separate mean-backward tensor and their sum.  Four channels per lane; 32 lanes x 8 frame groups per utterance.
-__global__ __launch_bounds__(256) void utt_dot4_kernel(const float* dy, const float* x, int T, int C, float* ds) {
+template <typename TX = float>
+__global__ __launch_bounds__(256) void utt_dot4_kernel(const float* dy, const TX* x, int T, int C, float* ds) {
     __shared__ float sm[256][4];
     const int lc = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int b = blockIdx.y, c4 = blockIdx.x * 32 + lc;
     const bool ok = c4 < (C >> 2);
     const int c = ok ? c4 * 4 : 0;
     const float* gb = dy + (size_t)b * T * C + c;
-    const float* xb = x + (size_t)b * T * C + c;
+    const TX* xb = x + (size_t)b * T * C + c;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     int t = rg;
     for (; t + 24 < T; t += 32) {
@@ -1860,8 +1861,17 @@ int vp_scale_rows_bwd_f32(vp_ctx* ctx, const float* dy, const float* x, const fl
 int vp_utt_dot_f32(vp_ctx* ctx, const float* dy, const float* x, int B, int T, int C, float* ds, vp_stream stream) {
     if (!ctx || !dy || !x || !ds || B <= 0 || T <= 0 || C <= 0 || (C & 3) || B > 65535 || (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)ds) & 15))
         VP_FAIL(ctx, VP_EINVAL, "utt_dot: bad arguments");
-    hipLaunchKernelGGL(utt_dot4_kernel, dim3((C / 4 + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, dy, x, T, C, ds);
+    hipLaunchKernelGGL(utt_dot4_kernel<float>, dim3((C / 4 + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, dy, x, T, C, ds);
     VP_LAUNCH_CHECK(ctx, "utt_dot");
+    return VP_OK;
+}
+
+// x stored as bf16 (the SE block's input kept in the low precision: its gate's gradient ds[b,c] = sum_t dy * x)
+int vp_utt_dot_x16(vp_ctx* ctx, const float* dy, const void* x_bf16, int B, int T, int C, float* ds, vp_stream stream) {
+    if (!ctx || !dy || !x_bf16 || !ds || B <= 0 || T <= 0 || C <= 0 || (C & 3) || B > 65535 || (((uintptr_t)dy | (uintptr_t)ds) & 15) || ((uintptr_t)x_bf16 & 7))
+        VP_FAIL(ctx, VP_EINVAL, "utt_dot_x16: bad arguments");
+    hipLaunchKernelGGL(utt_dot4_kernel<bf16_t>, dim3((C / 4 + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, dy, (const bf16_t*)x_bf16, T, C, ds);
+    VP_LAUNCH_CHECK(ctx, "utt_dot_x16");
     return VP_OK;
 }
 

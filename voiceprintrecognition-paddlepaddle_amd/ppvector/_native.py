@@ -287,6 +287,7 @@ _PROTOS = {
     'vp_time_stats_bwd_add_x16': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_int,
                                            c_void_p, c_int, c_void_p]),
     'vp_utt_sums_b16': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'vp_utt_dot_x16': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'vp_attn_stats_bwd_de16': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
                                       c_void_p, c_int, c_void_p]),
     'vp_act_f32': (c_int, [c_void_p, c_int, c_void_p, C.c_longlong, c_void_p, c_void_p]),

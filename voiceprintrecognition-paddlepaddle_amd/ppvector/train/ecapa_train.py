@@ -13,14 +13,17 @@ from ppvector.train.segments import cut
 from ppvector.train.tdnn_train import asp_forward
 
 
-def tdnn_block(blk, x, B, T, want_tsums=False):
+def tdnn_block(blk, x, B, T, want_tsums=False, y_bf16=False):
     """TDNNBlock (models/utils.py:122-148): BN(ReLU(Conv1d 'same' reflect)).  want_tsums: the consumer takes time statistics of the
     output (SE squeeze): the conv's fused per-utterance sums travel with the tensor instead of a pass over it."""
     conv, norm = blk.conv.conv, blk.norm.norm
-    cfg = dict(B=B, T=T, dilation=blk.conv.dilation, pad='reflect', relu=True, momentum=norm.momentum, eps=norm.eps, want_tsums=want_tsums)
+    cfg = dict(B=B, T=T, dilation=blk.conv.dilation, pad='reflect', relu=True, momentum=norm.momentum, eps=norm.eps, want_tsums=want_tsums,
+               y_bf16=y_bf16)
     y = ConvBlock.apply(x, conv.weight, conv.bias, None, norm.weight, norm.bias, norm._mean, norm._variance, cfg)
     if cfg.get('_tsums') is not None:
         y._vp_tsums = cfg.pop('_tsums')
+    if cfg.get('_y16') is not None:                              # y is a memory-less f32 placeholder for the tape; the values are this twin
+        y._vp_bf16, y._vp_bf16_only = cfg.pop('_y16'), True
     return y
 
 
@@ -53,11 +56,19 @@ def se_res2net_block(blk, x, B, T, shadow=None):
                                       dict(B=B, T=T, dilation=blk.tdnn1.conv.dilation, pad='reflect', relu=True,
                                            momentum=norm.momentum, eps=norm.eps))
     h = res2net_block(blk.res2net_block, h, B, T)
-    h = tdnn_block(blk.tdnn2, h, B, T, want_tsums=True)
+    # all-bf16 SE stage (enable_amp at scale, the MFA operand buffer given): tdnn2's output, the residual and the block output exist as
+    # bf16 only; the tape sees f32 placeholders (functions._placeholder)
+    res16 = getattr(x, '_vp_bf16', None)
+    all16 = shadow is not None and res16 is not None and not os.environ.get('VPMI_SE_F32') and not os.environ.get('VPMI_NO_TSUMS')
+    h = tdnn_block(blk.tdnn2, h, B, T, want_tsums=True, y_bf16=all16)
+    if res16 is not None:
+        residual._vp_bf16 = res16                                # (a view of x: attributes do not travel with it)
     se = blk.se_block                                           # squeeze, two dense layers, gate, + residual: one tape entry
     out = SEBlockFn.apply(h, residual, se.conv1.conv.weight, se.conv1.conv.bias, se.conv2.conv.weight, se.conv2.conv.bias, B, T, shadow)
     if shadow is not None:
         out._vp_bf16 = shadow                                    # ConvBlock / CatConvBlock take the operand from here instead of converting
+        if getattr(h, '_vp_bf16_only', False):
+            out._vp_bf16_only = True                             # ... and it is the ONLY copy: `out` itself is a placeholder
     return out
 
 
@@ -74,6 +85,8 @@ def ecapa_forward_train(m, feats):
     if ppvector.get_train_amp() and os.environ.get('VPMI_TRAIN_BF16_OPS', '2') != '0' and not os.environ.get('VPMI_NO_SHADOW') \
             and B * T >= 4096 and Cb % 64 == 0 and Cb >= 256 and m.mfa.conv.conv.weight.shape[1] == Cb * len(blocks):
         xcat = torch.empty((B * T, Cb * len(blocks)), dtype=torch.bfloat16, device=x.device)
+    if xcat is not None and getattr(x, '_vp_bf16', None) is None:
+        x._vp_bf16 = x.to(torch.bfloat16)                        # block 0's output as the first block reads it (GEMM operand and residual)
     for i, blk in enumerate(blocks):
         x = se_res2net_block(blk, x, B, T, xcat[:, i * Cb:(i + 1) * Cb] if xcat is not None else None)
         outs.append(x)

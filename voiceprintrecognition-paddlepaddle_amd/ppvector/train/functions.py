@@ -95,6 +95,18 @@ def _wide_bf16(M, Cin, Cout, KW, bias, rowbias, gamma, cfg):
 # the forward run the 256-wide LDS-DMA kernel (bf16 -> bf16, statistics from the f32 accumulators) and halves z's three later reads.
 
 
+def _only16(t):
+    """The bf16 tensor that carries the values of `t` when `t` is a memory-less f32 placeholder on the tape (see ConvBlock cfg['y_bf16'],
+    SEBlockFn), else None."""
+    return getattr(t, '_vp_bf16', None) if getattr(t, '_vp_bf16_only', False) else None
+
+
+def _placeholder(shape, device):
+    """f32 tensor of `shape` that owns one element: what autograd sees of an activation that exists as bf16 only (autograd hands a
+    tensor's gradient over in the tensor's dtype, so a bf16 tensor on the tape would get its f32 gradient cast down)."""
+    return torch.zeros(1, dtype=torch.float32, device=device).expand(shape)
+
+
 def _narrow_to_wide(M, Cin, Cout, KW):
     """A plain 1x1 GEMM with few input and many output channels under enable_amp: worth a bf16 copy of its small operand."""
     return (ppvector.get_train_amp() and KW == 1 and Cin % 64 == 0 and Cout >= 256 and 4 * Cin <= Cout and M >= 4096
@@ -116,6 +128,10 @@ class ConvBlock(torch.autograd.Function):
                 raise N.VpmiError('ConvBlock: a bf16 input outside the wide mixed-precision layers')
             if x.stride(1) != 1 or x.stride(0) % 4:
                 x = x.contiguous()
+        elif _only16(x) is not None:                    # the producer wrote x as bf16 ONLY: x is a placeholder, the twin is the operand
+            if not wide:
+                raise N.VpmiError('ConvBlock: an input that exists as bf16 only outside the wide mixed-precision layers')
+            x = _only16(x)
         else:
             shadow = getattr(x, '_vp_bf16', None)         # the producer already wrote x as bf16 (SEBlockFn: a slice of the MFA operand)
             x = _f32c(x)
@@ -195,7 +211,7 @@ class ConvBlock(torch.autograd.Function):
                 # autograd hands a tensor's gradient over in the tensor's dtype: a bf16 y would get its 469 MB f32 gradient cast down.
                 # The tape therefore sees an f32 PLACEHOLDER of the right shape that owns no memory (one zero, expanded); the values
                 # travel as its bf16 twin, the way producers' twins do everywhere else (`_vp_bf16`), marked as the only copy.
-                y = torch.zeros(1, dtype=torch.float32, device=x.device).expand(z.shape)
+                y = _placeholder(z.shape, x.device)
                 cfg['_y16'] = y16t
             elif wide >= 2:
                 y = torch.empty(z.shape, dtype=torch.float32, device=x.device)
@@ -381,19 +397,21 @@ class CatConvBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, weight, bias, gamma, beta, run_mean, run_var, *xs):
-        xs = [_f32c(x) for x in xs]
         M, widths = xs[0].shape[0], [x.shape[1] for x in xs]
         Cout, Cin, KW = weight.shape
         if _wide_bf16(M, Cin, Cout, KW, bias, None, gamma, cfg):
             xcat = cfg.get('xcat')                         # filled slice by slice by the producers of xs (SEBlockFn's bf16 shadow), or:
             if xcat is None or tuple(xcat.shape) != (M, Cin) or xcat.dtype != torch.bfloat16:
+                if any(_only16(x) is not None for x in xs):
+                    raise N.VpmiError('CatConvBlock: inputs that exist as bf16 only need the shared bf16 concatenation (cfg[\'xcat\'])')
+                xs = [_f32c(x) for x in xs]
                 xcat = torch.empty((M, Cin), dtype=torch.bfloat16, device=xs[0].device)
                 at = 0
                 for x, wd in zip(xs, widths):
                     xcat[:, at:at + wd].copy_(x)
                     at += wd
         else:
-            xcat = torch.cat(xs, dim=1)
+            xcat = torch.cat([_f32c(x) for x in xs], dim=1)
         tp = _Tape((True,) * 9)
         y = ConvBlock.forward(tp, xcat, weight, bias, None, gamma, beta, run_mean, run_var, cfg)
         ctx.save_for_backward(*tp.saved_tensors)
@@ -649,9 +667,21 @@ class SEBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, res, w1, b1, w2, b2, B, T, shadow=None):
         lib, hctx = N.lib(), N.ctx(h.device)
-        res = _f32c(res)
         Cc = h.shape[1]
-        h = _f32c(h)                                          # (a contiguous tensor comes back as itself, with what its producer hung on it)
+        h16 = _only16(h)
+        res16 = getattr(res, '_vp_bf16', None)
+        # all-bf16 form (enable_amp at scale): h exists as bf16 only (tdnn2's cfg['y_bf16']), the residual has a bf16 twin, and the block
+        # output is written ONCE, as bf16, into its slice of the MFA operand -- 312 MB per block instead of 546
+        all16 = (h16 is not None and res16 is not None and shadow is not None and res16.shape == h.shape and res16.stride(1) == 1
+                 and shadow.stride(1) == 1 and Cc % 8 == 0 and res16.stride(0) % 8 == 0 and shadow.stride(0) % 8 == 0)
+        if h16 is not None and not all16:
+            raise N.VpmiError('SEBlockFn: an input that exists as bf16 only needs a bf16 residual twin and a bf16 output slice')
+        if all16:
+            if getattr(h, '_vp_tsums', None) is None or not ppvector.get_train_amp() or os.environ.get('VPMI_NO_TSUMS'):
+                raise N.VpmiError('SEBlockFn: a bf16-only input needs its producer\'s fused time sums')
+        else:
+            res = _f32c(res)
+            h = _f32c(h)                                      # (a contiguous tensor comes back as itself, with what its producer hung on it)
         mean = _time_stats(h, B, T, 1e-12, False)
         needs = (True,) * 9
         t1, t2 = _Tape(needs), _Tape(needs)
@@ -667,8 +697,16 @@ class SEBlockFn(torch.autograd.Function):
         else:
             a = ConvBlock.forward(t1, mean, w1, b1, None, None, None, None, None, dict(B=B, T=1, relu=True))
             s = ConvBlock.forward(t2, a, w2, b2, None, None, None, None, None, dict(B=B, T=1, sigmoid=True))
-        out = torch.empty_like(h)
-        if shadow is not None:                       # (B*T, Cc) bf16 view, unit column stride: the block output as the next GEMMs read it
+        if all16:
+            _chk(lib.vp_se_scale_residual(hctx, N.VP_BF16, h16.data_ptr(), h16.stride(0), 0, s.data_ptr(), res16.data_ptr(), res16.stride(0), 0,
+                                          shadow.data_ptr(), shadow.stride(0), 0, B, T, Cc, N.stream_ptr()), hctx)
+            out = _placeholder(h.shape, h.device)             # the caller hangs `shadow` on it as its only copy
+            h = h16
+        else:
+            out = torch.empty_like(h)
+        if all16:
+            pass
+        elif shadow is not None:                     # (B*T, Cc) bf16 view, unit column stride: the block output as the next GEMMs read it
             _chk(lib.vp_se_scale_residual_shadow(hctx, h.data_ptr(), Cc, 0, s.data_ptr(), res.data_ptr(), Cc, 0, out.data_ptr(), Cc, 0,
                                                  shadow.data_ptr(), shadow.stride(0), 0, B, T, Cc, N.stream_ptr()), hctx)
         else:
@@ -692,7 +730,12 @@ class SEBlockFn(torch.autograd.Function):
         dout = _f32c(dout)
         Cc = h.shape[1]
         ds = torch.empty_like(s)
-        _chk(lib.vp_utt_dot_f32(hctx, dout.data_ptr(), h.data_ptr(), B, T, Cc, ds.data_ptr(), N.stream_ptr()), hctx)
+        if h.dtype == torch.bfloat16:
+            if not h.is_contiguous():
+                h = h.contiguous()
+            _chk(lib.vp_utt_dot_x16(hctx, dout.data_ptr(), h.data_ptr(), B, T, Cc, ds.data_ptr(), N.stream_ptr()), hctx)
+        else:
+            _chk(lib.vp_utt_dot_f32(hctx, dout.data_ptr(), h.data_ptr(), B, T, Cc, ds.data_ptr(), N.stream_ptr()), hctx)
         if ctx.n1 < 0:                               # the fused dense layers: d mean and the four parameter gradients in two launches
             mean, a, w1, w2 = saved[2:6]
             H = w1.shape[0]
@@ -704,7 +747,7 @@ class SEBlockFn(torch.autograd.Function):
             _chk(lib.vp_se_dense_train_bwd(hctx, ds.data_ptr(), mean.data_ptr(), a.data_ptr(), s.data_ptr(), w1.data_ptr(), w2.data_ptr(),
                                            B, Cc, H, g1, dm.data_ptr(), dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(),
                                            ws.data_ptr(), ws.numel(), N.stream_ptr()), hctx)
-            dh = torch.empty_like(h)
+            dh = torch.empty(h.shape, dtype=torch.float32, device=h.device)
             _chk(lib.vp_scale_shift_rows_f32(hctx, dout.data_ptr(), s.data_ptr(), dm.data_ptr(), B, T, Cc, dh.data_ptr(), N.stream_ptr()), hctx)
             return dh, dout, dw1, db1, dw2, db2, None, None, None
         needs = (True,) * 9
@@ -713,7 +756,7 @@ class SEBlockFn(torch.autograd.Function):
         t2.saved_tensors, t2.geom = saved[2 + ctx.n1:], g2
         da, dw2, db2 = ConvBlock.backward(t2, ds)[:3]
         dm, dw1, db1 = ConvBlock.backward(t1, da)[:3]
-        dh = torch.empty_like(h)
+        dh = torch.empty(h.shape, dtype=torch.float32, device=h.device)
         _chk(lib.vp_scale_shift_rows_f32(hctx, dout.data_ptr(), s.data_ptr(), dm.data_ptr(), B, T, Cc, dh.data_ptr(), N.stream_ptr()), hctx)
         return dh, dout, dw1, db1, dw2, db2, None, None, None
 

@@ -48,6 +48,8 @@ class Recorder:
         for t, l in zip(keep, leaves):                    # (a producer's bf16 twin of the tensor travels with it: train/functions.py)
             if getattr(t, '_vp_bf16', None) is not None:
                 l._vp_bf16 = t._vp_bf16
+                if getattr(t, '_vp_bf16_only', False):        # ... which may be the ONLY copy (t is a memory-less placeholder)
+                    l._vp_bf16_only = True
         self.cuts.append((keep, leaves))
         it = iter(leaves)
         return tuple(next(it) if t.requires_grad else t for t in tensors)
