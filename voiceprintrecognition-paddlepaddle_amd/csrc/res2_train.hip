@@ -219,7 +219,8 @@ __global__ __launch_bounds__(RT_THREADS) void res2_train_fwd_kernel(Res2TrainArg
     const unsigned Mrows = (unsigned)a.B * a.T;
     const int ntile = a.TP / 16;
     float* slab = slab_all + wv * 16 * RT_SLD;
-    const __amdgpu_buffer_rsrc_t rx = rt_rsrc(a.x, (size_t)Mrows * a.C * 4), ro = rt_rsrc(a.out, (size_t)Mrows * a.C * 4);
+    const __amdgpu_buffer_rsrc_t rx = rt_rsrc(a.x, (size_t)Mrows * a.C * 4);
+    const __amdgpu_buffer_rsrc_t ro = rt_rsrc(a.out ? (const void*)a.out : (const void*)a.x, a.out ? (size_t)Mrows * a.C * 4 : 0);   // (absent: every store out of range)
     const __amdgpu_buffer_rsrc_t rz = rt_rsrc(a.z, (size_t)a.nconv * Mrows * RT_W * 4), ri = rt_rsrc(a.inb, (size_t)a.nconv * Mrows * RT_W * 2);
     const unsigned lx = (unsigned)(rl * a.C + cq) * 4, lz = (unsigned)(rl * RT_W + cq) * 4, lb = (unsigned)(rl * RT_W + cq) * 2;
     const unsigned pitch = (unsigned)a.C * 4;
@@ -670,7 +671,10 @@ static int rt_fill(vp_ctx* ctx, const vp_res2_train_desc* d, void* ws, size_t ws
     if (d->B > rt_num_cus(ctx)) return VP_EUNSUP;                        // the grid barrier needs every workgroup resident
     if (!ctx->grid_bar) return VP_EUNSUP;
     if ((size_t)d->B * d->T * d->C * 4 >= 0x0ff00000ull) return VP_EUNSUP;    // 32-bit buffer offsets with room for the out-of-range marker
-    if (!d->x || !d->out || !d->z || !d->stats || !ws || (bwd ? (!d->dzb || !d->dvec) : !d->inb)) VP_FAIL(ctx, VP_EINVAL, "res2_train: null argument");
+    // forward: `out` (f32) may be absent when the bf16 copy is asked for -- a caller whose only consumer reads the bf16 copy (tdnn2's GEMM operand)
+    // saves the 156 MB f32 store per block
+    const bool out_ok = d->out || (!bwd && d->out_bf16);
+    if (!d->x || !out_ok || !d->z || !d->stats || !ws || (bwd ? (!d->dzb || !d->dvec) : !d->inb)) VP_FAIL(ctx, VP_EINVAL, "res2_train: null argument");
     if (ws_bytes < vp_res2_train_workspace_bytes(d->B, d->scale)) VP_FAIL(ctx, VP_EWORKSPACE, "res2_train: workspace too small");
     if ((reinterpret_cast<uintptr_t>(d->x) | reinterpret_cast<uintptr_t>(d->out) | reinterpret_cast<uintptr_t>(d->z) |
          reinterpret_cast<uintptr_t>(d->inb) | reinterpret_cast<uintptr_t>(d->dzb)) & 15)

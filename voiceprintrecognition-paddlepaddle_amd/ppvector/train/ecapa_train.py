@@ -42,9 +42,12 @@ def res2net_block(r2, x, B, T):
     cfg = dict(B=B, T=T, scale=r2.scale, dilation=blocks[0].conv.dilation, momentum=n0.momentum, eps=n0.eps,
                bf16_twin=bool(ppvector.get_train_amp()) and os.environ.get('VPMI_TRAIN_BF16_OPS', '2') != '0'
                and not os.environ.get('VPMI_NO_SHADOW') and B * T >= 4096 and x.shape[1] >= 256)
+    cfg['out16_only'] = cfg['bf16_twin'] and not os.environ.get('VPMI_RES2_F32_OUT')      # tdnn2 reads the bf16 copy and nothing else reads the f32 one
     out = Res2Fn.apply(x, cfg, *params)
     if cfg.get('_twin') is not None:
         out._vp_bf16 = cfg['_twin']
+        if cfg.get('_twin_only'):
+            out._vp_bf16_only = True                             # `out` is a memory-less placeholder for the tape
     return out
 
 
