@@ -722,7 +722,9 @@ typedef struct {
     void* dzb;
     float* stats;
     float* dvec;
-    void* out_bf16;               /* forward, optional: out once more as bf16 (B*T, C), the operand of the conv behind the block */
+    void* out_bf16;               /* forward, optional: out once more as bf16 (B*T, C), the operand of the conv behind the block;
+                                     with it, `out` may be NULL (no f32 copy is written) */
+    int x_is_bf16;                /* forward: x points to bf16 (the producer wrote the block input as bf16 only) */
 } vp_res2_train_desc;
 /* nbatch convs of identical geometry in one launch (the chunk convs of a Res2Net block after vp_res2_train_bwd): conv c reads
  * x + c * x_bstride and dz + c * dz_bstride (bf16 elements), writes dW + c * Cout * Cin * KW; ws = nbatch x vp_conv1d_wgrad_workspace_bytes(d). */

@@ -49,6 +49,7 @@ struct Res2TrainArgs {
     bf16_t* outb;                           // forward, optional: out once more as bf16 (M, C) -- the operand of the conv that follows
     float* stats;                           // [nconv][2][64]: mean, invstd
     float* dvec;                            // [nconv][3][64]: d bias, d gamma, d beta  (backward only)
+    int x16;                                // forward: x is bf16 (M, C)
     float* part;                            // workspace [nconv][B][128] (+ backward: [nconv][B][64] behind it)
     unsigned* bar;                          // grid-barrier words (rt_grid_barrier)
     int B, T, C, nconv, dil, TP;
@@ -158,6 +159,13 @@ __device__ __forceinline__ float4 rt_ld(__amdgpu_buffer_rsrc_t r, unsigned vo, u
     return make_float4(__builtin_bit_cast(float, (unsigned)v[0]), __builtin_bit_cast(float, (unsigned)v[1]),
                        __builtin_bit_cast(float, (unsigned)v[2]), __builtin_bit_cast(float, (unsigned)v[3]));
 }
+// x of the forward, f32 or bf16 (wave-uniform): the byte offsets are written for f32 and halved for bf16 (RT_PAST / 2 stays out of range)
+__device__ __forceinline__ float4 rt_ldx(__amdgpu_buffer_rsrc_t r, bool x16, unsigned vo, unsigned so) {
+    if (!x16) return rt_ld(r, vo, so);
+    const rt_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, vo >> 1, so >> 1, 0);
+    return make_float4(__builtin_bit_cast(float, (unsigned)v[0] << 16), __builtin_bit_cast(float, (unsigned)v[0] & 0xffff0000u),
+                       __builtin_bit_cast(float, (unsigned)v[1] << 16), __builtin_bit_cast(float, (unsigned)v[1] & 0xffff0000u));
+}
 __device__ __forceinline__ void rt_st(__amdgpu_buffer_rsrc_t r, float4 v, unsigned vo, unsigned so) {
     rt_u32x4 u;
     u[0] = __builtin_bit_cast(unsigned, v.x); u[1] = __builtin_bit_cast(unsigned, v.y);
@@ -219,7 +227,8 @@ __global__ __launch_bounds__(RT_THREADS) void res2_train_fwd_kernel(Res2TrainArg
     const unsigned Mrows = (unsigned)a.B * a.T;
     const int ntile = a.TP / 16;
     float* slab = slab_all + wv * 16 * RT_SLD;
-    const __amdgpu_buffer_rsrc_t rx = rt_rsrc(a.x, (size_t)Mrows * a.C * 4);
+    const bool x16 = a.x16 != 0;
+    const __amdgpu_buffer_rsrc_t rx = rt_rsrc(a.x, (size_t)Mrows * a.C * (x16 ? 2 : 4));
     const __amdgpu_buffer_rsrc_t ro = rt_rsrc(a.out ? (const void*)a.out : (const void*)a.x, a.out ? (size_t)Mrows * a.C * 4 : 0);   // (absent: every store out of range)
     const __amdgpu_buffer_rsrc_t rz = rt_rsrc(a.z, (size_t)a.nconv * Mrows * RT_W * 4), ri = rt_rsrc(a.inb, (size_t)a.nconv * Mrows * RT_W * 2);
     const unsigned lx = (unsigned)(rl * a.C + cq) * 4, lz = (unsigned)(rl * RT_W + cq) * 4, lb = (unsigned)(rl * RT_W + cq) * 2;
@@ -238,8 +247,8 @@ __global__ __launch_bounds__(RT_THREADS) void res2_train_fwd_kernel(Res2TrainArg
             const int t = mt * 16 + rl + 4 * k;
             const bool ok = t < a.T;
             const unsigned so = (row0 + mt * 16 + 4 * k) * pitch;
-            const float4 v0 = rt_ld(rx, ok ? lx : RT_PAST, so);
-            const float4 v1 = rt_ld(rx, ok ? lx : RT_PAST, so + RT_W * 4);
+            const float4 v0 = rt_ldx(rx, x16, ok ? lx : RT_PAST, so);
+            const float4 v1 = rt_ldx(rx, x16, ok ? lx : RT_PAST, so + RT_W * 4);
             rt_st(ro, v0, ok ? lx : RT_PAST, so);
             {
                 bf16x4 ob;
@@ -345,7 +354,7 @@ __global__ __launch_bounds__(RT_THREADS) void res2_train_fwd_kernel(Res2TrainArg
 #pragma unroll
             for (int k = 0; k < 4; ++k) {                              // (past the utterance: out-of-range offsets -- zeros in, nothing out)
                 const bool ok = mt * 16 + rl + 4 * k < a.T;
-                xn[r][k] = rt_ld(rx, (has_next && ok) ? lx : RT_PAST, (row0 + mt * 16 + 4 * k) * pitch + (j + 2) * (RT_W * 4));
+                xn[r][k] = rt_ldx(rx, x16, (has_next && ok) ? lx : RT_PAST, (row0 + mt * 16 + 4 * k) * pitch + (j + 2) * (RT_W * 4));
                 rt_st(rz, rr[r][k], ok ? lz : RT_PAST, ((unsigned)j * Mrows + row0 + mt * 16 + 4 * k) * (RT_W * 4));
             }
         }
@@ -681,6 +690,7 @@ static int rt_fill(vp_ctx* ctx, const vp_res2_train_desc* d, void* ws, size_t ws
         VP_FAIL(ctx, VP_EINVAL, "res2_train: tensors must be 16-byte aligned");
     memset(&a, 0, sizeof(a));
     a.x = d->x; a.out = d->out; a.z = d->z; a.inb = (bf16_t*)d->inb; a.dzb = (bf16_t*)d->dzb; a.outb = bwd ? nullptr : (bf16_t*)d->out_bf16; a.stats = d->stats; a.dvec = d->dvec;
+    a.x16 = bwd ? 0 : d->x_is_bf16;
     a.part = (float*)ws; a.bar = ctx->grid_bar;
     for (int j = 0; j < nconv; ++j) {
         if (!d->w[j] || !d->gamma[j] || (!bwd && (!d->bias[j] || !d->beta[j]))) VP_FAIL(ctx, VP_EINVAL, "res2_train: null parameter");

@@ -59,7 +59,8 @@ class Res2TrainDesc(C.Structure):
                 ('momentum', c_float), ('eps', c_float), ('x', c_void_p), ('out', c_void_p),
                 ('w', c_void_p * 7), ('bias', c_void_p * 7), ('gamma', c_void_p * 7), ('beta', c_void_p * 7),
                 ('run_mean', c_void_p * 7), ('run_var', c_void_p * 7),
-                ('z', c_void_p), ('inb', c_void_p), ('dzb', c_void_p), ('stats', c_void_p), ('dvec', c_void_p), ('out_bf16', c_void_p)]
+                ('z', c_void_p), ('inb', c_void_p), ('dzb', c_void_p), ('stats', c_void_p), ('dvec', c_void_p), ('out_bf16', c_void_p),
+                ('x_is_bf16', c_int)]
 
 
 class TdnnLayer(C.Structure):

@@ -55,9 +55,12 @@ def se_res2net_block(blk, x, B, T, shadow=None):
     if blk.shortcut is not None:
         raise NotImplementedError('SERes2NetBlock with a shortcut conv is not built')
     conv, norm = blk.tdnn1.conv.conv, blk.tdnn1.norm.norm      # tdnn1 also hands x on as the residual (its gradient comes back here)
-    h, residual = ConvBlockSkip.apply(x, conv.weight, conv.bias, None, norm.weight, norm.bias, norm._mean, norm._variance,
-                                      dict(B=B, T=T, dilation=blk.tdnn1.conv.dilation, pad='reflect', relu=True,
-                                           momentum=norm.momentum, eps=norm.eps))
+    # (enable_amp at scale: tdnn1's output leaves its BatchNorm pass as bf16 only -- the fused Res2 chain reads it in that form)
+    cfg1 = dict(B=B, T=T, dilation=blk.tdnn1.conv.dilation, pad='reflect', relu=True, momentum=norm.momentum, eps=norm.eps,
+                y_bf16=shadow is not None and not os.environ.get('VPMI_TDNN1_F32_OUT'))
+    h, residual = ConvBlockSkip.apply(x, conv.weight, conv.bias, None, norm.weight, norm.bias, norm._mean, norm._variance, cfg1)
+    if cfg1.get('_y16') is not None:
+        h._vp_bf16, h._vp_bf16_only = cfg1.pop('_y16'), True
     h = res2net_block(blk.res2net_block, h, B, T)
     # all-bf16 SE stage (enable_amp at scale, the MFA operand buffer given): tdnn2's output, the residual and the block output exist as
     # bf16 only; the tape sees f32 placeholders (functions._placeholder)

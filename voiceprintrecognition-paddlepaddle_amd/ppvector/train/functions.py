@@ -200,8 +200,7 @@ class ConvBlock(torch.autograd.Function):
                                           cfg.get('eps', 1e-5), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
                                           shift.data_ptr(), N.stream_ptr()), hctx)
             into, add = cfg.get('y_into'), cfg.get('aux_add')
-            y16 = (wide >= 2 and cfg.get('y_bf16') and cfg.get('want_tsums') and ps is not None and ps.shape[0] > 1 and not tanh
-                   and not os.environ.get('VPMI_NO_TSUMS'))
+            y16 = wide >= 2 and cfg.get('y_bf16') and not tanh
             if y16:
                 # the output's only consumer reads it as bf16 and takes its time statistics from the fused sums (ECAPA's MFA -> ASP):
                 # 234 MB written instead of 469, and every later pass over it reads half
@@ -493,6 +492,7 @@ class Res2Fn(torch.autograd.Function):
         d.B, d.T, d.C, d.scale, d.width, d.dil = cfg['B'], cfg['T'], x.shape[1], S, x.shape[1] // S, cfg['dilation']
         d.momentum, d.eps = cfg['momentum'], cfg['eps']
         d.x, d.out = x.data_ptr(), (out.data_ptr() if out is not None else None)
+        d.x_is_bf16 = int(x.dtype == torch.bfloat16)
         for i in range(S - 1):
             wt, bs, g, b, rm, rv = params[6 * i:6 * i + 6]
             d.w[i], d.bias[i], d.gamma[i], d.beta[i] = wt.data_ptr(), bs.data_ptr(), g.data_ptr(), b.data_ptr()
@@ -517,14 +517,19 @@ class Res2Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, cfg, *params):
-        x = _f32c(x)
+        x16 = _only16(x)                                      # the producer (tdnn1) wrote the block input as bf16 only: the fused kernel reads that
         B, T, S = cfg['B'], cfg['T'], cfg['scale']
+        fused_ok = Res2Fn._fused_ok(x, cfg, params, S)
+        if x16 is not None and not (fused_ok and x16.is_contiguous()):
+            x, x16 = x16.float(), None                        # (the per-chunk path wants f32)
+        elif x16 is None:
+            x = _f32c(x)
+        xk = x16 if x16 is not None else x                    # what the kernel reads
         w = x.shape[1] // S
         # out16_only (with bf16_twin): the caller's only consumer reads the bf16 copy -- the fused kernel then skips the f32 store and the tape
         # gets a memory-less placeholder (_placeholder); the per-chunk fallback below always writes f32
         only16 = bool(cfg.get('bf16_twin') and cfg.get('out16_only'))
-        fused_ok = Res2Fn._fused_ok(x, cfg, params, S)
-        out = None if (only16 and fused_ok) else torch.empty_like(x)
+        out = None if (only16 and fused_ok) else torch.empty(x.shape, dtype=torch.float32, device=x.device)
         ctx.fused = False
         if fused_ok:
             lib, hctx = N.lib(), N.ctx(x.device)
@@ -532,7 +537,7 @@ class Res2Fn(torch.autograd.Function):
             z = torch.empty((S - 1, M, 64), dtype=torch.float32, device=x.device)
             inb = torch.empty((S - 1, M, 64), dtype=torch.bfloat16, device=x.device)
             stats = torch.empty((S - 1, 2, 64), dtype=torch.float32, device=x.device)
-            d = Res2Fn._fused_desc(x, out, cfg, params, S)
+            d = Res2Fn._fused_desc(xk, out, cfg, params, S)
             outb = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if cfg.get('bf16_twin') else None
             d.z, d.inb, d.stats = z.data_ptr(), inb.data_ptr(), stats.data_ptr()
             d.out_bf16 = outb.data_ptr() if outb is not None else None
@@ -549,7 +554,9 @@ class Res2Fn(torch.autograd.Function):
             if rc != N.VP_EUNSUP:
                 _chk(rc, hctx)
             if out is None:
-                out = torch.empty_like(x)
+                out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+            if x16 is not None:
+                x = x16.float()
         out[:, :w].copy_(x[:, :w])
         inp = x[:, w:2 * w].contiguous()
         saved, meta = [], []
