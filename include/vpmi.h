@@ -662,6 +662,8 @@ int vp_attn_stats_bwd_e16(vp_ctx* ctx, const void* e_bf16, const void* x, int x_
  * it (z bf16 -> y bf16), the context statistics' backward reading it, per-utterance sums of a bf16 gradient (d rowbias). */
 int vp_affine_rows_b16_b16(vp_ctx* ctx, const void* z, int ldz, const float* scale, const float* shift, long long M, int C, void* y,
                            int ldy, int relu, vp_stream stream);
+int vp_affine_rows_f32_b16(vp_ctx* ctx, const float* z, int ldz, const float* scale, const float* shift, long long M, int C, void* y,
+                           int ldy, int relu, vp_stream stream);
 int vp_time_stats_bwd_add_x16(vp_ctx* ctx, const void* x_bf16, int ldx, const float* stats, const float* dstats, int B, int T, int C, float eps,
                               int unbiased, const float* add, int ldadd, float* dx, int lddx, vp_stream stream);
 int vp_utt_sums_b16(vp_ctx* ctx, const void* a_bf16, int lda, int B, int T, int C, float* out, vp_stream stream);

@@ -1272,7 +1272,7 @@ def test_block_outputs_written_as_bf16_by_their_producer_change_nothing(N, amp, 
     """enable_amp, ECAPA at >= 4096 rows: the SE-Res2 block outputs reach the next block's tdnn1 and the MFA layer as bf16 operands.
     By default the kernel that produces them (vp_se_scale_residual_shadow) also writes the bf16 copy into its column slice of the MFA
     operand; VPMI_NO_SHADOW=1 converts afterwards (x.to(bfloat16) per consumer + three strided copies).  Same rounding of the same
-    values: loss and every parameter gradient must be bit-identical.  (Both runs with the four VPMI_*_F32* switches set: since round 4 the
+    values: loss and every parameter gradient must be bit-identical.  (Both runs with the five VPMI_*_F32* switches set: since round 4 the
     default keeps tdnn1's / the Res2 chain's / tdnn2's outputs, the residual, the block outputs and the MFA output as bf16 ONLY -- a different rounding, compared with
     this form in the second half of the test with the f32 engine's step as the yardstick: the bf16-only form must be no further from it
     than the form with f32 activations is (25 % slack; test_ecapa_amp_operand_levels_agree_at_bench_scale explains that floor).)"""
@@ -1284,7 +1284,7 @@ def test_block_outputs_written_as_bf16_by_their_producer_change_nothing(N, amp, 
     state = {k: v.clone() for k, v in m0.state_dict().items()}
     x = torch.randn(16, 298, 80, device='cuda')
     g = torch.randn(16, 192, device='cuda')
-    for name in ('VPMI_SE_F32', 'VPMI_MFA_F32_OUT', 'VPMI_TDNN1_F32_OUT', 'VPMI_RES2_F32_OUT'):
+    for name in ('VPMI_SE_F32', 'VPMI_MFA_F32_OUT', 'VPMI_TDNN1_F32_OUT', 'VPMI_RES2_F32_OUT', 'VPMI_BLOCK0_F32_OUT'):
         monkeypatch.setenv(name, '1')
 
     def run(no_shadow):
@@ -1306,7 +1306,7 @@ def test_block_outputs_written_as_bf16_by_their_producer_change_nothing(N, amp, 
     print(f'[bf16 shadows] embeddings identical: {torch.equal(e0, e1)}; worst |gradient difference| {worst:.1e}')
     assert torch.equal(e0, e1)
     assert all(torch.equal(g0[k], g1[k]) for k in g0)
-    for name in ('VPMI_SE_F32', 'VPMI_MFA_F32_OUT', 'VPMI_TDNN1_F32_OUT', 'VPMI_RES2_F32_OUT'):
+    for name in ('VPMI_SE_F32', 'VPMI_MFA_F32_OUT', 'VPMI_TDNN1_F32_OUT', 'VPMI_RES2_F32_OUT', 'VPMI_BLOCK0_F32_OUT'):
         monkeypatch.delenv(name)
     e2, g2 = run(False)                                   # the default: activations between the GEMMs as bf16 only
     ppvector.set_train_amp(False)                         # yardstick: the f32 engine's step on the same batch

@@ -1552,6 +1552,16 @@ int vp_affine_rows_b16_b16(vp_ctx* ctx, const void* z, int ldz, const float* sca
     return VP_OK;
 }
 
+// z f32, y bf16 (a layer outside the wide set whose only consumers read bf16: ECAPA's block 0 under enable_amp)
+int vp_affine_rows_f32_b16(vp_ctx* ctx, const float* z, int ldz, const float* scale, const float* shift, long long M, int C, void* y,
+                           int ldy, int relu, vp_stream stream) {
+    if (!ctx || !z || !scale || !shift || !y || M <= 0 || C <= 0 || (C | ldz | ldy) & 3) VP_FAIL(ctx, VP_EINVAL, "affine_rows_f32_b16: bad arguments");
+    hipLaunchKernelGGL((affine_rows_kernel<float, bf16_t>), dim3(grid1d(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, z, ldz, scale, shift, M,
+                       C / 4, (bf16_t*)y, ldy, relu);
+    VP_LAUNCH_CHECK(ctx, "affine_rows_f32_b16");
+    return VP_OK;
+}
+
 int vp_bn_relu_bwd_f32(vp_ctx* ctx, const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* invstd,
                        const float* gamma, const float* sums, long long M, int C, int relu_mask, float* dz, int lddz,
                        vp_stream stream) {

@@ -284,6 +284,7 @@ _PROTOS = {
     'vp_asp_softmax_stats_l16': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     'vp_attn_stats_bwd_e16': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
                                        c_void_p, c_int, c_void_p]),
+    'vp_affine_rows_f32_b16': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, C.c_longlong, c_int, c_void_p, c_int, c_int, c_void_p]),
     'vp_affine_rows_b16_b16': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, C.c_longlong, c_int, c_void_p, c_int, c_int, c_void_p]),
     'vp_time_stats_bwd_add_x16': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_int,
                                            c_void_p, c_int, c_void_p]),

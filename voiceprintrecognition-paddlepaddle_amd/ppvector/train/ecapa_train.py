@@ -69,6 +69,8 @@ def se_res2net_block(blk, x, B, T, shadow=None):
     h = tdnn_block(blk.tdnn2, h, B, T, want_tsums=True, y_bf16=all16)
     if res16 is not None:
         residual._vp_bf16 = res16                                # (a view of x: attributes do not travel with it)
+        if getattr(x, '_vp_bf16_only', False):
+            residual._vp_bf16_only = True
     se = blk.se_block                                           # squeeze, two dense layers, gate, + residual: one tape entry
     out = SEBlockFn.apply(h, residual, se.conv1.conv.weight, se.conv1.conv.bias, se.conv2.conv.weight, se.conv2.conv.bias, B, T, shadow)
     if shadow is not None:
@@ -81,15 +83,18 @@ def se_res2net_block(blk, x, B, T, shadow=None):
 def ecapa_forward_train(m, feats):
     B, T, F = feats.shape
     x = feats.reshape(B * T, F)
-    x = tdnn_block(m.blocks[0], x, B, T)
-    outs = []
     blocks = list(m.blocks)[1:]
+    Cb0 = m.blocks[0].conv.conv.weight.shape[0]
+    use_xcat = (ppvector.get_train_amp() and os.environ.get('VPMI_TRAIN_BF16_OPS', '2') != '0' and not os.environ.get('VPMI_NO_SHADOW')
+                and B * T >= 4096 and Cb0 % 64 == 0 and Cb0 >= 256 and m.mfa.conv.conv.weight.shape[1] == Cb0 * len(blocks))
+    # (with the bf16 operand path on, block 0's output is read as bf16 only -- tdnn1's operand and the first block's residual)
+    x = tdnn_block(m.blocks[0], x, B, T, y_bf16=use_xcat and not os.environ.get('VPMI_BLOCK0_F32_OUT'))
+    outs = []
     # enable_amp: the block outputs are GEMM operands twice (next block's tdnn1, the MFA concatenation) -- the kernel that produces
     # them also writes them as bf16, straight into their column slice of the MFA operand (VPMI_TRAIN_BF16_OPS=0: f32 operands)
     Cb = x.shape[1]
     xcat = None
-    if ppvector.get_train_amp() and os.environ.get('VPMI_TRAIN_BF16_OPS', '2') != '0' and not os.environ.get('VPMI_NO_SHADOW') \
-            and B * T >= 4096 and Cb % 64 == 0 and Cb >= 256 and m.mfa.conv.conv.weight.shape[1] == Cb * len(blocks):
+    if use_xcat:
         xcat = torch.empty((B * T, Cb * len(blocks)), dtype=torch.bfloat16, device=x.device)
     if xcat is not None and getattr(x, '_vp_bf16', None) is None:
         x._vp_bf16 = x.to(torch.bfloat16)                        # block 0's output as the first block reads it (GEMM operand and residual)

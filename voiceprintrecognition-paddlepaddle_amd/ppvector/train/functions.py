@@ -48,6 +48,8 @@ def _bytes(n, dev):
 def _f32c(t):
     if t.dtype != torch.float32 or not t.is_cuda:
         raise N.VpmiError('training functions take f32 GPU tensors (no CPU fallback)')
+    if getattr(t, '_vp_bf16_only', False) and getattr(t, '_vp_bf16', None) is not None:
+        return t._vp_bf16.float()         # a memory-less placeholder (_placeholder): a consumer without a bf16 path gets the values converted
     return t.contiguous()
 
 
@@ -225,6 +227,13 @@ class ConvBlock(torch.autograd.Function):
                                                 add.stride(0) if add is not None else 0, aux.data_ptr() if aux is not None else None,
                                                 Cout, N.stream_ptr()), hctx)
                 ctx.aux_out = aux
+            elif cfg.get('y_bf16') and not wide and not tanh and ppvector.get_train_amp():
+                # a layer outside the wide set whose consumers read bf16 only (ECAPA's block 0): the apply pass writes the bf16 form directly
+                y16t = torch.empty(z.shape, dtype=torch.bfloat16, device=x.device)
+                _chk(lib.vp_affine_rows_f32_b16(hctx, z.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(), B * T_out, Cout,
+                                                y16t.data_ptr(), Cout, 0, N.stream_ptr()), hctx)
+                y = _placeholder(z.shape, x.device)
+                cfg['_y16'] = y16t
             else:
                 y = torch.empty_like(z)
                 _chk(lib.vp_affine_rows_f32(hctx, z.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(), B * T_out, Cout,
