@@ -97,6 +97,9 @@ def _wide_bf16(M, Cin, Cout, KW, bias, rowbias, gamma, cfg):
 # the forward run the 256-wide LDS-DMA kernel (bf16 -> bf16, statistics from the f32 accumulators) and halves z's three later reads.
 
 
+_ZERO = {}
+
+
 def _only16(t):
     """The bf16 tensor that carries the values of `t` when `t` is a memory-less f32 placeholder on the tape (see ConvBlock cfg['y_bf16'],
     SEBlockFn), else None."""
@@ -106,7 +109,11 @@ def _only16(t):
 def _placeholder(shape, device):
     """f32 tensor of `shape` that owns one element: what autograd sees of an activation that exists as bf16 only (autograd hands a
     tensor's gradient over in the tensor's dtype, so a bf16 tensor on the tape would get its f32 gradient cast down)."""
-    return torch.zeros(1, dtype=torch.float32, device=device).expand(shape)
+    key = (device.type, device.index)
+    z = _ZERO.get(key)
+    if z is None:                  # one zero per device, made once (a torch.zeros per placeholder is a 5 us fill launch, 16 of them per step)
+        z = _ZERO[key] = torch.zeros(1, dtype=torch.float32, device=device)
+    return z.expand(shape)
 
 
 def _narrow_to_wide(M, Cin, Cout, KW):
