@@ -262,3 +262,88 @@ def test_cut_carries_the_producers_bf16_twin_to_the_next_stage():
     assert torch.allclose(a.grad, 8 * a.detach())
     y3, = cut(y)                                           # outside a recorder: identity
     assert y3 is y
+
+
+def test_bf16_only_activation_travels_as_a_placeholder_with_an_f32_gradient():
+    """Round 4: an activation that exists as bf16 only is put on the autograd tape as an f32 tensor that owns one element (a zero expanded
+    to the shape: ppvector/train/functions.py `_placeholder`); its values travel as the `_vp_bf16` twin with `_vp_bf16_only` set.  What
+    this relies on, checked on plain torch (CPU): (a) a custom Function may return such a view and receive an f32 gradient of the FULL
+    shape for it; (b) had the output been a bf16 tensor, autograd would hand its gradient over as bf16 -- the reason for the placeholder;
+    (c) a stage cut carries both attributes; (d) a consumer without a bf16 path gets the values (`_f32c`)."""
+    import torch
+    from ppvector.train.segments import Recorder, cut
+    seen = {}
+
+    class Producer(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, as_bf16):
+            ctx.save_for_backward(x)
+            if as_bf16:
+                return (x * 3).to(torch.bfloat16)
+            return torch.zeros(1).expand(x.shape)            # placeholder; the caller hangs the twin on it
+
+        @staticmethod
+        def backward(ctx, g):
+            seen['producer_grad'] = (g.dtype, tuple(g.shape), g.clone())
+            return g.float() * 3, None
+
+    class Consumer(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, y):
+            twin = y._vp_bf16 if getattr(y, '_vp_bf16_only', False) else y
+            ctx.save_for_backward(twin)
+            return twin.float().pow(2).sum()
+
+        @staticmethod
+        def backward(ctx, g):
+            twin, = ctx.saved_tensors
+            return g * 2 * twin.float()                        # f32 gradient of the full shape, whatever the input's storage is
+
+    a = torch.randn(5, 7, requires_grad=True)
+    y = Producer.apply(a, False)
+    assert y.dtype == torch.float32 and tuple(y.shape) == (5, 7) and y.untyped_storage().nbytes() == 4
+    y._vp_bf16, y._vp_bf16_only = (a.detach() * 3).to(torch.bfloat16), True
+    with Recorder() as rec:
+        y2, = cut(y)
+        assert getattr(y2, '_vp_bf16_only', False) and y2._vp_bf16 is y._vp_bf16
+        rec.backward(Consumer.apply(y2))
+    dt, shape, g = seen['producer_grad']
+    assert dt == torch.float32 and shape == (5, 7)
+    ref = 2 * (a.detach() * 3).to(torch.bfloat16).float()
+    assert torch.equal(g, ref) and torch.equal(a.grad, ref * 3)
+    # (b) the same graph with a bf16 tensor on the tape: the consumer's f32 gradient arrives rounded to bf16
+    a2 = a.detach().clone().requires_grad_()
+    Consumer.apply(Producer.apply(a2, True)).backward()
+    assert seen['producer_grad'][0] == torch.bfloat16
+    # (d) _f32c on a placeholder returns the twin's values (GPU-only helper: checked for its branch logic on a stand-in)
+    from ppvector.train import functions as F
+    ph = torch.zeros(1).expand(5, 7)
+    ph._vp_bf16, ph._vp_bf16_only = y._vp_bf16, True
+    assert F._only16(ph) is y._vp_bf16 and F._only16(torch.zeros(2)) is None
+
+
+def test_pass_through_gradients_are_handed_on_without_a_copy():
+    """Recorder.backward: a leaf that only travels through a cut (consumed further down) receives the later leaf's gradient as the SAME
+    tensor; what its own stage adds is accumulated by autograd.  Gradients equal the single-tape result."""
+    import torch
+    from ppvector.train.segments import Recorder, cut
+    w1, w2, w3 = (torch.randn(4, 4, requires_grad=True) for _ in range(3))
+    x = torch.randn(3, 4)
+
+    def net(record):
+        o1 = torch.tanh(x @ w1)
+        o1c, = cut(o1) if record else (o1,)
+        o2 = torch.tanh(o1c @ w2)
+        o1d, o2d = cut(o1c, o2) if record else (o1c, o2)       # o1 travels through this cut to reach its second consumer
+        return (torch.cat([o1d, o2d], dim=1) @ torch.cat([w3, w3], dim=0)).pow(2).sum()
+
+    net(False).backward()
+    want = [w.grad.clone() for w in (w1, w2, w3)]
+    for w in (w1, w2, w3):
+        w.grad = None
+    with Recorder() as rec:
+        loss = net(True)
+        assert rec.n_stages == 3
+        rec.backward(loss)
+    for w, g in zip((w1, w2, w3), want):
+        assert torch.allclose(w.grad, g, rtol=1e-5, atol=1e-6)
