@@ -1454,3 +1454,70 @@ def test_time_statistics_over_many_frames_vs_float64(N, B, T, C, tstp):
     e1, e2 = rel(st[:, :C], mean), rel(st[:, C:], std)
     print(f'[time stats B={B} T={T} C={C} tstp={tstp}] mean {e1:.1e}, std {e2:.1e}')
     assert e1 < 2e-6 and e2 < 2e-6
+
+
+@pytest.mark.parametrize('B,T,Cc', [(3, 47, 96), (5, 298, 192), (2, 160, 64)])
+def test_statistics_kernels_on_bf16_stored_tensors_vs_float64(N, B, T, Cc):
+    """Round 4: the training kernels that read activations STORED as bf16 (the values are exactly the bf16 numbers, so the float64
+    reference over those numbers is exact up to the kernels' own f32 arithmetic): vp_asp_softmax_stats_l16 and vp_attn_stats_bwd_e16 (bf16
+    logits, x f32 or bf16; d e written as bf16: compared at bf16 resolution), vp_time_stats_bwd_add_x16, vp_utt_sums_b16, vp_utt_dot_x16,
+    vp_affine_rows_b16_b16 / _f32_b16."""
+    lib, ctx = N.lib(), N.ctx(torch.device('cuda', 0))
+    g = torch.Generator().manual_seed(B * 31 + T)
+    bf = lambda t: t.to(torch.bfloat16)
+    x16 = bf(torch.randn(B * T, Cc, generator=g))
+    e16 = bf(torch.randn(B * T, Cc, generator=g) * 2)
+    dp = torch.randn(B, 2 * Cc, generator=g)
+    dpd, x16d = dp.cuda(), x16.cuda()                    # (device copies kept alive in names: a temporary's memory may be reused before its kernel runs)
+    for x_is16 in (False, True):
+        xs = x16 if x_is16 else torch.randn(B * T, Cc, generator=g)
+        x = xs.double().view(B, T, Cc).requires_grad_()
+        e = e16.double().view(B, T, Cc).requires_grad_()
+        al = torch.softmax(e, dim=1)
+        mu = (al * x).sum(1)
+        sd = torch.sqrt(((al * (x - mu[:, None]) ** 2).sum(1)).clamp(min=1e-12))
+        pooled_ref = torch.cat([mu, sd], 1)
+        (pooled_ref * dp.double()).sum().backward()
+        xd, ed = xs.cuda(), e16.cuda()
+        pooled = torch.empty(B, 2 * Cc, device='cuda')
+        dt = N.VP_BF16 if x_is16 else N.VP_F32
+        N.check(lib.vp_asp_softmax_stats_l16(ctx, ed.data_ptr(), xd.data_ptr(), dt, Cc, 0, B, T, Cc, 1e-12, pooled.data_ptr(), N.stream_ptr()), ctx)
+        assert rel(pooled, pooled_ref.detach()) < 5e-6
+        de = torch.empty(B * T, Cc, dtype=torch.bfloat16, device='cuda')
+        dx = torch.empty(B * T, Cc, device='cuda')
+        N.check(lib.vp_attn_stats_bwd_e16(ctx, ed.data_ptr(), xd.data_ptr(), dt, Cc, pooled.data_ptr(), dpd.data_ptr(), B, T, Cc, 1e-12,
+                                          de.data_ptr(), dx.data_ptr(), Cc, N.stream_ptr()), ctx)
+        assert rel(dx.view(B, T, Cc), x.grad) < 3e-5
+        assert rel(de.float().view(B, T, Cc), e.grad) < 4e-3           # d e leaves as bf16: 2^-9 per element
+    # context statistics' backward over a bf16 x, added to another gradient
+    x = x16.double().view(B, T, Cc).requires_grad_()
+    m0 = x.mean(1)
+    s0 = torch.sqrt((((x - m0[:, None]) ** 2).mean(1)).clamp(min=1e-12))
+    ds = torch.randn(B, 2 * Cc, generator=g)
+    (torch.cat([m0, s0], 1) * ds.double()).sum().backward()
+    add = torch.randn(B * T, Cc, generator=g)
+    stats = torch.cat([m0, s0], 1).detach().float().cuda()
+    out, dsd_ = add.clone().cuda(), ds.cuda()
+    N.check(lib.vp_time_stats_bwd_add_x16(ctx, x16d.data_ptr(), Cc, stats.data_ptr(), dsd_.data_ptr(), B, T, Cc, 1e-12, 0,
+                                          out.data_ptr(), Cc, out.data_ptr(), Cc, N.stream_ptr()), ctx)
+    assert rel(out.view(B, T, Cc), x.grad + add.double().view(B, T, Cc)) < 2e-6
+    # per-utterance sums of a bf16 tensor, per-utterance dot of an f32 gradient with a bf16 tensor
+    sums = torch.empty(B, Cc, device='cuda')
+    N.check(lib.vp_utt_sums_b16(ctx, x16d.data_ptr(), Cc, B, T, Cc, sums.data_ptr(), N.stream_ptr()), ctx)
+    assert (sums.double().cpu() - x16.double().view(B, T, Cc).sum(1)).abs().max().item() < 2e-6 * x16.double().abs().view(B, T, Cc).sum(1).max().item()
+    dy = torch.randn(B * T, Cc, generator=g)
+    dsd, dyd = torch.empty(B, Cc, device='cuda'), dy.cuda()
+    N.check(lib.vp_utt_dot_x16(ctx, dyd.data_ptr(), x16d.data_ptr(), B, T, Cc, dsd.data_ptr(), N.stream_ptr()), ctx)
+    want = (dy.double() * x16.double()).view(B, T, Cc).sum(1)
+    assert (dsd.double().cpu() - want).abs().max().item() < 2e-6 * (dy.double() * x16.double()).abs().view(B, T, Cc).sum(1).max().item()
+    # BatchNorm apply pass with a bf16 result: z bf16 or f32 in, bf16 out = the f32 result rounded once
+    scale, shift = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g)
+    zf = torch.randn(B * T, Cc, generator=g)
+    scd, shd = scale.cuda(), shift.cuda()
+    for z in (x16, zf):
+        y, zd = torch.empty(B * T, Cc, dtype=torch.bfloat16, device='cuda'), z.cuda()
+        fn = lib.vp_affine_rows_b16_b16 if z.dtype == torch.bfloat16 else lib.vp_affine_rows_f32_b16
+        N.check(fn(ctx, zd.data_ptr(), Cc, scd.data_ptr(), shd.data_ptr(), B * T, Cc, y.data_ptr(), Cc, 0, N.stream_ptr()), ctx)
+        want = (z.float() * scale + shift)                                # the kernel's f32 fma may differ from this by one f32 ulp before rounding
+        assert (y.float().cpu() - want).abs().max().item() <= 2 ** -8 * want.abs().max().item()
+        assert (y.cpu() != want.to(torch.bfloat16)).float().mean().item() < 2e-3     # same bf16 number except where the f32 values straddle a rounding boundary
