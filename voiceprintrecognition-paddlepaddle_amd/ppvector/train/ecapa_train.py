@@ -13,12 +13,12 @@ from ppvector.train.segments import cut
 from ppvector.train.tdnn_train import asp_forward
 
 
-def tdnn_block(blk, x, B, T, want_tsums=False, y_bf16=False):
+def tdnn_block(blk, x, B, T, want_tsums=False, y_bf16=False, wide_taps=False):
     """TDNNBlock (models/utils.py:122-148): BN(ReLU(Conv1d 'same' reflect)).  want_tsums: the consumer takes time statistics of the
     output (SE squeeze): the conv's fused per-utterance sums travel with the tensor instead of a pass over it."""
     conv, norm = blk.conv.conv, blk.norm.norm
     cfg = dict(B=B, T=T, dilation=blk.conv.dilation, pad='reflect', relu=True, momentum=norm.momentum, eps=norm.eps, want_tsums=want_tsums,
-               y_bf16=y_bf16)
+               y_bf16=y_bf16, wide_taps=wide_taps)
     y = ConvBlock.apply(x, conv.weight, conv.bias, None, norm.weight, norm.bias, norm._mean, norm._variance, cfg)
     if cfg.get('_tsums') is not None:
         y._vp_tsums = cfg.pop('_tsums')
@@ -88,7 +88,8 @@ def ecapa_forward_train(m, feats):
     use_xcat = (ppvector.get_train_amp() and os.environ.get('VPMI_TRAIN_BF16_OPS', '2') != '0' and not os.environ.get('VPMI_NO_SHADOW')
                 and B * T >= 4096 and Cb0 % 64 == 0 and Cb0 >= 256 and m.mfa.conv.conv.weight.shape[1] == Cb0 * len(blocks))
     # (with the bf16 operand path on, block 0's output is read as bf16 only -- tdnn1's operand and the first block's residual)
-    x = tdnn_block(m.blocks[0], x, B, T, y_bf16=use_xcat and not os.environ.get('VPMI_BLOCK0_F32_OUT'))
+    x = tdnn_block(m.blocks[0], x, B, T, y_bf16=use_xcat and not os.environ.get('VPMI_BLOCK0_F32_OUT'),
+                   wide_taps=use_xcat and not os.environ.get('VPMI_BLOCK0_F32_OPS'))
     outs = []
     # enable_amp: the block outputs are GEMM operands twice (next block's tdnn1, the MFA concatenation) -- the kernel that produces
     # them also writes them as bf16, straight into their column slice of the MFA operand (VPMI_TRAIN_BF16_OPS=0: f32 operands)

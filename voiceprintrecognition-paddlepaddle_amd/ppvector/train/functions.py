@@ -86,6 +86,13 @@ def _wide_bf16(M, Cin, Cout, KW, bias, rowbias, gamma, cfg):
     """Mixed precision, wide 1x1 TDNN blocks (tdnn1 / tdnn2 / MFA of ECAPA): the GEMM operands x and dz are kept as bf16 tensors --
     what the matrix cores would round them to anyway -- so the forward, data-gradient and weight-gradient kernels read half the
     bytes and skip the conversion (vp_conv1d_fwd bf16 -> f32, vp_conv1d_wgrad_bf16_oik).  VPMI_TRAIN_BF16_OPS=0 keeps f32 operands."""
+    if cfg.get('wide_taps') and KW > 1:
+        # a tapped layer the caller names (ECAPA's block 0: 80 -> 512, k = 5): the same bf16 operand / bf16 pre-BatchNorm form on the
+        # 256-wide tapped LDS-DMA kernel the inference engine runs it on (f32 operands: 163 us forward, 228 us weight gradient)
+        if not (ppvector.get_train_amp() and gamma is not None and bias is not None and rowbias is None and Cin % 8 == 0 and Cout % 64 == 0
+                and Cout >= 256 and M >= 4096 and not cfg.get('tanh', False) and cfg.get('T', 0) >= 128):
+            return 0
+        return int(os.environ.get('VPMI_TRAIN_BF16_OPS', '2'))
     if not (ppvector.get_train_amp() and KW == 1 and gamma is not None and bias is not None and rowbias is None and Cin % 64 == 0
             and Cin >= 256 and Cout >= 256 and Cout % 4 == 0 and M >= 4096 and not cfg.get('tanh', False)):
         return 0
