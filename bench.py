@@ -518,7 +518,7 @@ def run_train(args, rank, local_rank, world, dist, steps=None, warmup=None, emit
     wav = torch.from_numpy(wav_all[list(idx)] if not args.weak else wav_all).to(dev)
     labels = ((torch.arange(gbatch) * 7) % N_CLASSES)[list(idx)].to(dev)
     import ppvector
-    ppvector.set_train_amp(bool(args.amp))      # enable_amp: bf16 matrix cores over f32 tensors in the three conv GEMMs
+    ppvector.set_train_amp(bool(args.amp))      # enable_amp: bf16 matrix cores in the three conv GEMMs, bf16-stored activations between them
     fz, backbone, head, _, _ = build_ecapa(dev, 'float32')
     model = torch.nn.Sequential(backbone, head).to(dev)
     crit = AAMLoss(margin=0.2, scale=32, easy_margin=False, label_smoothing=0.0)
@@ -574,7 +574,7 @@ def run_train(args, rank, local_rank, world, dist, steps=None, warmup=None, emit
         'metric': 'utterances/sec (3 s, 16 kHz) ECAPA-TDNN training step (Fbank + fwd + AAM + bwd + DP all-reduce + Adam)',
         'value': round(value, 1), 'unit': 'utterances/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
         'ms_per_step': round(ms_step, 4), 'higher_is_better': True, 'scaling': 'weak' if args.weak else 'strong',
-        'vs_baseline': None, 'dtype': 'bf16 matrix cores over f32 tensors (enable_amp), f32 master weights' if args.amp else 'f32', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': 'enable_amp: bf16 matrix cores, activations between the GEMMs stored as bf16, f32 accumulation / statistics / gradients / master weights' if args.amp else 'f32', 'data': 'synthetic',
         'config': {'workload': 'ECAPA-TDNN (C=512, MFA 1536, ASP, embd 192) + Kaldi Fbank 80, 3 s @ 16 kHz (T=298), 2796-class cosine head + '
                                'AAMLoss, train-mode forward (batch-statistics BN) + backward + flat Adam, '
                                + ('conv GEMMs (forward, data and weight gradient) on the bf16 matrix cores, ' if args.amp else 'f32 matrix cores, ') +
@@ -608,7 +608,7 @@ def main():
     ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float32'])
     ap.add_argument('--streams', type=int, default=2, help='concurrent launch sequences per GPU (infer mode)')
     ap.add_argument('--graph', type=int, default=1, help='infer mode: replay the step from one captured HIP graph (1) or launch eagerly (0)')
-    ap.add_argument('--amp', type=int, default=1, help='training: conv GEMMs on the bf16 matrix cores over f32 tensors (enable_amp); 0 = exact f32')
+    ap.add_argument('--amp', type=int, default=1, help='training: conv GEMMs on the bf16 matrix cores, bf16-stored activations (enable_amp); 0 = exact f32')
     ap.add_argument('--global-batch', type=int, default=BATCH, help='train mode: global batch (strong scaling)')
     ap.add_argument('--weak', action='store_true', help='train mode: keep --global-batch utterances PER GPU')
     ap.add_argument('--train-graph', type=int, default=1, help='training: replay forward + backward from a captured HIP graph (1) or launch eagerly (0)')
