@@ -134,7 +134,9 @@ def roofline_pass(reps):
             rbv = torch.randn((BATCH, cout), device=dev, generator=g); keep.append(rbv); d.rowbias = rbv.data_ptr()
         if 'tanh' in extras:
             d.act2 = N.VP_ACT_TANH
-        for _ in range(2):
+        # warm launches: enough sustained load (20 launches = 1-7 ms) that the timed launches behind them run in the GPU's loaded power
+        # state -- with 2, the pass read 0.31-0.34 of peak where the same launches in steady state read 0.36 (same box, same session)
+        for _ in range(20):
             N.check(lib.vp_conv1d_fwd(ctx, C.byref(d), N.stream_ptr()), ctx)
         # `reps` back-to-back launches between ONE pair of events on the launching stream: the average launch duration as the
         # kernel trace reports it (an event pair per launch adds ~3 us of event processing to a 60 us kernel)
@@ -508,7 +510,7 @@ def run_infer(args, rank, local_rank, world, dist):
             out['dp_train_f32'] = {k: dp_f32[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'loss', 'stage_roofline_frac', 'steps')
                                    if k in dp_f32}
     if world == 1 and not args.no_roofline and want16:
-        out['roofline'] = roofline_pass(reps=10)
+        out['roofline'] = roofline_pass(reps=30)
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(state, head_w)
     print(json.dumps(out), flush=True)
