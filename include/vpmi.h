@@ -270,7 +270,12 @@ int vp_se_gate_fwd(vp_ctx* ctx, const float* psum, const float* shift, int B, in
 /* vp_asp_utt_fwd: the WHOLE AttentiveStatisticsPooling.forward (pooling.py:105-123) of the bf16 engine as one kernel per utterance:
  *   h = tanh(BN(ReLU(tdnn.w x + tdnn.bias + rowbias[b]))) (rowbias = the [mean; std] columns of the attention TDNN applied to the global
  *   context, (B, att) f32 or NULL), logits = conv_w h (+ conv_b: constant over time, cancels), softmax over time, pooled (B, 2C) f32 =
- *   [sum_t a x | sqrt(max(sum_t a x^2 - mean^2, eps))] -- the reference's own uncentred form.  x (B*T, ldx) bf16, tdnn.w [att][C] bf16,
+ *   [sum_t a x | sqrt(max(sum_t a x^2 - mean^2, eps))].  The reference computes the CENTRED form sqrt(clip(sum_t a (x - mean)^2, eps))
+ *   (pooling.py:44-46 `_compute_statistics`); the uncentred form needs one pass over x and equals it up to the cancellation in
+ *   E[x^2] - mean^2: with f32 sums over bf16 x the absolute error of the variance is <= ~2^-22 (mean^2 + var) per channel, i.e. the std
+ *   loses accuracy only where |mean| >> std (|mean| / std > ~100 for 1e-3 relative); BatchNorm in front of ASP keeps the MFA output's
+ *   per-channel |mean| / std of order one, and tests/test_gpu_kernels.py::test_asp_utt_kernel_vs_float64 bounds the result against the
+ *   centred float64 form (3e-4 abs).  x (B*T, ldx) bf16, tdnn.w [att][C] bf16,
  *   conv_w [C][att] bf16.  VP_EUNSUP unless att == 128, C % 64 == 0, T <= 304, tdnn = 1x1 with BN (vp_ecapa_fwd then runs the
  *   conv GEMM + vp_asp_fused_fwd pair). */
 int vp_asp_utt_fwd(vp_ctx* ctx, const void* x, int ldx, const vp_tdnn_layer* tdnn, const float* rowbias, const void* conv_w,
@@ -746,11 +751,25 @@ int vp_res2_train_fwd(vp_ctx* ctx, const vp_res2_train_desc* d, void* ws, size_t
 int vp_res2_train_bwd(vp_ctx* ctx, const vp_res2_train_desc* d, void* ws, size_t ws_bytes, vp_stream stream);
 /* 0 unless a grid barrier of this context gave up waiting since the last reset (it never does on a healthy launch; tests assert it).
    Host-synchronising 4-byte read.  While the word is set the optimiser entry points (vp_adam_step_f32 ...) leave the parameters
-   untouched and vp_res2_train_fwd leaves the BatchNorm running statistics untouched: a step computed from incomplete statistics
+   untouched and vp_res2_train_fwd / vp_bn_train_finalize leave the BatchNorm running statistics untouched: a step computed from incomplete statistics
    never reaches the weights (reference: trainer.py:206-274 has no such failure mode -- this guards OUR fused kernels). */
 int vp_grid_barrier_status(vp_ctx* ctx);
 /* Clears the barrier words (after a bail-out, once the caller has switched to the per-chunk kernels). */
 int vp_grid_barrier_reset(vp_ctx* ctx, vp_stream stream);
+/* The 512 barrier words (2048 bytes, 256-byte aligned, zeroed) may live in CALLER-owned device memory: word 257 is the bail-out flag
+ * every persistent-state writer tests (the optimiser entry points, vp_bn_train_finalize's running statistics, vp_res2_train_fwd's).
+ * The data-parallel step (ppvector/train/step.py; reference: fleet.distributed_model keeps replicas identical, trainer.py:316-320)
+ * owns them as a tensor so that it can MAX-all-reduce the flag with the gradients -- every rank drops the same steps -- and read it
+ * back every step with an asynchronous 4-byte copy.  NULL returns to the context's own words.  Call before any launch is captured
+ * into a graph (captured launches keep the pointer they saw). */
+int vp_set_grid_barrier_words(vp_ctx* ctx, void* words);
+/* CUs the grid-barrier kernels must leave free for kernels of OTHER queues (the collective running beside a data-parallel step,
+ * trainer.py:316-320): a launch of more than (#CUs - n_cus) workgroups returns VP_EUNSUP (callers run the per-chunk entry points).
+ * Independently of the reserve, a launch is refused when the runtime's occupancy query says the grid cannot be resident at once. */
+int vp_set_grid_reserve_cus(vp_ctx* ctx, int n_cus);
+/* Diagnostic: n_workgroups workgroups that each hold a CU slot and lds_bytes of LDS for ~usec microseconds on `stream` -- the
+ * stand-in for a persistent kernel of another queue in the co-residency tests of the grid-barrier kernels (no reference counterpart). */
+int vp_occupy_cus(vp_ctx* ctx, int n_workgroups, int lds_bytes, int usec, vp_stream stream);
 /* The SE block's backward as two passes (SEBlock + residual, ecapa_tdnn.py:50-82, 139-141):
  * vp_utt_dot_f32: ds[b][c] = sum_t dy[b,t,c] * x[b,t,c];  vp_scale_shift_rows_f32: dx[b,t,c] = dy[b,t,c] * s[b][c] + dm[b][c] / T
  * (dm = the gradient that reached the squeeze mean through the two dense layers).  C % 4 == 0, contiguous (B*T, C) tensors. */

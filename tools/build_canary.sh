@@ -1,8 +1,9 @@
 #!/bin/bash
-# Builds the co-run screen's victim kernels (tools/canary.hip -> <pkg>/lib/libcanary.so, git-ignored, travels to the GPU box).
-# The canaries are compiled WITH packed-f32 instructions -- they are the reproducer of the hazard the product build avoids.
+# Builds the co-run screen's victim kernels (tools/canary.hip -> tools/bin/libcanary.so, git-ignored, travels to the GPU box).
+# The canaries are compiled WITH packed-f32 instructions -- they are the reproducer of the hazard the product build avoids --
+# and therefore live OUTSIDE the product's lib/ directory.
 set -e
 HERE=$(dirname "$0")
-PKG=$HERE/../voiceprintrecognition-paddlepaddle_amd
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $HERE/canary.hip -o $PKG/lib/libcanary.so
-echo $PKG/lib/libcanary.so
+mkdir -p $HERE/bin
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $HERE/canary.hip -o $HERE/bin/libcanary.so
+echo $HERE/bin/libcanary.so

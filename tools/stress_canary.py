@@ -14,7 +14,7 @@ from ppvector import _native as N
 IT = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 NS = int(os.environ.get('NSTREAMS', '4'))
 lib, ctx = N.lib(), N.ctx(0)
-can = C.CDLL(os.path.join(PKG, 'lib', 'libcanary.so'))
+can = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'bin', 'libcanary.so'))     # bash tools/build_canary.sh
 can.canary_launch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
 can.canary_fill_launch.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
 can.canary_fill_w_launch.argtypes = [C.c_void_p, C.c_int, C.c_void_p]

@@ -52,7 +52,6 @@ struct AspUttArgs {
     const bf16_t* wc;       // [C][128]
     float* pooled;          // (B, 2C)
     int ldx, T, C; float eps;
-    int dbg;                // timing study (VPMI_ASP_DBG, tools/prof_asp.sh): 1 = no phase-1 K loop, 2 = no phase-2 block loop
 };
 
 __device__ __forceinline__ float au_tanh(float v) {
@@ -109,7 +108,7 @@ __global__ __launch_bounds__(AU_THREADS, 1) void asp_utt_kernel(const AspUttArgs
     const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.wt), 0, (unsigned)(AU_ATT * C * 2), 0x00020000);
     const unsigned ldwb = (unsigned)C * 2u;
     const unsigned wl = (unsigned)prow * ldwb + (unsigned)(((lane & 3) ^ ((0 - (prow >> 2)) & 3)) << 4);
-    const int NK = (a.dbg & 1) ? 0 : C / AU_KS;
+    const int NK = C / AU_KS;
     // x pieces wv, wv + 8, (wv + 16 for waves 0-3) of the stage's 20; W_t piece wv of its 8
     const bool four = wv < 4;
     auto issue = [&](int k, int slot) {
@@ -183,7 +182,7 @@ __global__ __launch_bounds__(AU_THREADS, 1) void asp_utt_kernel(const AspUttArgs
     // stage n = 32 channels: x (304 rows x 64 B = 19 pieces) + W_c rows (32 x 256 B = 8 pieces of 4 rows: lane l at row l >> 4, position
     // l & 15, fetching chunk position ^ (row & 15)).  Pieces per wave: x wv, wv + 8, (wv + 16 for waves 0-2), W_c wv.
     const __amdgpu_buffer_rsrc_t csrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.wc), 0, (unsigned)(C * AU_ATT * 2), 0x00020000);
-    const int NC = (a.dbg & 2) ? 0 : C / 32;
+    const int NC = C / 32;
     const bool four2 = wv < 3;
     auto issue2 = [&](int n, int slot) {
         char* st = smem + slot * AU_STAGE2;
@@ -408,7 +407,8 @@ int vp_asp_utt_bf16(vp_ctx* ctx, const void* x, int ldx, const vp_tdnn_layer* td
         ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(tdnn->w) | reinterpret_cast<uintptr_t>(conv_w)) & 15) ||
         (size_t)T * ldx * 2 >= 0xe0000000ull)
         return VP_EUNSUP;
-    static bool attr_set = false;
+    static bool attr_dev[64] = {};                    // the attribute is per DEVICE (a process may drive several GPUs)
+    bool& attr_set = attr_dev[ctx->device & 63];
     if (!attr_set) {
         VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(asp_utt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, AU_SMEM));
         attr_set = true;
@@ -418,7 +418,6 @@ int vp_asp_utt_bf16(vp_ctx* ctx, const void* x, int ldx, const vp_tdnn_layer* td
     a.bn_shift = tdnn->bn_shift; a.wc = (const bf16_t*)conv_w; a.pooled = pooled;
     (void)conv_b;                                                        // constant over time: cancels in the softmax
     a.ldx = ldx; a.T = T; a.C = C; a.eps = eps;
-    { static const int dbg = getenv("VPMI_ASP_DBG") ? atoi(getenv("VPMI_ASP_DBG")) : 0; a.dbg = dbg; }
     hipLaunchKernelGGL(asp_utt_kernel, dim3(B), dim3(AU_THREADS), AU_SMEM, st, a);
     VP_LAUNCH_CHECK(ctx, "asp_utt");
     return VP_OK;

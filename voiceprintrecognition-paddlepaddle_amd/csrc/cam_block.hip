@@ -400,7 +400,8 @@ int vp_cam_block_bf16(vp_ctx* ctx, const vp_cam_layer* layers, int n_layers, voi
     }
     constexpr size_t smem = (size_t)2 * CB_TP * 128 + (size_t)(CB_TP + 1) * CB_HROW + (size_t)CB_GR * CB_WLROW +
                             (size_t)(2 * CB_MAX_CH + (CB_MAX_SEG + 1) * CB_BNC + CB_MAX_SEG * CB_H + CB_MAX_SEG * CB_GR + CB_THREADS) * 4;
-    static bool attr_set = false;
+    static bool attr_dev[64] = {};                    // the attribute is per DEVICE (a process may drive several GPUs)
+    bool& attr_set = attr_dev[ctx->device & 63];
     if (!attr_set) {
         VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(cam_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;

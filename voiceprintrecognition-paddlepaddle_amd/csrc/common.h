@@ -34,6 +34,10 @@ struct vp_ctx {
     // counters of the in-kernel grid barrier (res2_train.hip): eight arrival counters 32 words apart, [256] departures, [257] bail-out
     // flag (VP_FAULT_WORD); zero between launches
     unsigned* grid_bar;
+    unsigned* grid_bar_own;   // the context's own allocation of them (vp_set_grid_barrier_words may point grid_bar at caller-owned words)
+    // CUs the fused grid-barrier kernels leave to kernels of other queues (a collective running beside the step): a launch of more than
+    // (#CUs - reserve) workgroups takes the per-chunk path instead (vp_set_grid_reserve_cus)
+    int grid_reserve_cus;
 };
 constexpr int VP_FAULT_WORD = 8 * 32 + 1;
 // the bail-out word the optimiser kernels test before they update anything (nullptr: no barrier words on this context)

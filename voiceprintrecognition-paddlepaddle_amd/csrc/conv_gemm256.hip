@@ -1199,7 +1199,8 @@ template <typename TO>
 int launch128x256_ring(vp_ctx* ctx, const ConvArgs& a, hipStream_t st) {
     constexpr int smem = R2_BYTES;                             // >= the epilogue's 4 x 64 x 272 images + 8 KB of column-sum partials
     static_assert(4 * 64 * 272 + 2 * 2 * 2 * T2 * 4 <= R2_BYTES, "epilogue image must fit the ring");
-    static bool attr_set = false;
+    static bool attr_dev[64] = {};                    // the attribute is per DEVICE (a process may drive several GPUs)
+    bool& attr_set = attr_dev[ctx->device & 63];
     if (!attr_set) {
         VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm128x256_ring_kernel<TO>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -1213,7 +1214,8 @@ int launch128x256_ring(vp_ctx* ctx, const ConvArgs& a, hipStream_t st) {
 template <int MODE>
 int launch256_ring(vp_ctx* ctx, const ConvArgs& a, hipStream_t st) {
     constexpr int smem = 8 * 64 * 272 + 2 * 4 * 2 * T2 * 4;      // output slabs + column-sum partials (> the 128 KB ring)
-    static bool attr_set = false;
+    static bool attr_dev[64] = {};                    // the attribute is per DEVICE (a process may drive several GPUs)
+    bool& attr_set = attr_dev[ctx->device & 63];
     if (!attr_set) {
         VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm256_ring_kernel<MODE, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -1227,7 +1229,8 @@ int launch256_ring(vp_ctx* ctx, const ConvArgs& a, hipStream_t st) {
 template <int MODE, int SCHED>
 int launch256(vp_ctx* ctx, const ConvArgs& a, hipStream_t st) {
     constexpr int smem = 8 * 64 * 272 + 2 * 4 * 2 * T2 * 4;      // output slabs + column-sum partials (> the K panels)
-    static bool attr_set = false;
+    static bool attr_dev[64] = {};                    // the attribute is per DEVICE (a process may drive several GPUs)
+    bool& attr_set = attr_dev[ctx->device & 63];
     if (!attr_set) {
         VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm256_kernel<MODE, SCHED>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem));

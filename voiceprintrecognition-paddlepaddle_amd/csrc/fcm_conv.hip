@@ -446,7 +446,8 @@ int vp_conv3x3_c32_bf16(vp_ctx* ctx, const void* x, void* y, const vp_tdnn_layer
     if (shortcut) { a.w2 = (const bf16_t*)shortcut->w; a.bias2 = shortcut->bias; a.scale2 = shortcut->bn_scale; a.shift2 = shortcut->bn_shift; }
     a.B = B; a.T = T; a.F_in = F_in; a.F_out = F_out; a.TT = TT; a.relu = relu;
     a.feats = (const bf16_t*)c1_feats; a.c1_w = c1_w; a.c1_b = c1_b; a.c1_scale = c1_scale; a.c1_shift = c1_shift;
-    static bool attr_set = false;
+    static bool attr_dev[64] = {};                    // the attribute is per DEVICE (a process may drive several GPUs)
+    bool& attr_set = attr_dev[ctx->device & 63];
     if (!attr_set) {
         VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
         VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
@@ -484,7 +485,8 @@ int vp_resblock_c32_bf16(vp_ctx* ctx, const void* x, void* y, const vp_tdnn_laye
     a.w1 = (const bf16_t*)conv1->w; a.b1 = conv1->bias; a.s1 = conv1->bn_scale; a.h1 = conv1->bn_shift;
     a.w2 = (const bf16_t*)conv2->w; a.b2 = conv2->bias; a.s2 = conv2->bn_scale; a.h2 = conv2->bn_shift;
     a.B = B; a.T = T; a.F = F; a.TT = TT;
-    static bool attr_set = false;
+    static bool attr_dev[64] = {};                    // the attribute is per DEVICE (a process may drive several GPUs)
+    bool& attr_set = attr_dev[ctx->device & 63];
     if (!attr_set) {
         VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_c32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
         attr_set = true;

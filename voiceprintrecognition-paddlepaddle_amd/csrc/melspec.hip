@@ -191,7 +191,8 @@ size_t mel_smem() {
 template <int NC, int WAVES>
 int launch_mel(vp_ctx* ctx, const MelArgs& a, hipStream_t st) {
     const size_t smem = mel_smem<NC, WAVES>();
-    static bool attr_set = false;
+    static bool attr_dev[64] = {};                    // the attribute is per DEVICE (a process may drive several GPUs)
+    bool& attr_set = attr_dev[ctx->device & 63];
     if (!attr_set) {
         VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(melspec_frames_kernel<NC, WAVES>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

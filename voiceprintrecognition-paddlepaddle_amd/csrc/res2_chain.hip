@@ -242,7 +242,8 @@ int vp_res2_chain_bf16(vp_ctx* ctx, const vp_tdnn_layer* layers, int nconv, cons
 #ifdef VP_TIMING
     a.dbg = g_res2_dbg;
 #endif
-    static bool attr_set = false;
+    static bool attr_dev[64] = {};                    // the attribute is per DEVICE (a process may drive several GPUs)
+    bool& attr_set = attr_dev[ctx->device & 63];
     if (!attr_set) {
         VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(res2_chain_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

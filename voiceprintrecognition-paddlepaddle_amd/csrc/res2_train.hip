@@ -671,13 +671,30 @@ static int rt_num_cus(vp_ctx* ctx) {
     return cus[dev];
 }
 
+// Does a grid of nwg workgroups of `kernel` fit the device at once?  hipOccupancyMaxActiveBlocksPerMultiprocessor is the runtime's own
+// answer for the kernel's registers / LDS (asked once per device and kernel); the reserve is subtracted from the CU count.
+static bool rt_fits(vp_ctx* ctx, const void* kernel, int which, size_t smem, int nwg) {
+    static int per_cu[16][2] = {};
+    int& n = per_cu[ctx->device & 15][which];
+    if (!n) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, RT_THREADS, smem) != hipSuccess || nb < 1) nb = -1;
+        n = nb;
+    }
+    if (n < 1) return false;
+    const long long slots = (long long)n * (rt_num_cus(ctx) - ctx->grid_reserve_cus);
+    return nwg <= slots && nwg <= rt_num_cus(ctx) - ctx->grid_reserve_cus;      // (the dispatcher places one workgroup per CU first)
+}
+
 static int rt_fill(vp_ctx* ctx, const vp_res2_train_desc* d, void* ws, size_t ws_bytes, bool bwd, Res2TrainArgs& a) {
     if (!ctx || !d) return VP_EINVAL;
     const int nconv = d->scale - 1;
     if (d->width != RT_W || nconv < 1 || nconv > RT_MAXC || d->C != d->scale * RT_W) return VP_EUNSUP;
     const int TP = (d->T + 15) / 16 * 16;
     if (d->dil < 1 || d->dil > 8 || d->T < 2 * d->dil + 2 || TP / 16 > RT_WAVES * RT_ROUNDS - 1 || d->B < 1) return VP_EUNSUP;
-    if (d->B > rt_num_cus(ctx)) return VP_EUNSUP;                        // the grid barrier needs every workgroup resident
+    // the grid barrier needs every workgroup resident: one per CU (100-140 KB of LDS each; checked against the occupancy the runtime
+    // computes for the kernel in rt_fits), minus the CUs the caller asked to leave to other queues (vp_set_grid_reserve_cus)
+    if (d->B > rt_num_cus(ctx) - ctx->grid_reserve_cus) return VP_EUNSUP;
     if (!ctx->grid_bar) return VP_EUNSUP;
     if ((size_t)d->B * d->T * d->C * 4 >= 0x0ff00000ull) return VP_EUNSUP;    // 32-bit buffer offsets with room for the out-of-range marker
     // forward: `out` (f32) may be absent when the bf16 copy is asked for -- a caller whose only consumer reads the bf16 copy (tdnn2's GEMM operand)
@@ -713,11 +730,13 @@ int vp_res2_train_fwd(vp_ctx* ctx, const vp_res2_train_desc* d, void* ws, size_t
     const int rc = rt_fill(ctx, d, ws, ws_bytes, false, a);
     if (rc != VP_OK) return rc;
     const size_t smem = (size_t)a.TP * 128 + RT_WT_BYTES + (RT_WAVES * 16 * RT_SLD + RT_WAVES * 128 + 16 * 128 + 2 * 64) * sizeof(float);
-    static bool attr_set = false;
+    static bool attr_dev[64] = {};                    // the attribute is per DEVICE (a process may drive several GPUs)
+    bool& attr_set = attr_dev[ctx->device & 63];
     if (!attr_set) {
         VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(res2_train_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
+    if (!rt_fits(ctx, reinterpret_cast<const void*>(res2_train_fwd_kernel), 0, smem, a.B)) return VP_EUNSUP;
     hipLaunchKernelGGL(res2_train_fwd_kernel, dim3(a.B), dim3(RT_THREADS), smem, (hipStream_t)stream, a);
     VP_LAUNCH_CHECK(ctx, "res2_train_fwd");
     return VP_OK;
@@ -729,11 +748,13 @@ int vp_res2_train_bwd(vp_ctx* ctx, const vp_res2_train_desc* d, void* ws, size_t
     if (rc != VP_OK) return rc;
     const size_t smem = (size_t)(a.TP + 1) * 128 + 2 * RT_WT_BYTES +
                         (RT_WAVES * 16 * RT_SLD + 16 * 64 + RT_WAVES * 128 + 16 * 128 + 3 * 64) * sizeof(float);
-    static bool attr_set = false;
+    static bool attr_dev[64] = {};                    // the attribute is per DEVICE (a process may drive several GPUs)
+    bool& attr_set = attr_dev[ctx->device & 63];
     if (!attr_set) {
         VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(res2_train_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
+    if (!rt_fits(ctx, reinterpret_cast<const void*>(res2_train_bwd_kernel), 1, smem, a.B)) return VP_EUNSUP;
     hipLaunchKernelGGL(res2_train_bwd_kernel, dim3(a.B), dim3(RT_THREADS), smem, (hipStream_t)stream, a);
     VP_LAUNCH_CHECK(ctx, "res2_train_bwd");
     return VP_OK;

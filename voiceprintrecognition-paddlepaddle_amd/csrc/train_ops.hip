@@ -563,6 +563,7 @@ struct BnFinArgs {
     const float* psum; const float* psumsq; int nparts; int M, C;
     const float* gamma; const float* beta; float* run_mean; float* run_var; float momentum, eps;
     float* mean; float* invstd; float* scale; float* shift;
+    const unsigned* fault;      // the context's grid-barrier bail-out word: while it is set the running statistics are left untouched
 };
 
 // One workgroup = 16 channels x 16 part-lanes: the nparts partial rows (tiles x segments: ~1200 at B = 256 x 3 s) are
@@ -598,6 +599,9 @@ __global__ __launch_bounds__(256) void bn_train_finalize_kernel(BnFinArgs a) {
     const float g = a.gamma ? a.gamma[c] : 1.f, be = a.beta ? a.beta[c] : 0.f;
     a.scale[c] = g * is;
     a.shift[c] = be - mu * g * is;
+    // a fused training kernel upstream gave up at its grid barrier: this layer's batch statistics come from incomplete sums.  The step is
+    // dropped by the optimiser kernels; the PERSISTENT state written here (the running statistics) must not see it either
+    if (a.fault && __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     if (a.run_mean) a.run_mean[c] = a.momentum * a.run_mean[c] + (1.f - a.momentum) * mu;
     if (a.run_var) a.run_var[c] = a.momentum * a.run_var[c] + (1.f - a.momentum) * var;
 }
@@ -1358,7 +1362,8 @@ static int wgrad_impl(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int
     if (tr == VP_OK) {
     } else if (d->mfma_bf16 || bf_in) {
         constexpr int smem = 2 * 2 * WA_T * 128;
-        static bool attr_set = false;
+        static bool attr_dev[64] = {};                    // the attribute is per DEVICE (a process may drive several GPUs)
+    bool& attr_set = attr_dev[ctx->device & 63];
         if (!attr_set) {
             VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_amp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
             VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_amp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -1518,7 +1523,7 @@ int vp_bn_train_finalize(vp_ctx* ctx, const float* psum, const float* psumsq, in
                          float* invstd, float* scale, float* shift, vp_stream stream) {
     if (!ctx || !psum || !psumsq || nparts <= 0 || M <= 0 || C <= 0 || !mean || !invstd || !scale || !shift)
         VP_FAIL(ctx, VP_EINVAL, "bn_finalize: bad arguments");
-    BnFinArgs a{psum, psumsq, nparts, (int)M, C, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift};
+    BnFinArgs a{psum, psumsq, nparts, (int)M, C, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, vp_fault_word(ctx)};
     hipLaunchKernelGGL(bn_train_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, a);
     VP_LAUNCH_CHECK(ctx, "bn_train_finalize");
     return VP_OK;

@@ -184,7 +184,8 @@ int vp_wgrad_tr256_bf16(vp_ctx* ctx, const void* x, int ldx, int xoff, const voi
     long long rps = (M + S - 1) / S;
     rps = (rps + WT_KS - 1) / WT_KS * WT_KS;
     if (rps * (long long)(lddz > ldx ? lddz : ldx) * 2 >= 0x70000000LL) return VP_EUNSUP;      // 32-bit buffer offsets
-    static bool attr_set = false;
+    static bool attr_dev[64] = {};                    // the attribute is per DEVICE (a process may drive several GPUs)
+    bool& attr_set = attr_dev[ctx->device & 63];
     if (!attr_set) {
         VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tr256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WT_SMEM));
         attr_set = true;

@@ -181,6 +181,9 @@ _PROTOS = {
     'vp_res2_train_bwd': (c_int, [c_void_p, C.POINTER(Res2TrainDesc), c_void_p, c_size_t, c_void_p]),
     'vp_grid_barrier_status': (c_int, [c_void_p]),
     'vp_grid_barrier_reset': (c_int, [c_void_p, c_void_p]),
+    'vp_set_grid_barrier_words': (c_int, [c_void_p, c_void_p]),
+    'vp_set_grid_reserve_cus': (c_int, [c_void_p, c_int]),
+    'vp_occupy_cus': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     'vp_cosine_aam_tiled_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'vp_cosine_aam_tiled_bwd_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'vp_cosine_aam_tiled_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_int, c_float,
@@ -392,7 +395,28 @@ def ctx(device=None):
             if not h:
                 raise VpmiError(f'vp_create({device}) failed')
             _ctx[device] = h
+            # the grid-barrier words of the fused training kernels live in a tensor of OURS (csrc/api.hip: vp_set_grid_barrier_words): the
+            # data-parallel step all-reduces the bail-out flag with the gradients and polls it with an asynchronous copy (train/step.py)
+            words = torch.zeros(GRID_WORDS, dtype=torch.int32, device=torch.device('cuda', device))
+            torch.cuda.synchronize(device)
+            if library.vp_set_grid_barrier_words(h, words.data_ptr()) == 0:
+                _grid_words[device] = words
     return _ctx[device]
+
+
+GRID_WORDS, FAULT_WORD = 512, 8 * 32 + 1       # csrc/common.h: VP_FAULT_WORD
+_grid_words = {}
+
+
+def grid_words(device=None):
+    """The context's grid-barrier words as an int32 tensor (512,) -- element FAULT_WORD is the bail-out flag -- or None."""
+    ctx(device)
+    if device is None:
+        device = torch.cuda.current_device()
+    device = torch.device(device).index if not isinstance(device, int) else device
+    if device is None:
+        device = torch.cuda.current_device()
+    return _grid_words.get(device)
 
 
 def stream_ptr():

@@ -89,15 +89,6 @@ class _Engine:
         cur = torch.cuda.current_stream(x.device)
         emb = torch.empty((B, self.W.embd_dim), dtype=torch.float32, device=x.device)
         bounds = [(B * i) // S for i in range(S + 1)]
-        split = os.environ.get('VPMI_SHARD_SPLIT')          # study switch: relative shard sizes, e.g. "3,5" (tools: profiles/r04_shard_split.log)
-        if split:
-            wts = [float(v) for v in split.split(',')]
-            if len(wts) == S:
-                acc, bounds = 0.0, [0]
-                for wv in wts[:-1]:
-                    acc += wv
-                    bounds.append(int(round(B * acc / sum(wts))))
-                bounds.append(B)
         for i in range(S):
             st = self._streams[i]
             st.wait_stream(cur)

@@ -36,6 +36,18 @@ def all_reduce_sum_(t, async_op=False):
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
 
 
+def all_reduce_max_(t, async_op=False):
+    """In-place maximum over the ranks (the grid-barrier bail-out flag that travels with the gradients: train/step.py)."""
+    if world_size() == 1:
+        return _Done() if async_op else None
+    if t.is_cuda and dist.get_backend() == 'gloo':
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX)
+        t.copy_(h)
+        return _Done() if async_op else None
+    return dist.all_reduce(t, op=dist.ReduceOp.MAX, async_op=async_op)
+
+
 def allreduce_mean_(flat_grad, bucket_bytes=256 << 20):
     """In-place average of a flat gradient buffer over all ranks, in buckets (one collective per bucket_bytes)."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:

@@ -192,7 +192,7 @@ class ConvBlock(torch.autograd.Function):
             ps = torch.empty((tiles * nseg, Cout), dtype=torch.float32, device=x.device)
             pq = torch.empty_like(ps)
             d.psum, d.psumsq = ps.data_ptr(), pq.data_ptr()
-        if T_in == 1 and KW == 1 and not bn and rowbias is None and not wide and B <= 4096 and Cin >= 1024:
+        if T_in == 1 and KW == 1 and not bn and rowbias is None and not wide and not narrow and B <= 4096 and Cin >= 1024:
             # a per-utterance dense layer (ASP's context term, the embedding layer): B rows are one or two tiles of the conv GEMM, which
             # then walks K = 3072 serially (70 us at B = 256); the small-M dense kernel takes 11 us (exact f32).  Long K only: the short
             # per-utterance layers (the SE block's unfused form) keep the rounding their fused twin is tested against

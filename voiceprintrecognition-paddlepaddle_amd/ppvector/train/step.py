@@ -13,7 +13,7 @@ PPVectorTrainer and bench.py run: forward + backward replayed from captured HIP 
 import torch
 import torch.distributed as dist
 
-from ppvector.train.ddp import OverlappedReducer, all_reduce_sum_, world_size
+from ppvector.train.ddp import OverlappedReducer, all_reduce_max_, all_reduce_sum_, world_size
 from ppvector.train.segments import Recorder
 
 MIN_CHUNK = 1 << 20            # 4 MB of f32 gradients: below this a ring all-reduce over xGMI is latency-bound
@@ -56,6 +56,9 @@ class TrainStep:
         # data-parallel gradient average: bucketed all-reduce launched from autograd hooks while backward is still running
         self.reducer = OverlappedReducer(optimizer) if overlap_allreduce else None
         self.skip_allreduce = False            # measurement switch (bench.py: the same step without the collective)
+        self.faults = 0                        # grid-barrier bail-outs noticed so far (check_faults)
+        self._poll = None                      # (pinned host word, event, side stream) of the asynchronous poll in flight
+        self._reserve_set = False
 
     def _features(self, inputs):
         feats = inputs
@@ -72,6 +75,109 @@ class TrainStep:
         if self.margin_scheduler is not None:
             self.margin_scheduler.step()
         self.step_id += 1
+        self._poll_faults()                    # every step, eager or replayed: no host stall (the copy issued a step ago is read)
+
+    # ------------------------------------------------------------------------------------------------ grid-barrier bail-out
+    # The fused Res2Net training kernels (csrc/res2_train.hip) meet at an in-kernel grid barrier that GIVES UP instead of hanging the
+    # device when its workgroups cannot all be resident.  Device side, immediately: the bail-out word makes every writer of persistent
+    # state (optimiser kernels, BatchNorm running statistics) a no-op, so the step is dropped.  Data-parallel: the word is
+    # MAX-all-reduced with the gradients (`_share_fault`), so every rank drops the SAME steps and the replicas stay identical (the
+    # faulted rank's gradient is garbage on every rank; nobody applies it).  Host side, one step later, without a stall: `_poll_faults`
+    # reads the word through an asynchronous 4-byte copy on a side stream and `_on_fault` switches the process to the per-chunk kernels.
+    def _device(self):
+        return self.optimizer.flat.device
+
+    def _fault_word(self):
+        from ppvector import _native as N
+        dev = self._device()
+        if dev.type != 'cuda':
+            return None
+        w = N.grid_words(dev)
+        return None if w is None else w[N.FAULT_WORD:N.FAULT_WORD + 1]
+
+    def _reserve_cus(self, world):
+        """A collective runs beside the step when there are peers: the grid-barrier kernels leave it CUs (VPMI_GRID_RESERVE_CUS, default
+        64 of 256) so that their own workgroups are co-resident whatever the collective holds."""
+        if self._reserve_set or self._device().type != 'cuda':
+            return
+        import os
+        from ppvector import _native as N
+        ctx = N.ctx(self._device())
+        n = int(os.environ.get('VPMI_GRID_RESERVE_CUS', '64')) if world > 1 else 0
+        N.check(N.lib().vp_set_grid_reserve_cus(ctx, max(0, n)), ctx)
+        self._reserve_set = True
+
+    def _share_fault(self, world):
+        """The bail-out word as every rank will see it: maximum over the ranks, in place, asynchronous like the gradient chunks."""
+        if world <= 1:
+            return None
+        w = self._fault_word()
+        return None if w is None else all_reduce_max_(w, async_op=True)
+
+    def _poll_faults(self):
+        if self._device().type != 'cuda' or torch.cuda.is_current_stream_capturing():
+            return False
+        found = False
+        if self._poll is not None:
+            host, ev, side = self._poll
+            if ev.query():                                 # issued a step ago: done unless the GPU is several steps behind the host
+                found = int(host[0]) != 0
+                self._poll = None
+            else:
+                return False
+        if found:
+            self._on_fault()
+            return True
+        w = self._fault_word()
+        if w is None:
+            return False
+        cur = torch.cuda.current_stream(w.device)
+        side = getattr(self, '_poll_stream', None)
+        if side is None:
+            side = self._poll_stream = torch.cuda.Stream(w.device)
+            self._poll_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            self._poll_host.copy_(w, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self._poll = (self._poll_host, ev, side)
+        return False
+
+    def check_faults(self):
+        """Synchronous form (checkpoints, the end of an epoch): did a grid barrier give up since the last look?  Returns True when a
+        fault was found -- the steps since it happened did not update the model on ANY rank."""
+        from ppvector import _native as N
+        if self._device().type != 'cuda':
+            return False
+        self._poll = None
+        ctx = N.ctx(self._device())
+        if N.lib().vp_grid_barrier_status(ctx) <= 0:
+            return False
+        self._on_fault()
+        return True
+
+    def _on_fault(self):
+        import warnings
+        import ppvector
+        from ppvector import _native as N
+        self.faults += 1
+        ppvector.set_fused_grid_kernels(False)
+        ctx = N.ctx(self._device())
+        N.check(N.lib().vp_grid_barrier_reset(ctx, N.stream_ptr()), ctx)
+        torch.cuda.synchronize()
+        self._drop_captures()
+        # the device dropped every update since the fault, running statistics included; what it cannot undo is state written by kernels
+        # that ran BEFORE the faulting one inside the same step -- valid statistics of valid activations.  Anything non-finite here
+        # would mean the guard has a hole: stop rather than checkpoint it
+        bad = [n for n, b in self.model.named_buffers() if b.is_floating_point() and not bool(torch.isfinite(b).all())]
+        if bad or not bool(torch.isfinite(self.optimizer.flat).all()):
+            raise N.VpmiError(f'grid-barrier bail-out left non-finite state behind ({bad[:3]}): refusing to continue')
+        warnings.warn('a grid barrier of the fused Res2Net training kernels timed out (is another process using this GPU?): every rank '
+                      'dropped the affected steps on the device; continuing on the per-chunk kernels', RuntimeWarning)
+
+    def _drop_captures(self):
+        pass
 
     def _eager(self, feats, labels):
         outputs = self.model(feats)
@@ -80,12 +186,17 @@ class TrainStep:
         world = 1 if self.skip_allreduce else world_size()
         if self.reducer is not None:
             self.reducer.finish()
+            fw = self._share_fault(world)
+            if fw is not None:
+                fw.wait()
         else:
             self.optimizer.pack_grads()
             if world > 1:                                 # the same chunks, in the same order, as the graphed step of a peer
                 works = [all_reduce_sum_(self.optimizer.grad[lo:hi], async_op=True) for lo, hi in reduce_chunks(self.optimizer.grad.numel())]
+                works.append(self._share_fault(world))    # ... and the bail-out word behind them, as there
                 for w in works:
-                    w.wait()
+                    if w is not None:
+                        w.wait()
         self.optimizer.step(grad_scale=1.0 / world)
         self.optimizer.clear_grad()
         with torch.no_grad():
@@ -96,6 +207,7 @@ class TrainStep:
     def __call__(self, inputs, labels):
         """inputs: waveforms (B, L) when a featurizer was given, else features (B, T, F).  Returns (loss, accuracy) tensors."""
         self.model.train()
+        self._reserve_cus(1 if self.skip_allreduce else world_size())
         return self._eager(self._features(inputs), labels)
 
 
@@ -126,32 +238,11 @@ class GraphedTrainStep(TrainStep):
         self._plans, self._seen = {}, {}
         self.capture_error = None
         self._margin = None
-        self.fault_every = fault_every           # steps between polls of the grid-barrier bail-out word (a host sync each)
-        self.faults = 0
+        self.fault_every = fault_every           # (kept for callers that pass it: the word is now polled EVERY step, asynchronously)
 
-    def check_faults(self):
-        """Did a grid barrier of the fused training kernels give up since the last poll?  The device has already protected the
-        weights (the optimiser kernels and the running-statistics update test the same word); here the host finds out, switches the
-        fused kernels off for the rest of the process, re-arms the barrier words and drops the captured graphs (they replay the
-        fused kernels).  Called every `fault_every` steps, and by the trainer before every checkpoint / at the end of an epoch.
-        Returns True when a fault was found (the steps since the last poll did not update the model)."""
-        from ppvector import _native as N
-        import ppvector
-        if not torch.cuda.is_available():
-            return False
-        ctx = N.ctx(torch.device('cuda', torch.cuda.current_device()))
-        if N.lib().vp_grid_barrier_status(ctx) <= 0:
-            return False
-        self.faults += 1
-        ppvector.set_fused_grid_kernels(False)
-        N.check(N.lib().vp_grid_barrier_reset(ctx, N.stream_ptr()), ctx)
-        torch.cuda.synchronize()
-        self._plans.clear()
+    def _drop_captures(self):
+        self._plans.clear()                    # the captured graphs replay the fused kernels
         self._seen.clear()
-        import warnings
-        warnings.warn('a grid barrier of the fused Res2Net training kernels timed out (is another process using this GPU?): the '
-                      'optimiser dropped the affected steps on the device; continuing on the per-chunk kernels', RuntimeWarning)
-        return True
 
     # ------------------------------------------------------------------------------------------------ capture
     def _spans(self, params):
@@ -242,6 +333,7 @@ class GraphedTrainStep(TrainStep):
     def __call__(self, inputs, labels):
         from ppvector import _native as N
         self.model.train()
+        self._reserve_cus(1 if self.skip_allreduce else world_size())
         feats = self._features(inputs)
         labels = labels.to(feats.device)
         key = (tuple(feats.shape), feats.dtype, tuple(labels.shape))
@@ -271,6 +363,7 @@ class GraphedTrainStep(TrainStep):
                 lo, hi = plan['chunks'][nxt]              # complete after this stage: travels while the next stage replays
                 works.append(all_reduce_sum_(self.optimizer.grad[lo:hi], async_op=True))
                 nxt += 1
+        works.append(self._share_fault(world))            # the bail-out word behind the last chunk: every rank drops the same steps
         for w in works:
             if w is not None:
                 w.wait()
@@ -279,10 +372,7 @@ class GraphedTrainStep(TrainStep):
         self.optimizer.step(grad_scale=1.0 / world)
         self.optimizer.clear_grad()
         self._after()
-        out = plan['static']['loss'].clone(), plan['static']['acc'].clone()
-        if self.fault_every and self.step_id % self.fault_every == 0:
-            self.check_faults()
-        return out
+        return plan['static']['loss'].clone(), plan['static']['acc'].clone()
 
     @property
     def n_stages(self):
