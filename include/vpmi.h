@@ -587,6 +587,12 @@ int vp_conv1d_wgrad_f32(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, i
 int vp_conv1d_wgrad_oik_f32(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int lddz, float* dW, void* ws, size_t ws_bytes,
                             vp_stream stream);
 int vp_conv_weight_layouts_f32(vp_ctx* ctx, const float* w, int Cout, int Cin, int KW, float* wp, float* w2, vp_stream stream);
+/* vp_prep_weights_bf16: for n f32 matrices w[i] (rows[i] x cols[i], row pitch ld[i] >= cols[i] -- HOST arrays of n entries): the bf16 copy
+ * w16[i] [rows][cols] and / or the bf16 transpose wt16[i] [cols][rows] (either may be NULL) in one launch per 24 matrices -- the forward and
+ * data-gradient weight panels of every wide 1x1 layer of a mixed-precision step (paddle.amp.auto_cast casts each conv's weight at each
+ * call, trainer.py:209-213; here: once per step, all layers together). */
+int vp_prep_weights_bf16(vp_ctx* ctx, const void* const* w, void* const* w16, void* const* wt16, const int* rows, const int* cols,
+                         const int* ld, int n, vp_stream stream);
 size_t vp_col_sums_workspace_bytes(long long M, int C);
 int vp_col_sums_f32(vp_ctx* ctx, const float* a, int lda, const float* b, int ldb, const float* bmean, const float* bscale,
                     long long M, int C, float* sums, void* ws, size_t ws_bytes, vp_stream stream);

@@ -467,6 +467,45 @@ __global__ __launch_bounds__(256) void weight_layouts_kernel(const float* w, int
     }
 }
 
+// ---------------------------------------------------------------------------------------------- bf16 weight panels, all layers at once
+// For up to WPREP_MAX f32 matrices w_e (rows_e x cols_e, row pitch ld_e: a column slice of a wider tensor is allowed): the bf16 copy
+// w16_e [rows][cols] (the forward GEMM's panel) and the bf16 TRANSPOSE wt16_e [cols][rows] (the data-gradient GEMM's panel) in ONE
+// launch -- what a mixed-precision step used to do with two conversion launches per wide layer (auto_cast casts every conv's weight per
+// call in the reference, trainer.py:209-213).  64 x 64 tiles through LDS: both outputs leave as 128-byte rows.
+constexpr int WPREP_MAX = 24;
+struct WPrepArgs {
+    const float* w[WPREP_MAX]; bf16_t* w16[WPREP_MAX]; bf16_t* wt16[WPREP_MAX];
+    int rows[WPREP_MAX], cols[WPREP_MAX], ld[WPREP_MAX], tile0[WPREP_MAX + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void weight_prep_kernel(WPrepArgs a) {
+    __shared__ float sm[64][65];
+    int e = 0;
+    while (e + 1 < a.n && (int)blockIdx.x >= a.tile0[e + 1]) ++e;
+    const int t = blockIdx.x - a.tile0[e];
+    const int rows = a.rows[e], cols = a.cols[e], ld = a.ld[e];
+    const int tc = (cols + 63) / 64;
+    const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+    const float* __restrict__ w = a.w[e];
+    bf16_t* __restrict__ w16 = a.w16[e];
+    bf16_t* __restrict__ wt = a.wt16[e];
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int i = ly; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + lx;
+        const float v = (r < rows && c < cols) ? w[(size_t)r * ld + c] : 0.f;
+        sm[i][lx] = v;
+        if (w16 && r < rows && c < cols) w16[(size_t)r * cols + c] = (bf16_t)v;
+    }
+    if (!wt) return;
+    __syncthreads();
+#pragma unroll 4
+    for (int i = ly; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + lx;
+        if (c < cols && r < rows) wt[(size_t)c * rows + r] = (bf16_t)sm[lx][i];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- column sums over rows
 // part[chunk][which][c]: which 0 = sum_m a[m][c], 1 = sum_m a[m][c] * (b[m][c] - bmean[c]) * bscale[c]  (second only when b)
 struct ColSumArgs { const float* a; const float* b; const float* bmean; const float* bscale; float* part; int lda, ldb, M, C, rows_per_chunk; };
@@ -1376,7 +1415,8 @@ static int wgrad_impl(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int
         // VPMI_WGRAD_NARROW_F32=1 dispatches it for study)
         if (d->Cout <= 64 && K > 128 && ((bf_in && !two_d && d->stride == 1) || (!bf_in && getenv_once("VPMI_WGRAD_NARROW_F32")))) {
             constexpr int smem64 = 2 * (64 + 256) * 128;
-            static bool attr64 = false;
+            static bool attr64_dev[64] = {};
+            bool& attr64 = attr64_dev[ctx->device & 63];
             if (!attr64) {
                 VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_n64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem64));
                 VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_n64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem64));
@@ -1428,6 +1468,28 @@ int vp_conv_weight_layouts_f32(vp_ctx* ctx, const float* w, int Cout, int Cin, i
     hipLaunchKernelGGL(weight_layouts_kernel, dim3(grid1d((long long)Cout * Cin * KW)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, KW,
                        wp, w2);
     VP_LAUNCH_CHECK(ctx, "weight_layouts");
+    return VP_OK;
+}
+
+int vp_prep_weights_bf16(vp_ctx* ctx, const void* const* w, void* const* w16, void* const* wt16, const int* rows, const int* cols,
+                         const int* ld, int n, vp_stream stream) {
+    if (!ctx || !w || !w16 || !wt16 || !rows || !cols || !ld || n <= 0) VP_FAIL(ctx, VP_EINVAL, "prep_weights: bad arguments");
+    for (int i0 = 0; i0 < n; i0 += WPREP_MAX) {
+        WPrepArgs a;
+        memset(&a, 0, sizeof(a));
+        const int m = n - i0 < WPREP_MAX ? n - i0 : WPREP_MAX;
+        int tiles = 0;
+        for (int i = 0; i < m; ++i) {
+            const int k = i0 + i;
+            if (!w[k] || (!w16[k] && !wt16[k]) || rows[k] <= 0 || cols[k] <= 0 || ld[k] < cols[k]) VP_FAIL(ctx, VP_EINVAL, "prep_weights: bad entry %d", k);
+            a.w[i] = (const float*)w[k]; a.w16[i] = (bf16_t*)w16[k]; a.wt16[i] = (bf16_t*)wt16[k];
+            a.rows[i] = rows[k]; a.cols[i] = cols[k]; a.ld[i] = ld[k]; a.tile0[i] = tiles;
+            tiles += ((rows[k] + 63) / 64) * ((cols[k] + 63) / 64);
+        }
+        a.tile0[m] = tiles; a.n = m;
+        hipLaunchKernelGGL(weight_prep_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
+        VP_LAUNCH_CHECK(ctx, "weight_prep");
+    }
     return VP_OK;
 }
 

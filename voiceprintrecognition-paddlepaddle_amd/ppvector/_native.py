@@ -179,6 +179,7 @@ _PROTOS = {
     'vp_res2_train_workspace_bytes': (c_size_t, [c_int, c_int]),
     'vp_res2_train_fwd': (c_int, [c_void_p, C.POINTER(Res2TrainDesc), c_void_p, c_size_t, c_void_p]),
     'vp_res2_train_bwd': (c_int, [c_void_p, C.POINTER(Res2TrainDesc), c_void_p, c_size_t, c_void_p]),
+    'vp_prep_weights_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'vp_grid_barrier_status': (c_int, [c_void_p]),
     'vp_grid_barrier_reset': (c_int, [c_void_p, c_void_p]),
     'vp_set_grid_barrier_words': (c_int, [c_void_p, c_void_p]),
