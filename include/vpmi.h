@@ -170,6 +170,9 @@ int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream);
  * ring, 5 = half-tile ring with resident workgroups (csrc/conv_gemm.hip).  Process-wide; returns the previous value; out-of-range values only query.  Results
  * are identical for every schedule. */
 int vp_conv256_select(int schedule);
+/* A/B switch of the 128 x 256 ring kernel's start stagger (csrc/conv_gemm.hip: g_ring_dephase): each CU's second workgroup starts
+ * `percent` % of an estimated tile time late; 0 = together.  Returns the previous value; results are unaffected (no reference counterpart). */
+int vp_conv_ring_dephase(int percent);
 
 /* mean / std over time from the conv1d partial sums: stats[b][0:C] = mean, stats[b][C:2C] = std,
  * std = sqrt(max(E[(x-mean)^2], eps)) -- pooling.py:90-93 with the all-ones mask of pooling.py:94-101

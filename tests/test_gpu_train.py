@@ -1556,3 +1556,23 @@ def test_enable_amp_trains_like_f32(N, tmp_path):
         assert ta >= 0.9 and tl < first / 3, (amp, first, tl, ta)
     assert c['tail_loss_amp'] <= 1.25 * c['tail_loss_f32'] + 0.05, c
     assert abs(c['eer_amp'] - c['eer_f32']) <= 0.03, c
+
+
+def test_weight_prep_launch_writes_every_bf16_panel(N, monkeypatch):
+    """vp_prep_weights_bf16 (one launch for all wide layers of a step: W bf16 and W^T bf16, column slices allowed) against torch's own
+    conversion, bit for bit; and the registry ConvBlock reads them from goes stale with the weights epoch (an optimiser step)."""
+    from ppvector.train import functions as Fn
+    g = torch.Generator().manual_seed(9)
+    ws = [torch.randn(512, 512, 1, generator=g).cuda(), torch.randn(1536, 1536, 1, generator=g).cuda(), torch.randn(128, 4608, 1, generator=g).cuda(),
+          torch.randn(1536, 128, 1, generator=g).cuda(), torch.randn(70, 200, 1, generator=g).cuda()]
+    items = [(ws[0], 0, 512), (ws[1], 0, 1536), (ws[2], 0, 1536), (ws[3], 0, 128), (ws[4], 8, 100)]
+    Fn.prep_weights_bf16(items)
+    torch.cuda.synchronize()
+    for w, c0, nc in items:
+        p = Fn._panels16(w, c0, nc)
+        assert p is not None
+        ref = w[:, c0:c0 + nc, 0].to(torch.bfloat16)
+        assert torch.equal(p[0], ref) and torch.equal(p[1], ref.t().contiguous()), (tuple(w.shape), c0, nc)
+    assert Fn._panels16(ws[2], 0, 4608) is None                      # another slice of the same parameter was never prepared
+    N.bump_weights_epoch()
+    assert all(Fn._panels16(w, c0, nc) is None for w, c0, nc in items)

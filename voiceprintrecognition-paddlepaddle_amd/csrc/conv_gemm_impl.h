@@ -31,6 +31,10 @@ struct ConvArgs {
     int F_in, F_out, KF, stride_f, pad_f;
     int gate_len, gate_nseg;
     int tiles_m, tiles_n, nseg, group_m;
+    // 128 x 256 ring kernel, two workgroups per CU: workgroups [dephase_lo, dephase_hi) -- the SECOND workgroup each CU receives in the
+    // launch's first wave -- start dephase_ticks (100 MHz) late, so that one workgroup's prologue / epilogue falls under the other's
+    // K-loop instead of under its prologue / epilogue (0 = off)
+    int dephase_ticks, dephase_lo, dephase_hi;
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;

@@ -8,7 +8,7 @@ import os
 import torch
 
 import ppvector
-from ppvector.train.functions import BNRows, CatConvBlock, ConvBlock, ConvBlockSkip, Res2Fn, SEBlockFn
+from ppvector.train.functions import BNRows, CatConvBlock, ConvBlock, ConvBlockSkip, Res2Fn, SEBlockFn, prep_weights_bf16
 from ppvector.train.segments import cut
 from ppvector.train.tdnn_train import asp_forward
 
@@ -88,6 +88,20 @@ def ecapa_forward_train(m, feats):
     use_xcat = (ppvector.get_train_amp() and os.environ.get('VPMI_TRAIN_BF16_OPS', '2') != '0' and not os.environ.get('VPMI_NO_SHADOW')
                 and B * T >= 4096 and Cb0 % 64 == 0 and Cb0 >= 256 and m.mfa.conv.conv.weight.shape[1] == Cb0 * len(blocks))
     # (with the bf16 operand path on, block 0's output is read as bf16 only -- tdnn1's operand and the first block's residual)
+    if ppvector.get_train_amp() and os.environ.get('VPMI_TRAIN_BF16_OPS', '2') != '0' and B * T >= 4096:
+        # every bf16 weight panel the step will read (W for the forward GEMMs, W^T for the data-gradient GEMMs of the wide 1x1 layers
+        # and of ASP's two convs) from ONE launch -- they were 22 conversion launches spread over the step
+        items = []
+        for blk in blocks:
+            for t in (blk.tdnn1, blk.tdnn2):
+                wt = t.conv.conv.weight
+                items.append((wt, 0, wt.shape[1]))
+        wt = m.mfa.conv.conv.weight
+        items.append((wt, 0, wt.shape[1]))
+        wa, wc = m.asp.tdnn.conv.conv.weight, m.asp.conv.conv.weight
+        items.append((wa, 0, wc.shape[0] if m.asp.global_context else wa.shape[1]))       # the x columns of the attention TDNN
+        items.append((wc, 0, wc.shape[1]))
+        prep_weights_bf16([it for it in items if it[0].shape[2] == 1])
     x = tdnn_block(m.blocks[0], x, B, T, y_bf16=use_xcat and not os.environ.get('VPMI_BLOCK0_F32_OUT'),
                    wide_taps=use_xcat and not os.environ.get('VPMI_BLOCK0_F32_OPS'))
     outs = []

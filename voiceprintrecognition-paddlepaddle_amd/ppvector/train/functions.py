@@ -11,6 +11,7 @@ reference for free (ppvector/trainer.py:213-219: loss.backward()) is spelled out
 """
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -129,13 +130,65 @@ def _narrow_to_wide(M, Cin, Cout, KW):
             and os.environ.get('VPMI_TRAIN_BF16_OPS', '2') != '0')
 
 
+# ---------------------------------------------------------------------------------------------------- bf16 weight panels
+# The wide mixed-precision layers read their weights as bf16 twice per step: W in the forward GEMM, W^T in the data-gradient GEMM.  Each
+# used to be a conversion launch of its own (13 + 9 per ECAPA step).  A backbone's training forward now hands ALL of them to ONE launch
+# up front (vp_prep_weights_bf16); the panels live in this registry -- keyed by the parameter and the column slice, stamped with the
+# weights epoch (an optimiser step / a graph replay moves it: stale panels are never read) -- and ConvBlock looks them up.
+_W16 = {}
+
+
+def prep_weights_bf16(items):
+    """items: [(weight (Cout, Cin_total, 1) f32 parameter, col0, ncols)] -- the 1x1 conv weights (or column slices of one: the x part of
+    ASP's attention TDNN) whose bf16 panel W [Cout][ncols] and transpose W^T [ncols][Cout] the step will read.  One launch."""
+    items = [(w, c0, nc) for w, c0, nc in items if w is not None and w.is_cuda and w.dtype == torch.float32 and w.dim() == 3
+             and w.shape[2] == 1 and w.is_contiguous()]
+    if not items:
+        return
+    lib, hctx = N.lib(), N.ctx(items[0][0].device)
+    n = len(items)
+    dev = items[0][0].device
+    total = sum(w.shape[0] * nc for w, _, nc in items)
+    pool = torch.empty(2 * total, dtype=torch.bfloat16, device=dev)
+    ws, w16s, wts, rows, cols, lds, at = [], [], [], [], [], [], 0
+    epoch = N.weights_epoch()
+    for w, c0, nc in items:
+        co, ct = w.shape[0], w.shape[1]
+        a = pool[at:at + co * nc].view(co, nc)
+        b = pool[at + co * nc:at + 2 * co * nc].view(nc, co)
+        at += 2 * co * nc
+        ws.append(w.data_ptr() + 4 * c0)
+        w16s.append(a.data_ptr())
+        wts.append(b.data_ptr())
+        rows.append(co)
+        cols.append(nc)
+        lds.append(ct)
+        _W16[(id(w), c0, nc)] = (weakref.ref(w), epoch, a, b)
+    arr = lambda t, v: (t * n)(*v)
+    _chk(lib.vp_prep_weights_bf16(hctx, arr(C.c_void_p, ws), arr(C.c_void_p, w16s), arr(C.c_void_p, wts), arr(C.c_int, rows),
+                                  arr(C.c_int, cols), arr(C.c_int, lds), n, N.stream_ptr()), hctx)
+
+
+def _panels16(w, c0=0, nc=None):
+    """(W bf16 [Cout][ncols], W^T bf16 [ncols][Cout]) of this step's prep_weights_bf16 launch, or None."""
+    if w is None or w.dim() != 3:
+        return None
+    e = _W16.get((id(w), c0, w.shape[1] if nc is None else nc))
+    if e is None or e[0]() is not w or e[1] != N.weights_epoch() or os.environ.get('VPMI_NO_WPREP'):
+        return None
+    return e[2], e[3]
+
+
 class ConvBlock(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, rowbias, gamma, beta, run_mean, run_var, cfg):
         lib, hctx = N.lib(), N.ctx(x.device)
+        p16 = cfg.get('_w16') or _panels16(weight)              # this step's bf16 panels of the weight (prep_weights_bf16), or None
         weight = _f32c(weight)
         B, T_in, dil = cfg['B'], cfg['T'], cfg.get('dilation', 1)
         Cout, Cin, KW = weight.shape
+        if KW != 1 or p16 is None or tuple(p16[0].shape) != (Cout, Cin):
+            p16 = None
         wide = _wide_bf16(B * T_in, Cin, Cout, KW, bias, rowbias, gamma, cfg)
         if x.dtype == torch.bfloat16:
             if not wide and KW == 1 and ppvector.get_train_amp() and Cin % 8 == 0 and Cout % 4 == 0 and bias is not None:
@@ -173,13 +226,13 @@ class ConvBlock(torch.autograd.Function):
         out16 = narrow and bool(cfg.get('out_bf16')) and not cfg.get('tanh', False) and not cfg.get('sigmoid', False)
         z = torch.empty((B * T_out, Cout), dtype=torch.bfloat16 if (wide >= 2 or out16) else torch.float32, device=x.device)
         if wide:
-            wp = wp.to(torch.bfloat16)
+            wp = p16[0] if p16 is not None else wp.to(torch.bfloat16)
         xin = x
         if narrow:
             # enable_amp, few inputs -> many outputs (ASP's logits conv, 128 -> 1536): the kernel rounds x to bf16 anyway; rounding it up
             # front (39 MB) lets the launch take the LDS-DMA ring kernel with f32 output instead of the 128-wide register-staged one,
             # which is bound by its 469 MB of stores (206 -> ~115 us).  Saved for backward: the f32 x, as before.
-            xin, wp = x.to(torch.bfloat16), wp.to(torch.bfloat16)
+            xin, wp = x.to(torch.bfloat16), (p16[0] if p16 is not None else wp.to(torch.bfloat16))
         d = _conv_desc(xin, B, T_in, T_out, Cin, Cout, KW, dil, _PAD[pad], pad_left, wp, bias, rowbias, relu)
         if wide or xin is not x:
             d.dtype_in = N.VP_BF16
@@ -262,6 +315,7 @@ class ConvBlock(torch.autograd.Function):
         ctx.save_for_backward(x, weight, z, mean, invstd, gamma, y if tanh else None, w2)
         ctx.geom = (B, T_in, T_out, Cin, Cout, KW, dil, pad, pad_left, relu, bn, tanh, bias is not None, rowbias is not None)
         ctx.wide = wide
+        ctx.wt16 = p16[1] if p16 is not None else None           # W^T as bf16: the data-gradient GEMM's panel, from the same launch
         ctx.zero_dbias = bool(cfg.get('zero_bias_grad', False))
         return y
 
@@ -351,7 +405,12 @@ def _conv_block_bwd(ctx, dy, skip=None, fold=None):
     # data gradient: the forward kernel over dz with reversed taps and swapped channel roles
     dx = None
     if ctx.needs_input_grad[0]:
-        if w2 is None:                                  # KW = 1: W^T
+        wt16 = getattr(ctx, 'wt16', None) if KW == 1 else None
+        # (a many -> few layer's data gradient is a few -> many GEMM over dz and runs on bf16 operands too: see the last branch below)
+        narrow_d = bool(not wide and KW == 1 and dz.dtype == torch.float32 and pad == 'none' and _narrow_to_wide(B * T_out, Cout, Cin, KW))
+        if w2 is None and (wide or narrow_d) and wt16 is not None:     # KW = 1: W^T, already there as bf16 (this step's weight-prep launch)
+            w2 = wt16
+        elif w2 is None:
             w2 = weight.view(Cout, Cin).t().to(torch.bfloat16 if wide else torch.float32, memory_format=torch.contiguous_format)
             if not wide:
                 w2 = w2.contiguous()
@@ -391,11 +450,11 @@ def _conv_block_bwd(ctx, dy, skip=None, fold=None):
             dx = tuple(dx)
         else:
             dzin = dz
-            if not wide and dz.dtype == torch.float32 and pad == 'none' and _narrow_to_wide(B * T_out, Cout, Cin, KW):
+            if narrow_d:
                 # the data gradient of a many-inputs -> few-outputs layer (ASP's attention TDNN, 1536 -> 128) is a few -> many GEMM over
                 # dz: the same up-front rounding of the small operand, the same kernel (341 -> ~215 us with the other path's gradient
                 # added in its epilogue)
-                dzin, w2 = dz.to(torch.bfloat16), w2.to(torch.bfloat16)
+                dzin, w2 = dz.to(torch.bfloat16), (w2 if w2.dtype == torch.bfloat16 else w2.to(torch.bfloat16))
             d2 = _conv_desc(dzin, B, T_out, T_in, Cout, Cin, KW, dil, N.VP_PAD_ZERO, dil * (KW - 1) - pad_left, w2)
             if wide or dzin is not dz:
                 d2.dtype_in = N.VP_BF16
@@ -437,14 +496,14 @@ class CatConvBlock(torch.autograd.Function):
         tp = _Tape((True,) * 9)
         y = ConvBlock.forward(tp, xcat, weight, bias, None, gamma, beta, run_mean, run_var, cfg)
         ctx.save_for_backward(*tp.saved_tensors)
-        ctx.inner = (tp.geom, tp.wide, widths)
+        ctx.inner = (tp.geom, tp.wide, widths, tp.wt16)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         tp = _Tape((True,) * 9)
         tp.saved_tensors = ctx.saved_tensors
-        tp.geom, tp.wide, widths = ctx.inner
+        tp.geom, tp.wide, widths, tp.wt16 = ctx.inner
         tp.out_splits = widths
         r = _conv_block_bwd(tp, dy)
         dxs = r[0] if isinstance(r[0], tuple) else r[0].split(widths, dim=1)
@@ -887,8 +946,10 @@ class AspFn(torch.autograd.Function):
         if gc:
             stats = _time_stats(x, B, T, 1e-12, True)
             rowbias = ConvBlock.forward(t0, stats, w[:, Cc:].contiguous(), None, None, None, None, None, None, dict(B=B, T=1))
+        # (the x columns of the attention TDNN's weight: their bf16 panels come from the step's weight-prep launch when the backbone asked)
         h = ConvBlock.forward(t1, x, w[:, :Cc].contiguous() if gc else w, bias, rowbias, gamma, beta, run_mean, run_var,
-                              dict(B=B, T=T, relu=True, tanh=True, momentum=cfg['momentum'], eps=cfg['eps']))
+                              dict(B=B, T=T, relu=True, tanh=True, momentum=cfg['momentum'], eps=cfg['eps'],
+                                   _w16=_panels16(w, 0, Cc) if gc else None))
         # the logits' bias shifts every frame of an utterance alike and the softmax over time removes it: its gradient,
         # sum_t alpha_t (dalpha_t - S) = S - S, is exactly zero -- no 469 MB column-sum pass over d e for it
         # enable_amp: the logits leave their conv as bf16 (what Paddle's O1 conv hands the f32 softmax) -- 234 instead of 469 MB written
@@ -906,7 +967,7 @@ class AspFn(torch.autograd.Function):
                                           N.stream_ptr()), hctx)
         tapes = (t0, t1, t2) if gc else (t1, t2)
         ctx.save_for_backward(x, stats, e, pooled, *(t for tp in tapes for t in tp.saved_tensors))
-        ctx.tape_meta = [(len(tp.saved_tensors), tp.geom, tp.zero_dbias, getattr(tp, 'wide', 0)) for tp in tapes]
+        ctx.tape_meta = [(len(tp.saved_tensors), tp.geom, tp.zero_dbias, getattr(tp, 'wide', 0), getattr(tp, 'wt16', None)) for tp in tapes]
         ctx.geom = (B, T, gc)
         return pooled
 
@@ -918,9 +979,9 @@ class AspFn(torch.autograd.Function):
         lib, hctx = N.lib(), N.ctx(x.device)
         Cc = x.shape[1]
         tapes, at = [], 4
-        for n, geom, zero_dbias, wide in ctx.tape_meta:
+        for n, geom, zero_dbias, wide, wt16 in ctx.tape_meta:
             tp = _Tape((True,) * 9)
-            tp.saved_tensors, tp.geom, tp.zero_dbias, tp.wide = saved[at:at + n], geom, zero_dbias, wide
+            tp.saved_tensors, tp.geom, tp.zero_dbias, tp.wide, tp.wt16 = saved[at:at + n], geom, zero_dbias, wide, wt16
             tapes.append(tp)
             at += n
         t2, t1 = tapes[-1], tapes[-2]
