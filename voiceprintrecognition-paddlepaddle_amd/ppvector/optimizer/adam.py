@@ -68,9 +68,6 @@ class FlatOptimizer:
     def pack_range(self, params):
         """Gather the .grad tensors of `params` into their slots of the flat gradient buffer (zeros where .grad is None)."""
         import ctypes as C
-        if self.grad.is_cuda:
-            from ppvector.train.functions import join_side
-            join_side()                            # weight gradients still running on the side launch sequence (train/functions.py: _beside)
         todo = [p for p in params if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * self._offset(p)]
         if not todo:
             return

@@ -179,70 +179,11 @@ def _panels16(w, c0=0, nc=None):
     return e[2], e[3]
 
 
-# ---------------------------------------------------------------------------------------------------- weight gradients beside the chain
-# Nothing inside a backward pass waits for a WEIGHT gradient: the chain runs dy -> dz -> dx -> the previous layer, dW only meets the
-# optimiser.  At the strong-scaled batch (32 utterances per GPU) every kernel is a fraction of one round of tiles, so the step is a sum of
-# ~190 dependent launch latencies, a third of them weight gradients and their partial-sum reductions.  They are therefore issued on a
-# second launch sequence (a side stream, forked off the chain when dz is ready) and joined once, at the end of the autograd pass that
-# forked them (the engine's queue_callback: one join per backward stage of GraphedTrainStep, inside the stage's captured graph) -- and
-# in FlatOptimizer.pack_range, which is where the gradients are first read.  Tensors the side sequence reads are kept alive until the join
-# (the caching allocator knows nothing of the second stream).  VPMI_NO_WGRAD_FORK=1: everything on the chain's own stream.
-class _Side:
-    def __init__(self, dev):
-        self.stream = torch.cuda.Stream(dev)
-        self.held = []
-        self.open = False
-
-
-_SIDES = {}
-
-
-def join_side():
-    """Every forked launch sequence back into the current stream (no-op when none is open)."""
-    for dev, sd in _SIDES.items():
-        if sd.open:
-            torch.cuda.current_stream(dev).wait_stream(sd.stream)
-            sd.held.clear()
-            sd.open = False
-
-
-class _Inline:
-    def __enter__(self):
-        return None
-
-    def __exit__(self, *exc):
-        return False
-
-
-def _beside(dev, *hold):
-    """Context under which launches go to the device's side sequence (after everything issued so far on the current stream), or -- outside
-    an autograd pass, or when switched off -- stay where they are.  `hold`: tensors the launches read that the caller may free."""
-    if os.environ.get('VPMI_NO_WGRAD_FORK') or dev.type != 'cuda':
-        return _Inline()
-    sd = _SIDES.get(dev)
-    if sd is None:
-        if torch.cuda.is_current_stream_capturing():
-            return _Inline()                              # (the first sighting creates the stream: never under a capture)
-        sd = _SIDES[dev] = _Side(dev)
-    if not sd.open:
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(join_side)
-        except RuntimeError:                              # not inside a backward pass: nobody would join
-            return _Inline()
-        sd.open = True
-    sd.held.extend(t for t in hold if t is not None)
-    sd.stream.wait_stream(torch.cuda.current_stream(dev))
-    return torch.cuda.stream(sd.stream)
-
-
 class ConvBlock(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, rowbias, gamma, beta, run_mean, run_var, cfg):
         lib, hctx = N.lib(), N.ctx(x.device)
         p16 = cfg.get('_w16') or _panels16(weight)              # this step's bf16 panels of the weight (prep_weights_bf16), or None
-        # the weight gradient may run beside the backward chain (_beside) only when NOTHING but the optimiser reads it: the weight is a
-        # parameter handed over as it is (a view / slice / transpose of one sends d W through autograd nodes that launch on the chain's stream)
-        ctx.wparam = weakref.ref(weight) if isinstance(weight, torch.nn.Parameter) and weight.is_contiguous() else None
         weight = _f32c(weight)
         B, T_in, dil = cfg['B'], cfg['T'], cfg.get('dilation', 1)
         Cout, Cin, KW = weight.shape
@@ -383,17 +324,12 @@ class ConvBlock(torch.autograd.Function):
         return _conv_block_bwd(ctx, dy)
 
 
-def _conv_block_bwd(ctx, dy, skip=None, fold=None, fork=None):
+def _conv_block_bwd(ctx, dy, skip=None, fold=None):
     """ConvBlock's backward.  skip: a gradient that reached x along another path (the block residual, another consumer of the
     same tensor), added in the data-gradient conv's epilogue instead of by a separate pass.  fold: {'dx': slice view of a wider
     gradient tensor, 'add': slice view or None} -- d x is written into that slice and the returned tensor is d x + add (or None):
-    the Res2Net hand-off (Res2Fn).  fork: True = the caller consumes d W on the side launch sequence itself (AspFn's concatenation);
-    None = decided here: a parameter handed over directly whose .grad is empty (autograd then stores d W without a launch)."""
+    the Res2Net hand-off (Res2Fn)."""
     x, weight, z, mean, invstd, gamma, yt, w2 = ctx.saved_tensors
-    if fork is None:
-        wp = getattr(ctx, 'wparam', None)
-        wp = wp() if wp is not None else None
-        fork = wp is not None and wp.grad is None
     B, T_in, T_out, Cin, Cout, KW, dil, pad, pad_left, relu, bn, tanh, has_bias, has_rb = ctx.geom
     lib, hctx = N.lib(), N.ctx(x.device)
     dev = x.device
@@ -455,18 +391,17 @@ def _conv_block_bwd(ctx, dy, skip=None, fold=None, fork=None):
         drb = torch.empty((B, Cout), dtype=torch.float32, device=dev)
         fn = lib.vp_utt_sums_b16 if dz.dtype == torch.bfloat16 else lib.vp_utt_sums_f32
         _chk(fn(hctx, dz.data_ptr(), Cout, B, T_out, Cout, drb.data_ptr(), N.stream_ptr()), hctx)
-    # weight gradient: on the side launch sequence -- nothing in this backward pass waits for it (see _beside)
+    # weight gradient
     d = _conv_desc(x, B, T_in, T_out, Cin, Cout, KW, dil, _PAD[pad], pad_left, weight)
-    with (_beside(dev, x, dz) if fork else _Inline()):
-        dW = torch.empty((Cout, Cin, KW), dtype=torch.float32, device=dev)      # reduced straight into the model's layout
-        ws = _bytes(lib.vp_conv1d_wgrad_workspace_bytes(C.byref(d)), dev)
-        if wide:                                            # x (saved as bf16) and dz both bf16 in memory
-            d.dtype_in = N.VP_BF16
-            _chk(lib.vp_conv1d_wgrad_bf16_oik(hctx, C.byref(d), dz.data_ptr(), Cout, dW.data_ptr(), ws.data_ptr(), ws.numel(),
-                                              N.stream_ptr()), hctx)
-        else:
-            _chk(lib.vp_conv1d_wgrad_oik_f32(hctx, C.byref(d), dz.data_ptr(), Cout, dW.data_ptr(), ws.data_ptr(), ws.numel(),
-                                             N.stream_ptr()), hctx)
+    dW = torch.empty((Cout, Cin, KW), dtype=torch.float32, device=dev)      # reduced straight into the model's layout
+    ws = _bytes(lib.vp_conv1d_wgrad_workspace_bytes(C.byref(d)), dev)
+    if wide:                                            # x (saved as bf16) and dz both bf16 in memory
+        d.dtype_in = N.VP_BF16
+        _chk(lib.vp_conv1d_wgrad_bf16_oik(hctx, C.byref(d), dz.data_ptr(), Cout, dW.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          N.stream_ptr()), hctx)
+    else:
+        _chk(lib.vp_conv1d_wgrad_oik_f32(hctx, C.byref(d), dz.data_ptr(), Cout, dW.data_ptr(), ws.data_ptr(), ws.numel(),
+                                         N.stream_ptr()), hctx)
     # data gradient: the forward kernel over dz with reversed taps and swapped channel roles
     dx = None
     if ctx.needs_input_grad[0]:
@@ -561,14 +496,14 @@ class CatConvBlock(torch.autograd.Function):
         tp = _Tape((True,) * 9)
         y = ConvBlock.forward(tp, xcat, weight, bias, None, gamma, beta, run_mean, run_var, cfg)
         ctx.save_for_backward(*tp.saved_tensors)
-        ctx.inner = (tp.geom, tp.wide, widths, tp.wt16, tp.wparam)
+        ctx.inner = (tp.geom, tp.wide, widths, tp.wt16)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         tp = _Tape((True,) * 9)
         tp.saved_tensors = ctx.saved_tensors
-        tp.geom, tp.wide, widths, tp.wt16, tp.wparam = ctx.inner
+        tp.geom, tp.wide, widths, tp.wt16 = ctx.inner
         tp.out_splits = widths
         r = _conv_block_bwd(tp, dy)
         dxs = r[0] if isinstance(r[0], tuple) else r[0].split(widths, dim=1)
@@ -744,16 +679,15 @@ class Res2Fn(torch.autograd.Function):
             ws = _bytes(lib.vp_res2_train_workspace_bytes(B, S), dout.device)
             _chk(lib.vp_res2_train_bwd(hctx, C.byref(d), ws.data_ptr(), ws.numel(), N.stream_ptr()), hctx)
             grads = [None] * (6 * (S - 1))
+            dw_all = torch.empty((S - 1, 64, 64, 3), dtype=torch.float32, device=dout.device)
             wd = N.Conv1dDesc()
             wd.dtype_in = wd.dtype_out = N.VP_BF16
             wd.B, wd.T_in, wd.T_out, wd.Cin, wd.Cout, wd.KW, wd.dilation, wd.stride = B, T, T, 64, 64, 3, cfg['dilation'], 1
             wd.pad_mode, wd.pad_left, wd.ldx, wd.xoff, wd.ldy, wd.mfma_bf16 = N.VP_PAD_REFLECT, cfg['dilation'], 64, 0, 64, 1
-            with _beside(dout.device, inb, dzb):                         # (beside the chain, like every weight gradient)
-                dw_all = torch.empty((S - 1, 64, 64, 3), dtype=torch.float32, device=dout.device)
-                wws = _bytes(lib.vp_conv1d_wgrad_workspace_bytes(C.byref(wd)) * (S - 1), dout.device)
-                wd.x, wd.w = inb.data_ptr(), wg[0].data_ptr()            # weight gradients dz_i^T in_i of all chunks in one launch
-                _chk(lib.vp_conv1d_wgrad_bf16_oik_batched(hctx, C.byref(wd), dzb.data_ptr(), 64, dw_all.data_ptr(), S - 1, M * 64, M * 64,
-                                                          wws.data_ptr(), wws.numel(), N.stream_ptr()), hctx)
+            wws = _bytes(lib.vp_conv1d_wgrad_workspace_bytes(C.byref(wd)) * (S - 1), dout.device)
+            wd.x, wd.w = inb.data_ptr(), wg[0].data_ptr()                # weight gradients dz_i^T in_i of all chunks in one launch
+            _chk(lib.vp_conv1d_wgrad_bf16_oik_batched(hctx, C.byref(wd), dzb.data_ptr(), 64, dw_all.data_ptr(), S - 1, M * 64, M * 64,
+                                                      wws.data_ptr(), wws.numel(), N.stream_ptr()), hctx)
             for i in range(S - 1):
                 grads[6 * i:6 * i + 4] = [dw_all[i], dvec[i, 0], dvec[i, 1], dvec[i, 2]]
             return (dx, None, *grads)
@@ -782,8 +716,6 @@ class _Tape:
     def __init__(self, needs_input_grad):
         self.needs_input_grad = needs_input_grad
         self.saved_tensors = ()
-        self.wparam = None
-        self.wt16 = None
 
     def save_for_backward(self, *tensors):
         self.saved_tensors = tensors
@@ -1035,10 +967,8 @@ class AspFn(torch.autograd.Function):
                                           N.stream_ptr()), hctx)
         tapes = (t0, t1, t2) if gc else (t1, t2)
         ctx.save_for_backward(x, stats, e, pooled, *(t for tp in tapes for t in tp.saved_tensors))
-        ctx.tape_meta = [(len(tp.saved_tensors), tp.geom, tp.zero_dbias, getattr(tp, 'wide', 0), getattr(tp, 'wt16', None), getattr(tp, 'wparam', None))
-                         for tp in tapes]
+        ctx.tape_meta = [(len(tp.saved_tensors), tp.geom, tp.zero_dbias, getattr(tp, 'wide', 0), getattr(tp, 'wt16', None)) for tp in tapes]
         ctx.geom = (B, T, gc)
-        ctx.w_ref = weakref.ref(w) if isinstance(w, torch.nn.Parameter) and w.is_contiguous() else None
         return pooled
 
     @staticmethod
@@ -1049,9 +979,9 @@ class AspFn(torch.autograd.Function):
         lib, hctx = N.lib(), N.ctx(x.device)
         Cc = x.shape[1]
         tapes, at = [], 4
-        for n, geom, zero_dbias, wide, wt16, wparam in ctx.tape_meta:
+        for n, geom, zero_dbias, wide, wt16 in ctx.tape_meta:
             tp = _Tape((True,) * 9)
-            tp.saved_tensors, tp.geom, tp.zero_dbias, tp.wide, tp.wt16, tp.wparam = saved[at:at + n], geom, zero_dbias, wide, wt16, wparam
+            tp.saved_tensors, tp.geom, tp.zero_dbias, tp.wide, tp.wt16 = saved[at:at + n], geom, zero_dbias, wide, wt16
             tapes.append(tp)
             at += n
         t2, t1 = tapes[-1], tapes[-2]
@@ -1069,19 +999,14 @@ class AspFn(torch.autograd.Function):
             _chk(fn(hctx, e.data_ptr(), x.data_ptr(), Cc, pooled.data_ptr(), _f32c(dp).data_ptr(), B, T, Cc, 1e-12, de.data_ptr(),
                     dx.data_ptr(), Cc, N.stream_ptr()), hctx)
         dh, dw2, db2 = _conv_block_bwd(t2, de)[:3]
-        # the attention TDNN's weight reaches its two convs as column slices: its gradient is the concatenation of theirs.  Both weight
-        # gradients AND the concatenation run on the side launch sequence (fork=True: this function is their only consumer) when the
-        # parameter's .grad is empty, i.e. autograd will store the result without a launch of its own
-        fork_w = not gc or (isinstance(ctx.w_ref, weakref.ref) and ctx.w_ref() is not None and ctx.w_ref().grad is None)
-        dx, dwx, dbias, drb, dgamma, dbeta = _conv_block_bwd(t1, dh, dx, fork=fork_w if gc else None)[:6]   # dx: TDNN's + the weighted statistics'
+        dx, dwx, dbias, drb, dgamma, dbeta = _conv_block_bwd(t1, dh, dx)[:6]        # dx: TDNN's + the weighted statistics'
         dw = dwx
         if gc:
-            dstats, dwc = _conv_block_bwd(tapes[0], drb, fork=fork_w)[:2]
+            dstats, dwc = _conv_block_bwd(tapes[0], drb)[:2]
             fn = lib.vp_time_stats_bwd_add_x16 if x16 else lib.vp_time_stats_bwd_add_f32
             _chk(fn(hctx, x.data_ptr(), Cc, stats.data_ptr(), dstats.data_ptr(), B, T, Cc, 1e-12, 0,
                     dx.data_ptr(), Cc, dx.data_ptr(), Cc, N.stream_ptr()), hctx)
-            with (_beside(x.device, dwx, dwc) if fork_w else _Inline()):
-                dw = torch.cat([dwx, dwc], dim=1)
+            dw = torch.cat([dwx, dwc], dim=1)
         return dx, dw, dbias, dgamma, dbeta, None, None, dw2, db2, None
 
 
