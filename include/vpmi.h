@@ -783,6 +783,21 @@ int vp_occupy_cus(vp_ctx* ctx, int n_workgroups, int lds_bytes, int usec, vp_str
  * vp_utt_dot_f32: ds[b][c] = sum_t dy[b,t,c] * x[b,t,c];  vp_scale_shift_rows_f32: dx[b,t,c] = dy[b,t,c] * s[b][c] + dm[b][c] / T
  * (dm = the gradient that reached the squeeze mean through the two dense layers).  C % 4 == 0, contiguous (B*T, C) tensors. */
 int vp_utt_dot_f32(vp_ctx* ctx, const float* dy, const float* x, int B, int T, int C, float* ds, vp_stream stream);
+/* The conv -> ReLU -> BatchNorm -> SEBlock -> + residual tail of an SE-Res2 block (ecapa_tdnn.py:125-142) under enable_amp WITHOUT the two
+ * tensors between the conv and the SE gate: h = BN(z) is never stored forward (vp_se_scale_residual_z16: out = bf16(z * bn_scale + bn_shift)
+ * * s[b] + res over the conv's bf16 pre-BatchNorm output z), and the SE block's input gradient dh = dout * s[b] + dmean[b] / T is never stored
+ * backward: vp_utt_dot_z16 (ds[b][c] = sum_t dout * h), then the BatchNorm-backward reductions and the BatchNorm + ReLU backward read dout
+ * and form dh on the fly (vp_col_sums_f32_b16_utt / vp_bn_relu_bwd_dbias_b16_utt: d y = dy * utt_scale[b] + utt_shift[b] / T, b = row / T).
+ * Bit-identical to the passes they replace (vp_affine_rows_b16_b16, vp_utt_dot_x16, vp_scale_shift_rows_f32 + the plain reductions). */
+int vp_se_scale_residual_z16(vp_ctx* ctx, const void* z, int ldz, const float* bn_scale, const float* bn_shift, const float* s, const void* res,
+                             int ldr, int roff, void* out, int ldo, int ooff, int B, int T, int C, vp_stream stream);
+int vp_utt_dot_z16(vp_ctx* ctx, const float* dy, const void* z_bf16, const float* bn_scale, const float* bn_shift, int B, int T, int C,
+                   float* ds, vp_stream stream);
+int vp_col_sums_f32_b16_utt(vp_ctx* ctx, const float* a, int lda, const float* utt_scale, const float* utt_shift, int T, const void* b, int ldb,
+                            const float* bmean, const float* bscale, long long M, int C, float* sums, void* ws, size_t ws_bytes, vp_stream stream);
+int vp_bn_relu_bwd_dbias_b16_utt(vp_ctx* ctx, const float* dy, int lddy, const float* utt_scale, const float* utt_shift, int T, const void* z,
+                                 int ldz, const float* mean, const float* invstd, const float* gamma, const float* sums, long long M, int C,
+                                 int relu_mask, void* dz, int lddz, float* dbias, void* ws, size_t ws_bytes, vp_stream stream);
 int vp_scale_shift_rows_f32(vp_ctx* ctx, const float* dy, const float* s, const float* dm, int B, int T, int C, float* dx, vp_stream stream);
 /* [mean | std] over the frames of f32 (B, T, C) for MANY frames per utterance (the (B, T*F', C) feature maps of ResNetSE's SE squeeze,
  * resnet_se.py:60-66): the frames spread over ~2048 workgroups, chunk partials reduced in order.  Else VP_EUNSUP -> vp_time_stats_f32. */

@@ -1576,3 +1576,53 @@ def test_weight_prep_launch_writes_every_bf16_panel(N, monkeypatch):
     assert Fn._panels16(ws[2], 0, 4608) is None                      # another slice of the same parameter was never prepared
     N.bump_weights_epoch()
     assert all(Fn._panels16(w, c0, nc) is None for w, c0, nc in items)
+
+
+def test_conv_se_tail_as_one_tape_entry_changes_nothing(N, amp, monkeypatch):
+    """ConvSEFn (tdnn2 + SE gate + residual of an SE-Res2 block as one tape entry: the BatchNorm output h and the SE block's input gradient
+    dh are formed on the fly inside the passes that read them, never stored) against the two entries it replaces (ConvBlock + SEBlockFn,
+    VPMI_SE_TAIL_UNFUSED=1): loss, embeddings, every parameter gradient and every running statistic of an ECAPA-TDNN training
+    forward + backward at 16 x 298 frames, bit for bit."""
+    from ppvector.loss.aamloss import AAMLoss
+    from ppvector.models.ecapa_tdnn import EcapaTdnn
+    from ppvector.models.fc import SpeakerIdentification
+    from ppvector.train import functions as Fn
+    g = torch.Generator().manual_seed(41)
+    x = (torch.randn(16, 298, 80, generator=g) * 2).cuda()
+    y = torch.randint(0, 11, (16,), generator=g).cuda()
+
+    def run(unfused):
+        if unfused:
+            monkeypatch.setenv('VPMI_SE_TAIL_UNFUSED', '1')
+        else:
+            monkeypatch.delenv('VPMI_SE_TAIL_UNFUSED', raising=False)
+        calls = {'n': 0}
+        orig = Fn.ConvSEFn.usable
+
+        def counted(*a, **k):
+            r = orig(*a, **k)
+            calls['n'] += int(bool(r))
+            return r
+        monkeypatch.setattr(Fn.ConvSEFn, 'usable', staticmethod(counted))
+        m = EcapaTdnn(80, embd_dim=192, pooling_type='ASP', channels=[512, 512, 512, 512, 1536])
+        m.load_state_dict(om.ecapa_params(80, seed=21))
+        head = SpeakerIdentification(192, 11)
+        head.load_state_dict({'weight': om.head_params(192, 11, seed=22)})
+        model = torch.nn.Sequential(m, head).cuda().train()
+        out = model(x)
+        loss = AAMLoss(margin=0.2, scale=32)(out, y)
+        loss.backward()
+        torch.cuda.synchronize()
+        monkeypatch.setattr(Fn.ConvSEFn, 'usable', staticmethod(orig))
+        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        bufs = {k: b.detach().clone() for k, b in model.named_buffers()}
+        return float(loss), out['features'].detach().clone(), grads, bufs, calls['n']
+
+    la, ea, ga, ba, na = run(False)
+    lb, eb, gb, bb, nb = run(True)
+    assert na == 3 and nb == 0, (na, nb)                      # the one-entry form ran for all three blocks / not at all
+    assert la == lb and torch.equal(ea, eb)
+    diff = [k for k in ga if not torch.equal(ga[k], gb[k])]
+    assert not diff, diff[:5]
+    assert all(torch.equal(ba[k], bb[k]) for k in ba)
+    print(f'[conv + SE tail as one tape entry] loss {la:.6f}: {len(ga)} parameter gradients and {len(ba)} buffers bit-identical to the two-entry form')

@@ -172,6 +172,32 @@ struct SeArgs {
     bf16_t* shadow; int lds_, soff;          // f32 flavour only: the same values once more as bf16 (the next GEMM's operand), or NULL
 };
 
+// bf16, x = the PRE-BatchNorm activation z of the conv in front of the SE block: h = bf16(z * bsc + bsh) formed on the fly (the values the
+// BatchNorm apply pass would have stored), out = h * s[b] + res -- the training step's block output without a stored h
+struct SeZArgs { const bf16_t* z; const float* bsc; const float* bsh; const float* s; const bf16_t* res; bf16_t* out;
+                 int ldz, ldr, roff, ldo, ooff, T_, C; long long total; };
+__global__ __launch_bounds__(256) void se_scale_residual_z16_kernel(SeZArgs a) {
+    const int cv = a.C / 8;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < a.total; idx += (long long)gridDim.x * 256) {
+        const long long m = idx / cv;
+        const int c = (int)(idx - m * cv) * 8;
+        const int b = (int)(m / a.T_);
+        const uint4 zr = *reinterpret_cast<const uint4*>(a.z + m * a.ldz + c);
+        const uint4 rr = *reinterpret_cast<const uint4*>(a.res + m * a.ldr + a.roff + c);
+        const bf16_t* ze = reinterpret_cast<const bf16_t*>(&zr);
+        const bf16_t* re = reinterpret_cast<const bf16_t*>(&rr);
+        const float* sp = a.s + (size_t)b * a.C + c;
+        uint4 o;
+        bf16_t* oe = reinterpret_cast<bf16_t*>(&o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float h = (float)(bf16_t)__fmaf_rn((float)ze[e], a.bsc[c + e], a.bsh[c + e]);
+            oe[e] = (bf16_t)__fmaf_rn(h, sp[e], (float)re[e]);
+        }
+        *reinterpret_cast<uint4*>(a.out + m * a.ldo + a.ooff + c) = o;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void se_scale_residual_kernel(SeArgs<T> a) {
     constexpr int V = 16 / (int)sizeof(T);
@@ -189,7 +215,7 @@ __global__ __launch_bounds__(256) void se_scale_residual_kernel(SeArgs<T> a) {
         T* oe = reinterpret_cast<T*>(&o);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            float v = vp_to_f32(xe[e]) * sp[e] + vp_to_f32(re[e]);
+            float v = __fmaf_rn(vp_to_f32(xe[e]), sp[e], vp_to_f32(re[e]));
             if (a.relu) v = fmaxf(v, 0.f);
             oe[e] = vp_from_f32<T>(v);
         }
@@ -737,6 +763,21 @@ int vp_se_scale_residual_shadow(vp_ctx* ctx, const float* x, int ldx, int xoff, 
                                 vp_stream stream) {
     return se_scale_residual_impl(ctx, VP_F32, x, ldx, xoff, s, res, ldr, roff, out, ldo, ooff, B, T, C, 0, shadow, ld_shadow, shadow_off,
                                   (hipStream_t)stream);
+}
+
+int vp_se_scale_residual_z16(vp_ctx* ctx, const void* z, int ldz, const float* bn_scale, const float* bn_shift, const float* s, const void* res,
+                             int ldr, int roff, void* out, int ldo, int ooff, int B, int T, int C, vp_stream stream) {
+    if (!ctx || !z || !bn_scale || !bn_shift || !s || !res || !out || B <= 0 || T <= 0 || C <= 0) VP_FAIL(ctx, VP_EINVAL, "se_z16: bad arguments");
+    if (C % 8 || ldz % 8 || ldr % 8 || roff % 8 || ldo % 8 || ooff % 8 ||
+        ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(out)) & 15))
+        VP_FAIL(ctx, VP_EINVAL, "se_z16: C / ld / offsets must be multiples of 8, tensors 16-byte aligned");
+    const long long total = (long long)B * T * (C / 8);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    SeZArgs a{(const bf16_t*)z, bn_scale, bn_shift, s, (const bf16_t*)res, (bf16_t*)out, ldz, ldr, roff, ldo, ooff, T, C, total};
+    hipLaunchKernelGGL(se_scale_residual_z16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    VP_LAUNCH_CHECK(ctx, "se_scale_residual_z16");
+    return VP_OK;
 }
 
 int vp_se_scale_residual(vp_ctx* ctx, int dtype, const void* x, int ldx, int xoff, const float* s,

@@ -537,9 +537,23 @@ __global__ __launch_bounds__(256) void col_sums_kernel(ColSumArgs p) {
 // instead of 256 B, and four rows' loads are issued before the first add.  Workgroup = CL column lanes x (256 / CL) row groups
 // over rows_per_chunk rows; CL = 64 / 32 / 16 by width so that 64-channel tensors (the Res2 convs) still fill the lanes.
 struct ColSum4Args { const float* a; const float* b; const float* bmean; const float* bscale; float* part; int lda, ldb, M, C4, rows_per_chunk, cl_shift;
-                     const float* ms; const float* mh; };   // optional: a counts only where b * ms + mh > 0 (a ReLU BEHIND the BatchNorm, resnet_se.py:72-74)
+                     const float* ms; const float* mh;      // optional: a counts only where b * ms + mh > 0 (a ReLU BEHIND the BatchNorm, resnet_se.py:72-74)
+                     // UTT: the summed tensor is a * us[b] + um[b] * inv_t per utterance b = row / T -- the SE block's input gradient
+                     // dh = dout * s + dmean / T (ecapa_tdnn.py:50-82 backward) formed on the fly, never stored
+                     const float* us; const float* um; int T; float inv_t; };
 
-template <bool HASB, typename TB = float>
+template <bool UTT>
+__device__ __forceinline__ void utt_affine4(float (&v)[4], const float* us, const float* um, int T, float inv_t, int C, int m, int c) {
+    if constexpr (UTT) {
+        const size_t o = (size_t)(m / T) * C + c;
+        float sv[4], dv[4];
+        vp_load4(us + o, sv); vp_load4(um + o, dv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __fmaf_rn(v[e], sv[e], dv[e] * inv_t);
+    }
+}
+
+template <bool HASB, typename TB = float, bool UTT = false>
 __global__ __launch_bounds__(256) void col_sums4_kernel(ColSum4Args p) {
     const TB* __restrict__ gb = reinterpret_cast<const TB*>(p.b);
     __shared__ float sm[2][256][4];
@@ -562,6 +576,8 @@ __global__ __launch_bounds__(256) void col_sums4_kernel(ColSum4Args p) {
                 if (HASB) vp_load4(gb + (size_t)(m + u * RG) * p.ldb + c, bv[u]);
             }
 #pragma unroll
+            for (int u = 0; u < 4; ++u) utt_affine4<UTT>(av[u], p.us, p.um, p.T, p.inv_t, p.C4 * 4, m + u * RG, c);
+#pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -574,6 +590,7 @@ __global__ __launch_bounds__(256) void col_sums4_kernel(ColSum4Args p) {
             float av[4], bv[4];
             vp_load4(p.a + (size_t)m * p.lda + c, av);
             if (HASB) vp_load4(gb + (size_t)m * p.ldb + c, bv);
+            utt_affine4<UTT>(av, p.us, p.um, p.T, p.inv_t, p.C4 * 4, m, c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float g = (!HASB || (float)bv[e] * ms[e] + mh[e] > 0.f) ? av[e] : 0.f;
@@ -655,7 +672,7 @@ __global__ __launch_bounds__(256) void affine_rows_kernel(const TZ* z, int ldz, 
         float v[4], s[4], h[4];
         vp_load4(z + m * ldz + c, v); vp_load4(scale + c, s); vp_load4(shift + c, h);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = v[e] * s[e] + h[e]; if (relu) v[e] = fmaxf(v[e], 0.f); }
+        for (int e = 0; e < 4; ++e) { v[e] = __fmaf_rn(v[e], s[e], h[e]); if (relu) v[e] = fmaxf(v[e], 0.f); }
         vp_store4(y + m * ldy + c, v);
     }
 }
@@ -689,6 +706,7 @@ struct BnBwdArgs {
     const float* dy; const float* z; const float* mean; const float* invstd; const float* gamma; const float* sums;   // sums [2][C]
     float* dz; int lddy, ldz, lddz, C4, relu_mask; long long M;
     const float* ms; const float* mh;       // optional: d y counts only where z * ms + mh > 0 (a ReLU BEHIND the BatchNorm)
+    const float* us; const float* um; int T; float inv_t;      // bn_relu_bwd_dbias_kernel<.., UTT>: d y = dy * us[b] + um[b] * inv_t, b = row / T
 };
 
 __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdArgs a) {
@@ -723,7 +741,7 @@ struct BnBwdSumArgs { BnBwdArgs b; float* part; int M, rows_per_chunk, cl_shift;
 
 // TO = bf16_t: dz leaves as bf16 (b.dz reinterpreted, lddz in elements) -- the operand the wide layers' data- and weight-gradient
 // GEMMs read (they would round it to bf16 anyway); the column sums are of the unrounded values.
-template <typename TO, typename TZ = float>
+template <typename TO, typename TZ = float, bool UTT = false>
 __global__ __launch_bounds__(256) void bn_relu_bwd_dbias_kernel(BnBwdSumArgs p) {
     __shared__ float sm[256][4];
     const BnBwdArgs& a = p.b;
@@ -757,11 +775,14 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_dbias_kernel(BnBwdSumArgs p) 
                 vp_load4(gz + (size_t)(m + u * RG) * a.ldz + c, z[u]);
             }
 #pragma unroll
+            for (int u = 0; u < 4; ++u) utt_affine4<UTT>(dy[u], a.us, a.um, a.T, a.inv_t, C, m + u * RG, c);
+#pragma unroll
             for (int u = 0; u < 4; ++u) { one(dy[u], z[u], o); vp_store4(gdz + (size_t)(m + u * RG) * a.lddz + c, o); }
         }
         for (; m < m1; m += RG) {
             float dy[4], z[4], o[4];
             vp_load4(a.dy + (size_t)m * a.lddy + c, dy); vp_load4(gz + (size_t)m * a.ldz + c, z);
+            utt_affine4<UTT>(dy, a.us, a.um, a.T, a.inv_t, C, m, c);
             one(dy, z, o);
             vp_store4(gdz + (size_t)m * a.lddz + c, o);
         }
@@ -1107,8 +1128,19 @@ __global__ __launch_bounds__(256) void scale_rows_bwd_chunk_kernel(SrbArgs a) {
 // The SE gate's backward in two passes (see SEBlockFn in train/functions.py): ds[b,c] = sum_t dy * x first -- the squeeze path's
 // gradient dm[b,c] (through the two dense layers) depends on it -- then dx = dy * s[b,c] + dm[b,c] / T in one write of dx, instead
 // of dx = dy * s, a separate mean-backward tensor and their sum.  Four channels per lane; 32 lanes x 8 frame groups per utterance.
-template <typename TX = float>
-__global__ __launch_bounds__(256) void utt_dot4_kernel(const float* dy, const TX* x, int T, int C, float* ds) {
+// AFF: x is the PRE-BatchNorm activation z (bf16); the SE block's input h = bf16(z * bsc + bsh) is formed on the fly -- the same values
+// the BatchNorm apply pass (vp_affine_rows_b16_b16) would have stored
+template <bool AFF>
+__device__ __forceinline__ void bn_affine4_b16(float (&v)[4], const float (&sc)[4], const float (&sh)[4]) {
+    if constexpr (AFF) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (float)(bf16_t)__fmaf_rn(v[e], sc[e], sh[e]);
+    }
+}
+
+template <typename TX = float, bool AFF = false>
+__global__ __launch_bounds__(256) void utt_dot4_kernel(const float* dy, const TX* x, int T, int C, float* ds, const float* bsc = nullptr,
+                                                       const float* bsh = nullptr) {
     __shared__ float sm[256][4];
     const int lc = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int b = blockIdx.y, c4 = blockIdx.x * 32 + lc;
@@ -1117,11 +1149,15 @@ __global__ __launch_bounds__(256) void utt_dot4_kernel(const float* dy, const TX
     const float* gb = dy + (size_t)b * T * C + c;
     const TX* xb = x + (size_t)b * T * C + c;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (AFF) { vp_load4(bsc + c, sc); vp_load4(bsh + c, sh); }
     int t = rg;
     for (; t + 24 < T; t += 32) {
         float g[4][4], v[4][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) { vp_load4(gb + (size_t)(t + 8 * u) * C, g[u]); vp_load4(xb + (size_t)(t + 8 * u) * C, v[u]); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bn_affine4_b16<AFF>(v[u], sc, sh);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -1130,6 +1166,7 @@ __global__ __launch_bounds__(256) void utt_dot4_kernel(const float* dy, const TX
     for (; t < T; t += 8) {
         float g[4], v[4];
         vp_load4(gb + (size_t)t * C, g); vp_load4(xb + (size_t)t * C, v);
+        bn_affine4_b16<AFF>(v, sc, sh);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] += g[e] * v[e];
     }
@@ -1154,7 +1191,7 @@ __global__ __launch_bounds__(256) void scale_shift_rows4_kernel(const float* dy,
         float g[4], sv[4], d[4], o[4];
         vp_load4(dy + m * C + c, g); vp_load4(s + b * C + c, sv); vp_load4(dm + b * C + c, d);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = g[e] * sv[e] + d[e] * inv_t;
+        for (int e = 0; e < 4; ++e) o[e] = __fmaf_rn(g[e], sv[e], d[e] * inv_t);       // (the form utt_affine4 evaluates: bit-identical A/B)
         vp_store4(dx + m * C + c, o);
     }
 }
@@ -1571,12 +1608,32 @@ int vp_col_sums_f32_b16(vp_ctx* ctx, const float* a, int lda, const void* b, int
     if (!ws || ws_bytes < vp_col_sums_workspace_bytes(M, C)) VP_FAIL(ctx, VP_EWORKSPACE, "col_sums_b16: workspace too small");
     int cl_shift, colblocks, rpc, chunks;
     colsum4_geometry(M, C / 4, cl_shift, colblocks, rpc, chunks);
-    ColSum4Args p{a, (const float*)b, bmean, bscale, (float*)ws, lda, ldb, (int)M, C / 4, rpc, cl_shift, nullptr, nullptr};
+    ColSum4Args p{a, (const float*)b, bmean, bscale, (float*)ws, lda, ldb, (int)M, C / 4, rpc, cl_shift, nullptr, nullptr, nullptr, nullptr, 1, 0.f};
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL((col_sums4_kernel<true, bf16_t>), dim3(colblocks, (unsigned)chunks), dim3(256), 0, st, p);
     VP_LAUNCH_CHECK(ctx, "col_sums_b16");
     launch_sum_partials((const float*)ws, chunks, (long long)2 * C, sums, st);
     VP_LAUNCH_CHECK(ctx, "col_sums_b16_reduce");
+    return VP_OK;
+}
+
+// the same sums of a * us[b] + um[b] / T (b = row / T) against bf16 b: the BatchNorm-backward reductions of the conv in front of an SE
+// block, with the SE block's input gradient dh = dout * s + dmean / T formed on the fly (vp_scale_shift_rows_f32 never runs)
+int vp_col_sums_f32_b16_utt(vp_ctx* ctx, const float* a, int lda, const float* utt_scale, const float* utt_shift, int T, const void* b, int ldb,
+                            const float* bmean, const float* bscale, long long M, int C, float* sums, void* ws, size_t ws_bytes, vp_stream stream) {
+    if (!ctx || !a || !b || !bmean || !bscale || !sums || !utt_scale || !utt_shift || T <= 0 || M <= 0 || M % T || M > 0x7fffffffLL || C <= 0 ||
+        (C | lda | ldb) & 3 || (((uintptr_t)a | (uintptr_t)utt_scale | (uintptr_t)utt_shift) & 15) || ((uintptr_t)b & 7))
+        VP_FAIL(ctx, VP_EINVAL, "col_sums_b16_utt: bad arguments");
+    if (!ws || ws_bytes < vp_col_sums_workspace_bytes(M, C)) VP_FAIL(ctx, VP_EWORKSPACE, "col_sums_b16_utt: workspace too small");
+    int cl_shift, colblocks, rpc, chunks;
+    colsum4_geometry(M, C / 4, cl_shift, colblocks, rpc, chunks);
+    ColSum4Args p{a, (const float*)b, bmean, bscale, (float*)ws, lda, ldb, (int)M, C / 4, rpc, cl_shift, nullptr, nullptr, utt_scale, utt_shift, T,
+                  1.f / (float)T};
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((col_sums4_kernel<true, bf16_t, true>), dim3(colblocks, (unsigned)chunks), dim3(256), 0, st, p);
+    VP_LAUNCH_CHECK(ctx, "col_sums_b16_utt");
+    launch_sum_partials((const float*)ws, chunks, (long long)2 * C, sums, st);
+    VP_LAUNCH_CHECK(ctx, "col_sums_b16_utt_reduce");
     return VP_OK;
 }
 
@@ -1679,6 +1736,28 @@ int vp_bn_relu_bwd_dbias_b16(vp_ctx* ctx, const float* dy, int lddy, const void*
                              const float* gamma, const float* sums, long long M, int C, int relu_mask, void* dz, int lddz,
                              float* dbias, void* ws, size_t ws_bytes, vp_stream stream) {
     return bn_bwd_dbias_impl(ctx, dy, lddy, z, ldz, mean, invstd, gamma, sums, M, C, relu_mask, dz, lddz, true, dbias, ws, ws_bytes, stream, true);
+}
+
+// z AND dz bf16, d y = dy * utt_scale[b] + utt_shift[b] / T (b = row / T) formed on the fly: BatchNorm + ReLU backward of the conv in
+// front of an SE block straight from the block's OUTPUT gradient (see vp_col_sums_f32_b16_utt)
+int vp_bn_relu_bwd_dbias_b16_utt(vp_ctx* ctx, const float* dy, int lddy, const float* utt_scale, const float* utt_shift, int T, const void* z,
+                                 int ldz, const float* mean, const float* invstd, const float* gamma, const float* sums, long long M, int C,
+                                 int relu_mask, void* dz, int lddz, float* dbias, void* ws, size_t ws_bytes, vp_stream stream) {
+    if (!ctx || !dy || !z || !mean || !invstd || !sums || !dz || !dbias || !utt_scale || !utt_shift || T <= 0 || M <= 0 || M % T ||
+        M > 0x7fffffffLL || C <= 0 || (C | lddy | ldz | lddz) & 3 || (((uintptr_t)dy | (uintptr_t)utt_scale | (uintptr_t)utt_shift) & 15) ||
+        (((uintptr_t)z | (uintptr_t)dz) & 7))
+        VP_FAIL(ctx, VP_EINVAL, "bn_relu_bwd_dbias_utt: bad arguments");
+    if (!ws || ws_bytes < vp_bn_relu_bwd_dbias_workspace_bytes(M, C)) VP_FAIL(ctx, VP_EWORKSPACE, "bn_relu_bwd_dbias_utt: workspace too small");
+    int cl_shift, colblocks, rpc, chunks;
+    colsum4_geometry(M, C / 4, cl_shift, colblocks, rpc, chunks);
+    BnBwdSumArgs p{{dy, (const float*)z, mean, invstd, gamma, sums, (float*)dz, lddy, ldz, lddz, C / 4, relu_mask, M, nullptr, nullptr,
+                    utt_scale, utt_shift, T, 1.f / (float)T}, (float*)ws, (int)M, rpc, cl_shift};
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((bn_relu_bwd_dbias_kernel<bf16_t, bf16_t, true>), dim3(colblocks, (unsigned)chunks), dim3(256), 0, st, p);
+    VP_LAUNCH_CHECK(ctx, "bn_relu_bwd_dbias_utt");
+    launch_sum_partials((const float*)ws, chunks, (long long)C, dbias, st);
+    VP_LAUNCH_CHECK(ctx, "bn_relu_bwd_dbias_utt_reduce");
+    return VP_OK;
 }
 
 static int bn_bwd_dbias_impl(vp_ctx* ctx, const float* dy, int lddy, const void* z, int ldz, const float* mean, const float* invstd,
@@ -1949,6 +2028,19 @@ int vp_utt_dot_x16(vp_ctx* ctx, const float* dy, const void* x_bf16, int B, int 
         VP_FAIL(ctx, VP_EINVAL, "utt_dot_x16: bad arguments");
     hipLaunchKernelGGL(utt_dot4_kernel<bf16_t>, dim3((C / 4 + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, dy, (const bf16_t*)x_bf16, T, C, ds);
     VP_LAUNCH_CHECK(ctx, "utt_dot_x16");
+    return VP_OK;
+}
+
+// ds[b][c] = sum_t dy * bf16(z * bn_scale + bn_shift): the SE gate's gradient over the PRE-BatchNorm activation of the conv in front of
+// it (bf16), the BatchNorm apply pass folded into the read (the block's input h is never stored)
+int vp_utt_dot_z16(vp_ctx* ctx, const float* dy, const void* z_bf16, const float* bn_scale, const float* bn_shift, int B, int T, int C,
+                   float* ds, vp_stream stream) {
+    if (!ctx || !dy || !z_bf16 || !bn_scale || !bn_shift || !ds || B <= 0 || T <= 0 || C <= 0 || (C & 3) || B > 65535 ||
+        (((uintptr_t)dy | (uintptr_t)ds | (uintptr_t)bn_scale | (uintptr_t)bn_shift) & 15) || ((uintptr_t)z_bf16 & 7))
+        VP_FAIL(ctx, VP_EINVAL, "utt_dot_z16: bad arguments");
+    hipLaunchKernelGGL((utt_dot4_kernel<bf16_t, true>), dim3((C / 4 + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, dy, (const bf16_t*)z_bf16, T, C,
+                       ds, bn_scale, bn_shift);
+    VP_LAUNCH_CHECK(ctx, "utt_dot_z16");
     return VP_OK;
 }
 

@@ -179,6 +179,13 @@ _PROTOS = {
     'vp_res2_train_workspace_bytes': (c_size_t, [c_int, c_int]),
     'vp_res2_train_fwd': (c_int, [c_void_p, C.POINTER(Res2TrainDesc), c_void_p, c_size_t, c_void_p]),
     'vp_res2_train_bwd': (c_int, [c_void_p, C.POINTER(Res2TrainDesc), c_void_p, c_size_t, c_void_p]),
+    'vp_se_scale_residual_z16': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
+                                 c_int, c_int, c_int, c_void_p]),
+    'vp_utt_dot_z16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'vp_col_sums_f32_b16_utt': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, C.c_longlong,
+                                c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'vp_bn_relu_bwd_dbias_b16_utt': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, C.c_longlong, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'vp_prep_weights_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'vp_grid_barrier_status': (c_int, [c_void_p]),
     'vp_grid_barrier_reset': (c_int, [c_void_p, c_void_p]),

@@ -8,7 +8,7 @@ import os
 import torch
 
 import ppvector
-from ppvector.train.functions import BNRows, CatConvBlock, ConvBlock, ConvBlockSkip, Res2Fn, SEBlockFn, prep_weights_bf16
+from ppvector.train.functions import BNRows, CatConvBlock, ConvBlock, ConvBlockSkip, ConvSEFn, Res2Fn, SEBlockFn, prep_weights_bf16
 from ppvector.train.segments import cut
 from ppvector.train.tdnn_train import asp_forward
 
@@ -66,12 +66,22 @@ def se_res2net_block(blk, x, B, T, shadow=None):
     # bf16 only; the tape sees f32 placeholders (functions._placeholder)
     res16 = getattr(x, '_vp_bf16', None)
     all16 = shadow is not None and res16 is not None and not os.environ.get('VPMI_SE_F32') and not os.environ.get('VPMI_NO_TSUMS')
-    h = tdnn_block(blk.tdnn2, h, B, T, want_tsums=True, y_bf16=all16)
     if res16 is not None:
         residual._vp_bf16 = res16                                # (a view of x: attributes do not travel with it)
         if getattr(x, '_vp_bf16_only', False):
             residual._vp_bf16_only = True
     se = blk.se_block                                           # squeeze, two dense layers, gate, + residual: one tape entry
+    c2, n2 = blk.tdnn2.conv.conv, blk.tdnn2.norm.norm
+    if (all16 and getattr(h, '_vp_bf16_only', False) and c2.bias is not None
+            and ConvSEFn.usable(h, residual, c2.weight, se.conv1.conv.weight, se.conv2.conv.weight, se.conv1.conv.bias, se.conv2.conv.bias,
+                                shadow, B, T)):
+        # tdnn2 + SE gate + residual as ONE tape entry: neither tdnn2's BatchNorm output nor the SE block's input gradient is ever stored
+        cfg2 = dict(B=B, T=T, dilation=blk.tdnn2.conv.dilation, pad='reflect', relu=True, momentum=n2.momentum, eps=n2.eps)
+        out = ConvSEFn.apply(h, c2.weight, c2.bias, n2.weight, n2.bias, n2._mean, n2._variance, residual, se.conv1.conv.weight,
+                             se.conv1.conv.bias, se.conv2.conv.weight, se.conv2.conv.bias, cfg2, shadow)
+        out._vp_bf16, out._vp_bf16_only = shadow, True
+        return out
+    h = tdnn_block(blk.tdnn2, h, B, T, want_tsums=True, y_bf16=all16)
     out = SEBlockFn.apply(h, residual, se.conv1.conv.weight, se.conv1.conv.bias, se.conv2.conv.weight, se.conv2.conv.bias, B, T, shadow)
     if shadow is not None:
         out._vp_bf16 = shadow                                    # ConvBlock / CatConvBlock take the operand from here instead of converting

@@ -270,7 +270,11 @@ class ConvBlock(torch.autograd.Function):
                                           shift.data_ptr(), N.stream_ptr()), hctx)
             into, add = cfg.get('y_into'), cfg.get('aux_add')
             y16 = wide >= 2 and cfg.get('y_bf16') and not tanh
-            if y16:
+            if y16 and cfg.get('_no_apply'):
+                # the consumer folds the BatchNorm apply into its own read of z (ConvSEFn: the SE gate + residual pass): y is never stored
+                y = _placeholder(z.shape, x.device)
+                cfg['_zaff'] = (z, scale, shift)
+            elif y16:
                 # the output's only consumer reads it as bf16 and takes its time statistics from the fused sums (ECAPA's MFA -> ASP):
                 # 234 MB written instead of 469, and every later pass over it reads half
                 y16t = torch.empty(z.shape, dtype=torch.bfloat16, device=x.device)
@@ -281,6 +285,8 @@ class ConvBlock(torch.autograd.Function):
                 # travel as its bf16 twin, the way producers' twins do everywhere else (`_vp_bf16`), marked as the only copy.
                 y = _placeholder(z.shape, x.device)
                 cfg['_y16'] = y16t
+            if y16:
+                pass
             elif wide >= 2:
                 y = torch.empty(z.shape, dtype=torch.float32, device=x.device)
                 _chk(lib.vp_affine_rows_b16_f32(hctx, z.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(), B * T_out, Cout,
@@ -324,11 +330,12 @@ class ConvBlock(torch.autograd.Function):
         return _conv_block_bwd(ctx, dy)
 
 
-def _conv_block_bwd(ctx, dy, skip=None, fold=None):
+def _conv_block_bwd(ctx, dy, skip=None, fold=None, utt=None):
     """ConvBlock's backward.  skip: a gradient that reached x along another path (the block residual, another consumer of the
     same tensor), added in the data-gradient conv's epilogue instead of by a separate pass.  fold: {'dx': slice view of a wider
     gradient tensor, 'add': slice view or None} -- d x is written into that slice and the returned tensor is d x + add (or None):
-    the Res2Net hand-off (Res2Fn)."""
+    the Res2Net hand-off (Res2Fn).  utt: (s (B, Cout), dm (B, Cout), T) -- the output gradient is dy * s[b] + dm[b] / T per utterance,
+    formed on the fly by the BatchNorm-backward passes (ConvSEFn: the SE block behind this conv never stores its input gradient)."""
     x, weight, z, mean, invstd, gamma, yt, w2 = ctx.saved_tensors
     B, T_in, T_out, Cin, Cout, KW, dil, pad, pad_left, relu, bn, tanh, has_bias, has_rb = ctx.geom
     lib, hctx = N.lib(), N.ctx(x.device)
@@ -351,8 +358,16 @@ def _conv_block_bwd(ctx, dy, skip=None, fold=None):
         dy = t
     dgamma = dbeta = None
     if bn or relu:
+        if utt is not None and not (bn and z.dtype == torch.bfloat16 and has_bias and Cout % 4 == 0 and not tanh):
+            raise N.VpmiError('ConvBlock backward: a per-utterance affine on the output gradient needs the bf16 pre-BatchNorm form')
         if bn:
-            if z.dtype == torch.bfloat16:
+            if z.dtype == torch.bfloat16 and utt is not None:
+                sums = torch.empty((2, Cout), dtype=torch.float32, device=dev)
+                ws = _bytes(lib.vp_col_sums_workspace_bytes(M, Cout), dev)
+                _chk(lib.vp_col_sums_f32_b16_utt(hctx, dy.data_ptr(), Cout, utt[0].data_ptr(), utt[1].data_ptr(), int(utt[2]), z.data_ptr(), Cout,
+                                                 mean.data_ptr(), invstd.data_ptr(), M, Cout, sums.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                 N.stream_ptr()), hctx)
+            elif z.dtype == torch.bfloat16:
                 sums = torch.empty((2, Cout), dtype=torch.float32, device=dev)
                 ws = _bytes(lib.vp_col_sums_workspace_bytes(M, Cout), dev)
                 _chk(lib.vp_col_sums_f32_b16(hctx, dy.data_ptr(), Cout, z.data_ptr(), Cout, mean.data_ptr(), invstd.data_ptr(), M, Cout,
@@ -371,10 +386,15 @@ def _conv_block_bwd(ctx, dy, skip=None, fold=None):
             ws = _bytes(lib.vp_bn_relu_bwd_dbias_workspace_bytes(M, Cout), dev)
             fn = (lib.vp_bn_relu_bwd_dbias_b16 if z.dtype == torch.bfloat16 else
                   lib.vp_bn_relu_bwd_dbias_bf16out if wide else lib.vp_bn_relu_bwd_dbias_f32)
-            _chk(fn(hctx, dy.data_ptr(), Cout, z.data_ptr(), Cout, mu.data_ptr(), istd.data_ptr(),
-                                              g.data_ptr() if g is not None else None, sums.data_ptr(), M, Cout, int(relu),
-                                              dz.data_ptr(), Cout, dbias.data_ptr(), ws.data_ptr(), ws.numel(),
-                                              N.stream_ptr()), hctx)
+            if utt is not None:
+                _chk(lib.vp_bn_relu_bwd_dbias_b16_utt(hctx, dy.data_ptr(), Cout, utt[0].data_ptr(), utt[1].data_ptr(), int(utt[2]), z.data_ptr(),
+                                                      Cout, mu.data_ptr(), istd.data_ptr(), g.data_ptr() if g is not None else None,
+                                                      sums.data_ptr(), M, Cout, int(relu), dz.data_ptr(), Cout, dbias.data_ptr(),
+                                                      ws.data_ptr(), ws.numel(), N.stream_ptr()), hctx)
+            else:
+                _chk(fn(hctx, dy.data_ptr(), Cout, z.data_ptr(), Cout, mu.data_ptr(), istd.data_ptr(),
+                        g.data_ptr() if g is not None else None, sums.data_ptr(), M, Cout, int(relu),
+                        dz.data_ptr(), Cout, dbias.data_ptr(), ws.data_ptr(), ws.numel(), N.stream_ptr()), hctx)
         else:
             _chk(lib.vp_bn_relu_bwd_f32(hctx, dy.data_ptr(), Cout, z.data_ptr(), Cout, mu.data_ptr(), istd.data_ptr(),
                                         g.data_ptr() if g is not None else None, sums.data_ptr(), M, Cout, int(relu),
@@ -857,6 +877,90 @@ class SEBlockFn(torch.autograd.Function):
         dh = torch.empty(h.shape, dtype=torch.float32, device=h.device)
         _chk(lib.vp_scale_shift_rows_f32(hctx, dout.data_ptr(), s.data_ptr(), dm.data_ptr(), B, T, Cc, dh.data_ptr(), N.stream_ptr()), hctx)
         return dh, dout, dw1, db1, dw2, db2, None, None, None
+
+
+class ConvSEFn(torch.autograd.Function):
+    """tdnn2 -> SEBlock -> + residual of an SE-Res2 block (ecapa_tdnn.py:125-142) as ONE tape entry, for the all-bf16 form of the mixed-
+    precision step: conv (bf16 pre-BatchNorm output z, fused time sums) -> batch statistics -> [the BatchNorm apply is folded into the
+    gate pass: h = BN(z) is never stored] -> squeeze mean from the fused sums -> the two dense layers -> out = h * s + res written once, as
+    bf16, into its slice of the MFA operand.  Backward: ds = sum_t dout * h (h re-formed from z), the dense layers' backward down to
+    dmean, then the conv's BatchNorm + ReLU backward reads dout and forms the SE block's input gradient dh = dout * s + dmean / T on the
+    fly [dh is never stored].  As two entries (ConvBlock + SEBlockFn) the step wrote and re-read h (2 x 78 MB per block at 256 x 298
+    frames) and dh (156 MB f32 written, read twice); the arithmetic is the same to the last bit
+    (tests/test_gpu_train.py::test_conv_se_tail_as_one_tape_entry_changes_nothing).  VPMI_SE_TAIL_UNFUSED=1 keeps the two entries."""
+
+    @staticmethod
+    def usable(x, res, conv_w, w1, w2, b1, b2, shadow, B, T):
+        Cc, H = conv_w.shape[0], w1.shape[0]
+        Cin = conv_w.shape[1]
+        res16 = getattr(res, '_vp_bf16', None)
+        if not (B * T >= 4096 and Cin % 64 == 0 and Cin >= 256 and Cc >= 256):          # (the conv must take _wide_bf16's level 2)
+            return False
+        return bool(ppvector.get_train_amp() and not os.environ.get('VPMI_SE_TAIL_UNFUSED') and not os.environ.get('VPMI_SE_DENSE_UNFUSED')
+                    and not os.environ.get('VPMI_NO_TSUMS') and os.environ.get('VPMI_TRAIN_BF16_OPS', '2') == '2'
+                    and shadow is not None and res16 is not None and tuple(res16.shape) == (B * T, Cc) and res16.stride(1) == 1
+                    and shadow.stride(1) == 1 and Cc % 8 == 0 and res16.stride(0) % 8 == 0 and shadow.stride(0) % 8 == 0
+                    and tuple(w1.shape) == (H, Cc, 1) and tuple(w2.shape) == (Cc, H, 1) and Cc <= 1024 and H <= 1024 and H % 4 == 0
+                    and b1 is not None and b2 is not None and all(t.dtype == torch.float32 and t.is_contiguous() for t in (w1, b1, w2, b2))
+                    and conv_w.shape[2] == 1 and lib_nseg_ok(T))
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, run_mean, run_var, res, w1, b1, w2, b2, cfg, shadow):
+        lib, hctx = N.lib(), N.ctx(weight.device)
+        B, T = cfg['B'], cfg['T']
+        tp = _Tape((True,) * 9)
+        c2 = dict(cfg, want_tsums=True, y_bf16=True, _no_apply=True)
+        ConvBlock.forward(tp, x, weight, bias, None, gamma, beta, run_mean, run_var, c2)
+        if c2.get('_zaff') is None or c2.get('_tsums') is None:
+            raise N.VpmiError('ConvSEFn: the conv did not take the bf16 pre-BatchNorm form with fused time sums (check ConvSEFn.usable)')
+        z, scale, shift = c2['_zaff']
+        ps, pq = c2['_tsums'][:2]
+        Cc, H = z.shape[1], w1.shape[0]
+        dev = z.device
+        mean = torch.empty((B, Cc), dtype=torch.float32, device=dev)          # squeeze: time mean of h from the conv's fused sums of z
+        _chk(lib.vp_moments_finalize_affine(hctx, ps.data_ptr(), pq.data_ptr(), scale.data_ptr(), shift.data_ptr(), B, T, Cc, 1e-12, 0,
+                                            mean.data_ptr(), N.stream_ptr()), hctx)
+        a = torch.empty((B, H), dtype=torch.float32, device=dev)
+        s = torch.empty((B, Cc), dtype=torch.float32, device=dev)
+        _chk(lib.vp_se_dense_train_fwd(hctx, mean.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), B, Cc, H,
+                                       int(ppvector.get_train_amp()), a.data_ptr(), s.data_ptr(), N.stream_ptr()), hctx)
+        res16 = res._vp_bf16
+        _chk(lib.vp_se_scale_residual_z16(hctx, z.data_ptr(), Cc, scale.data_ptr(), shift.data_ptr(), s.data_ptr(), res16.data_ptr(),
+                                          res16.stride(0), 0, shadow.data_ptr(), shadow.stride(0), 0, B, T, Cc, N.stream_ptr()), hctx)
+        ctx.save_for_backward(*tp.saved_tensors, s, mean, a, w1, w2, scale, shift)
+        ctx.n_conv = len(tp.saved_tensors)
+        ctx.inner = (tp.geom, tp.wide, getattr(tp, 'wt16', None), tp.zero_dbias, B, T, int(ppvector.get_train_amp()))
+        return _placeholder(z.shape, dev)                      # the caller hangs `shadow` on it as its only copy
+
+    @staticmethod
+    def backward(ctx, dout):
+        saved = ctx.saved_tensors
+        tp = _Tape((True,) * 9)
+        tp.saved_tensors = saved[:ctx.n_conv]
+        tp.geom, tp.wide, tp.wt16, tp.zero_dbias, B, T, amp = ctx.inner
+        s, mean, a, w1, w2, scale, shift = saved[ctx.n_conv:]
+        z = tp.saved_tensors[2]
+        lib, hctx = N.lib(), N.ctx(z.device)
+        dout = _f32c(dout)
+        Cc, H = z.shape[1], w1.shape[0]
+        ds = torch.empty_like(s)
+        _chk(lib.vp_utt_dot_z16(hctx, dout.data_ptr(), z.data_ptr(), scale.data_ptr(), shift.data_ptr(), B, T, Cc, ds.data_ptr(),
+                                N.stream_ptr()), hctx)
+        dm = torch.empty_like(mean)
+        dw1, dw2 = torch.empty_like(w1), torch.empty_like(w2)
+        db1 = torch.empty(H, dtype=torch.float32, device=z.device)
+        db2 = torch.empty(Cc, dtype=torch.float32, device=z.device)
+        ws = _bytes(lib.vp_se_dense_train_bwd_workspace_bytes(B, Cc, H), z.device)
+        _chk(lib.vp_se_dense_train_bwd(hctx, ds.data_ptr(), mean.data_ptr(), a.data_ptr(), s.data_ptr(), w1.data_ptr(), w2.data_ptr(),
+                                       B, Cc, H, amp, dm.data_ptr(), dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), N.stream_ptr()), hctx)
+        r = _conv_block_bwd(tp, dout, utt=(s, dm, T))
+        return r[0], r[1], r[2], r[4], r[5], None, None, dout, dw1, db1, dw2, db2, None, None
+
+
+def lib_nseg_ok(T):
+    """The conv GEMM's fused per-utterance sums exist for utterances of >= ~19 frames (at most 8 segments per 128-row tile)."""
+    return N.lib().vp_conv1d_nseg(int(T)) <= 8
 
 
 class TimeStats(torch.autograd.Function):
