@@ -795,6 +795,19 @@ int vp_utt_dot_z16(vp_ctx* ctx, const float* dy, const void* z_bf16, const float
                    float* ds, vp_stream stream);
 int vp_col_sums_f32_b16_utt(vp_ctx* ctx, const float* a, int lda, const float* utt_scale, const float* utt_shift, int T, const void* b, int ldb,
                             const float* bmean, const float* bscale, long long M, int C, float* sums, void* ws, size_t ws_bytes, vp_stream stream);
+/* The context-statistics gradient of a pooling layer folded into the BatchNorm-backward passes of the TDNNBlock that feeds it (MFA -> ASP,
+ * ecapa_tdnn.py:262-267 + pooling.py:97-104): the gradient reaching y = BN(z) through [mean_t y | std_t y] is alpha[b][c] + beta[b][c] * y
+ * (vp_time_stats_bwd_coeffs: ab = [alpha | beta], each (B, C)); vp_col_sums_f32_b16_ctx / vp_bn_relu_bwd_dbias_b16_ctx add it to their d y
+ * on the fly with y = bf16(z * bn_scale + bn_shift) re-formed from the bf16 z they read anyway -- the vp_time_stats_bwd_add_x16 pass
+ * (read x, read + write d x: 1.17 GB at 256 x 298 x 1536) never runs. */
+int vp_time_stats_bwd_coeffs(vp_ctx* ctx, const float* stats, const float* dstats, int B, int T, int C, float eps, float* ab, vp_stream stream);
+int vp_col_sums_f32_b16_ctx(vp_ctx* ctx, const float* a, int lda, const float* alpha, const float* beta, int T, const float* bn_scale,
+                            const float* bn_shift, const void* b, int ldb, const float* bmean, const float* bscale, long long M, int C, float* sums,
+                            void* ws, size_t ws_bytes, vp_stream stream);
+int vp_bn_relu_bwd_dbias_b16_ctx(vp_ctx* ctx, const float* dy, int lddy, const float* alpha, const float* beta, int T, const float* bn_scale,
+                                 const float* bn_shift, const void* z, int ldz, const float* mean, const float* invstd, const float* gamma,
+                                 const float* sums, long long M, int C, int relu_mask, void* dz, int lddz, float* dbias, void* ws,
+                                 size_t ws_bytes, vp_stream stream);
 int vp_bn_relu_bwd_dbias_b16_utt(vp_ctx* ctx, const float* dy, int lddy, const float* utt_scale, const float* utt_shift, int T, const void* z,
                                  int ldz, const float* mean, const float* invstd, const float* gamma, const float* sums, long long M, int C,
                                  int relu_mask, void* dz, int lddz, float* dbias, void* ws, size_t ws_bytes, vp_stream stream);

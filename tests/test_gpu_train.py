@@ -1626,3 +1626,57 @@ def test_conv_se_tail_as_one_tape_entry_changes_nothing(N, amp, monkeypatch):
     assert not diff, diff[:5]
     assert all(torch.equal(ba[k], bb[k]) for k in ba)
     print(f'[conv + SE tail as one tape entry] loss {la:.6f}: {len(ga)} parameter gradients and {len(ba)} buffers bit-identical to the two-entry form')
+
+
+def test_mfa_asp_as_one_tape_entry_stays_within_rounding_noise(N, amp, monkeypatch):
+    """MfaAspFn (MFA TDNNBlock + AttentiveStatisticsPooling as one tape entry: the pooling layer's context-statistics gradient
+    alpha[b, c] + beta[b, c] * y is added inside the MFA layer's two BatchNorm-backward passes instead of by a pass over the (B*T, 1536)
+    tensors) against the two entries it replaces (VPMI_MFA_ASP_UNFUSED=1) at 56 x 298 frames: the forward is the same launches (loss,
+    embeddings and running statistics bit-identical); the gradients differ by the rounding of alpha + beta * y against
+    dmean / T + dstd / std * (y - mean) / T and by the bf16 roundings of dz that flip with it -- bounded here at 1e-3 of each tensor's norm
+    (the mixed-precision step sits ~1e-1 from the f32 step)."""
+    from ppvector.loss.aamloss import AAMLoss
+    from ppvector.models.ecapa_tdnn import EcapaTdnn
+    from ppvector.models.fc import SpeakerIdentification
+    from ppvector.train import functions as Fn
+    g = torch.Generator().manual_seed(43)
+    x = (torch.randn(56, 298, 80, generator=g) * 2).cuda()
+    y = torch.randint(0, 11, (56,), generator=g).cuda()
+
+    def run(unfused):
+        if unfused:
+            monkeypatch.setenv('VPMI_MFA_ASP_UNFUSED', '1')
+        else:
+            monkeypatch.delenv('VPMI_MFA_ASP_UNFUSED', raising=False)
+        calls = {'n': 0}
+        orig = Fn._asp_backward
+
+        def counted(ctx, dp, defer_ctx=False):
+            calls['n'] += int(bool(defer_ctx))
+            return orig(ctx, dp, defer_ctx)
+        monkeypatch.setattr(Fn, '_asp_backward', counted)
+        m = EcapaTdnn(80, embd_dim=192, pooling_type='ASP', channels=[512, 512, 512, 512, 1536])
+        m.load_state_dict(om.ecapa_params(80, seed=21))
+        head = SpeakerIdentification(192, 11)
+        head.load_state_dict({'weight': om.head_params(192, 11, seed=22)})
+        model = torch.nn.Sequential(m, head).cuda().train()
+        out = model(x)
+        loss = AAMLoss(margin=0.2, scale=32)(out, y)
+        loss.backward()
+        torch.cuda.synchronize()
+        monkeypatch.setattr(Fn, '_asp_backward', orig)
+        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        bufs = {k: b.detach().clone() for k, b in model.named_buffers()}
+        return float(loss), out['features'].detach().clone(), grads, bufs, calls['n']
+
+    la, ea, ga, ba, na = run(False)
+    lb, eb, gb, bb, nb = run(True)
+    assert na == 1 and nb == 0, (na, nb)
+    assert la == lb and torch.equal(ea, eb) and all(torch.equal(ba[k], bb[k]) for k in ba)
+    worst, wk = 0.0, None
+    for k in ga:
+        d = rel(ga[k], gb[k])
+        if d > worst:
+            worst, wk = d, k
+    print(f'[MFA + ASP as one tape entry] loss {la:.6f} (identical); worst parameter-gradient rel-L2 against the two-entry form {worst:.2e} ({wk})')
+    assert worst < 1e-3, (worst, wk)

@@ -536,15 +536,22 @@ __global__ __launch_bounds__(256) void col_sums_kernel(ColSumArgs p) {
 // Four channels per lane (C and the row pitches multiples of 4, 16-byte aligned bases): a wave-instruction moves 1 KB of a row
 // instead of 256 B, and four rows' loads are issued before the first add.  Workgroup = CL column lanes x (256 / CL) row groups
 // over rows_per_chunk rows; CL = 64 / 32 / 16 by width so that 64-channel tensors (the Res2 convs) still fill the lanes.
+#ifndef VP_BNBWD_ROWS
+#define VP_BNBWD_ROWS 8             // rows in flight per thread of the BatchNorm-backward passes (tools/build_variant.sh u4 -DVP_BNBWD_ROWS=4: A/B)
+#endif
 struct ColSum4Args { const float* a; const float* b; const float* bmean; const float* bscale; float* part; int lda, ldb, M, C4, rows_per_chunk, cl_shift;
                      const float* ms; const float* mh;      // optional: a counts only where b * ms + mh > 0 (a ReLU BEHIND the BatchNorm, resnet_se.py:72-74)
                      // UTT: the summed tensor is a * us[b] + um[b] * inv_t per utterance b = row / T -- the SE block's input gradient
                      // dh = dout * s + dmean / T (ecapa_tdnn.py:50-82 backward) formed on the fly, never stored
-                     const float* us; const float* um; int T; float inv_t; };
+                     const float* us; const float* um; int T; float inv_t;
+                     // UTT == 2: the summed tensor is a + us[b] + um[b] * bf16(b * xsc + xsh) -- the gradient that reaches a TDNNBlock's output y = BN(z)
+                     // through its consumer's context statistics [mean_t y | std_t y] (pooling.py:97-104), affine in y per utterance and
+                     // channel: us = alpha, um = beta of vp_time_stats_bwd_coeffs; y re-formed from the bf16 z the pass reads anyway
+                     const float* xsc; const float* xsh; };
 
-template <bool UTT>
+template <int UTT>
 __device__ __forceinline__ void utt_affine4(float (&v)[4], const float* us, const float* um, int T, float inv_t, int C, int m, int c) {
-    if constexpr (UTT) {
+    if constexpr (UTT == 1) {
         const size_t o = (size_t)(m / T) * C + c;
         float sv[4], dv[4];
         vp_load4(us + o, sv); vp_load4(um + o, dv);
@@ -553,7 +560,20 @@ __device__ __forceinline__ void utt_affine4(float (&v)[4], const float* us, cons
     }
 }
 
-template <bool HASB, typename TB = float, bool UTT = false>
+// UTT == 2: v += alpha[b] + beta[b] * bf16(z * xsc + xsh)
+template <int UTT>
+__device__ __forceinline__ void ctx_affine4(float (&v)[4], const float (&zv)[4], const float* ua, const float* ub, const float (&xsc)[4],
+                                            const float (&xsh)[4], int T, int C, int m, int c) {
+    if constexpr (UTT == 2) {
+        const size_t o = (size_t)(m / T) * C + c;
+        float al[4], be[4];
+        vp_load4(ua + o, al); vp_load4(ub + o, be);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += __fmaf_rn(be[e], (float)(bf16_t)__fmaf_rn(zv[e], xsc[e], xsh[e]), al[e]);
+    }
+}
+
+template <bool HASB, typename TB = float, int UTT = 0>
 __global__ __launch_bounds__(256) void col_sums4_kernel(ColSum4Args p) {
     const TB* __restrict__ gb = reinterpret_cast<const TB*>(p.b);
     __shared__ float sm[2][256][4];
@@ -567,18 +587,26 @@ __global__ __launch_bounds__(256) void col_sums4_kernel(ColSum4Args p) {
         if (HASB) { vp_load4(p.bmean + c, mu); vp_load4(p.bscale + c, sc); }
         float ms[4] = {0.f, 0.f, 0.f, 0.f}, mh[4] = {1.f, 1.f, 1.f, 1.f};          // (no mask: 0 * b + 1 > 0 always)
         if (HASB && p.ms) { vp_load4(p.ms + c, ms); vp_load4(p.mh + c, mh); }
+        float xsc[4] = {0.f, 0.f, 0.f, 0.f}, xsh[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (UTT == 2) { vp_load4(p.xsc + c, xsc); vp_load4(p.xsh + c, xsh); }
         int m = m0 + rg;
-        for (; m + 3 * RG < m1; m += 4 * RG) {
-            float av[4][4], bv[4][4];
+        // eight rows per trip, their loads issued together (round 5: four rows per trip left each thread ~9 dependent load round trips per
+        // chunk -- 3.7 TB/s on the (76 288, 512) tensors; the sums are taken in the same row order, bit-identical)
+        constexpr int U = UTT ? 4 : VP_BNBWD_ROWS;              // (the per-utterance operands cost the registers of four rows)
+        for (; m + (U - 1) * RG < m1; m += U * RG) {
+            float av[U][4], bv[U][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 vp_load4(p.a + (size_t)(m + u * RG) * p.lda + c, av[u]);
                 if (HASB) vp_load4(gb + (size_t)(m + u * RG) * p.ldb + c, bv[u]);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) utt_affine4<UTT>(av[u], p.us, p.um, p.T, p.inv_t, p.C4 * 4, m + u * RG, c);
+            for (int u = 0; u < U; ++u) {
+                utt_affine4<UTT>(av[u], p.us, p.um, p.T, p.inv_t, p.C4 * 4, m + u * RG, c);
+                if constexpr (HASB) ctx_affine4<UTT>(av[u], bv[u], p.us, p.um, xsc, xsh, p.T, p.C4 * 4, m + u * RG, c);
+            }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float g = (!HASB || (float)bv[u][e] * ms[e] + mh[e] > 0.f) ? av[u][e] : 0.f;
@@ -591,6 +619,7 @@ __global__ __launch_bounds__(256) void col_sums4_kernel(ColSum4Args p) {
             vp_load4(p.a + (size_t)m * p.lda + c, av);
             if (HASB) vp_load4(gb + (size_t)m * p.ldb + c, bv);
             utt_affine4<UTT>(av, p.us, p.um, p.T, p.inv_t, p.C4 * 4, m, c);
+            if constexpr (HASB) ctx_affine4<UTT>(av, bv, p.us, p.um, xsc, xsh, p.T, p.C4 * 4, m, c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float g = (!HASB || (float)bv[e] * ms[e] + mh[e] > 0.f) ? av[e] : 0.f;
@@ -707,6 +736,7 @@ struct BnBwdArgs {
     float* dz; int lddy, ldz, lddz, C4, relu_mask; long long M;
     const float* ms; const float* mh;       // optional: d y counts only where z * ms + mh > 0 (a ReLU BEHIND the BatchNorm)
     const float* us; const float* um; int T; float inv_t;      // bn_relu_bwd_dbias_kernel<.., UTT>: d y = dy * us[b] + um[b] * inv_t, b = row / T
+    const float* xsc; const float* xsh;                        // UTT == 2: d y = dy + us[b] + um[b] * bf16(z * xsc + xsh) (see ColSum4Args)
 };
 
 __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdArgs a) {
@@ -741,7 +771,7 @@ struct BnBwdSumArgs { BnBwdArgs b; float* part; int M, rows_per_chunk, cl_shift;
 
 // TO = bf16_t: dz leaves as bf16 (b.dz reinterpreted, lddz in elements) -- the operand the wide layers' data- and weight-gradient
 // GEMMs read (they would round it to bf16 anyway); the column sums are of the unrounded values.
-template <typename TO, typename TZ = float, bool UTT = false>
+template <typename TO, typename TZ = float, int UTT = 0>
 __global__ __launch_bounds__(256) void bn_relu_bwd_dbias_kernel(BnBwdSumArgs p) {
     __shared__ float sm[256][4];
     const BnBwdArgs& a = p.b;
@@ -757,6 +787,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_dbias_kernel(BnBwdSumArgs p) 
         float mu[4], is[4], g[4], s1[4], s2[4];
         vp_load4(a.mean + c, mu); vp_load4(a.invstd + c, is); vp_load4(a.sums + c, s1); vp_load4(a.sums + C + c, s2);
         if (a.gamma) vp_load4(a.gamma + c, g); else { g[0] = g[1] = g[2] = g[3] = 1.f; }
+        float xsc[4] = {0.f, 0.f, 0.f, 0.f}, xsh[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (UTT == 2) { vp_load4(a.xsc + c, xsc); vp_load4(a.xsh + c, xsh); }
         auto one = [&](const float* dy, const float* z, float* o) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -767,22 +799,27 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_dbias_kernel(BnBwdSumArgs p) 
             }
         };
         int m = m0 + rg;
-        for (; m + 3 * RG < m1; m += 4 * RG) {
-            float dy[4][4], z[4][4], o[4];
+        constexpr int U = UTT ? 4 : VP_BNBWD_ROWS;               // (eight rows in flight per thread: see col_sums4_kernel)
+        for (; m + (U - 1) * RG < m1; m += U * RG) {
+            float dy[U][4], z[U][4], o[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 vp_load4(a.dy + (size_t)(m + u * RG) * a.lddy + c, dy[u]);
                 vp_load4(gz + (size_t)(m + u * RG) * a.ldz + c, z[u]);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) utt_affine4<UTT>(dy[u], a.us, a.um, a.T, a.inv_t, C, m + u * RG, c);
+            for (int u = 0; u < U; ++u) {
+                utt_affine4<UTT>(dy[u], a.us, a.um, a.T, a.inv_t, C, m + u * RG, c);
+                ctx_affine4<UTT>(dy[u], z[u], a.us, a.um, xsc, xsh, a.T, C, m + u * RG, c);
+            }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { one(dy[u], z[u], o); vp_store4(gdz + (size_t)(m + u * RG) * a.lddz + c, o); }
+            for (int u = 0; u < U; ++u) { one(dy[u], z[u], o); vp_store4(gdz + (size_t)(m + u * RG) * a.lddz + c, o); }
         }
         for (; m < m1; m += RG) {
             float dy[4], z[4], o[4];
             vp_load4(a.dy + (size_t)m * a.lddy + c, dy); vp_load4(gz + (size_t)m * a.ldz + c, z);
             utt_affine4<UTT>(dy, a.us, a.um, a.T, a.inv_t, C, m, c);
+            ctx_affine4<UTT>(dy, z, a.us, a.um, xsc, xsh, a.T, C, m, c);
             one(dy, z, o);
             vp_store4(gdz + (size_t)m * a.lddz + c, o);
         }
@@ -900,6 +937,21 @@ __global__ __launch_bounds__(256) void time_stats_bwd_kernel(TsBwdArgs a) {
         }
         vp_store4(a.dx + m * a.lddx + c, o);
     }
+}
+
+// The same gradient as per-utterance coefficients: dx[b,t,c] = alpha[b,c] + beta[b,c] * x[b,t,c] with beta = [var > eps] dstd / (std T),
+// alpha = dmean / T - beta * mean -- what the BatchNorm-backward passes of the producing layer add to their d y on the fly
+// (ColSum4Args UTT == 2) instead of a pass over the (B*T, C) tensor.  ab: [2][B][C]
+__global__ __launch_bounds__(256) void time_stats_bwd_coeffs_kernel(const float* stats, const float* dstats, int B, int C, int T, float eps, float* ab) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C;
+    const float invT = 1.f / (float)T;
+    const float mu = stats[(size_t)b * 2 * C + c], sd = stats[(size_t)b * 2 * C + C + c];
+    const float dm = dstats[(size_t)b * 2 * C + c], ds = dstats[(size_t)b * 2 * C + C + c];
+    const float be = (sd * sd > eps) ? ds / sd * invT : 0.f;
+    ab[i] = __fmaf_rn(-be, mu, dm * invT);
+    ab[(size_t)B * C + i] = be;
 }
 
 // Backward of attentive statistics (pooling.py:114-123): alpha = softmax_t(e), mu = sum alpha x, sd = sqrt(max(sum alpha (x-mu)^2, eps)).
@@ -1630,7 +1682,7 @@ int vp_col_sums_f32_b16_utt(vp_ctx* ctx, const float* a, int lda, const float* u
     ColSum4Args p{a, (const float*)b, bmean, bscale, (float*)ws, lda, ldb, (int)M, C / 4, rpc, cl_shift, nullptr, nullptr, utt_scale, utt_shift, T,
                   1.f / (float)T};
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL((col_sums4_kernel<true, bf16_t, true>), dim3(colblocks, (unsigned)chunks), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((col_sums4_kernel<true, bf16_t, 1>), dim3(colblocks, (unsigned)chunks), dim3(256), 0, st, p);
     VP_LAUNCH_CHECK(ctx, "col_sums_b16_utt");
     launch_sum_partials((const float*)ws, chunks, (long long)2 * C, sums, st);
     VP_LAUNCH_CHECK(ctx, "col_sums_b16_utt_reduce");
@@ -1738,6 +1790,57 @@ int vp_bn_relu_bwd_dbias_b16(vp_ctx* ctx, const float* dy, int lddy, const void*
     return bn_bwd_dbias_impl(ctx, dy, lddy, z, ldz, mean, invstd, gamma, sums, M, C, relu_mask, dz, lddz, true, dbias, ws, ws_bytes, stream, true);
 }
 
+// alpha / beta of the context-statistics gradient (time_stats_bwd_coeffs_kernel): ab [2][B][C]
+int vp_time_stats_bwd_coeffs(vp_ctx* ctx, const float* stats, const float* dstats, int B, int T, int C, float eps, float* ab, vp_stream stream) {
+    if (!ctx || !stats || !dstats || !ab || B <= 0 || T <= 0 || C <= 0) VP_FAIL(ctx, VP_EINVAL, "time_stats_bwd_coeffs: bad arguments");
+    hipLaunchKernelGGL(time_stats_bwd_coeffs_kernel, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, dstats, B, C, T, eps, ab);
+    VP_LAUNCH_CHECK(ctx, "time_stats_bwd_coeffs");
+    return VP_OK;
+}
+
+// The two BatchNorm-backward passes of a TDNNBlock whose output y = BN(z) is consumed by a pooling layer's context statistics: d y =
+// dy + alpha[b] + beta[b] * bf16(z * bn_scale + bn_shift) (vp_time_stats_bwd_coeffs), y re-formed from the bf16 z the passes read anyway --
+// vp_time_stats_bwd_add_x16's pass over the (B*T, C) tensors never runs.  sums: [2][C]
+int vp_col_sums_f32_b16_ctx(vp_ctx* ctx, const float* a, int lda, const float* alpha, const float* beta, int T, const float* bn_scale,
+                            const float* bn_shift, const void* b, int ldb, const float* bmean, const float* bscale, long long M, int C, float* sums,
+                            void* ws, size_t ws_bytes, vp_stream stream) {
+    if (!ctx || !a || !b || !bmean || !bscale || !sums || !alpha || !beta || !bn_scale || !bn_shift || T <= 0 || M <= 0 || M % T ||
+        M > 0x7fffffffLL || C <= 0 || (C | lda | ldb) & 3 || (((uintptr_t)a | (uintptr_t)alpha | (uintptr_t)beta) & 15) || ((uintptr_t)b & 7))
+        VP_FAIL(ctx, VP_EINVAL, "col_sums_b16_ctx: bad arguments");
+    if (!ws || ws_bytes < vp_col_sums_workspace_bytes(M, C)) VP_FAIL(ctx, VP_EWORKSPACE, "col_sums_b16_ctx: workspace too small");
+    int cl_shift, colblocks, rpc, chunks;
+    colsum4_geometry(M, C / 4, cl_shift, colblocks, rpc, chunks);
+    ColSum4Args p{a, (const float*)b, bmean, bscale, (float*)ws, lda, ldb, (int)M, C / 4, rpc, cl_shift, nullptr, nullptr, alpha, beta, T, 0.f,
+                  bn_scale, bn_shift};
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((col_sums4_kernel<true, bf16_t, 2>), dim3(colblocks, (unsigned)chunks), dim3(256), 0, st, p);
+    VP_LAUNCH_CHECK(ctx, "col_sums_b16_ctx");
+    launch_sum_partials((const float*)ws, chunks, (long long)2 * C, sums, st);
+    VP_LAUNCH_CHECK(ctx, "col_sums_b16_ctx_reduce");
+    return VP_OK;
+}
+
+int vp_bn_relu_bwd_dbias_b16_ctx(vp_ctx* ctx, const float* dy, int lddy, const float* alpha, const float* beta, int T, const float* bn_scale,
+                                 const float* bn_shift, const void* z, int ldz, const float* mean, const float* invstd, const float* gamma,
+                                 const float* sums, long long M, int C, int relu_mask, void* dz, int lddz, float* dbias, void* ws,
+                                 size_t ws_bytes, vp_stream stream) {
+    if (!ctx || !dy || !z || !mean || !invstd || !sums || !dz || !dbias || !alpha || !beta || !bn_scale || !bn_shift || T <= 0 || M <= 0 ||
+        M % T || M > 0x7fffffffLL || C <= 0 || (C | lddy | ldz | lddz) & 3 || (((uintptr_t)dy | (uintptr_t)alpha | (uintptr_t)beta) & 15) ||
+        (((uintptr_t)z | (uintptr_t)dz) & 7))
+        VP_FAIL(ctx, VP_EINVAL, "bn_relu_bwd_dbias_ctx: bad arguments");
+    if (!ws || ws_bytes < vp_bn_relu_bwd_dbias_workspace_bytes(M, C)) VP_FAIL(ctx, VP_EWORKSPACE, "bn_relu_bwd_dbias_ctx: workspace too small");
+    int cl_shift, colblocks, rpc, chunks;
+    colsum4_geometry(M, C / 4, cl_shift, colblocks, rpc, chunks);
+    BnBwdSumArgs p{{dy, (const float*)z, mean, invstd, gamma, sums, (float*)dz, lddy, ldz, lddz, C / 4, relu_mask, M, nullptr, nullptr,
+                    alpha, beta, T, 0.f, bn_scale, bn_shift}, (float*)ws, (int)M, rpc, cl_shift};
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((bn_relu_bwd_dbias_kernel<bf16_t, bf16_t, 2>), dim3(colblocks, (unsigned)chunks), dim3(256), 0, st, p);
+    VP_LAUNCH_CHECK(ctx, "bn_relu_bwd_dbias_ctx");
+    launch_sum_partials((const float*)ws, chunks, (long long)C, dbias, st);
+    VP_LAUNCH_CHECK(ctx, "bn_relu_bwd_dbias_ctx_reduce");
+    return VP_OK;
+}
+
 // z AND dz bf16, d y = dy * utt_scale[b] + utt_shift[b] / T (b = row / T) formed on the fly: BatchNorm + ReLU backward of the conv in
 // front of an SE block straight from the block's OUTPUT gradient (see vp_col_sums_f32_b16_utt)
 int vp_bn_relu_bwd_dbias_b16_utt(vp_ctx* ctx, const float* dy, int lddy, const float* utt_scale, const float* utt_shift, int T, const void* z,
@@ -1753,7 +1856,7 @@ int vp_bn_relu_bwd_dbias_b16_utt(vp_ctx* ctx, const float* dy, int lddy, const f
     BnBwdSumArgs p{{dy, (const float*)z, mean, invstd, gamma, sums, (float*)dz, lddy, ldz, lddz, C / 4, relu_mask, M, nullptr, nullptr,
                     utt_scale, utt_shift, T, 1.f / (float)T}, (float*)ws, (int)M, rpc, cl_shift};
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL((bn_relu_bwd_dbias_kernel<bf16_t, bf16_t, true>), dim3(colblocks, (unsigned)chunks), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((bn_relu_bwd_dbias_kernel<bf16_t, bf16_t, 1>), dim3(colblocks, (unsigned)chunks), dim3(256), 0, st, p);
     VP_LAUNCH_CHECK(ctx, "bn_relu_bwd_dbias_utt");
     launch_sum_partials((const float*)ws, chunks, (long long)C, dbias, st);
     VP_LAUNCH_CHECK(ctx, "bn_relu_bwd_dbias_utt_reduce");

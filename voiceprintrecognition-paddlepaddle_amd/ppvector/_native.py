@@ -186,6 +186,12 @@ _PROTOS = {
                                 c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'vp_bn_relu_bwd_dbias_b16_utt': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                      c_void_p, C.c_longlong, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'vp_time_stats_bwd_coeffs': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    'vp_col_sums_f32_b16_ctx': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                C.c_longlong, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'vp_bn_relu_bwd_dbias_b16_ctx': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, C.c_longlong, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t,
+                                     c_void_p]),
     'vp_prep_weights_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'vp_grid_barrier_status': (c_int, [c_void_p]),
     'vp_grid_barrier_reset': (c_int, [c_void_p, c_void_p]),

@@ -8,7 +8,7 @@ import os
 import torch
 
 import ppvector
-from ppvector.train.functions import BNRows, CatConvBlock, ConvBlock, ConvBlockSkip, ConvSEFn, Res2Fn, SEBlockFn, prep_weights_bf16
+from ppvector.train.functions import BNRows, CatConvBlock, ConvBlock, ConvBlockSkip, ConvSEFn, MfaAspFn, Res2Fn, SEBlockFn, prep_weights_bf16
 from ppvector.train.segments import cut
 from ppvector.train.tdnn_train import asp_forward
 
@@ -136,6 +136,18 @@ def ecapa_forward_train(m, feats):
     cfg = dict(B=B, T=T, dilation=m.mfa.conv.dilation, pad='reflect', relu=True, momentum=norm.momentum, eps=norm.eps, xcat=xcat,
                want_tsums=True, y_bf16=xcat is not None and bool(m.asp.global_context) and T <= 320 and B * T >= 16384
                and not os.environ.get('VPMI_MFA_F32_OUT'))
+    if cfg['y_bf16'] and not os.environ.get('VPMI_MFA_ASP_UNFUSED'):
+        # MFA + ASP as ONE tape entry: the pooling layer's context-statistics gradient is folded into the MFA layer's BatchNorm backward
+        # instead of a pass of its own over the (B*T, 1536) tensors (functions.MfaAspFn)
+        a = m.asp
+        ac, an, a2 = a.tdnn.conv.conv, a.tdnn.norm.norm, a.conv.conv
+        acfg = dict(B=B, T=T, global_context=bool(a.global_context), momentum=an.momentum, eps=an.eps)
+        p = MfaAspFn.apply(cfg, acfg, conv.weight, conv.bias, norm.weight, norm.bias, norm._mean, norm._variance, ac.weight, ac.bias,
+                           an.weight, an.bias, an._mean, an._variance, a2.weight, a2.bias, *outs)
+        n = m.asp_bn.norm
+        p = BNRows.apply(p, n.weight, n.bias, n._mean, n._variance, n.momentum, n.eps)
+        fc = m.fc.conv
+        return ConvBlock.apply(p, fc.weight, fc.bias, None, None, None, None, None, dict(B=B, T=1))
     x = CatConvBlock.apply(cfg, conv.weight, conv.bias, norm.weight, norm.bias, norm._mean, norm._variance, *outs)
     if cfg.get('_tsums') is not None:
         x._vp_tsums = cfg.pop('_tsums')

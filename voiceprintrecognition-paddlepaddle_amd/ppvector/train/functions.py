@@ -334,8 +334,10 @@ def _conv_block_bwd(ctx, dy, skip=None, fold=None, utt=None):
     """ConvBlock's backward.  skip: a gradient that reached x along another path (the block residual, another consumer of the
     same tensor), added in the data-gradient conv's epilogue instead of by a separate pass.  fold: {'dx': slice view of a wider
     gradient tensor, 'add': slice view or None} -- d x is written into that slice and the returned tensor is d x + add (or None):
-    the Res2Net hand-off (Res2Fn).  utt: (s (B, Cout), dm (B, Cout), T) -- the output gradient is dy * s[b] + dm[b] / T per utterance,
-    formed on the fly by the BatchNorm-backward passes (ConvSEFn: the SE block behind this conv never stores its input gradient)."""
+    the Res2Net hand-off (Res2Fn).  utt: ('se', s (B, Cout), dm (B, Cout), T) -- the output gradient is dy * s[b] + dm[b] / T per
+    utterance (ConvSEFn: the SE block behind this conv never stores its input gradient) -- or ('ctx', alpha, beta, T, bn_scale, bn_shift)
+    -- dy + alpha[b] + beta[b] * y (MfaAspFn: the pooling layer's context-statistics gradient), formed on the fly by the two
+    BatchNorm-backward passes."""
     x, weight, z, mean, invstd, gamma, yt, w2 = ctx.saved_tensors
     B, T_in, T_out, Cin, Cout, KW, dil, pad, pad_left, relu, bn, tanh, has_bias, has_rb = ctx.geom
     lib, hctx = N.lib(), N.ctx(x.device)
@@ -359,12 +361,21 @@ def _conv_block_bwd(ctx, dy, skip=None, fold=None, utt=None):
     dgamma = dbeta = None
     if bn or relu:
         if utt is not None and not (bn and z.dtype == torch.bfloat16 and has_bias and Cout % 4 == 0 and not tanh):
-            raise N.VpmiError('ConvBlock backward: a per-utterance affine on the output gradient needs the bf16 pre-BatchNorm form')
+            raise N.VpmiError('ConvBlock backward: a per-utterance term on the output gradient needs the bf16 pre-BatchNorm form')
         if bn:
-            if z.dtype == torch.bfloat16 and utt is not None:
+            if z.dtype == torch.bfloat16 and utt is not None and utt[0] == 'ctx':
+                # d y = dy + alpha[b] + beta[b] * y: a consumer's context-statistics gradient (MfaAspFn), y re-formed from z
+                _, al, be, Tu, bsc, bsh = utt
                 sums = torch.empty((2, Cout), dtype=torch.float32, device=dev)
                 ws = _bytes(lib.vp_col_sums_workspace_bytes(M, Cout), dev)
-                _chk(lib.vp_col_sums_f32_b16_utt(hctx, dy.data_ptr(), Cout, utt[0].data_ptr(), utt[1].data_ptr(), int(utt[2]), z.data_ptr(), Cout,
+                _chk(lib.vp_col_sums_f32_b16_ctx(hctx, dy.data_ptr(), Cout, al.data_ptr(), be.data_ptr(), int(Tu), bsc.data_ptr(), bsh.data_ptr(),
+                                                 z.data_ptr(), Cout, mean.data_ptr(), invstd.data_ptr(), M, Cout, sums.data_ptr(), ws.data_ptr(),
+                                                 ws.numel(), N.stream_ptr()), hctx)
+            elif z.dtype == torch.bfloat16 and utt is not None:
+                # d y = dy * s[b] + dm[b] / T: the SE block behind this conv (ConvSEFn)
+                sums = torch.empty((2, Cout), dtype=torch.float32, device=dev)
+                ws = _bytes(lib.vp_col_sums_workspace_bytes(M, Cout), dev)
+                _chk(lib.vp_col_sums_f32_b16_utt(hctx, dy.data_ptr(), Cout, utt[1].data_ptr(), utt[2].data_ptr(), int(utt[3]), z.data_ptr(), Cout,
                                                  mean.data_ptr(), invstd.data_ptr(), M, Cout, sums.data_ptr(), ws.data_ptr(), ws.numel(),
                                                  N.stream_ptr()), hctx)
             elif z.dtype == torch.bfloat16:
@@ -386,8 +397,14 @@ def _conv_block_bwd(ctx, dy, skip=None, fold=None, utt=None):
             ws = _bytes(lib.vp_bn_relu_bwd_dbias_workspace_bytes(M, Cout), dev)
             fn = (lib.vp_bn_relu_bwd_dbias_b16 if z.dtype == torch.bfloat16 else
                   lib.vp_bn_relu_bwd_dbias_bf16out if wide else lib.vp_bn_relu_bwd_dbias_f32)
-            if utt is not None:
-                _chk(lib.vp_bn_relu_bwd_dbias_b16_utt(hctx, dy.data_ptr(), Cout, utt[0].data_ptr(), utt[1].data_ptr(), int(utt[2]), z.data_ptr(),
+            if utt is not None and utt[0] == 'ctx':
+                _, al, be, Tu, bsc, bsh = utt
+                _chk(lib.vp_bn_relu_bwd_dbias_b16_ctx(hctx, dy.data_ptr(), Cout, al.data_ptr(), be.data_ptr(), int(Tu), bsc.data_ptr(), bsh.data_ptr(),
+                                                      z.data_ptr(), Cout, mu.data_ptr(), istd.data_ptr(), g.data_ptr() if g is not None else None,
+                                                      sums.data_ptr(), M, Cout, int(relu), dz.data_ptr(), Cout, dbias.data_ptr(),
+                                                      ws.data_ptr(), ws.numel(), N.stream_ptr()), hctx)
+            elif utt is not None:
+                _chk(lib.vp_bn_relu_bwd_dbias_b16_utt(hctx, dy.data_ptr(), Cout, utt[1].data_ptr(), utt[2].data_ptr(), int(utt[3]), z.data_ptr(),
                                                       Cout, mu.data_ptr(), istd.data_ptr(), g.data_ptr() if g is not None else None,
                                                       sums.data_ptr(), M, Cout, int(relu), dz.data_ptr(), Cout, dbias.data_ptr(),
                                                       ws.data_ptr(), ws.numel(), N.stream_ptr()), hctx)
@@ -954,7 +971,7 @@ class ConvSEFn(torch.autograd.Function):
         _chk(lib.vp_se_dense_train_bwd(hctx, ds.data_ptr(), mean.data_ptr(), a.data_ptr(), s.data_ptr(), w1.data_ptr(), w2.data_ptr(),
                                        B, Cc, H, amp, dm.data_ptr(), dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(),
                                        ws.data_ptr(), ws.numel(), N.stream_ptr()), hctx)
-        r = _conv_block_bwd(tp, dout, utt=(s, dm, T))
+        r = _conv_block_bwd(tp, dout, utt=('se', s, dm, T))
         return r[0], r[1], r[2], r[4], r[5], None, None, dout, dw1, db1, dw2, db2, None, None
 
 
@@ -1077,41 +1094,102 @@ class AspFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dp):
-        saved = ctx.saved_tensors
-        x, stats, e, pooled = saved[:4]
-        B, T, gc = ctx.geom
-        lib, hctx = N.lib(), N.ctx(x.device)
-        Cc = x.shape[1]
-        tapes, at = [], 4
-        for n, geom, zero_dbias, wide, wt16 in ctx.tape_meta:
-            tp = _Tape((True,) * 9)
-            tp.saved_tensors, tp.geom, tp.zero_dbias, tp.wide, tp.wt16 = saved[at:at + n], geom, zero_dbias, wide, wt16
-            tapes.append(tp)
-            at += n
-        t2, t1 = tapes[-1], tapes[-2]
-        de16 = _asp_de16(B, T, Cc)
-        de = torch.empty_like(e, dtype=torch.bfloat16 if de16 else torch.float32)
-        dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-        x16 = x.dtype == torch.bfloat16
-        if e.dtype == torch.bfloat16 and not de16:
-            raise N.VpmiError('AspFn: bf16 logits without a bf16 logit gradient (enable_amp changed between forward and backward?)')
-        if e.dtype == torch.bfloat16:
-            _chk(lib.vp_attn_stats_bwd_e16(hctx, e.data_ptr(), x.data_ptr(), N.VP_BF16 if x16 else N.VP_F32, Cc, pooled.data_ptr(),
-                                           _f32c(dp).data_ptr(), B, T, Cc, 1e-12, de.data_ptr(), dx.data_ptr(), Cc, N.stream_ptr()), hctx)
+        return _asp_backward(ctx, dp)[0]
+
+
+def _asp_backward(ctx, dp, defer_ctx=False):
+    """AspFn's backward.  defer_ctx: the context statistics' gradient is NOT added to d x here; it comes back as (stats, d stats) for the
+    caller to fold into the producing layer's BatchNorm backward (MfaAspFn).  -> (AspFn's gradient tuple, (stats, dstats) or None)"""
+    saved = ctx.saved_tensors
+    x, stats, e, pooled = saved[:4]
+    B, T, gc = ctx.geom
+    lib, hctx = N.lib(), N.ctx(x.device)
+    Cc = x.shape[1]
+    tapes, at = [], 4
+    for n, geom, zero_dbias, wide, wt16 in ctx.tape_meta:
+        tp = _Tape((True,) * 9)
+        tp.saved_tensors, tp.geom, tp.zero_dbias, tp.wide, tp.wt16 = saved[at:at + n], geom, zero_dbias, wide, wt16
+        tapes.append(tp)
+        at += n
+    t2, t1 = tapes[-1], tapes[-2]
+    de16 = _asp_de16(B, T, Cc)
+    de = torch.empty_like(e, dtype=torch.bfloat16 if de16 else torch.float32)
+    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    x16 = x.dtype == torch.bfloat16
+    if e.dtype == torch.bfloat16 and not de16:
+        raise N.VpmiError('AspFn: bf16 logits without a bf16 logit gradient (enable_amp changed between forward and backward?)')
+    if e.dtype == torch.bfloat16:
+        _chk(lib.vp_attn_stats_bwd_e16(hctx, e.data_ptr(), x.data_ptr(), N.VP_BF16 if x16 else N.VP_F32, Cc, pooled.data_ptr(),
+                                       _f32c(dp).data_ptr(), B, T, Cc, 1e-12, de.data_ptr(), dx.data_ptr(), Cc, N.stream_ptr()), hctx)
+    else:
+        fn = lib.vp_attn_stats_bwd_de16 if de16 else lib.vp_attn_stats_bwd_f32
+        _chk(fn(hctx, e.data_ptr(), x.data_ptr(), Cc, pooled.data_ptr(), _f32c(dp).data_ptr(), B, T, Cc, 1e-12, de.data_ptr(),
+                dx.data_ptr(), Cc, N.stream_ptr()), hctx)
+    dh, dw2, db2 = _conv_block_bwd(t2, de)[:3]
+    dx, dwx, dbias, drb, dgamma, dbeta = _conv_block_bwd(t1, dh, dx)[:6]        # dx: TDNN's + the weighted statistics'
+    dw = dwx
+    deferred = None
+    if gc:
+        dstats, dwc = _conv_block_bwd(tapes[0], drb)[:2]
+        if defer_ctx:
+            deferred = (stats, dstats)
         else:
-            fn = lib.vp_attn_stats_bwd_de16 if de16 else lib.vp_attn_stats_bwd_f32
-            _chk(fn(hctx, e.data_ptr(), x.data_ptr(), Cc, pooled.data_ptr(), _f32c(dp).data_ptr(), B, T, Cc, 1e-12, de.data_ptr(),
-                    dx.data_ptr(), Cc, N.stream_ptr()), hctx)
-        dh, dw2, db2 = _conv_block_bwd(t2, de)[:3]
-        dx, dwx, dbias, drb, dgamma, dbeta = _conv_block_bwd(t1, dh, dx)[:6]        # dx: TDNN's + the weighted statistics'
-        dw = dwx
-        if gc:
-            dstats, dwc = _conv_block_bwd(tapes[0], drb)[:2]
             fn = lib.vp_time_stats_bwd_add_x16 if x16 else lib.vp_time_stats_bwd_add_f32
             _chk(fn(hctx, x.data_ptr(), Cc, stats.data_ptr(), dstats.data_ptr(), B, T, Cc, 1e-12, 0,
                     dx.data_ptr(), Cc, dx.data_ptr(), Cc, N.stream_ptr()), hctx)
-            dw = torch.cat([dwx, dwc], dim=1)
-        return dx, dw, dbias, dgamma, dbeta, None, None, dw2, db2, None
+        dw = torch.cat([dwx, dwc], dim=1)
+    return (dx, dw, dbias, dgamma, dbeta, None, None, dw2, db2, None), deferred
+
+
+class MfaAspFn(torch.autograd.Function):
+    """ECAPA's MFA TDNNBlock over the concatenated block outputs and the AttentiveStatisticsPooling behind it (ecapa_tdnn.py:262-267,
+    pooling.py:86-125) as ONE tape entry, for the all-bf16 form of the mixed-precision step.  As two entries (CatConvBlock + AspFn) the
+    pooling layer's three gradient contributions to the MFA output y -- weighted statistics, attention TDNN, context statistics -- were
+    summed into one (B*T, 1536) f32 tensor by three passes; the third (read y, read + write the gradient: 1.17 GB at 256 x 298 frames)
+    exists only to add alpha[b, c] + beta[b, c] * y.  Here that term is handed to the MFA layer's two BatchNorm-backward passes, which
+    re-form y from the bf16 z they read anyway (_conv_block_bwd utt=('ctx', ...)).  VPMI_MFA_ASP_UNFUSED=1 keeps the two entries."""
+
+    @staticmethod
+    def forward(ctx, cfg, acfg, weight, bias, gamma, beta, run_mean, run_var, aw, abias, agamma, abeta, arm, arv, aw2, ab2, *xs):
+        widths = [t.shape[1] for t in xs]
+        xcat = cfg['xcat']
+        tpM, tpA = _Tape((True,) * 9), _Tape((True,) * 10)
+        y = ConvBlock.forward(tpM, xcat, weight, bias, None, gamma, beta, run_mean, run_var, cfg)
+        if cfg.get('_y16') is None or cfg.get('_tsums') is None:
+            raise N.VpmiError('MfaAspFn: the MFA conv did not take the all-bf16 form (bf16 output, fused time sums)')
+        y._vp_bf16, y._vp_bf16_only, y._vp_tsums = cfg['_y16'], True, cfg['_tsums']
+        scale, shift = cfg['_tsums'][2], cfg['_tsums'][3]
+        pooled = AspFn.forward(tpA, y, aw, abias, agamma, abeta, arm, arv, aw2, ab2, acfg)
+        nM, nA = len(tpM.saved_tensors), len(tpA.saved_tensors)
+        ctx.save_for_backward(*tpM.saved_tensors, *tpA.saved_tensors, scale, shift)
+        ctx.counts = (nM, nA)
+        ctx.metaM = (tpM.geom, tpM.wide, widths, getattr(tpM, 'wt16', None))
+        ctx.metaA = (tpA.tape_meta, tpA.geom)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dp):
+        saved = ctx.saved_tensors
+        nM, nA = ctx.counts
+        tpM, tpA = _Tape((True,) * 9), _Tape((True,) * 10)
+        tpM.saved_tensors, tpA.saved_tensors = saved[:nM], saved[nM:nM + nA]
+        scale, shift = saved[nM + nA:]
+        tpM.geom, tpM.wide, widths, tpM.wt16 = ctx.metaM
+        tpM.out_splits = widths
+        tpA.tape_meta, tpA.geom = ctx.metaA
+        (dx, dw, dbias, dgamma, dbeta, _, _, dw2, db2, _), deferred = _asp_backward(tpA, dp, defer_ctx=True)
+        utt = None
+        if deferred is not None:
+            stats, dstats = deferred
+            B, T = tpA.geom[0], tpA.geom[1]
+            Cc = stats.shape[1] // 2
+            lib, hctx = N.lib(), N.ctx(stats.device)
+            ab = torch.empty((2, B, Cc), dtype=torch.float32, device=stats.device)
+            _chk(lib.vp_time_stats_bwd_coeffs(hctx, stats.data_ptr(), dstats.data_ptr(), B, T, Cc, 1e-12, ab.data_ptr(), N.stream_ptr()), hctx)
+            utt = ('ctx', ab[0], ab[1], T, scale, shift)
+        r = _conv_block_bwd(tpM, dx, utt=utt)
+        dxs = r[0] if isinstance(r[0], tuple) else r[0].split(widths, dim=1)
+        return (None, None, r[1], r[2], r[4], r[5], None, None, dw, dbias, dgamma, dbeta, None, None, dw2, db2, *dxs)
 
 
 class BNRows(torch.autograd.Function):
