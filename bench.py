@@ -23,7 +23,7 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
   "roofline"     : the dominant kernel (conv_gemm128x256_ring_kernel, the LDS-DMA conv GEMM, bf16 in / bf16 out -- seven launches
                    per step, 87 % of the forward's flops): every shape replayed back to back between HIP events on the launching
                    stream, against the dense bf16 MFMA peak; "traffic" = HBM bytes per launch from the committed PMC passes
-                   (profiles/r04_pmc_infer.json, while the hash of csrc/conv_gemm256.hip matches); "family" adds the two other conv launches;
+                   (profiles/r05_pmc_infer.json, while the hash of csrc/conv_gemm256.hip matches); "family" adds the two other conv launches;
   "single_stream_ms" : the same step as one launch sequence; "clocks": rocm-smi before / after the timed region;
   "cpu_baseline" : the CPU oracle (reference algorithm restated on NumPy + PyTorch-CPU fp32 -- NOT the PaddlePaddle
                    binary) timed on this host's cores on a bounded sample;
@@ -65,7 +65,7 @@ def conv_family_shapes(T):
     return s
 
 
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r04_pmc_infer.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r05_pmc_infer.json')
 CPU_THREADS = 32
 GRAPH_PREREPLAYS = 40
 
@@ -97,7 +97,7 @@ def gpu_clocks(index=0):
         return None
 
 
-def roofline_pass(reps):
+def roofline_pass(reps, warm=20):
     """Replays the dominant kernel family shape by shape (same shapes, dtypes, epilogue options and buffer sizes as inside the
     step): `reps` back-to-back launches of a shape between HIP events on the launching stream."""
     from ppvector import _native as N
@@ -136,7 +136,7 @@ def roofline_pass(reps):
             d.act2 = N.VP_ACT_TANH
         # warm launches: enough sustained load (20 launches = 1-7 ms) that the timed launches behind them run in the GPU's loaded power
         # state -- with 2, the pass read 0.31-0.34 of peak where the same launches in steady state read 0.36 (same box, same session)
-        for _ in range(20):
+        for _ in range(warm):
             N.check(lib.vp_conv1d_fwd(ctx, C.byref(d), N.stream_ptr()), ctx)
         # `reps` back-to-back launches between ONE pair of events on the launching stream: the average launch duration as the
         # kernel trace reports it (an event pair per launch adds ~3 us of event processing to a 60 us kernel)
@@ -361,7 +361,7 @@ def build_ecapa(dev, dtype_name):
     return fz, model, head, state, head_w
 
 
-def make_infer_step(dev, dtype, streams, wav, labels, graph=True, parts=None):
+def make_infer_step(dev, dtype, streams, wav, labels, graph=True, parts=None, prereplays=None):
     """The timed step of --mode infer, built in ONE place (tests/test_gpu_timed_path.py checks exactly this object against the
     oracle): waveforms resident in HBM -> Fbank + CMN -> ECAPA forward -> cosine head -> AAM loss; `streams` concurrent launch
     sequences per GPU (each shard's featurizer + backbone on its own stream, head + loss over the whole batch behind the join),
@@ -403,10 +403,11 @@ def make_infer_step(dev, dtype, streams, wav, labels, graph=True, parts=None):
         # graph (~50 ms of load), so that the W untimed warm-up steps and the K timed ones start on a GPU that is already in its
         # loaded power state (measured, same box, same session: 20 timed steps after an idle gap and W = 5: 1.277 ms; after W = 50 or
         # inside a 200-step run: 1.236 ms).  Their count is reported on the JSON line ("graph_prereplays").
-        for _ in range(GRAPH_PREREPLAYS):
+        npre = GRAPH_PREREPLAYS if prereplays is None else int(prereplays)
+        for _ in range(npre):
             g.replay()
         torch.cuda.synchronize()
-        info['graph_prereplays'] = GRAPH_PREREPLAYS
+        info['graph_prereplays'] = npre
 
         def run():
             g.replay()
@@ -445,6 +446,17 @@ def run_infer(args, rank, local_rank, world, dist):
                                   parts=(info['fz'], info['model'], info['head'], info['state'], info['head_w']))
         dt1, _ = run_timed(run1, args.steps, args.warmup, None, dev)
         single_ms = round(dt1 / args.steps * 1e3, 4)
+    # the SAME two-sequence step under the protocol of rounds 1-3 (report both): a freshly captured graph with NO pre-replays,
+    # timed right behind an idle gap like the one the clock query used to leave -- W warm-up + K timed steps, nothing else
+    cold_ms = None
+    if args.graph and world == 1:
+        import time as _time
+        _time.sleep(0.6)
+        run0, info0 = make_infer_step(dev, args.dtype, args.streams, wav, labels, graph=True, prereplays=0,
+                                      parts=(info['fz'], info['model'], info['head'], info['state'], info['head_w']))
+        if info0['graph']:
+            dt0, _ = run_timed(run0, args.steps, args.warmup, None, dev)
+            cold_ms = round(dt0 / args.steps * 1e3, 4)
     out = {
         'metric': 'utterances/sec (3 s, 16 kHz) ECAPA-TDNN fwd+AAM', 'value': round(value, 1),
         'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -459,6 +471,7 @@ def run_infer(args, rank, local_rank, world, dist):
         'loss': round(loss_v, 5),
         'stage_roofline_frac': round(value / world * ALG_GFLOP_PER_UTT / 1e3 / PEAK_BF16_TFLOPS, 4),
         'single_stream_ms': single_ms,
+        'ms_per_step_without_prereplays': cold_ms,
         'clocks': {'before_step_build': clocks[0], 'after_timed_region': clocks[1]} if rank == 0 else None,
     }
     # the path that COMMUNICATES, measured in the same job: the data-parallel training step (global batch 256 split over the
@@ -510,7 +523,13 @@ def run_infer(args, rank, local_rank, world, dist):
             out['dp_train_f32'] = {k: dp_f32[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'loss', 'stage_roofline_frac', 'steps')
                                    if k in dp_f32}
     if world == 1 and not args.no_roofline and want16:
-        out['roofline'] = roofline_pass(reps=30)
+        # both protocols on one line: "cold" = rounds 1-3 (2 warm + 10 timed launches per shape, taken first), "loaded" = round 4
+        # (20 warm + 30 timed: the launches run in the GPU's loaded power state, as inside the step); `frac` stays the loaded number
+        cold = roofline_pass(reps=10, warm=2)
+        out['roofline'] = roofline_pass(reps=30, warm=20)
+        out['roofline']['frac_loaded'] = out['roofline']['frac']
+        out['roofline']['frac_cold'] = cold['frac']
+        out['roofline']['avg_launch_ms_cold'] = cold['avg_launch_ms']
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(state, head_w)
     print(json.dumps(out), flush=True)

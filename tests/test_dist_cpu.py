@@ -347,3 +347,20 @@ def test_pass_through_gradients_are_handed_on_without_a_copy():
         rec.backward(loss)
     for w, g in zip((w1, w2, w3), want):
         assert torch.allclose(w.grad, g, rtol=1e-5, atol=1e-6)
+
+
+def test_collective_schedule_of_the_named_configs():
+    """The fixed chunk list of the data-parallel step (train/step.py: reduce_chunks; the reference's fleet reducer, trainer.py:316-320) at the
+    gradient sizes of the BASELINE configs: ECAPA + 2 796 classes (6.73 M parameters, 26.9 MB): seven chunks; CAM++ + 7 205 classes
+    (8.2 M): eight; ERes2Net-large + the 200 000-class head (93.6 M + 38.4 M parameters, 528 MB of f32 gradients; 374 MB backbone alone):
+    fifteen / sixteen chunks and the chunk that has to wait for the LAST backward stage -- the only one no later stage can hide -- is at most
+    10 % of the buffer.  Chunks tile the buffer exactly, last parameters first, whatever the size."""
+    from ppvector.train.step import MAX_CHUNKS, MIN_CHUNK, reduce_chunks
+    for n, want in ((6_730_000, 7), (8_200_000, 8), (93_600_000, 15), (93_600_000 + 38_400_000, 16), (1, 1), (MIN_CHUNK, 1), (MIN_CHUNK + 1, 2)):
+        ch = reduce_chunks(n)
+        assert len(ch) == want <= MAX_CHUNKS, (n, len(ch))
+        assert ch[0][1] == n and ch[-1][0] == 0 and all(a[0] == b[1] for a, b in zip(ch, ch[1:]))
+        assert all(hi > lo for lo, hi in ch)
+    for n in (93_600_000, 93_600_000 + 38_400_000):
+        lo, hi = reduce_chunks(n)[-1]                       # parameters [0, ...): complete only after the first layers' backward
+        assert (hi - lo) / n <= 0.10, (n, (hi - lo) / n)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The round's measurement package on ONE box, PMC pass last (it is the slowest and nothing after it depends on it):
 #   bash tools/final_measure.sh <tag>     -> gpurun_out/{bench,kernel_stats_infer,kernel_stats_train,pmc,smoke}_<tag>.*
-TAG=${1:-r04}
+TAG=${1:-r05}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_$TAG.log 2>&1; echo "bench rc=$?"; tail -n 1 gpurun_out/bench_$TAG.log | cut -c1-400

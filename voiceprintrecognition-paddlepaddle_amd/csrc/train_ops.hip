@@ -537,7 +537,9 @@ __global__ __launch_bounds__(256) void col_sums_kernel(ColSumArgs p) {
 // instead of 256 B, and four rows' loads are issued before the first add.  Workgroup = CL column lanes x (256 / CL) row groups
 // over rows_per_chunk rows; CL = 64 / 32 / 16 by width so that 64-channel tensors (the Res2 convs) still fill the lanes.
 #ifndef VP_BNBWD_ROWS
-#define VP_BNBWD_ROWS 8             // rows in flight per thread of the BatchNorm-backward passes (tools/build_variant.sh u4 -DVP_BNBWD_ROWS=4: A/B)
+// rows in flight per thread of the BatchNorm-backward passes.  Round 5 A/B (tools/build_variant.sh u8 -DVP_BNBWD_ROWS=8, one box, one
+// session): 8 rows 8.043 ms per ECAPA B = 256 training step, 4 rows 8.011 ms -- the passes are not short of loads in flight; 4 it stays
+#define VP_BNBWD_ROWS 4
 #endif
 struct ColSum4Args { const float* a; const float* b; const float* bmean; const float* bscale; float* part; int lda, ldb, M, C4, rows_per_chunk, cl_shift;
                      const float* ms; const float* mh;      // optional: a counts only where b * ms + mh > 0 (a ReLU BEHIND the BatchNorm, resnet_se.py:72-74)
@@ -590,8 +592,7 @@ __global__ __launch_bounds__(256) void col_sums4_kernel(ColSum4Args p) {
         float xsc[4] = {0.f, 0.f, 0.f, 0.f}, xsh[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (UTT == 2) { vp_load4(p.xsc + c, xsc); vp_load4(p.xsh + c, xsh); }
         int m = m0 + rg;
-        // eight rows per trip, their loads issued together (round 5: four rows per trip left each thread ~9 dependent load round trips per
-        // chunk -- 3.7 TB/s on the (76 288, 512) tensors; the sums are taken in the same row order, bit-identical)
+        // VP_BNBWD_ROWS rows per trip, their loads issued together, summed in row order
         constexpr int U = UTT ? 4 : VP_BNBWD_ROWS;              // (the per-utterance operands cost the registers of four rows)
         for (; m + (U - 1) * RG < m1; m += U * RG) {
             float av[U][4], bv[U][4];
@@ -799,7 +800,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_dbias_kernel(BnBwdSumArgs p) 
             }
         };
         int m = m0 + rg;
-        constexpr int U = UTT ? 4 : VP_BNBWD_ROWS;               // (eight rows in flight per thread: see col_sums4_kernel)
+        constexpr int U = UTT ? 4 : VP_BNBWD_ROWS;               // (rows in flight per thread: see col_sums4_kernel)
         for (; m + (U - 1) * RG < m1; m += U * RG) {
             float dy[U][4], z[U][4], o[4];
 #pragma unroll

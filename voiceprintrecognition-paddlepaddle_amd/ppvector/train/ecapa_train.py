@@ -136,7 +136,7 @@ def ecapa_forward_train(m, feats):
     cfg = dict(B=B, T=T, dilation=m.mfa.conv.dilation, pad='reflect', relu=True, momentum=norm.momentum, eps=norm.eps, xcat=xcat,
                want_tsums=True, y_bf16=xcat is not None and bool(m.asp.global_context) and T <= 320 and B * T >= 16384
                and not os.environ.get('VPMI_MFA_F32_OUT'))
-    if cfg['y_bf16'] and not os.environ.get('VPMI_MFA_ASP_UNFUSED'):
+    if cfg['y_bf16'] and os.environ.get('VPMI_TRAIN_BF16_OPS', '2') == '2' and not os.environ.get('VPMI_MFA_ASP_UNFUSED'):
         # MFA + ASP as ONE tape entry: the pooling layer's context-statistics gradient is folded into the MFA layer's BatchNorm backward
         # instead of a pass of its own over the (B*T, 1536) tensors (functions.MfaAspFn)
         a = m.asp
