@@ -955,7 +955,9 @@ def test_col_sums_kernel_vs_float64(N, M, C, two):
 
 
 @pytest.mark.parametrize('M,Cout,Cin,ldx,xoff', [(4133, 512, 256, 256, 0), (9000, 256, 768, 1032, 264), (76288, 512, 512, 512, 0), (64, 256, 256, 256, 0),
-                                                  (2500, 1536, 1536, 1536, 0), (3000, 192, 512, 512, 0)])
+                                                  (2500, 1536, 1536, 1536, 0), (3000, 192, 512, 512, 0),
+                                                  # round 5: a 128-column side on the 256-tile kernel (ASP's attention TDNN and logits conv at 256 x 298 frames)
+                                                  (76288, 128, 1536, 1536, 0), (76288, 1536, 128, 128, 0), (76289, 128, 1536, 1800, 264)])
 def test_wgrad_of_bf16_operands_vs_float64(N, M, Cout, Cin, ldx, xoff):
     """vp_conv1d_wgrad_bf16_oik on the wide 1x1 layers: the 256-tile kernel on transposing LDS reads (csrc/wgrad_tr.hip; the last case has
     Cout % 256 != 0 and runs the 128-tile kernel).  bf16 products are exact in f32, so the only error is the f32 accumulation order:
@@ -1678,5 +1680,64 @@ def test_mfa_asp_as_one_tape_entry_stays_within_rounding_noise(N, amp, monkeypat
         d = rel(ga[k], gb[k])
         if d > worst:
             worst, wk = d, k
-    print(f'[MFA + ASP as one tape entry] loss {la:.6f} (identical); worst parameter-gradient rel-L2 against the two-entry form {worst:.2e} ({wk})')
-    assert worst < 1e-3, (worst, wk)
+    whole = rel(torch.cat([ga[k].reshape(-1) for k in ga]), torch.cat([gb[k].reshape(-1) for k in ga]))
+    tail = {k: rel(ga[k], gb[k]) for k in ga if k.startswith(('0.mfa.', '0.asp', '0.fc', '1.'))}      # first-order: the layers the term reaches directly
+    print(f'[MFA + ASP as one tape entry] loss {la:.6f} (identical); whole gradient rel-L2 against the two-entry form {whole:.2e}; MFA / ASP / '
+          f'head parameters worst {max(tail.values()):.2e}; worst tensor {worst:.2e} ({wk})')
+    # the term itself is exact to f32 rounding (test_context_statistics_gradient_folded_into_the_bn_backward_vs_float64); what is bounded here
+    # is how far that rounding travels: the MFA layer's own parameters see it first-order, the blocks upstream through bf16 roundings of dz
+    # and ReLU masks that flip with it (the Res2 chain amplifies a 1e-7 change of a statistic to 1e-2 on a 64-element bias: DESIGN.md 7c)
+    assert max(tail.values()) < 2e-4 and whole < 2e-3 and worst < 3e-2, (max(tail.values()), whole, worst, wk)
+
+
+@pytest.mark.parametrize('B,T,C', [(56, 298, 1536), (5, 40, 512), (3, 23, 64)])
+def test_context_statistics_gradient_folded_into_the_bn_backward_vs_float64(N, B, T, C):
+    """vp_time_stats_bwd_coeffs + vp_col_sums_f32_b16_ctx + vp_bn_relu_bwd_dbias_b16_ctx (the pooling layer's context-statistics gradient
+    alpha[b, c] + beta[b, c] * y added to d y inside the producing TDNNBlock's two BatchNorm-backward passes, y = bf16(z * scale + shift)
+    re-formed from z) against float64: the coefficients against d/dy of [mean_t y | sqrt(max(var_t y, eps))] (pooling.py:97-104), the
+    sums and d z against the formula over dy + that gradient."""
+    lib, ctx = N.lib(), N.ctx(0)
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    M = B * T
+    z = torch.randn(M, C, generator=g).to(torch.bfloat16)
+    dy = torch.randn(M, C, generator=g)
+    bsc, bsh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    mean, invstd = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    gam = torch.randn(C, generator=g)
+    dstats = torch.randn(B, 2 * C, generator=g)
+    y = (z.float() * bsc + bsh).to(torch.bfloat16).double().reshape(B, T, C)        # (one f32 multiply-add, rounded to bf16: as the apply pass stores it)
+    mu = y.mean(1)
+    var = ((y - mu[:, None]) ** 2).mean(1)
+    sd = var.clamp(min=1e-12).sqrt()
+    stats = torch.cat([mu, sd], dim=1).float()
+    be = torch.where(var > 1e-12, dstats[:, C:].double() / stats[:, C:].double() / T, torch.zeros_like(var))
+    al = dstats[:, :C].double() / T - be * stats[:, :C].double()
+    ab = torch.empty((2, B, C), device='cuda')
+    sc_, dc_ = stats.cuda(), dstats.cuda()
+    N.check(lib.vp_time_stats_bwd_coeffs(ctx, sc_.data_ptr(), dc_.data_ptr(), B, T, C, 1e-12, ab.data_ptr(), N.stream_ptr()), ctx)
+    assert rel(ab[0], al) < 1e-6 and rel(ab[1], be) < 1e-6
+    dye = dy.double().reshape(B, T, C) + al[:, None] + be[:, None] * y
+    dye = dye.reshape(M, C)
+    zh = (z.double() - mean.double()) * invstd.double()
+    wsum = torch.stack([dye.sum(0), (dye * zh).sum(0)])
+    zc, dyc, bscc, bshc, mc, ic, gc = z.cuda(), dy.cuda(), bsc.cuda(), bsh.cuda(), mean.cuda(), invstd.cuda(), gam.cuda()
+    sums = torch.empty((2, C), device='cuda')
+    ws = torch.empty(lib.vp_col_sums_workspace_bytes(M, C), dtype=torch.uint8, device='cuda')
+    N.check(lib.vp_col_sums_f32_b16_ctx(ctx, dyc.data_ptr(), C, ab[0].data_ptr(), ab[1].data_ptr(), T, bscc.data_ptr(), bshc.data_ptr(),
+                                        zc.data_ptr(), C, mc.data_ptr(), ic.data_ptr(), M, C, sums.data_ptr(), ws.data_ptr(), ws.numel(),
+                                        N.stream_ptr()), ctx)
+    torch.cuda.synchronize()
+    scale = dye.abs().sum(0).max().item()
+    assert (sums.double().cpu() - wsum).abs().max().item() <= 3e-6 * scale * (invstd.max().item() * 4), (sums.double().cpu() - wsum).abs().max().item()
+    want = gam.double() * invstd.double() * (dye - wsum[0] / M - zh * wsum[1] / M) * (z.double() > 0)
+    dz = torch.empty((M, C), dtype=torch.bfloat16, device='cuda')
+    db = torch.empty(C, device='cuda')
+    ws2 = torch.empty(lib.vp_bn_relu_bwd_dbias_workspace_bytes(M, C), dtype=torch.uint8, device='cuda')
+    N.check(lib.vp_bn_relu_bwd_dbias_b16_ctx(ctx, dyc.data_ptr(), C, ab[0].data_ptr(), ab[1].data_ptr(), T, bscc.data_ptr(), bshc.data_ptr(),
+                                             zc.data_ptr(), C, mc.data_ptr(), ic.data_ptr(), gc.data_ptr(), wsum.float().cuda().data_ptr(), M, C, 1,
+                                             dz.data_ptr(), C, db.data_ptr(), ws2.data_ptr(), ws2.numel(), N.stream_ptr()), ctx)
+    torch.cuda.synchronize()
+    assert rel(dz.float(), want) < 3e-3                           # bf16 storage of dz: 2^-9 per element
+    assert torch.equal(dz.cpu() == 0, (want == 0) | (dz.cpu() == 0)) and bool(((dz.cpu() == 0) | (z > 0)).all())
+    assert (db.double().cpu() - want.sum(0)).abs().max().item() <= 1e-5 * want.abs().sum(0).max().item()
+    print(f'[context-statistics gradient in the BN backward] B {B} T {T} C {C}: coeffs {rel(ab[0], al):.1e} / {rel(ab[1], be):.1e}, dz rel-L2 {rel(dz.float(), want):.1e}')

@@ -1435,7 +1435,7 @@ size_t vp_conv1d_wgrad_workspace_bytes(const vp_conv1d_desc* d) {
     if (S > 256) S = 256;
     if ((long long)S * 64 > M) S = (int)((M + 63) / 64);
     // the 256-tile kernel of the wide 1x1 layers (wgrad_tr.hip) splits the rows differently
-    if (d->KW == 1 && d->Cout % 256 == 0 && K % 256 == 0 && M >= 32) {
+    if (d->KW == 1 && (d->Cout % 256 == 0 || d->Cout == 128) && (K % 256 == 0 || K == 128) && M >= 32) {
         const int s2 = vp_wgrad_tr256_splits(M, d->Cout, K);
         if (s2 > S) S = s2;
     }

@@ -1,4 +1,4 @@
-// Weight gradient of the WIDE 1x1 layers (ECAPA tdnn1 / tdnn2: 512 x 512, MFA: 1536 x 1536) on bf16 operands:
+// Weight gradient of the WIDE 1x1 layers (ECAPA tdnn1 / tdnn2: 512 x 512, MFA: 1536 x 1536; round 5: ASP's 128 x 1536 and 1536 x 128) on bf16 operands:
 //     dW[n][c] = sum_m dz[m][n] * x[m][c]            (Conv1D backward of models/utils.py:65-93, batch-norm blocks of ecapa_tdnn.py)
 // The reduction index is the ROW of both operands, so both MFMA operands are "k-major" in memory.  conv_wgrad_amp_kernel (train_ops.hip)
 // transposes them through registers (bit surgery per element, 128 x 128 tiles: on the MFA layer every operand byte is fetched twelve
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_tr256_kernel(const WgradTrA
     const int nblk = gridDim.x, bid = blockIdx.x;
     const int qq = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
     const int swz = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-    const int tx = a.K / WT, ty = a.N / WT;
+    const int tx = (a.K + WT - 1) / WT, ty = (a.N + WT - 1) / WT;       // (N or K = 128: one half-used tile on that side, see the host)
     const int split = swz / (tx * ty), rem = swz - split * (tx * ty);
     const int nb = (rem / tx) * WT, cb = (rem % tx) * WT;
     const int m_begin = split * a.rows_per_split;
@@ -65,10 +65,14 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_tr256_kernel(const WgradTrA
     float* out = a.part + (size_t)split * a.N * a.K;
     if (rows <= 0) return;                                               // (the host sizes the splits so that none is empty)
     const unsigned lddzb = (unsigned)a.lddz * 2u, ldxb = (unsigned)a.ldx * 2u;
+    // A 128-column operand (ASP's attention TDNN: 128 outputs; its logits conv: 128 inputs) takes the same 256-wide tile: the descriptor
+    // ends with the operand's LAST valid element, so the missing columns of the last row read as zeros and those of every other row read
+    // the next row's first columns -- finite values that only reach accumulators the store below leaves out
+    const int ncn = min(WT, a.N - nb), ncc = min(WT, a.K - cb);
     const __amdgpu_buffer_rsrc_t dzr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_t*>(a.dz + (size_t)m_begin * a.lddz + nb), 0, (unsigned)(((size_t)(rows - 1) * a.lddz + WT) * 2), 0x00020000);
+        const_cast<bf16_t*>(a.dz + (size_t)m_begin * a.lddz + nb), 0, (unsigned)(((size_t)(rows - 1) * a.lddz + ncn) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_t*>(a.x + (size_t)m_begin * a.ldx + cb), 0, (unsigned)(((size_t)(rows - 1) * a.ldx + WT) * 2), 0x00020000);
+        const_cast<bf16_t*>(a.x + (size_t)m_begin * a.ldx + cb), 0, (unsigned)(((size_t)(rows - 1) * a.ldx + ncc) * 2), 0x00020000);
 
     // staging: a DMA instruction fills two LDS rows (64 lanes x 16 B); wave wv owns rows 4 wv .. 4 wv + 3 of both operands
     unsigned vdz[2], vx[2];
@@ -151,6 +155,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_tr256_kernel(const WgradTrA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the zero-fill DMAs of the stages past the end
 
     const int n0 = nb + wn * 64, c0 = cb + wc * 128;
+    if (n0 >= a.N || c0 >= a.K) return;                                 // (wave-uniform: the unused half of a 128-column side)
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_tr256_kernel(const WgradTrA
 
 // rows per split of the 256-tile kernel for an (N, K) layer over M rows: one workgroup per CU
 int vp_wgrad_tr256_splits(long long M, int N, int K) {
-    const int tiles = (N / WT) * (K / WT);
+    const int tiles = ((N + WT - 1) / WT) * ((K + WT - 1) / WT);
     int S = 256 / tiles;
     if (S < 1) S = 1;
     if ((long long)S * WT_KS > M) S = (int)((M + WT_KS - 1) / WT_KS);
@@ -175,7 +180,10 @@ int vp_wgrad_tr256_splits(long long M, int N, int K) {
 // part: [splits][N][K] f32.  VP_EUNSUP when the layer is not covered (the caller runs the 128-tile kernel).
 int vp_wgrad_tr256_bf16(vp_ctx* ctx, const void* x, int ldx, int xoff, const void* dz, int lddz, long long M, int N, int K, float* part,
                         int* splits_out, hipStream_t st) {
-    if (N <= 0 || K <= 0 || N % WT || K % WT || (ldx | xoff | lddz) % 8 || M < WT_KS) return VP_EUNSUP;
+    // sides: multiples of 256, or exactly 128 (a half-used tile: wave columns wn < 2 / wc < 1 hold the outputs, the rest is discarded --
+    // 64 x 128 per wave, so 128 is the one narrower width whose valid part is whole waves on either side)
+    const bool n_ok = N % WT == 0 || N == 128, k_ok = K % WT == 0 || K == 128;
+    if (N <= 0 || K <= 0 || !n_ok || !k_ok || (N == 128 && K == 128) || (ldx | xoff | lddz) % 8 || M < WT_KS) return VP_EUNSUP;
     // small problems: one workgroup per CU leaves each split a handful of stages and the partial sums cost more than the GEMM
     // (512 x 512 over 9536 rows: 37 us here against 28 us on the 128-tile kernel; 1536 x 1536 over the same rows: 78 against 101)
     if (2.0 * (double)M * N * K < 3e10) return VP_EUNSUP;
@@ -193,7 +201,7 @@ int vp_wgrad_tr256_bf16(vp_ctx* ctx, const void* x, int ldx, int xoff, const voi
     WgradTrArgs a;
     a.x = static_cast<const bf16_t*>(x) + xoff; a.dz = static_cast<const bf16_t*>(dz); a.part = part;
     a.ldx = ldx; a.lddz = lddz; a.M = (int)M; a.N = N; a.K = K; a.rows_per_split = (int)rps;
-    hipLaunchKernelGGL(conv_wgrad_tr256_kernel, dim3((K / WT) * (N / WT) * S), dim3(512), WT_SMEM, st, a);
+    hipLaunchKernelGGL(conv_wgrad_tr256_kernel, dim3(((K + WT - 1) / WT) * ((N + WT - 1) / WT) * S), dim3(512), WT_SMEM, st, a);
     VP_LAUNCH_CHECK(ctx, "conv_wgrad_tr256");
     *splits_out = S;
     return VP_OK;
