@@ -8,7 +8,7 @@ import os
 import torch
 
 import ppvector
-from ppvector.train.functions import BNRows, CatConvBlock, ConvBlock, ConvBlockSkip, ConvSEFn, MfaAspFn, Res2Fn, SEBlockFn, prep_weights_bf16
+from ppvector.train.functions import asp16_min_rows, BNRows, CatConvBlock, ConvBlock, ConvBlockSkip, ConvSEFn, MfaAspFn, Res2Fn, SEBlockFn, prep_weights_bf16
 from ppvector.train.segments import cut
 from ppvector.train.tdnn_train import asp_forward
 
@@ -134,7 +134,7 @@ def ecapa_forward_train(m, feats):
     # ASP's context statistics come from the MFA conv's fused sums; under enable_amp (bf16 operand path) the MFA output itself leaves
     # its BatchNorm pass as bf16 -- ASP is its only consumer and reads it as a GEMM operand and in three statistics passes
     cfg = dict(B=B, T=T, dilation=m.mfa.conv.dilation, pad='reflect', relu=True, momentum=norm.momentum, eps=norm.eps, xcat=xcat,
-               want_tsums=True, y_bf16=xcat is not None and bool(m.asp.global_context) and T <= 320 and B * T >= 16384
+               want_tsums=True, y_bf16=xcat is not None and bool(m.asp.global_context) and T <= 320 and B * T >= asp16_min_rows()
                and not os.environ.get('VPMI_MFA_F32_OUT'))
     if cfg['y_bf16'] and os.environ.get('VPMI_TRAIN_BF16_OPS', '2') == '2' and not os.environ.get('VPMI_MFA_ASP_UNFUSED'):
         # MFA + ASP as ONE tape entry: the pooling layer's context-statistics gradient is folded into the MFA layer's BatchNorm backward

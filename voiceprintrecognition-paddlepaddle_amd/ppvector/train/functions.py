@@ -1033,9 +1033,14 @@ class AttnStats(torch.autograd.Function):
         return de, dx, None, None
 
 
+def asp16_min_rows():
+    """Rows (B * T) from which the MFA output, ASP's logits and their gradients take the all-bf16 form (VPMI_ASP16_MIN_ROWS for A/B)."""
+    return int(os.environ.get('VPMI_ASP16_MIN_ROWS', '16384'))
+
+
 def _asp_de16(B, T, Cc):
     """enable_amp at scale: the statistics' backward writes d e as bf16 (the operand the logits conv's two backward GEMMs round it to)."""
-    return bool(ppvector.get_train_amp() and B * T >= 16384 and Cc % 4 == 0 and os.environ.get('VPMI_TRAIN_BF16_OPS', '2') != '0')
+    return bool(ppvector.get_train_amp() and B * T >= asp16_min_rows() and Cc % 4 == 0 and os.environ.get('VPMI_TRAIN_BF16_OPS', '2') != '0')
 
 
 class AspFn(torch.autograd.Function):
