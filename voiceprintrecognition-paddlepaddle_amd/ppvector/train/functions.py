@@ -1035,7 +1035,7 @@ class AttnStats(torch.autograd.Function):
 
 def asp16_min_rows():
     """Rows (B * T) from which the MFA output, ASP's logits and their gradients take the all-bf16 form (VPMI_ASP16_MIN_ROWS for A/B)."""
-    return int(os.environ.get('VPMI_ASP16_MIN_ROWS', '16384'))
+    return int(os.environ.get('VPMI_ASP16_MIN_ROWS', '4096'))
 
 
 def _asp_de16(B, T, Cc):
