@@ -186,12 +186,18 @@ __global__ __launch_bounds__(256) void se_scale_residual_z16_kernel(SeZArgs a) {
         const uint4 rr = *reinterpret_cast<const uint4*>(a.res + m * a.ldr + a.roff + c);
         const bf16_t* ze = reinterpret_cast<const bf16_t*>(&zr);
         const bf16_t* re = reinterpret_cast<const bf16_t*>(&rr);
-        const float* sp = a.s + (size_t)b * a.C + c;
+        float sp[8], sc[8], sh[8];                            // (C % 8 == 0 and 16-byte aligned vectors: host-checked)
+        *reinterpret_cast<float4*>(sp) = *reinterpret_cast<const float4*>(a.s + (size_t)b * a.C + c);
+        *reinterpret_cast<float4*>(sp + 4) = *reinterpret_cast<const float4*>(a.s + (size_t)b * a.C + c + 4);
+        *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(a.bsc + c);
+        *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(a.bsc + c + 4);
+        *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(a.bsh + c);
+        *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(a.bsh + c + 4);
         uint4 o;
         bf16_t* oe = reinterpret_cast<bf16_t*>(&o);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float h = (float)(bf16_t)__fmaf_rn((float)ze[e], a.bsc[c + e], a.bsh[c + e]);
+            const float h = (float)(bf16_t)__fmaf_rn((float)ze[e], sc[e], sh[e]);
             oe[e] = (bf16_t)__fmaf_rn(h, sp[e], (float)re[e]);
         }
         *reinterpret_cast<uint4*>(a.out + m * a.ldo + a.ooff + c) = o;
@@ -769,7 +775,8 @@ int vp_se_scale_residual_z16(vp_ctx* ctx, const void* z, int ldz, const float* b
                              int ldr, int roff, void* out, int ldo, int ooff, int B, int T, int C, vp_stream stream) {
     if (!ctx || !z || !bn_scale || !bn_shift || !s || !res || !out || B <= 0 || T <= 0 || C <= 0) VP_FAIL(ctx, VP_EINVAL, "se_z16: bad arguments");
     if (C % 8 || ldz % 8 || ldr % 8 || roff % 8 || ldo % 8 || ooff % 8 ||
-        ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(out)) & 15))
+        ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(s) |
+          reinterpret_cast<uintptr_t>(bn_scale) | reinterpret_cast<uintptr_t>(bn_shift)) & 15))
         VP_FAIL(ctx, VP_EINVAL, "se_z16: C / ld / offsets must be multiples of 8, tensors 16-byte aligned");
     const long long total = (long long)B * T * (C / 8);
     long long blocks = (total + 255) / 256;
