@@ -186,7 +186,9 @@ int vp_wgrad_tr256_bf16(vp_ctx* ctx, const void* x, int ldx, int xoff, const voi
     if (N <= 0 || K <= 0 || !n_ok || !k_ok || (N == 128 && K == 128) || (ldx | xoff | lddz) % 8 || M < WT_KS) return VP_EUNSUP;
     // small problems: one workgroup per CU leaves each split a handful of stages and the partial sums cost more than the GEMM
     // (512 x 512 over 9536 rows: 37 us here against 28 us on the 128-tile kernel; 1536 x 1536 over the same rows: 78 against 101)
-    if (2.0 * (double)M * N * K < 3e10) return VP_EUNSUP;
+    // (a 128-column side executes a 256-wide tile: counted as such -- ASP's 128 x 1536 over 76 288 rows is 2.9998e10 flop as stated)
+    const int Ne = N < WT ? WT : N, Ke = K < WT ? WT : K;
+    if (2.0 * (double)M * Ne * Ke < 3e10) return VP_EUNSUP;
     if (((uintptr_t)x | (uintptr_t)dz) & 15) return VP_EUNSUP;
     const int S = vp_wgrad_tr256_splits(M, N, K);
     long long rps = (M + S - 1) / S;
