@@ -412,10 +412,13 @@ def ctx(device=None):
             _ctx[device] = h
             # the grid-barrier words of the fused training kernels live in a tensor of OURS (csrc/api.hip: vp_set_grid_barrier_words): the
             # data-parallel step all-reduces the bail-out flag with the gradients and polls it with an asynchronous copy (train/step.py)
-            words = torch.zeros(GRID_WORDS, dtype=torch.int32, device=torch.device('cuda', device))
-            torch.cuda.synchronize(device)
-            if library.vp_set_grid_barrier_words(h, words.data_ptr()) == 0:
-                _grid_words[device] = words
+            # (never under a stream capture: an allocation + synchronise there would break it; the context then keeps its own words, which
+            # work the same on one rank -- only the collective drop across ranks needs the tensor)
+            if not torch.cuda.is_current_stream_capturing():
+                words = torch.zeros(GRID_WORDS, dtype=torch.int32, device=torch.device('cuda', device))
+                torch.cuda.synchronize(device)
+                if library.vp_set_grid_barrier_words(h, words.data_ptr()) == 0:
+                    _grid_words[device] = words
     return _ctx[device]
 
 
