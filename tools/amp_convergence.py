@@ -113,9 +113,11 @@ def build_dataset(root, n_spk=64, train_files=8, seconds=4.0, steps_per_epoch=30
 
 
 def configs(root, n_spk, batch, max_epoch, enable_amp, model='EcapaTdnn'):
-    margs = dict(embd_dim=192, pooling_type='ASP')
-    if model == 'EcapaTdnn':
-        margs['channels'] = [512, 512, 512, 512, 1536]
+    # model_args of the reference's shipped YAMLs (configs/{ecapa_tdnn,tdnn,cam++,resnet_se,eres2net}.yml)
+    margs = {'EcapaTdnn': dict(embd_dim=192, pooling_type='ASP', channels=[512, 512, 512, 512, 1536]),
+             'TDNN': dict(embd_dim=192, channels=512, pooling_type='ASP'), 'CAMPPlus': dict(embd_dim=192),
+             'ResNetSE': dict(embd_dim=192, pooling_type='ASP'), 'ERes2Net': dict(embd_dim=192, m_channels=32),
+             'ERes2NetV2': dict(embd_dim=192, m_channels=32)}[model]
     return dict(
         dataset_conf=dict(dataset=dict(min_duration=0.3, max_duration=3, sample_rate=SR, use_dB_normalization=True, target_dB=-20),
                           sampler=dict(batch_size=batch, shuffle=True, drop_last=True), dataLoader=dict(num_workers=8),
