@@ -1,0 +1,125 @@
+"""Training DYNAMICS of the engine against the oracle graph on the same GPU: is what a multi-hundred-step run does a property of the
+configuration, or of our kernels?
+
+tools/amp_convergence.py found CAM++ collapsing when the AAM margin ramps (both in f32 and under enable_amp, batch 64, lr 1e-3) while the
+other four backbones train.  Per-step gradients of every backbone match float64 autograd over the oracle graphs (tests/test_gpu_train.py),
+but a slow drift would not show there.  Here the SAME run is made twice from the same initial weights on the same feature batches with
+the same LR and margin schedules (the reference's: warm-up + cosine, scheduler.py:6-40; exp margin ramp between 0.3 and 0.7 of the epochs,
+scheduler.py:79-99):
+    engine : this package's train-mode forward / backward (f32 engine) + vp_adam_step_f32
+    oracle : oracle/*.py graph (the restatement of ppvector/models/*.py pinned on the reference's own files) moved to the GPU, torch
+             autograd, torch.optim.Adam (coupled L2 weight decay = paddle's Adam(weight_decay=float)), f32, TF32-free
+and the two loss / accuracy curves are printed side by side.   python tools/train_dynamics_ab.py [CAMPPlus|EcapaTdnn|TDNN] [steps] [batch]"""
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'voiceprintrecognition-paddlepaddle_amd'), os.path.join(ROOT, 'tools')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import amp_convergence as ac  # noqa: E402
+from oracle import campplus as oc  # noqa: E402
+from oracle import models as om  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else 'CAMPPlus'
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 320
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+n_spk, epochs = 64, 10
+spe = steps // epochs
+torch.backends.cuda.matmul.allow_tf32 = False
+torch.backends.cudnn.allow_tf32 = False
+
+from ppvector.data_utils.featurizer import AudioFeaturizer  # noqa: E402
+from ppvector.loss.aamloss import AAMLoss  # noqa: E402
+from ppvector.models.campplus import CAMPPlus  # noqa: E402
+from ppvector.models.ecapa_tdnn import EcapaTdnn  # noqa: E402
+from ppvector.models.fc import SpeakerIdentification  # noqa: E402
+from ppvector.models.tdnn import TDNN  # noqa: E402
+from ppvector.optimizer.adam import Adam  # noqa: E402
+from ppvector.train.step import TrainStep  # noqa: E402
+
+# ---- the same feature batches for both sides: synthetic speakers -> the engine's Fbank, a pool of 24 batches cycled
+table = ac.speaker_table(n_spk, 1000)
+fz = AudioFeaturizer('Fbank', dict(sr=16000, n_mels=80))
+rng = np.random.RandomState(5)
+pool = []
+for i in range(24):
+    lab = rng.randint(0, n_spk, B)
+    wav = np.stack([ac.synth_utterance(table, int(s), 48000, np.random.RandomState(100000 + i * 1000 + k)) for k, s in enumerate(lab)]).astype(np.float32)
+    with torch.no_grad():
+        pool.append((fz(torch.from_numpy(wav).cuda()).contiguous(), torch.from_numpy(lab).cuda()))
+print(f'# {name}: {steps} steps of {B} (24 fixed batches cycled), {n_spk} synthetic speakers, Adam 1e-3 warm-up {spe} steps -> cosine 1e-5, wd 1e-6, '
+      f'AAM scale 32, margin 0 -> 0.3 (exp ramp between steps {int(epochs * 0.3) * spe} and {int(epochs * 0.7) * spe})', flush=True)
+
+
+def lr_at(i):
+    if i < spe:
+        return 1e-3 * (i + 1) / spe
+    t = (i - spe) / max(1, steps - spe)
+    return 1e-5 + 0.5 * (1e-3 - 1e-5) * (1.0 + math.cos(math.pi * t))
+
+
+def margin_at(i):
+    return om.margin_schedule(i, spe, epochs, 0.0, 0.3)
+
+
+def make():
+    torch.manual_seed(7)
+    if name == 'CAMPPlus':
+        m = CAMPPlus(80, embd_dim=192)
+    elif name == 'TDNN':
+        m = TDNN(80)
+    else:
+        m = EcapaTdnn(80)
+    head = SpeakerIdentification(192, n_spk)
+    return torch.nn.Sequential(m, head).cuda()
+
+
+# ---- engine
+model = make()
+init = {k: v.detach().clone() for k, v in model.state_dict().items()}
+cur = {'i': 0}
+crit = AAMLoss(margin=0.0, scale=32)
+opt = Adam(model.parameters(), learning_rate=lambda: lr_at(cur['i']), weight_decay=1e-6)
+step = TrainStep(model, crit, opt, overlap_allreduce=False)
+eng = []
+for i in range(steps):
+    cur['i'] = i
+    crit.update(margin=margin_at(i))
+    x, y = pool[i % len(pool)]
+    loss, acc = step(x, y)
+    eng.append((float(loss), float(acc)))
+torch.cuda.synchronize()
+
+# ---- oracle graph, torch autograd + torch Adam, from the same initial weights
+fwd = {'CAMPPlus': oc.campplus_forward, 'TDNN': om.tdnn_forward, 'EcapaTdnn': om.ecapa_forward}[name]
+p = {k[2:]: v.detach().clone().requires_grad_(v.is_floating_point() and not k.endswith(('_mean', '_variance'))) for k, v in init.items() if k.startswith('0.')}
+W = init['1.weight'].detach().clone().requires_grad_(True)
+params = [v for v in p.values() if v.requires_grad] + [W]
+topt = torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-6)
+orc = []
+for i in range(steps):
+    for gparam in topt.param_groups:
+        gparam['lr'] = lr_at(i)
+    x, y = pool[i % len(pool)]
+    emb = fwd(p, x, training=True)
+    logits = om.cosine_head(emb, W)
+    loss = om.aam_loss(logits, y, margin_at(i), 32.0)
+    topt.zero_grad(set_to_none=True)
+    loss.backward()
+    topt.step()
+    orc.append((float(loss), float((logits.argmax(1) == y).float().mean())))
+torch.cuda.synchronize()
+
+print('step   margin      lr    engine_loss engine_acc   oracle_loss oracle_acc   (means over 10 steps)')
+for s in range(0, steps, 10):
+    e = np.mean(eng[s:s + 10], axis=0)
+    o = np.mean(orc[s:s + 10], axis=0)
+    print(f'{s:4d}  {margin_at(s):7.4f} {lr_at(s):8.2e}   {e[0]:10.5f} {e[1]:9.4f}   {o[0]:10.5f} {o[1]:9.4f}')
+k = max(1, steps // 5)
+print(f'## tail (last {k} steps): engine loss {np.mean([v[0] for v in eng[-k:]]):.5f} acc {np.mean([v[1] for v in eng[-k:]]):.4f}; '
+      f'oracle loss {np.mean([v[0] for v in orc[-k:]]):.5f} acc {np.mean([v[1] for v in orc[-k:]]):.4f}')
