@@ -79,6 +79,25 @@ def make():
     return torch.nn.Sequential(m, head).cuda()
 
 
+CHECK = (int(os.environ['VP_DYN_CHECK'].split(',')[0]), int(os.environ['VP_DYN_CHECK'].split(',')[1])) if os.environ.get('VP_DYN_CHECK') else None
+fwd = {'CAMPPlus': oc.campplus_forward, 'TDNN': om.tdnn_forward, 'EcapaTdnn': om.ecapa_forward}[name]
+
+
+def oracle_grads(model, x, y, margin):
+    """Loss and parameter gradients of torch autograd over the oracle graph AT THE MODEL'S CURRENT WEIGHTS (float64 on request)."""
+    dt = torch.float64 if os.environ.get('VP_DYN_F64') else torch.float32
+    sd = model.state_dict()
+    p = {k[2:]: v.detach().to(dt).clone().requires_grad_(v.is_floating_point() and not k.endswith(('_mean', '_variance'))) for k, v in sd.items()
+         if k.startswith('0.')}
+    W = sd['1.weight'].detach().to(dt).clone().requires_grad_(True)
+    emb = fwd(p, x.to(dt), training=True)
+    loss = om.aam_loss(om.cosine_head(emb, W), y, margin, 32.0)
+    loss.backward()
+    g = {'0.' + k: v.grad for k, v in p.items() if v.requires_grad}
+    g['1.weight'] = W.grad
+    return float(loss), g
+
+
 # ---- engine
 model = make()
 init = {k: v.detach().clone() for k, v in model.state_dict().items()}
@@ -91,12 +110,35 @@ for i in range(steps):
     cur['i'] = i
     crit.update(margin=margin_at(i))
     x, y = pool[i % len(pool)]
+    if CHECK is not None and CHECK[0] <= i < CHECK[1]:
+        # this step by hand, with the engine's gradients compared against autograd over the oracle graph at the same weights
+        model.train()
+        out = model(x)
+        l_e = crit(out, y)
+        l_e.backward()
+        opt.pack_grads()
+        l_o, go = oracle_grads(model, x, y, margin_at(i))
+        worst, wk, bad = 0.0, None, []
+        for k, prm in model.named_parameters():
+            ge = prm.grad if prm.grad is not None else torch.zeros_like(prm)
+            gr = go[k].to(torch.float32)
+            if not bool(torch.isfinite(ge).all()):
+                bad.append(k)
+            d = ((ge.double() - gr.double()).norm() / gr.double().norm().clamp(min=1e-30)).item()
+            if d > worst:
+                worst, wk = d, k
+        gn = opt.grad.norm().item()
+        print(f'[check] step {i}: loss engine {float(l_e):.6f} oracle {l_o:.6f}  |grad| {gn:.4e}  worst parameter-gradient rel-L2 {worst:.3e} ({wk})'
+              + (f'  NON-FINITE engine gradients: {bad[:4]}' if bad else ''), flush=True)
+        opt.step()
+        opt.clear_grad()
+        eng.append((float(l_e), 0.0))
+        continue
     loss, acc = step(x, y)
     eng.append((float(loss), float(acc)))
 torch.cuda.synchronize()
 
 # ---- oracle graph, torch autograd + torch Adam, from the same initial weights
-fwd = {'CAMPPlus': oc.campplus_forward, 'TDNN': om.tdnn_forward, 'EcapaTdnn': om.ecapa_forward}[name]
 p = {k[2:]: v.detach().clone().requires_grad_(v.is_floating_point() and not k.endswith(('_mean', '_variance'))) for k, v in init.items() if k.startswith('0.')}
 W = init['1.weight'].detach().clone().requires_grad_(True)
 params = [v for v in p.values() if v.requires_grad] + [W]
