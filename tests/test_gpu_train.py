@@ -1742,3 +1742,30 @@ def test_context_statistics_gradient_folded_into_the_bn_backward_vs_float64(N, B
     assert torch.equal(dz.cpu() == 0, (want == 0) | (dz.cpu() == 0)) and bool(((dz.cpu() == 0) | (z > 0)).all())
     assert (db.double().cpu() - want.sum(0)).abs().max().item() <= 1e-5 * want.abs().sum(0).max().item()
     print(f'[context-statistics gradient in the BN backward] B {B} T {T} C {C}: coeffs {rel(ab[0], al):.1e} / {rel(ab[1], be):.1e}, dz rel-L2 {rel(dz.float(), want):.1e}')
+
+
+def test_statistics_pooling_backward_of_a_constant_channel_is_finite(N):
+    """CAM++'s statistics pooling (campplus.py:24-30: [mean_t x | std_t x], unbiased, NO epsilon) over a ReLU output: a channel that is zero
+    over all frames of an utterance has std = 0 and d sqrt(var) / d x is 0 / 0 there.  Round 5 found this NaN reaching Adam ~200 steps into
+    a CAM++ training run (f32 and enable_amp alike; tools/train_dynamics_ab.py, profiles/r05_campplus_dynamics.log) while the oracle graph
+    trained on: torch.std masks the singular point.  The kernel now returns that limit -- no contribution from the std -- and equals float64
+    autograd of torch.std everywhere."""
+    from ppvector.train.functions import TimeStats
+    g = torch.Generator().manual_seed(17)
+    B, T, C = 3, 37, 64
+    x = torch.relu(torch.randn(B, T, C, generator=g))
+    x[1, :, 5] = 0.0                      # dead for the whole utterance
+    x[2, :, 9] = 1.25                     # constant, non-zero
+    x[0, :, :4] = 0.0
+    xd = x.double().clone().requires_grad_(True)
+    want = torch.cat([xd.mean(1), xd.std(1, unbiased=True)], dim=-1)
+    gs = torch.randn(B, 2 * C, generator=g)
+    want.backward(gs.double())
+    xc = x.reshape(B * T, C).cuda().requires_grad_(True)
+    got = TimeStats.apply(xc, B, T, True, 0.0)
+    got.backward(gs.cuda())
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(xc.grad).all())
+    assert rel(got, want.detach()) < 1e-6
+    assert rel(xc.grad.reshape(B, T, C), xd.grad) < 1e-5
+    assert torch.equal(xc.grad.reshape(B, T, C)[1, :, 5].cpu(), (gs[1, 5] / T).expand(T).float())      # only the mean's share reaches a dead channel

@@ -928,7 +928,11 @@ __global__ __launch_bounds__(256) void time_stats_bwd_kernel(TsBwdArgs a) {
         vp_load4(a.dstats + b * 2 * C + c, dm); vp_load4(a.dstats + b * 2 * C + C + c, ds);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            o[e] = a.unbiased ? dm[e] * invT + ds[e] / sd[e] * (x[e] - mu[e]) / (float)(a.T > 1 ? a.T - 1 : 1)      // sd = sqrt(var_unbiased + eps)
+            // sd = sqrt(var_unbiased + eps).  eps = 0 (CAM++'s statistics pooling, campplus.py:24-30) and a channel that is constant over an
+            // utterance's frames (a ReLU output that is zero throughout) give sd = 0: the term is 0 / 0.  Its limit -- and what autograd
+            // frameworks return for d sqrt(var) at var = 0 (torch masks it; round 5: this NaN reached Adam ~200 steps into a CAM++ run and
+            // killed the model, tools/train_dynamics_ab.py) -- is no contribution from the std
+            o[e] = a.unbiased ? dm[e] * invT + (sd[e] > 0.f ? ds[e] / sd[e] * (x[e] - mu[e]) / (float)(a.T > 1 ? a.T - 1 : 1) : 0.f)
                               : dm[e] * invT + ((sd[e] * sd[e] > a.eps) ? ds[e] / sd[e] * (x[e] - mu[e]) * invT : 0.f);
         if (a.add) {
             float ad[4];
