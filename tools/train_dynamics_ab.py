@@ -23,7 +23,9 @@ import torch  # noqa: E402
 
 import amp_convergence as ac  # noqa: E402
 from oracle import campplus as oc  # noqa: E402
+from oracle import eres2net as oer  # noqa: E402
 from oracle import models as om  # noqa: E402
+from oracle import resnet_se as orse  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else 'CAMPPlus'
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 320
@@ -37,6 +39,8 @@ from ppvector.data_utils.featurizer import AudioFeaturizer  # noqa: E402
 from ppvector.loss.aamloss import AAMLoss  # noqa: E402
 from ppvector.models.campplus import CAMPPlus  # noqa: E402
 from ppvector.models.ecapa_tdnn import EcapaTdnn  # noqa: E402
+from ppvector.models.eres2net import ERes2Net  # noqa: E402
+from ppvector.models.resnet_se import ResNetSE  # noqa: E402
 from ppvector.models.fc import SpeakerIdentification  # noqa: E402
 from ppvector.models.tdnn import TDNN  # noqa: E402
 from ppvector.optimizer.adam import Adam  # noqa: E402
@@ -69,18 +73,15 @@ def margin_at(i):
 
 def make():
     torch.manual_seed(7)
-    if name == 'CAMPPlus':
-        m = CAMPPlus(80, embd_dim=192)
-    elif name == 'TDNN':
-        m = TDNN(80)
-    else:
-        m = EcapaTdnn(80)
+    m = {'CAMPPlus': lambda: CAMPPlus(80, embd_dim=192), 'TDNN': lambda: TDNN(80), 'EcapaTdnn': lambda: EcapaTdnn(80),
+         'ResNetSE': lambda: ResNetSE(80, embd_dim=192), 'ERes2Net': lambda: ERes2Net(80, embd_dim=192, m_channels=32)}[name]()
     head = SpeakerIdentification(192, n_spk)
     return torch.nn.Sequential(m, head).cuda()
 
 
 CHECK = (int(os.environ['VP_DYN_CHECK'].split(',')[0]), int(os.environ['VP_DYN_CHECK'].split(',')[1])) if os.environ.get('VP_DYN_CHECK') else None
-fwd = {'CAMPPlus': oc.campplus_forward, 'TDNN': om.tdnn_forward, 'EcapaTdnn': om.ecapa_forward}[name]
+fwd = {'CAMPPlus': oc.campplus_forward, 'TDNN': om.tdnn_forward, 'EcapaTdnn': om.ecapa_forward, 'ResNetSE': orse.resnetse_forward,
+       'ERes2Net': oer.eres2net_forward}[name]
 
 
 def oracle_grads(model, x, y, margin):
@@ -118,18 +119,24 @@ for i in range(steps):
         l_e.backward()
         opt.pack_grads()
         l_o, go = oracle_grads(model, x, y, margin_at(i))
-        worst, wk, bad = 0.0, None, []
+        worst, wk, bad, num, den = 0.0, None, [], 0.0, 0.0
+        tot = math.sqrt(sum(float(v.double().pow(2).sum()) for v in go.values()))
         for k, prm in model.named_parameters():
             ge = prm.grad if prm.grad is not None else torch.zeros_like(prm)
             gr = go[k].to(torch.float32)
             if not bool(torch.isfinite(ge).all()):
                 bad.append(k)
-            d = ((ge.double() - gr.double()).norm() / gr.double().norm().clamp(min=1e-30)).item()
-            if d > worst:
-                worst, wk = d, k
+            dd = float((ge.double() - gr.double()).pow(2).sum())
+            nn_ = float(gr.double().pow(2).sum())
+            num += dd
+            den += nn_
+            # (a bias in front of a BatchNorm has an exactly-zero gradient: both sides hold rounding noise there -- only tensors that carry a
+            # visible share of the gradient are ranked)
+            if math.sqrt(nn_) > 1e-3 * tot and math.sqrt(dd / max(nn_, 1e-300)) > worst:
+                worst, wk = math.sqrt(dd / max(nn_, 1e-300)), k
         gn = opt.grad.norm().item()
-        print(f'[check] step {i}: loss engine {float(l_e):.6f} oracle {l_o:.6f}  |grad| {gn:.4e}  worst parameter-gradient rel-L2 {worst:.3e} ({wk})'
-              + (f'  NON-FINITE engine gradients: {bad[:4]}' if bad else ''), flush=True)
+        print(f'[check] step {i}: loss engine {float(l_e):.6f} oracle {l_o:.6f}  |grad| {gn:.4e}  whole-gradient rel-L2 {math.sqrt(num / max(den, 1e-300)):.3e}  '
+              f'worst tensor {worst:.3e} ({wk})' + (f'  NON-FINITE engine gradients: {bad[:4]}' if bad else ''), flush=True)
         opt.step()
         opt.clear_grad()
         eng.append((float(l_e), 0.0))
