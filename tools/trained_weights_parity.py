@@ -38,55 +38,11 @@ from ppvector.models.tdnn import TDNN  # noqa: E402
 from ppvector.optimizer.adam import Adam  # noqa: E402
 from ppvector.train.step import TrainStep  # noqa: E402
 
-name = sys.argv[1] if len(sys.argv) > 1 else 'EcapaTdnn'
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 240
-B = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 n_spk, epochs = 64, 10
-spe = max(1, steps // epochs)
-table = ac.speaker_table(n_spk, 1000)
-fz = AudioFeaturizer('Fbank', dict(sr=16000, n_mels=80))
-
-
-def batch(seed, n):
-    rng = np.random.RandomState(seed)
-    lab = rng.randint(0, n_spk, n)
-    wav = np.stack([ac.synth_utterance(table, int(s), 48000, np.random.RandomState(seed * 1000 + k)) for k, s in enumerate(lab)]).astype(np.float32)
-    with torch.no_grad():
-        return fz(torch.from_numpy(wav).cuda()).contiguous(), torch.from_numpy(lab).cuda()
-
-
-pool = [batch(200 + i, B) for i in range(16)]
-torch.manual_seed(7)
-m = {'CAMPPlus': lambda: CAMPPlus(80, embd_dim=192), 'TDNN': lambda: TDNN(80), 'EcapaTdnn': lambda: EcapaTdnn(80),
-     'ResNetSE': lambda: ResNetSE(80, embd_dim=192), 'ERes2Net': lambda: ERes2Net(80, embd_dim=192, m_channels=32)}[name]()
-model = torch.nn.Sequential(m, SpeakerIdentification(192, n_spk)).cuda()
-ppvector.set_train_amp(True)
-cur = {'i': 0}
-
-
-def lr_at(i):
-    if i < spe:
-        return 1e-3 * (i + 1) / spe
-    return 1e-5 + 0.5 * (1e-3 - 1e-5) * (1.0 + math.cos(math.pi * (i - spe) / max(1, steps - spe)))
-
-
-crit = AAMLoss(margin=0.0, scale=32)
-opt = Adam(model.parameters(), learning_rate=lambda: lr_at(cur['i']), weight_decay=1e-6)
-step = TrainStep(model, crit, opt, overlap_allreduce=False)
-for i in range(steps):
-    cur['i'] = i
-    crit.update(margin=om.margin_schedule(i, spe, epochs, 0.0, 0.3))
-    loss, acc = step(*pool[i % len(pool)])
-torch.cuda.synchronize()
-print(f'# {name}: trained {steps} steps of {B} under enable_amp: last loss {float(loss):.4f}, accuracy {float(acc):.3f}')
-
-feats, lab = batch(999, 96)
-m.eval()
-sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
-fwd = {'CAMPPlus': oc.campplus_forward, 'TDNN': om.tdnn_forward, 'EcapaTdnn': om.ecapa_forward, 'ResNetSE': orse.resnetse_forward,
-       'ERes2Net': oer.eres2net_forward}[name]
-with torch.no_grad():
-    e_or = fwd(sd, feats.cpu())
+FWD = {'CAMPPlus': oc.campplus_forward, 'TDNN': om.tdnn_forward, 'EcapaTdnn': om.ecapa_forward, 'ResNetSE': orse.resnetse_forward,
+       'ERes2Net': oer.eres2net_forward}
+MAKE = {'CAMPPlus': lambda: CAMPPlus(80, embd_dim=192), 'TDNN': lambda: TDNN(80), 'EcapaTdnn': lambda: EcapaTdnn(80),
+        'ResNetSE': lambda: ResNetSE(80, embd_dim=192), 'ERes2Net': lambda: ERes2Net(80, embd_dim=192, m_channels=32)}
 
 
 def scores(e):
@@ -95,16 +51,81 @@ def scores(e):
     return e @ e.t()
 
 
-s_or = scores(e_or)
-same = (lab.cpu()[:, None] == lab.cpu()[None, :])
-off = ~torch.eye(96, dtype=torch.bool)
-print(f'  oracle scores: same-speaker pairs mean {s_or[same & off].mean():.3f}, different-speaker pairs mean {s_or[~same].mean():.3f}')
-for dt in ('float32', 'bfloat16'):
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        eng = m.engine(dt)
+def run(name, steps=240, B=64, n_eval=96, verbose=True):
+    """Train `name` for `steps` steps of B under enable_amp, then score n_eval held-out utterances all-pairs with the CPU oracle and both
+    engines -> dict(loss, acc, err_f32, err_bf16, rel_f32, rel_bf16, eer_oracle, eer_f32, eer_bf16)."""
+    from ppvector.metric.metrics import evaluate_trials
+    spe = max(1, steps // epochs)
+    table = ac.speaker_table(n_spk, 1000)
+    fz = AudioFeaturizer('Fbank', dict(sr=16000, n_mels=80))
+
+    def batch(seed, n):
+        rng = np.random.RandomState(seed)
+        lab = rng.randint(0, n_spk, n)
+        wav = np.stack([ac.synth_utterance(table, int(s), 48000, np.random.RandomState(seed * 1000 + k)) for k, s in enumerate(lab)]).astype(np.float32)
+        with torch.no_grad():
+            return fz(torch.from_numpy(wav).cuda()).contiguous(), torch.from_numpy(lab).cuda()
+
+    pool = [batch(200 + i, B) for i in range(16)]
+    torch.manual_seed(7)
+    m = MAKE[name]()
+    model = torch.nn.Sequential(m, SpeakerIdentification(192, n_spk)).cuda()
+    was = ppvector.get_train_amp()
+    ppvector.set_train_amp(True)
+    cur = {'i': 0}
+
+    def lr_at(i):
+        if i < spe:
+            return 1e-3 * (i + 1) / spe
+        return 1e-5 + 0.5 * (1e-3 - 1e-5) * (1.0 + math.cos(math.pi * (i - spe) / max(1, steps - spe)))
+
+    crit = AAMLoss(margin=0.0, scale=32)
+    opt = Adam(model.parameters(), learning_rate=lambda: lr_at(cur['i']), weight_decay=1e-6)
+    step = TrainStep(model, crit, opt, overlap_allreduce=False)
+    try:
+        for i in range(steps):
+            cur['i'] = i
+            crit.update(margin=om.margin_schedule(i, spe, epochs, 0.0, 0.3))
+            loss, acc = step(*pool[i % len(pool)])
+        torch.cuda.synchronize()
+    finally:
+        ppvector.set_train_amp(was)
+    out = dict(loss=float(loss), acc=float(acc))
+    if verbose:
+        print(f'# {name}: trained {steps} steps of {B} under enable_amp: last loss {out["loss"]:.4f}, accuracy {out["acc"]:.3f}')
+    feats, lab = batch(999, n_eval)
+    m.eval()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
     with torch.no_grad():
-        e = eng.forward(feats.to(torch.bfloat16) if dt == 'bfloat16' else feats).float().cpu()
-    d = (scores(e) - s_or).abs().max().item()
-    rl = ((e.double() - e_or.double()).norm() / e_or.double().norm()).item()
-    print(f'  {dt:9s} engine vs CPU oracle at the trained weights: max |cosine score difference| over 96 x 96 pairs {d:.2e} (north_star: 1e-4), embeddings rel-L2 {rl:.2e}')
+        e_or = FWD[name](sd, feats.cpu())
+    s_or = scores(e_or)
+    labc = lab.cpu()
+    same = labc[:, None] == labc[None, :]
+    off = ~torch.eye(n_eval, dtype=torch.bool)
+    h = n_eval // 2
+
+    def eer_of(e):
+        e = e.float()
+        return float(evaluate_trials(e[:h].cuda(), labc[:h].numpy(), e[h:].cuda(), labc[h:].numpy())[0])
+
+    out['eer_oracle'] = eer_of(e_or)
+    if verbose:
+        print(f'  oracle scores: same-speaker pairs mean {s_or[same & off].mean():.3f}, different-speaker pairs mean {s_or[~same].mean():.3f}; '
+              f'EER of the second half scored against the first {out["eer_oracle"]:.4f}')
+    for dt, tag in (('float32', 'f32'), ('bfloat16', 'bf16')):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            eng = m.engine(dt)
+        with torch.no_grad():
+            e = eng.forward(feats.to(torch.bfloat16) if dt == 'bfloat16' else feats).float().cpu()
+        out['err_' + tag] = (scores(e) - s_or).abs().max().item()
+        out['rel_' + tag] = ((e.double() - e_or.double()).norm() / e_or.double().norm()).item()
+        out['eer_' + tag] = eer_of(e)
+        if verbose:
+            print(f'  {dt:9s} engine vs CPU oracle at the trained weights: max |cosine score difference| over {n_eval} x {n_eval} pairs {out["err_" + tag]:.2e} '
+                  f'(north_star: 1e-4), embeddings rel-L2 {out["rel_" + tag]:.2e}, EER {out["eer_" + tag]:.4f}')
+    return out
+
+
+if __name__ == '__main__':
+    run(sys.argv[1] if len(sys.argv) > 1 else 'EcapaTdnn', int(sys.argv[2]) if len(sys.argv) > 2 else 240, int(sys.argv[3]) if len(sys.argv) > 3 else 64)
