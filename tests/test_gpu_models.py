@@ -5,6 +5,8 @@ oracle/gen_golden.py) and the CPU oracle.  Tolerances, per BASELINE.json north_s
   bf16 engine: bf16 storage of activations/weights, f32 accumulate: cosine between HIP and
                reference embeddings >= 1 - 1e-3, pair-score error bound stated in the test.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
