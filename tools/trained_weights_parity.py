@@ -96,6 +96,8 @@ def run(name, steps=240, B=64, n_eval=96, verbose=True):
     feats, lab = batch(999, n_eval)
     m.eval()
     sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    if os.environ.get('VP_TWP_SAVE'):                     # the trained operating point, for offline studies on the CPU oracle
+        torch.save(dict(name=name, state=sd, feats=feats.cpu(), labels=lab.cpu()), os.environ['VP_TWP_SAVE'])
     with torch.no_grad():
         e_or = FWD[name](sd, feats.cpu())
     s_or = scores(e_or)
