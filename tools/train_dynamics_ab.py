@@ -84,9 +84,10 @@ fwd = {'CAMPPlus': oc.campplus_forward, 'TDNN': om.tdnn_forward, 'EcapaTdnn': om
        'ERes2Net': oer.eres2net_forward}[name]
 
 
-def oracle_grads(model, x, y, margin):
+def oracle_grads(model, x, y, margin, dt=None):
     """Loss and parameter gradients of torch autograd over the oracle graph AT THE MODEL'S CURRENT WEIGHTS (float64 on request)."""
-    dt = torch.float64 if os.environ.get('VP_DYN_F64') else torch.float32
+    if dt is None:
+        dt = torch.float64 if os.environ.get('VP_DYN_F64') else torch.float32
     sd = model.state_dict()
     p = {k[2:]: v.detach().to(dt).clone().requires_grad_(v.is_floating_point() and not k.endswith(('_mean', '_variance'))) for k, v in sd.items()
          if k.startswith('0.')}
@@ -134,9 +135,15 @@ for i in range(steps):
             # visible share of the gradient are ranked)
             if math.sqrt(nn_) > 1e-3 * tot and math.sqrt(dd / max(nn_, 1e-300)) > worst:
                 worst, wk = math.sqrt(dd / max(nn_, 1e-300)), k
+        cal = ''
+        if os.environ.get('VP_DYN_F64'):
+            # calibration: how far is torch's OWN f32 autograd over the same graph from the float64 one?
+            _, g32 = oracle_grads(model, x, y, margin_at(i), torch.float32)
+            n2 = sum(float((g32[k].double() - go[k].double()).pow(2).sum()) for k in go)
+            cal = f'  [torch f32 autograd vs float64: {math.sqrt(n2 / max(den, 1e-300)):.3e}]'
         gn = opt.grad.norm().item()
         print(f'[check] step {i}: loss engine {float(l_e):.6f} oracle {l_o:.6f}  |grad| {gn:.4e}  whole-gradient rel-L2 {math.sqrt(num / max(den, 1e-300)):.3e}  '
-              f'worst tensor {worst:.3e} ({wk})' + (f'  NON-FINITE engine gradients: {bad[:4]}' if bad else ''), flush=True)
+              f'worst tensor {worst:.3e} ({wk})' + cal + (f'  NON-FINITE engine gradients: {bad[:4]}' if bad else ''), flush=True)
         opt.step()
         opt.clear_grad()
         eng.append((float(l_e), 0.0))
