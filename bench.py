@@ -24,6 +24,10 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
                    per step, 87 % of the forward's flops): every shape replayed back to back between HIP events on the launching
                    stream, against the dense bf16 MFMA peak; "traffic" = HBM bytes per launch from the committed PMC passes
                    (profiles/r05_pmc_infer.json, while the hash of csrc/conv_gemm256.hip matches); "family" adds the two other conv launches;
+                   "frac" = "frac_loaded" (20 warm + 30 timed launches per shape: the loaded power state the step runs in) and "frac_cold"
+                   (2 warm + 10 timed, taken first: the protocol of rounds 1-3) -- both reported, neither replaces the rocprof average
+                   of the same kernel (profiles/r05_kernel_stats_infer.csv: 0.333);
+  "ms_per_step_without_prereplays" : the same two-sequence graph freshly captured WITHOUT the set-up replays, timed behind an idle gap;
   "single_stream_ms" : the same step as one launch sequence; "clocks": rocm-smi before / after the timed region;
   "cpu_baseline" : the CPU oracle (reference algorithm restated on NumPy + PyTorch-CPU fp32 -- NOT the PaddlePaddle
                    binary) timed on this host's cores on a bounded sample;
