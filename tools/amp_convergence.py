@@ -77,7 +77,7 @@ def _write_wav(path, x):
         w.writeframes(pcm.tobytes())
 
 
-def build_dataset(root, n_spk=64, train_files=8, seconds=4.0, steps_per_epoch=30, batch=256, seed=1000):
+def build_dataset(root, n_spk=64, train_files=8, seconds=4.0, steps_per_epoch=30, batch=256, seed=1000, ragged=False):
     """WAV files + the three list files of the reference's layout under `root`.  Every training file is listed often enough for
     `steps_per_epoch` batches; the loader crops a random 3 s window out of the 4 s file each time it is drawn."""
     from concurrent.futures import ThreadPoolExecutor
@@ -88,7 +88,10 @@ def build_dataset(root, n_spk=64, train_files=8, seconds=4.0, steps_per_epoch=30
     for s in range(n_spk):
         for u in range(train_files):
             p = f'{root}/tr_{s}_{u}.wav'
-            jobs.append((p, s, n, seed * 7919 + s * 131 + u))
+            # ragged: half of the files are SHORTER than the 3 s crop (1.2 .. 2.8 s): batches then mix lengths and take the ragged Fbank +
+            # zero-padded collate path (reader.py:72-109, collate_fn.py:5-23)
+            nu = int((1.2 + 1.6 * ((s * 7 + u * 3) % 10) / 9.0) * SR) if (ragged and u % 2) else n
+            jobs.append((p, s, nu, seed * 7919 + s * 131 + u))
             files.append((p, s))
     lists = {}
     for name, per, base in (('enroll', 1, 500), ('trials', 3, 600)):
@@ -153,7 +156,7 @@ class _Curve(logging.Handler):
             self.points.append(((e - 1) * n + b, float(m.group(4)), float(m.group(5))))
 
 
-def run(root, n_spk, batch, max_epoch, enable_amp, model='EcapaTdnn', save=None):
+def run(root, n_spk, batch, max_epoch, enable_amp, model='EcapaTdnn', save=None, aug=None):
     """One training run through PPVectorTrainer.train + .evaluate -> dict(curve, eer, min_dcf, threshold, seconds, steps)."""
     import random
     import torch
@@ -166,7 +169,7 @@ def run(root, n_spk, batch, max_epoch, enable_amp, model='EcapaTdnn', save=None)
     try:
         random.seed(1000)
         np.random.seed(1000)
-        tr = PPVectorTrainer(configs(root, n_spk, batch, max_epoch, enable_amp, model), use_gpu=True, data_augment_configs=AUG)
+        tr = PPVectorTrainer(configs(root, n_spk, batch, max_epoch, enable_amp, model), use_gpu=True, data_augment_configs=aug or AUG)
         t0 = time.time()
         tr.train(save_model_path=save or f'{root}/models_{"amp" if enable_amp else "f32"}', do_eval=False)
         torch.cuda.synchronize()
@@ -200,6 +203,10 @@ def main():
     ap.add_argument('--epochs', type=int, default=10)
     ap.add_argument('--model', default='EcapaTdnn')
     ap.add_argument('--out', default=None)
+    ap.add_argument('--ragged', action='store_true', help='half of the training files shorter than the crop: the ragged Fbank / collate path')
+    ap.add_argument('--speed', action='store_true', help='the reference default: speed perturbation on every utterance (augmentation.yml:1-6)')
+    ap.add_argument('--speed3', action='store_true', help='... with the 3-class label offset (trainer.py:171-173)')
+    ap.add_argument('--volume', action='store_true', help='volume perturbation, prob 0.5')
     a = ap.parse_args()
     lines = []
 
@@ -208,12 +215,18 @@ def main():
         lines.append(s)
 
     with tempfile.TemporaryDirectory(prefix='vp_ampconv_') as root:
-        spe = build_dataset(root, a.speakers, steps_per_epoch=max(1, a.steps // a.epochs), batch=a.batch)
+        spe = build_dataset(root, a.speakers, steps_per_epoch=max(1, a.steps // a.epochs), batch=a.batch, ragged=a.ragged)
+        aug = dict(AUG)
+        if a.speed or a.speed3:
+            aug['speed'] = dict(prob=1.0, speed_perturb_3_class=bool(a.speed3))
+        if a.volume:
+            aug['volume'] = dict(prob=0.5, min_gain_dBFS=-15, max_gain_dBFS=15)
+        say(f'# options: ragged={a.ragged} speed={a.speed or a.speed3} speed_perturb_3_class={a.speed3} volume={a.volume}')
         say(f'# enable_amp vs f32 through PPVectorTrainer: {a.model}, {a.speakers} synthetic speakers, batch {a.batch}, '
             f'{a.epochs} epochs x {spe} steps, Fbank 80, AAMLoss + margin scheduler, Adam 1e-3 warm-up 1 epoch -> cosine, SpecAugment 0.5')
         res = {}
         for amp in (False, True):
-            r = res[amp] = run(root, a.speakers, a.batch, a.epochs, amp, a.model)
+            r = res[amp] = run(root, a.speakers, a.batch, a.epochs, amp, a.model, aug=aug)
             say(f'## enable_amp={amp}: {r["steps"]} steps in {r["seconds"]:.1f} s (data loading included), EER {r["eer"]:.5f}, '
                 f'minDCF {r["min_dcf"]:.5f}, threshold {r["threshold"]:.2f}, grid-barrier faults {r["barrier_faults"]}, '
                 f'capture_error {r["capture_error"]}')
