@@ -698,6 +698,24 @@ int vp_seg_ctx_bwd_f32(vp_ctx* ctx, const float* dctx, int B, int T, int C, int 
 int vp_seg_scale_f32(vp_ctx* ctx, const float* y, const float* m, int B, int T, int C, int seg_len, float* out, vp_stream stream);
 int vp_seg_scale_bwd_f32(vp_ctx* ctx, const float* g, const float* y, const float* m, int B, int T, int C, int seg_len, float* dy, float* dm,
                          vp_stream stream);
+/* The whole gate of a CAMLayer behind its local conv as ONE launch forward and TWO backward, one workgroup per utterance
+ * (CAMLayer.forward, models/campplus.py:88-95: context = x.mean(-1) + seg_pooling(x); m = sigmoid(linear2(relu(linear1(context))));
+ * return linear_local(x) * m).  h (B*T, C) = the layer's input, y (B*T, O) = linear_local(h) from the conv GEMM, W1 (H, C), W2 (O, H):
+ * vp_cam_gate_fwd_f32  : out = y * m[b, seg(t)];  ctx (B*nseg, C), hid (B*nseg, H), m (B*nseg, O) kept for backward.
+ * vp_cam_gate_bwd_f32  : from g = d out: dy = g * m, dpre2 / dpre1 = the gradients at the two dense layers' pre-activations, dh = the part
+ *                        of d h that arrives through the context (the caller adds it in the local conv's data-gradient epilogue),
+ *                        dyb (B, O) = per-utterance column sums of dy (the local conv's bias gradient, summed by the next call).
+ * vp_cam_gate_wgrad_f32: dW1 = dpre1^T ctx, db1, dW2 = dpre2^T hid, db2, dbl[o] = sum_b dyb[b][o] (dbl / dyb may be NULL), rows summed in order.
+ * C, O % 4 == 0, C <= 1024, O <= 128, 16-byte aligned rows, one utterance's context within 128 KB of LDS, else VP_EUNSUP (the caller keeps the
+ * per-op path: vp_seg_ctx_f32 -> two vp_conv1d_fwd -> vp_seg_scale_f32). */
+int vp_cam_gate_fwd_f32(vp_ctx* ctx, const float* h, int ldh, const float* y, int ldy, const float* w1, const float* b1, const float* w2,
+                        const float* b2, int B, int T, int C, int H, int O, int seg_len, float* ctx_out, float* hid_out, float* m_out,
+                        float* out, int ldo, vp_stream stream);
+int vp_cam_gate_bwd_f32(vp_ctx* ctx, const float* g, int ldg, const float* y, int ldy, const float* hid, const float* m, const float* w1,
+                        const float* w2, int B, int T, int C, int H, int O, int seg_len, float* dy, int lddy, float* dpre1, float* dpre2,
+                        float* dh, int lddh, float* dyb, vp_stream stream);
+int vp_cam_gate_wgrad_f32(vp_ctx* ctx, const float* dpre1, const float* dpre2, const float* ctx_in, const float* hid, const float* dyb, int B,
+                          int nseg, int C, int H, int O, float* dw1, float* db1, float* dw2, float* db2, float* dbl, vp_stream stream);
 /* AFF output (eres2net.py:48-51) and its backward: o = x (1 + t) + y (1 - t) on dense (rows, C) f32 tensors. */
 int vp_aff_combine_f32(vp_ctx* ctx, const float* t, const float* x, const float* y, long long rows, int C, float* out, vp_stream stream);
 int vp_aff_combine_bwd_f32(vp_ctx* ctx, const float* g, const float* t, const float* x, const float* y, long long n, float* dx, float* dy,

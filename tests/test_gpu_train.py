@@ -549,6 +549,77 @@ def test_campplus_training_step_vs_oracle_autograd(N, B, gtol):
     m.eval()
 
 
+@pytest.mark.parametrize('case', [
+    # B, T, C, O, k, dil, seg_len
+    (5, 115, 128, 32, 3, 1, 100),         # the bench geometry of a CAM dense layer: two segments, the second of 15 frames
+    (3, 64, 128, 32, 3, 2, 100),          # one segment
+    (2, 301, 64, 32, 3, 2, 100),          # four segments, the last of one frame
+    (4, 50, 192, 16, 5, 1, 20),           # C not a power of two, a 5-tap local conv, short segments
+])
+def test_cam_layer_as_one_tape_entry_vs_float64(N, case):
+    """CamLayerFn (local conv + vp_cam_gate_fwd_f32 / vp_cam_gate_bwd_f32 / vp_cam_gate_wgrad_f32) against float64 autograd over
+    CAMLayer.forward as the reference writes it (campplus.py:88-106), with the output gradient handed over as a column slice of a wider
+    tensor (what the DenseNet concatenation's backward hands it); and against the per-op tape it replaces."""
+    from ppvector.train.functions import CamLayerFn, Conv2dBlock, ConvBlock, SegCtx, SegScale
+    B, T, Cc, O, k, dil, seg = case
+    H = Cc // 2
+    g = torch.Generator().manual_seed(31 + T)
+    h = torch.randn(B, T, Cc, generator=g, dtype=torch.float64, requires_grad=True)
+    mk = lambda *sh, s=1.0: (torch.randn(*sh, generator=g, dtype=torch.float64) * s).requires_grad_()
+    wl, bl = mk(O, Cc, k, s=(Cc * k) ** -0.5), mk(O, s=0.1)
+    w1, b1 = mk(H, Cc, 1, s=Cc ** -0.5 * 3), mk(H, s=0.3)
+    w2, b2 = mk(O, H, 1, s=H ** -0.5 * 3), mk(O, s=0.3)
+    x = h.transpose(1, 2)
+    y = F.conv1d(x, wl, bl, dilation=dil, padding=(k - 1) // 2 * dil)
+    segm = F.avg_pool1d(x, kernel_size=seg, stride=seg, ceil_mode=True)
+    segm = segm.unsqueeze(-1).expand(*segm.shape, seg).reshape(B, Cc, -1)[..., :T]
+    ctx = x.mean(-1, keepdim=True) + segm
+    out = (y * torch.sigmoid(F.conv1d(F.relu(F.conv1d(ctx, w1, b1)), w2, b2))).transpose(1, 2)
+    gw = torch.randn(B * T, O + 24, generator=g, dtype=torch.float64)
+    out.backward(gw[:, 8:8 + O].reshape(B, T, O))
+    ref = [out.detach().reshape(B * T, O), h.grad.reshape(B * T, Cc), wl.grad, bl.grad, w1.grad, b1.grad, w2.grad, b2.grad]
+
+    def run(fused):
+        leaves = [t.detach().float().cuda().requires_grad_() for t in (h.reshape(B * T, Cc), wl, bl, w1, b1, w2, b2)]
+        hd = leaves[0]
+        if fused:
+            assert CamLayerFn.usable(hd, leaves[1], leaves[3], leaves[5], T, seg)
+            o = CamLayerFn.apply(*leaves, dict(B=B, T=T, seg_len=seg, dilation=dil))
+        else:
+            yy = Conv2dBlock.apply(hd, leaves[1].unsqueeze(2), leaves[2], None, None, None, None, dict(B=B, T=T, F=1, dilation=dil, act=None))
+            nseg = (T + seg - 1) // seg
+            c = SegCtx.apply(hd, B, T, seg)
+            c = ConvBlock.apply(c, leaves[3], leaves[4], None, None, None, None, None, dict(B=B * nseg, T=1, relu=True))
+            mm = ConvBlock.apply(c, leaves[5], leaves[6], None, None, None, None, None, dict(B=B * nseg, T=1, sigmoid=True))
+            o = SegScale.apply(yy, mm, B, T, seg)
+        o.backward(gw.float().cuda()[:, 8:8 + O])
+        return [o.detach()] + [t.grad for t in leaves]
+
+    got, per_op = run(True), run(False)
+    names = ['out', 'd h', 'd W_local', 'd b_local', 'd W1', 'd b1', 'd W2', 'd b2']
+    for nm, a, b, r in zip(names, got, per_op, ref):
+        ea, eb = rel(a.reshape(r.shape), r), rel(b.reshape(r.shape), r)
+        print(f'[cam layer {case}] {nm:10s} one tape entry vs float64 {ea:.2e}   per-op tape vs float64 {eb:.2e}')
+        assert ea < 1e-4, (nm, ea)
+        assert ea < max(3 * eb, 5e-6), (nm, ea, eb)
+
+
+def test_placeholder_read_as_data_is_loud(N):
+    """An activation that exists as bf16 only travels on the tape as an f32 placeholder that owns ONE element, its values on the
+    `_vp_bf16` attribute (functions._placeholder).  A consumer that forgets _f32c / _only16 and reads the placeholder itself must not
+    train on silent zeros: the element is NaN, so any arithmetic on it poisons the loss at the first step; the sanctioned readers get
+    the values."""
+    from ppvector.train.functions import _f32c, _only16, _placeholder
+    dev = torch.device('cuda', 0)
+    vals = torch.arange(32, dtype=torch.float32, device=dev).reshape(4, 8).to(torch.bfloat16)
+    p = _placeholder((4, 8), dev)
+    p._vp_bf16, p._vp_bf16_only = vals, True
+    assert p.shape == (4, 8) and p.untyped_storage().nbytes() == 4
+    assert bool(torch.isnan(p).all()) and bool(torch.isnan((p * 0.0).sum()))           # a raw read is NaN, even scaled by zero
+    assert _only16(p) is vals
+    assert torch.equal(_f32c(p), vals.float())
+
+
 def test_eval_engine_follows_training_updates(N):
     """The packed eval engine (and its HIP graph) must not survive a training step: Adam and the BatchNorm running statistics
     are written through raw pointers, which torch's version counters never see (PPVectorTrainer.train(do_eval=True) evaluates

@@ -1,5 +1,6 @@
-"""Which PyTorch-side (aten) kernels the ECAPA training step launches, and from where: torch.profiler over three steps,
-grouped by operator and by the two innermost Python frames.  (The libvpmi launches do not appear here: they go through ctypes.)"""
+"""Which PyTorch-side (aten) kernels a training step launches, and from where: torch.profiler over three steps, grouped by
+operator and by the two innermost Python frames.  (The libvpmi launches do not appear here: they go through ctypes.)
+python tools/train_aten_profile.py [batch] [EcapaTdnn|CAMPPlus]"""
 import os
 import sys
 
@@ -17,8 +18,13 @@ from ppvector.optimizer.adam import Adam  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 ppvector.set_train_amp(True)
-m = EcapaTdnn(80)
-m.load_state_dict(om.ecapa_params(80))
+if len(sys.argv) > 2 and sys.argv[2] == 'CAMPPlus':
+    from ppvector.models.campplus import CAMPPlus
+    torch.manual_seed(0)
+    m = CAMPPlus(80, embd_dim=192)
+else:
+    m = EcapaTdnn(80)
+    m.load_state_dict(om.ecapa_params(80))
 model = torch.nn.Sequential(m, SpeakerIdentification(192, 2796)).cuda().train()
 crit = AAMLoss()
 opt = Adam(model.parameters(), learning_rate=1e-4, weight_decay=1e-6)

@@ -1,10 +1,11 @@
 """Training-mode forward of CAM++ (ppvector/models/campplus.py:331-335) through the autograd functions of functions.py.
 Activations are position-major: (B*T*F, C) in the FCM head, (B*T, C) in the D-TDNN.  The DenseNet concatenations are
-torch.cat; every conv / BatchNorm / activation / context gate / pooling runs in libvpmi.
+torch.cat; every conv / BatchNorm / activation / context gate / pooling runs in libvpmi.  A CAMLayer (local conv + context gate) is ONE
+tape entry (functions.py: CamLayerFn; VPMI_CAM_LAYER_UNFUSED=1 keeps the per-op form the tests compare it with).
 Input (B, T, F) f32 on the GPU -> embeddings (B, embd_dim)."""
 import torch
 
-from ppvector.train.functions import Act, BNRows, Conv2dBlock, ConvBlock, SegCtx, SegScale, TimeStats
+from ppvector.train.functions import Act, BNRows, CamLayerFn, Conv2dBlock, ConvBlock, SegCtx, SegScale, TimeStats
 
 SEG_LEN = 100       # CAMLayer.seg_pooling default (campplus.py:96)
 
@@ -62,6 +63,10 @@ def cam_dense_layer(lay, x, B, T):
     h = _bnrelu(h, lay.nonlinear2.batchnorm)
     cl = lay.cam_layer
     wl = cl.linear_local.weight                                          # (out, bn, k)
+    if CamLayerFn.usable(h, wl, cl.linear1.weight, cl.linear2.weight, T, SEG_LEN):
+        # the local conv + the whole context gate as one tape entry: 3 launches forward, 5 backward (per-op form below: 6 and ~25)
+        return CamLayerFn.apply(h, wl, cl.linear_local.bias, cl.linear1.weight, cl.linear1.bias, cl.linear2.weight, cl.linear2.bias,
+                                dict(B=B, T=T, seg_len=SEG_LEN, dilation=cl.dilation))
     y = Conv2dBlock.apply(h, wl.unsqueeze(2), cl.linear_local.bias, None, None, None, None,
                           dict(B=B, T=T, F=1, dilation=cl.dilation, act=None))
     nseg = (T + SEG_LEN - 1) // SEG_LEN

@@ -116,11 +116,14 @@ def _only16(t):
 
 def _placeholder(shape, device):
     """f32 tensor of `shape` that owns one element: what autograd sees of an activation that exists as bf16 only (autograd hands a
-    tensor's gradient over in the tensor's dtype, so a bf16 tensor on the tape would get its f32 gradient cast down)."""
+    tensor's gradient over in the tensor's dtype, so a bf16 tensor on the tape would get its f32 gradient cast down).  The element is
+    NaN: a consumer that reads the placeholder's own memory instead of its bf16 twin (a missed _f32c / _only16) poisons the loss and
+    every gradient behind it at the first step, instead of training on zeros (tests/test_gpu_train.py:
+    test_placeholder_read_as_data_is_loud)."""
     key = (device.type, device.index)
     z = _ZERO.get(key)
-    if z is None:                  # one zero per device, made once (a torch.zeros per placeholder is a 5 us fill launch, 16 of them per step)
-        z = _ZERO[key] = torch.zeros(1, dtype=torch.float32, device=device)
+    if z is None:                  # one element per device, made once (a fill per placeholder is a 5 us launch, 16 of them per step)
+        z = _ZERO[key] = torch.full((1,), float('nan'), dtype=torch.float32, device=device)
     return z.expand(shape)
 
 
@@ -419,7 +422,9 @@ def _conv_block_bwd(ctx, dy, skip=None, fold=None, utt=None):
             dbias = col_sums(dz)[0] if has_bias else None
     else:
         dz = dy
-        if has_bias and getattr(ctx, 'zero_dbias', False):      # the caller knows sum_rows dz == 0 (a bias in front of a softmax over time)
+        if has_bias and getattr(ctx, 'given_dbias', None) is not None:      # the caller's own pass over dz already summed its columns
+            dbias = ctx.given_dbias
+        elif has_bias and getattr(ctx, 'zero_dbias', False):      # the caller knows sum_rows dz == 0 (a bias in front of a softmax over time)
             dbias = torch.zeros(Cout, dtype=torch.float32, device=dev)
         else:
             dbias = col_sums(dz if dz.dtype == torch.float32 else dz.float())[0] if has_bias else None
@@ -1198,7 +1203,9 @@ class MfaAspFn(torch.autograd.Function):
 
 
 class BNRows(torch.autograd.Function):
-    """BatchNorm1D with batch statistics on a (M, C) tensor."""
+    """BatchNorm1D with batch statistics on a (M, C) tensor [-> ReLU].  With the ReLU, its backward is folded into the two
+    BatchNorm-backward passes (they re-evaluate x * scale + shift > 0: vp_col_sums_masked_f32 / vp_bn_relu_bwd_masked_f32), so neither
+    the output nor a d(activation) tensor is kept (VPMI_BN_RELU_UNFOLDED=1: the three-pass form)."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, run_mean, run_var, momentum, eps, relu=False):
@@ -1215,7 +1222,9 @@ class BNRows(torch.autograd.Function):
         y = torch.empty_like(x)
         _chk(lib.vp_affine_rows_f32(hctx, x.data_ptr(), Cc, scale.data_ptr(), shift.data_ptr(), M, Cc, y.data_ptr(), Cc, int(relu),
                                     N.stream_ptr()), hctx)
-        ctx.save_for_backward(x, mean, invstd, gamma, y if relu else None)
+        fold = bool(relu) and Cc % 4 == 0 and not os.environ.get('VPMI_BN_RELU_UNFOLDED')
+        ctx.fold = (scale, shift) if fold else None
+        ctx.save_for_backward(x, mean, invstd, gamma, y if relu and not fold else None)
         return y
 
     @staticmethod
@@ -1224,6 +1233,23 @@ class BNRows(torch.autograd.Function):
         lib, hctx = N.lib(), N.ctx(x.device)
         dy = _f32c(dy)
         M, Cc = x.shape
+        fold = ctx.fold
+        if fold is not None:
+            ms, mh = fold
+            sums = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+            ws = _bytes(lib.vp_col_sums_workspace_bytes(M, Cc), x.device)
+            rc = lib.vp_col_sums_masked_f32(hctx, dy.data_ptr(), Cc, x.data_ptr(), Cc, mean.data_ptr(), invstd.data_ptr(), ms.data_ptr(),
+                                            mh.data_ptr(), M, Cc, sums.data_ptr(), ws.data_ptr(), ws.numel(), N.stream_ptr())
+            if rc == N.VP_EUNSUP:                     # (misaligned views: materialise the mask the plain way)
+                yr = torch.empty_like(x)
+                _chk(lib.vp_affine_rows_f32(hctx, x.data_ptr(), Cc, ms.data_ptr(), mh.data_ptr(), M, Cc, yr.data_ptr(), Cc, 1, N.stream_ptr()), hctx)
+                fold = None
+            else:
+                _chk(rc, hctx)
+                dx = torch.empty_like(x)
+                _chk(lib.vp_bn_relu_bwd_masked_f32(hctx, dy.data_ptr(), Cc, x.data_ptr(), Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                                                   sums.data_ptr(), ms.data_ptr(), mh.data_ptr(), M, Cc, dx.data_ptr(), Cc, N.stream_ptr()), hctx)
+                return dx, sums[1], sums[0], None, None, None, None, None
         if yr is not None:
             t = torch.empty_like(dy)
             _chk(lib.vp_act_bwd_f32(hctx, N.VP_ACT_RELU, dy.data_ptr(), yr.data_ptr(), dy.numel(), t.data_ptr(), N.stream_ptr()), hctx)
@@ -1526,7 +1552,7 @@ class Conv2dBlock(torch.autograd.Function):
             if strided:                                 # zero-insertion: the strided data gradient as a stride-1 conv
                 src = torch.empty((B * T * Fq, Cout), dtype=torch.float32, device=dev)
                 _chk(lib.vp_zero_insert_2d_f32(hctx, dz.data_ptr(), B, To, Fo, Cout, T, Fq, st, sf, src.data_ptr(), N.stream_ptr()), hctx)
-            w2 = weight.flip(2, 3).permute(1, 3, 2, 0).reshape(Cin, KT * KF * Cout).contiguous()
+            w2 = (weight if KT * KF == 1 else weight.flip(2, 3)).permute(1, 3, 2, 0).reshape(Cin, KT * KF * Cout).contiguous()
             dx = torch.empty((B * T * Fq, Cin), dtype=torch.float32, device=dev)
             Ts, Fs = (T, Fq) if strided else (To, Fo)
             d2 = _conv_desc(src, B, Ts, T, Cout, Cin, KT * KF, dil, N.VP_PAD_ZERO, dil * (KT - 1) - pad, w2)
@@ -1631,3 +1657,74 @@ class SegScale(torch.autograd.Function):
         _chk(lib.vp_seg_scale_bwd_f32(hctx, g.data_ptr(), y.data_ptr(), m.data_ptr(), B, T, y.shape[1], seg_len, dy.data_ptr(), dm.data_ptr(),
                                       N.stream_ptr()), hctx)
         return dy, dm, None, None, None
+
+
+class CamLayerFn(torch.autograd.Function):
+    """CAMLayer (models/campplus.py:88-95) as one tape entry: out = linear_local(h) * sigmoid(linear2(relu(linear1(mean_t h + segment means of h)))).
+    The local conv is a ConvBlock (same kernels as everywhere); everything behind it is vp_cam_gate_fwd_f32 forward (one launch for the
+    segment means, both dense layers and the gate) and vp_cam_gate_bwd_f32 + vp_cam_gate_wgrad_f32 backward; the gradient that reaches h
+    through the context is added in the local conv's data-gradient epilogue, the conv's bias gradient comes out of the gate's backward pass.
+    h (B*T, C) f32; weights as the reference stores them: wl (O, C, k), w1 (H, C, 1), w2 (O, H, 1)."""
+
+    @staticmethod
+    def usable(h, wl, w1, w2, T, seg_len):
+        Cc, O, H = wl.shape[1], wl.shape[0], w1.shape[0]
+        nseg = (T + seg_len - 1) // seg_len
+        # (the kernels' layout: float4 rows, C <= 1024, O <= 128, everything of one utterance's context in 128 KB of LDS)
+        return (h.dtype == torch.float32 and Cc % 4 == 0 and Cc <= 1024 and O % 4 == 0 and O <= 128
+                and (nseg * (Cc + H + 2 * O) + Cc + 16 * O + 8192 + 16) * 4 <= 128 * 1024 and not os.environ.get('VPMI_CAM_LAYER_UNFUSED'))
+
+    @staticmethod
+    def forward(ctx, h, wl, bl, w1, b1, w2, b2, cfg):
+        lib, hctx = N.lib(), N.ctx(h.device)
+        B, T, seg_len = cfg['B'], cfg['T'], cfg['seg_len']
+        h = _f32c(h)
+        dev = h.device
+        O, Cc, _ = wl.shape
+        H = w1.shape[0]
+        nseg = (T + seg_len - 1) // seg_len
+        tape = _Tape((ctx.needs_input_grad[0], True, bl is not None, False, False, False, False, False, False))
+        y = ConvBlock.forward(tape, h, wl, bl, None, None, None, None, None, dict(B=B, T=T, dilation=cfg.get('dilation', 1), pad='zero'))
+        w1c, w2c = _f32c(w1).view(H, Cc), _f32c(w2).view(O, H)
+        cx = torch.empty((B * nseg, Cc), dtype=torch.float32, device=dev)
+        hid = torch.empty((B * nseg, H), dtype=torch.float32, device=dev)
+        m = torch.empty((B * nseg, O), dtype=torch.float32, device=dev)
+        out = torch.empty((B * T, O), dtype=torch.float32, device=dev)
+        _chk(lib.vp_cam_gate_fwd_f32(hctx, h.data_ptr(), Cc, y.data_ptr(), O, w1c.data_ptr(), b1.data_ptr(), w2c.data_ptr(), b2.data_ptr(),
+                                     B, T, Cc, H, O, seg_len, cx.data_ptr(), hid.data_ptr(), m.data_ptr(), out.data_ptr(), O, N.stream_ptr()), hctx)
+        ctx.tape = tape
+        ctx.save_for_backward(y, cx, hid, m, w1c, w2c)
+        ctx.geom = (B, T, Cc, H, O, seg_len, nseg, bl is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        y, cx, hid, m, w1c, w2c = ctx.saved_tensors
+        B, T, Cc, H, O, seg_len, nseg, has_bl = ctx.geom
+        lib, hctx = N.lib(), N.ctx(y.device)
+        dev = y.device
+        if g.dtype != torch.float32 or g.stride(1) != 1 or g.stride(0) % 4 or g.data_ptr() % 16:
+            g = _f32c(g)
+        ldg = g.stride(0)                        # (a column slice of the DenseNet concatenation's gradient keeps its pitch: no copy)
+        dy = torch.empty_like(y)
+        dp1 = torch.empty((B * nseg, H), dtype=torch.float32, device=dev)
+        dp2 = torch.empty((B * nseg, O), dtype=torch.float32, device=dev)
+        dh_ctx = torch.empty((B * T, Cc), dtype=torch.float32, device=dev)
+        dyb = torch.empty((B, O), dtype=torch.float32, device=dev)
+        _chk(lib.vp_cam_gate_bwd_f32(hctx, g.data_ptr(), ldg, y.data_ptr(), O, hid.data_ptr(), m.data_ptr(), w1c.data_ptr(), w2c.data_ptr(),
+                                     B, T, Cc, H, O, seg_len, dy.data_ptr(), O, dp1.data_ptr(), dp2.data_ptr(), dh_ctx.data_ptr(), Cc,
+                                     dyb.data_ptr(), N.stream_ptr()), hctx)
+        dw1 = torch.empty((H, Cc, 1), dtype=torch.float32, device=dev)
+        dw2 = torch.empty((O, H, 1), dtype=torch.float32, device=dev)
+        db1 = torch.empty(H, dtype=torch.float32, device=dev)
+        db2 = torch.empty(O, dtype=torch.float32, device=dev)
+        dbl = torch.empty(O, dtype=torch.float32, device=dev) if has_bl else None
+        _chk(lib.vp_cam_gate_wgrad_f32(hctx, dp1.data_ptr(), dp2.data_ptr(), cx.data_ptr(), hid.data_ptr(), dyb.data_ptr(), B, nseg, Cc, H, O,
+                                       dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), dbl.data_ptr() if has_bl else None,
+                                       N.stream_ptr()), hctx)
+        tape = ctx.tape
+        tape.given_dbias = dbl
+        r = _conv_block_bwd(tape, dy, skip=dh_ctx)
+        tape.given_dbias = None              # (a second reference would make autograd COPY the gradient into .grad instead of adopting it)
+        del dbl
+        return r[0], r[1], r[2], dw1, db1, dw2, db2, None
