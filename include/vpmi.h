@@ -838,13 +838,15 @@ int vp_time_stats_ws_f32(vp_ctx* ctx, const float* x, int ldx, int B, int T, int
 /* BatchNorm -> ReLU units (Conv2D -> BatchNorm2D -> ReLU, resnet_se.py:72-74; eres2net.py; campplus.py FCM): the ReLU's backward folded into
  * the two BatchNorm-backward passes -- d y counts only where the unit's output z * mask_scale + mask_shift (mask_scale = gamma * invstd,
  * mask_shift = beta - mean * mask_scale: what vp_bn_train_finalize returned) was positive; no d(activation) tensor.  vp_col_sums_masked_f32:
- * sums[0] = sum m dy, sums[1] = sum m dy zhat;  vp_bn_relu_bwd_masked_f32: dz from them.  C % 4 == 0, 16-byte aligned (else VP_EUNSUP). */
+ * sums[0] = sum m dy, sums[1] = sum m dy zhat;  vp_bn_relu_bwd_masked_f32: dz from them.  C % 4 == 0, 16-byte aligned (else VP_EUNSUP).
+ * mask_hi > 0: the unit's activation is Hardtanh(0, mask_hi) (ERes2Net's ReLU = nn.Hardtanh(0, 20), eres2net.py:14-22): d y also counts only
+ * where the output was BELOW mask_hi; mask_hi = 0: plain ReLU.  The forward's apply pass: vp_affine_rows_f32 with relu = 2 (clamp to [0, 20]). */
 int vp_col_sums_masked_f32(vp_ctx* ctx, const float* a, int lda, const float* b, int ldb, const float* bmean, const float* bscale,
-                           const float* mask_scale, const float* mask_shift, long long M, int C, float* sums, void* ws, size_t ws_bytes,
-                           vp_stream stream);
+                           const float* mask_scale, const float* mask_shift, float mask_hi, long long M, int C, float* sums, void* ws,
+                           size_t ws_bytes, vp_stream stream);
 int vp_bn_relu_bwd_masked_f32(vp_ctx* ctx, const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* invstd,
-                              const float* gamma, const float* sums, const float* mask_scale, const float* mask_shift, long long M, int C,
-                              float* dz, int lddz, vp_stream stream);
+                              const float* gamma, const float* sums, const float* mask_scale, const float* mask_shift, float mask_hi,
+                              long long M, int C, float* dz, int lddz, vp_stream stream);
 int vp_scale_rows_bwd_f32(vp_ctx* ctx, const float* dy, const float* x, const float* s, int B, int T, int C, float* dx, float* ds,
                           vp_stream stream);
 /* The same for utterances of many positions (the (B, T*F', C) feature maps of ResNetSE / ERes2Net, resnet_se.py:60-75): positions spread over

@@ -365,6 +365,49 @@ def test_conv2d_block_grads_vs_autograd(N, case):
         assert rel(got, ref) < 3e-5, (name, rel(got, ref))
 
 
+@pytest.mark.parametrize('case', [(2, 13, 10, 8, 16, 3, 1), (3, 9, 8, 16, 8, 1, 2)])
+def test_conv2d_block_hardtanh_folded_vs_autograd(N, case):
+    """Conv2D -> BatchNorm2D -> Hardtanh(0, 20) (ERes2Net's ReLU, eres2net.py:14-22): the clamp leaves with the BatchNorm apply pass and
+    its mask 0 < y < 20 is re-evaluated inside the two BatchNorm-backward passes (mask_hi of vp_col_sums_masked_f32 /
+    vp_bn_relu_bwd_masked_f32) -- no activation pass either way.  gamma is large enough that BOTH clamps are active."""
+    from ppvector.train.functions import Conv2dBlock
+    B, T, Fq, Cin, Cout, k, s = case
+    g = torch.Generator().manual_seed(77 + k + s)
+    x = torch.randn(B, Cin, Fq, T, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Cout, Cin, k, k, generator=g, dtype=torch.float64) / (Cin * k * k) ** 0.5).requires_grad_()
+    b = torch.randn(Cout, generator=g, dtype=torch.float64, requires_grad=True)
+    ga = ((torch.rand(Cout, generator=g, dtype=torch.float64) + 0.5) * 14.0).requires_grad_()
+    be = (torch.randn(Cout, generator=g, dtype=torch.float64) * 3 + 6).requires_grad_()
+    z = F.conv2d(x, w, b, stride=s, padding=(k - 1) // 2)
+    mean, var = z.mean(dim=(0, 2, 3)), z.var(dim=(0, 2, 3), unbiased=False)
+    pre = (z - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + 1e-5) * ga[None, :, None, None] + be[None, :, None, None]
+    y = F.hardtanh(pre, 0.0, 20.0)
+    lo, hi = (pre <= 0).double().mean().item(), (pre >= 20).double().mean().item()
+    assert lo > 0.05 and hi > 0.05, (lo, hi)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    to2d = lambda t: t.permute(0, 3, 2, 1).reshape(-1, t.shape[1])
+    res = {}
+    for unfolded in (False, True):
+        if unfolded:
+            os.environ['VPMI_BN_RELU_UNFOLDED'] = '1'
+        try:
+            xd = to2d(x.detach()).float().cuda().requires_grad_()
+            wd, bd = w.detach().float().cuda().requires_grad_(), b.detach().float().cuda().requires_grad_()
+            gd, hd = ga.detach().float().cuda().requires_grad_(), be.detach().float().cuda().requires_grad_()
+            rm, rv = torch.zeros(Cout, device='cuda'), torch.ones(Cout, device='cuda')
+            out = Conv2dBlock.apply(xd, wd, bd, gd, hd, rm, rv, dict(B=B, T=T, F=Fq, stride=s, act='hardtanh'))
+            out.backward(to2d(dy).float().cuda())
+            res[unfolded] = (out.detach(), xd.grad, wd.grad, gd.grad, hd.grad)
+        finally:
+            os.environ.pop('VPMI_BN_RELU_UNFOLDED', None)
+    ref = (to2d(y.detach()), to2d(x.grad), w.grad, ga.grad, be.grad)
+    for name, got, per_op, want in zip(('y', 'dx', 'dW', 'dgamma', 'dbeta'), res[False], res[True], ref):
+        e, e0 = rel(got, want), rel(per_op, want)
+        print(f'[conv2d hardtanh {case}] {name:7s} folded vs float64 {e:.2e}   separate activation passes vs float64 {e0:.2e}   clamped at 0 / 20: {lo:.2f} / {hi:.2f}')
+        assert e < 3e-5, (name, e)
+
+
 def test_resnetse_training_step_vs_oracle_autograd(N):
     """ResNetSE (configs/resnet_se.yml architecture, one bottleneck per stage to keep the float64 oracle quick)."""
     from oracle import resnet_se as orse

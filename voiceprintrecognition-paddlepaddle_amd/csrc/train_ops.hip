@@ -549,7 +549,8 @@ struct ColSum4Args { const float* a; const float* b; const float* bmean; const f
                      // UTT == 2: the summed tensor is a + us[b] + um[b] * bf16(b * xsc + xsh) -- the gradient that reaches a TDNNBlock's output y = BN(z)
                      // through its consumer's context statistics [mean_t y | std_t y] (pooling.py:97-104), affine in y per utterance and
                      // channel: us = alpha, um = beta of vp_time_stats_bwd_coeffs; y re-formed from the bf16 z the pass reads anyway
-                     const float* xsc; const float* xsh; };
+                     const float* xsc; const float* xsh;
+                     float mask_hi; };     // with ms / mh: a also counts only where b * ms + mh < mask_hi (0: no upper bound) -- Hardtanh(0, 20) behind the BatchNorm (eres2net.py)
 
 template <int UTT>
 __device__ __forceinline__ void utt_affine4(float (&v)[4], const float* us, const float* um, int T, float inv_t, int C, int m, int c) {
@@ -610,7 +611,11 @@ __global__ __launch_bounds__(256) void col_sums4_kernel(ColSum4Args p) {
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float g = (!HASB || (float)bv[u][e] * ms[e] + mh[e] > 0.f) ? av[u][e] : 0.f;
+                    float g = av[u][e];
+                    if constexpr (HASB) {
+                        const float mv = (float)bv[u][e] * ms[e] + mh[e];
+                        g = (mv > 0.f && (p.mask_hi == 0.f || mv < p.mask_hi)) ? g : 0.f;
+                    }
                     s1[e] += g;
                     if (HASB) s2[e] += g * (bv[u][e] - mu[e]) * sc[e];
                 }
@@ -623,7 +628,11 @@ __global__ __launch_bounds__(256) void col_sums4_kernel(ColSum4Args p) {
             if constexpr (HASB) ctx_affine4<UTT>(av, bv, p.us, p.um, xsc, xsh, p.T, p.C4 * 4, m, c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float g = (!HASB || (float)bv[e] * ms[e] + mh[e] > 0.f) ? av[e] : 0.f;
+                float g = av[e];
+                if constexpr (HASB) {
+                    const float mv = (float)bv[e] * ms[e] + mh[e];
+                    g = (mv > 0.f && (p.mask_hi == 0.f || mv < p.mask_hi)) ? g : 0.f;
+                }
                 s1[e] += g;
                 if (HASB) s2[e] += g * (bv[e] - mu[e]) * sc[e];
             }
@@ -702,7 +711,11 @@ __global__ __launch_bounds__(256) void affine_rows_kernel(const TZ* z, int ldz, 
         float v[4], s[4], h[4];
         vp_load4(z + m * ldz + c, v); vp_load4(scale + c, s); vp_load4(shift + c, h);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = __fmaf_rn(v[e], s[e], h[e]); if (relu) v[e] = fmaxf(v[e], 0.f); }
+        for (int e = 0; e < 4; ++e) {
+            v[e] = __fmaf_rn(v[e], s[e], h[e]);
+            if (relu) v[e] = fmaxf(v[e], 0.f);
+            if (relu == 2) v[e] = fminf(v[e], 20.f);          // Hardtanh(0, 20)
+        }
         vp_store4(y + m * ldy + c, v);
     }
 }
@@ -738,6 +751,7 @@ struct BnBwdArgs {
     const float* ms; const float* mh;       // optional: d y counts only where z * ms + mh > 0 (a ReLU BEHIND the BatchNorm)
     const float* us; const float* um; int T; float inv_t;      // bn_relu_bwd_dbias_kernel<.., UTT>: d y = dy * us[b] + um[b] * inv_t, b = row / T
     const float* xsc; const float* xsh;                        // UTT == 2: d y = dy + us[b] + um[b] * bf16(z * xsc + xsh) (see ColSum4Args)
+    float mask_hi;                                             // with ms / mh: ... and z * ms + mh < mask_hi (0: no upper bound)
 };
 
 __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdArgs a) {
@@ -754,7 +768,10 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdArgs a) {
             float ms[4], mh[4];
             vp_load4(a.ms + c, ms); vp_load4(a.mh + c, mh);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dy[e] = z[e] * ms[e] + mh[e] > 0.f ? dy[e] : 0.f;
+            for (int e = 0; e < 4; ++e) {
+                const float mv = z[e] * ms[e] + mh[e];
+                dy[e] = (mv > 0.f && (a.mask_hi == 0.f || mv < a.mask_hi)) ? dy[e] : 0.f;
+            }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1609,7 +1626,7 @@ size_t vp_col_sums_workspace_bytes(long long M, int C) {
 // sums [2][C]: sum_m a[m][c] and (when b) sum_m a[m][c] * (b[m][c] - bmean[c]) * bscale[c]
 static int col_sums_impl(vp_ctx* ctx, const float* a, int lda, const float* b, int ldb, const float* bmean, const float* bscale,
                          const float* mask_scale, const float* mask_shift, long long M, int C, float* sums, void* ws, size_t ws_bytes,
-                         vp_stream stream);
+                         vp_stream stream, float mask_hi = 0.f);
 
 int vp_col_sums_f32(vp_ctx* ctx, const float* a, int lda, const float* b, int ldb, const float* bmean, const float* bscale,
                     long long M, int C, float* sums, void* ws, size_t ws_bytes, vp_stream stream) {
@@ -1620,16 +1637,16 @@ int vp_col_sums_f32(vp_ctx* ctx, const float* a, int lda, const float* b, int ld
 // counts only where the unit's output b * mask_scale + mask_shift (the BatchNorm affine of the saved pre-BN tensor b) was positive -- the
 // same expression the forward's vp_affine_rows_f32 evaluates.  C % 4 == 0, 16-byte aligned; else VP_EUNSUP.
 int vp_col_sums_masked_f32(vp_ctx* ctx, const float* a, int lda, const float* b, int ldb, const float* bmean, const float* bscale,
-                           const float* mask_scale, const float* mask_shift, long long M, int C, float* sums, void* ws, size_t ws_bytes,
-                           vp_stream stream) {
-    if (!b || !mask_scale || !mask_shift) VP_FAIL(ctx, VP_EINVAL, "col_sums_masked: bad arguments");
+                           const float* mask_scale, const float* mask_shift, float mask_hi, long long M, int C, float* sums, void* ws,
+                           size_t ws_bytes, vp_stream stream) {
+    if (!b || !mask_scale || !mask_shift || mask_hi < 0.f) VP_FAIL(ctx, VP_EINVAL, "col_sums_masked: bad arguments");
     if (((C | lda | ldb) & 3) || (((uintptr_t)a | (uintptr_t)b) & 15)) return VP_EUNSUP;
-    return col_sums_impl(ctx, a, lda, b, ldb, bmean, bscale, mask_scale, mask_shift, M, C, sums, ws, ws_bytes, stream);
+    return col_sums_impl(ctx, a, lda, b, ldb, bmean, bscale, mask_scale, mask_shift, M, C, sums, ws, ws_bytes, stream, mask_hi);
 }
 
 static int col_sums_impl(vp_ctx* ctx, const float* a, int lda, const float* b, int ldb, const float* bmean, const float* bscale,
                          const float* mask_scale, const float* mask_shift, long long M, int C, float* sums, void* ws, size_t ws_bytes,
-                         vp_stream stream) {
+                         vp_stream stream, float mask_hi) {
     if (!ctx || !a || !sums || M <= 0 || C <= 0 || (b && (!bmean || !bscale))) VP_FAIL(ctx, VP_EINVAL, "col_sums: bad arguments");
     if (!ws || ws_bytes < vp_col_sums_workspace_bytes(M, C)) VP_FAIL(ctx, VP_EWORKSPACE, "col_sums: workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -1640,6 +1657,7 @@ static int col_sums_impl(vp_ctx* ctx, const float* a, int lda, const float* b, i
         colsum4_geometry(M, C / 4, cl_shift, colblocks, rpc, ch);
         chunks = ch;
         ColSum4Args p{a, b, bmean, bscale, (float*)ws, lda, ldb, (int)M, C / 4, rpc, cl_shift, mask_scale, mask_shift};
+        p.mask_hi = mask_hi;
         if (b) hipLaunchKernelGGL(col_sums4_kernel<true>, dim3(colblocks, (unsigned)chunks), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(col_sums4_kernel<false>, dim3(colblocks, (unsigned)chunks), dim3(256), 0, st, p);
     } else {
@@ -1756,11 +1774,13 @@ int vp_bn_relu_bwd_f32(vp_ctx* ctx, const float* dy, int lddy, const float* z, i
 
 // BatchNorm backward with a ReLU BEHIND the BatchNorm folded in (see vp_col_sums_masked_f32): d y counts only where z * mask_scale + mask_shift > 0
 int vp_bn_relu_bwd_masked_f32(vp_ctx* ctx, const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* invstd,
-                              const float* gamma, const float* sums, const float* mask_scale, const float* mask_shift, long long M, int C,
-                              float* dz, int lddz, vp_stream stream) {
-    if (!ctx || !dy || !z || !mean || !invstd || !sums || !dz || !mask_scale || !mask_shift || M <= 0 || C <= 0 || (C | lddy | ldz | lddz) & 3)
+                              const float* gamma, const float* sums, const float* mask_scale, const float* mask_shift, float mask_hi,
+                              long long M, int C, float* dz, int lddz, vp_stream stream) {
+    if (!ctx || !dy || !z || !mean || !invstd || !sums || !dz || !mask_scale || !mask_shift || mask_hi < 0.f || M <= 0 || C <= 0 ||
+        (C | lddy | ldz | lddz) & 3)
         VP_FAIL(ctx, VP_EINVAL, "bn_relu_bwd_masked: bad arguments");
     BnBwdArgs a{dy, z, mean, invstd, gamma, sums, dz, lddy, ldz, lddz, C / 4, 0, M, mask_scale, mask_shift};
+    a.mask_hi = mask_hi;
     hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(grid1d(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
     VP_LAUNCH_CHECK(ctx, "bn_relu_bwd_masked");
     return VP_OK;

@@ -1239,7 +1239,7 @@ class BNRows(torch.autograd.Function):
             sums = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
             ws = _bytes(lib.vp_col_sums_workspace_bytes(M, Cc), x.device)
             rc = lib.vp_col_sums_masked_f32(hctx, dy.data_ptr(), Cc, x.data_ptr(), Cc, mean.data_ptr(), invstd.data_ptr(), ms.data_ptr(),
-                                            mh.data_ptr(), M, Cc, sums.data_ptr(), ws.data_ptr(), ws.numel(), N.stream_ptr())
+                                            mh.data_ptr(), 0.0, M, Cc, sums.data_ptr(), ws.data_ptr(), ws.numel(), N.stream_ptr())
             if rc == N.VP_EUNSUP:                     # (misaligned views: materialise the mask the plain way)
                 yr = torch.empty_like(x)
                 _chk(lib.vp_affine_rows_f32(hctx, x.data_ptr(), Cc, ms.data_ptr(), mh.data_ptr(), M, Cc, yr.data_ptr(), Cc, 1, N.stream_ptr()), hctx)
@@ -1248,7 +1248,7 @@ class BNRows(torch.autograd.Function):
                 _chk(rc, hctx)
                 dx = torch.empty_like(x)
                 _chk(lib.vp_bn_relu_bwd_masked_f32(hctx, dy.data_ptr(), Cc, x.data_ptr(), Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
-                                                   sums.data_ptr(), ms.data_ptr(), mh.data_ptr(), M, Cc, dx.data_ptr(), Cc, N.stream_ptr()), hctx)
+                                                   sums.data_ptr(), ms.data_ptr(), mh.data_ptr(), 0.0, M, Cc, dx.data_ptr(), Cc, N.stream_ptr()), hctx)
                 return dx, sums[1], sums[0], None, None, None, None, None
         if yr is not None:
             t = torch.empty_like(dy)
@@ -1471,6 +1471,7 @@ class Conv2dBlock(torch.autograd.Function):
         _chk(lib.vp_conv1d_fwd(hctx, C.byref(d), N.stream_ptr()), hctx)
         mean = invstd = None
         y = z
+        clamp = 0
         if bn:
             zeros, ones = _const(0.0, Cout, x.device), _const(1.0, Cout, x.device)
             sums = col_sums(z, z, zeros, ones)
@@ -1480,17 +1481,21 @@ class Conv2dBlock(torch.autograd.Function):
                                           run_var.data_ptr() if run_var is not None else None, cfg.get('momentum', 0.9),
                                           cfg.get('eps', 1e-5), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
                                           shift.data_ptr(), N.stream_ptr()), hctx)
+            # ReLU and Hardtanh(0, 20) (ERes2Net's "ReLU", eres2net.py:14-22) leave with the apply pass; the other activations get their own
+            clamp = {N.VP_ACT_RELU: 1, N.VP_ACT_HARDTANH20: 2}.get(act, 0)
+            if clamp == 2 and os.environ.get('VPMI_BN_RELU_UNFOLDED'):
+                clamp = 0
             y = torch.empty_like(z)
             _chk(lib.vp_affine_rows_f32(hctx, z.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(), z.shape[0], Cout, y.data_ptr(),
-                                        Cout, int(act == N.VP_ACT_RELU), N.stream_ptr()), hctx)
+                                        Cout, clamp, N.stream_ptr()), hctx)
         pre = y                                       # the activation's input (SiLU's backward needs it)
-        if act and not (bn and act == N.VP_ACT_RELU):
+        if act and not (bn and clamp):
             y = torch.empty_like(pre)
             _chk(lib.vp_act_f32(hctx, act, pre.data_ptr(), pre.numel(), y.data_ptr(), N.stream_ptr()), hctx)
-        # BatchNorm -> ReLU: the backward folds the ReLU mask into the BatchNorm-backward passes (it re-evaluates z * scale + shift > 0);
-        # then the output is not kept for backward
-        fold = bn and act == N.VP_ACT_RELU and Cout % 4 == 0 and not os.environ.get('VPMI_BN_RELU_UNFOLDED')
-        ctx.fold = (scale, shift) if fold else None
+        # BatchNorm -> ReLU / Hardtanh: the backward folds the activation's mask into the BatchNorm-backward passes (they re-evaluate
+        # 0 < z * scale + shift [< 20]); then the output is not kept for backward
+        fold = bn and clamp and Cout % 4 == 0 and not os.environ.get('VPMI_BN_RELU_UNFOLDED')
+        ctx.fold = (scale, shift, 20.0 if clamp == 2 else 0.0) if fold else None
         ctx.save_for_backward(x, weight, z, mean, invstd, gamma, None if fold else ((pre if act == N.VP_ACT_SILU else y) if act else None))
         ctx.geom = (B, T, Fq, To, Fo, Cin, Cout, KT, KF, s, pad, act, bn, bias is not None)
         return y
@@ -1505,15 +1510,15 @@ class Conv2dBlock(torch.autograd.Function):
         M = B * To * Fo
         fold = getattr(ctx, 'fold', None)
         if fold is not None:                          # BatchNorm -> ReLU with the mask folded into the two passes below
-            ms, mh = fold
+            ms, mh, hi = fold
             sums = torch.empty((2, Cout), dtype=torch.float32, device=dev)
             ws = _bytes(lib.vp_col_sums_workspace_bytes(M, Cout), dev)
             rc = lib.vp_col_sums_masked_f32(hctx, dy.data_ptr(), Cout, z.data_ptr(), Cout, mean.data_ptr(), invstd.data_ptr(), ms.data_ptr(),
-                                            mh.data_ptr(), M, Cout, sums.data_ptr(), ws.data_ptr(), ws.numel(), N.stream_ptr())
+                                            mh.data_ptr(), hi, M, Cout, sums.data_ptr(), ws.data_ptr(), ws.numel(), N.stream_ptr())
             if rc == N.VP_EUNSUP:                     # (misaligned views: materialise the mask the plain way)
                 yr = torch.empty_like(z)
-                _chk(lib.vp_affine_rows_f32(hctx, z.data_ptr(), Cout, ms.data_ptr(), mh.data_ptr(), M, Cout, yr.data_ptr(), Cout, 1,
-                                            N.stream_ptr()), hctx)
+                _chk(lib.vp_affine_rows_f32(hctx, z.data_ptr(), Cout, ms.data_ptr(), mh.data_ptr(), M, Cout, yr.data_ptr(), Cout,
+                                            2 if hi else 1, N.stream_ptr()), hctx)
                 fold = None
             else:
                 _chk(rc, hctx)
@@ -1521,7 +1526,7 @@ class Conv2dBlock(torch.autograd.Function):
             dgamma, dbeta = sums[1], sums[0]
             dz = torch.empty_like(dy)
             _chk(lib.vp_bn_relu_bwd_masked_f32(hctx, dy.data_ptr(), Cout, z.data_ptr(), Cout, mean.data_ptr(), invstd.data_ptr(),
-                                               gamma.data_ptr(), sums.data_ptr(), ms.data_ptr(), mh.data_ptr(), M, Cout, dz.data_ptr(), Cout,
+                                               gamma.data_ptr(), sums.data_ptr(), ms.data_ptr(), mh.data_ptr(), hi, M, Cout, dz.data_ptr(), Cout,
                                                N.stream_ptr()), hctx)
             bn = False                                # (done)
         elif relu:                                    # `relu` holds the activation code here
