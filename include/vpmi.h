@@ -590,6 +590,10 @@ int vp_conv1d_wgrad_f32(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, i
 int vp_conv1d_wgrad_oik_f32(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int lddz, float* dW, void* ws, size_t ws_bytes,
                             vp_stream stream);
 int vp_conv_weight_layouts_f32(vp_ctx* ctx, const float* w, int Cout, int Cin, int KW, float* wp, float* w2, vp_stream stream);
+/* The same pair of panels for a 2-D conv (nn.Conv2D weights are (Cout, Cin, KF, KT): resnet_se.py, eres2net.py, campplus.py FCM): the kernels'
+ * tap order is kt * KF + kf, so wp is (Cout, KT, KF, Cin) and w2 (Cin, KT, KF, Cout) with both tap axes reversed.  With a 2-D descriptor
+ * (KF > 1) vp_conv1d_wgrad_oik_f32 likewise reduces straight into (Cout, Cin, KF, KT). */
+int vp_conv2d_weight_layouts_f32(vp_ctx* ctx, const float* w, int Cout, int Cin, int KF, int KT, float* wp, float* w2, vp_stream stream);
 /* vp_prep_weights_bf16: for n f32 matrices w[i] (rows[i] x cols[i], row pitch ld[i] >= cols[i] -- HOST arrays of n entries): the bf16 copy
  * w16[i] [rows][cols] and / or the bf16 transpose wt16[i] [cols][rows] (either may be NULL) in one launch per 24 matrices -- the forward and
  * data-gradient weight panels of every wide 1x1 layer of a mixed-precision step (paddle.amp.auto_cast casts each conv's weight at each

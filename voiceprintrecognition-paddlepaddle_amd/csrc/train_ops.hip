@@ -407,15 +407,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_n64_kernel(WgradArgs a) {
 // out[i] = sum_k part[k][i]: 16 outputs x 16 partial-lanes per workgroup, fixed order (one thread walking all S partials
 // serially took 33 us per call -- 3.6 ms of a 39 ms training step over ~110 calls)
 // (KW > 1: the weight gradient leaves in the model's (Cout, Cin, KW) layout: partial index (o, tap, c) -> (o, c, tap))
-__device__ __forceinline__ long long oik_index(long long idx, int Cin, int KW) {
+// (2-D convs, KF > 1: the partial's tap index is kt * KF + kf -- the forward kernel's order -- the model's is kf * KT + kt)
+__device__ __forceinline__ long long oik_index(long long idx, int Cin, int KW, int KF = 1) {
     if (KW <= 1) return idx;
     const long long o = idx / ((long long)KW * Cin);
     const int r = (int)(idx - o * KW * Cin);
-    const int j = r / Cin, c = r - j * Cin;
+    int j = r / Cin;
+    const int c = r - j * Cin;
+    if (KF > 1) j = (j % KF) * (KW / KF) + j / KF;
     return (o * Cin + c) * KW + j;
 }
 
-__global__ __launch_bounds__(256) void sum_partials_kernel(const float* part, int S, long long n, float* out, int Cin, int KW) {
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* part, int S, long long n, float* out, int Cin, int KW, int KF) {
     __shared__ float sm[16][17];
     part += (size_t)blockIdx.y * S * n;               // batched weight gradients: one (S, n) slab and one output per blockIdx.y
     out += (size_t)blockIdx.y * n;
@@ -439,28 +442,32 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* part, in
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += sm[k][ol];
-        out[oik_index(idx, Cin, KW)] = t;
+        out[oik_index(idx, Cin, KW, KF)] = t;
     }
 }
 
-__global__ __launch_bounds__(256) void sum_partials_wide_kernel(const float* part, int S, long long n, float* out, int Cin, int KW) {
+__global__ __launch_bounds__(256) void sum_partials_wide_kernel(const float* part, int S, long long n, float* out, int Cin, int KW, int KF) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     part += (size_t)blockIdx.y * S * n;
     out += (size_t)blockIdx.y * n;
     float s = 0.f;
     for (int k = 0; k < S; ++k) s += part[(size_t)k * n + i];
-    out[oik_index(i, Cin, KW)] = s;
+    out[oik_index(i, Cin, KW, KF)] = s;
 }
 
 // wp[o][tap * Cin + c] = w[o][c][tap] (the forward kernel's weight panel) and w2[c][(KW - 1 - tap) * Cout + o] = w[o][c][tap]
-// (the data-gradient conv's: taps reversed, channel roles swapped) from the model's (Cout, Cin, KW) tensor in one launch
-__global__ __launch_bounds__(256) void weight_layouts_kernel(const float* w, int Cout, int Cin, int KW, float* wp, float* w2) {
+// (the data-gradient conv's: taps reversed, channel roles swapped) from the model's (Cout, Cin, KW) tensor in one launch.
+// 2-D (KF > 1): the model stores (Cout, Cin, KF, KT), tap kf * KT + kt; the kernels' tap order is kt * KF + kf (KW = KF * KT taps).
+__global__ __launch_bounds__(256) void weight_layouts_kernel(const float* w, int Cout, int Cin, int KW, int KF, float* wp, float* w2) {
     const long long n = (long long)Cout * Cin * KW;
+    const int KT = KW / KF;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const int o = (int)(i / ((long long)Cin * KW));
         const int r = (int)(i - (long long)o * Cin * KW);
-        const int c = r / KW, j = r - c * KW;
+        const int c = r / KW;
+        int j = r - c * KW;
+        if (KF > 1) j = (j % KT) * KF + j / KT;
         const float v = w[i];
         if (wp) wp[((size_t)o * KW + j) * Cin + c] = v;
         if (w2) w2[((size_t)c * KW + (KW - 1 - j)) * Cout + o] = v;
@@ -1439,9 +1446,10 @@ static bool getenv_once(const char* name) {       // A/B switches: read at first
     return v;
 }
 
-static void launch_sum_partials(const float* part, int S, long long n, float* out, hipStream_t st, int Cin = 1, int KW = 1, int batch = 1) {
-    if (n >= 32768) hipLaunchKernelGGL(sum_partials_wide_kernel, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, st, part, S, n, out, Cin, KW);
-    else hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n + 15) / 16), batch), dim3(256), 0, st, part, S, n, out, Cin, KW);
+static void launch_sum_partials(const float* part, int S, long long n, float* out, hipStream_t st, int Cin = 1, int KW = 1, int batch = 1,
+                                int KF = 1) {
+    if (n >= 32768) hipLaunchKernelGGL(sum_partials_wide_kernel, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, st, part, S, n, out, Cin, KW, KF);
+    else hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n + 15) / 16), batch), dim3(256), 0, st, part, S, n, out, Cin, KW, KF);
 }
 
 extern "C" {
@@ -1543,7 +1551,7 @@ static int wgrad_impl(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int
     }
     VP_LAUNCH_CHECK(ctx, "conv_wgrad");
     const long long n = (long long)d->Cout * K;
-    launch_sum_partials((const float*)ws, S, n, dW, st, d->Cin, oik ? d->KW : 1, nbatch);
+    launch_sum_partials((const float*)ws, S, n, dW, st, d->Cin, oik ? d->KW : 1, nbatch, (oik && two_d) ? d->KF : 1);
     VP_LAUNCH_CHECK(ctx, "wgrad_reduce");
     return VP_OK;
 }
@@ -1576,9 +1584,17 @@ int vp_conv1d_wgrad_bf16_oik_batched(vp_ctx* ctx, const vp_conv1d_desc* d, const
 
 int vp_conv_weight_layouts_f32(vp_ctx* ctx, const float* w, int Cout, int Cin, int KW, float* wp, float* w2, vp_stream stream) {
     if (!ctx || !w || (!wp && !w2) || Cout <= 0 || Cin <= 0 || KW <= 0) VP_FAIL(ctx, VP_EINVAL, "weight_layouts: bad arguments");
-    hipLaunchKernelGGL(weight_layouts_kernel, dim3(grid1d((long long)Cout * Cin * KW)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, KW,
+    hipLaunchKernelGGL(weight_layouts_kernel, dim3(grid1d((long long)Cout * Cin * KW)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, KW, 1,
                        wp, w2);
     VP_LAUNCH_CHECK(ctx, "weight_layouts");
+    return VP_OK;
+}
+
+int vp_conv2d_weight_layouts_f32(vp_ctx* ctx, const float* w, int Cout, int Cin, int KF, int KT, float* wp, float* w2, vp_stream stream) {
+    if (!ctx || !w || (!wp && !w2) || Cout <= 0 || Cin <= 0 || KF <= 0 || KT <= 0) VP_FAIL(ctx, VP_EINVAL, "weight_layouts_2d: bad arguments");
+    hipLaunchKernelGGL(weight_layouts_kernel, dim3(grid1d((long long)Cout * Cin * KF * KT)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin,
+                       KF * KT, KF, wp, w2);
+    VP_LAUNCH_CHECK(ctx, "weight_layouts_2d");
     return VP_OK;
 }
 

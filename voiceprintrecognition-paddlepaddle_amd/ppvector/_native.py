@@ -265,6 +265,7 @@ _PROTOS = {
     'vp_conv1d_wgrad_f32': (c_int, [c_void_p, C.POINTER(Conv1dDesc), c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'vp_conv1d_wgrad_oik_f32': (c_int, [c_void_p, C.POINTER(Conv1dDesc), c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'vp_conv_weight_layouts_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'vp_conv2d_weight_layouts_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'vp_col_sums_workspace_bytes': (c_size_t, [C.c_longlong, c_int]),
     'vp_col_sums_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, C.c_longlong, c_int, c_void_p,
                                 c_void_p, c_size_t, c_void_p]),

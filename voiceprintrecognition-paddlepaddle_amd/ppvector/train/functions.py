@@ -54,6 +54,15 @@ def _f32c(t):
     return t.contiguous()
 
 
+def _f32_rows(t):
+    """_f32c, except that a column slice of a wider f32 tensor (unit channel stride, 16-byte aligned rows) is taken as it is: the conv
+    kernels read their input with a row pitch (Conv1dDesc.ldx), so a chunk of a torch.split needs no copy."""
+    if (t.dtype == torch.float32 and t.is_cuda and t.dim() == 2 and not getattr(t, '_vp_bf16_only', False) and t.stride(1) == 1
+            and t.stride(0) >= t.shape[1] and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0):
+        return t
+    return _f32c(t)
+
+
 def _conv_desc(x, B, T_in, T_out, Cin, Cout, KW, dil, pad_mode, pad_left, w, bias=None, rowbias=None, relu=False):
     d = N.Conv1dDesc()
     d.dtype_in = d.dtype_out = N.VP_F32
@@ -1452,7 +1461,7 @@ class Conv2dBlock(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, run_mean, run_var, cfg):
         lib, hctx = N.lib(), N.ctx(x.device)
-        x, weight = _f32c(x), _f32c(weight)
+        x, weight = _f32_rows(x), _f32c(weight)
         B, T, Fq = cfg['B'], cfg['T'], cfg['F']
         st, sf = cfg.get('stride_t', cfg.get('stride', 1)), cfg.get('stride_f', cfg.get('stride', 1))
         dil = cfg.get('dilation', 1)                       # along time
@@ -1463,7 +1472,15 @@ class Conv2dBlock(torch.autograd.Function):
         act = {None: 0, 'relu': N.VP_ACT_RELU, 'hardtanh': N.VP_ACT_HARDTANH20, 'silu': N.VP_ACT_SILU, 'tanh': N.VP_ACT_TANH}[
             cfg.get('act', 'relu' if cfg.get('relu', False) else None)]
         relu, bn = act != 0, gamma is not None
-        wp = weight.permute(0, 3, 2, 1).reshape(Cout, KT * KF * Cin).contiguous()
+        w2 = None
+        if KT * KF > 1:     # the forward panel (Cout, kt, kf, Cin) and the data-gradient one (Cin, reversed kt, reversed kf, Cout) in one launch
+            wp = torch.empty((Cout, KT * KF * Cin), dtype=torch.float32, device=x.device)
+            if ctx.needs_input_grad[0]:
+                w2 = torch.empty((Cin, KT * KF * Cout), dtype=torch.float32, device=x.device)
+            _chk(lib.vp_conv2d_weight_layouts_f32(hctx, weight.data_ptr(), Cout, Cin, KF, KT, wp.data_ptr(),
+                                                  w2.data_ptr() if w2 is not None else None, N.stream_ptr()), hctx)
+        else:
+            wp = weight.view(Cout, Cin)
         z = torch.empty((B * To * Fo, Cout), dtype=torch.float32, device=x.device)
         d = _conv_desc(x, B, T, To, Cin, Cout, KT * KF, dil, N.VP_PAD_ZERO, pad, wp, bias)
         d.F_in, d.F_out, d.KF, d.stride, d.stride_f, d.pad_f = Fq, Fo, KF, st, sf, padf
@@ -1496,13 +1513,13 @@ class Conv2dBlock(torch.autograd.Function):
         # 0 < z * scale + shift [< 20]); then the output is not kept for backward
         fold = bn and clamp and Cout % 4 == 0 and not os.environ.get('VPMI_BN_RELU_UNFOLDED')
         ctx.fold = (scale, shift, 20.0 if clamp == 2 else 0.0) if fold else None
-        ctx.save_for_backward(x, weight, z, mean, invstd, gamma, None if fold else ((pre if act == N.VP_ACT_SILU else y) if act else None))
+        ctx.save_for_backward(x, weight, z, mean, invstd, gamma, None if fold else ((pre if act == N.VP_ACT_SILU else y) if act else None), w2)
         ctx.geom = (B, T, Fq, To, Fo, Cin, Cout, KT, KF, s, pad, act, bn, bias is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight, z, mean, invstd, gamma, yr = ctx.saved_tensors
+        x, weight, z, mean, invstd, gamma, yr, w2 = ctx.saved_tensors
         B, T, Fq, To, Fo, Cin, Cout, KT, KF, s, pad, relu, bn, has_bias = ctx.geom
         lib, hctx = N.lib(), N.ctx(x.device)
         dev = x.device
@@ -1546,10 +1563,9 @@ class Conv2dBlock(torch.autograd.Function):
         st, sf, dil, padf = s
         d = _conv_desc(x, B, T, To, Cin, Cout, KT * KF, dil, N.VP_PAD_ZERO, pad, weight)
         d.F_in, d.F_out, d.KF, d.stride, d.stride_f, d.pad_f = Fq, Fo, KF, st, sf, padf
-        dwp = torch.empty((Cout, KT * KF * Cin), dtype=torch.float32, device=dev)
+        dW = torch.empty((Cout, Cin, KF, KT), dtype=torch.float32, device=dev)       # reduced straight into the model's layout
         ws = _bytes(lib.vp_conv1d_wgrad_workspace_bytes(C.byref(d)), dev)
-        _chk(lib.vp_conv1d_wgrad_f32(hctx, C.byref(d), dz.data_ptr(), Cout, dwp.data_ptr(), ws.data_ptr(), ws.numel(), N.stream_ptr()), hctx)
-        dW = dwp.view(Cout, KT, KF, Cin).permute(0, 3, 2, 1).contiguous()
+        _chk(lib.vp_conv1d_wgrad_oik_f32(hctx, C.byref(d), dz.data_ptr(), Cout, dW.data_ptr(), ws.data_ptr(), ws.numel(), N.stream_ptr()), hctx)
         dx = None
         if ctx.needs_input_grad[0]:
             src = dz
@@ -1557,7 +1573,8 @@ class Conv2dBlock(torch.autograd.Function):
             if strided:                                 # zero-insertion: the strided data gradient as a stride-1 conv
                 src = torch.empty((B * T * Fq, Cout), dtype=torch.float32, device=dev)
                 _chk(lib.vp_zero_insert_2d_f32(hctx, dz.data_ptr(), B, To, Fo, Cout, T, Fq, st, sf, src.data_ptr(), N.stream_ptr()), hctx)
-            w2 = (weight if KT * KF == 1 else weight.flip(2, 3)).permute(1, 3, 2, 0).reshape(Cin, KT * KF * Cout).contiguous()
+            if w2 is None:                              # 1x1: W^T
+                w2 = weight.view(Cout, Cin).t().contiguous()
             dx = torch.empty((B * T * Fq, Cin), dtype=torch.float32, device=dev)
             Ts, Fs = (T, Fq) if strided else (To, Fo)
             d2 = _conv_desc(src, B, Ts, T, Cout, Cin, KT * KF, dil, N.VP_PAD_ZERO, dil * (KT - 1) - pad, w2)
