@@ -4,14 +4,17 @@
 //     out[b, t]  = y[b, t] * m[b, seg(t)]                                             (y = linear_local(h), computed by the conv GEMM)
 // The unfused tape runs this as a segment-mean pass, two 1x1 convs over B * nseg rows (128 rows at B = 64: one GEMM tile each) and a
 // scale pass forward, and ~16 launches backward (activation backward, bias sums, weight and data gradient of each tiny conv, the two
-// segment passes, autograd's add of the two gradients of h).  Here: ONE launch forward, TWO backward, one workgroup per utterance --
-// the two dense layers are a few thousand multiply-adds per utterance and live in LDS between the segment means and the gate.
+// segment passes, autograd's add of the two gradients of h).  Here: ONE launch forward, TWO backward, one workgroup of 1 024 threads per
+// utterance -- the two dense layers are a few thousand multiply-adds per utterance and live in LDS (weights included, when they fit)
+// between the segment means and the gate.  The passes are latency-bound (150 frames x 128 channels per utterance at the bench shape), so
+// the rows are spread over all 16 waves (float4 per thread) and reduced through LDS in a fixed order: 15 / 15 / 4 us per layer at B = 64
+// (a first version with 256 threads and scalar loads: 51 / 38 / 27 us).
 //   forward : cam_gate_fwd_kernel      -> out, and ctx / hid / m kept for backward
 //   backward: cam_gate_bwd_kernel      -> d y (= g * m), the gradient that reaches h THROUGH THE CONTEXT (the caller hands it to the local
 //                                         conv's data-gradient GEMM as its epilogue addend), d pre-activations of both dense layers,
 //                                         per-utterance column sums of d y (the local conv's bias gradient)
-//             cam_gate_wgrad_kernel    -> d W1, d b1, d W2, d b2, d bias of the local conv: sums over the B * nseg rows / B utterances in
-//                                         row order (deterministic)
+//             cam_gate_wgrad_kernel    -> d W1, d b1, d W2, d b2, d bias of the local conv: sums over the B * nseg rows / B utterances, each
+//                                         output by 8 lanes (row r to lane r % 8) folded by three shuffles -- a fixed order, no atomics
 // f32 throughout (these layers hold < 0.1 % of a CAM++ step's flops; under enable_amp the unfused 1x1 convs round their operands to bf16,
 // this path does not).
 #include "common.h"
