@@ -850,7 +850,8 @@ int vp_col_sums_masked_f32(vp_ctx* ctx, const float* a, int lda, const float* b,
                            size_t ws_bytes, vp_stream stream);
 int vp_bn_relu_bwd_masked_f32(vp_ctx* ctx, const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* invstd,
                               const float* gamma, const float* sums, const float* mask_scale, const float* mask_shift, float mask_hi,
-                              long long M, int C, float* dz, int lddz, vp_stream stream);
+                              long long M, int C, float* dz, int lddz, int accumulate /* dz += : a DenseNet block's shared gradient buffer */,
+                              vp_stream stream);
 int vp_scale_rows_bwd_f32(vp_ctx* ctx, const float* dy, const float* x, const float* s, int B, int T, int C, float* dx, float* ds,
                           vp_stream stream);
 /* The same for utterances of many positions (the (B, T*F', C) feature maps of ResNetSE / ERes2Net, resnet_se.py:60-75): positions spread over

@@ -647,6 +647,55 @@ def test_cam_layer_as_one_tape_entry_vs_float64(N, case):
         assert ea < max(3 * eb, 5e-6), (nm, ea, eb)
 
 
+def test_cam_dense_block_on_one_buffer_vs_concatenations(N):
+    """CamDenseBlockFn (a CAMDenseTDNNBlock on one preallocated buffer, one gradient buffer backward) against the per-layer tape with
+    torch.cat (VPMI_CAM_BLOCK_UNFUSED=1): the forward runs the same kernels on the same values (embeddings equal), the backward adds
+    the layers' input gradients in a different order (f32 rounding only)."""
+    from oracle import campplus as oc
+    from ppvector.models.campplus import CAMPPlus
+    from ppvector.train.functions import HeadLoss
+    B, T, Cc = 6, 230, 8
+    p = oc.campplus_params(80, 192, seed=23)
+    g = torch.Generator().manual_seed(24)
+    x = (torch.randn(B, T, 80, generator=g) * 2).cuda()
+    labels = torch.randint(0, Cc, (B,), generator=g).cuda()
+    Wh = om.head_params(192, Cc, seed=6)
+    res = {}
+    for unfused in (False, True):
+        if unfused:
+            os.environ['VPMI_CAM_BLOCK_UNFUSED'] = '1'
+        try:
+            m = CAMPPlus(80, embd_dim=192)
+            m.load_state_dict(p)
+            m = m.cuda().train()
+            Wd = Wh.clone().cuda().requires_grad_()
+            emb = m(x)
+            loss = HeadLoss.apply(emb, Wd, labels, 0.2, 32.0, 0.0, False)[0]
+            loss.backward()
+            res[unfused] = (emb.detach(), {k: v.grad.clone() for k, v in m.named_parameters()}, {k: v.clone() for k, v in m.named_buffers()})
+            m.eval()
+        finally:
+            os.environ.pop('VPMI_CAM_BLOCK_UNFUSED', None)
+    assert rel(res[False][0], res[True][0]) < 1e-6
+    for k, v in res[True][2].items():                                  # running statistics: the same finalize launches
+        assert rel(res[False][2][k].float(), v.float()) < 1e-6, k
+    gscale = max(v.abs().max().item() for v in res[True][1].values())
+    num = den = 0.0
+    worst, wk = 0.0, ''
+    for k, ref in res[True][1].items():
+        got = res[False][1][k]
+        if ref.norm().item() < 1e-6 * gscale * ref.numel() ** 0.5:     # a bias in front of a BatchNorm: rounding noise on both sides
+            continue
+        num += (got.double() - ref.double()).pow(2).sum().item()
+        den += ref.double().pow(2).sum().item()
+        r = rel(got, ref)
+        if r > worst:
+            worst, wk = r, k
+    print(f'[cam dense block] one buffer vs torch.cat per layer: embeddings {rel(res[False][0], res[True][0]):.1e}, whole gradient rel-L2 '
+          f'{(num / den) ** 0.5:.2e}, worst tensor {worst:.2e} ({wk})')
+    assert (num / den) ** 0.5 < 1e-3 and worst < 2e-2
+
+
 def test_placeholder_read_as_data_is_loud(N):
     """An activation that exists as bf16 only travels on the tape as an f32 placeholder that owns ONE element, its values on the
     `_vp_bf16` attribute (functions._placeholder).  A consumer that forgets _f32c / _only16 and reads the placeholder itself must not

@@ -759,6 +759,7 @@ struct BnBwdArgs {
     const float* us; const float* um; int T; float inv_t;      // bn_relu_bwd_dbias_kernel<.., UTT>: d y = dy * us[b] + um[b] * inv_t, b = row / T
     const float* xsc; const float* xsh;                        // UTT == 2: d y = dy + us[b] + um[b] * bf16(z * xsc + xsh) (see ColSum4Args)
     float mask_hi;                                             // with ms / mh: ... and z * ms + mh < mask_hi (0: no upper bound)
+    int accumulate;                                            // bn_relu_bwd_kernel: dz += (a DenseNet block's shared gradient buffer, campplus.py:168-171)
 };
 
 __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdArgs a) {
@@ -785,6 +786,12 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdArgs a) {
             const float zh = (z[e] - mu[e]) * is[e];
             const float v = g[e] * is[e] * (dy[e] - s1[e] * invM - zh * s2[e] * invM);
             o[e] = (a.relu_mask && !(z[e] > 0.f)) ? 0.f : v;
+        }
+        if (a.accumulate) {
+            float old[4];
+            vp_load4(a.dz + m * a.lddz + c, old);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += old[e];
         }
         vp_store4(a.dz + m * a.lddz + c, o);
     }
@@ -1791,12 +1798,13 @@ int vp_bn_relu_bwd_f32(vp_ctx* ctx, const float* dy, int lddy, const float* z, i
 // BatchNorm backward with a ReLU BEHIND the BatchNorm folded in (see vp_col_sums_masked_f32): d y counts only where z * mask_scale + mask_shift > 0
 int vp_bn_relu_bwd_masked_f32(vp_ctx* ctx, const float* dy, int lddy, const float* z, int ldz, const float* mean, const float* invstd,
                               const float* gamma, const float* sums, const float* mask_scale, const float* mask_shift, float mask_hi,
-                              long long M, int C, float* dz, int lddz, vp_stream stream) {
+                              long long M, int C, float* dz, int lddz, int accumulate, vp_stream stream) {
     if (!ctx || !dy || !z || !mean || !invstd || !sums || !dz || !mask_scale || !mask_shift || mask_hi < 0.f || M <= 0 || C <= 0 ||
         (C | lddy | ldz | lddz) & 3)
         VP_FAIL(ctx, VP_EINVAL, "bn_relu_bwd_masked: bad arguments");
     BnBwdArgs a{dy, z, mean, invstd, gamma, sums, dz, lddy, ldz, lddz, C / 4, 0, M, mask_scale, mask_shift};
     a.mask_hi = mask_hi;
+    a.accumulate = accumulate != 0;
     hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(grid1d(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
     VP_LAUNCH_CHECK(ctx, "bn_relu_bwd_masked");
     return VP_OK;

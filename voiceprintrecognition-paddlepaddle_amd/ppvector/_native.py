@@ -175,7 +175,7 @@ _PROTOS = {
     'vp_col_sums_masked_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, C.c_float, C.c_longlong,
                                c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'vp_bn_relu_bwd_masked_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                  C.c_float, C.c_longlong, c_int, c_void_p, c_int, c_void_p]),
+                                  C.c_float, C.c_longlong, c_int, c_void_p, c_int, c_int, c_void_p]),
     'vp_res2_train_workspace_bytes': (c_size_t, [c_int, c_int]),
     'vp_res2_train_fwd': (c_int, [c_void_p, C.POINTER(Res2TrainDesc), c_void_p, c_size_t, c_void_p]),
     'vp_res2_train_bwd': (c_int, [c_void_p, C.POINTER(Res2TrainDesc), c_void_p, c_size_t, c_void_p]),

@@ -1,11 +1,12 @@
 """Training-mode forward of CAM++ (ppvector/models/campplus.py:331-335) through the autograd functions of functions.py.
 Activations are position-major: (B*T*F, C) in the FCM head, (B*T, C) in the D-TDNN.  The DenseNet concatenations are
-torch.cat; every conv / BatchNorm / activation / context gate / pooling runs in libvpmi.  A CAMLayer (local conv + context gate) is ONE
-tape entry (functions.py: CamLayerFn; VPMI_CAM_LAYER_UNFUSED=1 keeps the per-op form the tests compare it with).
+ONE buffer per dense block (functions.py: CamDenseBlockFn -- no torch.cat; VPMI_CAM_BLOCK_UNFUSED=1: torch.cat per layer); every conv /
+BatchNorm / activation / context gate / pooling runs in libvpmi.  A CAMLayer (local conv + context gate) is ONE tape entry
+(CamLayerFn; VPMI_CAM_LAYER_UNFUSED=1 keeps the per-op form the tests compare it with).
 Input (B, T, F) f32 on the GPU -> embeddings (B, embd_dim)."""
 import torch
 
-from ppvector.train.functions import Act, BNRows, CamLayerFn, Conv2dBlock, ConvBlock, SegCtx, SegScale, TimeStats
+from ppvector.train.functions import Act, BNRows, CamDenseBlockFn, CamLayerFn, Conv2dBlock, ConvBlock, SegCtx, SegScale, TimeStats
 
 SEG_LEN = 100       # CAMLayer.seg_pooling default (campplus.py:96)
 
@@ -76,6 +77,17 @@ def cam_dense_layer(lay, x, B, T):
     return SegScale.apply(y, m, B, T, SEG_LEN)
 
 
+def dense_block(layers, x, B, T):
+    """CAMDenseTDNNBlock (campplus.py:137-171) as ONE tape entry on one preallocated buffer (functions.CamDenseBlockFn)."""
+    params, bufs = [], []
+    for lay in layers:
+        bn1, bn2, cl = lay.nonlinear1.batchnorm, lay.nonlinear2.batchnorm, lay.cam_layer
+        params += [bn1.weight, bn1.bias, lay.linear1.weight, lay.linear1.bias, bn2.weight, bn2.bias, cl.linear_local.weight, cl.linear_local.bias,
+                   cl.linear1.weight, cl.linear1.bias, cl.linear2.weight, cl.linear2.bias]
+        bufs.append((bn1._mean, bn1._variance, bn1.momentum, bn1.eps, bn2._mean, bn2._variance, bn2.momentum, bn2.eps, cl.dilation))
+    return CamDenseBlockFn.apply(x, dict(B=B, T=T, seg_len=SEG_LEN, bufs=bufs), *params)
+
+
 def campplus_forward_train(m, feats):
     B = feats.shape[0]
     x, T = fcm(m.head, feats)
@@ -87,8 +99,12 @@ def campplus_forward_train(m, feats):
     T = (T + 2 * 2 - 4 - 1) // td.stride + 1
     for bi, (nl, _, _) in enumerate(m.block_cfg, start=1):
         blk = getattr(xv, f'block{bi}')
-        for l in range(1, nl + 1):
-            x = torch.cat([x, cam_dense_layer(getattr(blk, f'tdnnd{l}'), x, B, T)], dim=1)
+        layers = [getattr(blk, f'tdnnd{l}') for l in range(1, nl + 1)]
+        if CamDenseBlockFn.usable(x, layers, T, SEG_LEN):
+            x = dense_block(layers, x, B, T)         # the whole block on one buffer (no torch.cat, one gradient buffer backward)
+        else:
+            for lay in layers:
+                x = torch.cat([x, cam_dense_layer(lay, x, B, T)], dim=1)
         tr = getattr(xv, f'transit{bi}')
         x = _c1x1(_bnrelu(x, tr.nonlinear.batchnorm), tr.linear, B, T)
     x = _bnrelu(x, xv.out_nonlinear.batchnorm)

@@ -1257,7 +1257,7 @@ class BNRows(torch.autograd.Function):
                 _chk(rc, hctx)
                 dx = torch.empty_like(x)
                 _chk(lib.vp_bn_relu_bwd_masked_f32(hctx, dy.data_ptr(), Cc, x.data_ptr(), Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
-                                                   sums.data_ptr(), ms.data_ptr(), mh.data_ptr(), 0.0, M, Cc, dx.data_ptr(), Cc, N.stream_ptr()), hctx)
+                                                   sums.data_ptr(), ms.data_ptr(), mh.data_ptr(), 0.0, M, Cc, dx.data_ptr(), Cc, 0, N.stream_ptr()), hctx)
                 return dx, sums[1], sums[0], None, None, None, None, None
         if yr is not None:
             t = torch.empty_like(dy)
@@ -1544,7 +1544,7 @@ class Conv2dBlock(torch.autograd.Function):
             dz = torch.empty_like(dy)
             _chk(lib.vp_bn_relu_bwd_masked_f32(hctx, dy.data_ptr(), Cout, z.data_ptr(), Cout, mean.data_ptr(), invstd.data_ptr(),
                                                gamma.data_ptr(), sums.data_ptr(), ms.data_ptr(), mh.data_ptr(), hi, M, Cout, dz.data_ptr(), Cout,
-                                               N.stream_ptr()), hctx)
+                                               0, N.stream_ptr()), hctx)
             bn = False                                # (done)
         elif relu:                                    # `relu` holds the activation code here
             t = torch.empty_like(dy)
@@ -1711,9 +1711,14 @@ class CamLayerFn(torch.autograd.Function):
         cx = torch.empty((B * nseg, Cc), dtype=torch.float32, device=dev)
         hid = torch.empty((B * nseg, H), dtype=torch.float32, device=dev)
         m = torch.empty((B * nseg, O), dtype=torch.float32, device=dev)
-        out = torch.empty((B * T, O), dtype=torch.float32, device=dev)
+        out = cfg.get('out_into')                    # a column slice of a DenseNet block's buffer (CamDenseBlockFn), or a tensor of its own
+        if out is None:
+            out = torch.empty((B * T, O), dtype=torch.float32, device=dev)
+        elif tuple(out.shape) != (B * T, O) or out.dtype != torch.float32 or out.stride(1) != 1:
+            raise ValueError('CamLayerFn: out_into does not match the layer output')
         _chk(lib.vp_cam_gate_fwd_f32(hctx, h.data_ptr(), Cc, y.data_ptr(), O, w1c.data_ptr(), b1.data_ptr(), w2c.data_ptr(), b2.data_ptr(),
-                                     B, T, Cc, H, O, seg_len, cx.data_ptr(), hid.data_ptr(), m.data_ptr(), out.data_ptr(), O, N.stream_ptr()), hctx)
+                                     B, T, Cc, H, O, seg_len, cx.data_ptr(), hid.data_ptr(), m.data_ptr(), out.data_ptr(), out.stride(0),
+                                     N.stream_ptr()), hctx)
         ctx.tape = tape
         ctx.save_for_backward(y, cx, hid, m, w1c, w2c)
         ctx.geom = (B, T, Cc, H, O, seg_len, nseg, bl is not None)
@@ -1750,3 +1755,93 @@ class CamLayerFn(torch.autograd.Function):
         tape.given_dbias = None              # (a second reference would make autograd COPY the gradient into .grad instead of adopting it)
         del dbl
         return r[0], r[1], r[2], dw1, db1, dw2, db2, None
+
+
+class CamDenseBlockFn(torch.autograd.Function):
+    """CAMDenseTDNNBlock (models/campplus.py:137-171: x = concat([x, layer(x)]) layer after layer) on ONE preallocated (B*T, C_final) buffer:
+    a layer reads its input as the first C_l columns of the buffer IN PLACE (row pitch C_final) and its CAMLayer writes its 32 output
+    channels into the next column slice -- no torch.cat; backward walks the layers in reverse over ONE gradient buffer: a layer's output
+    gradient is a column slice of it, and the layer's BatchNorm + ReLU backward ADDS its input gradient into the first C_l columns
+    (vp_bn_relu_bwd_masked_f32, accumulate) -- no narrow copies, none of autograd's strided adds of the concatenation's gradient.
+    Per layer (nonlinear1 -> linear1 -> nonlinear2 -> CAMLayer, campplus.py:108-134) the kernels are the ones the per-layer tape runs
+    (BNRows' passes, ConvBlock, CamLayerFn).  params: 12 per layer -- bn1 weight, bias; linear1 weight, bias; bn2 weight, bias;
+    cam_layer.linear_local weight, bias; .linear1 weight, bias; .linear2 weight, bias.  cfg['bufs'][l] = (bn1 running mean, variance,
+    momentum, eps, bn2 running mean, variance, momentum, eps, dilation)."""
+
+    @staticmethod
+    def usable(x, layers, T, seg_len):
+        if os.environ.get('VPMI_CAM_BLOCK_UNFUSED') or x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] % 4:
+            return False
+        for lay in layers:
+            cl = lay.cam_layer
+            wl = cl.linear_local.weight
+            if wl.shape[0] % 4 or lay.linear1.bias is None or cl.linear_local.bias is None:
+                return False
+            if not CamLayerFn.usable(x, wl, cl.linear1.weight, cl.linear2.weight, T, seg_len):
+                return False
+        return True
+
+    @staticmethod
+    def forward(ctx, x0, cfg, *params):
+        lib, hctx = N.lib(), N.ctx(x0.device)
+        B, T, seg_len, bufs = cfg['B'], cfg['T'], cfg['seg_len'], cfg['bufs']
+        x0 = _f32c(x0)
+        dev = x0.device
+        M, C0 = x0.shape
+        L = len(params) // 12
+        G = params[6].shape[0]
+        Cf = C0 + L * G
+        X = torch.empty((M, Cf), dtype=torch.float32, device=dev)
+        X[:, :C0].copy_(x0)
+        tapes = []
+        for l in range(L):
+            g1, be1, wl1, bl1, g2, be2, wloc, bloc, w1, b1, w2, b2 = params[12 * l:12 * l + 12]
+            rm1, rv1, mom1, eps1, rm2, rv2, mom2, eps2, dil = bufs[l]
+            Cl = C0 + l * G
+            # nonlinear1: BatchNorm (batch statistics) -> ReLU over the first Cl columns, read where they are
+            zeros, ones = _const(0.0, Cl, dev), _const(1.0, Cl, dev)
+            sums = torch.empty((2, Cl), dtype=torch.float32, device=dev)
+            ws = _bytes(lib.vp_col_sums_workspace_bytes(M, Cl), dev)
+            _chk(lib.vp_col_sums_f32(hctx, X.data_ptr(), Cf, X.data_ptr(), Cf, zeros.data_ptr(), ones.data_ptr(), M, Cl, sums.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), N.stream_ptr()), hctx)
+            mean, invstd, scale, shift = (torch.empty(Cl, dtype=torch.float32, device=dev) for _ in range(4))
+            _chk(lib.vp_bn_train_finalize(hctx, sums[0].data_ptr(), sums[1].data_ptr(), 1, M, Cl, g1.data_ptr(), be1.data_ptr(),
+                                          rm1.data_ptr() if rm1 is not None else None, rv1.data_ptr() if rv1 is not None else None, mom1, eps1,
+                                          mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), N.stream_ptr()), hctx)
+            h0 = torch.empty((M, Cl), dtype=torch.float32, device=dev)
+            _chk(lib.vp_affine_rows_f32(hctx, X.data_ptr(), Cf, scale.data_ptr(), shift.data_ptr(), M, Cl, h0.data_ptr(), Cl, 1,
+                                        N.stream_ptr()), hctx)
+            t2, t3, t4 = _Tape((True,) * 9), _Tape((True,) * 8), _Tape((True,) * 8)
+            z1 = ConvBlock.forward(t2, h0, wl1, bl1, None, None, None, None, None, dict(B=B, T=T))
+            h = BNRows.forward(t3, z1, g2, be2, rm2, rv2, mom2, eps2, True)
+            CamLayerFn.forward(t4, h, wloc, bloc, w1, b1, w2, b2, dict(B=B, T=T, seg_len=seg_len, dilation=dil, out_into=X[:, Cl:Cl + G]))
+            tapes.append((Cl, mean, invstd, scale, shift, g1, t2, t3, t4))
+        ctx.tapes = tapes
+        ctx.geom = (M, C0, G, L, Cf)
+        ctx.save_for_backward(X)
+        return X
+
+    @staticmethod
+    def backward(ctx, g):
+        (X,) = ctx.saved_tensors
+        M, C0, G, L, Cf = ctx.geom
+        lib, hctx = N.lib(), N.ctx(X.device)
+        dev = X.device
+        # ONE gradient buffer for the whole block, updated in place: the gradient of the block's output as its only consumer handed it over
+        Gb = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
+        grads = [None] * (12 * L)
+        for l in reversed(range(L)):
+            Cl, mean, invstd, scale, shift, g1, t2, t3, t4 = ctx.tapes[l]
+            r4 = CamLayerFn.backward(t4, Gb[:, Cl:Cl + G])
+            r3 = BNRows.backward(t3, r4[0])
+            r2 = _conv_block_bwd(t2, r3[0])
+            dh0 = r2[0]
+            sums = torch.empty((2, Cl), dtype=torch.float32, device=dev)
+            ws = _bytes(lib.vp_col_sums_workspace_bytes(M, Cl), dev)
+            _chk(lib.vp_col_sums_masked_f32(hctx, dh0.data_ptr(), Cl, X.data_ptr(), Cf, mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
+                                            shift.data_ptr(), 0.0, M, Cl, sums.data_ptr(), ws.data_ptr(), ws.numel(), N.stream_ptr()), hctx)
+            _chk(lib.vp_bn_relu_bwd_masked_f32(hctx, dh0.data_ptr(), Cl, X.data_ptr(), Cf, mean.data_ptr(), invstd.data_ptr(), g1.data_ptr(),
+                                               sums.data_ptr(), scale.data_ptr(), shift.data_ptr(), 0.0, M, Cl, Gb.data_ptr(), Cf, 1,
+                                               N.stream_ptr()), hctx)
+            grads[12 * l:12 * l + 12] = [sums[1], sums[0], r2[1], r2[2], r3[1], r3[2], r4[1], r4[2], r4[3], r4[4], r4[5], r4[6]]
+        return (Gb[:, :C0].contiguous(), None, *grads)
