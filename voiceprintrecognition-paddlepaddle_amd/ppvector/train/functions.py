@@ -1845,3 +1845,48 @@ class CamDenseBlockFn(torch.autograd.Function):
                                                N.stream_ptr()), hctx)
             grads[12 * l:12 * l + 12] = [sums[1], sums[0], r2[1], r2[2], r3[1], r3[2], r4[1], r4[2], r4[3], r4[4], r4[5], r4[6]]
         return (Gb[:, :C0].contiguous(), None, *grads)
+
+
+class SEDenseFn(torch.autograd.Function):
+    """s = sigmoid(W2 relu(W1 m + b1) + b2) over m (B, C): the two dense layers of a squeeze-excitation gate (resnet_se.py:48-63;
+    ecapa_tdnn.py:50-82 runs the same kernels inside SEBlockFn) as ONE launch forward and TWO backward (csrc/se_train.hip:
+    vp_se_dense_train_fwd / _bwd) instead of two conv-GEMM launches over B rows forward and ~14 launches backward (activation backward,
+    bias sums, weight and data gradient of each layer with their partial-sum stages).  w1 (H, C, 1), w2 (C, H, 1) contiguous f32."""
+
+    @staticmethod
+    def usable(m, w1, b1, w2, b2):
+        Cc, H = m.shape[1], w1.shape[0]
+        return (not os.environ.get('VPMI_SE_DENSE_UNFUSED') and m.dtype == torch.float32 and tuple(w1.shape) == (H, Cc, 1)
+                and tuple(w2.shape) == (Cc, H, 1) and Cc <= 1024 and H <= 1024 and Cc % 4 == 0 and H % 4 == 0 and b1 is not None and b2 is not None)
+
+    @staticmethod
+    def forward(ctx, m, w1, b1, w2, b2):
+        lib, hctx = N.lib(), N.ctx(m.device)
+        m, w1, b1, w2, b2 = (_f32c(t) for t in (m, w1, b1, w2, b2))
+        B, Cc = m.shape
+        H = w1.shape[0]
+        a = torch.empty((B, H), dtype=torch.float32, device=m.device)
+        s = torch.empty((B, Cc), dtype=torch.float32, device=m.device)
+        amp = int(ppvector.get_train_amp())
+        _chk(lib.vp_se_dense_train_fwd(hctx, m.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), B, Cc, H, amp,
+                                       a.data_ptr(), s.data_ptr(), N.stream_ptr()), hctx)
+        ctx.save_for_backward(m, a, s, w1, w2)
+        ctx.amp = amp
+        return s
+
+    @staticmethod
+    def backward(ctx, ds):
+        m, a, s, w1, w2 = ctx.saved_tensors
+        lib, hctx = N.lib(), N.ctx(m.device)
+        ds = _f32c(ds)
+        B, Cc = m.shape
+        H = w1.shape[0]
+        dm = torch.empty_like(m)
+        dw1, dw2 = torch.empty_like(w1), torch.empty_like(w2)
+        db1 = torch.empty(H, dtype=torch.float32, device=m.device)
+        db2 = torch.empty(Cc, dtype=torch.float32, device=m.device)
+        ws = _bytes(lib.vp_se_dense_train_bwd_workspace_bytes(B, Cc, H), m.device)
+        _chk(lib.vp_se_dense_train_bwd(hctx, ds.data_ptr(), m.data_ptr(), a.data_ptr(), s.data_ptr(), w1.data_ptr(), w2.data_ptr(), B, Cc, H,
+                                       ctx.amp, dm.data_ptr(), dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), ws.data_ptr(),
+                                       ws.numel(), N.stream_ptr()), hctx)
+        return dm, dw1, db1, dw2, db2

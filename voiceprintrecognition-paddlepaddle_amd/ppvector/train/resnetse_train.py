@@ -3,7 +3,7 @@ Activations are (B*T*F, C) position-major; the reference's reshape (B, C*F/8, T/
 of a small tensor (data movement).  Input (B, T, F) f32 on the GPU -> embeddings (B, embd_dim)."""
 import torch
 
-from ppvector.train.functions import Act, BNRows, Conv2dBlock, ConvBlock, SEScale, TimeStats
+from ppvector.train.functions import Act, BNRows, Conv2dBlock, ConvBlock, SEDenseFn, SEScale, TimeStats
 from ppvector.train.tdnn_train import asp_forward
 
 
@@ -26,8 +26,12 @@ def bottleneck(b, x, B, T, F):
     # SELayer (:48-63): global average over (F, T) -> Linear -> ReLU -> Linear -> sigmoid (paddle Linear weights are [in, out])
     y = TimeStats.apply(out, B, To * Fo)[:, :Cc]
     fc0, fc2 = b.se.fc[0], b.se.fc[2]
-    y = ConvBlock.apply(y, fc0.weight.t().unsqueeze(2), fc0.bias, None, None, None, None, None, dict(B=B, T=1, relu=True))
-    y = ConvBlock.apply(y, fc2.weight.t().unsqueeze(2), fc2.bias, None, None, None, None, None, dict(B=B, T=1, sigmoid=True))
+    w1, w2 = fc0.weight.t().unsqueeze(2), fc2.weight.t().unsqueeze(2)         # (H, C, 1), (C, H, 1)
+    if SEDenseFn.usable(y, w1, fc0.bias, w2, fc2.bias):
+        y = SEDenseFn.apply(y.contiguous(), w1.contiguous(), fc0.bias, w2.contiguous(), fc2.bias)      # one launch forward, two backward
+    else:
+        y = ConvBlock.apply(y, w1, fc0.bias, None, None, None, None, None, dict(B=B, T=1, relu=True))
+        y = ConvBlock.apply(y, w2, fc2.bias, None, None, None, None, None, dict(B=B, T=1, sigmoid=True))
     res = x
     if b.downsample is not None:
         dconv, dbn = b.downsample[0], b.downsample[1]
