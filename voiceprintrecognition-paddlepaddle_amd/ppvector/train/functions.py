@@ -1559,7 +1559,13 @@ class Conv2dBlock(torch.autograd.Function):
             dz = torch.empty_like(dy)
             _chk(lib.vp_bn_relu_bwd_f32(hctx, dy.data_ptr(), Cout, z.data_ptr(), Cout, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
                                         sums.data_ptr(), M, Cout, 0, dz.data_ptr(), Cout, N.stream_ptr()), hctx)
-        dbias = col_sums(dz)[0] if has_bias else None
+        # a conv bias directly in front of a train-mode BatchNorm: sum_rows dz is IDENTICALLY zero (dz = gamma invstd (dy - mean(dy) - zhat
+        # mean(dy zhat)), sum zhat = 0) -- what a column-sum pass returns there is rounding noise (1e-9 of the gradient scale, in the
+        # reference's autograd as here); the pass is not launched.  VPMI_BN_BIAS_GRAD_SUMS=1 runs it.
+        if has_bias and ctx.geom[12] and not os.environ.get('VPMI_BN_BIAS_GRAD_SUMS'):
+            dbias = torch.zeros(Cout, dtype=torch.float32, device=dev)
+        else:
+            dbias = col_sums(dz)[0] if has_bias else None
         st, sf, dil, padf = s
         d = _conv_desc(x, B, T, To, Cin, Cout, KT * KF, dil, N.VP_PAD_ZERO, pad, weight)
         d.F_in, d.F_out, d.KF, d.stride, d.stride_f, d.pad_f = Fq, Fo, KF, st, sf, padf
@@ -1812,7 +1818,9 @@ class CamDenseBlockFn(torch.autograd.Function):
             _chk(lib.vp_affine_rows_f32(hctx, X.data_ptr(), Cf, scale.data_ptr(), shift.data_ptr(), M, Cl, h0.data_ptr(), Cl, 1,
                                         N.stream_ptr()), hctx)
             t2, t3, t4 = _Tape((True,) * 9), _Tape((True,) * 8), _Tape((True,) * 8)
-            z1 = ConvBlock.forward(t2, h0, wl1, bl1, None, None, None, None, None, dict(B=B, T=T))
+            # (linear1's bias sits directly in front of nonlinear2's BatchNorm: its gradient is identically zero, see Conv2dBlock.backward)
+            z1 = ConvBlock.forward(t2, h0, wl1, bl1, None, None, None, None, None,
+                                   dict(B=B, T=T, zero_bias_grad=not os.environ.get('VPMI_BN_BIAS_GRAD_SUMS')))
             h = BNRows.forward(t3, z1, g2, be2, rm2, rv2, mom2, eps2, True)
             CamLayerFn.forward(t4, h, wloc, bloc, w1, b1, w2, b2, dict(B=B, T=T, seg_len=seg_len, dilation=dil, out_into=X[:, Cl:Cl + G]))
             tapes.append((Cl, mean, invstd, scale, shift, g1, t2, t3, t4))
