@@ -1515,6 +1515,21 @@ static int wgrad_impl(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int
     if (S > 256) S = 256;
     if (nbatch > 1 && S > 512 / nbatch) S = 512 / nbatch > 1 ? 512 / nbatch : 1;      // the batch fills the chip: fewer, longer row splits (less to reduce)
     if ((long long)S * 64 > M) S = (int)((M + 63) / 64);
+    if ((d->mfma_bf16 || bf_in) && nbatch == 1) {
+        // The 128 x 128 mixed-precision kernel keeps two workgroups per CU resident.  A grid of 1.5 rounds of them costs two rounds of
+        // time with half-empty CUs in the second (a 3 x 3 conv of 32 channels: 3 tiles x 256 splits = 768 workgroups on 512 slots): take the
+        // largest split count that fills WHOLE rounds instead (3 x 170 = 510: the same rows in one round, and a third fewer partial rows).
+        static int cus_dev[64] = {};
+        int& cus = cus_dev[ctx->device & 63];
+        if (!cus && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess) cus = 256;
+        const long long slots = 2LL * cus;
+        const long long tiles128 = (long long)((K + 127) / 128) * ((d->Cout + 127) / 128);
+        const long long W = tiles128 * S;
+        if (W > slots) {
+            const long long S2 = slots * (W / slots) / tiles128;
+            if (S2 >= 1 && S2 < S) S = (int)S2;
+        }
+    }
     if ((d->Cin | d->Cout | d->ldx | d->xoff | lddz) & 3) VP_FAIL(ctx, VP_EINVAL, "wgrad: Cin / Cout / ldx / xoff / lddz must be multiples of 4");
     int rps = (int)((M + S - 1) / S);
     const int rq = (d->mfma_bf16 || bf_in) ? 64 : 32;             // rows per staged chunk of the kernel
