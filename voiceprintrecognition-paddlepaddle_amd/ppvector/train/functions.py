@@ -1835,8 +1835,11 @@ class CamDenseBlockFn(torch.autograd.Function):
         M, C0, G, L, Cf = ctx.geom
         lib, hctx = N.lib(), N.ctx(X.device)
         dev = X.device
-        # ONE gradient buffer for the whole block, updated in place: the gradient of the block's output as its only consumer handed it over
-        Gb = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
+        # ONE gradient buffer for the whole block, updated in place.  A copy of the incoming gradient (one pass per block): autograd's
+        # tensors are not ours to write into (a retain_grad() or a hook on the block output would see the sums)
+        Gb = g.float().contiguous()
+        if Gb is g or Gb.data_ptr() == g.data_ptr():
+            Gb = g.clone()
         grads = [None] * (12 * L)
         for l in reversed(range(L)):
             Cl, mean, invstd, scale, shift, g1, t2, t3, t4 = ctx.tapes[l]
