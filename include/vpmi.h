@@ -31,7 +31,9 @@ typedef struct vp_ctx vp_ctx;
 typedef void* vp_stream; /* hipStream_t */
 
 enum { VP_OK = 0, VP_EINVAL = -1, VP_ENOMEM = -2, VP_EHIP = -3, VP_EUNSUP = -4, VP_EWORKSPACE = -5 };
-enum { VP_F32 = 0, VP_BF16 = 1 };                  /* element type of activations / GEMM weights     */
+enum { VP_F32 = 0, VP_BF16 = 1,                    /* element type of activations / GEMM weights     */
+       VP_F32X3 = 2 };                             /* `dtype` of a whole-backbone weights struct only: f32 tensors (as VP_F32), every
+                                                      conv / GEMM in split precision (vp_conv1d_desc.mfma_bf16 = 2)                  */
 enum { VP_PAD_NONE = 0, VP_PAD_REFLECT = 1, VP_PAD_ZERO = 2 };
 enum { VP_ACT_NONE = 0, VP_ACT_RELU = 1, VP_ACT_SIGMOID = 2, VP_ACT_TANH = 3,
        VP_ACT_HARDTANH20 = 4,   /* clamp to [0, 20]: ERes2Net's "ReLU" (models/eres2net.py:12-20) */
@@ -158,8 +160,11 @@ typedef struct {
     const void* res; int ld_res, res_off;        /* residual added after BN, before act2 (dtype_out)     */
     const float* gate; int gate_len, gate_nseg;  /* [B*gate_nseg][Cout]: y *= gate[b, t / gate_len, :]   */
     /* --- mixed-precision training (trainer.py:209-229, auto_cast O1) --------------------------------------------------- */
-    int mfma_bf16;                       /* f32 tensors only: 1 = round x and w to bf16 while staging and run the bf16
-                                            matrix cores (f32 accumulate, f32 out); 0 = exact f32 matrix cores            */
+    int mfma_bf16;                       /* f32 tensors only: 0 = exact f32 matrix cores; 1 = round x and w to bf16 while staging
+                                            and run the bf16 matrix cores (f32 accumulate, f32 out); 2 = split precision: x and w
+                                            each become bf16 hi + lo while staging, hi*hi + hi*lo + lo*hi on the bf16 matrix cores
+                                            (~2^-16 relative per product: the reference's 1e-4 score tolerance at 1/3 of the
+                                            bf16 rate = 5.3x the exact-f32 rate)                                          */
 } vp_conv1d_desc;
 
 int vp_conv1d_tiles_m(int B, int T_out);            /* rows of the psum arrays                     */
@@ -170,9 +175,6 @@ int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream);
  * ring, 5 = half-tile ring with resident workgroups (csrc/conv_gemm.hip).  Process-wide; returns the previous value; out-of-range values only query.  Results
  * are identical for every schedule. */
 int vp_conv256_select(int schedule);
-/* A/B switch of the 128 x 256 ring kernel's start stagger (csrc/conv_gemm.hip: g_ring_dephase): each CU's second workgroup starts
- * `percent` % of an estimated tile time late; 0 = together.  Returns the previous value; results are unaffected (no reference counterpart). */
-int vp_conv_ring_dephase(int percent);
 
 /* mean / std over time from the conv1d partial sums: stats[b][0:C] = mean, stats[b][C:2C] = std,
  * std = sqrt(max(E[(x-mean)^2], eps)) -- pooling.py:90-93 with the all-ones mask of pooling.py:94-101

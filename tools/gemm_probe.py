@@ -1,8 +1,6 @@
 """Micro-benchmark of the 256-wide conv GEMM (no model around it): every schedule of the kernel on the bench shapes,
 interleaved rounds in ONE process (A/B), full-output check against a torch matmul of the same bf16 operands.
-Usage: python tools/gemm_probe.py [rounds] [schedules, e.g. 3,4] [CinxCout ...]
-A schedule id 6xx = schedule 6 with the start stagger of each CU's second workgroup set to xx percent of a tile time (vp_conv_ring_dephase),
-e.g. 6,630,650 compares together / 30 % / 50 %."""
+Usage: python tools/gemm_probe.py [rounds] [schedules, e.g. 3,4] [CinxCout ...]"""
 import ctypes as C
 import os
 import sys
@@ -41,8 +39,7 @@ for cin, cout in shapes:
     worst = {s: 0.0 for s in scheds}
     for r in range(rounds):
         for s in scheds:
-            lib.vp_conv256_select(6 if s >= 600 else s)
-            lib.vp_conv_ring_dephase(s - 600 if s >= 600 else 0)
+            lib.vp_conv256_select(s)
             y.zero_()
             reps = 4
             evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
@@ -61,4 +58,3 @@ for cin, cout in shapes:
               f'({2.0 * M * cin * cout / mn / 1e9:7.1f} TF)  worst rel-err over {rounds} rounds {worst[s]:.2e}', flush=True)
     del x, w, y, ref
 lib.vp_conv256_select(-1)
-lib.vp_conv_ring_dephase(0)

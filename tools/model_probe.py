@@ -1,5 +1,5 @@
-"""Forward-time probe of the built backbones at a given batch (3 s utterances, T = 298, bf16 and f32), with each engine's fraction
-of ITS matrix-core peak (MI355X_MICROARCH.md: 2.5 PFLOP/s dense bf16, 157 TFLOP/s f32 MFMA).  The f32 engine is the one that meets
+"""Forward-time probe of the built backbones at a given batch (3 s utterances, T = 298; bf16, split-precision 'float32x3' and f32), with
+each engine's fraction of ITS matrix-core peak (MI355X_MICROARCH.md: 2.5 PFLOP/s dense bf16 -- a third of it for x3 --, 157 TFLOP/s f32 MFMA).  The f32 engine is the one that meets
 north_star's 1e-4 on ResNetSE / ERes2Net (bf16: 2.1e-4 / 1.8e-4, tests/test_gpu_models.py), so ITS throughput is the parity-clean
 number for BASELINE configs 4 and 5.   python tools/model_probe.py [B] [model ...]"""
 import os
@@ -21,7 +21,7 @@ from ppvector.models.tdnn import TDNN  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 x = torch.randn(B, 298, 80, device='cuda') * 3
-PEAK = {'bfloat16': 2500.0, 'float32': 157.3}
+PEAK = {'bfloat16': 2500.0, 'float32': 157.3, 'float32x3': 2500.0 / 3}       # x3: three bf16 MFMAs per product
 GF = {'EcapaTdnn': 2.857, 'TDNN': 1.47, 'CAMPPlus': 3.20, 'ResNetSE': 11.07, 'ERes2Net': 10.2}
 for name, cls, params in (('EcapaTdnn', EcapaTdnn, om.ecapa_params(80)), ('TDNN', TDNN, om.tdnn_params(80)),
                           ('CAMPPlus', lambda f: CAMPPlus(f, embd_dim=192), oc.campplus_params(80, 192)),
@@ -32,7 +32,8 @@ for name, cls, params in (('EcapaTdnn', EcapaTdnn, om.ecapa_params(80)), ('TDNN'
     m = cls(80)
     m.load_state_dict(params)
     m = m.cuda().eval()
-    for dt in (('bfloat16',) if os.environ.get('VP_BF16_ONLY') == '1' else ('bfloat16', 'float32')):
+    dts = os.environ.get('VP_DTYPES')
+    for dt in (tuple(dts.split(',')) if dts else ('bfloat16',) if os.environ.get('VP_BF16_ONLY') == '1' else ('bfloat16', 'float32x3', 'float32')):
         eng = m.engine(dt)
         xin = x.to(torch.bfloat16) if dt == 'bfloat16' else x
         for _ in range(2):

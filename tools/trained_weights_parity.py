@@ -5,7 +5,7 @@ different operating point (sparser ReLU outputs, larger dynamic range, a peaked 
 hundred steps on the synthetic speakers of tools/amp_convergence.py (this package's own training step, enable_amp), then scores 96
 held-out utterances all-pairs with
     the CPU oracle (f32; oracle/*.py, the restatement pinned on the reference's model files) -- the yardstick,
-    the f32 engine and the bf16 engine of this package, eval mode, the same features,
+    the f32 engine, the split-precision ('float32x3') engine and the bf16 engine of this package, eval mode, the same features,
 and prints the largest cosine-score difference of each engine from the oracle.
     python tools/trained_weights_parity.py [EcapaTdnn|TDNN|CAMPPlus|ResNetSE|ERes2Net] [steps] [batch]"""
 import math
@@ -53,7 +53,7 @@ def scores(e):
 
 def run(name, steps=240, B=64, n_eval=96, verbose=True):
     """Train `name` for `steps` steps of B under enable_amp, then score n_eval held-out utterances all-pairs with the CPU oracle and both
-    engines -> dict(loss, acc, err_f32, err_bf16, rel_f32, rel_bf16, eer_oracle, eer_f32, eer_bf16)."""
+    engines -> dict(loss, acc, err_{f32,x3,bf16}, rel_{f32,x3,bf16}, eer_oracle, eer_{f32,x3,bf16})."""
     from ppvector.metric.metrics import evaluate_trials
     spe = max(1, steps // epochs)
     table = ac.speaker_table(n_spk, 1000)
@@ -114,7 +114,7 @@ def run(name, steps=240, B=64, n_eval=96, verbose=True):
     if verbose:
         print(f'  oracle scores: same-speaker pairs mean {s_or[same & off].mean():.3f}, different-speaker pairs mean {s_or[~same].mean():.3f}; '
               f'EER of the second half scored against the first {out["eer_oracle"]:.4f}')
-    for dt, tag in (('float32', 'f32'), ('bfloat16', 'bf16')):
+    for dt, tag in (('float32', 'f32'), ('float32x3', 'x3'), ('bfloat16', 'bf16')):
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
             eng = m.engine(dt)

@@ -262,7 +262,7 @@ void plan_cam(const vp_campplus_weights* w, int B, int T, void* ws, CamPlan& p) 
 
 void conv2d_desc(vp_conv1d_desc& d, const vp_tdnn_layer& L, int dt, int B, int T, int F_in, int F_out, int stride_f) {
     memset(&d, 0, sizeof(d));
-    d.dtype_in = dt; d.dtype_out = dt; d.B = B; d.T_in = T; d.T_out = T;
+    vp_desc_dtype(d, dt); d.B = B; d.T_in = T; d.T_out = T;
     d.Cin = L.cin; d.Cout = L.cout; d.KW = L.kw; d.dilation = 1; d.stride = 1;
     d.KF = L.kw == 9 ? 3 : 1;
     d.pad_left = L.kw == 9 ? 1 : 0; d.pad_f = L.kw == 9 ? 1 : 0; d.pad_mode = VP_PAD_ZERO;
@@ -333,7 +333,7 @@ size_t vp_campplus_workspace_bytes(const vp_campplus_weights* w, int B, int T) {
 int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats, int B, int T, float* emb,
                     void* ws, size_t ws_bytes, vp_stream stream) {
     if (!ctx || !w || !feats || !emb || B <= 0 || T <= 0) VP_FAIL(ctx, VP_EINVAL, "campplus: bad arguments");
-    if (w->dtype != VP_F32 && w->dtype != VP_BF16) VP_FAIL(ctx, VP_EINVAL, "campplus: bad dtype");
+    if (!vp_backbone_dtype_ok(w->dtype)) VP_FAIL(ctx, VP_EINVAL, "campplus: bad dtype");
     if (w->m_channels != 32 || w->feat_dim % 8 || w->n_blocks < 1 || w->n_blocks > 4 || w->bn_channels > 256 ||
         256 % w->bn_channels || w->seg_len < 1)
         VP_FAIL(ctx, VP_EUNSUP, "campplus: geometry not built (m_channels 32, feat_dim %% 8 == 0, bn_channels | 256)");
@@ -343,7 +343,7 @@ int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats
     if (!ws || ws_bytes < p.total) VP_FAIL(ctx, VP_EWORKSPACE, "campplus: workspace %zu < %zu", ws_bytes, p.total);
     if (p.Tn < 2) VP_FAIL(ctx, VP_EINVAL, "campplus: %d frames are too few", T);
     hipStream_t st = (hipStream_t)stream;
-    const int dt = w->dtype;
+    const int dtc = w->dtype, dt = vp_storage_dtype(dtc);
     int rc;
     vp_conv1d_desc d;
 
@@ -386,11 +386,11 @@ int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats
         if (fast == VP_OK) {
             if (R.has_shortcut) sc = t2;
         } else {
-            conv2d_desc(d, R.conv1, dt, B, T, F, Fo, R.stride);
+            conv2d_desc(d, R.conv1, dtc, B, T, F, Fo, R.stride);
             d.x = cur; d.y = t1; d.act2 = VP_ACT_RELU;
             if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
             if (R.has_shortcut) {      // bn(conv1x1 stride (s,1))
-                conv2d_desc(d, R.shortcut, dt, B, T, F, Fo, R.stride);
+                conv2d_desc(d, R.shortcut, dtc, B, T, F, Fo, R.stride);
                 d.x = cur; d.y = t2;
                 if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
                 sc = t2;
@@ -402,7 +402,7 @@ int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats
         if (dt == VP_BF16) fast = vp_conv3x3_c32_bf16(ctx, t1, outb, &R.conv2, sc, 1, nullptr, nullptr, B, T, Fo, 1, nullptr, nullptr, nullptr, nullptr, nullptr, st);
         if (fast != VP_OK && fast != VP_EUNSUP) return fast;
         if (fast != VP_OK) {
-            conv2d_desc(d, R.conv2, dt, B, T, Fo, Fo, 1);
+            conv2d_desc(d, R.conv2, dtc, B, T, Fo, Fo, 1);
             d.x = t1; d.y = outb; d.res = sc; d.ld_res = R.conv2.cout; d.act2 = VP_ACT_RELU;
             if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
         }
@@ -415,7 +415,7 @@ int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats
         if (dt == VP_BF16) fast = vp_conv3x3_c32_bf16(ctx, cur, t1, &w->fcm_conv2, nullptr, 1, nullptr, nullptr, B, T, F, 2, nullptr, nullptr, nullptr, nullptr, nullptr, st);
         if (fast != VP_OK && fast != VP_EUNSUP) return fast;
         if (fast != VP_OK) {
-            conv2d_desc(d, w->fcm_conv2, dt, B, T, F, Fo, 2);
+            conv2d_desc(d, w->fcm_conv2, dtc, B, T, F, Fo, 2);
             d.x = cur; d.y = t1; d.act2 = VP_ACT_RELU;
             if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
         }
@@ -427,7 +427,7 @@ int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats
     // ---- TDNN: conv k5 stride 2 zero-pad 2 -> BN -> ReLU, into columns [0, init) of cat[0]
     const int Tn = p.Tn, ld = p.Cmax;
     memset(&d, 0, sizeof(d));
-    d.dtype_in = dt; d.dtype_out = dt; d.B = B; d.T_in = T; d.T_out = Tn; d.Cin = Cf; d.Cout = w->tdnn.cout;
+    vp_desc_dtype(d, dtc); d.B = B; d.T_in = T; d.T_out = Tn; d.Cin = Cf; d.Cout = w->tdnn.cout;
     d.KW = w->tdnn.kw; d.dilation = 1; d.stride = 2; d.pad_left = (w->tdnn.kw - 1) / 2; d.pad_mode = VP_PAD_ZERO;
     d.x = t1; d.ldx = Cf; d.w = w->tdnn.w; d.bias = w->tdnn.bias; d.bn_scale = w->tdnn.bn_scale; d.bn_shift = w->tdnn.bn_shift;
     d.act2 = VP_ACT_RELU; d.y = p.cat[0]; d.ldy = ld;
@@ -448,7 +448,7 @@ int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats
             const vp_cam_layer& L = w->layers[li];
             // h2 = relu(bn2(linear1(relu(bn1(x[:, :ch])))))  -- bn1+relu is the conv's input prologue
             memset(&d, 0, sizeof(d));
-            d.dtype_in = dt; d.dtype_out = dt; d.B = B; d.T_in = Tn; d.T_out = Tn; d.Cin = ch; d.Cout = bnc; d.KW = 1;
+            vp_desc_dtype(d, dtc); d.B = B; d.T_in = Tn; d.T_out = Tn; d.Cin = ch; d.Cout = bnc; d.KW = 1;
             d.dilation = 1; d.stride = 1; d.pad_mode = VP_PAD_ZERO;
             d.x = cat; d.ldx = ld; d.w = L.linear1.w; d.bias = L.linear1.bias; d.pro_scale = L.bn1_scale; d.pro_shift = L.bn1_shift;
             d.bn_scale = L.linear1.bn_scale; d.bn_shift = L.linear1.bn_shift; d.act2 = VP_ACT_RELU; d.y = p.h2; d.ldy = bnc;
@@ -476,7 +476,7 @@ int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats
             }
             // y = linear_local(h2) * m, written in place as the layer's new channels
             memset(&d, 0, sizeof(d));
-            d.dtype_in = dt; d.dtype_out = dt; d.B = B; d.T_in = Tn; d.T_out = Tn; d.Cin = bnc; d.Cout = gr;
+            vp_desc_dtype(d, dtc); d.B = B; d.T_in = Tn; d.T_out = Tn; d.Cin = bnc; d.Cout = gr;
             d.KW = L.local.kw; d.dilation = L.local.dil; d.stride = 1; d.pad_left = L.local.dil * (L.local.kw - 1) / 2;
             d.pad_mode = VP_PAD_ZERO; d.x = p.h2; d.ldx = bnc; d.w = L.local.w; d.bias = L.local.bias;
             d.gate = p.gate; d.gate_len = w->seg_len; d.gate_nseg = nseg; d.y = cat; d.ldy = ld; d.yoff = ch;
@@ -486,7 +486,7 @@ int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats
         // transit: linear(relu(bn(x))) -> ch/2, into the other concat buffer
         const vp_transit& Tr = w->transit[b];
         memset(&d, 0, sizeof(d));
-        d.dtype_in = dt; d.dtype_out = dt; d.B = B; d.T_in = Tn; d.T_out = Tn; d.Cin = ch; d.Cout = ch / 2; d.KW = 1;
+        vp_desc_dtype(d, dtc); d.B = B; d.T_in = Tn; d.T_out = Tn; d.Cin = ch; d.Cout = ch / 2; d.KW = 1;
         d.dilation = 1; d.stride = 1; d.pad_mode = VP_PAD_ZERO; d.x = cat; d.ldx = ld; d.w = Tr.linear.w; d.bias = Tr.linear.bias;
         d.pro_scale = Tr.bn_scale; d.pro_shift = Tr.bn_shift; d.y = p.cat[cb ^ 1]; d.ldy = ld;
         if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;

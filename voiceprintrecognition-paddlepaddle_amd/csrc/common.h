@@ -107,6 +107,14 @@ __device__ __forceinline__ float vp_wave_max(float v) {
 }
 
 static inline size_t vp_dtype_size(int dt) { return dt == VP_BF16 ? 2 : 4; }
+// a backbone's `dtype` -> the element type of its tensors (VP_F32X3 = f32 tensors, split-precision contractions)
+static inline int vp_storage_dtype(int dt) { return dt == VP_F32X3 ? VP_F32 : dt; }
+static inline bool vp_backbone_dtype_ok(int dt) { return dt == VP_F32 || dt == VP_BF16 || dt == VP_F32X3; }
+// dtype fields of a conv descriptor from a backbone's `dtype`
+static inline void vp_desc_dtype(vp_conv1d_desc& d, int dt) {
+    d.dtype_in = d.dtype_out = vp_storage_dtype(dt);
+    d.mfma_bf16 = dt == VP_F32X3 ? 2 : 0;
+}
 
 // M-tile of the conv GEMM: the partial time-sum arrays are indexed by it
 #define VP_CONV_BM 128

@@ -28,6 +28,7 @@ int vp_conv_launch_bf16_bf16(vp_ctx* ctx, const void* args, int bn, int mode, hi
 int vp_conv_launch_bf16_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
 int vp_conv_launch_f32_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
 int vp_conv_launch_amp_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
+int vp_conv_launch_x3_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
 int vp_conv_launch256_bf16(vp_ctx* ctx, const void* args, int mode, int sched, int out_f32, hipStream_t st);
 
 // Schedule of the 256-wide kernel: 0 pins the 128-wide kernel; 1 = interleaved DMA, 2 = ping-pong phases, 3 = role-split
@@ -46,33 +47,12 @@ static int ring_min_cout() {
     return v;
 }
 
-// The 128 x 256 ring kernel's two workgroups per CU start together and stay in step: both in their K-loops (sharing the matrix cores),
-// then both in their epilogues (matrix cores idle).  g_ring_dephase > 0 starts each CU's second workgroup that percentage of an
-// estimated tile time late (VPMI_RING_DEPHASE presets it, vp_conv_ring_dephase() switches at run time for A/B in one process).
-static int g_ring_dephase = -1;
-static int ring_dephase() {
-    if (g_ring_dephase < 0) { const char* e = getenv("VPMI_RING_DEPHASE"); g_ring_dephase = e ? atoi(e) : 0; }
-    return g_ring_dephase;
-}
-static int device_cus(int device) {
-    static int cus[64] = {};
-    int& n = cus[device & 63];
-    if (!n && (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n < 1)) n = 256;
-    return n;
-}
-
 static int use_conv256() {
     if (g_conv256 == -2) { const char* e = getenv("VPMI_CONV256"); g_conv256 = e ? atoi(e) : -1; }
     return g_conv256;
 }
 
 extern "C" {
-
-int vp_conv_ring_dephase(int percent) {
-    const int prev = ring_dephase();
-    if (percent >= 0 && percent <= 100) g_ring_dephase = percent;
-    return prev;
-}
 
 int vp_conv256_select(int schedule) {
     const int prev = use_conv256();
@@ -189,19 +169,13 @@ int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream) {
                 a.group_m = 64 / a.tiles_n;
                 if (a.group_m < 1) a.group_m = 1;
                 if (a.group_m > 32) a.group_m = 32;
-                const int pct = ring_dephase(), cus = device_cus(ctx->device);
-                if (pct > 0 && a.tiles_m * a.tiles_n >= 2 * cus) {
-                    // tile time of this kernel with a co-resident twin, from the round-4 profiles: ~7.4 us of prologue + epilogue and
-                    // ~1.5 us per 64-wide K-step; wall_clock64 counts at 100 MHz
-                    a.dephase_ticks = (int)((7.4f + 1.5f * (float)a.KT) * (float)pct);
-                    a.dephase_lo = cus; a.dephase_hi = 2 * cus;
-                }
             }
             return vp_conv_launch256_bf16(ctx, &a, mode, sched - 1, out_f32 ? 1 : 0, st);
         }
     }
     if (d->dtype_in == VP_BF16 && d->dtype_out == VP_BF16) return vp_conv_launch_bf16_bf16(ctx, &a, bn, mode, st);
     if (d->dtype_in == VP_BF16 && d->dtype_out == VP_F32) return vp_conv_launch_bf16_f32(ctx, &a, bn, mode, st);
+    if (d->mfma_bf16 == 2) return vp_conv_launch_x3_f32(ctx, &a, bn, mode, st);
     if (d->mfma_bf16) return vp_conv_launch_amp_f32(ctx, &a, bn, mode, st);
     return vp_conv_launch_f32_f32(ctx, &a, bn, mode, st);
 }

@@ -1045,10 +1045,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm128x256_ring_kernel(const Con
     const int tn = rem / gm;
     const int tm = grp * a.group_m + (rem - tn * gm);
     const int m0 = tm * 128, n0 = tn * T2;
-    if (a.dephase_ticks > 0 && bid >= a.dephase_lo && bid < a.dephase_hi) {        // (wave-uniform: scalar branch, scalar clock reads)
-        const long long t0 = (long long)wall_clock64();
-        while ((long long)wall_clock64() - t0 < (long long)a.dephase_ticks) __builtin_amdgcn_s_sleep(8);
-    }
 
     // staging: a DMA piece is 8 rows x 128 B; lane l lands at row l >> 3, position l & 7 and fetches chunk position ^ row.
     // Wave wv fills rows [16 wv, +16) of an X half-tile (2 pieces) and rows [32 wv, +32) of a W half-tile (4 pieces).

@@ -31,10 +31,6 @@ struct ConvArgs {
     int F_in, F_out, KF, stride_f, pad_f;
     int gate_len, gate_nseg;
     int tiles_m, tiles_n, nseg, group_m;
-    // 128 x 256 ring kernel, two workgroups per CU: workgroups [dephase_lo, dephase_hi) -- the SECOND workgroup each CU receives in the
-    // launch's first wave -- start dephase_ticks (100 MHz) late, so that one workgroup's prologue / epilogue falls under the other's
-    // K-loop instead of under its prologue / epilogue (0 = off)
-    int dephase_ticks, dephase_lo, dephase_hi;
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -43,10 +39,18 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // (the mixed-precision training engine: paddle.amp.auto_cast O1 runs conv / matmul in low precision and keeps the rest f32,
 // trainer.py:209-229).  A stage is 32 k (one v_mfma_f32_16x16x32_bf16 step) = 64-byte LDS rows.
 struct amp_t { float v; };
+// x3_t: f32 tensors in memory, SPLIT into two bf16 terms on their way into LDS -- x = hi + lo with hi = bf16(x), lo = bf16(x - hi)
+// (both round-to-nearest-even; x - hi is exact in f32) -- and contracted as hi*hi + hi*lo + lo*hi on the bf16 matrix cores with f32
+// accumulation: the product of two f32 numbers to ~2^-16 relative (the dropped lo*lo term and lo's own rounding), against 2^-8 for a
+// single bf16 pass, at one third of the bf16 MFMA rate (833 TFLOP/s dense on MI355X, 5.3x the exact-f32 MFMA rate).  This is the
+// engine that carries the reference's 1e-4 score tolerance at trained weights.  A stage is 32 k: a 128-byte
+// LDS row = [32 hi | 32 lo], so the hi / lo fragments are the ks = 0 / ks = 1 reads of the bf16 layout (same swizzle, conflict-free).
+struct x3_t { float v; };
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { bf16x8 v; };
 template <> struct Frag<float> { float4 lo, hi; };
 template <> struct Frag<amp_t> { bf16x8 v; };
+template <> struct Frag<x3_t> { bf16x8 hi, lo; };
 constexpr int ROWB_AMP = 64;
 // 64-byte rows: the ds_read_b128 lane groups ({0-3,12-15,20-27}, ...) are conflict-free with the 16-B chunk g stored at
 // position g ^ ((-(row >> 2)) & 3)
@@ -64,6 +68,10 @@ __device__ __forceinline__ void load_frag(const char* tile, int row, int /*ks*/,
 __device__ __forceinline__ void load_frag(const char* tile, int row, int /*ks*/, int g, Frag<amp_t>& f) {
     f.v = *reinterpret_cast<const bf16x8*>(tile + row * ROWB_AMP + amp_pos(row, g));
 }
+__device__ __forceinline__ void load_frag(const char* tile, int row, int /*ks*/, int g, Frag<x3_t>& f) {
+    f.hi = *reinterpret_cast<const bf16x8*>(tile + row * ROWB + ((g ^ (row & 7)) << 4));
+    f.lo = *reinterpret_cast<const bf16x8*>(tile + row * ROWB + (((4 + g) ^ (row & 7)) << 4));
+}
 // D[n][m] += sum_k W[n][k] * X[m][k]: weights are the A operand (row = lane & 15 -> n), activations
 // the B operand (col = lane & 15 -> m); result register r of lane l = (n = (l >> 4) * 4 + r, m = l & 15).
 __device__ __forceinline__ void mma(const Frag<bf16_t>& w, const Frag<bf16_t>& x, f32x4& c) {
@@ -71,6 +79,11 @@ __device__ __forceinline__ void mma(const Frag<bf16_t>& w, const Frag<bf16_t>& x
 }
 __device__ __forceinline__ void mma(const Frag<amp_t>& w, const Frag<amp_t>& x, f32x4& c) {
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, x.v, c, 0, 0, 0);
+}
+__device__ __forceinline__ void mma(const Frag<x3_t>& w, const Frag<x3_t>& x, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.lo, x.hi, c, 0, 0, 0);      // the two cross terms, then the leading one
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.hi, x.lo, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.hi, x.hi, c, 0, 0, 0);
 }
 __device__ __forceinline__ void mma(const Frag<float>& w, const Frag<float>& x, f32x4& c) {
     // lane group g holds k = 8g .. 8g+7 of the 32-wide stage for BOTH operands; instruction e
@@ -129,6 +142,24 @@ __device__ __forceinline__ uint2 amp_pack(u32x4 v) {
     o.y = (unsigned)__builtin_bit_cast(unsigned short, b2) | ((unsigned)__builtin_bit_cast(unsigned short, b3) << 16);
     return o;
 }
+__device__ __forceinline__ u32x4 prologue_chunk(u32x4 v, const float (&s)[8], const float (&h)[8], x3_t) {
+    return prologue_chunk(v, s, h, float{});
+}
+// four f32 -> their bf16 hi terms and bf16 lo terms (x = hi + lo up to 2^-16 relative), 8 bytes each
+__device__ __forceinline__ void x3_split(u32x4 v, uint2& hi, uint2& lo) {
+    unsigned short h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned u = v[e];              // NOT bit_cast(v[e]): on a vector-element lvalue hipcc reads element 0
+        const float x = __builtin_bit_cast(float, u);
+        const bf16_t xh = (bf16_t)x;
+        const bf16_t xl = (bf16_t)(x - (float)xh);
+        h[e] = __builtin_bit_cast(unsigned short, xh);
+        l[e] = __builtin_bit_cast(unsigned short, xl);
+    }
+    hi.x = (unsigned)h[0] | ((unsigned)h[1] << 16); hi.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
+    lo.x = (unsigned)l[0] | ((unsigned)l[1] << 16); lo.y = (unsigned)l[2] | ((unsigned)l[3] << 16);
+}
 __device__ __forceinline__ u32x4 prologue_chunk(u32x4 v, const float (&s)[8], const float (&h)[8], float) {
     u32x4 o;
 #pragma unroll
@@ -150,6 +181,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
     constexpr int WCOLS = NI * 16;
     constexpr int BROWS = BN / 32;
     constexpr bool AMP = std::is_same<TI, amp_t>::value;
+    constexpr bool X3 = std::is_same<TI, x3_t>::value;
     constexpr int RB = AMP ? ROWB_AMP : ROWB;            // bytes per tile row per stage in LDS
     constexpr int STAGE = (BM + BN) * RB;
     constexpr bool PRO = MODE == MODE_1X1_PRO;
@@ -189,7 +221,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
 
     // global -> LDS staging assignment: 16-B chunk cc of rows r0 + 32 i
     const int cc = tid & 7, r0 = tid >> 3;
-    const int pw = AMP ? ((((cc >> 1) ^ ((0 - (r0 >> 2)) & 3)) << 4) + (cc & 1) * 8) : ((cc ^ (r0 & 7)) << 4);
+    // x3: chunk cc (4 f32) becomes 8 bytes of the hi plane (16-B chunk cc >> 1 of the row) and 8 bytes of the lo plane (chunk 4 + (cc >> 1))
+    const int pw = AMP ? ((((cc >> 1) ^ ((0 - (r0 >> 2)) & 3)) << 4) + (cc & 1) * 8)
+                 : X3  ? ((((cc >> 1) ^ (r0 & 7)) << 4) + (cc & 1) * 8)
+                       : ((cc ^ (r0 & 7)) << 4);
+    [[maybe_unused]] const int pw_lo = (((4 + (cc >> 1)) ^ (r0 & 7)) << 4) + (cc & 1) * 8;
     const bool zero_pad = a.pad_mode == VP_PAD_ZERO;
     const unsigned ldxb = (unsigned)a.ldx * ES;
     // per staged row: rowoff = byte offset of (utterance b, frame 0 [, freq 0]); tpos / fpos = the
@@ -301,12 +337,22 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
                 v = prologue_chunk(v, s8, h8, TI{});
             }
             if constexpr (AMP) *reinterpret_cast<uint2*>(As + (r0 + 32 * i) * RB + pw) = amp_pack(v);
-            else *reinterpret_cast<u32x4*>(As + (r0 + 32 * i) * RB + pw) = v;
+            else if constexpr (X3) {
+                uint2 hi, lo;
+                x3_split(v, hi, lo);
+                *reinterpret_cast<uint2*>(As + (r0 + 32 * i) * RB + pw) = hi;
+                *reinterpret_cast<uint2*>(As + (r0 + 32 * i) * RB + pw_lo) = lo;
+            } else *reinterpret_cast<u32x4*>(As + (r0 + 32 * i) * RB + pw) = v;
         }
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) {
             if constexpr (AMP) *reinterpret_cast<uint2*>(Bs + (r0 + 32 * i) * RB + pw) = amp_pack(rb[i]);
-            else *reinterpret_cast<u32x4*>(Bs + (r0 + 32 * i) * RB + pw) = rb[i];
+            else if constexpr (X3) {
+                uint2 hi, lo;
+                x3_split(rb[i], hi, lo);
+                *reinterpret_cast<uint2*>(Bs + (r0 + 32 * i) * RB + pw) = hi;
+                *reinterpret_cast<uint2*>(Bs + (r0 + 32 * i) * RB + pw_lo) = lo;
+            } else *reinterpret_cast<u32x4*>(Bs + (r0 + 32 * i) * RB + pw) = rb[i];
         }
     };
 

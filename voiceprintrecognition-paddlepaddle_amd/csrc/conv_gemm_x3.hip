@@ -1,0 +1,7 @@
+// Split-precision instantiations of the conv GEMM: f32 tensors, each operand split into bf16 hi + lo while staging, three bf16 MFMAs
+// per k-step (hi*hi + hi*lo + lo*hi), f32 accumulate, f32 out.  Kernel: conv_gemm_impl.h (x3_t).
+#include "conv_gemm_impl.h"
+
+int vp_conv_launch_x3_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st) {
+    return dispatch_conv<x3_t, float, true>(ctx, *static_cast<const ConvArgs*>(args), bn, mode, st);
+}

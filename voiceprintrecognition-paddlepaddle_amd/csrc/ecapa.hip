@@ -27,7 +27,8 @@ struct Carver {
 
 void tdnn_desc(vp_conv1d_desc& d, const vp_tdnn_layer& L, int dtype, int B, int T_in, int T_out, int pad_mode) {
     memset(&d, 0, sizeof(d));
-    d.dtype_in = dtype; d.dtype_out = dtype; d.B = B; d.T_in = T_in; d.T_out = T_out;
+    vp_desc_dtype(d, dtype);
+    d.B = B; d.T_in = T_in; d.T_out = T_out;
     d.Cin = L.cin; d.Cout = L.cout; d.KW = L.kw; d.dilation = L.dil; d.stride = 1;
     d.pad_mode = pad_mode;
     d.pad_left = pad_mode == VP_PAD_NONE ? 0 : L.dil * (L.kw - 1) / 2;
@@ -40,9 +41,10 @@ void tdnn_desc(vp_conv1d_desc& d, const vp_tdnn_layer& L, int dtype, int B, int 
 // Attentive statistics pooling over x (B*T, C).  When w.psum != NULL the global-context mean/std come
 // from the producing conv's partial sums (shift = its bn_shift or NULL); otherwise w.stats must
 // already hold [mean | std] per utterance.  Leaves pooled (B, 2C) = [mean | std].
-int vp_run_asp(vp_ctx* ctx, const vp_asp_weights& A, int dtype, const void* x, int ldx, const float* shift,
+int vp_run_asp(vp_ctx* ctx, const vp_asp_weights& A, int dtc, const void* x, int ldx, const float* shift,
                int B, int T, const VpAspBufs& w, hipStream_t st) {
     const int C = A.C;
+    const int dtype = vp_storage_dtype(dtc);
     int rc = VP_OK;
     if (w.psum) rc = vp_moments_finalize(ctx, w.psum, w.psumsq, shift, B, T, C, 1e-12f, 1, w.stats, st);
     if (rc) return rc;
@@ -56,7 +58,7 @@ int vp_run_asp(vp_ctx* ctx, const vp_asp_weights& A, int dtype, const void* x, i
         if (rc != VP_EUNSUP) return rc;
     }
     vp_conv1d_desc d;
-    tdnn_desc(d, A.tdnn, dtype, B, T, T, VP_PAD_REFLECT);
+    tdnn_desc(d, A.tdnn, dtc, B, T, T, VP_PAD_REFLECT);
     d.x = x; d.ldx = ldx; d.xoff = 0; d.rowbias = A.w_ctx ? w.rowbias : nullptr; d.act2 = VP_ACT_TANH;
     d.y = w.h; d.ldy = A.att; d.yoff = 0;
     rc = vp_conv1d_fwd(ctx, &d, st);
@@ -67,7 +69,8 @@ int vp_run_asp(vp_ctx* ctx, const vp_asp_weights& A, int dtype, const void* x, i
         if (rc != VP_EUNSUP) return rc;
     }
     memset(&d, 0, sizeof(d));
-    d.dtype_in = dtype; d.dtype_out = VP_F32; d.B = B; d.T_in = T; d.T_out = T; d.Cin = A.att; d.Cout = C;
+    vp_desc_dtype(d, dtc);
+    d.dtype_out = VP_F32; d.B = B; d.T_in = T; d.T_out = T; d.Cin = A.att; d.Cout = C;
     d.KW = 1; d.dilation = 1; d.stride = 1; d.pad_mode = VP_PAD_REFLECT; d.pad_left = 0;
     d.x = w.h; d.ldx = A.att; d.w = A.conv_w; d.bias = A.conv_b; d.y = w.e; d.ldy = C;
     rc = vp_conv1d_fwd(ctx, &d, st);
@@ -113,7 +116,7 @@ int plan_ecapa(const vp_ecapa_weights* w, int B, int T, void* ws, size_t cap, Ec
 }
 
 int check_ecapa(vp_ctx* ctx, const vp_ecapa_weights* w) {
-    if (w->dtype != VP_F32 && w->dtype != VP_BF16) VP_FAIL(ctx, VP_EINVAL, "ecapa: bad dtype");
+    if (!vp_backbone_dtype_ok(w->dtype)) VP_FAIL(ctx, VP_EINVAL, "ecapa: bad dtype");
     if (w->n_blocks < 1 || w->n_blocks > VP_MAX_SE_BLOCKS) VP_FAIL(ctx, VP_EINVAL, "ecapa: n_blocks %d", w->n_blocks);
     if (w->res2_scale < 2 || w->res2_scale - 1 > VP_MAX_RES2) VP_FAIL(ctx, VP_EINVAL, "ecapa: res2_scale %d", w->res2_scale);
     const int C = w->block0.cout;
@@ -180,13 +183,13 @@ int vp_ecapa_fwd(vp_ctx* ctx, const vp_ecapa_weights* w, const void* feats, int 
     plan_ecapa(w, B, T, ws, ws_bytes, p);
     if (!ws || ws_bytes < p.total) VP_FAIL(ctx, VP_EWORKSPACE, "ecapa: workspace %zu < %zu", ws_bytes, p.total);
     hipStream_t st = (hipStream_t)stream;
-    const int dt = w->dtype;
+    const int dtc = w->dtype, dt = vp_storage_dtype(dtc);
     const int C = w->block0.cout, Cm = w->mfa.cout, nb = w->n_blocks, sc = w->res2_scale;
     const int width = C / sc, ldcat = nb * C;
     vp_conv1d_desc d;
 
     // blocks[0]: TDNNBlock(F -> C, k5) on the (B, T, F) features
-    tdnn_desc(d, w->block0, dt, B, T, T, VP_PAD_REFLECT);
+    tdnn_desc(d, w->block0, dtc, B, T, T, VP_PAD_REFLECT);
     d.x = feats; d.ldx = w->feat_dim; d.y = p.cat0; d.ldy = C;
     if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
 
@@ -195,7 +198,7 @@ int vp_ecapa_fwd(vp_ctx* ctx, const vp_ecapa_weights* w, const void* feats, int 
     for (int i = 0; i < nb; ++i) {
         const vp_se_res2_block& blk = w->blk[i];
         // tdnn1 (1x1)
-        tdnn_desc(d, blk.tdnn1, dt, B, T, T, VP_PAD_REFLECT);
+        tdnn_desc(d, blk.tdnn1, dtc, B, T, T, VP_PAD_REFLECT);
         d.x = xin; d.ldx = ld_in; d.xoff = off_in; d.y = p.t1; d.ldy = C;
         d.y2 = p.r2; d.ldy2 = C; d.y2off = 0; d.ysplit = width;       // y_0 = x_0 goes straight into the concat
         if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
@@ -207,7 +210,7 @@ int vp_ecapa_fwd(vp_ctx* ctx, const vp_ecapa_weights* w, const void* feats, int 
         void* tin = nullptr;
         void* tout = p.tmpA;
         for (int j = 1; j < sc && fused != VP_OK; ++j) {
-            tdnn_desc(d, blk.res2[j - 1], dt, B, T, T, VP_PAD_REFLECT);
+            tdnn_desc(d, blk.res2[j - 1], dtc, B, T, T, VP_PAD_REFLECT);
             if (j == 1) { d.x = p.t1; d.ldx = C; d.xoff = width; }
             else { d.x = tin; d.ldx = width; d.xoff = 0; }
             d.y = p.r2; d.ldy = C; d.yoff = j * width;
@@ -220,7 +223,7 @@ int vp_ecapa_fwd(vp_ctx* ctx, const vp_ecapa_weights* w, const void* feats, int 
             tout = (tout == p.tmpA) ? p.tmpB : p.tmpA;
         }
         // tdnn2 (1x1) over concat(y_0 .. y_{s-1}) = r2, with the SE time sums fused
-        tdnn_desc(d, blk.tdnn2, dt, B, T, T, VP_PAD_REFLECT);
+        tdnn_desc(d, blk.tdnn2, dtc, B, T, T, VP_PAD_REFLECT);
         d.x = p.r2; d.ldx = C; d.xoff = 0;
         d.y = p.t2; d.ldy = C; d.psum = p.psum;
         if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
@@ -233,11 +236,11 @@ int vp_ecapa_fwd(vp_ctx* ctx, const vp_ecapa_weights* w, const void* feats, int 
         xin = p.cat; ld_in = ldcat; off_in = i * C;
     }
     // MFA (1x1 over the concat), with the global-context time moments fused
-    tdnn_desc(d, w->mfa, dt, B, T, T, VP_PAD_REFLECT);
+    tdnn_desc(d, w->mfa, dtc, B, T, T, VP_PAD_REFLECT);
     d.x = p.cat; d.ldx = ldcat; d.y = p.mfa; d.ldy = Cm; d.psum = p.psum; d.psumsq = p.psumsq;
     if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
     VpAspBufs ab{p.h, p.e, p.psum, p.psumsq, p.stats, p.rowbias, p.pooled};
-    if ((rc = vp_run_asp(ctx, w->asp, dt, p.mfa, Cm, w->mfa.bn_shift, B, T, ab, st))) return rc;
+    if ((rc = vp_run_asp(ctx, w->asp, dtc, p.mfa, Cm, w->mfa.bn_shift, B, T, ab, st))) return rc;
     // asp_bn (folded) + fc
     return vp_dense_f32_ex(ctx, p.pooled, 2 * Cm, w->fc_w, 0, w->fc_b, nullptr, nullptr, B, w->embd_dim, 2 * Cm,
                            VP_ACT_NONE, emb, w->embd_dim, st);
@@ -281,7 +284,7 @@ size_t vp_tdnn_workspace_bytes(const vp_tdnn_weights* w, int B, int T) {
 int vp_tdnn_fwd(vp_ctx* ctx, const vp_tdnn_weights* w, const void* feats, int B, int T, float* emb,
                 void* ws, size_t ws_bytes, vp_stream stream) {
     if (!ctx || !w || !feats || !emb || B <= 0 || T <= 0) VP_FAIL(ctx, VP_EINVAL, "tdnn: bad arguments");
-    if (w->dtype != VP_F32 && w->dtype != VP_BF16) VP_FAIL(ctx, VP_EINVAL, "tdnn: bad dtype");
+    if (!vp_backbone_dtype_ok(w->dtype)) VP_FAIL(ctx, VP_EINVAL, "tdnn: bad dtype");
     int Ts[6];
     tdnn_T(w, T, Ts);
     if (Ts[5] < 1) VP_FAIL(ctx, VP_EINVAL, "tdnn: %d frames are fewer than the receptive field", T);

@@ -83,7 +83,7 @@ void plan_ere(const vp_eres2net_weights* w, int B, int T, void* ws, ErePlan& p) 
 
 void conv_desc(vp_conv1d_desc& d, const vp_tdnn_layer& L, int dt) {
     memset(&d, 0, sizeof(d));
-    d.dtype_in = dt; d.dtype_out = dt; d.Cin = L.cin; d.Cout = L.cout; d.KW = L.kw; d.dilation = 1; d.stride = 1;
+    vp_desc_dtype(d, dt); d.Cin = L.cin; d.Cout = L.cout; d.KW = L.kw; d.dilation = 1; d.stride = 1;
     d.pad_mode = VP_PAD_ZERO; d.ldx = L.cin; d.ldy = L.cout;
     d.w = L.w; d.bias = L.bias; d.bn_scale = L.bn_scale; d.bn_shift = L.bn_shift;
 }
@@ -101,17 +101,18 @@ int conv1x1(vp_ctx* ctx, const vp_conv1d_desc& d, hipStream_t st) {
 }
 
 // AFF (eres2net.py:33-53): out = x (1 + tanh(att)) + y (1 - tanh(att)), att = BN(conv(SiLU(BN(conv(cat(x, y))))))
-int run_aff(vp_ctx* ctx, const vp_aff_weights& A, int dt, const void* x, int ldx, int xoff, const void* y, int ldy, int yoff,
+int run_aff(vp_ctx* ctx, const vp_aff_weights& A, int dtc, const void* x, int ldx, int xoff, const void* y, int ldy, int yoff,
             void* out, int ldo, int ooff, long long P, int C, void* cat, void* a1, void* att, hipStream_t st) {
+    const int dt = vp_storage_dtype(dtc);
     int rc;
     if ((rc = vp_copy_cols(ctx, dt, x, ldx, xoff, cat, 2 * C, 0, P, C, st))) return rc;
     if ((rc = vp_copy_cols(ctx, dt, y, ldy, yoff, cat, 2 * C, C, P, C, st))) return rc;
     if (P > 0x7fffffff / 4) VP_FAIL(ctx, VP_EINVAL, "aff: too many positions");
     vp_conv1d_desc d;
-    conv_desc(d, A.c1, dt);
+    conv_desc(d, A.c1, dtc);
     d.B = 1; d.T_in = (int)P; d.T_out = (int)P; d.x = cat; d.y = a1; d.act2 = VP_ACT_SILU;
     if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
-    conv_desc(d, A.c2, dt);
+    conv_desc(d, A.c2, dtc);
     d.B = 1; d.T_in = (int)P; d.T_out = (int)P; d.x = a1; d.y = att; d.act2 = VP_ACT_TANH;
     if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
     return vp_aff_combine(ctx, dt, att, C, x, ldx, xoff, y, ldy, yoff, out, ldo, ooff, P, C, st);
@@ -131,7 +132,7 @@ size_t vp_eres2net_workspace_bytes(const vp_eres2net_weights* w, int B, int T) {
 int vp_eres2net_fwd(vp_ctx* ctx, const vp_eres2net_weights* w, const void* feats, int B, int T, float* emb,
                     void* ws, size_t ws_bytes, vp_stream stream) {
     if (!ctx || !w || !feats || !emb || B <= 0 || T <= 0) VP_FAIL(ctx, VP_EINVAL, "eres2net: bad arguments");
-    if (w->dtype != VP_F32 && w->dtype != VP_BF16) VP_FAIL(ctx, VP_EINVAL, "eres2net: bad dtype");
+    if (!vp_backbone_dtype_ok(w->dtype)) VP_FAIL(ctx, VP_EINVAL, "eres2net: bad dtype");
     int nb = 0;
     for (int s = 0; s < 4; ++s) nb += w->stage_blocks[s];
     if (nb != w->n_blocks || w->n_blocks > VP_MAX_ERE_BLOCKS) VP_FAIL(ctx, VP_EINVAL, "eres2net: block counts do not add up");
@@ -140,7 +141,7 @@ int vp_eres2net_fwd(vp_ctx* ctx, const vp_eres2net_weights* w, const void* feats
     if (!ws || ws_bytes < p.total) VP_FAIL(ctx, VP_EWORKSPACE, "eres2net: workspace %zu < %zu", ws_bytes, p.total);
     if (p.t[4] < 2) VP_FAIL(ctx, VP_EINVAL, "eres2net: %d frames are too few (unbiased variance over T/8 frames)", T);
     hipStream_t st = (hipStream_t)stream;
-    const int dt = w->dtype;
+    const int dtc = w->dtype, dt = vp_storage_dtype(dtc);
     int rc;
     vp_conv1d_desc d;
     if ((rc = vp_conv3x3_c1(ctx, dt, feats, p.xa, w->c1_w, w->c1_b, w->c1_scale, w->c1_shift, B, T, w->feat_dim, w->m_channels, st)))
@@ -157,14 +158,14 @@ int vp_eres2net_fwd(vp_ctx* ctx, const vp_eres2net_weights* w, const void* feats
             if (b.scale < 1 || b.scale > VP_MAX_ERE_SCALE) VP_FAIL(ctx, VP_EINVAL, "eres2net: scale %d", b.scale);
             // o1 = hardtanh(bn1(conv1x1 stride s (x)))
             if (P > 0x7fffffff / 4) VP_FAIL(ctx, VP_EINVAL, "eres2net: too many positions");
-            conv_desc(d, b.conv1, dt);
+            conv_desc(d, b.conv1, dtc);
             if (b.stride == 1) { d.B = 1; d.T_in = (int)P; d.T_out = (int)P; }
             else geom2d(d, B, tin, fin, b.stride, false);
             d.x = x; d.y = p.o1; d.act2 = VP_ACT_HARDTANH20;
             if ((rc = b.stride == 1 ? conv1x1(ctx, d, st) : vp_conv1d_fwd(ctx, &d, st))) return rc;
             // chunk chain: sp_i = hardtanh(bn_i(conv3x3(in_i))) into o2[:, i*wd : (i+1)*wd]
             for (int i = 0; i < b.scale; ++i) {
-                conv_desc(d, b.convs[i], dt);
+                conv_desc(d, b.convs[i], dtc);
                 geom2d(d, B, to, fo, 1, true);
                 if (i == 0) { d.x = p.o1; d.ldx = W2; d.xoff = 0; }
                 else { d.x = p.spin; d.ldx = wd; d.xoff = 0; }
@@ -176,7 +177,7 @@ int vp_eres2net_fwd(vp_ctx* ctx, const vp_eres2net_weights* w, const void* feats
                 }
                 if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
                 if (more && b.use_aff) {
-                    if ((rc = run_aff(ctx, b.fuse[i], dt, p.o2, W2, i * wd, p.o1, W2, (i + 1) * wd, p.spin, wd, 0, P, wd, p.cat,
+                    if ((rc = run_aff(ctx, b.fuse[i], dtc, p.o2, W2, i * wd, p.o1, W2, (i + 1) * wd, p.spin, wd, 0, P, wd, p.cat,
                                       p.a1, p.att, st))) return rc;
                 }
             }
@@ -184,7 +185,7 @@ int vp_eres2net_fwd(vp_ctx* ctx, const vp_eres2net_weights* w, const void* feats
             const void* res = x;
             int ld_res = b.conv1.cin;
             if (b.has_shortcut) {
-                conv_desc(d, b.shortcut, dt);
+                conv_desc(d, b.shortcut, dtc);
                 if (b.stride == 1) { d.B = 1; d.T_in = (int)P; d.T_out = (int)P; }
                 else geom2d(d, B, tin, fin, b.stride, false);
                 d.x = x; d.y = p.res;
@@ -193,7 +194,7 @@ int vp_eres2net_fwd(vp_ctx* ctx, const vp_eres2net_weights* w, const void* feats
             }
             // out = hardtanh(bn3(conv1x1(o2)) + residual); the last block of a stage lands in the stage buffer
             void* dst = j + 1 == w->stage_blocks[s] ? p.stage[s] : (x == p.xa ? p.xb : p.xa);
-            conv_desc(d, b.conv3, dt);
+            conv_desc(d, b.conv3, dtc);
             d.B = 1; d.T_in = (int)P; d.T_out = (int)P; d.x = p.o2; d.y = dst;
             d.res = res; d.ld_res = ld_res; d.act2 = VP_ACT_HARDTANH20;
             if ((rc = conv1x1(ctx, d, st))) return rc;
@@ -208,12 +209,12 @@ int vp_eres2net_fwd(vp_ctx* ctx, const vp_eres2net_weights* w, const void* feats
     for (int k = w->first_fuse; k < 3; ++k) {
         const int C = w->down[k].cout;
         const long long P = (long long)B * p.t[k + 2] * p.f[k + 2];
-        conv_desc(d, w->down[k], dt);
+        conv_desc(d, w->down[k], dtc);
         geom2d(d, B, p.t[k + 1], p.f[k + 1], 2, true);
         d.x = low; d.y = p.ds;
         if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
         fout = (k & 1) ? p.fuse_b : p.fuse_a;
-        if ((rc = run_aff(ctx, w->fuse[k], dt, p.stage[k + 1], C, 0, p.ds, C, 0, fout, C, 0, P, C, p.fcat, p.fa1, p.fatt, st)))
+        if ((rc = run_aff(ctx, w->fuse[k], dtc, p.stage[k + 1], C, 0, p.ds, C, 0, fout, C, 0, P, C, p.fcat, p.fa1, p.fatt, st)))
             return rc;
         low = fout;
     }

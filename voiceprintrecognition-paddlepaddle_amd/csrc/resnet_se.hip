@@ -66,7 +66,7 @@ void plan_rse(const vp_resnetse_weights* w, int B, int T, void* ws, RsePlan& p) 
 
 void base_desc(vp_conv1d_desc& d, const vp_tdnn_layer& L, int dt) {
     memset(&d, 0, sizeof(d));
-    d.dtype_in = dt; d.dtype_out = dt; d.Cin = L.cin; d.Cout = L.cout; d.KW = L.kw; d.dilation = 1; d.stride = 1;
+    vp_desc_dtype(d, dt); d.Cin = L.cin; d.Cout = L.cout; d.KW = L.kw; d.dilation = 1; d.stride = 1;
     d.pad_mode = VP_PAD_ZERO; d.ldx = L.cin; d.ldy = L.cout;
     d.w = L.w; d.bias = L.bias; d.bn_scale = L.bn_scale; d.bn_shift = L.bn_shift;
 }
@@ -100,7 +100,7 @@ size_t vp_resnetse_workspace_bytes(const vp_resnetse_weights* w, int B, int T) {
 int vp_resnetse_fwd(vp_ctx* ctx, const vp_resnetse_weights* w, const void* feats, int B, int T, float* emb,
                     void* ws, size_t ws_bytes, vp_stream stream) {
     if (!ctx || !w || !feats || !emb || B <= 0 || T <= 0) VP_FAIL(ctx, VP_EINVAL, "resnetse: bad arguments");
-    if (w->dtype != VP_F32 && w->dtype != VP_BF16) VP_FAIL(ctx, VP_EINVAL, "resnetse: bad dtype");
+    if (!vp_backbone_dtype_ok(w->dtype)) VP_FAIL(ctx, VP_EINVAL, "resnetse: bad dtype");
     if (w->c1_channels != 32 || w->n_blocks < 1 || w->n_blocks > VP_MAX_RSE_BLOCKS)
         VP_FAIL(ctx, VP_EUNSUP, "resnetse: geometry not built (stem of 32 channels, <= %d blocks)", VP_MAX_RSE_BLOCKS);
     RsePlan p;
@@ -108,7 +108,7 @@ int vp_resnetse_fwd(vp_ctx* ctx, const vp_resnetse_weights* w, const void* feats
     if (!ws || ws_bytes < p.total) VP_FAIL(ctx, VP_EWORKSPACE, "resnetse: workspace %zu < %zu", ws_bytes, p.total);
     if (p.T4 < 2) VP_FAIL(ctx, VP_EINVAL, "resnetse: %d frames are too few", T);
     hipStream_t st = (hipStream_t)stream;
-    const int dt = w->dtype;
+    const int dtc = w->dtype, dt = vp_storage_dtype(dtc);
     int rc;
     vp_conv1d_desc d;
     if ((rc = vp_conv3x3_c1(ctx, dt, feats, p.xa, w->c1_w, w->c1_b, w->c1_scale, w->c1_shift, B, T, w->feat_dim, 32, st))) return rc;
@@ -120,7 +120,7 @@ int vp_resnetse_fwd(vp_ctx* ctx, const vp_resnetse_weights* w, const void* feats
         const int to = down(t, b.stride), fo = down(f, b.stride);
         const int C = b.conv3.cout;
         // o1 = relu(bn1(conv1x1(x))): a GEMM over the B*t*f positions
-        base_desc(d, b.conv1, dt);
+        base_desc(d, b.conv1, dtc);
         d.B = B; d.T_in = t * f; d.T_out = t * f; d.x = x; d.y = p.o1; d.act2 = VP_ACT_RELU;
         if ((rc = conv1x1(ctx, d, st))) return rc;
         // o2 = relu(bn2(conv3x3 stride s (o1))): the stage-1 blocks (32 -> 32 channels, stride 1, full-resolution maps) run on the
@@ -130,20 +130,20 @@ int vp_resnetse_fwd(vp_ctx* ctx, const vp_resnetse_weights* w, const void* feats
             fast = vp_conv3x3_c32_bf16(ctx, p.o1, p.o2, &b.conv2, nullptr, 1, nullptr, nullptr, B, t, f, 1, nullptr, nullptr, nullptr, nullptr, nullptr, st);
         if (fast != VP_OK && fast != VP_EUNSUP) return fast;
         if (fast != VP_OK) {
-            base_desc(d, b.conv2, dt);
+            base_desc(d, b.conv2, dtc);
             d.B = B; d.T_in = t; d.T_out = to; d.F_in = f; d.F_out = fo; d.KF = 3; d.stride = b.stride; d.stride_f = b.stride;
             d.pad_left = 1; d.pad_f = 1; d.x = p.o1; d.y = p.o2; d.act2 = VP_ACT_RELU;
             if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
         }
         // o3 = bn3(conv1x1(o2)) with the per-utterance sums of the SE squeeze fused in
-        base_desc(d, b.conv3, dt);
+        base_desc(d, b.conv3, dtc);
         d.B = B; d.T_in = to * fo; d.T_out = to * fo; d.x = p.o2; d.y = p.o3; d.psum = p.psum;
         if ((rc = conv1x1(ctx, d, st))) return rc;
         if ((rc = vp_se_gate(ctx, p.psum, b.conv3.bn_shift, B, to * fo, C, C / 8, b.se_w1, b.se_b1, b.se_w2, b.se_b2, p.se_s, st)))
             return rc;
         const void* res = x;
         if (b.has_down) {          // bn(conv1x1 stride (s, s)(x))
-            base_desc(d, b.down, dt);
+            base_desc(d, b.down, dtc);
             d.B = B; d.T_in = t; d.T_out = to; d.F_in = f; d.F_out = fo; d.KF = 1; d.stride = b.stride; d.stride_f = b.stride;
             d.x = x; d.y = p.res;
             if (b.stride == 1) {           // a plain pointwise conv over the B * t * f positions
@@ -162,7 +162,7 @@ int vp_resnetse_fwd(vp_ctx* ctx, const vp_resnetse_weights* w, const void* feats
     if (w->asp.C != Casp) VP_FAIL(ctx, VP_EINVAL, "resnetse: asp.C %d != %d", w->asp.C, Casp);
     if ((rc = vp_time_moments(ctx, dt, x, Casp, B, t, Casp, 1e-12f, 0, p.stats, st))) return rc;
     VpAspBufs ab{p.h, p.e, nullptr, nullptr, p.stats, p.rowbias, p.pooled};
-    if ((rc = vp_run_asp(ctx, w->asp, dt, x, Casp, nullptr, B, t, ab, st))) return rc;
+    if ((rc = vp_run_asp(ctx, w->asp, dtc, x, Casp, nullptr, B, t, ab, st))) return rc;
     return vp_dense_f32_ex(ctx, p.pooled, 2 * Casp, w->lin_w, 0, w->lin_b, nullptr, nullptr, B, w->embd_dim, 2 * Casp,
                            VP_ACT_NONE, emb, w->embd_dim, st);
 }

@@ -11,10 +11,15 @@ _COMPUTE_DTYPE = 'float32'
 
 
 def set_compute_dtype(name):
-    """'float32' (exact f32 matrix cores; the reference's precision) or 'bfloat16' (bf16 MFMA with
-    f32 accumulation and f32 statistics; the throughput path)."""
+    """Arithmetic of the eval-mode backbones:
+    'float32'   exact f32 matrix cores (v_mfma_f32_16x16x4_f32) -- the reference's precision, the default;
+    'float32x3' f32 tensors, every conv / GEMM in split precision: both operands become bf16 hi + lo on their way into LDS and are
+                contracted as hi*hi + hi*lo + lo*hi on the bf16 matrix cores with f32 accumulation (~2^-16 per product).  Meets the
+                reference's 1e-4 cosine-score tolerance at trained weights on every backbone at several times the f32 rate;
+    'bfloat16'  bf16 tensors and bf16 MFMA with f32 accumulation and f32 statistics -- the throughput path; at TRAINED weights its
+                scores differ from the f32 reference by 2e-3 (ECAPA-TDNN) to 4e-2 (ResNetSE): outside the 1e-4 tolerance."""
     global _COMPUTE_DTYPE
-    if name not in ('float32', 'bfloat16'):
+    if name not in ('float32', 'float32x3', 'bfloat16'):
         raise ValueError(f'unsupported compute dtype {name}')
     _COMPUTE_DTYPE = name
 

@@ -145,6 +145,7 @@ class FCM(nn.Module):
 
 
 class CAMPPlus(EngineMixin, nn.Module):
+    _bf16_trained_score_err = '1.3e-2'      # quoted by engine('bfloat16')'s warning (models/engine.py; profiles/r05_trained_weights_parity.log)
     _engine_cls = CamppEngine
 
     def __init__(self, input_size, embd_dim=512, growth_rate=32, bn_size=4, init_channels=128,

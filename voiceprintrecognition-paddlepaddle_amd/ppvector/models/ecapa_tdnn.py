@@ -48,6 +48,7 @@ class SERes2NetBlock(nn.Module):
 
 
 class EcapaTdnn(EngineMixin, nn.Module):
+    _bf16_trained_score_err = '1.9e-3'      # quoted by engine('bfloat16')'s warning (models/engine.py; profiles/r05_trained_weights_parity.log)
     _engine_cls = EcapaEngine
 
     def __init__(self, input_size, embd_dim=192, pooling_type="ASP", activation=nn.ReLU,

@@ -27,6 +27,7 @@ class _LinearParams(nn.Module):
 
 
 class TDNN(EngineMixin, nn.Module):
+    _bf16_trained_score_err = '1.7e-3'      # quoted by engine('bfloat16')'s warning (models/engine.py; profiles/r05_trained_weights_parity.log)
     _engine_cls = TdnnEngine
 
     def __init__(self, input_size, channels=512, embd_dim=192, pooling_type="ASP"):
