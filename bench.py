@@ -663,7 +663,7 @@ def main():
     ap.add_argument('--steps', type=int, default=300)     # 0.38 s of timed region at 1.27 ms per step: visible to an outside GPU-busy sampler
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'])
-    ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float32'])
+    ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float32x3', 'float32'])
     ap.add_argument('--streams', type=int, default=2, help='concurrent launch sequences per GPU (infer mode)')
     ap.add_argument('--graph', type=int, default=1, help='infer mode: replay the step from one captured HIP graph (1) or launch eagerly (0)')
     ap.add_argument('--amp', type=int, default=1, help='training: conv GEMMs on the bf16 matrix cores, bf16-stored activations (enable_amp); 0 = exact f32')

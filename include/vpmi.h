@@ -32,8 +32,13 @@ typedef void* vp_stream; /* hipStream_t */
 
 enum { VP_OK = 0, VP_EINVAL = -1, VP_ENOMEM = -2, VP_EHIP = -3, VP_EUNSUP = -4, VP_EWORKSPACE = -5 };
 enum { VP_F32 = 0, VP_BF16 = 1,                    /* element type of activations / GEMM weights     */
-       VP_F32X3 = 2 };                             /* `dtype` of a whole-backbone weights struct only: f32 tensors (as VP_F32), every
+       VP_F32X3 = 2,                               /* `dtype` of a whole-backbone weights struct only: f32 tensors (as VP_F32), every
                                                       conv / GEMM in split precision (vp_conv1d_desc.mfma_bf16 = 2)                  */
+       VP_HL32 = 3 };                              /* split bf16 planes, the storage form of split precision: a row of C channels
+                                                      (C % 32 == 0) is C / 32 groups of 128 bytes = [32 bf16 hi | 32 bf16 lo], value =
+                                                      hi + lo, hi = bf16(v), lo = bf16(v - hi).  4 bytes per element: leading dimensions
+                                                      and offsets count elements exactly as for f32 (multiples of 32).  The consumer's
+                                                      LDS K-stage row IS a group, so wide layers stream it by LDS-DMA               */
 enum { VP_PAD_NONE = 0, VP_PAD_REFLECT = 1, VP_PAD_ZERO = 2 };
 enum { VP_ACT_NONE = 0, VP_ACT_RELU = 1, VP_ACT_SIGMOID = 2, VP_ACT_TANH = 3,
        VP_ACT_HARDTANH20 = 4,   /* clamp to [0, 20]: ERes2Net's "ReLU" (models/eres2net.py:12-20) */
@@ -225,6 +230,8 @@ typedef struct {
     const float* bn_scale;    /* [cout] or NULL */
     const float* bn_shift;    /* [cout] or NULL */
     int cin, cout, kw, dil;
+    const void* w_hl;         /* optional (NULL = absent): the same weights as split bf16 planes (VP_HL32), [cout][kw*cin], kw*cin % 32
+                                 == 0 -- what the split-precision fast path of a VP_F32X3 backbone reads (LDS-DMA-able)  */
 } vp_tdnn_layer;
 
 typedef struct {
@@ -286,8 +293,20 @@ int vp_se_gate_fwd(vp_ctx* ctx, const float* psum, const float* shift, int B, in
 int vp_asp_utt_fwd(vp_ctx* ctx, const void* x, int ldx, const vp_tdnn_layer* tdnn, const float* rowbias, const void* conv_w,
                    const float* conv_b, int B, int T, int C, int att, float eps, float* pooled, vp_stream stream);
 
+/* The two fused kernels of the SPLIT-PRECISION ECAPA forward (w->dtype = VP_F32X3 with split weights present: csrc/ecapa.hip), tensors
+ * stored as split bf16 planes (VP_HL32), every product hi*hi + hi*lo + lo*hi on the bf16 matrix cores, f32 accumulate:
+ * vp_res2_chain_x3_fwd: Res2NetBlock.forward (ecapa_tdnn.py:36-47) as vp_res2_chain_fwd, t1 / r2 hl32 (B*T, C), weights layers[j].w_hl
+ *   (hl32 [64][192]).  The utterance is cut into time segments with recomputed halos so that a segment's ping-pong buffers and one
+ *   conv's weights fit the LDS (csrc/res2_x3.hip).  VP_EUNSUP unless width == 64, equal dilations, w_hl present, the segments fit.
+ * vp_asp_fused_x3_fwd: AttentiveStatisticsPooling.forward (pooling.py:112-123) from the attention hidden layer on, as vp_asp_fused_fwd:
+ *   h (B*T, att) hl32, w [C][att] F32 (split in registers), x (B*T, ldx) hl32.  att == 128, C and ldx multiples of 32. */
+int vp_res2_chain_x3_fwd(vp_ctx* ctx, const vp_tdnn_layer* layers, int nconv, const void* t1, void* r2, int B, int T, int C,
+                         int width, vp_stream stream);
+int vp_asp_fused_x3_fwd(vp_ctx* ctx, const void* h, const float* w, const float* bias, const void* x, int ldx, const float* center,
+                        int ldc, int B, int T, int C, int att, float eps, float* pooled, vp_stream stream);
+
 size_t vp_ecapa_workspace_bytes(const vp_ecapa_weights* w, int B, int T);
-/* feats: (B, T, feat_dim) in w->dtype; emb: (B, embd_dim) f32. */
+/* feats: (B, T, feat_dim) in w->dtype (f32 for VP_F32X3); emb: (B, embd_dim) f32. */
 int vp_ecapa_fwd(vp_ctx* ctx, const vp_ecapa_weights* w, const void* feats, int B, int T, float* emb,
                  void* ws, size_t ws_bytes, vp_stream stream);
 

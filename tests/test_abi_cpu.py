@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_header_layout():
     import ctypes as C
     from ppvector import _native as N
-    assert C.sizeof(N.TdnnLayer) == 4 * 8 + 4 * 4
+    assert C.sizeof(N.TdnnLayer) == 4 * 8 + 4 * 4 + 8              # four pointers, four ints, w_hl
     assert C.sizeof(N.FbankOpts) == 9 * 4
     assert C.sizeof(N.SeRes2Block) == 17 * C.sizeof(N.TdnnLayer) + 4 * 8
     assert C.sizeof(N.AspWeights) == C.sizeof(N.TdnnLayer) + 3 * 8 + 8

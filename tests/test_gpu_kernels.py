@@ -313,6 +313,99 @@ def test_conv1d_split_precision(N, case):
     assert not torch.isnan(ps).any() and not torch.isnan(pq).any()
 
 
+HL_CASES = [
+    # name, B, T, Cin, Cout, kw, in_fmt, out_fmt, extras
+    ('block0: f32 features in, hl32 out (128-wide kernel, taps)', 3, 298, 80, 512, 5, 'f32', 'hl', ()),
+    ('asp tdnn: hl32 in / out, tanh + rowbias (128-wide kernel)', 3, 298, 1536, 128, 1, 'hl', 'hl', ('tanh', 'rowbias')),
+    ('tdnn1: ring, hl32 in / out + pass-through chunk to y2', 16, 298, 512, 512, 1, 'hl', 'hl', ('ysplit',)),
+    ('tdnn2: ring, hl32 in / out + fused time sums', 16, 298, 512, 512, 1, 'hl', 'hl', ('sums',)),
+    ('mfa: ring, K = 1536, both sums, ragged last tile', 15, 298, 1536, 1536, 1, 'hl', 'hl', ('sums',)),
+    ('ring, hl32 in, f32 out', 16, 298, 512, 256, 1, 'hl', 'f32', ()),
+    ('ring, slow rows: residual + aux', 16, 298, 512, 256, 1, 'hl', 'hl', ('res', 'aux')),
+]
+
+
+@pytest.mark.parametrize('case', HL_CASES, ids=[c[0].split(':')[0] + f'_{i}' for i, c in enumerate(HL_CASES)])
+def test_conv1d_hl32(N, case):
+    """Split bf16 planes (VP_HL32) as a STORAGE format of the split-precision engine: the conv GEMMs of the ECAPA fast path read / write
+    them (128-wide kernel: f32 -> hl32 and hl32 -> hl32; 128 x 256 LDS-DMA ring: hl32 -> hl32 / f32).  Against the float64 conv of the
+    values the inputs actually carry (hi + lo), the output is held to split precision's error plus its own hl32 rounding (2^-17)."""
+    from ppvector.models.utils import pack_hl32, unpack_hl32
+    name, B, T, Cin, Cout, kw, fin, fout, extras = case
+    lib, ctx = N.lib(), N.ctx(0)
+    g = torch.Generator().manual_seed(HL_CASES.index(case) + 50)
+    x = torch.randn(B, T, Cin, generator=g)
+    w = torch.randn(Cout, Cin, kw, generator=g) / (Cin * kw) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    wp = w.permute(0, 2, 1).reshape(Cout, kw * Cin).contiguous()
+    if fin == 'hl':
+        xd, wd = pack_hl32(x).cuda(), pack_hl32(wp).cuda()
+        xv, wv = unpack_hl32(xd).double().cpu(), unpack_hl32(wd).double().cpu().reshape(Cout, kw, Cin).permute(0, 2, 1)
+    else:
+        xd, wd = x.cuda(), wp.cuda()
+        xv, wv = x.double(), w.double()
+    y = torch.zeros(B, T, Cout, device='cuda')
+    d = N.Conv1dDesc()
+    d.dtype_in = N.VP_HL32 if fin == 'hl' else N.VP_F32
+    d.dtype_out = N.VP_HL32 if fout == 'hl' else N.VP_F32
+    d.mfma_bf16 = 2
+    d.B, d.T_in, d.T_out, d.Cin, d.Cout, d.KW, d.dilation, d.stride = B, T, T, Cin, Cout, kw, 1, 1
+    d.pad_mode, d.pad_left = N.VP_PAD_REFLECT, (kw - 1) // 2
+    d.x, d.ldx, d.w, d.y, d.ldy = xd.data_ptr(), Cin, wd.data_ptr(), y.data_ptr(), Cout
+    bd, scd, shd = bias.cuda(), sc.cuda(), sh.cuda()
+    d.bias, d.act, d.bn_scale, d.bn_shift = bd.data_ptr(), N.VP_ACT_RELU, scd.data_ptr(), shd.data_ptr()
+    z = conv_ref(xv, wv, bias.double(), kw, 1, 'reflect')
+    keep = []
+    if 'rowbias' in extras:
+        rb = torch.randn(B, Cout, generator=g); rbd = rb.cuda(); keep.append(rbd)
+        d.rowbias = rbd.data_ptr()
+        z = z + rb.double()[:, None, :]
+    ref = torch.relu(z) * sc.double() + sh.double()
+    if 'res' in extras:
+        res = torch.randn(B, T, Cout, generator=g)
+        rsd = pack_hl32(res).cuda(); keep.append(rsd)
+        d.res, d.ld_res = rsd.data_ptr(), Cout
+        ref = ref + unpack_hl32(rsd).double().cpu()
+    if 'tanh' in extras:
+        d.act2 = N.VP_ACT_TANH
+        ref = torch.tanh(ref)
+    y2 = aux = ps = pq = None
+    if 'ysplit' in extras:
+        y2 = torch.zeros(B, T, 128, device='cuda'); d.y2, d.ldy2, d.y2off, d.ysplit = y2.data_ptr(), 128, 64, 64
+    if 'aux' in extras:
+        add = torch.randn(B, T, Cout, generator=g)
+        addd = pack_hl32(add).cuda(); aux = torch.zeros(B, T, Cout, device='cuda'); keep.append(addd)
+        d.add_in, d.ld_add, d.aux, d.ld_aux = addd.data_ptr(), Cout, aux.data_ptr(), Cout
+    if 'sums' in extras:
+        tiles, nseg = lib.vp_conv1d_tiles_m(B, T), lib.vp_conv1d_nseg(T)
+        ps = torch.full((tiles, nseg, Cout), float('nan'), device='cuda'); pq = torch.full((tiles, nseg, Cout), float('nan'), device='cuda')
+        d.psum, d.psumsq = ps.data_ptr(), pq.data_ptr()
+    N.check(lib.vp_conv1d_fwd(ctx, C.byref(d), N.stream_ptr()), ctx)
+    torch.cuda.synchronize()
+    got = (unpack_hl32(y) if fout == 'hl' else y).double().cpu()
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    print(f'[conv hl32] {name}: max |err| {err:.2e} (outputs up to {scale:.1f})')
+    assert err < 6e-5 * max(1.0, scale), err
+    if y2 is not None:
+        got2 = unpack_hl32(y2).double().cpu()
+        assert (got2[..., 64:128] - ref[..., :64]).abs().max().item() < 6e-5 * max(1.0, scale)
+        assert (y2[..., :64] == 0).all()
+    if aux is not None:
+        assert (unpack_hl32(aux).double().cpu() - (ref + unpack_hl32(addd).double().cpu())).abs().max().item() < 1.2e-4 * max(1.0, scale)
+    if ps is not None:
+        ps, pq = ps.double().cpu(), pq.double().cpu()
+        for b in range(B):
+            s1 = torch.zeros(Cout, dtype=torch.float64); s2 = torch.zeros(Cout, dtype=torch.float64)
+            for tm in range((b * T) // 128, ((b + 1) * T - 1) // 128 + 1):
+                sg = b - (tm * 128) // T
+                s1 += ps[tm, sg]; s2 += pq[tm, sg]
+            dref = ref[b] - sh.double()
+            assert (s1 - dref.sum(0)).abs().max().item() < 1e-4 * max(1.0, dref.sum(0).abs().max().item())
+            assert (s2 - (dref ** 2).sum(0)).abs().max().item() < 1e-4 * (dref ** 2).sum(0).abs().max().item()
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_conv1d_full_epilogue(N, dtype):
     B, T, Cin, Cout, kw, dil = 3, 70, 64, 192, 3, 2
@@ -925,6 +1018,98 @@ def test_res2_chain_kernel_vs_float64(N, B, T, dil):
     assert err.mean().item() < 2e-4 * scale
     edge = torch.cat([err[:, :2 * dil], err[:, -2 * dil:]], dim=1)            # the reflected frames, separately
     assert edge.max().item() < 2.0 ** -7 * scale
+
+
+@pytest.mark.parametrize('B,T,dil', [(3, 28, 2), (2, 298, 2), (2, 298, 3), (5, 298, 4), (2, 400, 4), (4, 17, 2), (3, 33, 4), (2, 600, 3)])
+def test_res2_chain_x3_kernel_vs_float64(N, B, T, dil):
+    """vp_res2_chain_x3_fwd (split precision, tensors as split bf16 planes, the utterance cut into time segments with recomputed halos)
+    against the float64 Res2NetBlock.forward (ecapa_tdnn.py:36-47) of the values the planes carry -- NO intermediate rounding in the
+    reference: every frame of every slice incl. the reflected boundary frames and the frames on both sides of a segment cut (T = 298:
+    two segments cut at 160; T = 400 / 600: three / four), held to split precision's own error."""
+    from ppvector.models.utils import pack_hl32, unpack_hl32
+    lib, ctx = N.lib(), N.ctx(0)
+    Cc, wdt, nconv = 512, 64, 7
+    g = torch.Generator().manual_seed(100 * T + dil)
+    t1d = pack_hl32(torch.randn(B, T, Cc, generator=g)).cuda()
+    t1 = unpack_hl32(t1d).double().cpu()
+    ws = [torch.randn(wdt, wdt, 3, generator=g) / (3 * wdt) ** 0.5 for _ in range(nconv)]
+    bs = [0.1 * torch.randn(wdt, generator=g, dtype=torch.float64).float().double() for _ in range(nconv)]
+    scs = [(torch.rand(wdt, generator=g, dtype=torch.float64) + 0.5).float().double() for _ in range(nconv)]
+    shs = [0.2 * torch.randn(wdt, generator=g, dtype=torch.float64).float().double() for _ in range(nconv)]
+    layers, keep = _tdnn_layers(N, [w.double() for w in ws], bs, scs, shs, dil)
+    wv = []
+    for j, w in enumerate(ws):                                         # k = tap * 64 + channel, as split planes
+        whl = pack_hl32(w.permute(0, 2, 1).reshape(wdt, 3 * wdt)).cuda()
+        keep.append(whl)
+        layers[j].w_hl = whl.data_ptr()
+        wv.append(unpack_hl32(whl).double().cpu().reshape(wdt, 3, wdt).permute(0, 2, 1))
+    ref = torch.zeros(B, T, Cc, dtype=torch.float64)
+    cur = t1[:, :, wdt:2 * wdt]
+    for j in range(nconv):
+        xt = F.pad(cur.transpose(1, 2), (dil, dil), mode='reflect')
+        v = (torch.relu(F.conv1d(xt, wv[j], bs[j], dilation=dil)) * scs[j][None, :, None] + shs[j][None, :, None]).transpose(1, 2)
+        ref[:, :, (j + 1) * wdt:(j + 2) * wdt] = v
+        if j + 1 < nconv:
+            cur = v + t1[:, :, (j + 2) * wdt:(j + 3) * wdt]
+    r2 = pack_hl32(torch.full((B, T, Cc), 7.0)).cuda()
+    N.check(lib.vp_res2_chain_x3_fwd(ctx, layers, nconv, t1d.data_ptr(), r2.data_ptr(), B, T, Cc, wdt, N.stream_ptr()), ctx)
+    torch.cuda.synchronize()
+    out = unpack_hl32(r2).double().cpu()
+    assert torch.all(out[:, :, :wdt] == 7.0)                                  # slice 0 belongs to the producing conv
+    err = (out[:, :, wdt:] - ref[:, :, wdt:]).abs()
+    scale = ref.abs().max().item()
+    print(f'[res2_chain_x3 B={B} T={T} d={dil}] max err {err.max().item():.3e} (max |ref| {scale:.2f}), mean {err.mean().item():.2e}')
+    assert err.max().item() < 1e-4 * max(1.0, scale), err.max().item()         # seven chained convs of ~2^-17 products + hl32 stores
+    assert err.mean().item() < 1e-5 * max(1.0, scale)
+
+
+def test_res2_chain_x3_refuses_shapes_it_does_not_cover(N):
+    from ppvector.models.utils import pack_hl32
+    lib, ctx = N.lib(), N.ctx(0)
+    g = torch.Generator().manual_seed(0)
+    ws = [torch.randn(64, 64, 3, generator=g, dtype=torch.float64) for _ in range(7)]
+    z = [torch.zeros(64, dtype=torch.float64) for _ in range(7)]
+    layers, keep = _tdnn_layers(N, ws, z, z, z, 2)
+    t1 = torch.zeros((1, 100, 512), device='cuda')
+    r2 = torch.zeros_like(t1)
+    assert lib.vp_res2_chain_x3_fwd(ctx, layers, 7, t1.data_ptr(), r2.data_ptr(), 1, 100, 512, 64, N.stream_ptr()) == N.VP_EUNSUP   # no split weights
+    for j in range(7):
+        whl = pack_hl32(ws[j].float().permute(0, 2, 1).reshape(64, 192)).cuda(); keep.append(whl)
+        layers[j].w_hl = whl.data_ptr()
+    assert lib.vp_res2_chain_x3_fwd(ctx, layers, 7, t1.data_ptr(), r2.data_ptr(), 1, 100, 512, 32, N.stream_ptr()) == N.VP_EUNSUP   # width != 64
+    assert lib.vp_res2_chain_x3_fwd(ctx, layers, 7, t1.data_ptr(), r2.data_ptr(), 1, 100, 512, 64, N.stream_ptr()) == N.VP_OK
+
+
+@pytest.mark.parametrize('B,T,Cc', [(3, 28, 1536), (2, 298, 1536), (3, 512, 512), (2, 37, 224)])
+def test_asp_fused_x3_kernel_vs_float64(N, B, T, Cc):
+    """vp_asp_fused_x3_fwd (split precision: h and x as split bf16 planes, f32 weights split in registers) against float64: logits GEMM
+    (128 -> C) + softmax over time + weighted mean / std (pooling.py:105-123); T not a multiple of the 16-frame tile, C not a multiple of
+    128.  Two orders tighter than the bf16 kernel's bound."""
+    from ppvector.models.utils import pack_hl32, unpack_hl32
+    lib, ctx = N.lib(), N.ctx(0)
+    att = 128
+    g = torch.Generator().manual_seed(T + Cc)
+    hd = pack_hl32(torch.tanh(torch.randn(B, T, att, generator=g))).cuda()
+    h = unpack_hl32(hd).double().cpu()
+    w32 = torch.randn(Cc, att, generator=g) * (3.0 / att ** 0.5)                                # logits spread over several units
+    bias = torch.randn(Cc, generator=g, dtype=torch.float64).float().double()
+    xd = pack_hl32(torch.randn(B, T, Cc, generator=g) * 2 + 0.5 * torch.randn(1, 1, Cc, generator=g)).cuda()
+    x = unpack_hl32(xd).double().cpu()
+    e = h @ w32.double().t() + bias
+    al = torch.softmax(e, dim=1)
+    mu = (al * x).sum(1)
+    sd = torch.sqrt(((al * (x - mu[:, None]) ** 2).sum(1)).clamp(min=1e-12))
+    ref = torch.cat([mu, sd], 1)
+    center = torch.cat([x.mean(1), x.std(1, unbiased=False)], 1)                                # the global-context stats buffer
+    wd, bd, cd = w32.cuda(), dev(bias, torch.float32), dev(center, torch.float32)
+    pooled = torch.full((B, 2 * Cc), float('nan'), dtype=torch.float32, device='cuda')
+    N.check(lib.vp_asp_fused_x3_fwd(ctx, hd.data_ptr(), wd.data_ptr(), bd.data_ptr(), xd.data_ptr(), Cc, cd.data_ptr(), 2 * Cc, B, T, Cc, att,
+                                    1e-12, pooled.data_ptr(), N.stream_ptr()), ctx)
+    torch.cuda.synchronize()
+    err = (pooled.double().cpu() - ref).abs()
+    print(f'[asp_fused_x3 B={B} T={T} C={Cc}] max err {err.max().item():.3e} (max |ref| {ref.abs().max().item():.2f})')
+    assert not torch.isnan(pooled).any()
+    assert err.max().item() < 2e-5 * max(1.0, ref.abs().max().item()), err.max().item()
 
 
 def test_res2_chain_refuses_shapes_it_does_not_cover(N):

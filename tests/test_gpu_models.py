@@ -119,6 +119,29 @@ def test_ecapa_vs_oracle_3s_batch(ecapa):
     assert np.all(1 - c < 1e-3)
 
 
+def test_ecapa_split_precision_engine_vs_oracle(ecapa):
+    """engine('float32x3') on 3 s utterances: at 16 utterances the ECAPA driver takes its hl32 fast path (tensors as split bf16 planes,
+    LDS-DMA ring GEMMs, fused Res2 chain in two time segments, fused pooling: csrc/ecapa.hip), at 5 (fewer than 4096 frames) the generic
+    split-precision path (f32 tensors, operands split while staging) -- both against the CPU oracle, and against each other on the
+    shared utterances: the two paths differ only in where the split happens."""
+    w = ofb.synth_waves(16, 48000, seed=1000, lowpass=0.9)
+    feats = ofb.featurize(w, method_args=dict(sr=16000, n_mels=80))
+    p = om.ecapa_params(80, seed=1000)
+    with torch.no_grad():
+        ref = om.ecapa_forward(p, torch.from_numpy(feats)).numpy()
+    eng = ecapa.engine('float32x3')
+    fast = eng.forward(torch.from_numpy(feats).cuda()).cpu().numpy()
+    gen = eng.forward(torch.from_numpy(feats[:5]).cuda()).cpu().numpy()
+    for name, emb, r in (('hl32 fast path, B = 16', fast, ref), ('generic, B = 5', gen, ref[:5])):
+        rel = np.linalg.norm(emb - r) / np.linalg.norm(r)
+        se = _score_err(emb, r)
+        print(f'[ecapa float32x3 {name}] rel-L2 {rel:.3e}  all-pairs max |score - oracle| {se:.3e}')
+        assert rel < 1e-4 and se < 2e-5, (name, rel, se)
+    d = np.linalg.norm(fast[:5] - gen) / np.linalg.norm(gen)
+    print(f'[ecapa float32x3] fast path vs generic path on the same 5 utterances: rel-L2 {d:.3e}')
+    assert d < 5e-5, d
+
+
 def test_full_size_batch_invariance(ecapa):
     """BASELINE config 2 shape (B=256, T=298): eval-mode embeddings are per-utterance functions, so
     any utterance's embedding must not depend on the batch it travels in (size-independent

@@ -1,6 +1,8 @@
 """Micro-benchmark of the 256-wide conv GEMM (no model around it): every schedule of the kernel on the bench shapes,
 interleaved rounds in ONE process (A/B), full-output check against a torch matmul of the same bf16 operands.
-Usage: python tools/gemm_probe.py [rounds] [schedules, e.g. 3,4] [CinxCout ...]"""
+Usage: python tools/gemm_probe.py [rounds] [schedules, e.g. 3,4] [CinxCout ...]
+X3=1: the split-precision form of the same layers (hl32 operands and output on the 128 x 256 ring, csrc/conv_gemm256.hip; schedule ids are
+ignored), checked against the f32 matmul of the values the planes carry; TF figures then count the algorithmic 2 M N K flops."""
 import ctypes as C
 import os
 import sys
@@ -9,6 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'voiceprintrecognition-paddlepaddle_amd'))
 import torch  # noqa: E402
 from ppvector import _native as N  # noqa: E402
+from ppvector.models.utils import pack_hl32, unpack_hl32  # noqa: E402
+
+X3 = os.environ.get('X3') == '1'
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 scheds = [int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else [3, 4, 5]
@@ -23,10 +28,16 @@ for cin, cout in shapes:
     bias = torch.randn((cout,), device='cuda', generator=g)
     sc = torch.rand((cout,), device='cuda', generator=g) + 0.5
     sh = torch.randn((cout,), device='cuda', generator=g)
-    ref = torch.relu(x.float() @ w.float().t() + bias) * sc + sh
-    y = torch.empty((M, cout), device='cuda', dtype=torch.bfloat16)
+    if X3:
+        x = pack_hl32(torch.randn((M, cin), device='cuda', generator=g))
+        w = pack_hl32(torch.randn((cout, cin), device='cuda', generator=g) / cin ** 0.5)
+        ref = torch.relu(unpack_hl32(x).double() @ unpack_hl32(w).double().t() + bias) * sc + sh
+    else:
+        ref = torch.relu(x.float() @ w.float().t() + bias) * sc + sh
+    y = torch.empty((M, cout), device='cuda', dtype=torch.float32 if X3 else torch.bfloat16)
     d = N.Conv1dDesc()
-    d.dtype_in = d.dtype_out = N.VP_BF16
+    d.dtype_in = d.dtype_out = N.VP_HL32 if X3 else N.VP_BF16
+    d.mfma_bf16 = 2 if X3 else 0
     d.B, d.T_in, d.T_out, d.Cin, d.Cout, d.KW, d.dilation, d.stride = B, T, T, cin, cout, 1, 1, 1
     d.pad_mode = N.VP_PAD_REFLECT
     d.x, d.ldx, d.w, d.y, d.ldy = x.data_ptr(), cin, w.data_ptr(), y.data_ptr(), cout
@@ -49,7 +60,7 @@ for cin, cout in shapes:
                 b.record()
             torch.cuda.synchronize()
             times[s] += [a.elapsed_time(b) for a, b in evs[1:]]
-            err = (y.float() - ref).abs().max().item() / ref.abs().max().item()      # every element, every round (races show up here)
+            err = ((unpack_hl32(y) if X3 else y.float()) - ref).abs().max().item() / ref.abs().max().item()      # every element, every round (races show up here)
             worst[s] = max(worst[s], err)
     for s in scheds:
         t = sorted(times[s])

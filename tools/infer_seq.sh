@@ -1,7 +1,8 @@
-# ordered kernel list of ONE inference step (the last of the run, one stream, no graph) with durations: bash tools/infer_seq.sh
+# ordered kernel list of ONE inference step (the last of the run, one stream, no graph) with durations: bash tools/infer_seq.sh [batch] [dtype]
 export TMPDIR=/tmp
 GB=${1:-256}
-(cd /tmp && timeout 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/iseq -o tr -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --graph 0 --streams 1 --no-cpu-baseline --no-roofline --no-train-line > /tmp/iseq.log 2>&1)
+DT=${2:-bfloat16}
+(cd /tmp && timeout 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/iseq -o tr -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --dtype $DT --graph 0 --streams 1 --no-cpu-baseline --no-roofline --no-train-line > /tmp/iseq.log 2>&1)
 f=$(find /tmp/iseq -name "*kernel_trace.csv" | head -n 1)
 python3 - "$f" <<'PY'
 import csv, sys, re

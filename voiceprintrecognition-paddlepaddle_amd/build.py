@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libvpmi.so')
-SOURCES = ['api.hip', 'fbank.hip', 'melspec.hip', 'conv_gemm.hip', 'conv_gemm_bf16.hip', 'conv_gemm256.hip', 'conv_gemm_f32.hip', 'conv_gemm_x3.hip', 'small_ops.hip', 'head.hip', 'head_tiled.hip', 'losses.hip', 'res2_chain.hip', 'asp_fused.hip', 'asp_utt.hip', 'ecapa.hip', 'campplus.hip', 'cam_block.hip', 'fcm_conv.hip', 'pointwise.hip', 'resnet_se.hip', 'eres2net.hip', 'augment.hip', 'train_ops.hip', 'wgrad_tr.hip', 'res2_train.hip', 'se_train.hip', 'cam_train.hip']
+SOURCES = ['api.hip', 'fbank.hip', 'melspec.hip', 'conv_gemm.hip', 'conv_gemm_bf16.hip', 'conv_gemm256.hip', 'conv_gemm_f32.hip', 'conv_gemm_x3.hip', 'small_ops.hip', 'head.hip', 'head_tiled.hip', 'losses.hip', 'res2_chain.hip', 'res2_x3.hip', 'asp_x3.hip', 'asp_fused.hip', 'asp_utt.hip', 'ecapa.hip', 'campplus.hip', 'cam_block.hip', 'fcm_conv.hip', 'pointwise.hip', 'resnet_se.hip', 'eres2net.hip', 'augment.hip', 'train_ops.hip', 'wgrad_tr.hip', 'res2_train.hip', 'se_train.hip', 'cam_train.hip']
 # -packed-fp32-ops: NO v_pk_{fma,mul,add}_f32 anywhere in the library.  On gfx950 a packed-f32 VALU instruction that reads registers a
 # vector-memory load has just returned can see stale data in lanes 48-63 when an MFMA-heavy wave of another kernel shares its SIMD
 # (reproducer tools/canary.hip + tools/stress_canary.py; tests/test_isa_cpu.py keeps the count at zero).  The

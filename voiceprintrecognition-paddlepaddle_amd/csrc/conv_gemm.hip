@@ -29,6 +29,9 @@ int vp_conv_launch_bf16_f32(vp_ctx* ctx, const void* args, int bn, int mode, hip
 int vp_conv_launch_f32_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
 int vp_conv_launch_amp_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
 int vp_conv_launch_x3_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
+int vp_conv_launch_x3_hl(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
+int vp_conv_launch_hl_hl(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
+int vp_conv_launch_ring_x3(vp_ctx* ctx, const void* args, int out_f32, hipStream_t st);
 int vp_conv_launch256_bf16(vp_ctx* ctx, const void* args, int mode, int sched, int out_f32, hipStream_t st);
 
 // Schedule of the 256-wide kernel: 0 pins the 128-wide kernel; 1 = interleaved DMA, 2 = ping-pong phases, 3 = role-split
@@ -65,9 +68,21 @@ int vp_conv1d_nseg(int T_out) { return T_out > 0 ? (BM - 1) / T_out + 2 : 0; }
 
 int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream) {
     if (!ctx || !d || !d->x || !d->w || !d->y) VP_FAIL(ctx, VP_EINVAL, "conv1d: null argument");
-    if ((d->dtype_in != VP_F32 && d->dtype_in != VP_BF16) || (d->dtype_out != VP_F32 && d->dtype_out != VP_BF16))
+    if ((d->dtype_in != VP_F32 && d->dtype_in != VP_BF16 && d->dtype_in != VP_HL32) ||
+        (d->dtype_out != VP_F32 && d->dtype_out != VP_BF16 && d->dtype_out != VP_HL32))
         VP_FAIL(ctx, VP_EINVAL, "conv1d: bad dtype");
     if (d->dtype_in == VP_F32 && d->dtype_out == VP_BF16) VP_FAIL(ctx, VP_EUNSUP, "conv1d: f32 -> bf16 not built");
+    const bool hl_in = d->dtype_in == VP_HL32, hl_out = d->dtype_out == VP_HL32;
+    if (hl_in || hl_out) {
+        // split bf16 planes (vpmi.h: VP_HL32): 32-channel groups; f32 x (split while staging, mfma_bf16 = 2) or hl32 x, hl32 w with hl32 x
+        if ((hl_in && (d->Cin % 32 || d->ldx % 32 || d->xoff % 32)) ||
+            (hl_out && (d->Cout % 32 || d->ldy % 32 || d->yoff % 32 || d->ysplit % 32 || d->ldy2 % 32 || d->y2off % 32 || d->ld_add % 32 ||
+                        d->add_off % 32 || d->ld_aux % 32 || d->aux_off % 32 || d->ld_res % 32 || d->res_off % 32)))
+            VP_FAIL(ctx, VP_EINVAL, "conv1d: hl32 tensors need channel counts, leading dimensions and offsets that are multiples of 32");
+        if (d->dtype_in == VP_BF16 || d->dtype_out == VP_BF16 || (d->dtype_in == VP_F32 && d->mfma_bf16 != 2) || d->gate || d->pro_scale ||
+            d->KF > 1 || d->F_in > 1 || d->F_out > 1)
+            VP_FAIL(ctx, VP_EUNSUP, "conv1d: hl32 is built for 1-D layers of the split-precision engine (f32 / hl32 in with mfma_bf16 = 2 semantics)");
+    }
     const int epc = d->dtype_in == VP_BF16 ? 8 : 4;
     if (d->B <= 0 || d->T_in <= 0 || d->T_out <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KW <= 0 || d->stride <= 0 ||
         d->dilation <= 0)
@@ -128,6 +143,7 @@ int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream) {
     int bn = d->Cout <= 32 ? 32 : (d->Cout <= 64 ? 64 : 128);
     if (mode == MODE_1X1_PRO && bn > 64) bn = 64;
     if (d->dtype_in == VP_BF16 && d->dtype_out == VP_F32) bn = 128;
+    if (hl_in || hl_out) bn = 128;
     // (Round 3 pinned the bf16-input 128-column tile to 64 columns: kernels running beside it returned wrong lanes.  Round 4 found the
     // cause in the VICTIMS, not here -- packed-f32 VALU instructions reading freshly loaded registers next to an MFMA-heavy wave,
     // DESIGN.md section 8 -- and the library is now built without packed-f32 instructions; VPMI_BN64=1 keeps the narrow tile for A/B.)
@@ -173,6 +189,22 @@ int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream) {
             return vp_conv_launch256_bf16(ctx, &a, mode, sched - 1, out_f32 ? 1 : 0, st);
         }
     }
+    if (hl_in) {
+        // wide 1x1 layers: the 128 x 256 LDS-DMA ring in split precision (conv_gemm256.hip); the rest on the 128 x 128 kernel
+        if (mode == MODE_1X1 && d->Cout >= ring_min_cout() && (!d->psum || d->T_out >= 128) && d->stride == 1 && d->pad_left == 0 &&
+            d->T_in == d->T_out && xbytes < 0xe0000000ull && wbytes < 0xe0000000ull && a.M >= 128 * 32 && use_conv256()) {
+            a.tiles_m = (a.M + 127) / 128;
+            a.tiles_n = (a.N + 255) / 256;
+            a.group_m = 64 / a.tiles_n;
+            if (a.group_m < 1) a.group_m = 1;
+            if (a.group_m > 32) a.group_m = 32;
+            { static int gm = -1; if (gm < 0) { const char* e = getenv("VPMI_GROUP_M"); gm = e ? atoi(e) : 0; } if (gm > 0) a.group_m = gm; }
+            return vp_conv_launch_ring_x3(ctx, &a, hl_out ? 0 : 1, st);
+        }
+        if (!hl_out) VP_FAIL(ctx, VP_EUNSUP, "conv1d: hl32 -> f32 is built on the ring kernel only (wide 1x1 layers)");
+        return vp_conv_launch_hl_hl(ctx, &a, bn, mode, st);
+    }
+    if (hl_out) return vp_conv_launch_x3_hl(ctx, &a, bn, mode, st);
     if (d->dtype_in == VP_BF16 && d->dtype_out == VP_BF16) return vp_conv_launch_bf16_bf16(ctx, &a, bn, mode, st);
     if (d->dtype_in == VP_BF16 && d->dtype_out == VP_F32) return vp_conv_launch_bf16_f32(ctx, &a, bn, mode, st);
     if (d->mfma_bf16 == 2) return vp_conv_launch_x3_f32(ctx, &a, bn, mode, st);

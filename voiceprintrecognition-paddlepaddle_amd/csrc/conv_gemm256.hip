@@ -45,7 +45,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 template <int NW, typename TO>
 __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8], char* ebase, int tid, int tm, int m0, int n0) {
     constexpr int RS = 64;
-    constexpr bool F32O = sizeof(TO) == 4;
+    constexpr bool HLO = std::is_same<TO, hl_t>::value;           // split bf16 planes out (conv_gemm_impl.h: hl_t)
+    constexpr bool F32O = sizeof(TO) == 4 && !HLO;
     constexpr int OROW = 272;
     constexpr int NP = 64 / RS;                                // row passes per 64-channel half
     constexpr int NWM = NW / 2;                                // row groups (wm) of the tile
@@ -81,7 +82,7 @@ __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8
             if (a.bn_scale) load4(a.bn_scale + nb, sc4);
             if (a.bn_shift) load4(a.bn_shift + nb, sh4);
         }
-        constexpr int AL = F32O ? 3 : 7;                       // elements per 16 bytes - 1
+        constexpr int AL = HLO ? 31 : F32O ? 3 : 7;            // elements per 16 bytes - 1 (hl32: per 128-byte group)
         const bool res_ok = !RES || (F32O && !a.psum && a.act2 == VP_ACT_NONE && ((a.ld_res | a.res_off) & 3) == 0 &&
                                      (reinterpret_cast<uintptr_t>(a.res) & 15) == 0);
         const bool fast_cols = nh + 64 <= a.N && !a.rowbias && res_ok && !AUX && a.act2 != VP_ACT_TANH && a.act2 != VP_ACT_SILU &&
@@ -120,6 +121,10 @@ __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8
                 const bool split = a.ysplit > nh;
                 TO* dst2 = split ? Y2 + (size_t)(mwp + q8) * a.ldy2 + a.y2off + nc : nullptr;
                 const size_t dstep2 = (size_t)8 * a.ldy2;
+                // hl32: the lane's 8 channels are 16 bytes of the hi plane and 16 bytes of the lo plane of their group
+                [[maybe_unused]] const int hlo = (nc >> 5) * 128 + (nc & 31) * 2;
+                [[maybe_unused]] char* dsth = reinterpret_cast<char*>(Y) + ((size_t)(mwp + q8) * a.ldy + a.yoff) * 4 + hlo;
+                [[maybe_unused]] char* dsth2 = split ? reinterpret_cast<char*>(Y2) + ((size_t)(mwp + q8) * a.ldy2 + a.y2off) * 4 + hlo : nullptr;
                 [[maybe_unused]] const TO* rsrc = RES ? RES + (size_t)(mwp + q8) * a.ld_res + a.res_off + nc : nullptr;
                 [[maybe_unused]] const size_t rstep = (size_t)8 * a.ld_res;
                 const bool sums = a.psum != nullptr;
@@ -149,7 +154,23 @@ __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8
                                 v[e + 4] = fminf(fmaxf(v[e + 4], lo2), hi2);
                             }
                         }
-                        if constexpr (F32O) {
+                        if constexpr (HLO) {
+                            unsigned short hh[8], ll[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) hl_split(v[e], hh[e], ll[e]);
+                            const u32x4 oh = u32x4{(unsigned)hh[0] | ((unsigned)hh[1] << 16), (unsigned)hh[2] | ((unsigned)hh[3] << 16),
+                                                   (unsigned)hh[4] | ((unsigned)hh[5] << 16), (unsigned)hh[6] | ((unsigned)hh[7] << 16)};
+                            const u32x4 ol = u32x4{(unsigned)ll[0] | ((unsigned)ll[1] << 16), (unsigned)ll[2] | ((unsigned)ll[3] << 16),
+                                                   (unsigned)ll[4] | ((unsigned)ll[5] << 16), (unsigned)ll[6] | ((unsigned)ll[7] << 16)};
+                            *reinterpret_cast<u32x4*>(dsth) = oh;
+                            *reinterpret_cast<u32x4*>(dsth + 64) = ol;
+                            dsth += dstep * 4;
+                            if (split) {
+                                *reinterpret_cast<u32x4*>(dsth2) = oh;
+                                *reinterpret_cast<u32x4*>(dsth2 + 64) = ol;
+                                dsth2 += dstep2 * 4;
+                            }
+                        } else if constexpr (F32O) {
                             f32x4 o0 = f32x4{v[0], v[1], v[2], v[3]}, o1 = f32x4{v[4], v[5], v[6], v[7]};
                             if (RES) {                     // (no second activation with a residual here: res_ok)
                                 o0 += *reinterpret_cast<const f32x4*>(rsrc);
@@ -210,7 +231,7 @@ __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8
                     float v[4];
                     float rbias[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f};
                     if (ok && a.rowbias) load4(a.rowbias + (size_t)b * a.N + nb, rbias);
-                    if (ok && RES) load4(RES + (size_t)m * a.ld_res + a.res_off + nb, rs);
+                    if (ok && RES) ld4(RES, (size_t)m * a.ld_res + a.res_off, nb, rs);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float x = av[r] + bias4[r] + rbias[r];
@@ -223,13 +244,13 @@ __device__ __forceinline__ void epilogue256(const ConvArgs& a, f32x4 (&acc)[4][8
                         v[r] = x;
                     }
                     if (ok) {
-                        store4(Y + (size_t)m * a.ldy + a.yoff + nb, v);
-                        if (nb < a.ysplit) store4(Y2 + (size_t)m * a.ldy2 + a.y2off + nb, v);
+                        st4(Y, (size_t)m * a.ldy + a.yoff, nb, v);
+                        if (nb < a.ysplit) st4(Y2, (size_t)m * a.ldy2 + a.y2off, nb, v);
                         if (AUX) {
                             float ad[4];
-                            load4(ADD + (size_t)m * a.ld_add + a.add_off + nb, ad);
+                            ld4(ADD, (size_t)m * a.ld_add + a.add_off, nb, ad);
                             float s4[4] = {v[0] + ad[0], v[1] + ad[1], v[2] + ad[2], v[3] + ad[3]};
-                            store4(AUX + (size_t)m * a.ld_aux + a.aux_off + nb, s4);
+                            st4(AUX, (size_t)m * a.ld_aux + a.aux_off, nb, s4);
                         }
                     }
                     if (a.psum)
@@ -1023,9 +1044,15 @@ constexpr int HW = 128 * ROWB;               // W half-tile
 constexpr int R2_XA0 = 0, R2_XB0 = HX, R2_XA1 = 2 * HX, R2_XB1 = 3 * HX, R2_WA0 = 4 * HX, R2_WA1 = 4 * HX + HW, R2_WB = 4 * HX + 2 * HW;
 constexpr int R2_BYTES = 4 * HX + 3 * HW;    // 81,920 B: two workgroups fill the CU's 160 KB
 
-template <typename TO>
+// X3 (split precision, TO = hl_t or float): both operands are hl32 tensors (conv_gemm_impl.h: hl_t) -- a 128-byte row of a K-step is
+// ONE group [32 hi | 32 lo], so the DMA ring, the swizzle and the fragment reads are those of the bf16 kernel with the two k-halves
+// re-read as (hi, lo); a K-step is 32 deep and a quadrant phase is 24 MFMAs (lo*hi, hi*lo, hi*hi per accumulator) on the same
+// fragments: 1.5 x the matrix-core work per staged byte.
+template <typename TO, bool X3>
 __global__ __launch_bounds__(256, 2) void conv_gemm128x256_ring_kernel(const ConvArgs a) {
     constexpr int MI = 4, NI = 8;
+    constexpr unsigned ESB = X3 ? 4u : 2u;     // bytes per element of an operand row
+    constexpr int NMMA = X3 ? 24 : 16;         // MFMAs of a quadrant phase
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1053,8 +1080,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm128x256_ring_kernel(const Con
     // -- two VGPRs for all twelve pieces; rows past M / N and K-steps past K are past num_records = zeros, no select.
     const int srow = lane >> 3;
     const unsigned cb = (unsigned)((lane & 7) ^ srow) << 4;
-    const unsigned ldxb = (unsigned)a.ldx * 2u, ldwb = (unsigned)a.K * 2u;
-    const unsigned xl = (unsigned)srow * ldxb + cb + (unsigned)a.xoff * 2u;
+    const unsigned ldxb = (unsigned)a.ldx * ESB, ldwb = (unsigned)a.K * ESB;
+    const unsigned xl = (unsigned)srow * ldxb + cb + (unsigned)a.xoff * ESB;
     const unsigned wl = (unsigned)srow * ldwb + cb;
     const unsigned xs0 = (unsigned)(m0 + (wv >> 1) * 64 + (wv & 1) * 16) * ldxb;      // scalar: the wave's first row of XA
     const unsigned ws0 = (unsigned)(n0 + (wv >> 1) * 128 + (wv & 1) * 32) * ldwb;     // scalar: the wave's first row of WA
@@ -1104,7 +1131,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm128x256_ring_kernel(const Con
 #pragma unroll
         for (int e = e0; e < e1; ++e) {
             const int ks = e >> 3, mi2 = (e >> 2) & 1, ni4 = e & 3;
-            mma(w[ni4 * 2 + ks], x[mi2 * 2 + ks], acc[mi0 + mi2][ni0 + ni4]);
+            if constexpr (X3) {                                 // fragment [.. + 0] = hi plane, [.. + 1] = lo plane; cross terms first
+                const int kw = ks == 0 ? 1 : 0, kx = ks == 1 ? 1 : 0;
+                mma(w[ni4 * 2 + kw], x[mi2 * 2 + kx], acc[mi0 + mi2][ni0 + ni4]);
+            } else {
+                mma(w[ni4 * 2 + ks], x[mi2 * 2 + ks], acc[mi0 + mi2][ni0 + ni4]);
+            }
         }
     };
 
@@ -1150,7 +1182,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm128x256_ring_kernel(const Con
         constexpr bool DX = decltype(dx)::value;
         constexpr int NPC = DX ? 2 : 4;
         __builtin_amdgcn_sched_barrier(0);
-        quad_mma(xc, wc, mi0, ni0, 4 + 2 * NPC, 16);            // MFMA-only half first
+        quad_mma(xc, wc, mi0, ni0, 4 + 2 * NPC, NMMA);          // MFMA-only half first
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (RX) read_x(rbuf, xr); else read_w(rbuf, wr);
         quad_mma(xc, wc, mi0, ni0, 0, 4);
@@ -1195,18 +1227,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm128x256_ring_kernel(const Con
     epilogue256<4, TO>(a, acc, smem, tid, tm, m0, n0);
 }
 
-template <typename TO>
+template <typename TO, bool X3>
 int launch128x256_ring(vp_ctx* ctx, const ConvArgs& a, hipStream_t st) {
     constexpr int smem = R2_BYTES;                             // >= the epilogue's 4 x 64 x 272 images + 8 KB of column-sum partials
     static_assert(4 * 64 * 272 + 2 * 2 * 2 * T2 * 4 <= R2_BYTES, "epilogue image must fit the ring");
     static bool attr_dev[64] = {};                    // the attribute is per DEVICE (a process may drive several GPUs)
     bool& attr_set = attr_dev[ctx->device & 63];
     if (!attr_set) {
-        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm128x256_ring_kernel<TO>),
+        VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm128x256_ring_kernel<TO, X3>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv_gemm128x256_ring_kernel<TO>, dim3(a.tiles_m * a.tiles_n), dim3(256), smem, st, a);
+    hipLaunchKernelGGL((conv_gemm128x256_ring_kernel<TO, X3>), dim3(a.tiles_m * a.tiles_n), dim3(256), smem, st, a);
     VP_LAUNCH_CHECK(ctx, "conv_gemm128x256_ring");
     return VP_OK;
 }
@@ -1243,6 +1275,12 @@ int launch256(vp_ctx* ctx, const ConvArgs& a, hipStream_t st) {
 
 }  // namespace
 
+// split precision: x and w hl32 tensors (1x1 layer, source row m for output row m), hl32 or f32 out; args as for schedule 6
+int vp_conv_launch_ring_x3(vp_ctx* ctx, const void* args, int out_f32, hipStream_t st) {
+    const ConvArgs& a = *static_cast<const ConvArgs*>(args);
+    return out_f32 ? launch128x256_ring<float, true>(ctx, a, st) : launch128x256_ring<hl_t, true>(ctx, a, st);
+}
+
 // args: ConvArgs with tiles_m / tiles_n / group_m already set for 256-wide tiles
 // out_f32: bf16 operands, f32 output (the training engine's data-gradient GEMMs) -- schedule 6 only
 int vp_conv_launch256_bf16(vp_ctx* ctx, const void* args, int mode, int sched, int out_f32, hipStream_t st) {
@@ -1256,7 +1294,7 @@ int vp_conv_launch256_bf16(vp_ctx* ctx, const void* args, int mode, int sched, i
         if (mode == MODE_TAPS) return launch256<MODE_TAPS, 1>(ctx, a, st);
     } else if (sched == 5) {
         // two workgroups per CU on 128 x 256 tiles (1x1 layers); args carry tiles_m in 128-row units
-        if (mode == MODE_1X1) return out_f32 ? launch128x256_ring<float>(ctx, a, st) : launch128x256_ring<bf16_t>(ctx, a, st);
+        if (mode == MODE_1X1) return out_f32 ? launch128x256_ring<float, false>(ctx, a, st) : launch128x256_ring<bf16_t, false>(ctx, a, st);
     } else if (sched == 3 || sched == 4) {
         // half-tile ring: one workgroup per tile (3) or resident workgroups (4)
         if (mode == MODE_1X1) return launch256_ring<MODE_1X1>(ctx, a, st);      // (4 = resident workgroups: no longer built, runs as 3)

@@ -46,11 +46,18 @@ struct amp_t { float v; };
 // engine that carries the reference's 1e-4 score tolerance at trained weights.  A stage is 32 k: a 128-byte
 // LDS row = [32 hi | 32 lo], so the hi / lo fragments are the ks = 0 / ks = 1 reads of the bf16 layout (same swizzle, conflict-free).
 struct x3_t { float v; };
+// hl_t: a tensor STORED as split bf16 planes ("hl32"): a row of C channels (C % 32 == 0) is C / 32 groups of 128 bytes, each
+// [32 x bf16 hi | 32 x bf16 lo] of its 32 channels, value = hi + lo -- 4 bytes per element like f32, so byte offsets / leading
+// dimensions are those of an f32 tensor, and a 128-byte LDS row of a K-stage is one group: the layout x3_t builds while staging is
+// what an hl_t operand already has in memory (no split arithmetic in the consumer, LDS-DMA-able: conv_gemm256.hip).  Producers split
+// once per output element in their epilogue.  As an OUTPUT type the epilogue stores hi / lo halves instead of f32 words.
+struct hl_t { float v; };
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { bf16x8 v; };
 template <> struct Frag<float> { float4 lo, hi; };
 template <> struct Frag<amp_t> { bf16x8 v; };
 template <> struct Frag<x3_t> { bf16x8 hi, lo; };
+template <> struct Frag<hl_t> { bf16x8 hi, lo; };
 constexpr int ROWB_AMP = 64;
 // 64-byte rows: the ds_read_b128 lane groups ({0-3,12-15,20-27}, ...) are conflict-free with the 16-B chunk g stored at
 // position g ^ ((-(row >> 2)) & 3)
@@ -72,6 +79,10 @@ __device__ __forceinline__ void load_frag(const char* tile, int row, int /*ks*/,
     f.hi = *reinterpret_cast<const bf16x8*>(tile + row * ROWB + ((g ^ (row & 7)) << 4));
     f.lo = *reinterpret_cast<const bf16x8*>(tile + row * ROWB + (((4 + g) ^ (row & 7)) << 4));
 }
+__device__ __forceinline__ void load_frag(const char* tile, int row, int /*ks*/, int g, Frag<hl_t>& f) {
+    f.hi = *reinterpret_cast<const bf16x8*>(tile + row * ROWB + ((g ^ (row & 7)) << 4));
+    f.lo = *reinterpret_cast<const bf16x8*>(tile + row * ROWB + (((4 + g) ^ (row & 7)) << 4));
+}
 // D[n][m] += sum_k W[n][k] * X[m][k]: weights are the A operand (row = lane & 15 -> n), activations
 // the B operand (col = lane & 15 -> m); result register r of lane l = (n = (l >> 4) * 4 + r, m = l & 15).
 __device__ __forceinline__ void mma(const Frag<bf16_t>& w, const Frag<bf16_t>& x, f32x4& c) {
@@ -82,6 +93,11 @@ __device__ __forceinline__ void mma(const Frag<amp_t>& w, const Frag<amp_t>& x, 
 }
 __device__ __forceinline__ void mma(const Frag<x3_t>& w, const Frag<x3_t>& x, f32x4& c) {
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.lo, x.hi, c, 0, 0, 0);      // the two cross terms, then the leading one
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.hi, x.lo, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.hi, x.hi, c, 0, 0, 0);
+}
+__device__ __forceinline__ void mma(const Frag<hl_t>& w, const Frag<hl_t>& x, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.lo, x.hi, c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.hi, x.lo, c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.hi, x.hi, c, 0, 0, 0);
 }
@@ -115,6 +131,41 @@ __device__ __forceinline__ void load4(const bf16_t* p, float v[4]) {
     v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
 }
 
+// value -> (hi, lo) bf16 pair of the split representation
+__device__ __forceinline__ void hl_split(float x, unsigned short& h, unsigned short& l) {
+    const bf16_t xh = (bf16_t)x;
+    const bf16_t xl = (bf16_t)(x - (float)xh);
+    h = __builtin_bit_cast(unsigned short, xh);
+    l = __builtin_bit_cast(unsigned short, xl);
+}
+// 4 consecutive channels `col` .. `col + 3` (col % 4 == 0) of an hl32 row starting at byte address `row`
+__device__ __forceinline__ void hl_store4(char* row, int col, const float v[4]) {
+    unsigned short h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) hl_split(v[e], h[e], l[e]);
+    char* p = row + (col >> 5) * 128 + (col & 31) * 2;
+    *reinterpret_cast<uint2*>(p) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+    *reinterpret_cast<uint2*>(p + 64) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+}
+__device__ __forceinline__ void hl_load4(const char* row, int col, float v[4]) {
+    const char* p = row + (col >> 5) * 128 + (col & 31) * 2;
+    const uint2 h = *reinterpret_cast<const uint2*>(p), l = *reinterpret_cast<const uint2*>(p + 64);
+    v[0] = __builtin_bit_cast(float, h.x << 16) + __builtin_bit_cast(float, l.x << 16);
+    v[1] = __builtin_bit_cast(float, h.x & 0xffff0000u) + __builtin_bit_cast(float, l.x & 0xffff0000u);
+    v[2] = __builtin_bit_cast(float, h.y << 16) + __builtin_bit_cast(float, l.y << 16);
+    v[3] = __builtin_bit_cast(float, h.y & 0xffff0000u) + __builtin_bit_cast(float, l.y & 0xffff0000u);
+}
+// epilogue accessors: tensor `base` of element type T, `off` = element offset of the row's channel 0 (row * ld + channel offset),
+// `col` = channel within the row slice.  Plain types: base[off + col ..]; hl_t: the row's groups (off % 32 == 0, host-checked).
+template <typename T> __device__ __forceinline__ void st4(T* base, size_t off, int col, const float v[4]) { store4(base + off + col, v); }
+template <> __device__ __forceinline__ void st4<hl_t>(hl_t* base, size_t off, int col, const float v[4]) {
+    hl_store4(reinterpret_cast<char*>(base) + off * 4, col, v);
+}
+template <typename T> __device__ __forceinline__ void ld4(const T* base, size_t off, int col, float v[4]) { load4(base + off + col, v); }
+template <> __device__ __forceinline__ void ld4<hl_t>(const hl_t* base, size_t off, int col, float v[4]) {
+    hl_load4(reinterpret_cast<const char*>(base) + off * 4, col, v);
+}
+
 // input prologue on one staged 16-byte chunk: x <- relu(x * s + h), per channel
 __device__ __forceinline__ u32x4 prologue_chunk(u32x4 v, const float (&s)[8], const float (&h)[8], bf16_t) {
     u32x4 o;
@@ -145,6 +196,7 @@ __device__ __forceinline__ uint2 amp_pack(u32x4 v) {
 __device__ __forceinline__ u32x4 prologue_chunk(u32x4 v, const float (&s)[8], const float (&h)[8], x3_t) {
     return prologue_chunk(v, s, h, float{});
 }
+__device__ __forceinline__ u32x4 prologue_chunk(u32x4 v, const float (&)[8], const float (&)[8], hl_t) { return v; }   // (never dispatched)
 // four f32 -> their bf16 hi terms and bf16 lo terms (x = hi + lo up to 2^-16 relative), 8 bytes each
 __device__ __forceinline__ void x3_split(u32x4 v, uint2& hi, uint2& lo) {
     unsigned short h[4], l[4];
@@ -440,7 +492,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
             float rbias[4] = {0.f, 0.f, 0.f, 0.f}, gt[4] = {1.f, 1.f, 1.f, 1.f}, rs[4] = {0.f, 0.f, 0.f, 0.f};
             if (ok && a.rowbias) load4(a.rowbias + (size_t)rowb[mi] * a.N + nb, rbias);
             if (ok && a.gate) load4(a.gate + (size_t)rowg[mi] * a.N + nb, gt);
-            if (ok && RES) load4(RES + (size_t)m * a.ld_res + a.res_off + nb, rs);
+            if (ok && RES) ld4(RES, (size_t)m * a.ld_res + a.res_off, nb, rs);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float t = acc[mi][ni][r] + bias4[r] + rbias[r];
@@ -452,14 +504,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
                 else if (a.act2 == VP_ACT_SILU) t = vp_silu_for<TO>(t);
                 v[r] = t;
             }
-            store4(reinterpret_cast<TO*>(slab + (mi * 16 + li) * SLAB_ROW) + ni * 16 + g * 4, v);
+            st4(reinterpret_cast<TO*>(slab + (mi * 16 + li) * SLAB_ROW), 0, ni * 16 + g * 4, v);
             if (ok) {
-                if (nb < a.ysplit) store4(Y2 + (size_t)m * a.ldy2 + a.y2off + nb, v);
+                if (nb < a.ysplit) st4(Y2, (size_t)m * a.ldy2 + a.y2off, nb, v);
                 if (AUX) {
                     float ad[4];
-                    load4(ADD + (size_t)m * a.ld_add + a.add_off + nb, ad);
+                    ld4(ADD, (size_t)m * a.ld_add + a.add_off, nb, ad);
                     float s4[4] = {v[0] + ad[0], v[1] + ad[1], v[2] + ad[2], v[3] + ad[3]};
-                    store4(AUX + (size_t)m * a.ld_aux + a.aux_off + nb, s4);
+                    st4(AUX, (size_t)m * a.ld_aux + a.aux_off, nb, s4);
                 }
             }
             // keep (y - shift) for the column sums; zero for rows / columns outside the problem

@@ -53,6 +53,20 @@ int vp_run_asp(vp_ctx* ctx, const vp_asp_weights& A, int dtc, const void* x, int
                              w.rowbias, A.att, st);
         if (rc) return rc;
     }
+    if (dtc == VP_HL32) {
+        // split-precision fast path: x is stored as split bf16 planes.  Attention TDNN (hl32 in / out, tanh) on the 128-wide kernel, then
+        // logits + softmax + weighted statistics in one kernel (asp_x3.hip): no (B*T, C) logits tensor
+        if (!A.tdnn.w_hl) VP_FAIL(ctx, VP_EINVAL, "asp: hl32 input needs the attention TDNN's split weights (w_hl)");
+        vp_conv1d_desc d;
+        tdnn_desc(d, A.tdnn, VP_F32X3, B, T, T, VP_PAD_REFLECT);
+        d.dtype_in = d.dtype_out = VP_HL32; d.w = A.tdnn.w_hl;
+        d.x = x; d.ldx = ldx; d.xoff = 0; d.rowbias = A.w_ctx ? w.rowbias : nullptr; d.act2 = VP_ACT_TANH;
+        d.y = w.h; d.ldy = A.att; d.yoff = 0;
+        if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+        rc = vp_asp_fused_x3(ctx, w.h, (const float*)A.conv_w, A.conv_b, x, ldx, w.stats, 2 * C, B, T, C, A.att, 1e-12f, w.pooled, st);
+        if (rc == VP_EUNSUP) VP_FAIL(ctx, VP_EUNSUP, "asp: shape not covered by the split-precision kernel (attention width 128, C %% 32 == 0)");
+        return rc;
+    }
     if (dtype == VP_BF16) {                       // one kernel per utterance: attention TDNN + logits + softmax + weighted statistics
         rc = vp_asp_utt_bf16(ctx, x, ldx, &A.tdnn, A.w_ctx ? w.rowbias : nullptr, A.conv_w, A.conv_b, B, T, C, A.att, 1e-12f, w.pooled, st);
         if (rc != VP_EUNSUP) return rc;
@@ -132,6 +146,66 @@ int check_ecapa(vp_ctx* ctx, const vp_ecapa_weights* w) {
     return VP_OK;
 }
 
+// ---- split-precision fast path (dtype VP_F32X3): every big activation stored as split bf16 planes (vpmi.h: VP_HL32) -------------
+// The wide 1x1 layers stream both operands by LDS-DMA on the 128 x 256 ring (conv_gemm256.hip, three MFMAs per fragment pair), the
+// Res2 chain and the pooling run fused (res2_x3.hip, asp_x3.hip); producers split once per output element.  Same graph, same buffers
+// (an hl32 tensor has f32's footprint) and the same arithmetic contract as the generic VP_F32X3 path (f32 tensors, operands split
+// while staging) -- taken when every layer it touches has its split weights and the shapes fit; VPMI_X3_GENERIC=1 pins the generic path.
+bool ecapa_hl_ok(const vp_ecapa_weights* w, int B, int T) {
+    static const bool off = getenv("VPMI_X3_GENERIC") != nullptr;
+    const int C = w->block0.cout, Cm = w->mfa.cout, sc = w->res2_scale;
+    if (off || C % 32 || Cm % 32 || C % sc || w->asp.att != 128 || !w->mfa.w_hl || !w->asp.tdnn.w_hl || !w->asp.w_ctx || T < 128 ||
+        (long long)B * T < 128 * 32 || w->block0.cout < 256 || Cm < 256)
+        return false;
+    for (int i = 0; i < w->n_blocks; ++i) {
+        const vp_se_res2_block& b = w->blk[i];
+        if (!b.tdnn1.w_hl || !b.tdnn2.w_hl || !vp_res2_chain_x3_ok(b.res2, sc - 1, T, C, C / sc)) return false;
+    }
+    return true;
+}
+
+int ecapa_fwd_hl(vp_ctx* ctx, const vp_ecapa_weights* w, const void* feats, int B, int T, float* emb, const EcapaPlan& p, hipStream_t st) {
+    const int C = w->block0.cout, Cm = w->mfa.cout, nb = w->n_blocks, sc = w->res2_scale;
+    const int width = C / sc, ldcat = nb * C;
+    int rc;
+    vp_conv1d_desc d;
+    auto hl_layer = [&](const vp_tdnn_layer& L) {
+        tdnn_desc(d, L, VP_F32X3, B, T, T, VP_PAD_REFLECT);
+        d.dtype_in = d.dtype_out = VP_HL32; d.w = L.w_hl;
+    };
+    // blocks[0]: f32 features in (split while staging), hl32 out
+    tdnn_desc(d, w->block0, VP_F32X3, B, T, T, VP_PAD_REFLECT);
+    d.dtype_out = VP_HL32;
+    d.x = feats; d.ldx = w->feat_dim; d.y = p.cat0; d.ldy = C;
+    if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+    const void* xin = p.cat0;
+    int ld_in = C, off_in = 0;
+    for (int i = 0; i < nb; ++i) {
+        const vp_se_res2_block& blk = w->blk[i];
+        hl_layer(blk.tdnn1);
+        d.x = xin; d.ldx = ld_in; d.xoff = off_in; d.y = p.t1; d.ldy = C;
+        d.y2 = p.r2; d.ldy2 = C; d.y2off = 0; d.ysplit = width;
+        if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+        rc = vp_res2_chain_x3(ctx, blk.res2, sc - 1, p.t1, p.r2, B, T, C, width, st);
+        if (rc == VP_EUNSUP) VP_FAIL(ctx, VP_EUNSUP, "ecapa: Res2 chain left the split-precision kernel's range after the shape check");
+        if (rc) return rc;
+        hl_layer(blk.tdnn2);
+        d.x = p.r2; d.ldx = C; d.xoff = 0; d.y = p.t2; d.ldy = C; d.psum = p.psum;
+        if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+        if ((rc = vp_se_gate(ctx, p.psum, blk.tdnn2.bn_shift, B, T, C, w->se_ch, blk.se_w1, blk.se_b1, blk.se_w2, blk.se_b2, p.se_s, st)))
+            return rc;
+        if ((rc = vp_se_scale_residual_ex(ctx, VP_HL32, p.t2, C, 0, p.se_s, xin, ld_in, off_in, p.cat, ldcat, i * C, B, T, C, 0, st))) return rc;
+        xin = p.cat; ld_in = ldcat; off_in = i * C;
+    }
+    hl_layer(w->mfa);
+    d.x = p.cat; d.ldx = ldcat; d.y = p.mfa; d.ldy = Cm; d.psum = p.psum; d.psumsq = p.psumsq;
+    if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
+    VpAspBufs ab{p.h, p.e, p.psum, p.psumsq, p.stats, p.rowbias, p.pooled};
+    if ((rc = vp_run_asp(ctx, w->asp, VP_HL32, p.mfa, Cm, w->mfa.bn_shift, B, T, ab, st))) return rc;
+    return vp_dense_f32_ex(ctx, p.pooled, 2 * Cm, w->fc_w, 0, w->fc_b, nullptr, nullptr, B, w->embd_dim, 2 * Cm,
+                           VP_ACT_NONE, emb, w->embd_dim, st);
+}
+
 }  // namespace
 
 extern "C" {
@@ -162,6 +236,22 @@ int vp_asp_fused_fwd(vp_ctx* ctx, const void* h, const void* w, const float* bia
     return rc;
 }
 
+int vp_res2_chain_x3_fwd(vp_ctx* ctx, const vp_tdnn_layer* layers, int nconv, const void* t1, void* r2, int B, int T, int C,
+                         int width, vp_stream stream) {
+    if (!ctx || !layers || !t1 || !r2 || B <= 0 || T <= 0 || C <= 0) VP_FAIL(ctx, VP_EINVAL, "res2_chain_x3: bad arguments");
+    const int rc = vp_res2_chain_x3(ctx, layers, nconv, t1, r2, B, T, C, width, (hipStream_t)stream);
+    if (rc == VP_EUNSUP) VP_FAIL(ctx, VP_EUNSUP, "res2_chain_x3: shape not covered (width 64, equal dilations, split weights present, segments fit the LDS)");
+    return rc;
+}
+
+int vp_asp_fused_x3_fwd(vp_ctx* ctx, const void* h, const float* w, const float* bias, const void* x, int ldx, const float* center,
+                        int ldc, int B, int T, int C, int att, float eps, float* pooled, vp_stream stream) {
+    if (!ctx || !h || !w || !bias || !x || !pooled || B <= 0) VP_FAIL(ctx, VP_EINVAL, "asp_fused_x3: bad arguments");
+    const int rc = vp_asp_fused_x3(ctx, h, w, bias, x, ldx, center, ldc, B, T, C, att, eps, pooled, (hipStream_t)stream);
+    if (rc == VP_EUNSUP) VP_FAIL(ctx, VP_EUNSUP, "asp_fused_x3: shape not covered (attention width 128, C and ldx multiples of 32, 16-byte aligned)");
+    return rc;
+}
+
 int vp_se_gate_fwd(vp_ctx* ctx, const float* psum, const float* shift, int B, int T, int C, int H, const float* w1, const float* b1,
                    const float* w2, const float* b2, float* out, vp_stream stream) {
     return vp_se_gate(ctx, psum, shift, B, T, C, H, w1, b1, w2, b2, out, (hipStream_t)stream);
@@ -187,6 +277,7 @@ int vp_ecapa_fwd(vp_ctx* ctx, const vp_ecapa_weights* w, const void* feats, int 
     const int C = w->block0.cout, Cm = w->mfa.cout, nb = w->n_blocks, sc = w->res2_scale;
     const int width = C / sc, ldcat = nb * C;
     vp_conv1d_desc d;
+    if (dtc == VP_F32X3 && ecapa_hl_ok(w, B, T)) return ecapa_fwd_hl(ctx, w, feats, B, T, emb, p, st);
 
     // blocks[0]: TDNNBlock(F -> C, k5) on the (B, T, F) features
     tdnn_desc(d, w->block0, dtc, B, T, T, VP_PAD_REFLECT);

@@ -237,6 +237,45 @@ __global__ __launch_bounds__(256) void se_scale_residual_kernel(SeArgs<T> a) {
     }
 }
 
+// the same on tensors stored as split bf16 planes (vpmi.h: VP_HL32): a thread takes 8 channels = 16 B of the hi plane + 16 B of the lo
+// plane of their 32-channel group, works on hi + lo in f32 and splits the result again
+struct SeHlArgs { const char* x; const float* s; const char* res; char* out; int ldx, xoff, ldr, roff, ldo, ooff, T_, C, relu; long long total; };
+__global__ __launch_bounds__(256) void se_scale_residual_hl_kernel(SeHlArgs a) {
+    const int cv = a.C / 8;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < a.total; idx += (long long)gridDim.x * 256) {
+        const long long m = idx / cv;
+        const int c = (int)(idx - m * cv) * 8;
+        const int b = (int)(m / a.T_);
+        const int go = (c >> 5) * 128 + (c & 31) * 2;                       // (offsets are multiples of 32 channels: host-checked)
+        const char* xp = a.x + (m * a.ldx + a.xoff) * 4 + go;
+        const char* rp = a.res + (m * a.ldr + a.roff) * 4 + go;
+        const uint4 xh = *reinterpret_cast<const uint4*>(xp), xl = *reinterpret_cast<const uint4*>(xp + 64);
+        const uint4 rh = *reinterpret_cast<const uint4*>(rp), rl = *reinterpret_cast<const uint4*>(rp + 64);
+        const unsigned xhw[4] = {xh.x, xh.y, xh.z, xh.w}, xlw[4] = {xl.x, xl.y, xl.z, xl.w};
+        const unsigned rhw[4] = {rh.x, rh.y, rh.z, rh.w}, rlw[4] = {rl.x, rl.y, rl.z, rl.w};
+        float sp[8];
+        *reinterpret_cast<float4*>(sp) = *reinterpret_cast<const float4*>(a.s + (size_t)b * a.C + c);
+        *reinterpret_cast<float4*>(sp + 4) = *reinterpret_cast<const float4*>(a.s + (size_t)b * a.C + c + 4);
+        unsigned oh[4], ol[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x0 = __builtin_bit_cast(float, xhw[e] << 16) + __builtin_bit_cast(float, xlw[e] << 16);
+            const float x1 = __builtin_bit_cast(float, xhw[e] & 0xffff0000u) + __builtin_bit_cast(float, xlw[e] & 0xffff0000u);
+            const float r0 = __builtin_bit_cast(float, rhw[e] << 16) + __builtin_bit_cast(float, rlw[e] << 16);
+            const float r1 = __builtin_bit_cast(float, rhw[e] & 0xffff0000u) + __builtin_bit_cast(float, rlw[e] & 0xffff0000u);
+            float v0 = __fmaf_rn(x0, sp[2 * e], r0), v1 = __fmaf_rn(x1, sp[2 * e + 1], r1);
+            if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+            const bf16_t h0 = (bf16_t)v0, h1 = (bf16_t)v1;
+            const bf16_t l0 = (bf16_t)(v0 - (float)h0), l1 = (bf16_t)(v1 - (float)h1);
+            oh[e] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+            ol[e] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+        }
+        char* op = a.out + (m * a.ldo + a.ooff) * 4 + go;
+        *reinterpret_cast<uint4*>(op) = make_uint4(oh[0], oh[1], oh[2], oh[3]);
+        *reinterpret_cast<uint4*>(op + 64) = make_uint4(ol[0], ol[1], ol[2], ol[3]);
+    }
+}
+
 // ---------------------------------------------------------------- ASP softmax over time + weighted stats
 // pooling.py:114-123: attn = softmax_t(logits); mean = sum attn x; std = sqrt(clip(sum attn (x-mean)^2, eps)).
 // One workgroup = 64 channels of one utterance; the 4 waves split the frames, online softmax per
@@ -296,9 +335,18 @@ static int se_scale_residual_impl(vp_ctx* ctx, int dtype, const void* x, int ldx
     if (!ctx || !x || !s || !res || !out || B <= 0 || T <= 0 || C <= 0) VP_FAIL(ctx, VP_EINVAL, "se: bad arguments");
     if (shadow && (dtype != VP_F32 || (ld_shadow | shadow_off) & 3 || reinterpret_cast<uintptr_t>(shadow) & 7))
         VP_FAIL(ctx, VP_EINVAL, "se: the bf16 shadow goes with f32 tensors, ld / offset multiples of 4");
-    const int V = dtype == VP_BF16 ? 8 : 4;
+    const int V = dtype == VP_HL32 ? 32 : dtype == VP_BF16 ? 8 : 4;
     if (C % V || ldx % V || xoff % V || ldr % V || roff % V || ldo % V || ooff % V)
         VP_FAIL(ctx, VP_EINVAL, "se: C/ld/off must be multiples of %d", V);
+    if (dtype == VP_HL32) {
+        const long long tot = (long long)B * T * (C / 8);
+        long long nb = (tot + 255) / 256;
+        if (nb > 256 * 16) nb = 256 * 16;
+        SeHlArgs a{(const char*)x, s, (const char*)res, (char*)out, ldx, xoff, ldr, roff, ldo, ooff, T, C, relu, tot};
+        hipLaunchKernelGGL(se_scale_residual_hl_kernel, dim3((unsigned)nb), dim3(256), 0, st, a);
+        VP_LAUNCH_CHECK(ctx, "se_scale_residual_hl");
+        return VP_OK;
+    }
     const long long total = (long long)B * T * (C / V);
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(HERE)
 LIB_PATH = os.environ.get('VPMI_LIB') or os.path.join(PKG_ROOT, 'lib', 'libvpmi.so')   # VPMI_LIB: A/B a build
 
-VP_F32, VP_BF16, VP_F32X3 = 0, 1, 2
+VP_F32, VP_BF16, VP_F32X3, VP_HL32 = 0, 1, 2, 3
 VP_OK, VP_EINVAL, VP_ENOMEM, VP_EHIP, VP_EUNSUP, VP_EWORKSPACE = 0, -1, -2, -3, -4, -5
 VP_PAD_NONE, VP_PAD_REFLECT, VP_PAD_ZERO = 0, 1, 2
 VP_ACT_NONE, VP_ACT_RELU, VP_ACT_SIGMOID, VP_ACT_TANH, VP_ACT_HARDTANH20, VP_ACT_SILU = 0, 1, 2, 3, 4, 5
@@ -65,7 +65,7 @@ class Res2TrainDesc(C.Structure):
 
 class TdnnLayer(C.Structure):
     _fields_ = [('w', c_void_p), ('bias', c_void_p), ('bn_scale', c_void_p), ('bn_shift', c_void_p),
-                ('cin', c_int), ('cout', c_int), ('kw', c_int), ('dil', c_int)]
+                ('cin', c_int), ('cout', c_int), ('kw', c_int), ('dil', c_int), ('w_hl', c_void_p)]
 
 
 class SeRes2Block(C.Structure):
@@ -351,6 +351,9 @@ _PROTOS = {
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'vp_pointwise_fwd': (c_int, [c_void_p, C.POINTER(Conv1dDesc), c_void_p]),
     'vp_res2_chain_fwd': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'vp_res2_chain_x3_fwd': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'vp_asp_fused_x3_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                    c_float, c_void_p, c_void_p]),
     'vp_asp_utt_fwd': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     'vp_asp_fused_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                  c_float, c_void_p, c_void_p]),

@@ -13,7 +13,7 @@ import torch
 
 import ppvector
 from ppvector import _native as N
-from ppvector.models.utils import f32, pack_conv_weight
+from ppvector.models.utils import f32, pack_conv_weight, pack_hl32
 
 _TORCH_DT = {'float32': torch.float32, 'float32x3': torch.float32, 'bfloat16': torch.bfloat16}
 
@@ -53,6 +53,8 @@ class _Engine:
             sc, sh = bn.folded()
             L.bn_scale, L.bn_shift = self._p(sc), self._p(sh)
         L.cin, L.cout, L.kw, L.dil = (w.shape[1] // kw), cout, kw, dil
+        if self.dtype_name == 'float32x3' and w.shape[1] % 32 == 0:      # split bf16 planes of the same weights: the hl32 fast path
+            L.w_hl = self._p(pack_hl32(w))
 
     def asp(self, A, asp):
         Cc = asp.channels

@@ -100,3 +100,23 @@ def pack_conv_weight(weight, dtype):
 
 def f32(t):
     return None if t is None else t.detach().float().contiguous()
+
+
+def pack_hl32(t):
+    """(..., C) float tensor, C % 32 == 0  ->  the same shape as torch.float32 whose BYTES are the split bf16 planes of include/vpmi.h's
+    VP_HL32: per 32-channel group [32 x bf16 hi | 32 x bf16 lo], hi = bf16(v) (round to nearest even), lo = bf16(v - hi)."""
+    t = t.detach().float().contiguous()
+    C = t.shape[-1]
+    if C % 32:
+        raise ValueError(f'hl32 needs a multiple of 32 channels, got {C}')
+    hi = t.to(torch.bfloat16)
+    lo = (t - hi.float()).to(torch.bfloat16)
+    g = torch.cat([hi.reshape(*t.shape[:-1], C // 32, 32), lo.reshape(*t.shape[:-1], C // 32, 32)], dim=-1)      # (..., C/32, 64) bf16
+    return g.contiguous().view(torch.float32).reshape(t.shape)
+
+
+def unpack_hl32(t):
+    """Inverse view of pack_hl32: the values hi + lo as float32."""
+    C = t.shape[-1]
+    g = t.contiguous().view(torch.bfloat16).reshape(*t.shape[:-1], C // 32, 64).float()
+    return (g[..., :32] + g[..., 32:]).reshape(t.shape)
