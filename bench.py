@@ -28,8 +28,11 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
                    (2 warm + 10 timed, taken first: the protocol of rounds 1-3) -- both reported, neither replaces the rocprof average
                    of the same kernel (profiles/r05_kernel_stats_infer.csv: 0.333);
   "ms_per_step_without_prereplays" : the same two-sequence graph freshly captured WITHOUT the set-up replays, timed behind an idle gap;
-  "parity_engine_f32" : the same step on the exact-f32 matrix cores -- the engine that meets the 1e-4 score bar at trained weights too --
-                   with its fraction of the 157 TFLOP/s f32 MFMA peak;
+  "parity_engine_x3" : the same step on the SPLIT-PRECISION engine ('float32x3': tensors as split bf16 planes, hi*hi + hi*lo + lo*hi on the
+                   bf16 matrix cores) -- the engine that meets the 1e-4 score bar at trained weights at matrix-core speed -- with its
+                   fraction of the 833 TFLOP/s (= bf16 peak / 3) it is bound by; "parity_engine_f32": the exact-f32 matrix cores (157 TFLOP/s);
+  "score_err_trained_weights" : the timed engine's all-pairs cosine-score error against the f32 oracle at trained weights (bf16: 2e-3,
+                   outside north_star's 1e-4 -- the headline is BASELINE configs[1]'s stated dtype, the parity engines are beside it);
   "single_stream_ms" : the same step as one launch sequence; "clocks": rocm-smi before / after the timed region;
   "cpu_baseline" : the CPU oracle (reference algorithm restated on NumPy + PyTorch-CPU fp32 -- NOT the PaddlePaddle
                    binary) timed on this host's cores on a bounded sample;
@@ -58,6 +61,10 @@ import torch  # noqa: E402
 BATCH, N_SAMPLES, N_MELS, N_CLASSES, EMBD = 256, 48000, 80, 2796, 192
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3            # f32 MFMA (the training engine's matrix cores today)
+PEAK_X3_TFLOPS = PEAK_BF16_TFLOPS / 3      # split precision: three bf16 MFMAs per product (hi*hi + hi*lo + lo*hi)
+# all-pairs cosine-score error of each engine against the f32 CPU oracle at TRAINED weights (profiles/r06_trained_weights_parity.log,
+# asserted in tests/test_gpu_models.py::test_score_parity_at_trained_weights); north_star's tolerance is 1e-4
+SCORE_ERR_TRAINED = {'bfloat16': 1.96e-3, 'float32x3': 3.2e-6, 'float32': 2.6e-7}
 ALG_GFLOP_PER_UTT = 2.857          # ECAPA forward, algorithmic
 
 
@@ -463,28 +470,39 @@ def run_infer(args, rank, local_rank, world, dist):
         if info0['graph']:
             dt0, _ = run_timed(run0, args.steps, args.warmup, None, dev)
             cold_ms = round(dt0 / args.steps * 1e3, 4)
-    # the PARITY engine beside the headline: the same step on the exact-f32 matrix cores (v_mfma_f32_16x16x4_f32) -- the engine that meets
-    # north_star's 1e-4 score bar at trained weights on every backbone (the bf16 engine's 8-bit mantissa does not: README, DESIGN.md 0d,
-    # profiles/r05_trained_weights_parity.log); same batch, same graph / stream structure, a shorter run
-    f32_eng = None
-    if want16 and world == 1 and not args.no_roofline:
+    # the PARITY engines beside the headline, same batch, same graph / stream structure, shorter runs:
+    #   float32x3  split precision -- tensors as split bf16 planes, hi*hi + hi*lo + lo*hi on the bf16 matrix cores (csrc/ecapa.hip fast
+    #              path): meets north_star's 1e-4 score bar at trained weights on every backbone at ~3x the f32 engine's rate
+    #   float32    exact f32 matrix cores (v_mfma_f32_16x16x4_f32): the reference's own arithmetic
+    # (the bf16 engine's 8-bit mantissa does NOT meet the bar at trained weights: README, profiles/r06_trained_weights_parity.log)
+    def side_engine(dt, peak, note, ksteps):
         try:
-            run32, info32 = make_infer_step(dev, 'float32', args.streams, wav, labels, graph=bool(args.graph))
-            ksteps = max(4, args.steps // 2)
-            dt32, loss32 = run_timed(run32, ksteps, 2, None, dev)
-            v32 = BATCH * ksteps / dt32
-            f32_eng = {'dtype': 'f32', 'value': round(v32, 1), 'unit': 'utterances/s', 'ms_per_step': round(dt32 / ksteps * 1e3, 4), 'steps': ksteps,
-                       'stage_roofline_frac': round(v32 * ALG_GFLOP_PER_UTT / 1e3 / PEAK_F32_TFLOPS, 4), 'peak_TFLOPs': PEAK_F32_TFLOPS,
-                       'loss': round(float(loss32), 5),
-                       'note': 'exact f32 MFMA; all-pairs cosine scores within 1e-4 of the CPU oracle at random-init AND trained weights'}
-            del run32, info32
+            runx, infox = make_infer_step(dev, dt, args.streams, wav, labels, graph=bool(args.graph))
+            dtx, lossx = run_timed(runx, ksteps, 3, None, dev)
+            vx = BATCH * ksteps / dtx
+            return {'dtype': dt, 'value': round(vx, 1), 'unit': 'utterances/s', 'ms_per_step': round(dtx / ksteps * 1e3, 4), 'steps': ksteps,
+                    'stage_roofline_frac': round(vx * ALG_GFLOP_PER_UTT / 1e3 / peak, 4), 'peak_TFLOPs': round(peak, 1),
+                    'loss': round(float(lossx), 5), 'score_err_trained_weights': SCORE_ERR_TRAINED[dt], 'note': note}
         except Exception as e:                 # noqa: BLE001 -- a side measurement must not cost the headline
-            f32_eng = {'error': f'{type(e).__name__}: {e}'[:200]}
+            return {'error': f'{type(e).__name__}: {e}'[:200]}
+
+    f32_eng = x3_eng = None
+    if want16 and world == 1 and not args.no_roofline:
+        x3_eng = side_engine('float32x3', PEAK_X3_TFLOPS, 'split precision (bf16 hi + lo operands, three MFMAs per product, f32 accumulate); '
+                             'all-pairs cosine scores within 1e-4 of the CPU oracle at random-init AND trained weights on all five backbones',
+                             max(8, args.steps // 2))
+        f32_eng = side_engine('float32', PEAK_F32_TFLOPS, 'exact f32 MFMA; all-pairs cosine scores within 1e-4 of the CPU oracle at random-init '
+                              'AND trained weights', max(4, args.steps // 4))
     out = {
         'metric': 'utterances/sec (3 s, 16 kHz) ECAPA-TDNN fwd+AAM', 'value': round(value, 1),
         'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'bf16' if want16 else 'f32', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': 'bf16' if want16 else ('f32 tensors as split bf16 planes, three bf16 MFMAs per product (split precision)'
+                                                               if args.dtype == 'float32x3' else 'f32'), 'data': 'synthetic',
+        # the engine's all-pairs cosine-score error against the f32 oracle at TRAINED weights (north_star's tolerance: 1e-4).  The bf16
+        # headline is BASELINE configs[1]'s stated dtype and is OUTSIDE that tolerance; "parity_engine_x3" is the engine that meets it
+        'score_err_trained_weights': SCORE_ERR_TRAINED[args.dtype],
+        'meets_1e-4_score_tolerance': SCORE_ERR_TRAINED[args.dtype] < 1e-4,
         'config': {'workload': 'BASELINE configs[1]: ECAPA-TDNN (C=512, MFA 1536, ASP, embd 192) + Kaldi Fbank 80, '
                                '3 s @ 16 kHz (T=298), 2796-class cosine head + AAMLoss, eval-mode forward, '
                                f'batch {BATCH} per GPU, inputs resident in HBM, random-init weights',
@@ -492,9 +510,11 @@ def run_infer(args, rank, local_rank, world, dist):
                    'streams_per_gpu': args.streams, 'hip_graph': bool(args.graph),
                    'graph_prereplays': info.get('graph_prereplays', 0)},
         'loss': round(loss_v, 5),
-        'stage_roofline_frac': round(value / world * ALG_GFLOP_PER_UTT / 1e3 / PEAK_BF16_TFLOPS, 4),
+        'stage_roofline_frac': round(value / world * ALG_GFLOP_PER_UTT / 1e3 /
+                                     {'bfloat16': PEAK_BF16_TFLOPS, 'float32x3': PEAK_X3_TFLOPS, 'float32': PEAK_F32_TFLOPS}[args.dtype], 4),
         'single_stream_ms': single_ms,
         'ms_per_step_without_prereplays': cold_ms,
+        'parity_engine_x3': x3_eng,
         'parity_engine_f32': f32_eng,
         'clocks': {'before_step_build': clocks[0], 'after_timed_region': clocks[1]} if rank == 0 else None,
     }
