@@ -494,6 +494,68 @@ def test_eres2net_training_step_vs_oracle_autograd(N, two_emb):
     m.eval()
 
 
+def test_eres2net_large_training_step_vs_oracle_autograd(N):
+    """BASELINE configs[4]'s backbone as a TRAINING step: ERes2Net-large (55.2 M parameters at F = 80: m_channels 64, mul_channel 2,
+    expansion 4, base_width 24, scale 3, all 16 blocks) on a reduced map (T = 24, F = 16) -- forward, AAM head over 1000 classes and every
+    parameter gradient against float64 autograd over the oracle graph.  The widths of this variant (chunks of 24 / 48 / 96 / 192 channels,
+    three per block) take code paths the 6.6 M base model never reaches.
+    At random init this 16-block graph is ILL-CONDITIONED in f32: torch's own float32 autograd over the same oracle graph lands 2 - 5 % from
+    its float64 run on most parameter gradients (Hardtanh / ReLU kinks and batch statistics over maps that shrink to 3 x 2 positions;
+    profiles/r06_eres2net_large_gradient_conditioning.log).  So each gradient is held to the larger of 5e-3 and 3 x what float32 autograd
+    itself achieves (per tensor, or its median over the tensors) -- a wrong
+    kernel (a missing tap, a transposed chunk) is off by O(1), not by a factor on the rounding noise."""
+    from oracle import eres2net as oer
+    from ppvector.models.eres2net import ERes2Net
+    from ppvector.train.functions import HeadLoss
+    LARGE = dict(m_channels=64, mul_channel=2, expansion=4, base_width=24, scale=3)
+    FW = dict(m_channels=64, expansion=4, base_width=24, scale=3)
+    B, T, Fdim, Cc = 4, 24, 16, 1000
+    p = oer.eres2net_params(Fdim, 192, seed=23, **LARGE)
+    g = torch.Generator().manual_seed(24)
+    x = torch.randn(B, T, Fdim, generator=g) * 2
+    labels = torch.randint(0, Cc, (B,), generator=g)
+    Wh = om.head_params(192, Cc, seed=5)
+    ref = {}
+    for dt in (torch.float64, torch.float32):
+        pr = {k: v.clone().to(dt).requires_grad_(not k.endswith(('_mean', '_variance'))) for k, v in p.items()}
+        Wr = Wh.clone().to(dt).requires_grad_()
+        e = oer.eres2net_forward(pr, x.to(dt), training=True, **FW)
+        lo = om.aam_loss(om.cosine_head(e, Wr), labels, 0.2, 32.0, False, 0.0)
+        lo.backward()
+        ref[dt] = (e.detach(), lo.detach(), Wr.grad, {k: v.grad for k, v in pr.items() if v.grad is not None})
+    emb_ref, loss_ref, gW, gp = ref[torch.float64]
+    emb32, _, gW32, gp32 = ref[torch.float32]
+    m = ERes2Net(Fdim, embd_dim=192, **LARGE)
+    m.load_state_dict(p)
+    m = m.cuda().train()
+    Wd = Wh.cuda().requires_grad_()
+    emb = m(x.cuda())
+    assert rel(emb, emb_ref) < max(1e-4, 3 * rel(emb32, emb_ref))
+    loss = HeadLoss.apply(emb, Wd, labels.cuda(), 0.2, 32.0, 0.0, False)[0]
+    assert abs(loss.item() - loss_ref.item()) < 5e-4 * abs(loss_ref.item())
+    loss.backward()
+    assert rel(Wd.grad, gW) < max(1e-3, 3 * rel(gW32, gW))
+    live = [k for k, _ in m.named_parameters() if k in gp and gp[k].norm().item() >= 1e-9]
+    r32s = sorted(rel(gp32[k], gp[k]) for k in live)
+    noise = r32s[len(r32s) // 2]                       # what float32 autograd of the oracle graph typically achieves here
+    worst, wk, n, ratio = 0.0, '', 0, []
+    for k, v in m.named_parameters():
+        if k not in live:
+            assert v.grad is None or v.grad.abs().max().item() < 1e-4, k
+            continue
+        r, r32 = rel(v.grad, gp[k]), rel(gp32[k], gp[k])
+        n += 1
+        ratio.append(r / max(r32, 1e-12))
+        if r > worst:
+            worst, wk = r, k
+        assert r < max(5e-3, 3 * max(r32, noise)), (k, r, r32, noise)
+    ratio.sort()
+    print(f'[eres2net-large train] loss {loss.item():.5f} (oracle {loss_ref.item():.5f}); {n} parameter tensors, worst gradient rel-L2 vs float64 {worst:.2e} ({wk}); '
+          f'engine error / float32-autograd error: median {ratio[len(ratio) // 2]:.2f}, max {ratio[-1]:.2f}')
+    assert ratio[len(ratio) // 2] < 2.5
+    m.eval()
+
+
 def test_eres2netv2_training_step_vs_oracle_autograd(N):
     """ERes2NetV2 (base_width 26: chunk widths 13 / 26 / 52 / 104 -- the first two run on zero-padded chunks; one bottom-up
     fusion) against autograd over the oracle graph; running statistics land in the reference-shaped buffers."""

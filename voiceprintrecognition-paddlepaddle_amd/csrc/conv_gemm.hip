@@ -121,8 +121,41 @@ int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream) {
     const size_t es = d->dtype_in == VP_BF16 ? 2 : 4;
     const unsigned long long xbytes = ((unsigned long long)d->B * d->T_in * F_in - 1) * d->ldx * es + (d->xoff + d->Cin) * es;
     const unsigned long long wbytes = (unsigned long long)d->Cout * d->KW * d->Cin * es;
-    if (xbytes >= 0xffffff00ull || wbytes >= 0xffffff00ull)
-        VP_FAIL(ctx, VP_EUNSUP, "conv1d: operand larger than 4 GiB (32-bit buffer offsets)");
+    if (wbytes >= 0xffffff00ull) VP_FAIL(ctx, VP_EUNSUP, "conv1d: weights larger than 4 GiB (32-bit buffer offsets)");
+    if (xbytes >= 0xffffff00ull) {
+        // The kernels address x through a 32-bit buffer offset.  Utterances are independent rows of the GEMM, so a larger activation
+        // tensor (ERes2Net-large at 128 utterances per GPU: BASELINE configs[4]) runs as consecutive launches over batch slices; a
+        // slice of the fused time sums must start on an M-tile boundary of the partial-sum arrays.
+        const unsigned long long per_utt = (unsigned long long)d->T_in * F_in * d->ldx * es;
+        long long bc = (long long)(0xe0000000ull / (per_utt ? per_utt : 1));
+        if (d->psum) {
+            int ga = d->T_out, gb = BM;                         // slices of bc utterances with bc * T_out a multiple of the M-tile
+            while (gb) { const int t_ = ga % gb; ga = gb; gb = t_; }
+            const long long q = BM / ga;
+            bc = bc / q * q;
+        }
+        if (bc < 1 || d->B < 2) VP_FAIL(ctx, VP_EUNSUP, "conv1d: one utterance's activations exceed 4 GiB (32-bit buffer offsets)");
+        const size_t eo = d->dtype_out == VP_BF16 ? 2 : 4;
+        for (long long b0 = 0; b0 < d->B; b0 += bc) {
+            vp_conv1d_desc s = *d;
+            s.B = (int)(d->B - b0 < bc ? d->B - b0 : bc);
+            const size_t rin = (size_t)b0 * d->T_in * F_in, rout = (size_t)b0 * d->T_out * F_out;
+            s.x = static_cast<const char*>(d->x) + rin * d->ldx * es;
+            s.y = static_cast<char*>(d->y) + rout * d->ldy * eo;
+            if (d->y2) s.y2 = static_cast<char*>(d->y2) + rout * d->ldy2 * eo;
+            if (d->add_in) s.add_in = static_cast<const char*>(d->add_in) + rout * d->ld_add * eo;
+            if (d->aux) s.aux = static_cast<char*>(d->aux) + rout * d->ld_aux * eo;
+            if (d->res) s.res = static_cast<const char*>(d->res) + rout * d->ld_res * eo;
+            if (d->rowbias) s.rowbias = d->rowbias + (size_t)b0 * d->Cout;
+            if (d->gate) s.gate = d->gate + (size_t)b0 * d->gate_nseg * d->Cout;
+            const size_t pso = rout / BM * (size_t)vp_conv1d_nseg(d->T_out) * d->Cout;
+            if (d->psum) s.psum = d->psum + pso;
+            if (d->psumsq) s.psumsq = d->psumsq + pso;
+            const int rc = vp_conv1d_fwd(ctx, &s, stream);
+            if (rc) return rc;
+        }
+        return VP_OK;
+    }
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.x = d->x; a.w = d->w; a.bias = d->bias; a.rowbias = d->rowbias;
