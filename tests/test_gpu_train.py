@@ -930,7 +930,7 @@ def test_ecapa_training_step_mixed_precision(N, amp):
     m.eval()
 
 
-def _graphed_vs_eager(make_model, xs, ys, n_classes, margin_at=None):
+def _graphed_vs_eager(make_model, xs, ys, n_classes, margin_at=None, tol=1e-5):
     from ppvector.loss.aamloss import AAMLoss
     from ppvector.optimizer.adam import Adam
     from ppvector.train.step import GraphedTrainStep, TrainStep
@@ -963,7 +963,7 @@ def _graphed_vs_eager(make_model, xs, ys, n_classes, margin_at=None):
     for k in se:
         d = (se[k].double() - sg[k].double()).abs().max().item()
         worst = max(worst, d / max(1.0, se[k].abs().max().item()))
-        assert d <= 1e-5 * max(1.0, se[k].abs().max().item()), (k, d)
+        assert d <= tol * max(1.0, se[k].abs().max().item()), (k, d)
     print(f'[graphed step] worst relative parameter / running-statistic difference after {len(xs)} steps: {worst:.2e}')
     return st
 
@@ -989,6 +989,61 @@ def test_graphed_train_step_equals_the_eager_step(N):
 
     st = _graphed_vs_eager(make, xs, ys, 12, margin_at=5)
     assert st.n_stages == 1                                       # TDNN declares no cut points
+
+
+@pytest.mark.parametrize('name', ['eres2net', 'resnetse'])
+def test_graphed_2d_backbone_step_in_backward_stages_equals_the_eager_step(N, name):
+    """ERes2Net / ResNetSE declare a cut point after each of their first three stages (train/eres2net_train.py, train/resnetse_train.py):
+    the captured step is FOUR graphs (layer4 + fusion / pooling + embedding + head | layer3 | layer2 | stem + layer1).  Same losses,
+    parameters and running statistics as the eager step; the first backward stage already holds the LATE parameters -- the bulk of the
+    flat gradient buffer -- so the data-parallel all-reduce of BASELINE configs[3] / [4] starts under the remaining stages."""
+    from ppvector.models.eres2net import ERes2Net
+    from ppvector.models.fc import SpeakerIdentification
+    from ppvector.models.resnet_se import ResNetSE
+    g = torch.Generator().manual_seed(31)
+    xs = [(torch.randn(4, 40, 16, generator=g) * 2).cuda() for _ in range(7)]
+    ys = [torch.randint(0, 9, (4,), generator=g).cuda() for _ in range(7)]
+
+    def make():
+        torch.manual_seed(3)
+        m = ERes2Net(16, num_blocks=[1, 1, 1, 1]) if name == 'eres2net' else ResNetSE(16, layers=[1, 1, 1, 1])
+        head = SpeakerIdentification(192, 9)
+        head.load_state_dict({'weight': om.head_params(192, 9, seed=22)})
+        return torch.nn.Sequential(m, head).cuda()
+
+    # (1) one backward through the cut tape against one through the uncut tape, same weights, same batch: every parameter gradient.  A
+    # stage output that feeds the next stage AND the bottom-up fusion collects its two contributions at the cut's leaf in another order
+    # than the uncut tape adds them -- f32 rounding apart, nothing more
+    from ppvector.loss.aamloss import AAMLoss
+    from ppvector.train.segments import Recorder
+    grads = {}
+    for mode in ('plain', 'cut'):
+        model = make().train()
+        crit = AAMLoss(margin=0.2, scale=32)
+        if mode == 'cut':
+            rec = Recorder()
+            with rec:
+                loss = crit(model(xs[0]), ys[0])
+                rec.backward(loss)
+            assert rec.n_stages == 4
+        else:
+            crit(model(xs[0]), ys[0]).backward()
+        grads[mode] = {k: v.grad.detach().double().clone() for k, v in model.named_parameters() if v.grad is not None}
+    assert grads['plain'].keys() == grads['cut'].keys()
+    worst = max(((grads['cut'][k] - g).norm() / g.norm().clamp(min=1e-12)).item() for k, g in grads['plain'].items() if g.norm().item() > 1e-9)
+    print(f'[graphed {name}] one backward, cut tape vs uncut tape: worst parameter-gradient rel-L2 {worst:.2e}')
+    assert worst < 2e-5, worst
+    # (2) the captured step against the eager step over seven Adam steps (lr 2e-3): g / sqrt(v) amplifies the rounding-level gradient
+    # differences of (1) where a gradient is tiny -- 1e-3 of a weight's scale for ERes2Net; the plain chain (ResNetSE) stays at 1e-5
+    st = _graphed_vs_eager(make, xs, ys, 9, margin_at=5, tol=1e-3 if name == 'eres2net' else 1e-5)
+    assert st.n_stages == 4
+    plan = next(iter(st._plans.values()))
+    n = st.optimizer.grad.numel()
+    first = sum(b - a for a, b in plan['spans'][0])
+    covered = sorted(sp for stage in plan['spans'] for sp in stage)
+    assert covered[0][0] == 0 and covered[-1][1] == n and all(a[1] == b[0] for a, b in zip(covered, covered[1:])), covered   # a tiling
+    print(f'[graphed {name}] {st.n_stages} backward stages; the first holds {first / n:.0%} of the flat gradient buffer; chunk ready stages {plan["ready"]}')
+    assert first > 0.5 * n
 
 
 def test_graphed_ecapa_step_in_backward_stages_equals_the_eager_step(N):

@@ -11,6 +11,7 @@ import torch
 import torch.nn.functional as TF
 
 from ppvector.train.functions import Act, AffCombine, Conv2dBlock, ConvBlock, TimeStats
+from ppvector.train.segments import cut
 
 
 def _bn(p):
@@ -117,11 +118,18 @@ def _stem_and_stages(m, feats):
     w4 = torch.cat([w, torch.zeros((w.shape[0], 3, 3, 3), dtype=w.dtype, device=w.device)], dim=1)
     x = Conv2dBlock.apply(x, w4, m.conv1.bias, *_bn(m.bn1), dict(B=B, T=T, F=F, act='relu', momentum=m.bn1.momentum, eps=m.bn1.eps))
     stages, dims = [], []
-    for layer in (m.layer1, m.layer2, m.layer3, m.layer4):
+    for li, layer in enumerate((m.layer1, m.layer2, m.layer3, m.layer4)):
         for b in layer:
             x, T, F = block(b, x, B, T, F)
         stages.append(x)
         dims.append((T, F))
+        if li < 3:
+            # backward stage boundary (train/segments.py): the stage outputs so far are all live across it -- the next stage reads the
+            # last one, the bottom-up fusion reads every one.  Stage 0 of the backward then holds layer4 + the fusion + seg_1 + the head
+            # (85 % of ERes2Net-large's 93.6 M gradients with the 200 k-class head): their all-reduce chunks travel while the three
+            # expensive full-resolution stages are still being differentiated (BASELINE configs[4]: "grad all-reduce overlapped with backward")
+            stages = list(cut(*stages))
+            x = stages[-1]
     return stages, dims
 
 

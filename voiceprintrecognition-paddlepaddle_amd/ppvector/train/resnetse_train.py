@@ -5,6 +5,7 @@ import torch
 
 from ppvector.train.functions import Act, BNRows, Conv2dBlock, ConvBlock, SEDenseFn, SEScale, TimeStats
 from ppvector.train.tdnn_train import asp_forward
+from ppvector.train.segments import cut
 
 
 def _bn(p):
@@ -48,9 +49,11 @@ def resnetse_forward_train(m, feats):
     w = m.conv1.weight
     w4 = torch.cat([w, torch.zeros((w.shape[0], 3, 3, 3), dtype=w.dtype, device=w.device)], dim=1)
     x = Conv2dBlock.apply(x, w4, m.conv1.bias, *_bn(m.bn1), _cfg(B, T, F, m.bn1, relu=True))
-    for layer in (m.layer1, m.layer2, m.layer3, m.layer4):
+    for li, layer in enumerate((m.layer1, m.layer2, m.layer3, m.layer4)):
         for b in layer:
             x, T, F = bottleneck(b, x, B, T, F)
+        if li < 3:
+            (x,) = cut(x)          # backward stage boundary (train/segments.py): a plain chain, one live tensor
     Cc = x.shape[1]
     # (B, T', F', C) -> the reference's (B, C*F', T') channel order c*F' + f, frame-major for the pooling: (B*T', C*F')
     x = x.reshape(B, T, F, Cc).permute(0, 1, 3, 2).reshape(B * T, Cc * F)
