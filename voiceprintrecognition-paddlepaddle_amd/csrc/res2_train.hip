@@ -672,17 +672,13 @@ static int rt_num_cus(vp_ctx* ctx) {
 }
 
 // Does a grid of nwg workgroups of `kernel` fit the device at once?  hipOccupancyMaxActiveBlocksPerMultiprocessor is the runtime's own
-// answer for the kernel's registers / LDS (asked once per device and kernel); the reserve is subtracted from the CU count.
-static bool rt_fits(vp_ctx* ctx, const void* kernel, int which, size_t smem, int nwg) {
-    static int per_cu[16][2] = {};
-    int& n = per_cu[ctx->device & 15][which];
-    if (!n) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, RT_THREADS, smem) != hipSuccess || nb < 1) nb = -1;
-        n = nb;
-    }
-    if (n < 1) return false;
-    const long long slots = (long long)n * (rt_num_cus(ctx) - ctx->grid_reserve_cus);
+// answer for the kernel's registers and THIS launch's LDS (smem grows with T): asked on every call -- a cheap host query -- and never
+// cached (a per-(device, kernel) cache kept the first T's answer, and a first failure disabled the kernel for good); the
+// reserve is subtracted from the CU count.
+static bool rt_fits(vp_ctx* ctx, const void* kernel, size_t smem, int nwg) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, RT_THREADS, smem) != hipSuccess || nb < 1) return false;
+    const long long slots = (long long)nb * (rt_num_cus(ctx) - ctx->grid_reserve_cus);
     return nwg <= slots && nwg <= rt_num_cus(ctx) - ctx->grid_reserve_cus;      // (the dispatcher places one workgroup per CU first)
 }
 
@@ -736,7 +732,7 @@ int vp_res2_train_fwd(vp_ctx* ctx, const vp_res2_train_desc* d, void* ws, size_t
         VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(res2_train_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    if (!rt_fits(ctx, reinterpret_cast<const void*>(res2_train_fwd_kernel), 0, smem, a.B)) return VP_EUNSUP;
+    if (!rt_fits(ctx, reinterpret_cast<const void*>(res2_train_fwd_kernel), smem, a.B)) return VP_EUNSUP;
     hipLaunchKernelGGL(res2_train_fwd_kernel, dim3(a.B), dim3(RT_THREADS), smem, (hipStream_t)stream, a);
     VP_LAUNCH_CHECK(ctx, "res2_train_fwd");
     return VP_OK;
@@ -754,7 +750,7 @@ int vp_res2_train_bwd(vp_ctx* ctx, const vp_res2_train_desc* d, void* ws, size_t
         VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(res2_train_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    if (!rt_fits(ctx, reinterpret_cast<const void*>(res2_train_bwd_kernel), 1, smem, a.B)) return VP_EUNSUP;
+    if (!rt_fits(ctx, reinterpret_cast<const void*>(res2_train_bwd_kernel), smem, a.B)) return VP_EUNSUP;
     hipLaunchKernelGGL(res2_train_bwd_kernel, dim3(a.B), dim3(RT_THREADS), smem, (hipStream_t)stream, a);
     VP_LAUNCH_CHECK(ctx, "res2_train_bwd");
     return VP_OK;

@@ -146,8 +146,15 @@ def _narrow_to_wide(M, Cin, Cout, KW):
 # The wide mixed-precision layers read their weights as bf16 twice per step: W in the forward GEMM, W^T in the data-gradient GEMM.  Each
 # used to be a conversion launch of its own (13 + 9 per ECAPA step).  A backbone's training forward now hands ALL of them to ONE launch
 # up front (vp_prep_weights_bf16); the panels live in this registry -- keyed by the parameter and the column slice, stamped with the
-# weights epoch (an optimiser step / a graph replay moves it: stale panels are never read) -- and ConvBlock looks them up.
+# weights epoch (an optimiser step / a graph replay moves it) AND the parameter's torch version counter (load_state_dict, a checkpoint
+# resume, a manual in-place edit move that one: ADVICE r05): stale panels are never read -- and ConvBlock looks them up.
 _W16 = {}
+
+
+def drop_weight_panels():
+    """Forget every bf16 panel (GraphedTrainStep drops its captures / a fault was handled: the panels of a captured step live in that
+    graph's private pool)."""
+    _W16.clear()
 
 
 def prep_weights_bf16(items):
@@ -175,7 +182,7 @@ def prep_weights_bf16(items):
         rows.append(co)
         cols.append(nc)
         lds.append(ct)
-        _W16[(id(w), c0, nc)] = (weakref.ref(w), epoch, a, b)
+        _W16[(id(w), c0, nc)] = (weakref.ref(w), (epoch, w._version), a, b)
     arr = lambda t, v: (t * n)(*v)
     _chk(lib.vp_prep_weights_bf16(hctx, arr(C.c_void_p, ws), arr(C.c_void_p, w16s), arr(C.c_void_p, wts), arr(C.c_int, rows),
                                   arr(C.c_int, cols), arr(C.c_int, lds), n, N.stream_ptr()), hctx)
@@ -186,7 +193,7 @@ def _panels16(w, c0=0, nc=None):
     if w is None or w.dim() != 3:
         return None
     e = _W16.get((id(w), c0, w.shape[1] if nc is None else nc))
-    if e is None or e[0]() is not w or e[1] != N.weights_epoch() or os.environ.get('VPMI_NO_WPREP'):
+    if e is None or e[0]() is not w or e[1] != (N.weights_epoch(), w._version) or os.environ.get('VPMI_NO_WPREP'):
         return None
     return e[2], e[3]
 
@@ -297,8 +304,6 @@ class ConvBlock(torch.autograd.Function):
                 # travel as its bf16 twin, the way producers' twins do everywhere else (`_vp_bf16`), marked as the only copy.
                 y = _placeholder(z.shape, x.device)
                 cfg['_y16'] = y16t
-            if y16:
-                pass
             elif wide >= 2:
                 y = torch.empty(z.shape, dtype=torch.float32, device=x.device)
                 _chk(lib.vp_affine_rows_b16_f32(hctx, z.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(), B * T_out, Cout,
@@ -492,7 +497,10 @@ def _conv_block_bwd(ctx, dy, skip=None, fold=None, utt=None):
             for wd in splits:
                 part = torch.empty((B * T_in, wd), dtype=torch.float32, device=dev)
                 d2 = _conv_desc(dz, B, T_out, T_in, Cout, wd, 1, 1, N.VP_PAD_ZERO, 0, w2[at:at + wd])
-                if wide:
+                # the descriptor's operand type follows the operands actually handed over (never from the gating flags alone)
+                if w2.dtype == torch.bfloat16:
+                    if dz.dtype != torch.bfloat16:
+                        raise N.VpmiError('conv backward: bf16 W^T rows with an f32 dz in the split data-gradient branch')
                     d2.dtype_in = N.VP_BF16
                 d2.y = part.data_ptr()
                 _chk(lib.vp_conv1d_fwd(hctx, C.byref(d2), N.stream_ptr()), hctx)
@@ -507,7 +515,9 @@ def _conv_block_bwd(ctx, dy, skip=None, fold=None, utt=None):
                 # added in its epilogue)
                 dzin, w2 = dz.to(torch.bfloat16), (w2 if w2.dtype == torch.bfloat16 else w2.to(torch.bfloat16))
             d2 = _conv_desc(dzin, B, T_out, T_in, Cout, Cin, KW, dil, N.VP_PAD_ZERO, dil * (KW - 1) - pad_left, w2)
-            if wide or dzin is not dz:
+            if (w2.dtype == torch.bfloat16) != (dzin.dtype == torch.bfloat16):
+                raise N.VpmiError(f'conv backward: operand types disagree (W^T {w2.dtype}, dz {dzin.dtype})')
+            if w2.dtype == torch.bfloat16:
                 d2.dtype_in = N.VP_BF16
             d2.y = dx.data_ptr()
             if skip is not None:

@@ -34,6 +34,20 @@ def reduce_chunks(n, chunk=None):
     return [(i * chunk, min(n, (i + 1) * chunk)) for i in reversed(range(k))]
 
 
+class _FaultWork:
+    """Handle of the step's fault-word collective: wait() = the all-reduce's wait, then the reduced word back into the rank's own
+    barrier words (when it has any), so that every rank's optimiser kernels test the same value."""
+
+    def __init__(self, work, buf, word):
+        self.work, self.buf, self.word = work, buf, word
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        if self.word is not None:
+            self.word.copy_(self.buf.view(self.word.dtype) if self.word.dtype != self.buf.dtype else self.buf)
+
+
 def batch_accuracy(outputs, labels, K=1):
     """trainer.py:233-236: argmax of the logits against the labels; SubCenter heads score a class by its best sub-centre."""
     pred = getattr(outputs, 'pred', None)
@@ -108,11 +122,23 @@ class TrainStep:
         self._reserve_set = True
 
     def _share_fault(self, world):
-        """The bail-out word as every rank will see it: maximum over the ranks, in place, asynchronous like the gradient chunks."""
+        """The bail-out word as every rank will see it: maximum over the ranks, asynchronous like the gradient chunks.
+        The collective is issued by EVERY rank on EVERY step whatever its local state (a rank without barrier words -- its
+        context was created inside a capture, vp_set_grid_barrier_words failed -- must not issue one collective fewer than its peers:
+        the next gradient chunk would pair with their 1-element MAX).  The word travels through a dedicated one-element int32 tensor:
+        copied in (0 when this rank has no words), MAX-reduced, copied back behind the collective by `_FaultWork.wait`."""
         if world <= 1:
             return None
         w = self._fault_word()
-        return None if w is None else all_reduce_max_(w, async_op=True)
+        dev = self._device()
+        buf = getattr(self, '_fault_buf', None)
+        if buf is None or buf.device != dev:
+            buf = self._fault_buf = torch.zeros(1, dtype=torch.int32, device=dev)
+        if w is not None:
+            buf.copy_(w.view(torch.int32) if w.dtype != torch.int32 else w)
+        else:
+            buf.zero_()
+        return _FaultWork(all_reduce_max_(buf, async_op=True), buf, w)
 
     def _poll_faults(self):
         if self._device().type != 'cuda' or torch.cuda.is_current_stream_capturing():
@@ -241,8 +267,10 @@ class GraphedTrainStep(TrainStep):
         self.fault_every = fault_every           # (kept for callers that pass it: the word is now polled EVERY step, asynchronously)
 
     def _drop_captures(self):
+        from ppvector.train.functions import drop_weight_panels
         self._plans.clear()                    # the captured graphs replay the fused kernels
         self._seen.clear()
+        drop_weight_panels()                   # bf16 weight panels of a captured step point into that graph's private pool
 
     # ------------------------------------------------------------------------------------------------ capture
     def _spans(self, params):
