@@ -561,18 +561,59 @@ def test_conv1d_rejects_bad_shapes(N):
     w = torch.randn(16, 16, 3, dtype=torch.float64)
     with pytest.raises(N.VpmiError):
         run_conv(N, x, w, None, 3, 4, 'reflect', 'f32')             # reflect pad >= T
-    # maximum sizes: an operand past the 32-bit buffer-offset range (4 GiB) is refused before any launch
+    # maximum sizes: the kernels address x through 32-bit buffer offsets.  A batch whose activations pass 4 GiB runs as batch slices
+    # (test_conv1d_activations_past_4gib_run_as_batch_slices); ONE utterance past 4 GiB is refused before any launch
     lib, ctx = N.lib(), N.ctx(0)
     small = torch.zeros(64, dtype=torch.bfloat16, device='cuda')
     d = N.Conv1dDesc()
     d.dtype_in = d.dtype_out = N.VP_BF16
-    d.B, d.T_in, d.T_out, d.Cin, d.Cout, d.KW, d.dilation, d.stride = 4096, 4096, 4096, 512, 512, 1, 1, 1
+    d.B, d.T_in, d.T_out, d.Cin, d.Cout, d.KW, d.dilation, d.stride = 1, 4200000, 4200000, 512, 512, 1, 1, 1
     d.pad_mode = N.VP_PAD_REFLECT
     d.x, d.ldx, d.w, d.y, d.ldy = small.data_ptr(), 512, small.data_ptr(), small.data_ptr(), 512
     rc = lib.vp_conv1d_fwd(ctx, C.byref(d), N.stream_ptr())
     assert rc == N.VP_EUNSUP and b'4 GiB' in lib.vp_last_error(ctx)
     d.B = 0                                                          # empty batch
     assert lib.vp_conv1d_fwd(ctx, C.byref(d), N.stream_ptr()) == N.VP_EINVAL
+
+
+def test_conv1d_activations_past_4gib_run_as_batch_slices(N):
+    """BASELINE configs[4] at its per-GPU batch (ERes2Net-large, 128 utterances) has activation tensors past 4 GiB; the conv kernels
+    address x through a 32-bit buffer offset, so vp_conv1d_fwd runs such a launch as consecutive batch slices (csrc/conv_gemm.hip) --
+    with the fused time sums cut on M-tile boundaries.  Here: a 64-channel slice of a 4.4 GB f32 buffer (leading dimension 8192),
+    136 utterances, against the same conv over the two halves launched separately and against float64 on a few utterances."""
+    lib, ctx = N.lib(), N.ctx(0)
+    B, T, Cin, Cout, ld = 136, 1024, 64, 64, 8192
+    g = torch.Generator(device='cuda').manual_seed(9)
+    xbig = torch.empty((B, T, ld), device='cuda')
+    assert xbig.numel() * 4 > 2 ** 32
+    xbig[:, :, 256:256 + Cin] = torch.randn((B, T, Cin), device='cuda', generator=g)
+    w = torch.randn((Cout, Cin), device='cuda', generator=g) / Cin ** 0.5
+    bias = torch.randn(Cout, device='cuda', generator=g)
+
+    def run(b0, nb, y, ps):
+        d = N.Conv1dDesc()
+        d.dtype_in = d.dtype_out = N.VP_F32
+        d.B, d.T_in, d.T_out, d.Cin, d.Cout, d.KW, d.dilation, d.stride = nb, T, T, Cin, Cout, 1, 1, 1
+        d.pad_mode = N.VP_PAD_REFLECT
+        d.x, d.ldx, d.xoff, d.w, d.bias = xbig[b0:].data_ptr(), ld, 256, w.data_ptr(), bias.data_ptr()
+        d.y, d.ldy = y.data_ptr(), Cout
+        d.psum = ps.data_ptr()
+        N.check(lib.vp_conv1d_fwd(ctx, C.byref(d), N.stream_ptr()), ctx)
+
+    tiles, nseg = lib.vp_conv1d_tiles_m(B, T), lib.vp_conv1d_nseg(T)
+    y = torch.zeros((B, T, Cout), device='cuda')
+    ps = torch.zeros((tiles, nseg, Cout), device='cuda')
+    run(0, B, y, ps)                                                   # 4.4 GB: sliced inside the library
+    y2 = torch.zeros_like(y)
+    ps2 = torch.zeros_like(ps)
+    h = B // 2
+    run(0, h, y2[:h], ps2[:h * T // 128])                              # the same in two launches, each under 4 GiB
+    run(h, B - h, y2[h:], ps2[h * T // 128:])
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2) and torch.equal(ps, ps2)
+    for b in (0, 67, 68, 135):                                         # utterances on both sides of the library's cut
+        ref = xbig[b, :, 256:256 + Cin].double() @ w.double().t() + bias.double()
+        assert (y[b].double() - ref).abs().max().item() < 1e-4
 
 
 def test_empty_and_degenerate_inputs_are_refused(N):
