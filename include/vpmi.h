@@ -230,8 +230,9 @@ typedef struct {
     const float* bn_scale;    /* [cout] or NULL */
     const float* bn_shift;    /* [cout] or NULL */
     int cin, cout, kw, dil;
-    const void* w_hl;         /* optional (NULL = absent): the same weights as split bf16 planes (VP_HL32), [cout][kw*cin], kw*cin % 32
-                                 == 0 -- what the split-precision fast path of a VP_F32X3 backbone reads (LDS-DMA-able)  */
+    const void* w_hl;         /* optional (NULL = absent): the same weights as split bf16 planes (VP_HL32), [cout][Kp], Kp = kw*cin
+                                 rounded up to a multiple of 32 with zero columns -- what the split-precision fast path of a
+                                 VP_F32X3 backbone reads (LDS-DMA-able)                                                  */
 } vp_tdnn_layer;
 
 typedef struct {

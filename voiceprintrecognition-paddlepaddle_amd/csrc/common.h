@@ -138,6 +138,7 @@ int vp_conv3x3_c1(vp_ctx* ctx, int dtype, const void* feats, void* out, const fl
 int vp_se_scale_residual_ex(vp_ctx* ctx, int dtype, const void* x, int ldx, int xoff, const float* s,
                             const void* res, int ldr, int roff, void* out, int ldo, int ooff, int B, int T, int C,
                             int relu, hipStream_t st);
+int vp_im2col_hl32(vp_ctx* ctx, const float* x, int B, int T, int F, int KW, int dil, int pad, void* out, int Kp, hipStream_t st);
 int vp_time_moments(vp_ctx* ctx, int dtype, const void* x, int ldx, int B, int T, int C, float eps, int unbiased,
                     float* stats, hipStream_t st);
 int vp_se_gate(vp_ctx* ctx, const float* psum, const float* shift, int B, int T, int C, int H, const float* w1, const float* b1,

@@ -176,7 +176,7 @@ int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream) {
     int bn = d->Cout <= 32 ? 32 : (d->Cout <= 64 ? 64 : 128);
     if (mode == MODE_1X1_PRO && bn > 64) bn = 64;
     if (d->dtype_in == VP_BF16 && d->dtype_out == VP_F32) bn = 128;
-    if (hl_in || hl_out) bn = 128;
+    if (hl_in || hl_out) bn = (hl_in && hl_out && mode == MODE_1X1 && d->Cout <= 128 && getenv("VPMI_HL_BN128") == nullptr) ? 64 : 128;
     // (Round 3 pinned the bf16-input 128-column tile to 64 columns: kernels running beside it returned wrong lanes.  Round 4 found the
     // cause in the VICTIMS, not here -- packed-f32 VALU instructions reading freshly loaded registers next to an MFMA-heavy wave,
     // DESIGN.md section 8 -- and the library is now built without packed-f32 instructions; VPMI_BN64=1 keeps the narrow tile for A/B.)

@@ -12,5 +12,7 @@ int vp_conv_launch_x3_hl(vp_ctx* ctx, const void* args, int bn, int mode, hipStr
     return dispatch_conv<x3_t, hl_t, false>(ctx, *static_cast<const ConvArgs*>(args), bn, mode, st);
 }
 int vp_conv_launch_hl_hl(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st) {
+    // 64-column tiles for the narrow 1x1 layers (the ASP attention TDNN, 1536 -> 128: 596 M-tiles are 1.16 rounds of 128-wide tiles)
+    if (bn == 64 && mode == MODE_1X1) return launch_conv<hl_t, hl_t, 64, MODE_1X1>(ctx, *static_cast<const ConvArgs*>(args), st);
     return dispatch_conv<hl_t, hl_t, false>(ctx, *static_cast<const ConvArgs*>(args), bn, mode, st);
 }

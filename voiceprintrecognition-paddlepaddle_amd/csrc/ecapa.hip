@@ -95,7 +95,7 @@ int vp_run_asp(vp_ctx* ctx, const vp_asp_weights& A, int dtc, const void* x, int
 namespace {
 
 struct EcapaPlan {
-    void *cat0, *cat, *t1, *r2, *t2, *tmpA, *tmpB, *mfa, *h;
+    void *cat0, *cat, *t1, *r2, *t2, *tmpA, *tmpB, *mfa, *h, *im;
     float *e, *psum, *psumsq, *stats, *se_h, *se_s, *rowbias, *pooled;
     size_t total;
 };
@@ -125,6 +125,8 @@ int plan_ecapa(const vp_ecapa_weights* w, int B, int T, void* ws, size_t cap, Ec
     p.se_s = (float*)c.take((size_t)B * C * sizeof(float));
     p.rowbias = (float*)c.take((size_t)B * w->asp.att * sizeof(float));
     p.pooled = (float*)c.take((size_t)B * 2 * Cm * sizeof(float));
+    // split-precision fast path: blocks[0]'s tapped operand rows as an hl32 matrix (B*T, roundup(kw * cin, 32))
+    p.im = (w->dtype == VP_F32X3 && w->block0.w_hl) ? c.take(M * (size_t)vp_align_up((size_t)w->block0.kw * w->block0.cin, 32) * 4) : nullptr;
     p.total = c.off;
     return VP_OK;
 }
@@ -173,10 +175,22 @@ int ecapa_fwd_hl(vp_ctx* ctx, const vp_ecapa_weights* w, const void* feats, int 
         tdnn_desc(d, L, VP_F32X3, B, T, T, VP_PAD_REFLECT);
         d.dtype_in = d.dtype_out = VP_HL32; d.w = L.w_hl;
     };
-    // blocks[0]: f32 features in (split while staging), hl32 out
-    tdnn_desc(d, w->block0, VP_F32X3, B, T, T, VP_PAD_REFLECT);
-    d.dtype_out = VP_HL32;
-    d.x = feats; d.ldx = w->feat_dim; d.y = p.cat0; d.ldy = C;
+    // blocks[0]: with split weights present (w_hl = [C][roundup(kw * F, 32)], zero-padded) the taps are laid out as operand rows (im2col
+    // into split planes, 127 MB at 256 x 3 s) and the layer runs as a 1x1 GEMM on the LDS-DMA ring; else f32 features in (split while
+    // staging) on the 128-wide tapped kernel.  hl32 out either way
+    const int Kp0 = (int)vp_align_up((size_t)w->block0.kw * w->block0.cin, 32);
+    if (w->block0.w_hl && p.im && w->feat_dim == w->block0.cin && w->block0.cin % 8 == 0) {
+        const int pad = w->block0.dil * (w->block0.kw - 1) / 2;
+        if ((rc = vp_im2col_hl32(ctx, (const float*)feats, B, T, w->block0.cin, w->block0.kw, w->block0.dil, pad, p.im, Kp0, st))) return rc;
+        tdnn_desc(d, w->block0, VP_F32X3, B, T, T, VP_PAD_REFLECT);
+        d.dtype_in = d.dtype_out = VP_HL32; d.w = w->block0.w_hl;
+        d.Cin = Kp0; d.KW = 1; d.dilation = 1; d.pad_left = 0;
+        d.x = p.im; d.ldx = Kp0; d.y = p.cat0; d.ldy = C;
+    } else {
+        tdnn_desc(d, w->block0, VP_F32X3, B, T, T, VP_PAD_REFLECT);
+        d.dtype_out = VP_HL32;
+        d.x = feats; d.ldx = w->feat_dim; d.y = p.cat0; d.ldy = C;
+    }
     if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
     const void* xin = p.cat0;
     int ld_in = C, off_in = 0;

@@ -276,6 +276,41 @@ __global__ __launch_bounds__(256) void se_scale_residual_hl_kernel(SeHlArgs a) {
     }
 }
 
+// (B, T, F) f32 features -> the tapped conv's operand rows as split bf16 planes: out[b*T + t][j*F + c] = x[b][reflect(t - pad + j*dil)][c],
+// columns [KW*F, Kp) zero -- blocks[0] of the split-precision ECAPA path (ecapa_tdnn.py:249: TDNNBlock(F -> C, k5)) then runs as a 1x1
+// layer on the LDS-DMA ring kernel (csrc/conv_gemm256.hip) instead of the 128-wide tapped kernel.  A thread = 8 consecutive columns.
+struct Im2colArgs { const float* x; char* out; int T, F, KW, dil, pad, Kp; long long total; };
+__global__ __launch_bounds__(256) void im2col_hl_kernel(Im2colArgs a) {
+    const int cv = a.Kp / 8;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < a.total; idx += (long long)gridDim.x * 256) {
+        const long long m = idx / cv;
+        const int k0 = (int)(idx - m * cv) * 8;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (k0 < a.KW * a.F) {                                          // (F % 8 == 0: the 8 columns share a tap)
+            const int j = k0 / a.F, c = k0 - j * a.F;
+            const long long b = m / a.T;
+            const int t = (int)(m - b * a.T);
+            int ts = t - a.pad + j * a.dil;
+            ts = ts < 0 ? -ts : ts;
+            ts = ts >= a.T ? 2 * (a.T - 1) - ts : ts;
+            const float* src = a.x + ((size_t)b * a.T + ts) * a.F + c;
+            *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(src);
+            *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(src + 4);
+        }
+        unsigned oh[4], ol[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bf16_t h0 = (bf16_t)v[2 * e], h1 = (bf16_t)v[2 * e + 1];
+            const bf16_t l0 = (bf16_t)(v[2 * e] - (float)h0), l1 = (bf16_t)(v[2 * e + 1] - (float)h1);
+            oh[e] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+            ol[e] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+        }
+        char* op = a.out + (size_t)m * a.Kp * 4 + (k0 >> 5) * 128 + (k0 & 31) * 2;
+        *reinterpret_cast<uint4*>(op) = make_uint4(oh[0], oh[1], oh[2], oh[3]);
+        *reinterpret_cast<uint4*>(op + 64) = make_uint4(ol[0], ol[1], ol[2], ol[3]);
+    }
+}
+
 // ---------------------------------------------------------------- ASP softmax over time + weighted stats
 // pooling.py:114-123: attn = softmax_t(logits); mean = sum attn x; std = sqrt(clip(sum attn (x-mean)^2, eps)).
 // One workgroup = 64 channels of one utterance; the 4 waves split the frames, online softmax per
@@ -368,6 +403,19 @@ int vp_se_scale_residual_ex(vp_ctx* ctx, int dtype, const void* x, int ldx, int 
                             const void* res, int ldr, int roff, void* out, int ldo, int ooff, int B, int T, int C,
                             int relu, hipStream_t st) {
     return se_scale_residual_impl(ctx, dtype, x, ldx, xoff, s, res, ldr, roff, out, ldo, ooff, B, T, C, relu, nullptr, 0, 0, st);
+}
+
+int vp_im2col_hl32(vp_ctx* ctx, const float* x, int B, int T, int F, int KW, int dil, int pad, void* out, int Kp, hipStream_t st) {
+    if (!ctx || !x || !out || B <= 0 || T <= 0 || F % 8 || Kp % 32 || Kp < KW * F || pad >= T || dil * (KW - 1) - pad >= T ||
+        (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15)
+        VP_FAIL(ctx, VP_EINVAL, "im2col_hl32: bad arguments");
+    const long long total = (long long)B * T * (Kp / 8);
+    long long nb = (total + 255) / 256;
+    if (nb > 256 * 32) nb = 256 * 32;
+    Im2colArgs a{x, (char*)out, T, F, KW, dil, pad, Kp, total};
+    hipLaunchKernelGGL(im2col_hl_kernel, dim3((unsigned)nb), dim3(256), 0, st, a);
+    VP_LAUNCH_CHECK(ctx, "im2col_hl32");
+    return VP_OK;
 }
 
 // mean / std over time straight from the activations (small T): stats[b] = [mean(C) | sqrt(max(E[(x-m)^2], eps))]

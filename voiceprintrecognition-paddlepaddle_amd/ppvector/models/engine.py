@@ -53,8 +53,9 @@ class _Engine:
             sc, sh = bn.folded()
             L.bn_scale, L.bn_shift = self._p(sc), self._p(sh)
         L.cin, L.cout, L.kw, L.dil = (w.shape[1] // kw), cout, kw, dil
-        if self.dtype_name == 'float32x3' and w.shape[1] % 32 == 0:      # split bf16 planes of the same weights: the hl32 fast path
-            L.w_hl = self._p(pack_hl32(w))
+        if self.dtype_name == 'float32x3':      # split bf16 planes of the same weights ([cout][K rounded up to 32], zero columns): the hl32 fast path
+            kp = (w.shape[1] + 31) // 32 * 32
+            L.w_hl = self._p(pack_hl32(torch.nn.functional.pad(w.float(), (0, kp - w.shape[1]))))
 
     def asp(self, A, asp):
         Cc = asp.channels
