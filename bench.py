@@ -78,7 +78,8 @@ def conv_family_shapes(T):
     return s
 
 
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r05_pmc_infer.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r06_pmc_infer.json')
+PMC_FILE_X3 = os.path.join(ROOT, 'profiles', 'r06_pmc_infer_x3.json')
 CPU_THREADS = 32
 GRAPH_PREREPLAYS = 40
 
@@ -110,10 +111,14 @@ def gpu_clocks(index=0):
         return None
 
 
-def roofline_pass(reps, warm=20):
+def roofline_pass(reps, warm=20, x3=False):
     """Replays the dominant kernel family shape by shape (same shapes, dtypes, epilogue options and buffer sizes as inside the
-    step): `reps` back-to-back launches of a shape between HIP events on the launching stream."""
+    step): `reps` back-to-back launches of a shape between HIP events on the launching stream.
+    x3: the split-precision engine's family -- operands and outputs as split bf16 planes (VP_HL32), blocks[0] as the 1x1 GEMM over its
+    im2col rows (K = 416) that the fast path runs, all eight wide layers on conv_gemm128x256_ring_kernel<hl_t, true>; priced against
+    a third of the bf16 MFMA peak (three MFMAs per product), algorithmic flops = 2 M N K of the layer as the reference states it."""
     from ppvector import _native as N
+    from ppvector.models.utils import pack_hl32
     lib, ctx = N.lib(), N.ctx()
     T = 298
     M = BATCH * T
@@ -122,14 +127,20 @@ def roofline_pass(reps, warm=20):
     total_ms, total_flop, per_shape = 0.0, 0.0, []
     tiles, nseg = lib.vp_conv1d_tiles_m(BATCH, T), lib.vp_conv1d_nseg(T)
     for (cin, cout, kw, dil, extras) in conv_family_shapes(T):
-        x = torch.randn((M, cin), device=dev, generator=g).to(torch.bfloat16)
-        w = (torch.randn((cout, kw * cin), device=dev, generator=g) / (kw * cin) ** 0.5).to(torch.bfloat16)
+        alg_k = kw * cin                                   # the layer's K as the reference states it (flops are counted on this)
+        if x3 and kw > 1:                                  # blocks[0]: a 1x1 GEMM over its im2col rows, K padded to a multiple of 32
+            cin, kw, dil = (kw * cin + 31) // 32 * 32, 1, 1
+        x = torch.randn((M, cin), device=dev, generator=g)
+        w = torch.randn((cout, kw * cin), device=dev, generator=g) / (kw * cin) ** 0.5
+        x, w = (pack_hl32(x), pack_hl32(w)) if x3 else (x.to(torch.bfloat16), w.to(torch.bfloat16))
         bias = torch.randn((cout,), device=dev, generator=g)
         sc = torch.rand((cout,), device=dev, generator=g) + 0.5
         sh = torch.randn((cout,), device=dev, generator=g)
-        y = torch.empty((M, cout), device=dev, dtype=torch.bfloat16)
+        odt = torch.float32 if x3 else torch.bfloat16      # (an hl32 tensor has f32's footprint)
+        y = torch.empty((M, cout), device=dev, dtype=odt)
         d = N.Conv1dDesc()
-        d.dtype_in = d.dtype_out = N.VP_BF16
+        d.dtype_in = d.dtype_out = N.VP_HL32 if x3 else N.VP_BF16
+        d.mfma_bf16 = 2 if x3 else 0
         d.B, d.T_in, d.T_out, d.Cin, d.Cout, d.KW, d.dilation, d.stride = BATCH, T, T, cin, cout, kw, dil, 1
         d.pad_mode, d.pad_left = N.VP_PAD_REFLECT, dil * (kw - 1) // 2
         d.x, d.ldx, d.w, d.bias = x.data_ptr(), cin, w.data_ptr(), bias.data_ptr()
@@ -137,7 +148,7 @@ def roofline_pass(reps, warm=20):
         d.y, d.ldy = y.data_ptr(), cout
         keep = []
         if 'ysplit' in extras:
-            y2 = torch.empty((M, 64), device=dev, dtype=torch.bfloat16); keep.append(y2)
+            y2 = torch.empty((M, 64), device=dev, dtype=odt); keep.append(y2)
             d.y2, d.ldy2, d.ysplit = y2.data_ptr(), 64, 64
         if 'psum' in extras:
             ps = torch.empty((tiles, nseg, cout), device=dev); keep.append(ps); d.psum = ps.data_ptr()
@@ -160,18 +171,34 @@ def roofline_pass(reps, warm=20):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
-        flop = 2.0 * M * cout * kw * cin
+        flop = 2.0 * M * cout * alg_k
         total_ms += ms
         total_flop += flop
-        per_shape.append({'cin': cin, 'cout': cout, 'kw': kw, 'ms': round(ms, 4), 'tflops': round(flop / ms / 1e9, 1)})
+        per_shape.append({'cin': cin, 'cout': cout, 'kw': kw, 'alg_k': alg_k, 'ms': round(ms, 4), 'tflops': round(flop / ms / 1e9, 1)})
         del x, w, y, keep
-    # dominant kernel = the 1x1 launches the host dispatches to the half-tile ring kernel (Cin % 64 == 0, Cout >= 256)
-    dom = [p for p in per_shape if p['kw'] == 1 and p['cin'] % 64 == 0 and p['cout'] >= 256]
+    # dominant kernel = the 1x1 launches the host dispatches to the half-tile ring kernel (bf16: Cin % 64 == 0; x3: % 32; Cout >= 256)
+    dom = [p for p in per_shape if p['kw'] == 1 and p['cin'] % (32 if x3 else 64) == 0 and p['cout'] >= 256]
     fam_ms, fam_flop = total_ms, total_flop
     total_ms = sum(p['ms'] for p in dom)
-    total_flop = sum(2.0 * M * p['cout'] * p['kw'] * p['cin'] for p in dom)
+    total_flop = sum(2.0 * M * p['cout'] * p['alg_k'] for p in dom)
     n = len(dom)
     achieved = total_flop / (total_ms * 1e-3) / 1e12
+    if x3:
+        traffic = None
+        if os.path.exists(PMC_FILE_X3):
+            try:
+                tj = json.load(open(PMC_FILE_X3))
+                if tj.get('csrc_hash') == kernel_git_hash():
+                    for name, v in tj['kernels'].items():
+                        if 'conv_gemm128x256_ring_kernel' in name and 'hl_t' in name:
+                            traffic = round((v['read_MB'] + v['write_MB']) * 1e6)
+            except Exception:
+                traffic = None
+        return {'bound': 'mfma', 'kernel': 'conv_gemm128x256_ring_kernel<hl_t, true> (8 launches/step: blocks[0] over im2col rows, 6 x 512->512, '
+                                           'MFA 1536->1536; split precision: three bf16 MFMAs per product)',
+                'achieved': round(achieved, 2), 'peak': round(PEAK_X3_TFLOPS, 1), 'unit': 'TFLOP/s (algorithmic f32-equivalent)',
+                'frac': round(achieved / PEAK_X3_TFLOPS, 4), 'traffic': traffic, 'flop_per_launch': total_flop / n,
+                'avg_launch_ms': round(total_ms / n, 4), 'launches': per_shape}
     # HBM bytes per launch (average over the same seven launches) from the PMC passes of tools/pmc_step.sh, kept in profiles/: only
     # while that file was taken on THESE kernel sources
     traffic = None
@@ -491,6 +518,11 @@ def run_infer(args, rank, local_rank, world, dist):
         x3_eng = side_engine('float32x3', PEAK_X3_TFLOPS, 'split precision (bf16 hi + lo operands, three MFMAs per product, f32 accumulate); '
                              'all-pairs cosine scores within 1e-4 of the CPU oracle at random-init AND trained weights on all five backbones',
                              max(8, args.steps // 2))
+        if isinstance(x3_eng, dict) and 'error' not in x3_eng:
+            try:
+                x3_eng['roofline'] = roofline_pass(reps=20, warm=10, x3=True)
+            except Exception as e:             # noqa: BLE001
+                x3_eng['roofline'] = {'error': f'{type(e).__name__}: {e}'[:200]}
         f32_eng = side_engine('float32', PEAK_F32_TFLOPS, 'exact f32 MFMA; all-pairs cosine scores within 1e-4 of the CPU oracle at random-init '
                               'AND trained weights', max(4, args.steps // 4))
     out = {
