@@ -10,7 +10,8 @@
 // one workgroup each, with a halo of H = nconv * dil frames on every interior cut: conv i needs frames within dil of its outputs, so
 // after i convs a segment's values are exact on [lo + i dil, hi - i dil) -- still covering its own frames after the last conv.  The halo
 // frames are recomputed by both neighbours (9 - 19 % more MFMA work at T = 298) and never stored.  LDS: act[2][2 groups][TP][128 B]
-// + wts[3 taps][2 groups][64][128 B] (single buffer: the next conv's weights arrive under this conv's epilogue) + the per-channel terms.
+// + wts[3 taps][2 groups][64][128 B] (single buffer: a tap's region takes the next conv's weights as soon as every wave holds the
+// tap's fragments in registers) + the per-channel terms.
 // A 32-channel group of a row is 128 B = [32 hi | 32 lo]: exactly the bf16 kernels' K-stage row, so LDS-DMA pieces (8 rows x 128 B, XOR
 // swizzle on the source chunk), fragment reads (chunk g = hi, chunk 4 + g = lo) and the coalesced copy-out are those of res2_chain.hip.
 // Per conv and wave: taps outermost (16 weight fragments live), up to two 16-frame tiles, 72 MFMAs per tile.
@@ -78,20 +79,20 @@ __global__ __launch_bounds__(RX_THREADS, 1) void res2_x3_kernel(Res2X3Args a) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (rx_lds_ptr)(dst + gq * grp_bytes + pr * 1024), 16, off, 0, 0, 0);
         }
     };
-    // weights of conv j -> wts as [tap * 2 + group][n][128 B]: 48 pieces of 8 rows, 6 per wave
-    auto dma_w = [&](int j) {
+    // weights of conv j, tap `tap` -> wts as [tap * 2 + group][n][128 B]: 16 pieces of 8 rows per tap, 2 per wave
+    auto dma_w = [&](int j, int tap) {
         const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.w[j]), 0, RX_WT_BYTES, 0x00020000);
 #pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const int p = wv + u * RX_WAVES;              // 0..47
-            const int q = p >> 3, nb = (p & 7) * 8;       // q = tap * 2 + group
+        for (int u = 0; u < 2; ++u) {
+            const int p = wv + u * RX_WAVES;              // 0..15
+            const int q = tap * 2 + (p >> 3), nb = (p & 7) * 8;       // q = tap * 2 + group
             const unsigned off = (unsigned)((nb + drow) * 768 + q * 128) + dchunk;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (rx_lds_ptr)(wts + (q * 64 + nb) * 128), 16, off, 0, 0, 0);
         }
     };
 
     dma_x(1, act0);
-    dma_w(0);
+    dma_w(0, 0); dma_w(0, 1); dma_w(0, 2);
     for (int i = tid; i < a.nconv * 192; i += RX_THREADS) {
         const int j = i / 192, k = i - j * 192, which = k >> 6, n = k & 63;
         prm[i] = which == 0 ? a.bias[j][n] : (which == 1 ? a.scale[j][n] : a.shift[j][n]);
@@ -124,6 +125,15 @@ __global__ __launch_bounds__(RX_THREADS, 1) void res2_x3_kernel(Res2X3Args a) {
                     wl[ni][gq] = *reinterpret_cast<const bf16x8*>(wr + ((sw_l ^ (n & 7)) << 4));
                 }
             }
+            if (has_next) {
+                // every wave holds this tap's weights in registers behind the barrier: the tap's LDS region is dead and takes the NEXT
+                // conv's weights of the same tap now, under this conv's MFMAs (a single weight buffer; loading all 48 KB after the
+                // MFMAs left ~1.5 us of L2 latency exposed per conv).  Raw s_barrier: __syncthreads() would also wait for the x DMA in flight
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                dma_w(j + 1, tap);
+            }
 #pragma unroll
             for (int r = 0; r < RX_ROUNDS; ++r) {
                 const int mt = wv + r * RX_WAVES;
@@ -149,7 +159,6 @@ __global__ __launch_bounds__(RX_THREADS, 1) void res2_x3_kernel(Res2X3Args a) {
         // own DMAs landed; after the barrier everyone's have, and every wave is done reading `ain` and the weights
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (has_next) dma_w(j + 1);                                      // lands under the epilogue and the copy-out
         const float* pj = prm + j * 192;
 #pragma unroll
         for (int r = 0; r < RX_ROUNDS; ++r) {
