@@ -142,6 +142,31 @@ def test_ecapa_split_precision_engine_vs_oracle(ecapa):
     assert d < 5e-5, d
 
 
+def test_ecapa_split_precision_fast_path_reads_no_unwritten_scratch(ecapa):
+    """The hl32 fast path with its whole workspace pre-filled with different garbage (NaN bit patterns, then 0x7f bytes) before each run:
+    bit-identical embeddings.  Catches reads of scratch the step never wrote -- the zero-padded K columns of the im2col operand, the halo
+    / tile-padding rows of the Res2 segments, the concat slice a later block fills, rows past M in the last ring tile."""
+    g = torch.Generator().manual_seed(8)
+    feats = (torch.randn(20, 298, 80, generator=g) * 2).cuda()
+    eng = ecapa.engine('float32x3')
+    ref = eng.forward(feats).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(ref).all()
+    for fill in (0xff, 0x7f, 0x00):
+        for buf in eng.ws.bufs.values():
+            buf.fill_(fill)
+        got = eng.forward(feats)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref), (fill, (got - ref).abs().max().item())
+    # and as two concurrent launch sequences (own workspace each), against the same shards run one after the other
+    halves = torch.cat([eng.forward(feats[:10].contiguous()), eng.forward(feats[10:].contiguous())]).clone()
+    for _ in range(4):
+        for w in eng._slots.values():
+            for buf in w.bufs.values():
+                buf.fill_(0xff)
+        assert torch.equal(eng.forward_streams(feats, 2), halves)
+
+
 def test_full_size_batch_invariance(ecapa):
     """BASELINE config 2 shape (B=256, T=298): eval-mode embeddings are per-utterance functions, so
     any utterance's embedding must not depend on the batch it travels in (size-independent
