@@ -11,12 +11,15 @@
 // two xor-shuffles at the end; waves never talk.  Roofline: HBM/L2 -- x once (T*C*4 B per utterance) + h per 128-channel block (L2-hot).
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int AX_ATT = 128;
 constexpr float AX_LOG2E = 1.4426950408889634f;
 constexpr int AX_HROW = 640;          // bytes per staged h row: 4 groups x 128 B + 128 pad (odd multiple of 128: rows alternate bank halves)
-constexpr int AX_XROW = 528;          // bytes per staged x row: 128 channels f32 + 16 pad (the 4 frame groups of a result-layout read land on disjoint banks)
+// bytes per staged x row: NW x 32 channels f32 + 16 pad (the 4 frame groups of a result-layout read land on disjoint banks)
+template <int NW> struct AxGeom { static constexpr int CB = NW * 32, XROW = CB * 4 + 16; };
 
 struct AspX3Args {
     const char* h;          // hl32 (B*T, att)
@@ -36,13 +39,18 @@ __device__ __forceinline__ void ax_merge(float& m, float& s0, float& s1, float& 
     s0 = s0 * f1 + a0 * f2; s1 = s1 * f1 + a1 * f2; s2 = s2 * f1 + a2 * f2; m = M;
 }
 
-__global__ __launch_bounds__(256) void asp_x3_kernel(AspX3Args a) {
+// NW waves per workgroup = NW x 32 channels of one utterance per h tile (the h tensor is read once per channel block: 12 x 39 MB at
+// C = 1536 with 128-channel blocks -- 40 % of the kernel's traffic by PMC; see the launcher for why 4 waves stay the default)
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void asp_x3_kernel(AspX3Args a) {
+    constexpr int CB = AxGeom<NW>::CB, AX_XROW = AxGeom<NW>::XROW;
+    constexpr int TPR = NW * 4;                   // staging threads per frame row: 16 rows x TPR = the workgroup
     __shared__ __attribute__((aligned(16))) char hs[2][16 * AX_HROW];
     __shared__ __attribute__((aligned(16))) char xs[2][16 * AX_XROW];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
     const int b = blockIdx.y;
-    const int cblk = blockIdx.x * 128;
+    const int cblk = blockIdx.x * CB;
     const int c0 = cblk + wv * 32;
     const size_t row0 = (size_t)b * a.T;
 
@@ -72,26 +80,28 @@ __global__ __launch_bounds__(256) void asp_x3_kernel(AspX3Args a) {
     float mx[2] = {-INFINITY, -INFINITY}, s0[2] = {0.f, 0.f}, s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
 
     const int ntile = (a.T + 15) / 16;
-    // frame tile mt: thread (row = tid >> 4, q = tid & 15) moves chunks 2q, 2q + 1 of the h row's 32 (group q >> 2, chunks 2 (q & 3) ..)
-    // and the 8 channels cblk + 8 q of the x row (16 B of the hi plane + 16 B of the lo plane of their group)
-    const int srow = tid >> 4, q = tid & 15;
+    // frame tile mt: thread (row = tid / TPR, q = tid % TPR) moves its share of the h row's 32 16-byte chunks (2 per thread with 4
+    // waves, 1 with 8: group = chunk >> 3) and the 8 channels cblk + 8 q of the x row (16 B of the hi plane + 16 B of the lo plane)
+    constexpr int HC = 32 / TPR;                  // h chunks per thread
+    const int srow = tid / TPR, q = tid % TPR;
     const int xcol = min(cblk + q * 8, a.C - 8);                        // clamped: columns past C feed lanes that never store
     const int xgo = (xcol >> 5) * 128 + (xcol & 31) * 2;
     const size_t ldxb = (size_t)a.ldx * 4;
     auto gload = [&](int mt, uint4& h0, uint4& h1, uint4& xh, uint4& xl) {
         const size_t t = row0 + min(mt * 16 + srow, a.T - 1);
-        const char* hp = a.h + t * (AX_ATT * 4) + q * 32;
+        const char* hp = a.h + t * (AX_ATT * 4) + q * (HC * 16);
         h0 = *reinterpret_cast<const uint4*>(hp);
-        h1 = *reinterpret_cast<const uint4*>(hp + 16);
+        if constexpr (HC == 2) h1 = *reinterpret_cast<const uint4*>(hp + 16);
         const char* xp = a.x + t * ldxb + xgo;
         xh = *reinterpret_cast<const uint4*>(xp);
         xl = *reinterpret_cast<const uint4*>(xp + 64);
     };
     auto swrite = [&](int buf, const uint4& h0, const uint4& h1, const uint4& xh, const uint4& xl) {
-        char* hr = hs[buf] + srow * AX_HROW + (q >> 2) * 128;
-        const int c = (q & 3) * 2;
+        const int c0h = q * HC;                                         // first chunk of the row's 32
+        char* hr = hs[buf] + srow * AX_HROW + (c0h >> 3) * 128;
+        const int c = c0h & 7;
         *reinterpret_cast<uint4*>(hr + ((c ^ (srow & 7)) << 4)) = h0;
-        *reinterpret_cast<uint4*>(hr + (((c + 1) ^ (srow & 7)) << 4)) = h1;
+        if constexpr (HC == 2) *reinterpret_cast<uint4*>(hr + (((c + 1) ^ (srow & 7)) << 4)) = h1;
         const unsigned hw[4] = {xh.x, xh.y, xh.z, xh.w}, lw[4] = {xl.x, xl.y, xl.z, xl.w};
         float v[8];
 #pragma unroll
@@ -140,7 +150,7 @@ __global__ __launch_bounds__(256) void asp_x3_kernel(AspX3Args a) {
             s0[ni] = fmaf(s0[ni], f, p0); s1[ni] = fmaf(s1[ni], f, p1); s2[ni] = fmaf(s2[ni], f, p2);
         }
     };
-    uint4 h0, h1, xh, xl;
+    uint4 h0, h1 = uint4{0u, 0u, 0u, 0u}, xh, xl;
     gload(0, h0, h1, xh, xl);
     swrite(0, h0, h1, xh, xl);
     __syncthreads();
@@ -176,7 +186,11 @@ int vp_asp_fused_x3(vp_ctx* ctx, const void* h, const float* w, const float* bia
     AspX3Args a;
     a.h = (const char*)h; a.w = w; a.bias = bias; a.x = (const char*)x; a.center = center;
     a.pooled = pooled; a.ldx = ldx; a.ldc = ldc; a.T = T; a.C = C; a.eps = eps;
-    hipLaunchKernelGGL(asp_x3_kernel, dim3((C + 127) / 128, B), dim3(256), 0, st, a);
+    // 256-channel blocks (8 waves) halve the h re-reads but measured SLOWER at 256 x 3 s, C = 1536: 187 us against 150 us with 128-channel
+    // blocks (a 512-thread workgroup with 53 KB of LDS leaves fewer independent workgroups per CU to hide the staging loads); kept for A/B
+    static const bool wide = getenv("VPMI_ASPX3_256") != nullptr;
+    if (C >= 512 && wide) hipLaunchKernelGGL(asp_x3_kernel<8>, dim3((C + 255) / 256, B), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL(asp_x3_kernel<4>, dim3((C + 127) / 128, B), dim3(256), 0, st, a);
     VP_LAUNCH_CHECK(ctx, "asp_x3");
     return VP_OK;
 }
