@@ -19,7 +19,7 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 scheds = [int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else [3, 4, 5]
 shapes = [(1536, 1536), (512, 512)] if len(sys.argv) < 4 else [tuple(int(v) for v in s.split('x')) for s in sys.argv[3:]]
 lib, ctx = N.lib(), N.ctx(0)
-B, T = 256, 298
+B, T = int(os.environ.get("GP_B", "256")), 298
 M = B * T
 g = torch.Generator(device='cuda').manual_seed(0)
 for cin, cout in shapes:
@@ -37,6 +37,8 @@ for cin, cout in shapes:
     y = torch.empty((M, cout), device='cuda', dtype=torch.float32 if X3 else torch.bfloat16)
     d = N.Conv1dDesc()
     d.dtype_in = d.dtype_out = N.VP_HL32 if X3 else N.VP_BF16
+    if X3 and os.environ.get('X3OUT') == 'f32':      # A/B: what the hl32 split + double stores of the epilogue cost
+        d.dtype_out = N.VP_F32
     d.mfma_bf16 = 2 if X3 else 0
     d.B, d.T_in, d.T_out, d.Cin, d.Cout, d.KW, d.dilation, d.stride = B, T, T, cin, cout, 1, 1, 1
     d.pad_mode = N.VP_PAD_REFLECT
@@ -60,7 +62,7 @@ for cin, cout in shapes:
                 b.record()
             torch.cuda.synchronize()
             times[s] += [a.elapsed_time(b) for a, b in evs[1:]]
-            err = ((unpack_hl32(y) if X3 else y.float()) - ref).abs().max().item() / ref.abs().max().item()      # every element, every round (races show up here)
+            err = ((unpack_hl32(y) if (X3 and os.environ.get('X3OUT') != 'f32') else y.float()) - ref).abs().max().item() / ref.abs().max().item()      # every element, every round (races show up here)
             worst[s] = max(worst[s], err)
     for s in scheds:
         t = sorted(times[s])

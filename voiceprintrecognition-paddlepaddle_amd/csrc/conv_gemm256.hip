@@ -1053,6 +1053,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm128x256_ring_kernel(const Con
     constexpr int MI = 4, NI = 8;
     constexpr unsigned ESB = X3 ? 4u : 2u;     // bytes per element of an operand row
     constexpr int NMMA = X3 ? 24 : 16;         // MFMAs of a quadrant phase
+#ifdef VP_TIMING
+    const unsigned long long tk0 = wall_clock64();
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1210,6 +1213,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm128x256_ring_kernel(const Con
     constexpr std::false_type W{};
     constexpr std::true_type TIGHT{};
     constexpr std::false_type LOOSE{};
+#ifdef VP_TIMING
+    const unsigned long long tk1 = wall_clock64();
+    const unsigned long long ck1 = clock64();
+#endif
     for (int t = 0; t < KTp; t += 2) {
         // even K-step t (set 0): XA in xpf, XB -> xqf
         phase(X, R2_XB0, xqf, wbf, X, t + 2, R2_XA0, 0, xpf, waf, 0, 0, TIGHT);
@@ -1223,8 +1230,21 @@ __global__ __launch_bounds__(256, 2) void conv_gemm128x256_ring_kernel(const Con
         phase(X, R2_XA0, xpf, wbf, W, t + 4, R2_WA0, 0, xqf, wbf, 0, 4, LOOSE);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // zero-fill DMAs of the tail still target the buffers
+#ifdef VP_TIMING
+    const unsigned long long tk2 = wall_clock64();
+    const unsigned long long ck2 = clock64();
+#endif
     __syncthreads();                                           // every wave is done reading the ring
     epilogue256<4, TO>(a, acc, smem, tid, tm, m0, n0);
+#ifdef VP_TIMING
+    if (!a.aux && a.add_in) {          // debug build only: per-workgroup phase stamps (100 MHz counter)
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long* o = (unsigned long long*)a.add_in + (size_t)blockIdx.x * 8;
+            o[0] = tk0; o[1] = tk1; o[2] = tk2; o[3] = wall_clock64(); o[4] = tk2; o[5] = ck2 - ck1; o[6] = tk2; o[7] = 0;
+        }
+    }
+#endif
 }
 
 template <typename TO, bool X3>
