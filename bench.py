@@ -570,14 +570,19 @@ def run_infer(args, rank, local_rank, world, dist):
             dog = threading.Timer(float(os.environ.get('VP_BENCH_TRAIN_TIMEOUT', '300')), bail, args=('dp_train did not finish in time',))
             dog.daemon = True
             dog.start()
-        dp_f32 = None
+        dp_f32 = dp_x3 = None
         try:
             dp_train = run_train(args, rank, local_rank, world, dist, steps=args.train_steps, warmup=3, emit=False)
             # the reference's DEFAULT training precision (enable_amp: False in every shipped YAML, configs/ecapa_tdnn.yml:100):
             # the same step on the exact-f32 matrix cores, a shorter run
             a32 = argparse.Namespace(**vars(args))
             a32.amp = 0
+            a32.train_x3 = 0
             dp_f32 = run_train(a32, rank, local_rank, world, dist, steps=max(4, args.train_steps // 3), warmup=3, emit=False)
+            # ... and the same f32 tensors with the three conv GEMMs in split precision (f32-grade gradients on the bf16 matrix cores)
+            ax3 = argparse.Namespace(**vars(args))
+            ax3.amp, ax3.train_x3 = 0, 1
+            dp_x3 = run_train(ax3, rank, local_rank, world, dist, steps=max(4, args.train_steps // 2), warmup=3, emit=False)
         except Exception as e:             # noqa: BLE001 -- anything here must not cost the headline line
             dp_err = f'{type(e).__name__}: {e}'[:300]
         if dog is not None:
@@ -598,6 +603,9 @@ def run_infer(args, rank, local_rank, world, dist):
         if dp_f32 is not None:
             out['dp_train_f32'] = {k: dp_f32[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'loss', 'stage_roofline_frac', 'steps')
                                    if k in dp_f32}
+        if dp_x3 is not None:
+            out['dp_train_x3'] = {k: dp_x3[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'loss', 'stage_roofline_frac', 'stage_roofline_peak', 'steps')
+                                  if k in dp_x3}
     if world == 1 and not args.no_roofline and want16:
         # both protocols on one line: "cold" = rounds 1-3 (2 warm + 10 timed launches per shape, taken first), "loaded" = round 4
         # (20 warm + 30 timed: the launches run in the GPU's loaded power state, as inside the step); `frac` stays the loaded number
@@ -628,6 +636,7 @@ def run_train(args, rank, local_rank, world, dist, steps=None, warmup=None, emit
     wav = torch.from_numpy(wav_all[list(idx)] if not args.weak else wav_all).to(dev)
     labels = ((torch.arange(gbatch) * 7) % N_CLASSES)[list(idx)].to(dev)
     import ppvector
+    ppvector.set_train_x3(bool(getattr(args, 'train_x3', 0)))      # split-precision GEMMs over f32 tensors (ignored under enable_amp)
     ppvector.set_train_amp(bool(args.amp))      # enable_amp: bf16 matrix cores in the three conv GEMMs, bf16-stored activations between them
     fz, backbone, head, _, _ = build_ecapa(dev, 'float32')
     model = torch.nn.Sequential(backbone, head).to(dev)
@@ -684,7 +693,8 @@ def run_train(args, rank, local_rank, world, dist, steps=None, warmup=None, emit
         'metric': 'utterances/sec (3 s, 16 kHz) ECAPA-TDNN training step (Fbank + fwd + AAM + bwd + DP all-reduce + Adam)',
         'value': round(value, 1), 'unit': 'utterances/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
         'ms_per_step': round(ms_step, 4), 'higher_is_better': True, 'scaling': 'weak' if args.weak else 'strong',
-        'vs_baseline': None, 'dtype': 'enable_amp: bf16 matrix cores, activations between the GEMMs stored as bf16, f32 accumulation / statistics / gradients / master weights' if args.amp else 'f32', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': 'enable_amp: bf16 matrix cores, activations between the GEMMs stored as bf16, f32 accumulation / statistics / gradients / master weights' if args.amp else
+                                      ('f32 tensors, conv GEMMs (forward, data and weight gradient) in split precision: bf16 hi + lo operands, three MFMAs per product' if getattr(args, 'train_x3', 0) else 'f32'), 'data': 'synthetic',
         'config': {'workload': 'ECAPA-TDNN (C=512, MFA 1536, ASP, embd 192) + Kaldi Fbank 80, 3 s @ 16 kHz (T=298), 2796-class cosine head + '
                                'AAMLoss, train-mode forward (batch-statistics BN) + backward + flat Adam, '
                                + ('conv GEMMs (forward, data and weight gradient) on the bf16 matrix cores, ' if args.amp else 'f32 matrix cores, ') +
@@ -698,8 +708,10 @@ def run_train(args, rank, local_rank, world, dist, steps=None, warmup=None, emit
                    'hip_graph': bool(graphed and getattr(step_obj, 'capture_error', None) is None),
                    'backward_stages': getattr(step_obj, 'n_stages', 1) if graphed else 1},
         'loss': round(loss_v, 5),
-        'stage_roofline_frac': round(value * 3 * ALG_GFLOP_PER_UTT / 1e3 / world / (PEAK_BF16_TFLOPS if args.amp else PEAK_F32_TFLOPS), 4),
-        'stage_roofline_peak': ('bf16 MFMA 2500' if args.amp else 'f32 MFMA 157.3') + ' TFLOP/s per GPU, 3 x forward flops per utterance',
+        'stage_roofline_frac': round(value * 3 * ALG_GFLOP_PER_UTT / 1e3 / world /
+                                     (PEAK_BF16_TFLOPS if args.amp else (PEAK_X3_TFLOPS if getattr(args, 'train_x3', 0) else PEAK_F32_TFLOPS)), 4),
+        'stage_roofline_peak': ('bf16 MFMA 2500' if args.amp else ('bf16 MFMA / 3 = 833' if getattr(args, 'train_x3', 0) else 'f32 MFMA 157.3')) +
+                               ' TFLOP/s per GPU, 3 x forward flops per utterance',
     }
     if graphed and getattr(step_obj, 'capture_error', None):
         out['hip_graph_error'] = step_obj.capture_error
@@ -718,6 +730,7 @@ def main():
     ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float32x3', 'float32'])
     ap.add_argument('--streams', type=int, default=2, help='concurrent launch sequences per GPU (infer mode)')
     ap.add_argument('--graph', type=int, default=1, help='infer mode: replay the step from one captured HIP graph (1) or launch eagerly (0)')
+    ap.add_argument('--train-x3', type=int, default=0, help='training with --amp 0: the conv GEMMs in split precision over f32 tensors')
     ap.add_argument('--amp', type=int, default=1, help='training: conv GEMMs on the bf16 matrix cores, bf16-stored activations (enable_amp); 0 = exact f32')
     ap.add_argument('--global-batch', type=int, default=BATCH, help='train mode: global batch (strong scaling)')
     ap.add_argument('--weak', action='store_true', help='train mode: keep --global-batch utterances PER GPU')

@@ -138,9 +138,15 @@ __device__ __forceinline__ int wa_L(int R) { return ((R >> 1) & 7) ^ ((R >> 4) &
 // BF: x and dz are already bf16 in memory (the wide layers' operands, see ConvBlock): 8-byte loads of four bf16, no rounding here.
 typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
 
-template <bool BF>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_amp_kernel(WgradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char wsm[];        // [2 stages][dz^T 16 KB | x^T 16 KB]
+// X3 (f32 operands only): split precision -- each operand is staged as TWO transposed bf16 planes (hi = bf16(v), lo = bf16(v - hi)) and
+// the contraction is lo*hi + hi*lo + hi*hi (conv_gemm_impl.h: x3_t): the weight gradient of the 'float32x3' training mode, ~2^-17 per
+// product.  Twice the LDS (128 KB: one workgroup per CU) and three MFMAs per fragment pair.
+template <bool BF, bool X3 = false>
+__global__ __launch_bounds__(256, X3 ? 1 : 2) void conv_wgrad_amp_kernel(WgradArgs a) {
+    static_assert(!(BF && X3), "split precision takes f32 operands");
+    constexpr int PLANES = X3 ? 2 : 1;
+    constexpr int STG = PLANES * 2 * WA_T * 128;                       // bytes per stage
+    extern __shared__ __attribute__((aligned(16))) char wsm[];        // [2 stages][dz^T 16 KB | x^T 16 KB] (x3: + the two lo planes)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int wn = wv & 1, wk = wv >> 1;
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_amp_kernel(WgradArgs a) {
         }
     };
     auto swrite = [&](int s) {
-        char* dzs = wsm + s * (2 * WA_T * 128);
+        char* dzs = wsm + s * STG;
         char* xs = dzs + WA_T * 128;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -212,15 +218,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_amp_kernel(WgradArgs a) {
                 *reinterpret_cast<u16x8*>(xs + R * 128 + pos) = vx;
             } else {
                 bf16x8 vd, vx;
+                [[maybe_unused]] bf16x8 ld, lx;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     const float d = e == 0 ? rdz[r].x : (e == 1 ? rdz[r].y : (e == 2 ? rdz[r].z : rdz[r].w));
                     const float xv = e == 0 ? rx[r].x : (e == 1 ? rx[r].y : (e == 2 ? rx[r].z : rx[r].w));
                     vd[r] = (bf16_t)d;
                     vx[r] = (bf16_t)xv;
+                    if constexpr (X3) {
+                        ld[r] = (bf16_t)(d - (float)vd[r]);
+                        lx[r] = (bf16_t)(xv - (float)vx[r]);
+                    }
                 }
                 *reinterpret_cast<bf16x8*>(dzs + R * 128 + pos) = vd;
                 *reinterpret_cast<bf16x8*>(xs + R * 128 + pos) = vx;
+                if constexpr (X3) {
+                    *reinterpret_cast<bf16x8*>(dzs + 2 * WA_T * 128 + R * 128 + pos) = ld;
+                    *reinterpret_cast<bf16x8*>(xs + 2 * WA_T * 128 + R * 128 + pos) = lx;
+                }
             }
         }
     };
@@ -235,25 +250,34 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_amp_kernel(WgradArgs a) {
         swrite(s);
         __syncthreads();
         gload(mb + WA_RC);                            // rows past m_end come back as zeros
-        const char* dzs = wsm + s * (2 * WA_T * 128);
+        const char* dzs = wsm + s * STG;
         const char* xs = dzs + WA_T * 128;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 af[4], bf[4];
+            [[maybe_unused]] bf16x8 al[4], bl[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const int R = wn * 64 + p * 16 + i;
                 af[p] = *reinterpret_cast<const bf16x8*>(dzs + R * 128 + (((ks * 4 + g) ^ wa_L(R)) << 4));
+                if constexpr (X3) al[p] = *reinterpret_cast<const bf16x8*>(dzs + 2 * WA_T * 128 + R * 128 + (((ks * 4 + g) ^ wa_L(R)) << 4));
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int R = wk * 64 + q * 16 + i;
                 bf[q] = *reinterpret_cast<const bf16x8*>(xs + R * 128 + (((ks * 4 + g) ^ wa_L(R)) << 4));
+                if constexpr (X3) bl[q] = *reinterpret_cast<const bf16x8*>(xs + 2 * WA_T * 128 + R * 128 + (((ks * 4 + g) ^ wa_L(R)) << 4));
             }
 #pragma unroll
             for (int p = 0; p < 4; ++p)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[p], bf[q], acc[p][q], 0, 0, 0);
+                for (int q = 0; q < 4; ++q) {
+                    if constexpr (X3) {
+                        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[p], bf[q], acc[p][q], 0, 0, 0);
+                        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[p], bl[q], acc[p][q], 0, 0, 0);
+                    }
+                    acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[p], bf[q], acc[p][q], 0, 0, 0);
+                }
         }
         s ^= 1;
     }
@@ -1515,6 +1539,7 @@ static int wgrad_impl(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int
     if (S > 256) S = 256;
     if (nbatch > 1 && S > 512 / nbatch) S = 512 / nbatch > 1 ? 512 / nbatch : 1;      // the batch fills the chip: fewer, longer row splits (less to reduce)
     if ((long long)S * 64 > M) S = (int)((M + 63) / 64);
+    const bool x3 = d->mfma_bf16 == 2 && !bf_in;       // split precision (f32 operands): the 128 x 128 kernel, one workgroup per CU
     if ((d->mfma_bf16 || bf_in) && nbatch == 1) {
         // The 128 x 128 mixed-precision kernel keeps two workgroups per CU resident.  A grid of 1.5 rounds of them costs two rounds of
         // time with half-empty CUs in the second (a 3 x 3 conv of 32 channels: 3 tiles x 256 splits = 768 workgroups on 512 slots): take the
@@ -1522,7 +1547,7 @@ static int wgrad_impl(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int
         static int cus_dev[64] = {};
         int& cus = cus_dev[ctx->device & 63];
         if (!cus && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess) cus = 256;
-        const long long slots = 2LL * cus;
+        const long long slots = (x3 ? 1LL : 2LL) * cus;
         const long long tiles128 = (long long)((K + 127) / 128) * ((d->Cout + 127) / 128);
         const long long W = tiles128 * S;
         if (W > slots) {
@@ -1568,7 +1593,7 @@ static int wgrad_impl(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int
         // kernel (2-D taps too: the 32- / 64-channel convs of ResNetSE / ERes2Net / the FCM head) is built but NOT dispatched: measured
         // slower than the square tile there (ResNetSE step 22.7 -> 23.8 ms, ERes2Net 31.4 -> 33.9 ms, CAM++ 30.1 -> 31.8 ms;
         // VPMI_WGRAD_NARROW_F32=1 dispatches it for study)
-        if (d->Cout <= 64 && K > 128 && ((bf_in && !two_d && d->stride == 1) || (!bf_in && getenv_once("VPMI_WGRAD_NARROW_F32")))) {
+        if (!x3 && d->Cout <= 64 && K > 128 && ((bf_in && !two_d && d->stride == 1) || (!bf_in && getenv_once("VPMI_WGRAD_NARROW_F32")))) {
             constexpr int smem64 = 2 * (64 + 256) * 128;
             static bool attr64_dev[64] = {};
             bool& attr64 = attr64_dev[ctx->device & 63];
@@ -1581,7 +1606,15 @@ static int wgrad_impl(vp_ctx* ctx, const vp_conv1d_desc* d, const float* dz, int
             if (bf_in) hipLaunchKernelGGL(conv_wgrad_n64_kernel<true>, g64, dim3(256), smem64, st, a);
             else hipLaunchKernelGGL(conv_wgrad_n64_kernel<false>, g64, dim3(256), smem64, st, a);
         } else if (bf_in) hipLaunchKernelGGL(conv_wgrad_amp_kernel<true>, grid, dim3(256), smem, st, a);
-        else hipLaunchKernelGGL(conv_wgrad_amp_kernel<false>, grid, dim3(256), smem, st, a);
+        else if (x3) {
+            static bool attr3_dev[64] = {};
+            bool& attr3 = attr3_dev[ctx->device & 63];
+            if (!attr3) {
+                VP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_amp_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * smem));
+                attr3 = true;
+            }
+            hipLaunchKernelGGL((conv_wgrad_amp_kernel<false, true>), grid, dim3(256), 2 * smem, st, a);
+        } else hipLaunchKernelGGL(conv_wgrad_amp_kernel<false>, grid, dim3(256), smem, st, a);
     } else {
         hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tk, tn, S), dim3(256), 0, st, a);
     }

@@ -72,6 +72,22 @@ def get_train_amp():
     return _TRAIN_AMP
 
 
+_TRAIN_X3 = False
+
+
+def set_train_x3(on):
+    """Split-precision training (no reference counterpart; off by default): tensors, statistics, gradients and master weights stay f32
+    exactly as in the default (exact-f32) step, but the convolution GEMMs of the step -- forward, data gradient, weight gradient -- carry
+    each f32 operand as bf16 hi + lo and contract hi*hi + hi*lo + lo*hi on the bf16 matrix cores with f32 accumulation (~2^-17 per product):
+    f32-grade gradients at a multiple of the f32 matrix-core rate.  Ignored while enable_amp (set_train_amp) is on."""
+    global _TRAIN_X3
+    _TRAIN_X3 = bool(on)
+
+
+def get_train_x3():
+    return _TRAIN_X3 and not _TRAIN_AMP
+
+
 _FUSED_GRID_KERNELS = True
 
 

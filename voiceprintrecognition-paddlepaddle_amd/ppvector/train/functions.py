@@ -76,7 +76,8 @@ def _conv_desc(x, B, T_in, T_out, Cin, Cout, KW, dil, pad_mode, pad_left, w, bia
         d.rowbias = rowbias.data_ptr()
     d.act = N.VP_ACT_RELU if relu else N.VP_ACT_NONE
     d.ldy = Cout
-    d.mfma_bf16 = int(ppvector.get_train_amp())          # enable_amp: bf16 matrix cores over f32 tensors (forward, dgrad and wgrad)
+    # enable_amp: bf16 matrix cores over f32 tensors (forward, dgrad and wgrad); set_train_x3: the same three GEMMs in split precision
+    d.mfma_bf16 = 1 if ppvector.get_train_amp() else (2 if ppvector.get_train_x3() else 0)
     return d
 
 

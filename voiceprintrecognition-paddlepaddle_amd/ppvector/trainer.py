@@ -209,6 +209,9 @@ class PPVectorTrainer(object):
             # enable_amp (trainer.py:209-229: auto_cast O1 + GradScaler): conv GEMMs on the bf16 matrix cores over f32 tensors;
             # bf16 keeps f32's exponent range, so there is no loss scale to maintain (amp_scaler stays None)
             ppvector.set_train_amp(bool(self.configs.train_conf.get('enable_amp', False)))
+            # an extension key (absent from the reference's YAMLs = off): the f32 step with its conv GEMMs in split precision
+            # (ppvector.set_train_x3); ignored under enable_amp
+            ppvector.set_train_x3(bool(self.configs.train_conf.get('split_precision', False)))
             num_class = self.configs.model_conf.classifier.num_speakers
             spd = self.data_augment_configs.get('speed') if self.data_augment_configs is not None else None
             if spd is not None and spd.get('prob', 0.0) > 0 and spd.get('speed_perturb_3_class', False):
