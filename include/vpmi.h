@@ -254,7 +254,7 @@ typedef struct {
 } vp_asp_weights;
 
 typedef struct {
-    int dtype;                /* VP_F32 | VP_BF16 */
+    int dtype;                /* VP_F32 | VP_F32X3 (f32 tensors, split-precision contractions) | VP_BF16 */
     int feat_dim, embd_dim, n_blocks, res2_scale, se_ch;
     vp_tdnn_layer block0;
     vp_se_res2_block blk[VP_MAX_SE_BLOCKS];
@@ -312,7 +312,7 @@ int vp_ecapa_fwd(vp_ctx* ctx, const vp_ecapa_weights* w, const void* feats, int 
                  void* ws, size_t ws_bytes, vp_stream stream);
 
 typedef struct {
-    int dtype;
+    int dtype;                /* VP_F32 | VP_F32X3 | VP_BF16 (as vp_ecapa_weights) */
     int feat_dim, embd_dim, channels;
     vp_tdnn_layer td[5];      /* un-padded convs, ReLU then BN (td[4]: no BN) */
     vp_asp_weights asp;
@@ -357,7 +357,7 @@ typedef struct {
 } vp_transit;
 
 typedef struct {
-    int dtype;
+    int dtype;                /* VP_F32 | VP_F32X3 | VP_BF16 (as vp_ecapa_weights) */
     int feat_dim, embd_dim, m_channels, init_channels, growth, bn_channels, seg_len;
     int n_blocks;
     int block_layers[VP_MAX_CAM_BLOCKS];
@@ -446,7 +446,7 @@ typedef struct {
 } vp_rse_block;
 
 typedef struct {
-    int dtype;
+    int dtype;                /* VP_F32 | VP_F32X3 | VP_BF16 (as vp_ecapa_weights) */
     int feat_dim, embd_dim, n_blocks, c1_channels;
     const float* c1_w;        /* [32][9] f32, tap = kt*3 + kf */
     const float* c1_b;
@@ -488,7 +488,7 @@ typedef struct {
 } vp_ere_block;
 
 typedef struct {
-    int dtype;
+    int dtype;                /* VP_F32 | VP_F32X3 | VP_BF16 (as vp_ecapa_weights) */
     int feat_dim, embd_dim, n_blocks, m_channels;
     int stage_blocks[4];
     int first_fuse;           /* 0: ERes2Net (three bottom-up fusions, down / fuse [0..2]); 2: ERes2NetV2 (layer3_ds + fuse34 only, slot 2) */

@@ -9,6 +9,9 @@
 // copies, torch.chunk / concat copies (slices of one (B*T, n*C) buffer are addressed in place),
 // the x_i + y_{i-1} temporaries' extra pass (written by the producing conv), the (B, 3C, T)
 // global-context concat of ASP (its mean/std columns collapse to a per-utterance bias).
+// Three arithmetic modes per backbone (`dtype` of the weights struct): VP_F32 exact f32 matrix cores; VP_BF16 bf16 tensors with the fused
+// bf16 kernels; VP_F32X3 split precision -- f32 tensors on the generic kernels, or, for ECAPA with split weights present, tensors as
+// split bf16 planes on the LDS-DMA ring / fused hl32 kernels (ecapa_fwd_hl below).
 #include "common.h"
 
 #include <stdlib.h>
