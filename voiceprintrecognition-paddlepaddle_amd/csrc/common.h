@@ -151,7 +151,7 @@ int vp_res2_chain_bf16(vp_ctx* ctx, const vp_tdnn_layer* layers, int nconv, cons
                        int C, int width, hipStream_t st);
 int vp_res2_chain_x3(vp_ctx* ctx, const vp_tdnn_layer* layers, int nconv, const void* t1, void* r2, int B, int T, int C, int width,
                      hipStream_t st);
-bool vp_res2_chain_x3_ok(const vp_tdnn_layer* layers, int nconv, int T, int C, int width);
+bool vp_res2_chain_x3_ok(const vp_tdnn_layer* layers, int nconv, int B, int T, int C, int width);
 int vp_asp_fused_x3(vp_ctx* ctx, const void* h, const float* w, const float* bias, const void* x, int ldx, const float* center, int ldc,
                     int B, int T, int C, int att, float eps, float* pooled, hipStream_t st);
 int vp_asp_fused_bf16(vp_ctx* ctx, const void* h, const void* w, const float* bias, const void* x, int ldx,

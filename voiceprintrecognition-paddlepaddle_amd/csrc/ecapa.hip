@@ -164,7 +164,7 @@ bool ecapa_hl_ok(const vp_ecapa_weights* w, int B, int T) {
         return false;
     for (int i = 0; i < w->n_blocks; ++i) {
         const vp_se_res2_block& b = w->blk[i];
-        if (!b.tdnn1.w_hl || !b.tdnn2.w_hl || !vp_res2_chain_x3_ok(b.res2, sc - 1, T, C, C / sc)) return false;
+        if (!b.tdnn1.w_hl || !b.tdnn2.w_hl || !vp_res2_chain_x3_ok(b.res2, sc - 1, B, T, C, C / sc)) return false;
     }
     return true;
 }

@@ -238,8 +238,10 @@ void rx_plan(int T, int H, int& nsplit, int& Tseg, int& TP) {
 }  // namespace
 
 // would vp_res2_chain_x3 take this chain?  (the ECAPA driver decides on its fast path before the first launch)
-bool vp_res2_chain_x3_ok(const vp_tdnn_layer* layers, int nconv, int T, int C, int width) {
-    if (width != RX_W || nconv < 1 || nconv > VP_MAX_RES2 || T < 2 || C % 32) return false;
+bool vp_res2_chain_x3_ok(const vp_tdnn_layer* layers, int nconv, int B, int T, int C, int width) {
+    if (width != RX_W || nconv < 1 || nconv > VP_MAX_RES2 || T < 2 || C % 32 || B < 1 || B > 65535 ||
+        (unsigned long long)B * T * C * 4 >= 0xffffff00ull)
+        return false;                                               // (32-bit buffer offsets into t1)
     const int dil = layers[0].dil;
     for (int j = 0; j < nconv; ++j) {
         const vp_tdnn_layer& L = layers[j];
