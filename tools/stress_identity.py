@@ -18,7 +18,7 @@ dev = torch.device('cuda', 0)
 fz, model, head, _, _ = bench.build_ecapa(dev, 'bfloat16')
 model.eval()
 wav = torch.from_numpy(bench.synth_waves(256, 48000, seed=5)).to(dev)
-for dt in ('bfloat16', 'float32'):
+for dt in ('bfloat16', 'float32x3', 'float32'):
     eng = model.engine(dt)
     w16 = dt == 'bfloat16'
     ref = eng.forward(fz(wav, want_bf16=w16)).clone()
