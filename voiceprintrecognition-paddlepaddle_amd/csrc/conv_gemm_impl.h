@@ -278,6 +278,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
                  : X3  ? ((((cc >> 1) ^ (r0 & 7)) << 4) + (cc & 1) * 8)
                        : ((cc ^ (r0 & 7)) << 4);
     [[maybe_unused]] const int pw_lo = (((4 + (cc >> 1)) ^ (r0 & 7)) << 4) + (cc & 1) * 8;
+    // x3: an 8-byte LDS write retires 16 lanes (= two tile rows of 8 chunks) per cycle onto 32 banks = 128 bytes.  The hi halves of rows r
+    // and r + 1 sit in the SAME 64-byte half of their 128-byte rows (the swizzle moves a row's hi plane to the other half only with bit 2
+    // of r): a 2-way conflict on every write (measured: SQ_LDS_BANK_CONFLICT 0.30-0.33 of the LDS cycles, the two write planes 120 of 366 us
+    // on a 512 x 1536 x 76288 layer).  Odd rows therefore write their LO plane first and their HI plane second: each 16-lane group then
+    // covers all 32 banks once.
+    [[maybe_unused]] const bool x3_swap = (r0 & 1) != 0;
+    [[maybe_unused]] const int pw_a = x3_swap ? pw_lo : pw, pw_b = x3_swap ? pw : pw_lo;
     const bool zero_pad = a.pad_mode == VP_PAD_ZERO;
     const unsigned ldxb = (unsigned)a.ldx * ES;
     // per staged row: rowoff = byte offset of (utterance b, frame 0 [, freq 0]); tpos / fpos = the
@@ -392,8 +399,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
             else if constexpr (X3) {
                 uint2 hi, lo;
                 x3_split(v, hi, lo);
-                *reinterpret_cast<uint2*>(As + (r0 + 32 * i) * RB + pw) = hi;
-                *reinterpret_cast<uint2*>(As + (r0 + 32 * i) * RB + pw_lo) = lo;
+                *reinterpret_cast<uint2*>(As + (r0 + 32 * i) * RB + pw_a) = x3_swap ? lo : hi;
+                *reinterpret_cast<uint2*>(As + (r0 + 32 * i) * RB + pw_b) = x3_swap ? hi : lo;
             } else *reinterpret_cast<u32x4*>(As + (r0 + 32 * i) * RB + pw) = v;
         }
 #pragma unroll
@@ -402,8 +409,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
             else if constexpr (X3) {
                 uint2 hi, lo;
                 x3_split(rb[i], hi, lo);
-                *reinterpret_cast<uint2*>(Bs + (r0 + 32 * i) * RB + pw) = hi;
-                *reinterpret_cast<uint2*>(Bs + (r0 + 32 * i) * RB + pw_lo) = lo;
+                *reinterpret_cast<uint2*>(Bs + (r0 + 32 * i) * RB + pw_a) = x3_swap ? lo : hi;
+                *reinterpret_cast<uint2*>(Bs + (r0 + 32 * i) * RB + pw_b) = x3_swap ? hi : lo;
             } else *reinterpret_cast<u32x4*>(Bs + (r0 + 32 * i) * RB + pw) = rb[i];
         }
     };
