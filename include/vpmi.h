@@ -169,7 +169,9 @@ typedef struct {
                                             and run the bf16 matrix cores (f32 accumulate, f32 out); 2 = split precision: x and w
                                             each become bf16 hi + lo while staging, hi*hi + hi*lo + lo*hi on the bf16 matrix cores
                                             (~2^-16 relative per product: the reference's 1e-4 score tolerance at 1/3 of the
-                                            bf16 rate = 5.3x the exact-f32 rate)                                          */
+                                            bf16 rate = 5.3x the exact-f32 rate); 3 = as 2, with `w` ALREADY split: split bf16
+                                            planes (VP_HL32) [Cout][Kw], Kw = KW*Cin rounded up to a multiple of 32 with zero
+                                            columns (vp_tdnn_layer.w_hl) -- only x is split while staging                 */
 } vp_conv1d_desc;
 
 int vp_conv1d_tiles_m(int B, int T_out);            /* rows of the psum arrays                     */

@@ -268,7 +268,8 @@ void conv2d_desc(vp_conv1d_desc& d, const vp_tdnn_layer& L, int dt, int B, int T
     d.pad_left = L.kw == 9 ? 1 : 0; d.pad_f = L.kw == 9 ? 1 : 0; d.pad_mode = VP_PAD_ZERO;
     d.F_in = F_in; d.F_out = F_out; d.stride_f = stride_f;
     d.ldx = L.cin; d.ldy = L.cout;
-    d.w = L.w; d.bias = L.bias; d.bn_scale = L.bn_scale; d.bn_shift = L.bn_shift;
+    vp_desc_weights(d, L);
+    d.bias = L.bias; d.bn_scale = L.bn_scale; d.bn_shift = L.bn_shift;
 }
 
 }  // namespace
@@ -429,7 +430,7 @@ int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats
     memset(&d, 0, sizeof(d));
     vp_desc_dtype(d, dtc); d.B = B; d.T_in = T; d.T_out = Tn; d.Cin = Cf; d.Cout = w->tdnn.cout;
     d.KW = w->tdnn.kw; d.dilation = 1; d.stride = 2; d.pad_left = (w->tdnn.kw - 1) / 2; d.pad_mode = VP_PAD_ZERO;
-    d.x = t1; d.ldx = Cf; d.w = w->tdnn.w; d.bias = w->tdnn.bias; d.bn_scale = w->tdnn.bn_scale; d.bn_shift = w->tdnn.bn_shift;
+    d.x = t1; d.ldx = Cf; vp_desc_weights(d, w->tdnn); d.bias = w->tdnn.bias; d.bn_scale = w->tdnn.bn_scale; d.bn_shift = w->tdnn.bn_shift;
     d.act2 = VP_ACT_RELU; d.y = p.cat[0]; d.ldy = ld;
     if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
 
@@ -450,7 +451,7 @@ int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats
             memset(&d, 0, sizeof(d));
             vp_desc_dtype(d, dtc); d.B = B; d.T_in = Tn; d.T_out = Tn; d.Cin = ch; d.Cout = bnc; d.KW = 1;
             d.dilation = 1; d.stride = 1; d.pad_mode = VP_PAD_ZERO;
-            d.x = cat; d.ldx = ld; d.w = L.linear1.w; d.bias = L.linear1.bias; d.pro_scale = L.bn1_scale; d.pro_shift = L.bn1_shift;
+            d.x = cat; d.ldx = ld; vp_desc_weights(d, L.linear1); d.bias = L.linear1.bias; d.pro_scale = L.bn1_scale; d.pro_shift = L.bn1_shift;
             d.bn_scale = L.linear1.bn_scale; d.bn_shift = L.linear1.bn_shift; d.act2 = VP_ACT_RELU; d.y = p.h2; d.ldy = bnc;
             if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
             // context gate m = sigmoid(W2 relu(W1 (mean + segmean) + b1) + b2), one row per (utterance, segment)
@@ -478,7 +479,7 @@ int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats
             memset(&d, 0, sizeof(d));
             vp_desc_dtype(d, dtc); d.B = B; d.T_in = Tn; d.T_out = Tn; d.Cin = bnc; d.Cout = gr;
             d.KW = L.local.kw; d.dilation = L.local.dil; d.stride = 1; d.pad_left = L.local.dil * (L.local.kw - 1) / 2;
-            d.pad_mode = VP_PAD_ZERO; d.x = p.h2; d.ldx = bnc; d.w = L.local.w; d.bias = L.local.bias;
+            d.pad_mode = VP_PAD_ZERO; d.x = p.h2; d.ldx = bnc; vp_desc_weights(d, L.local); d.bias = L.local.bias;
             d.gate = p.gate; d.gate_len = w->seg_len; d.gate_nseg = nseg; d.y = cat; d.ldy = ld; d.yoff = ch;
             if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
             ch += gr;
@@ -487,7 +488,7 @@ int vp_campplus_fwd(vp_ctx* ctx, const vp_campplus_weights* w, const void* feats
         const vp_transit& Tr = w->transit[b];
         memset(&d, 0, sizeof(d));
         vp_desc_dtype(d, dtc); d.B = B; d.T_in = Tn; d.T_out = Tn; d.Cin = ch; d.Cout = ch / 2; d.KW = 1;
-        d.dilation = 1; d.stride = 1; d.pad_mode = VP_PAD_ZERO; d.x = cat; d.ldx = ld; d.w = Tr.linear.w; d.bias = Tr.linear.bias;
+        d.dilation = 1; d.stride = 1; d.pad_mode = VP_PAD_ZERO; d.x = cat; d.ldx = ld; vp_desc_weights(d, Tr.linear); d.bias = Tr.linear.bias;
         d.pro_scale = Tr.bn_scale; d.pro_shift = Tr.bn_shift; d.y = p.cat[cb ^ 1]; d.ldy = ld;
         if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;
         cb ^= 1;

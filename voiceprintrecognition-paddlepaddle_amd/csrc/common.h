@@ -115,6 +115,12 @@ static inline void vp_desc_dtype(vp_conv1d_desc& d, int dt) {
     d.dtype_in = d.dtype_out = vp_storage_dtype(dt);
     d.mfma_bf16 = dt == VP_F32X3 ? 2 : 0;
 }
+// weights of a layer for a conv descriptor whose dtype fields are set: a split-precision backbone (VP_F32X3) hands over the layer's
+// pre-split weights when it has them (only the activations are then split while staging)
+static inline void vp_desc_weights(vp_conv1d_desc& d, const vp_tdnn_layer& L) {
+    d.w = L.w;
+    if (d.mfma_bf16 == 2 && d.dtype_in == VP_F32 && d.dtype_out == VP_F32 && L.w_hl) { d.w = L.w_hl; d.mfma_bf16 = 3; }
+}
 
 // M-tile of the conv GEMM: the partial time-sum arrays are indexed by it
 #define VP_CONV_BM 128

@@ -29,6 +29,7 @@ int vp_conv_launch_bf16_f32(vp_ctx* ctx, const void* args, int bn, int mode, hip
 int vp_conv_launch_f32_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
 int vp_conv_launch_amp_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
 int vp_conv_launch_x3_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
+int vp_conv_launch_x3w_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
 int vp_conv_launch_x3_hl(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
 int vp_conv_launch_hl_hl(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st);
 int vp_conv_launch_ring_x3(vp_ctx* ctx, const void* args, int out_f32, hipStream_t st);
@@ -120,7 +121,9 @@ int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream) {
     if (Mll > 0x7fffffffLL / 2) VP_FAIL(ctx, VP_EINVAL, "conv1d: too many output positions");
     const size_t es = d->dtype_in == VP_BF16 ? 2 : 4;
     const unsigned long long xbytes = ((unsigned long long)d->B * d->T_in * F_in - 1) * d->ldx * es + (d->xoff + d->Cin) * es;
-    const unsigned long long wbytes = (unsigned long long)d->Cout * d->KW * d->Cin * es;
+    // (mfma_bf16 = 3: the weights are split bf16 planes whose rows are zero-padded to whole 32-element groups)
+    const unsigned long long wrow = d->mfma_bf16 == 3 ? ((unsigned long long)d->KW * d->Cin + 31) / 32 * 32 : (unsigned long long)d->KW * d->Cin;
+    const unsigned long long wbytes = (unsigned long long)d->Cout * wrow * es;
     if (wbytes >= 0xffffff00ull) VP_FAIL(ctx, VP_EUNSUP, "conv1d: weights larger than 4 GiB (32-bit buffer offsets)");
     if (xbytes >= 0xffffff00ull) {
         // The kernels address x through a 32-bit buffer offset.  Utterances are independent rows of the GEMM, so a larger activation
@@ -166,7 +169,7 @@ int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream) {
     a.ldx = d->ldx; a.xoff = d->xoff; a.ldy2 = d->ldy2; a.y2off = d->y2off; a.ysplit = d->ysplit;
     a.ldy = d->ldy; a.yoff = d->yoff; a.ld_add = d->ld_add; a.add_off = d->add_off; a.ld_aux = d->ld_aux;
     a.aux_off = d->aux_off; a.ld_res = d->ld_res; a.res_off = d->res_off;
-    a.M = (int)Mll; a.N = d->Cout; a.K = d->KW * d->Cin; a.cpt = d->Cin / epc; a.KC = a.K / epc; a.Cin = d->Cin;
+    a.M = (int)Mll; a.N = d->Cout; a.K = d->KW * d->Cin; a.Kw = a.K; a.cpt = d->Cin / epc; a.KC = a.K / epc; a.Cin = d->Cin;
     a.KT = (a.KC + 7) / 8;
     a.T_in = d->T_in; a.T_out = d->T_out; a.dilation = d->dilation; a.stride = d->stride; a.pad_left = d->pad_left;
     a.pad_mode = d->pad_mode; a.act = d->act; a.act2 = d->act2;
@@ -240,6 +243,11 @@ int vp_conv1d_fwd(vp_ctx* ctx, const vp_conv1d_desc* d, vp_stream stream) {
     if (hl_out) return vp_conv_launch_x3_hl(ctx, &a, bn, mode, st);
     if (d->dtype_in == VP_BF16 && d->dtype_out == VP_BF16) return vp_conv_launch_bf16_bf16(ctx, &a, bn, mode, st);
     if (d->dtype_in == VP_BF16 && d->dtype_out == VP_F32) return vp_conv_launch_bf16_f32(ctx, &a, bn, mode, st);
+    if (d->mfma_bf16 == 3) {                 // split precision with the weights given as split planes, rows padded to 32-element groups
+        if (d->dtype_in != VP_F32 || d->dtype_out != VP_F32) VP_FAIL(ctx, VP_EINVAL, "conv1d: mfma_bf16 = 3 takes f32 tensors");
+        a.Kw = (int)wrow;
+        return vp_conv_launch_x3w_f32(ctx, &a, bn, mode, st);
+    }
     if (d->mfma_bf16 == 2) return vp_conv_launch_x3_f32(ctx, &a, bn, mode, st);
     if (d->mfma_bf16) return vp_conv_launch_amp_f32(ctx, &a, bn, mode, st);
     return vp_conv_launch_f32_f32(ctx, &a, bn, mode, st);

@@ -27,6 +27,7 @@ struct ConvArgs {
     unsigned x_bytes, w_bytes;
     int ldx, xoff, ldy, yoff, ldy2, y2off, ysplit, ld_add, add_off, ld_aux, aux_off, ld_res, res_off;
     int M, N, K, KC, cpt, KT, Cin;
+    int Kw;                 // elements per WEIGHT row (= K, or K rounded up to a multiple of 32 for weights given as split bf16 planes: x3w_t)
     int T_in, T_out, dilation, stride, pad_left, pad_mode, act, act2;
     int F_in, F_out, KF, stride_f, pad_f;
     int gate_len, gate_nseg;
@@ -52,12 +53,17 @@ struct x3_t { float v; };
 // what an hl_t operand already has in memory (no split arithmetic in the consumer, LDS-DMA-able: conv_gemm256.hip).  Producers split
 // once per output element in their epilogue.  As an OUTPUT type the epilogue stores hi / lo halves instead of f32 words.
 struct hl_t { float v; };
+// x3w_t: x3_t whose WEIGHTS arrive already split (hl32 planes, [Cout][Kw], Kw = K rounded up to a multiple of 32 with zero columns:
+// vp_tdnn_layer.w_hl) -- the activations are split while staging, the weight chunks are copied as they are.  Halves the split arithmetic
+// and the 8-byte LDS writes of a stage (the staging of x3_t is VALU-bound: ablation in profiles/r06_x3_staging_ablation.log).
+struct x3w_t { float v; };
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { bf16x8 v; };
 template <> struct Frag<float> { float4 lo, hi; };
 template <> struct Frag<amp_t> { bf16x8 v; };
 template <> struct Frag<x3_t> { bf16x8 hi, lo; };
 template <> struct Frag<hl_t> { bf16x8 hi, lo; };
+template <> struct Frag<x3w_t> { bf16x8 hi, lo; };
 constexpr int ROWB_AMP = 64;
 // 64-byte rows: the ds_read_b128 lane groups ({0-3,12-15,20-27}, ...) are conflict-free with the 16-B chunk g stored at
 // position g ^ ((-(row >> 2)) & 3)
@@ -79,6 +85,10 @@ __device__ __forceinline__ void load_frag(const char* tile, int row, int /*ks*/,
     f.hi = *reinterpret_cast<const bf16x8*>(tile + row * ROWB + ((g ^ (row & 7)) << 4));
     f.lo = *reinterpret_cast<const bf16x8*>(tile + row * ROWB + (((4 + g) ^ (row & 7)) << 4));
 }
+__device__ __forceinline__ void load_frag(const char* tile, int row, int /*ks*/, int g, Frag<x3w_t>& f) {
+    f.hi = *reinterpret_cast<const bf16x8*>(tile + row * ROWB + ((g ^ (row & 7)) << 4));
+    f.lo = *reinterpret_cast<const bf16x8*>(tile + row * ROWB + (((4 + g) ^ (row & 7)) << 4));
+}
 __device__ __forceinline__ void load_frag(const char* tile, int row, int /*ks*/, int g, Frag<hl_t>& f) {
     f.hi = *reinterpret_cast<const bf16x8*>(tile + row * ROWB + ((g ^ (row & 7)) << 4));
     f.lo = *reinterpret_cast<const bf16x8*>(tile + row * ROWB + (((4 + g) ^ (row & 7)) << 4));
@@ -93,6 +103,11 @@ __device__ __forceinline__ void mma(const Frag<amp_t>& w, const Frag<amp_t>& x, 
 }
 __device__ __forceinline__ void mma(const Frag<x3_t>& w, const Frag<x3_t>& x, f32x4& c) {
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.lo, x.hi, c, 0, 0, 0);      // the two cross terms, then the leading one
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.hi, x.lo, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.hi, x.hi, c, 0, 0, 0);
+}
+__device__ __forceinline__ void mma(const Frag<x3w_t>& w, const Frag<x3w_t>& x, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.lo, x.hi, c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.hi, x.lo, c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.hi, x.hi, c, 0, 0, 0);
 }
@@ -197,6 +212,7 @@ __device__ __forceinline__ u32x4 prologue_chunk(u32x4 v, const float (&s)[8], co
     return prologue_chunk(v, s, h, float{});
 }
 __device__ __forceinline__ u32x4 prologue_chunk(u32x4 v, const float (&)[8], const float (&)[8], hl_t) { return v; }   // (never dispatched)
+__device__ __forceinline__ u32x4 prologue_chunk(u32x4 v, const float (&s)[8], const float (&h)[8], x3w_t) { return prologue_chunk(v, s, h, float{}); }
 // four f32 -> their bf16 hi terms and bf16 lo terms (x = hi + lo up to 2^-16 relative), 8 bytes each
 __device__ __forceinline__ void x3_split(u32x4 v, uint2& hi, uint2& lo) {
     unsigned short h[4], l[4];
@@ -233,7 +249,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
     constexpr int WCOLS = NI * 16;
     constexpr int BROWS = BN / 32;
     constexpr bool AMP = std::is_same<TI, amp_t>::value;
-    constexpr bool X3 = std::is_same<TI, x3_t>::value;
+    constexpr bool WHL = std::is_same<TI, x3w_t>::value;           // weights given as split planes: copied, not split
+    constexpr bool X3 = std::is_same<TI, x3_t>::value || WHL;
     constexpr int RB = AMP ? ROWB_AMP : ROWB;            // bytes per tile row per stage in LDS
     constexpr int STAGE = (BM + BN) * RB;
     constexpr bool PRO = MODE == MODE_1X1_PRO;
@@ -319,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) {
         const int n = n0 + r0 + 32 * i;
-        woff[i] = n < a.N ? (unsigned)n * (unsigned)a.K * ES : OOB;
+        woff[i] = n < a.N ? (unsigned)n * (unsigned)a.Kw * ES : OOB;
     }
 
     // TWO register stages: the loads of K-stage k+2 are issued while stage k is computed and are
@@ -376,9 +393,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
                 ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrd, ok ? off : OOB, 0, 0);
             }
         }
+        const bool kvw = WHL ? q * EPC < a.Kw : kv;                 // (split-plane weight rows are zero-padded to whole 32-element groups)
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) {
-            const bool ok = kv && woff[i] != OOB;
+            const bool ok = kvw && woff[i] != OOB;
             rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wsrd, ok ? woff[i] + kb : OOB, 0, 0);
         }
     };
@@ -406,6 +424,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) {
             if constexpr (AMP) *reinterpret_cast<uint2*>(Bs + (r0 + 32 * i) * RB + pw) = amp_pack(rb[i]);
+            else if constexpr (WHL) *reinterpret_cast<u32x4*>(Bs + (r0 + 32 * i) * RB + ((cc ^ (r0 & 7)) << 4)) = rb[i];
             else if constexpr (X3) {
                 uint2 hi, lo;
                 x3_split(rb[i], hi, lo);

@@ -6,6 +6,11 @@ int vp_conv_launch_x3_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipSt
     return dispatch_conv<x3_t, float, true>(ctx, *static_cast<const ConvArgs*>(args), bn, mode, st);
 }
 
+// f32 activations split while staging, weights already split (hl32 planes, rows zero-padded to 32-element groups): mfma_bf16 = 3
+int vp_conv_launch_x3w_f32(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st) {
+    return dispatch_conv<x3w_t, float, true>(ctx, *static_cast<const ConvArgs*>(args), bn, mode, st);
+}
+
 // hl32 tensors (split bf16 planes in memory, conv_gemm_impl.h: hl_t): the layers of the ECAPA split-precision fast path that are not on
 // the LDS-DMA ring kernel -- blocks[0] (f32 features in, hl32 out) and the ASP attention TDNN (hl32 in, hl32 out).  128-column tiles only.
 int vp_conv_launch_x3_hl(vp_ctx* ctx, const void* args, int bn, int mode, hipStream_t st) {

@@ -35,7 +35,8 @@ void tdnn_desc(vp_conv1d_desc& d, const vp_tdnn_layer& L, int dtype, int B, int 
     d.Cin = L.cin; d.Cout = L.cout; d.KW = L.kw; d.dilation = L.dil; d.stride = 1;
     d.pad_mode = pad_mode;
     d.pad_left = pad_mode == VP_PAD_NONE ? 0 : L.dil * (L.kw - 1) / 2;
-    d.w = L.w; d.bias = L.bias; d.act = VP_ACT_RELU; d.bn_scale = L.bn_scale; d.bn_shift = L.bn_shift;
+    vp_desc_weights(d, L);
+    d.bias = L.bias; d.act = VP_ACT_RELU; d.bn_scale = L.bn_scale; d.bn_shift = L.bn_shift;
 }
 
 
@@ -191,7 +192,7 @@ int ecapa_fwd_hl(vp_ctx* ctx, const vp_ecapa_weights* w, const void* feats, int 
         d.x = p.im; d.ldx = Kp0; d.y = p.cat0; d.ldy = C;
     } else {
         tdnn_desc(d, w->block0, VP_F32X3, B, T, T, VP_PAD_REFLECT);
-        d.dtype_out = VP_HL32;
+        d.dtype_out = VP_HL32; d.w = w->block0.w; d.mfma_bf16 = 2;          // (f32 weights, split while staging: the hl32-output kernel's form)
         d.x = feats; d.ldx = w->feat_dim; d.y = p.cat0; d.ldy = C;
     }
     if ((rc = vp_conv1d_fwd(ctx, &d, st))) return rc;

@@ -85,7 +85,8 @@ void conv_desc(vp_conv1d_desc& d, const vp_tdnn_layer& L, int dt) {
     memset(&d, 0, sizeof(d));
     vp_desc_dtype(d, dt); d.Cin = L.cin; d.Cout = L.cout; d.KW = L.kw; d.dilation = 1; d.stride = 1;
     d.pad_mode = VP_PAD_ZERO; d.ldx = L.cin; d.ldy = L.cout;
-    d.w = L.w; d.bias = L.bias; d.bn_scale = L.bn_scale; d.bn_shift = L.bn_shift;
+    vp_desc_weights(d, L);
+    d.bias = L.bias; d.bn_scale = L.bn_scale; d.bn_shift = L.bn_shift;
 }
 
 // x (B, t, f, .) -> 2-D conv geometry on d (3x3 pad 1 or 1x1, stride s on both axes)

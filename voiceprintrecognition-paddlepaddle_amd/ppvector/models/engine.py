@@ -53,7 +53,12 @@ class _Engine:
             sc, sh = bn.folded()
             L.bn_scale, L.bn_shift = self._p(sc), self._p(sh)
         L.cin, L.cout, L.kw, L.dil = (w.shape[1] // kw), cout, kw, dil
-        if self.dtype_name == 'float32x3':      # split bf16 planes of the same weights ([cout][K rounded up to 32], zero columns): the hl32 fast path
+        self.split_weights(L, w)
+
+    def split_weights(self, L, w):
+        """'float32x3': the same [cout][K] weights as split bf16 planes, K zero-padded to a multiple of 32 (vp_tdnn_layer.w_hl) -- the conv
+        kernels then split only the activations while staging, and ECAPA's fast path streams them by LDS-DMA."""
+        if self.dtype_name == 'float32x3':
             kp = (w.shape[1] + 31) // 32 * 32
             L.w_hl = self._p(pack_hl32(torch.nn.functional.pad(w.float(), (0, kp - w.shape[1]))))
 
@@ -199,6 +204,7 @@ class CamppEngine(_Engine):
 
     def conv_layer(self, L, conv, bn, kw_taps, w_packed, dil=1):
         L.w = self._p(w_packed)
+        self.split_weights(L, w_packed)
         L.bias = self._p(f32(conv.bias))
         if bn is not None:
             sc, sh = bn.folded()
@@ -371,6 +377,7 @@ class Eres2netEngine(CamppEngine):
         wpad[out_map.to(w.device)[:, None], in_map.to(w.device)[None, :]] = w
         packed = wpad.permute(0, 3, 2, 1).reshape(cout_p, kt * kf * cin_p).to(self.tdtype).contiguous()
         L.w = self._p(packed)
+        self.split_weights(L, packed)
         bias = torch.zeros(cout_p, dtype=torch.float32, device=w.device)
         bias[out_map.to(w.device)] = conv.bias.detach().float()
         L.bias = self._p(bias)
