@@ -580,9 +580,10 @@ def run_infer(args, rank, local_rank, world, dist):
             a32.train_x3 = 0
             dp_f32 = run_train(a32, rank, local_rank, world, dist, steps=max(4, args.train_steps // 3), warmup=3, emit=False)
             # ... and the same f32 tensors with the three conv GEMMs in split precision (f32-grade gradients on the bf16 matrix cores)
-            ax3 = argparse.Namespace(**vars(args))
-            ax3.amp, ax3.train_x3 = 0, 1
-            dp_x3 = run_train(ax3, rank, local_rank, world, dist, steps=max(4, args.train_steps // 2), warmup=3, emit=False)
+            if world == 1:                 # (a side measurement: not worth another round of collectives under the multi-rank watchdog)
+                ax3 = argparse.Namespace(**vars(args))
+                ax3.amp, ax3.train_x3 = 0, 1
+                dp_x3 = run_train(ax3, rank, local_rank, world, dist, steps=max(4, args.train_steps // 2), warmup=3, emit=False)
         except Exception as e:             # noqa: BLE001 -- anything here must not cost the headline line
             dp_err = f'{type(e).__name__}: {e}'[:300]
         if dog is not None:
