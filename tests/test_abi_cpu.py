@@ -41,6 +41,36 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(N.AspWeights) == C.sizeof(N.TdnnLayer) + 3 * 8 + 8
 
 
+def test_hl32_packing_matches_the_header_definition():
+    """VP_HL32 (include/vpmi.h): a row of C channels = C / 32 groups of 128 bytes, each [32 x bf16 hi | 32 x bf16 lo], hi = bf16(v) round
+    to nearest even, lo = bf16(v - hi), 4 bytes per element.  ppvector.models.utils.pack_hl32 / unpack_hl32 against a NumPy restatement
+    of that definition, byte for byte -- the layout the split-precision kernels and every `w_hl` weight buffer rely on."""
+    import numpy as np
+    from ppvector.models.utils import pack_hl32, unpack_hl32
+
+    def bf16_rne(a):                                   # f32 -> bf16 bits (uint16), round to nearest even
+        u = a.astype(np.float32).view(np.uint32).astype(np.uint64)
+        return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF).astype(np.uint16)
+
+    def bf16_val(b):
+        return (b.astype(np.uint32) << 16).view(np.float32)
+
+    rng = np.random.RandomState(3)
+    x = (rng.randn(7, 96) * np.exp(rng.randn(7, 96) * 3)).astype(np.float32)
+    hi = bf16_rne(x)
+    lo = bf16_rne(x - bf16_val(hi))
+    want = np.concatenate([hi.reshape(7, 3, 32), lo.reshape(7, 3, 32)], axis=-1).reshape(7, 3 * 64)      # uint16 view of the rows
+    got = pack_hl32(torch.from_numpy(x))
+    assert got.shape == (7, 96) and got.dtype == torch.float32 and got.numel() * 4 == want.size * 2
+    assert np.array_equal(got.numpy().view(np.uint16).reshape(7, 192), want)
+    back = unpack_hl32(got).numpy()
+    assert np.array_equal(back, bf16_val(hi) + bf16_val(lo))
+    rel = np.abs(back - x) / np.abs(x)
+    assert rel.max() < 2.0 ** -15, rel.max()             # two 8-bit pieces: at most 2^-16 (1 + 2^-8) of the value
+    with pytest.raises(ValueError):
+        pack_hl32(torch.zeros(2, 40))
+
+
 def test_no_cpu_fallback():
     from ppvector import _native as N
     from ppvector.data_utils.featurizer import AudioFeaturizer
