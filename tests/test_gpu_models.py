@@ -206,7 +206,9 @@ def test_long_utterance_falls_back_to_per_conv_path(ecapa):
     """T = 600 frames (6 s): the fused Res2 chain does not fit LDS (T > 512) and the engine must take
     the per-conv launches; T = 28 (0.3 s, the reference's min_duration) exercises short tiles."""
     p = om.ecapa_params(80, seed=1000)
-    for T, B in ((600, 2), (28, 3)):
+    # (T = 2000 = the reference's max_duration of 20 s, 3 utterances = 6 000 frames: the split-precision engine stays on its hl32 fast path,
+    # the Res2 chains in 14 time segments)
+    for T, B in ((600, 2), (28, 3), (2000, 3)):
         g = torch.Generator().manual_seed(T)
         x = torch.randn(B, T, 80, generator=g) * 3.0
         with torch.no_grad():

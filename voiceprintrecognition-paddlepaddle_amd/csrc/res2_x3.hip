@@ -221,7 +221,7 @@ __global__ __launch_bounds__(RX_THREADS, 1) void res2_x3_kernel(Res2X3Args a) {
 // fewest time segments whose frames (own + halos) fit the LDS; nsplit = 0 when none does
 void rx_plan(int T, int H, int& nsplit, int& Tseg, int& TP) {
     nsplit = 0;
-    for (int ns = 1; ns <= 8 && !nsplit; ++ns) {
+    for (int ns = 1; ns <= 64 && !nsplit; ++ns) {                      // (20 s of audio = 2 000 frames: 14 segments at dilation 4)
         const int ts = ((T + ns - 1) / ns + 15) / 16 * 16;              // own frames per segment, whole tiles
         if (ns > 1 && (ns - 1) * ts >= T) break;                        // an empty last segment: not a useful cut
         int need = 0;
